@@ -1,0 +1,165 @@
+/*
+ * pcm_pointops.h -- C ABI of libpcm_pointops.so, the MI355X (gfx950) pointops library.
+ *
+ * This is the drop-in boundary for the reference's native layer
+ *   /root/reference/libs/pointops/src/<op>/<op>_cuda_kernel.h   (extern "C" *_cuda_launcher)
+ *   /root/reference/libs/pointops/src/pointops_api.cpp:15-32     (the 16 pybind entry points)
+ * Each pcm_*_hip below takes EXACTLY the reference launcher's argument list (cited per function)
+ * plus a trailing stream, and returns an int status instead of void:
+ *     0                success (kernel(s) enqueued on `stream`; asynchronous like the reference)
+ *     PCM_ERR_*        argument rejected before any launch (cases that are UB in the reference)
+ *     >= 1000          1000 + hipError_t from the launch
+ * Plain pointers and sizes only: no torch types, no C++ types.  All pointers are DEVICE pointers
+ * (HBM), row-major, fp32 data / int32 indices, packed "(n,3) + cumulative offset" layout
+ * (cloud i = [offset[i-1], offset[i]), offset[-1] := 0).
+ * `stream` is a hipStream_t passed as void* (NULL = the legacy default stream the reference uses).
+ * The library keeps no global state: every call is independent and thread-safe.
+ *
+ * Arithmetic contract: distances are un-contracted IEEE fp32, (a-b)*(a-b) summed x,y,z left to
+ * right (the library is built with -ffp-contract=off); FPS indices and kNN/ball-query neighbour
+ * lists are bit-exact against oracle/pcm_oracle.c, including tie cases.
+ */
+#ifndef PCM_POINTOPS_H
+#define PCM_POINTOPS_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCM_OK 0
+#define PCM_ERR_BAD_ARG 1      /* negative sizes, nsample out of range, n_max < 1 ...           */
+#define PCM_ERR_UNSUPPORTED 2  /* shape outside what the kernels cover (see each function)      */
+#define PCM_ERR_HIP_BASE 1000  /* + hipError_t                                                  */
+
+#define PCM_KNN_MAX_NSAMPLE 128   /* knn_query_cuda_kernel.cu:82-83  float best_dist[128]       */
+#define PCM_BALL_MAX_CAND 2048    /* ball_query_cuda_kernel.cu:86-87 float candi_dist[2048]     */
+
+/* Library / build identification (e.g. "pcm_pointops 0.1 gfx950 fp-contract=off"). */
+const char *pcm_version(void);
+
+/* cuda_utils.h:11-14 opt_n_threads(): the reference block size that defines FPS tie order. */
+int pcm_opt_n_threads(int work_size);
+
+/* ---- K1 farthest point sampling -------------------------------------------------------------
+ * replaces farthest_point_sampling_cuda_launcher   sampling/sampling_cuda_kernel.h:9-17
+ *          (kernel: sampling/sampling_cuda_kernel.cu:15-171; wrapper: functions/sampling.py:6-26)
+ * b clouds; n = n_max = max_i N_i (the reference passes this as `n`); xyz (sum N_i, 3);
+ * offset (b), new_offset (b); tmp (sum N_i) pre-filled with 1e10f by the caller (used only by the
+ * large-cloud path, N_i > 16384); idx (new_offset[b-1]) receives GLOBAL point indices. */
+int pcm_farthest_point_sampling_hip(int b, int n, const float *xyz, const int *offset,
+                                    const int *new_offset, float *tmp, int *idx, void *stream);
+
+/* ---- K2 kNN query ---------------------------------------------------------------------------
+ * replaces knn_query_cuda_launcher   knn_query/knn_query_cuda_kernel.h
+ *          (kernel: knn_query/knn_query_cuda_kernel.cu:60-112; wrapper: functions/query.py:6-23)
+ * idx (m, nsample) ascending by dist2, -1 / 1e10f padding when the cloud has < nsample points;
+ * dist2 (m, nsample) SQUARED distances (the Python wrapper takes the sqrt).  1 <= nsample <= 128. */
+int pcm_knn_query_hip(int m, int nsample, const float *xyz, const float *new_xyz,
+                      const int *offset, const int *new_offset, int *idx, float *dist2,
+                      void *stream);
+
+/* ---- K3 ball query --------------------------------------------------------------------------
+ * replaces ball_query_cuda_launcher   ball_query/ball_query_cuda_kernel.h
+ *          (kernel: ball_query/ball_query_cuda_kernel.cu:58-190; wrapper: functions/query.py:72-107)
+ * Reproduces the reference's candidate order (heap_sort without heapify), the -1 / 1e10f padding
+ * and the dist2 := index quirk of the subsample branch (:120).  A query with more than 2048
+ * in-range candidates (stack overflow / UB in the reference) yields an all -1 / 1e10f row. */
+int pcm_ball_query_hip(int m, int nsample, float min_radius, float max_radius, const float *xyz,
+                       const float *new_xyz, const int *offset, const int *new_offset, int *idx,
+                       float *dist2, void *stream);
+
+/* ---- K4 random ball query -------------------------------------------------------------------
+ * replaces random_ball_query_cuda_launcher   random_ball_query/random_ball_query_cuda_kernel.h
+ *          (kernel: ..._kernel.cu:58-123; wrapper: functions/query.py:26-69)
+ * order (sum N_i): per-cloud permutation of global indices (the wrapper's torch.randperm). */
+int pcm_random_ball_query_hip(int m, int nsample, float min_radius, float max_radius,
+                              const int *order, const float *xyz, const float *new_xyz,
+                              const int *offset, const int *new_offset, int *idx, float *dist2,
+                              void *stream);
+
+/* ---- K5 grouping ----------------------------------------------------------------------------
+ * replaces grouping_{forward,backward}_cuda_launcher   grouping/grouping_cuda_kernel.h
+ *          (kernels: grouping/grouping_cuda_kernel.cu:5-40; wrapper: functions/grouping.py:6-32)
+ * forward: output(m,nsample,c) = input[idx];  backward: grad_input(n,c) += scatter(grad_output)
+ * (grad_input pre-zeroed by the caller).  No -1 handling, like the reference. */
+int pcm_grouping_forward_hip(int m, int nsample, int c, const float *input, const int *idx,
+                             float *output, void *stream);
+int pcm_grouping_backward_hip(int m, int nsample, int c, const float *grad_output, const int *idx,
+                              float *grad_input, void *stream);
+
+/* ---- K6 interpolation -----------------------------------------------------------------------
+ * replaces interpolation_{forward,backward}_cuda_launcher   interpolation/interpolation_cuda_kernel.h
+ *          (kernels: interpolation_cuda_kernel.cu:5-47; wrapper: functions/interpolation.py:25-59)
+ * forward: output(n,c) += sum_k input[idx[n,k]] * weight[n,k] (k ascending; output pre-zeroed). */
+int pcm_interpolation_forward_hip(int n, int c, int k, const float *input, const int *idx,
+                                  const float *weight, float *output, void *stream);
+int pcm_interpolation_backward_hip(int n, int c, int k, const float *grad_output, const int *idx,
+                                   const float *weight, float *grad_input, void *stream);
+
+/* ---- K7 subtraction -------------------------------------------------------------------------
+ * replaces subtraction_{forward,backward}_cuda_launcher   subtraction/subtraction_cuda_kernel.h */
+int pcm_subtraction_forward_hip(int n, int nsample, int c, const float *input1,
+                                const float *input2, const int *idx, float *output, void *stream);
+int pcm_subtraction_backward_hip(int n, int nsample, int c, const int *idx,
+                                 const float *grad_output, float *grad_input1, float *grad_input2,
+                                 void *stream);
+
+/* ---- K8 aggregation -------------------------------------------------------------------------
+ * replaces aggregation_{forward,backward}_cuda_launcher   aggregation/aggregation_cuda_kernel.h */
+int pcm_aggregation_forward_hip(int n, int nsample, int c, int w_c, const float *input,
+                                const float *position, const float *weight, const int *idx,
+                                float *output, void *stream);
+int pcm_aggregation_backward_hip(int n, int nsample, int c, int w_c, const float *input,
+                                 const float *position, const float *weight, const int *idx,
+                                 const float *grad_output, float *grad_input, float *grad_position,
+                                 float *grad_weight, void *stream);
+
+/* ---- K9 attention steps ---------------------------------------------------------------------
+ * replaces attention_{relation,fusion}_step_{forward,backward}_cuda_launcher
+ *          attention/attention_cuda_kernel.h (kernels: attention_cuda_kernel.cu:9-147) */
+int pcm_attention_relation_step_forward_hip(int m, int g, int c, const float *query,
+                                            const float *key, const float *weight,
+                                            const int *index_target, const int *index_refer,
+                                            float *output, void *stream);
+int pcm_attention_relation_step_backward_hip(int m, int g, int c, const float *query,
+                                             float *grad_query, const float *key, float *grad_key,
+                                             const float *weight, float *grad_weight,
+                                             const int *index_target, const int *index_refer,
+                                             const float *grad_output, void *stream);
+int pcm_attention_fusion_step_forward_hip(int m, int g, int c, const float *weight,
+                                          const float *value, const int *index_target,
+                                          const int *index_refer, float *output, void *stream);
+int pcm_attention_fusion_step_backward_hip(int m, int g, int c, const float *weight,
+                                           float *grad_weight, const float *value,
+                                           float *grad_value, const int *index_target,
+                                           const int *index_refer, const float *grad_output,
+                                           void *stream);
+
+/* =============================================================================================
+ * Fused entry points with no native counterpart in the reference: they replace pure-PyTorch code
+ * on the hot path (same results, fewer HBM passes).
+ * ============================================================================================= */
+
+/* pcm_knn_query_hip with the number of clouds b made explicit (b = offset length): the cloud of a
+ * query is found by bisection instead of the reference's linear get_bt_idx scan.  Same outputs. */
+int pcm_knn_query_b_hip(int b, int m, int nsample, const float *xyz, const float *new_xyz,
+                        const int *offset, const int *new_offset, int *idx, float *dist2,
+                        void *stream);
+
+/* grouping(idx, feat, xyz, new_xyz, with_xyz)   functions/grouping.py:35-59
+ * with_xyz (xyz and new_xyz non-null): output (m, nsample, 3+c) =
+ *     [ (xyz[idx]-new_xyz[row]) * (idx != -1), feat[idx] or 0 ];
+ * features only (xyz == new_xyz == NULL): output (m, nsample, c) = feat[idx] or 0 for idx == -1. */
+int pcm_group_xyz_feat_forward_hip(int m, int nsample, int c, const float *xyz,
+                                   const float *new_xyz, const float *feat, const int *idx,
+                                   float *output, void *stream);
+/* backward of the above w.r.t. feat: grad_feat(n,c) += grad_output[..., xc:] scattered by idx,
+ * xc = with_xyz ? 3 : 0 (rows with idx == -1 skipped; grad_feat pre-zeroed by the caller). */
+int pcm_group_xyz_feat_backward_hip(int m, int nsample, int c, int with_xyz,
+                                    const float *grad_output, const int *idx, float *grad_feat,
+                                    void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,84 @@
+"""ctypes binding of ``lib/libpcm_pointops.so`` -- the C-ABI library declared in
+``include/pcm_pointops.h``.  There is NO fallback: if the library is missing or a symbol is absent
+the import of any product op raises, and every op refuses non-HIP tensors.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpcm_pointops.so")
+CSRC_DIR = os.path.join(_HERE, "csrc")
+
+_P = ctypes.c_void_p
+_i = ctypes.c_int
+_f = ctypes.c_float
+
+# name -> argtypes, exactly the declarations of include/pcm_pointops.h (stream last, as void*)
+SIGNATURES = {
+    "pcm_opt_n_threads": [_i],
+    "pcm_farthest_point_sampling_hip": [_i, _i, _P, _P, _P, _P, _P, _P],
+    "pcm_knn_query_hip": [_i, _i, _P, _P, _P, _P, _P, _P, _P],
+    "pcm_knn_query_b_hip": [_i, _i, _i, _P, _P, _P, _P, _P, _P, _P],
+    "pcm_ball_query_hip": [_i, _i, _f, _f, _P, _P, _P, _P, _P, _P, _P],
+    "pcm_random_ball_query_hip": [_i, _i, _f, _f, _P, _P, _P, _P, _P, _P, _P, _P],
+    "pcm_grouping_forward_hip": [_i, _i, _i, _P, _P, _P, _P],
+    "pcm_grouping_backward_hip": [_i, _i, _i, _P, _P, _P, _P],
+    "pcm_interpolation_forward_hip": [_i, _i, _i, _P, _P, _P, _P, _P],
+    "pcm_interpolation_backward_hip": [_i, _i, _i, _P, _P, _P, _P, _P],
+    "pcm_subtraction_forward_hip": [_i, _i, _i, _P, _P, _P, _P, _P],
+    "pcm_subtraction_backward_hip": [_i, _i, _i, _P, _P, _P, _P, _P],
+    "pcm_aggregation_forward_hip": [_i, _i, _i, _i, _P, _P, _P, _P, _P, _P],
+    "pcm_aggregation_backward_hip": [_i, _i, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "pcm_attention_relation_step_forward_hip": [_i, _i, _i, _P, _P, _P, _P, _P, _P, _P],
+    "pcm_attention_relation_step_backward_hip": [_i, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "pcm_attention_fusion_step_forward_hip": [_i, _i, _i, _P, _P, _P, _P, _P, _P],
+    "pcm_attention_fusion_step_backward_hip": [_i, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P],
+    "pcm_group_xyz_feat_forward_hip": [_i, _i, _i, _P, _P, _P, _P, _P, _P],
+    "pcm_group_xyz_feat_backward_hip": [_i, _i, _i, _i, _P, _P, _P, _P],
+}
+
+_LIB = None
+
+
+class PointopsLibraryError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile the HIP sources for gfx950 with hipcc (csrc/Makefile).  Cross-compiles without a GPU."""
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.check_call(["make", "-C", CSRC_DIR, "-j8"], stdout=out)
+    return LIB_PATH
+
+
+def load():
+    """Load the library and bind every declared symbol.  Raises PointopsLibraryError if anything
+    is missing -- the product never degrades to a non-HIP path."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise PointopsLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C {CSRC_DIR}` (hipcc --offload-arch=gfx950). There is no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise PointopsLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.argtypes = args
+        fn.restype = ctypes.c_int
+    lib.pcm_version.restype = ctypes.c_char_p
+    lib.pcm_version.argtypes = []
+    _LIB = lib
+    return lib
+
+
+def check(rc, name):
+    if rc != 0:
+        if rc >= 1000:
+            raise PointopsLibraryError(f"{name}: HIP error {rc - 1000}")
+        raise PointopsLibraryError(f"{name}: rejected arguments (status {rc})")

@@ -1,0 +1,184 @@
+// ball.hip -- ball query (K3) and random ball query (K4) for gfx950 (MI355X).
+//
+// Replaces ball_query_cuda_kernel (/root/reference/libs/pointops/src/ball_query/
+// ball_query_cuda_kernel.cu:58-190) and random_ball_query_cuda_kernel
+// (random_ball_query/random_ball_query_cuda_kernel.cu:58-123).  API-only ops (no call site in the
+// reference's src/) -- built for drop-in completeness and bit-exactness, not speed.
+//
+// One wave64 per query: lane l tests point chunk*64+l (coalesced xyz reads) and in-range points
+// are compacted with ballot + prefix popcount, which preserves the reference's scan order.
+//  * ball query: the reference then calls heap_sort on the candidate array WITHOUT heapifying it
+//    (:103) -- a deterministic but unsorted permutation that later feeds the strided subsample, so
+//    it must be replayed literally: candidates are staged in LDS (2048 x 8 B per query, the
+//    reference's stack-array bound) and lane 0 replays the exact swap/reheap sequence.
+//  * random ball query: first nsample hits in `order`; no LDS at all.
+#include "pcm_common.hpp"
+
+namespace {
+
+__device__ __forceinline__ bool in_ball(float d2, float min_r2, float max_r2)
+{
+    return (double)d2 <= 1e-5 || (d2 >= min_r2 && d2 < max_r2);  // :91, the 1e-5 test is in double
+}
+
+__global__ __launch_bounds__(64) void pcm_ball_query_kernel(int m, int nsample, float min_radius, float max_radius,
+                                                           const float *__restrict__ xyz,
+                                                           const float *__restrict__ new_xyz,
+                                                           const int *__restrict__ offset,
+                                                           const int *__restrict__ new_offset, int *__restrict__ idx,
+                                                           float *__restrict__ dist2)
+{
+    __shared__ float cd[PCM_BALL_MAX_CAND];
+    __shared__ int ci[PCM_BALL_MAX_CAND];
+    const int lane = threadIdx.x;
+    const float max_r2 = max_radius * max_radius;
+    const float min_r2 = min_radius * min_radius;
+    const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+
+    for (int q = blockIdx.x; q < m; q += gridDim.x) {
+        const int bt = pcm_cloud_of(q, new_offset, 0);
+        const int start = bt == 0 ? 0 : offset[bt - 1];
+        const int end = offset[bt];
+        const float qx = new_xyz[(size_t)q * 3 + 0];
+        const float qy = new_xyz[(size_t)q * 3 + 1];
+        const float qz = new_xyz[(size_t)q * 3 + 2];
+        int cnt = 0;
+        for (int base = start; base < end; base += 64) {
+            const int p = base + lane;
+            bool in = false;
+            float d2 = 0.f;
+            if (p < end) {
+                d2 = pcm_sqdist(qx, qy, qz, xyz[(size_t)p * 3 + 0], xyz[(size_t)p * 3 + 1], xyz[(size_t)p * 3 + 2]);
+                in = in_ball(d2, min_r2, max_r2);
+            }
+            const unsigned long long mask = __ballot(in);
+            const int pos = cnt + __builtin_popcountll(mask & lt_mask);
+            if (in && pos < PCM_BALL_MAX_CAND) {
+                cd[pos] = d2;
+                ci[pos] = p;
+            }
+            cnt += __builtin_popcountll(mask);
+        }
+        __syncthreads();
+        const bool overflow = cnt > PCM_BALL_MAX_CAND;  // UB in the reference; we emit an empty row
+        if (!overflow && lane == 0) {
+            // heap_sort(:33-42) on the un-heapified array, literal
+            for (int i = cnt - 1; i > 0; --i) {
+                float td = cd[0];
+                int ti = ci[0];
+                cd[0] = cd[i];
+                ci[0] = ci[i];
+                cd[i] = td;
+                ci[i] = ti;
+                int root = 0, child = 1;
+                while (child < i) {
+                    if (child + 1 < i && cd[child + 1] > cd[child]) child++;
+                    if (cd[root] > cd[child]) break;
+                    td = cd[root];
+                    ti = ci[root];
+                    cd[root] = cd[child];
+                    ci[root] = ci[child];
+                    cd[child] = td;
+                    ci[child] = ti;
+                    root = child;
+                    child = root * 2 + 1;
+                }
+            }
+        }
+        __syncthreads();
+        int *oi = idx + (size_t)q * nsample;
+        float *od = dist2 + (size_t)q * nsample;
+        if (overflow || cnt <= nsample) {
+            const int have = overflow ? 0 : cnt;
+            for (int i = lane; i < nsample; i += 64) {
+                oi[i] = i < have ? ci[i] : -1;
+                od[i] = i < have ? cd[i] : 1e10f;
+            }
+        } else {
+            const float sep = (float)cnt / nsample;  // :115
+            for (int i = lane; i < nsample; i += 64) {
+                const int index = (int)(sep * i);  // :118
+                oi[i] = ci[index];
+                od[i] = (float)ci[index];  // :120 (sic): the reference stores the index as dist2
+            }
+        }
+        __syncthreads();  // cd/ci are reused by the next query
+    }
+}
+
+__global__ __launch_bounds__(256) void pcm_random_ball_query_kernel(int m, int nsample, float min_radius, float max_radius,
+                                                                    const int *__restrict__ order,
+                                                                    const float *__restrict__ xyz,
+                                                                    const float *__restrict__ new_xyz,
+                                                                    const int *__restrict__ offset,
+                                                                    const int *__restrict__ new_offset,
+                                                                    int *__restrict__ idx, float *__restrict__ dist2)
+{
+    const int lane = threadIdx.x & 63;
+    const int waves_per_block = blockDim.x >> 6;
+    const float max_r2 = max_radius * max_radius;
+    const float min_r2 = min_radius * min_radius;
+    const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+
+    for (int q = blockIdx.x * waves_per_block + (threadIdx.x >> 6); q < m; q += gridDim.x * waves_per_block) {
+        const int bt = pcm_cloud_of(q, new_offset, 0);
+        const int start = bt == 0 ? 0 : offset[bt - 1];
+        const int end = offset[bt];
+        const float qx = new_xyz[(size_t)q * 3 + 0];
+        const float qy = new_xyz[(size_t)q * 3 + 1];
+        const float qz = new_xyz[(size_t)q * 3 + 2];
+        int *oi = idx + (size_t)q * nsample;
+        float *od = dist2 + (size_t)q * nsample;
+        int cnt = 0;
+        for (int base = start; base < end && cnt < nsample; base += 64) {
+            const int p = base + lane;
+            bool in = false;
+            float d2 = 0.f;
+            int o = 0;
+            if (p < end) {
+                o = order[p];
+                d2 = pcm_sqdist(qx, qy, qz, xyz[(size_t)o * 3 + 0], xyz[(size_t)o * 3 + 1], xyz[(size_t)o * 3 + 2]);
+                in = in_ball(d2, min_r2, max_r2);
+            }
+            const unsigned long long mask = __ballot(in);
+            const int pos = cnt + __builtin_popcountll(mask & lt_mask);
+            if (in && pos < nsample) {
+                od[pos] = d2;
+                oi[pos] = o;
+            }
+            cnt += __builtin_popcountll(mask);
+        }
+        if (cnt > nsample) cnt = nsample;
+        for (int i = cnt + lane; i < nsample; i += 64) {
+            oi[i] = -1;
+            od[i] = 1e10f;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int pcm_ball_query_hip(int m, int nsample, float min_radius, float max_radius, const float *xyz,
+                                  const float *new_xyz, const int *offset, const int *new_offset, int *idx,
+                                  float *dist2, void *stream)
+{
+    if (m < 0 || nsample < 1) return PCM_ERR_BAD_ARG;
+    if (m == 0) return PCM_OK;
+    int blocks = m < 256 * 16 ? m : 256 * 16;
+    hipLaunchKernelGGL(pcm_ball_query_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, m, nsample, min_radius,
+                       max_radius, xyz, new_xyz, offset, new_offset, idx, dist2);
+    return PCM_LAUNCH_STATUS();
+}
+
+extern "C" int pcm_random_ball_query_hip(int m, int nsample, float min_radius, float max_radius, const int *order,
+                                         const float *xyz, const float *new_xyz, const int *offset,
+                                         const int *new_offset, int *idx, float *dist2, void *stream)
+{
+    if (m < 0 || nsample < 1) return PCM_ERR_BAD_ARG;
+    if (m == 0) return PCM_OK;
+    int blocks = (m + 3) / 4;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(pcm_random_ball_query_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, m, nsample,
+                       min_radius, max_radius, order, xyz, new_xyz, offset, new_offset, idx, dist2);
+    return PCM_LAUNCH_STATUS();
+}

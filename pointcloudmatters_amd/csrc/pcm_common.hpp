@@ -1,0 +1,76 @@
+// pcm_common.hpp -- shared device helpers for the gfx950 pointops kernels.
+// CDNA4 only: wave = 64 lanes, DPP row ops, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pcm_pointops.h"
+
+#define PCM_WAVE 64
+
+static inline int pcm_status(hipError_t e) { return e == hipSuccess ? PCM_OK : PCM_ERR_HIP_BASE + (int)e; }
+#define PCM_LAUNCH_STATUS() pcm_status(hipGetLastError())
+
+// ---- cross-lane primitives ------------------------------------------------------------------
+// DPP controls (cdna4 ISA): quad_perm[a,b,c,d] = a|b<<2|c<<4|d<<6, row_half_mirror 0x141,
+// row_mirror 0x140, wave_shr:1 0x138, wave_shl:1 0x130.
+template <int CTRL>
+__device__ __forceinline__ uint32_t pcm_dpp(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+
+// After the four steps every lane of a 16-lane row holds the row's reduction; the four row
+// results are combined on the scalar unit.  Result is wave-uniform.
+__device__ __forceinline__ uint32_t pcm_wave_max_u32(uint32_t v)
+{
+    v = max(v, pcm_dpp<0xB1>(v));   // lane ^ 1
+    v = max(v, pcm_dpp<0x4E>(v));   // lane ^ 2
+    v = max(v, pcm_dpp<0x141>(v));  // mirror within 8
+    v = max(v, pcm_dpp<0x140>(v));  // mirror within 16
+    const uint32_t a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const uint32_t c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return max(max(a, b), max(c, d));
+}
+
+__device__ __forceinline__ uint32_t pcm_wave_min_u32(uint32_t v)
+{
+    v = min(v, pcm_dpp<0xB1>(v));
+    v = min(v, pcm_dpp<0x4E>(v));
+    v = min(v, pcm_dpp<0x141>(v));
+    v = min(v, pcm_dpp<0x140>(v));
+    const uint32_t a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const uint32_t c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return min(min(a, b), min(c, d));
+}
+
+__device__ __forceinline__ int pcm_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// Squared distance in the reference's order: (a-b)*(a-b) for x, y, z summed left to right.
+// The translation unit is compiled with -ffp-contract=off, so no FMA is formed here.
+__device__ __forceinline__ float pcm_sqdist(float ax, float ay, float az, float bx, float by, float bz)
+{
+    const float dx = ax - bx, dy = ay - by, dz = az - bz;
+    float d = dx * dx;
+    d = d + dy * dy;
+    d = d + dz * dz;
+    return d;
+}
+
+// get_bt_idx of the reference (knn_query_cuda_kernel.cu:45-56): first i with q < off[i].
+// With b > 0 (number of clouds known) the same answer by bisection: log2(b) dependent loads
+// instead of up to b.  b <= 0 keeps the reference's linear scan (its ABI does not carry b).
+__device__ __forceinline__ int pcm_cloud_of(int q, const int *__restrict__ off, int b)
+{
+    if (b <= 0) {
+        int i = 0;
+        while (!(q < off[i])) i++;
+        return i;
+    }
+    int lo = 0, hi = b - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (q < off[mid]) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}

@@ -1,0 +1,68 @@
+"""Shared plumbing for the pointops wrappers: HIP-tensor checks, stream, host-side offsets."""
+import torch
+
+from .. import _lib
+
+
+def lib():
+    return _lib.load()
+
+
+def require_hip(*tensors):
+    """Every product op runs on the GPU through libpcm_pointops.so; anything else is an error
+    (the reference has no CPU path either: its wrappers allocate torch.cuda.*Tensor)."""
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.PointopsLibraryError(
+                "pointops: expected a HIP (torch 'cuda') tensor, got device=%s. There is no CPU fallback." % t.device
+            )
+
+
+def f32c(t, name):
+    if t.dtype != torch.float32:
+        raise TypeError(f"pointops: {name} must be float32, got {t.dtype}")
+    assert t.is_contiguous(), f"pointops: {name} must be contiguous"
+    return t
+
+
+def i32c(t):
+    """offset.int() of the reference wrappers (sampling.py:20, query.py:21): no-op when already int32."""
+    t = t.to(torch.int32)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def host_offsets(offset):
+    """Cumulative offsets as a Python list.
+
+    The reference reads offsets element by element from the device (b+1 host syncs in
+    functions/sampling.py:14-17).  Here a tensor produced by our collate carries its host copy in
+    the attribute ``_pcm_host``; otherwise ONE device->host copy is made and cached on the tensor.
+    """
+    h = getattr(offset, "_pcm_host", None)
+    if h is None:
+        h = [int(v) for v in offset.tolist()]
+        try:
+            offset._pcm_host = h
+        except Exception:  # pragma: no cover - tensors always accept attributes
+            pass
+    return h
+
+
+def with_host(offset, host):
+    """Attach a known host copy to a device offset tensor (no sync later)."""
+    offset._pcm_host = [int(v) for v in host]
+    return offset
+
+
+def counts_from_offsets(host):
+    return [host[0]] + [host[i] - host[i - 1] for i in range(1, len(host))]

@@ -1,0 +1,219 @@
+"""GPU parity: HIP pointops (through the C ABI) vs the CPU oracle on the same seeded inputs.
+
+Bit-exact for FPS indices, kNN / ball-query neighbour lists and their dist2; fp32 gather outputs
+exact; atomic-scatter backward within 1e-5 relative (summation order is free in the reference too).
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import make_clouds, new_offsets
+
+pytestmark = pytest.mark.gpu
+
+FPS_CASES = [
+    # (sizes, ms, mode)
+    ([512], [128], "uniform"),
+    ([1024] * 8, [512] * 8, "uniform"),
+    ([2048] * 4, [1024] * 4, "uniform"),
+    ([4096] * 8, [2048] * 8, "uniform"),
+    ([3100, 4096, 5000, 3600], [2048] * 4, "uniform"),       # ragged, PPT 32 path (T=1024)
+    ([1000, 37, 260, 1023], [64, 50, 64, 600], "uniform"),    # ragged incl. N < M and N < BS
+    ([5, 3, 1], [8, 2, 4], "uniform"),                        # tiny, M > N
+    ([100], [100], "uniform"),                                # BS = 64 < T
+    ([300, 511], [40, 300], "uniform"),                       # BS = 256
+    ([700, 600], [350, 300], "uniform"),                      # BS = 512 (q = 2)
+    ([1024] * 8, [512] * 8, "lattice"),                       # forced distance ties
+    ([4096] * 2, [2048] * 2, "lattice"),
+    ([1500, 900], [1024, 1024], "dup"),                       # duplicates + M > N for one cloud
+    ([9000, 8000], [512, 512], "uniform"),                    # T = 1024, PPT = 16, xyz from global
+    ([16384], [256], "lattice"),
+    ([20000, 17000], [200, 100], "uniform"),                  # any-size kernel (tmp in HBM)
+    ([1024] * 128, [512] * 128, "uniform"),                   # DP-style batch of 128 clouds
+]
+
+
+@pytest.mark.parametrize("sizes,ms,mode", FPS_CASES)
+def test_fps_bit_exact(hip_device, sizes, ms, mode):
+    import pointcloudmatters_amd.pointops as po
+    from oracle import pointops_cpu as ref
+
+    xyz, off = make_clouds(sizes, seed=len(sizes) * 7 + sizes[0], mode=mode)
+    noff = new_offsets(ms)
+    want = ref.farthest_point_sampling(xyz, off, noff)
+    got = po.farthest_point_sampling(xyz.to(hip_device), off.to(hip_device), noff.to(hip_device))
+    assert got.dtype == torch.int32 and got.shape == want.shape
+    assert torch.equal(got.cpu(), want), f"first mismatch at {(got.cpu() != want).nonzero()[:4].flatten().tolist()}"
+
+
+KNN_CASES = [
+    ([1024] * 8, [512] * 8, 16, "uniform"),
+    ([4096] * 4, [2048] * 4, 16, "uniform"),
+    ([1000, 37, 260, 1023], [64, 50, 64, 600], 16, "uniform"),
+    ([5, 3, 20], [5, 3, 20], 16, "uniform"),                  # clouds smaller than nsample -> -1 padding
+    ([1024] * 4, [512] * 4, 16, "lattice"),                   # exact ties -> exact kernel path
+    ([2048] * 2, [1024] * 2, 16, "dup"),
+    ([2000], [700], 3, "uniform"),                            # interpolation's k
+    ([2000], [700], 63, "uniform"),                           # largest fast-path nsample
+    ([2000], [300], 64, "uniform"),                           # exact kernel only
+    ([500], [100], 128, "lattice"),
+    ([300], [300], 1, "dup"),
+]
+
+
+@pytest.mark.parametrize("sizes,ms,nsample,mode", KNN_CASES)
+def test_knn_bit_exact(hip_device, sizes, ms, nsample, mode):
+    import pointcloudmatters_amd.pointops as po
+    from pointcloudmatters_amd.pointops.query import knn_query_raw
+    from oracle import pointops_cpu as ref
+
+    xyz, off = make_clouds(sizes, seed=11 + nsample, mode=mode)
+    noff = new_offsets(ms)
+    sel = ref.farthest_point_sampling(xyz, off, noff).long()
+    new_xyz = xyz[sel].contiguous()
+    wi, wd = ref.knn_query_raw(nsample, xyz, off, new_xyz, noff)
+    gi, gd = knn_query_raw(nsample, xyz.to(hip_device), off.to(hip_device), new_xyz.to(hip_device), noff.to(hip_device))
+    assert torch.equal(gi.cpu(), wi)
+    assert torch.equal(gd.cpu(), wd)
+    # public wrapper: sqrt(dist2), pads -> 1e5
+    pi, pd = po.knn_query(nsample, xyz.to(hip_device), off.to(hip_device), new_xyz.to(hip_device), noff.to(hip_device))
+    assert torch.equal(pi.cpu(), wi) and torch.equal(pd.cpu(), torch.sqrt(wd))
+
+
+def test_knn_self_query_defaults(hip_device):
+    import pointcloudmatters_amd.pointops as po
+    from oracle import pointops_cpu as ref
+
+    xyz, off = make_clouds([700, 300], seed=5)
+    wi, wd = ref.knn_query(8, xyz, off)
+    gi, gd = po.knn_query(8, xyz.to(hip_device), off.to(hip_device))
+    assert torch.equal(gi.cpu(), wi) and torch.equal(gd.cpu(), wd)
+
+
+BALL_CASES = [
+    ([1024] * 4, [256] * 4, 16, 0.1, 0.0, "uniform"),
+    ([1024] * 2, [256] * 2, 32, 0.2, 0.02, "uniform"),       # cnt > nsample -> strided subsample + dist2:=idx quirk
+    ([500, 40], [100, 40], 8, 0.05, 0.0, "lattice"),
+    ([3000], [64], 16, 1.0, 0.0, "uniform"),                  # > 2048 candidates -> defined-empty row
+    ([10, 3], [10, 3], 16, 0.5, 0.0, "uniform"),
+]
+
+
+@pytest.mark.parametrize("sizes,ms,nsample,rmax,rmin,mode", BALL_CASES)
+def test_ball_query_bit_exact(hip_device, sizes, ms, nsample, rmax, rmin, mode):
+    from pointcloudmatters_amd.pointops.query import ball_query_raw
+    from oracle import lib as olib
+    from oracle import pointops_cpu as ref
+
+    xyz, off = make_clouds(sizes, seed=3, mode=mode)
+    noff = new_offsets(ms)
+    sel = ref.farthest_point_sampling(xyz, off, noff).long()
+    new_xyz = xyz[sel].contiguous()
+    L = olib.load()
+    wi = torch.zeros(new_xyz.shape[0], nsample, dtype=torch.int32)
+    wd = torch.zeros(new_xyz.shape[0], nsample, dtype=torch.float32)
+    rc = L.pcm_ball_query_cpu(new_xyz.shape[0], nsample, rmin, rmax, xyz.data_ptr(), new_xyz.data_ptr(),
+                              off.data_ptr(), noff.data_ptr(), wi.data_ptr(), wd.data_ptr())
+    assert rc in (0, 2)  # 2 = some query overflowed 2048 candidates (UB in the reference)
+    gi, gd = ball_query_raw(nsample, rmax, rmin, xyz.to(hip_device), off.to(hip_device), new_xyz.to(hip_device), noff.to(hip_device))
+    assert torch.equal(gi.cpu(), wi)
+    assert torch.equal(gd.cpu(), wd)
+
+
+@pytest.mark.parametrize("sizes,ms,nsample,rmax,rmin", [([1024] * 4, [256] * 4, 16, 0.1, 0.0), ([300, 20], [50, 20], 8, 0.3, 0.05)])
+def test_random_ball_query_bit_exact(hip_device, sizes, ms, nsample, rmax, rmin):
+    from pointcloudmatters_amd.pointops.query import random_ball_query_raw
+    from oracle import pointops_cpu as ref
+
+    xyz, off = make_clouds(sizes, seed=9)
+    noff = new_offsets(ms)
+    sel = ref.farthest_point_sampling(xyz, off, noff).long()
+    new_xyz = xyz[sel].contiguous()
+    g = torch.Generator().manual_seed(123)
+    order = ref.make_random_order(off, generator=g)
+    wi, wd = ref.random_ball_query_raw(nsample, rmax, rmin, xyz, off, new_xyz, noff, order)
+    gi, gd = random_ball_query_raw(nsample, rmax, rmin, xyz.to(hip_device), off.to(hip_device), new_xyz.to(hip_device),
+                                   noff.to(hip_device), order.to(hip_device))
+    assert torch.equal(gi.cpu(), wi) and torch.equal(gd.cpu(), wd)
+
+
+def _sa_inputs(sizes, ms, c, nsample, seed, mode="uniform"):
+    from oracle import pointops_cpu as ref
+
+    xyz, off = make_clouds(sizes, seed=seed, mode=mode)
+    noff = new_offsets(ms)
+    sel = ref.farthest_point_sampling(xyz, off, noff).long()
+    new_xyz = xyz[sel].contiguous()
+    idx, _ = ref.knn_query(nsample, xyz, off, new_xyz, noff)
+    g = torch.Generator().manual_seed(seed)
+    feat = torch.randn(xyz.shape[0], c, generator=g)
+    return xyz, off, new_xyz, noff, idx, feat
+
+
+@pytest.mark.parametrize("sizes,ms,c,with_xyz", [
+    ([1024] * 4, [512] * 4, 512, True),
+    ([1024] * 2, [512] * 2, 96, True),
+    ([5, 3, 40], [5, 3, 20], 7, True),      # -1 placeholders (clouds smaller than nsample)
+    ([5, 3, 40], [5, 3, 20], 8, False),
+    ([600], [100], 64, False),
+])
+def test_grouping_forward_backward(hip_device, sizes, ms, c, with_xyz):
+    import pointcloudmatters_amd.pointops as po
+    from oracle import pointops_cpu as ref
+
+    xyz, off, new_xyz, noff, idx, feat = _sa_inputs(sizes, ms, c, 16, seed=21)
+    f_ref = feat.clone().requires_grad_(True)
+    want = ref.grouping(idx, f_ref, xyz, new_xyz, with_xyz=with_xyz)
+    gout = torch.randn(want.shape, generator=torch.Generator().manual_seed(1))
+    want.backward(gout)
+
+    f_hip = feat.to(hip_device).requires_grad_(True)
+    got = po.grouping(idx.to(hip_device), f_hip, xyz.to(hip_device), new_xyz.to(hip_device), with_xyz=with_xyz)
+    assert torch.equal(got.detach().cpu(), want.detach())  # gather + one fp32 subtraction: exact
+    got.backward(gout.to(hip_device))
+    torch.testing.assert_close(f_hip.grad.cpu(), f_ref.grad, rtol=1e-5, atol=1e-5)
+
+
+def test_grouping_xyz_gradients(hip_device):
+    import pointcloudmatters_amd.pointops as po
+    from oracle import pointops_cpu as ref
+
+    xyz, off, new_xyz, noff, idx, feat = _sa_inputs([5, 60], [5, 30], 4, 16, seed=4)
+    a = [t.clone().requires_grad_(True) for t in (feat, xyz, new_xyz)]
+    want = ref.grouping(idx, a[0], a[1], a[2], with_xyz=True)
+    gout = torch.randn(want.shape, generator=torch.Generator().manual_seed(2))
+    want.backward(gout)
+    b = [t.to(hip_device).requires_grad_(True) for t in (feat, xyz, new_xyz)]
+    got = po.grouping(idx.to(hip_device), b[0], b[1], b[2], with_xyz=True)
+    got.backward(gout.to(hip_device))
+    for x, y in zip(a, b):
+        torch.testing.assert_close(y.grad.cpu(), x.grad, rtol=1e-5, atol=1e-5)
+
+
+def test_grouping2(hip_device):
+    import pointcloudmatters_amd.pointops as po
+    from oracle import pointops_cpu as ref
+
+    for c in (512, 96, 5):
+        xyz, off, new_xyz, noff, idx, feat = _sa_inputs([1024, 900], [256, 256], c, 16, seed=c)
+        f_ref = feat.clone().requires_grad_(True)
+        want = ref.grouping2(f_ref, idx)
+        gout = torch.randn(want.shape, generator=torch.Generator().manual_seed(1))
+        want.backward(gout)
+        f_hip = feat.to(hip_device).requires_grad_(True)
+        got = po.grouping2(f_hip, idx.to(hip_device))
+        assert torch.equal(got.detach().cpu(), want.detach())
+        got.backward(gout.to(hip_device))
+        torch.testing.assert_close(f_hip.grad.cpu(), f_ref.grad, rtol=1e-5, atol=1e-5)
+
+
+def test_knn_query_and_group(hip_device):
+    import pointcloudmatters_amd.pointops as po
+    from oracle import pointops_cpu as ref
+
+    xyz, off, new_xyz, noff, idx, feat = _sa_inputs([1024] * 2, [512] * 2, 32, 16, seed=8)
+    want, widx = ref.knn_query_and_group(feat, xyz, offset=off, new_xyz=new_xyz, new_offset=noff, nsample=16, with_xyz=True)
+    d = hip_device
+    got, gidx = po.knn_query_and_group(feat.to(d), xyz.to(d), offset=off.to(d), new_xyz=new_xyz.to(d), new_offset=noff.to(d),
+                                       nsample=16, with_xyz=True)
+    assert torch.equal(gidx.cpu(), widx) and torch.equal(got.cpu(), want)
