@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""bench.py -- BC train samples/sec (obs -> action), PointNet + set-abstraction tokenizer + ACT.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one full training step on one synthetic batch per GPU: forward (PointNet -> FPS -> kNN ->
+group -> Linear/BN/ReLU/max -> ACT CVAE + transformer) -> loss -> backward -> clip 0.5 -> AdamW ->
+OneCycleLR, with the inputs already resident in HBM.  Workload at N=1: BASELINE.json configs[1]
+("C2": B=8 clouds of 1024 points, 512 tokens, bf16 autocast for GEMM/attention, pointops fp32).
+Data parallel: one process per GPU, batch sharded (weak scaling: B per GPU fixed), gradient
+all-reduce over RCCL overlapped with backward.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--workload", default="C2", help="C2 (headline), C4, REF, C1")
+    ap.add_argument("--sa-impl", default=os.environ.get("PCM_SA_IMPL", "auto"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=4)
+    return ap.parse_args()
+
+
+def timed_events(fn, iters, warmup=3):
+    """Average duration (ms) of fn() measured with HIP events on the current stream."""
+    for _ in range(warmup):
+        fn()
+    start = torch.cuda.Event(enable_timing=True)
+    end = torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    start.record()
+    for _ in range(iters):
+        fn()
+    end.record()
+    end.synchronize()
+    return start.elapsed_time(end) / iters
+
+
+def kernel_rooflines(wl, device, c_feat=512, hidden=512):
+    """Time every hand-written hot-path kernel alone on this workload's shapes (HIP events on the
+    launch stream) and price it against its algorithmic HBM bytes (SURVEY.md 8d / DESIGN.md)."""
+    import pointcloudmatters_amd.pointops as po
+    from pointcloudmatters_amd.bc import make_act_batch
+    from pointcloudmatters_amd.pointops.query import knn_query_raw
+
+    b, n, m_per, k = wl["batch"], wl["n_points"], wl["pcd_npoints"], 16
+    batch = make_act_batch(b, n, seed=4242, ragged=wl["ragged"], device=device)
+    coord, off = batch["pcds"]["coord"], batch["pcds"]["offset"]
+    n_tot = coord.shape[0]
+    noff = torch.tensor([m_per * (i + 1) for i in range(b)], dtype=torch.int32, device=device)
+    noff._pcm_host = [m_per * (i + 1) for i in range(b)]
+    m = b * m_per
+    idx = po.farthest_point_sampling(coord, off, noff)
+    n_p = coord[idx.long()].contiguous()
+    knn_idx, _ = knn_query_raw(k, coord, off, n_p, noff)
+    feat = torch.randn(n_tot, c_feat, device=device).requires_grad_(True)
+    res = {}
+
+    def add(name, ms, nbytes, note):
+        res[name] = {"ms": round(ms, 5), "algorithmic_bytes": int(nbytes), "achieved_GBs": round(nbytes / ms / 1e6, 3),
+                     "frac_of_hbm_peak": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 6), "note": note}
+
+    add("fps", timed_events(lambda: po.farthest_point_sampling(coord, off, noff), 20), 12 * n_tot + 4 * m,
+        "serial-latency bound: %d dependent picks per cloud" % m_per)
+    add("knn", timed_events(lambda: knn_query_raw(k, coord, off, n_p, noff), 20), 12 * n_tot + 12 * m + 8 * m * k,
+        "ALU/LDS bound at this N: %.1f M distance evaluations" % (m * n / 1e6))
+    rows = m * k
+    grouped = po.grouping(knn_idx, feat, coord, n_p, with_xyz=True)
+    gbytes = 4 * rows + min(rows, n_tot) * (c_feat + 3) * 4 + 12 * m + rows * (c_feat + 3) * 4
+    add("group_fwd", timed_events(lambda: po.grouping(knn_idx, feat, coord, n_p, with_xyz=True), 20), gbytes, "HBM bound gather")
+    gout = torch.randn_like(grouped)
+
+    def bwd():
+        feat.grad = None
+        grouped.backward(gout, retain_graph=True)
+
+    add("group_bwd", timed_events(bwd, 20), rows * c_feat * 4 + 4 * rows + n_tot * c_feat * 4, "HBM bound atomic scatter")
+    return res
+
+
+def cpu_baseline(wl, steps):
+    """The reference path restated on the host: same harness, device=cpu, pointops = the C oracle
+    (OpenMP), model = plain PyTorch CPU ops in the reference's op order, fp32."""
+    from oracle import pointops_cpu
+    from pointcloudmatters_amd.bc import BCTrainer, build_act_policy, clone_batch, make_act_batch
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    policy = build_act_policy(pcd_npoints=wl["pcd_npoints"], pointops=pointops_cpu, sa_impl="reference")
+    trainer = BCTrainer(policy, total_steps=1000, precision="fp32", device="cpu", optim=dict(accumulate_grad_batches=1))
+    batch = make_act_batch(wl["batch"], wl["n_points"], seed=1000, ragged=wl["ragged"], device="cpu")
+    trainer.training_step(clone_batch(batch))  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        trainer.training_step(clone_batch(batch))
+    dt = time.perf_counter() - t0
+    return {"value": round(wl["batch"] * steps / dt, 4), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "%d optimizer steps of the same workload (B=%d, N=%d, M=%d, fp32) after 1 warm-up; %.1f s"
+                      % (steps, wl["batch"], wl["n_points"], wl["pcd_npoints"], dt)}
+
+
+def main():
+    args = parse()
+    from pointcloudmatters_amd.bc import BCTrainer, WORKLOADS, build_act_policy, clone_batch, make_act_batch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py measures the MI355X path; no HIP device found"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)  # "nccl" is RCCL on ROCm
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    wl = WORKLOADS[args.workload]
+    sa_impl = "torch" if args.sa_impl == "auto" else args.sa_impl
+    torch.manual_seed(1000 + rank)
+    policy = build_act_policy(pcd_npoints=wl["pcd_npoints"], sa_impl=sa_impl).to(device)
+    trainer = BCTrainer(policy, total_steps=max(args.steps + args.warmup, 100), precision=wl["dtype"], device=device,
+                        distributed=world > 1, optim=dict(accumulate_grad_batches=1))
+    batches = [make_act_batch(wl["batch"], wl["n_points"], seed=1000 + rank + 97 * i, ragged=wl["ragged"], device=device)
+               for i in range(4)]
+
+    def step(i):
+        trainer.training_step(clone_batch(batches[i % len(batches)]))
+
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    metrics = trainer.metrics()
+
+    if rank == 0:
+        samples = wl["batch"] * world * args.steps
+        out = {
+            "metric": "BC train samples/sec (obs->action), PointNet + SA tokenizer + ACT",
+            "value": round(samples / dt, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": wl["dtype"], "data": "synthetic",
+            "config": {"workload": "%s: ManiSkill2-PickCube-shaped batch, B=%d clouds x %d pts per GPU -> %d tokens, K=16, "
+                                   "PointNet(6->512) + SA(515->512) + ACT(4 enc / 7 dec, d=512, 100 queries)"
+                                   % (args.workload, wl["batch"], wl["n_points"], wl["pcd_npoints"]),
+                       "global_batch": wl["batch"] * world, "points_per_cloud": wl["n_points"],
+                       "tokens_per_cloud": wl["pcd_npoints"], "parallelism": "dp%d" % world, "sa_impl": sa_impl,
+                       "accumulate_grad_batches": 1, "optimizer_step_every_step": True},
+            "final_loss": round(metrics.get("train/loss", float("nan")), 4),
+        }
+        if not args.no_roofline:
+            kr = kernel_rooflines(wl, device)
+            dom = max(kr, key=lambda k: kr[k]["ms"] if k.startswith("group") else -1.0)
+            out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": kr[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": kr[dom]["frac_of_hbm_peak"], "traffic": None}
+            out["kernels"] = kr
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_steps)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

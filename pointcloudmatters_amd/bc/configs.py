@@ -1,0 +1,30 @@
+"""Frozen experiment shapes.  Hydra is absent on the GPU box, so the values the hot
+path needs are restated here with the YAML they come from.
+
+ACT hyper-parameters: /root/reference/configs/model/maniskill2_act_pcd_model.yaml:11-68,
+exp_maniskill2_act_policy/maniskill2_model/scratch_pointnet_pcd.yaml:10-22,
+exp_maniskill2_act_policy/maniskill2_pcd_task/PickCube-v0.yaml (action 7, qpos 9, goal 3),
+configs/data/maniskill2_act_pcd_dataset.yaml:14 (chunk_size 100), configs/trainer/ddp.yaml:4-15.
+Synthetic cloud sizes follow SURVEY.md section 8(d) / BASELINE.md section 3 (M = N/2).
+"""
+
+ACT_MODEL = dict(
+    hidden_dim=512, nhead=8, dim_feedforward=32, num_encoder_layers=4, num_decoder_layers=7, dropout=0.1,
+    normalize_before=False, return_intermediate_dec=True, latent_dim=32, kl_weight=10.0, num_queries=100,
+    action_dim=7, qpos_dim=9, goal_cond_dim=3, in_channels=6, pcd_nsample=16,
+)
+
+ACT_OPTIM = dict(lr=5e-5, weight_decay=0.05, pct_start=0.1, div_factor=100.0, final_div_factor=1000.0,
+                 gradient_clip_val=0.5, accumulate_grad_batches=2)
+
+# name -> per-GPU batch, points per cloud, tokens per cloud (pcd_npoints), compute dtype
+WORKLOADS = {
+    # BASELINE.json configs[0]: CPU plumbing case
+    "C1": dict(policy="act", batch=2, n_points=512, pcd_npoints=128, dtype="fp32", ragged=False),
+    # configs[1]: the single-GPU case the headline metric is quoted on
+    "C2": dict(policy="act", batch=8, n_points=1024, pcd_npoints=512, dtype="bf16", ragged=False),
+    # configs[3]: per-GPU shape of the 8-GPU ACT run
+    "C4": dict(policy="act", batch=8, n_points=2048, pcd_npoints=1024, dtype="bf16", ragged=False),
+    # the shipped ACT config (scratch_pointnet_pcd.yaml:10, maniskill2_act_pcd_model.yaml:67-68)
+    "REF": dict(policy="act", batch=8, n_points=4096, pcd_npoints=2048, dtype="bf16", ragged=True),
+}

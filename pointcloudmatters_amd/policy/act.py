@@ -1,0 +1,261 @@
+"""ACT (action-chunking transformer, CVAE) with the point-cloud tokenizer -- ``ACTPCD``.
+
+Behavioural counterpart of /root/reference/src/models/components/act/act.py:40-309 (ACT) and
+:312-598 (ACTPCD): same constructor arguments, same ``forward(data_dict) -> data_dict`` contract
+(keys ``a_hat``, ``is_pad_hat``, ``mu``, ``logvar``, ``action_loss``, ``kl_loss``, ``loss``) and the
+same parameter names, so Hydra ``_target_`` configs and reference checkpoints keep working.
+
+What is different is the execution plan, not the maths:
+* activations are batch-first end to end and attention is fused (policy/transformer.py);
+* farthest point sampling and the kNN query depend only on coordinates (act.py:395,447 use ``p``
+  alone for the indices), so they are issued on a side HIP stream and overlap the PointNet MLP;
+* the set-abstraction layer (act.py:384-465: FPS -> kNN -> group -> Linear -> BN -> ReLU -> max)
+  can run either in the reference's op order (``sa_impl="reference"``) or through the fused HIP
+  kernels of policy/sa_fused.py (``sa_impl="fused"``);
+* no per-cloud host synchronisation: offsets carry a host copy (pointops._common.host_offsets).
+
+``pointops`` is injected (default: the HIP package).  Tests and the CPU baseline inject the CPU
+oracle's module; the product never imports it.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .sa_layer import coord_embedding_sine, set_abstraction
+
+
+def get_sinusoid_encoding_table(n_position, d_hid):
+    """act/utils.py:42-55: (1, n_position, d_hid) float32, float64 angle arithmetic."""
+    pos = np.arange(n_position, dtype=np.float64)[:, None]
+    j = np.arange(d_hid)[None, :]
+    table = pos / np.power(10000, 2 * (j // 2) / d_hid)
+    table[:, 0::2] = np.sin(table[:, 0::2])
+    table[:, 1::2] = np.cos(table[:, 1::2])
+    return torch.FloatTensor(table).unsqueeze(0)
+
+
+def reparametrize(mu, logvar, eps=None):
+    """act/utils.py:36-39.  ``eps`` can be injected for reproducible parity tests."""
+    std = logvar.div(2).exp()
+    if eps is None:
+        eps = torch.randn_like(std)
+    return mu + std * eps
+
+
+class ACTPCD(nn.Module):
+    def __init__(
+        self,
+        backbone,
+        transformer,
+        encoder,
+        hidden_dim,
+        num_queries,
+        num_cameras=0,
+        action_dim=8,
+        qpos_dim=9,
+        env_state_dim=0,
+        latent_dim=32,
+        action_loss=None,
+        klloss=None,
+        kl_weight=20.0,
+        goal_cond_dim=0,
+        obs_feature_pos_embedding=None,
+        freeze_backbone=False,
+        pcd_nsample=16,
+        pcd_npoints=1024,
+        sampling="fps",
+        heatmap_th=0.1,
+        ignore_vae=False,
+        use_mask=False,
+        bg_ratio=0.0,
+        pre_sample=False,
+        in_channels=6,
+        pointops=None,
+        sa_impl="reference",
+        overlap_sampling=True,
+    ):
+        super().__init__()
+        if backbone is None:
+            raise ValueError("ACTPCD needs a point-cloud backbone")
+        if use_mask:
+            # act.py:396-442 indexes the unmasked cloud with indices local to the masked subset and
+            # concatenates fg/bg batch-major, breaking the (b n) token layout -- unsupported here.
+            raise NotImplementedError("use_mask=True (foreground/background split FPS) is not supported")
+        if pre_sample:
+            raise NotImplementedError("pre_sample=True is not used by any shipped config")
+        if "fps" not in sampling:
+            raise NotImplementedError(sampling)
+        if pointops is None:
+            from .. import pointops as _hip_pointops
+
+            pointops = _hip_pointops
+        self._pointops = [pointops]  # in a list: not a submodule / not in the state dict
+        self.sa_impl = sa_impl
+        self.overlap_sampling = overlap_sampling
+
+        self.backbone = backbone
+        self.transformer = transformer
+        self.encoder = encoder
+        self.num_queries = num_queries
+        self.num_cameras = 0
+        self.action_dim = action_dim
+        self.qpos_dim = qpos_dim
+        self.env_state_dim = env_state_dim
+        self.hidden_dim = hidden_dim
+        self.kl_weight = kl_weight
+        self.latent_dim = latent_dim
+        self.goal_cond_dim = goal_cond_dim
+        self.freeze_backbone = freeze_backbone
+        self.ignore_vae = ignore_vae
+        if freeze_backbone:
+            for p in self.backbone.parameters():
+                p.requires_grad = False
+        self.action_loss = action_loss if action_loss is not None else nn.MSELoss(reduction="none")
+        self.klloss = klloss
+
+        # ---- ACT.build_encoder (act.py:93-122); input_proj is set to None by ACTPCD (:361)
+        self.input_proj = None
+        self.input_proj_robot_state = nn.Linear(qpos_dim, hidden_dim)
+        self.cls_embed = nn.Embedding(1, hidden_dim)
+        self.encoder_action_proj = nn.Linear(action_dim, hidden_dim)
+        self.encoder_joint_proj = nn.Linear(qpos_dim, hidden_dim)
+        self.latent_proj = nn.Linear(hidden_dim, latent_dim * 2)
+        self.register_buffer("pos_table", get_sinusoid_encoding_table(1 + 1 + num_queries, hidden_dim))
+        if goal_cond_dim > 0:
+            self.proj_goal_cond_emb = nn.Linear(goal_cond_dim, hidden_dim)
+        # ---- ACT.build_decoder (act.py:124-135)
+        self.action_head = nn.Linear(hidden_dim, action_dim)
+        self.is_pad_head = nn.Linear(hidden_dim, 1)
+        self.query_embed = nn.Embedding(num_queries, hidden_dim)
+        self.latent_out_proj = nn.Linear(latent_dim, hidden_dim)
+        self.additional_pos_embed = nn.Embedding(2 + int(goal_cond_dim > 0), hidden_dim)
+        # ---- ACTPCD tokenizer (act.py:363-382)
+        self.pcd_nsample = pcd_nsample
+        self.pcd_npoints = pcd_npoints
+        self.pre_sample = pre_sample
+        self.linear = nn.Linear(3 + backbone.num_channels, hidden_dim, bias=False)
+        self.bn = nn.BatchNorm1d(hidden_dim)
+        self.pool = nn.MaxPool1d(pcd_nsample)
+        self.relu = nn.ReLU(inplace=True)
+        self.sampling = sampling
+        self.use_mask = use_mask
+        self.bg_ratio = bg_ratio
+        self._side_stream = None
+
+    @property
+    def pointops(self):
+        return self._pointops[0]
+
+    # ------------------------------------------------------------------ CVAE encoder (act.py:137-188)
+    def forward_encoder(self, data_dict):
+        qpos = data_dict["qpos"]
+        actions = data_dict.get("actions", None)
+        is_pad = data_dict.get("is_pad", None)
+        is_training = actions is not None
+        bs = qpos.shape[0]
+        data_dict["is_training"] = is_training
+        if is_training and not self.ignore_vae:
+            action_embed = self.encoder_action_proj(actions)  # (B, T, C)
+            qpos_embed = self.encoder_joint_proj(qpos).unsqueeze(1)  # (B, 1, C)
+            cls_embed = self.cls_embed.weight.unsqueeze(0).expand(bs, -1, -1)  # (B, 1, C)
+            enc_in = torch.cat([cls_embed, qpos_embed, action_embed], dim=1)  # (B, T+2, C)
+            pad = torch.cat([is_pad.new_zeros(bs, 2), is_pad], dim=1)  # CLS / qpos are never padding
+            enc_out = self.encoder(enc_in, pos=self.pos_table, src_key_padding_mask=pad)
+            latent_info = self.latent_proj(enc_out[:, 0])  # CLS token
+            mu = latent_info[:, : self.latent_dim]
+            logvar = latent_info[:, self.latent_dim :]
+            latent_sample = reparametrize(mu, logvar, data_dict.get("vae_eps", None))
+        else:
+            mu = logvar = None
+            latent_sample = torch.zeros([bs, self.latent_dim], dtype=torch.float32, device=qpos.device)
+        data_dict["mu"] = mu
+        data_dict["logvar"] = logvar
+        data_dict["latent_input"] = self.latent_out_proj(latent_sample)
+        return data_dict
+
+    # ------------------------------------------------------------------ tokenizer (act.py:384-551)
+    def _new_offsets(self, o):
+        """n_o = [M, 2M, ...] (act.py:387-391), cached per (b, device) with its host copy attached."""
+        b = int(o.shape[0])
+        key = (b, o.device)
+        cache = self.__dict__.setdefault("_n_o_cache", {})
+        if key not in cache:
+            host = [self.pcd_npoints * (i + 1) for i in range(b)]
+            t = torch.tensor(host, dtype=torch.int32, device=o.device)
+            t._pcm_host = host
+            cache[key] = t
+        return cache[key]
+
+    def pcd_sampling(self, pxo, mask=None, return_index=False):
+        """(p (n,3), x (n,c), o (b)) -> [n_p (m,3), x (m,H), n_o (b)] -- the set-abstraction layer."""
+        p, x, o = pxo
+        n_o = self._new_offsets(o)
+        out = set_abstraction(self, self.pointops, p, x, o, n_o, impl=self.sa_impl)
+        n_p, feat, idx = out
+        if return_index:
+            return [n_p, feat, n_o, idx]
+        return [n_p, feat, n_o]
+
+    def coord_embedding_sine(self, coord, temperature=10000, normalize=False, scale=None):
+        return coord_embedding_sine(coord, self.hidden_dim, temperature, normalize, scale)
+
+    def forward_pcd_embed(self, pcd_dict):
+        coord, offset = pcd_dict["coord"], pcd_dict["offset"]
+        n_o = self._new_offsets(offset)
+        # indices first (coordinates only), overlapped with the backbone when on the GPU
+        pre = set_abstraction.sample_and_query(self, self.pointops, coord, offset, n_o,
+                                               overlap=self.overlap_sampling and coord.is_cuda)
+        features = self.backbone(pcd_dict)
+        n_p, tokens, _ = set_abstraction(self, self.pointops, coord, features, offset, n_o, impl=self.sa_impl, pre=pre)
+        b = offset.shape[0]
+        pcd_pos = coord_embedding_sine(n_p, self.hidden_dim)
+        # "(b n) c -> b c 1 n"
+        tokens = tokens.view(b, self.pcd_npoints, -1).permute(0, 2, 1).unsqueeze(2)
+        pcd_pos = pcd_pos.view(b, self.pcd_npoints, -1).permute(0, 2, 1).unsqueeze(2)
+        return tokens, pcd_pos
+
+    # ------------------------------------------------------------------ act.py:553-598
+    def forward_obs_embed(self, data_dict):
+        qpos = data_dict["qpos"]
+        latent_input = data_dict["latent_input"]
+        goal_cond = None
+        if self.goal_cond_dim > 0:
+            if data_dict["goal_cond"].dim() > 2:
+                data_dict["goal_cond"] = data_dict["goal_cond"].reshape(data_dict["goal_cond"].shape[0], -1)
+            goal_cond = self.proj_goal_cond_emb(data_dict["goal_cond"])
+        pcd_tokens, pcd_pos = self.forward_pcd_embed(data_dict["pcds"])
+        proprio_input = self.input_proj_robot_state(qpos).unsqueeze(0)
+        if goal_cond is not None:
+            proprio_input = torch.cat([proprio_input, goal_cond.unsqueeze(0)], dim=0)
+        data_dict["src"] = pcd_tokens
+        data_dict["pos"] = pcd_pos
+        data_dict["latent_input"] = latent_input.unsqueeze(0)
+        data_dict["proprio_input"] = proprio_input
+        return data_dict
+
+    # ------------------------------------------------------------------ act.py:255-291
+    def forward_decoder(self, data_dict):
+        hs = self.transformer(
+            data_dict["src"], None, self.query_embed.weight, data_dict["pos"], data_dict["latent_input"],
+            data_dict["proprio_input"], self.additional_pos_embed.weight,
+        )[0]  # only the FIRST decoder layer's (normed) output feeds the heads, act.py:270
+        data_dict["a_hat"] = self.action_head(hs)
+        data_dict["is_pad_hat"] = self.is_pad_head(hs)
+        return data_dict
+
+    def forward_loss(self, data_dict):
+        total_kld = self.klloss(data_dict["mu"], data_dict["logvar"])
+        action_loss = self.action_loss(data_dict["a_hat"].float(), data_dict["actions"])
+        action_loss = (action_loss * ~data_dict["is_pad"].unsqueeze(-1)).mean()
+        data_dict["action_loss"] = action_loss
+        data_dict["kl_loss"] = total_kld
+        data_dict["loss"] = action_loss + total_kld * self.kl_weight
+        return data_dict
+
+    def forward(self, data_dict):
+        data_dict = self.forward_encoder(data_dict)
+        data_dict = self.forward_obs_embed(data_dict)
+        data_dict = self.forward_decoder(data_dict)
+        if not data_dict["is_training"]:
+            return data_dict
+        return self.forward_loss(data_dict)

@@ -1,0 +1,107 @@
+"""The set-abstraction ("pcd_sampling") layer shared by ACTPCD and PCDObsEncoder, and the 3-D sine
+position embedding of the tokens.
+
+Reference: /root/reference/src/models/components/act/act.py:384-465 (twin:
+diffusion_policy/vision/pcd_obs_encoder.py:123-198) and act.py:467-506.
+
+    FPS(p, o -> n_o)  ->  n_p = p[idx]  ->  kNN(n_p in p, K)  ->  group [rel xyz | feat]  (m, K, 3+C)
+    -> Linear(3+C -> H, no bias) -> BatchNorm1d(H) over the m*K rows -> ReLU -> max over K  -> (m, H)
+
+`owner` is the module that holds ``linear``, ``bn``, ``pool``, ``relu``, ``pcd_nsample`` under the
+reference's attribute names (so state-dict keys match).  Implementations:
+
+  "reference"  the reference's literal op sequence (materialises (m,K,3+C) and (m,H,K));
+  "torch"      same op order, BN applied on the (m*K, H) view (identical statistics) and a plain
+               max over K -- skips the transpose/contiguous copy;
+  "fused"      HIP kernels of policy/sa_fused.py: one (n,3+C)x(3+C,H) GEMM + gather/BN/ReLU/max
+               passes that never materialise the grouped tensor (fp32 sums re-associated: within
+               1e-4 relative of "reference", not bit-identical).
+"""
+import torch
+
+
+def coord_embedding_sine(coord, hidden_dim, temperature=10000, normalize=False, scale=None):
+    """act.py:467-506: per-axis interleaved sin/cos with H//3 features per axis, zero-padded to H."""
+    npf = hidden_dim // 3
+    pad = hidden_dim - npf * 3
+    if scale is not None and normalize is False:
+        raise ValueError("normalize should be True if scale is passed")
+    if scale is None:
+        scale = 2 * torch.pi
+    axes = [coord[:, 0:1], coord[:, 1:2], coord[:, 2:3]]
+    if normalize:
+        eps = 1e-6
+        axes = [coord[:, i] / (coord[:, i].max() + eps) * scale for i in range(3)]
+    dim_t = torch.arange(npf, dtype=torch.float32, device=coord.device)
+    dim_t = temperature ** (2 * (dim_t // 2) / npf)
+    parts = []
+    for a in axes:
+        ang = a[..., None] / dim_t  # (m, 1, npf)
+        parts.append(torch.stack((ang[..., 0::2].sin(), ang[..., 1::2].cos()), dim=2).flatten(1))
+    pos = torch.cat(parts, dim=1)
+    if pad:
+        pos = torch.cat((pos, pos.new_zeros(pos.shape[0], pad)), dim=1)
+    return pos
+
+
+def sample_and_query(owner, pointops, p, o, n_o, overlap=False):
+    """Coordinate-only part of the layer: FPS indices, sampled centres, kNN lists.
+
+    With ``overlap`` the three launches go to a side HIP stream so they run concurrently with
+    whatever the caller enqueues next on the current stream (the PointNet MLP); ``wait()`` joins.
+    """
+    nsample = owner.pcd_nsample
+
+    def run():
+        with torch.no_grad():
+            idx = pointops.farthest_point_sampling(p, o, n_o)  # (m) int32
+            n_p = p[idx.long(), :]  # (m, 3)
+            knn_idx, _ = pointops.knn_query(nsample, p, o, n_p, n_o)
+        return idx, n_p, knn_idx
+
+    if not (overlap and p.is_cuda):
+        idx, n_p, knn_idx = run()
+        return {"idx": idx, "n_p": n_p, "knn_idx": knn_idx, "event": None}
+    main = torch.cuda.current_stream(p.device)
+    side = getattr(owner, "_side_stream", None)
+    if side is None:
+        side = torch.cuda.Stream(device=p.device)
+        owner._side_stream = side
+    side.wait_stream(main)  # coordinates must be materialised
+    with torch.cuda.stream(side):
+        idx, n_p, knn_idx = run()
+        event = side.record_event()
+    for t in (idx, n_p, knn_idx):
+        t.record_stream(main)
+    return {"idx": idx, "n_p": n_p, "knn_idx": knn_idx, "event": event}
+
+
+def set_abstraction(owner, pointops, p, x, o, n_o, impl="reference", pre=None):
+    """Returns (n_p (m,3), tokens (m,H), fps_idx (m))."""
+    if pre is None:
+        pre = sample_and_query(owner, pointops, p, o, n_o, overlap=False)
+    if pre["event"] is not None:
+        torch.cuda.current_stream(p.device).wait_event(pre["event"])
+    idx, n_p, knn_idx = pre["idx"], pre["n_p"], pre["knn_idx"]
+    m, k = knn_idx.shape
+    if impl == "fused":
+        from .sa_fused import sa_fused_forward
+
+        tokens = sa_fused_forward(owner, p, x, n_p, idx, knn_idx)
+        return n_p, tokens, idx
+    grouped, _ = pointops.knn_query_and_group(x, p, offset=o, new_xyz=n_p, new_offset=n_o, idx=knn_idx,
+                                              nsample=k, with_xyz=True)  # (m, K, 3+C)
+    y = owner.linear(grouped)  # (m, K, H)
+    if impl == "reference":
+        y = owner.relu(owner.bn(y.transpose(1, 2).contiguous()))  # (m, H, K)
+        tokens = owner.pool(y).squeeze(-1)  # (m, H)
+    elif impl == "torch":
+        h = y.shape[-1]
+        y = owner.relu(owner.bn(y.reshape(m * k, h))).view(m, k, h)
+        tokens = y.max(dim=1).values
+    else:
+        raise ValueError(impl)
+    return n_p, tokens, idx
+
+
+set_abstraction.sample_and_query = sample_and_query

@@ -1,0 +1,232 @@
+"""DETR-style post/pre-norm transformer used by ACT, written batch-first around fused attention.
+
+Behavioural counterpart of /root/reference/src/models/components/act/transformer.py:16-425 with the
+SAME parameter names (``encoder.layers.N.self_attn.in_proj_weight`` ..., ``decoder.norm.weight``) so
+reference checkpoints load unchanged.  Differences in *how* it runs, not in what it computes:
+
+* activations stay (batch, tokens, dim) -- no (tokens, batch, dim) permutes;
+* attention goes through ``F.scaled_dot_product_attention`` (flash kernel on ROCm, bf16 under
+  autocast) instead of ``nn.MultiheadAttention.forward`` with its default ``need_weights=True``
+  that materialises an (S x S) probability matrix per head (S = 2051 on the shipped config);
+* q and k share one (2E x E) projection GEMM when they have the same input
+  (``q = k = x + pos`` in every self-attention of this model).
+
+``nn.MultiheadAttention`` modules are kept as parameter containers (packed ``in_proj_weight``,
+``out_proj``) for state-dict compatibility; their ``forward`` is never called.
+"""
+import copy
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor, nn
+
+
+def _split_heads(x: Tensor, nhead: int) -> Tensor:
+    b, l, e = x.shape
+    return x.view(b, l, nhead, e // nhead).transpose(1, 2)  # (B, H, L, hd)
+
+
+def attention(
+    mha: nn.MultiheadAttention,
+    query: Tensor,
+    key: Tensor,
+    value: Tensor,
+    key_padding_mask: Optional[Tensor] = None,
+    training: bool = False,
+) -> Tensor:
+    """Multi-head attention with the parameters of ``mha``; inputs (B, L, E) / (B, S, E).
+    ``key_padding_mask`` (B, S) bool, True = ignore (nn.MultiheadAttention convention)."""
+    e, h = mha.embed_dim, mha.num_heads
+    w, b = mha.in_proj_weight, mha.in_proj_bias
+    if query is key:
+        qk = F.linear(query, w[: 2 * e], b[: 2 * e])
+        q, k = qk[..., :e], qk[..., e:]
+    else:
+        q = F.linear(query, w[:e], b[:e])
+        k = F.linear(key, w[e : 2 * e], b[e : 2 * e])
+    v = F.linear(value, w[2 * e :], b[2 * e :])
+    mask = None
+    if key_padding_mask is not None:
+        mask = (~key_padding_mask)[:, None, None, :]  # True = attend
+    out = F.scaled_dot_product_attention(
+        _split_heads(q, h), _split_heads(k, h), _split_heads(v, h), attn_mask=mask,
+        dropout_p=mha.dropout if training else 0.0,
+    )
+    out = out.transpose(1, 2).reshape(query.shape[0], query.shape[1], e)
+    return mha.out_proj(out)
+
+
+def _activation(name):
+    if name == "relu":
+        return F.relu
+    if name == "gelu":
+        return F.gelu
+    if name == "glu":
+        return F.glu
+    raise RuntimeError(f"activation should be relu/gelu, not {name}.")
+
+
+def _add_pos(x, pos):
+    return x if pos is None else x + pos
+
+
+class TransformerEncoderLayer(nn.Module):
+    """transformer.py:209-287."""
+
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="relu", normalize_before=False):
+        super().__init__()
+        self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.dropout1 = nn.Dropout(dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.activation = _activation(activation)
+        self.normalize_before = normalize_before
+
+    def _ffn(self, x):
+        return self.linear2(self.dropout(self.activation(self.linear1(x))))
+
+    def forward(self, src, src_key_padding_mask=None, pos=None):
+        if self.normalize_before:
+            y = self.norm1(src)
+            qk = _add_pos(y, pos)
+            src = src + self.dropout1(attention(self.self_attn, qk, qk, y, src_key_padding_mask, self.training))
+            return src + self.dropout2(self._ffn(self.norm2(src)))
+        qk = _add_pos(src, pos)
+        src = self.norm1(src + self.dropout1(attention(self.self_attn, qk, qk, src, src_key_padding_mask, self.training)))
+        return self.norm2(src + self.dropout2(self._ffn(src)))
+
+
+class TransformerDecoderLayer(nn.Module):
+    """transformer.py:290-410."""
+
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="relu", normalize_before=False):
+        super().__init__()
+        self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.multihead_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.norm3 = nn.LayerNorm(d_model)
+        self.dropout1 = nn.Dropout(dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.dropout3 = nn.Dropout(dropout)
+        self.activation = _activation(activation)
+        self.normalize_before = normalize_before
+
+    def _ffn(self, x):
+        return self.linear2(self.dropout(self.activation(self.linear1(x))))
+
+    def forward(self, tgt, memory, memory_pos, memory_key_padding_mask=None, query_pos=None):
+        """memory_pos = memory + pos (the cross-attention key input), shared by all layers."""
+        if self.normalize_before:
+            y = self.norm1(tgt)
+            qk = _add_pos(y, query_pos)
+            tgt = tgt + self.dropout1(attention(self.self_attn, qk, qk, y, None, self.training))
+            y = self.norm2(tgt)
+            tgt = tgt + self.dropout2(
+                attention(self.multihead_attn, _add_pos(y, query_pos), memory_pos, memory, memory_key_padding_mask, self.training)
+            )
+            return tgt + self.dropout3(self._ffn(self.norm3(tgt)))
+        qk = _add_pos(tgt, query_pos)
+        tgt = self.norm1(tgt + self.dropout1(attention(self.self_attn, qk, qk, tgt, None, self.training)))
+        tgt = self.norm2(
+            tgt
+            + self.dropout2(
+                attention(self.multihead_attn, _add_pos(tgt, query_pos), memory_pos, memory, memory_key_padding_mask, self.training)
+            )
+        )
+        return self.norm3(tgt + self.dropout3(self._ffn(tgt)))
+
+
+def _clones(module, n):
+    return nn.ModuleList([copy.deepcopy(module) for _ in range(n)])
+
+
+class TransformerEncoder(nn.Module):
+    """transformer.py:118-159.  Batch-first: src (B, S, E), pos broadcastable to it."""
+
+    def __init__(self, d_model=256, nhead=8, dim_feedforward=2048, dropout=0.1, activation="relu",
+                 normalize_before=False, num_layers=4):
+        super().__init__()
+        layer = TransformerEncoderLayer(d_model, nhead, dim_feedforward, dropout, activation, normalize_before)
+        self.layers = _clones(layer, num_layers)
+        self.num_layers = num_layers
+        self.norm = nn.LayerNorm(d_model) if normalize_before else None
+
+    def forward(self, src, src_key_padding_mask=None, pos=None):
+        out = src
+        for layer in self.layers:
+            out = layer(out, src_key_padding_mask=src_key_padding_mask, pos=pos)
+        return out if self.norm is None else self.norm(out)
+
+
+class TransformerDecoder(nn.Module):
+    """transformer.py:162-206."""
+
+    def __init__(self, decoder_layer, num_layers, norm=None, return_intermediate=False):
+        super().__init__()
+        self.layers = _clones(decoder_layer, num_layers)
+        self.num_layers = num_layers
+        self.norm = norm
+        self.return_intermediate = return_intermediate
+
+    def forward(self, tgt, memory, memory_key_padding_mask=None, pos=None, query_pos=None):
+        out = tgt
+        memory_pos = _add_pos(memory, pos)
+        inter = []
+        for layer in self.layers:
+            out = layer(out, memory, memory_pos, memory_key_padding_mask=memory_key_padding_mask, query_pos=query_pos)
+            if self.return_intermediate:
+                inter.append(self.norm(out))
+        if self.return_intermediate:
+            # the reference pops the last entry and re-appends norm(out): same tensor
+            return torch.stack(inter)
+        if self.norm is not None:
+            out = self.norm(out)
+        return out.unsqueeze(0)
+
+
+class Transformer(nn.Module):
+    """transformer.py:16-115.  forward() takes the same arguments in the same order; `src` and
+    `pos_embed` are (B, C, H, W) like the reference, the result is (num_dec_layers, B, queries, C)."""
+
+    def __init__(self, d_model=512, nhead=8, num_encoder_layers=6, num_decoder_layers=6, dim_feedforward=2048,
+                 dropout=0.1, activation="relu", normalize_before=False, return_intermediate_dec=False):
+        super().__init__()
+        self.encoder = TransformerEncoder(d_model=d_model, nhead=nhead, dim_feedforward=dim_feedforward, dropout=dropout,
+                                          activation=activation, normalize_before=normalize_before,
+                                          num_layers=num_encoder_layers)
+        dec_layer = TransformerDecoderLayer(d_model, nhead, dim_feedforward, dropout, activation, normalize_before)
+        self.decoder = TransformerDecoder(dec_layer, num_decoder_layers, nn.LayerNorm(d_model),
+                                          return_intermediate=return_intermediate_dec)
+        for p in self.parameters():  # transformer.py:57-60
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        self.d_model = d_model
+        self.nhead = nhead
+
+    def forward(self, src, mask, query_embed, pos_embed, latent_input=None, proprio_input=None, additional_pos_embed=None):
+        bs = src.shape[0]
+        tokens = src.flatten(2).transpose(1, 2)  # (B, HW, C)
+        pos = pos_embed.flatten(2).transpose(1, 2)  # (B or 1, HW, C)
+        if pos.shape[0] == 1:
+            pos = pos.expand(bs, -1, -1)
+        add_pos = additional_pos_embed.unsqueeze(0).expand(bs, -1, -1)  # (B, 2+g, C)
+        pos = torch.cat([add_pos, pos], dim=1)
+        # latent_input / proprio_input arrive (1, B, C) / (k, B, C) [3-d] or (B, C) [2-d] like the reference
+        if latent_input.dim() == 2:
+            extra = torch.stack([latent_input, proprio_input], dim=1)
+        else:
+            extra = torch.cat([latent_input, proprio_input], dim=0).transpose(0, 1)
+        tokens = torch.cat([extra, tokens], dim=1)
+        memory = self.encoder(tokens, src_key_padding_mask=mask, pos=pos)
+        query_pos = query_embed.unsqueeze(0).expand(bs, -1, -1)
+        tgt = torch.zeros_like(query_pos)
+        return self.decoder(tgt, memory, memory_key_padding_mask=mask, pos=pos, query_pos=query_pos)
