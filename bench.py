@@ -35,9 +35,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default="C2", help="C2 (headline), C4, REF, C1")
     ap.add_argument("--sa-impl", default=os.environ.get("PCM_SA_IMPL", "auto"))
+    ap.add_argument("--mode", default="auto", help="auto | graph | flat | eager (eager = torch AdamW + DDP + SyncBN)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=6)
+    ap.add_argument("--cpu-threads", type=int, default=16)
     return ap.parse_args()
 
 
@@ -98,14 +100,17 @@ def kernel_rooflines(wl, device, c_feat=512, hidden=512):
     return res
 
 
-def cpu_baseline(wl, steps):
+def cpu_baseline(wl, steps, threads=16):
     """The reference path restated on the host: same harness, device=cpu, pointops = the C oracle
     (OpenMP), model = plain PyTorch CPU ops in the reference's op order, fp32."""
     from oracle import pointops_cpu
     from pointcloudmatters_amd.bc import BCTrainer, build_act_policy, clone_batch, make_act_batch
 
-    cores = os.cpu_count() or 1
+    # more host threads are SLOWER on this path (measured on the 256-core GPU box at C2: 16 threads
+    # 1.76 s/step, 64 threads 3.3 s/step, 256 threads > 100 s/step), so the baseline uses 16.
+    cores = min(os.cpu_count() or 1, threads)
     torch.set_num_threads(cores)
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     torch.manual_seed(0)
     policy = build_act_policy(pcd_npoints=wl["pcd_npoints"], pointops=pointops_cpu, sa_impl="reference")
     trainer = BCTrainer(policy, total_steps=1000, precision="fp32", device="cpu", optim=dict(accumulate_grad_batches=1))
@@ -139,8 +144,11 @@ def main():
     sa_impl = "torch" if args.sa_impl == "auto" else args.sa_impl
     torch.manual_seed(1000 + rank)
     policy = build_act_policy(pcd_npoints=wl["pcd_npoints"], sa_impl=sa_impl).to(device)
+    mode = args.mode
+    if mode == "auto":  # hipGraph replay needs static shapes; ragged workloads use the flat optimizer eagerly
+        mode = "flat" if wl["ragged"] else "graph"
     trainer = BCTrainer(policy, total_steps=max(args.steps + args.warmup, 100), precision=wl["dtype"], device=device,
-                        distributed=world > 1, optim=dict(accumulate_grad_batches=1))
+                        distributed=world > 1, optim=dict(accumulate_grad_batches=1), mode=mode)
     batches = [make_act_batch(wl["batch"], wl["n_points"], seed=1000 + rank + 97 * i, ragged=wl["ragged"], device=device)
                for i in range(4)]
 
@@ -176,7 +184,8 @@ def main():
                                    "PointNet(6->512) + SA(515->512) + ACT(4 enc / 7 dec, d=512, 100 queries)"
                                    % (args.workload, wl["batch"], wl["n_points"], wl["pcd_npoints"]),
                        "global_batch": wl["batch"] * world, "points_per_cloud": wl["n_points"],
-                       "tokens_per_cloud": wl["pcd_npoints"], "parallelism": "dp%d" % world, "sa_impl": sa_impl,
+                       "tokens_per_cloud": wl["pcd_npoints"], "parallelism": "dp%d" % world, "sa_impl": sa_impl, "step_mode": mode,
+                       "batchnorm": "sync" if trainer.sync_batchnorm else "per-rank",
                        "accumulate_grad_batches": 1, "optimizer_step_every_step": True},
             "final_loss": round(metrics.get("train/loss", float("nan")), 4),
         }
@@ -187,7 +196,7 @@ def main():
                                "unit": "GB/s", "frac": kr[dom]["frac_of_hbm_peak"], "traffic": None}
             out["kernels"] = kr
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_steps)
+            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_steps, args.cpu_threads)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

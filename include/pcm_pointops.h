@@ -159,6 +159,21 @@ int pcm_group_xyz_feat_backward_hip(int m, int nsample, int c, int with_xyz,
                                     const float *grad_output, const int *idx, float *grad_feat,
                                     void *stream);
 
+/* ---- training-step tail: global-norm clip + AdamW over one flat fp32 buffer ---------------------
+ * replaces the torch passes the reference runs per step: clip_grad_norm_ (configs/trainer/ddp.yaml:12)
+ * and AdamW.step (src/models/maniskill2_act_bc_module.py:347-367).  p, g, m, v: n floats each,
+ * 16-byte aligned.  hyper: 9 floats ON THE DEVICE = { lr, beta1, beta2, eps, weight_decay,
+ * 1-beta1^t, sqrt(1-beta2^t), max_norm (<=0: no clipping), grad_scale } so a captured hipGraph can
+ * replay the launches while the host rewrites only this array.
+ *   pcm_grad_sumsq_hip  writes <= pcm_optim_partials_capacity() per-block sums of g^2 into
+ *                       `partials` (fixed grid: deterministic) and their count into *npartials_out;
+ *   pcm_adamw_flat_hip  reduces the partials, derives clip_coef = min(1, max_norm/(norm+1e-6)) and
+ *                       applies torch.optim.AdamW's update; norm_out (optional) receives the norm. */
+int pcm_optim_partials_capacity(void);
+int pcm_grad_sumsq_hip(long n, const float *g, float *partials, int *npartials_out, void *stream);
+int pcm_adamw_flat_hip(long n, float *p, const float *g, float *m, float *v, const float *hyper,
+                       const float *partials, int npartials, float *norm_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,6 +36,9 @@ SIGNATURES = {
     "pcm_attention_fusion_step_backward_hip": [_i, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P],
     "pcm_group_xyz_feat_forward_hip": [_i, _i, _i, _P, _P, _P, _P, _P, _P],
     "pcm_group_xyz_feat_backward_hip": [_i, _i, _i, _i, _P, _P, _P, _P],
+    "pcm_optim_partials_capacity": [],
+    "pcm_grad_sumsq_hip": [ctypes.c_long, _P, _P, _P, _P],
+    "pcm_adamw_flat_hip": [ctypes.c_long, _P, _P, _P, _P, _P, _P, _i, _P, _P],
 }
 
 _LIB = None

@@ -1,0 +1,102 @@
+"""AdamW + global-norm clipping over one flat HBM buffer, driven by csrc/optim.hip.
+
+All trainable parameters of the policy are re-homed as views of one fp32 buffer (their gradients as
+views of a second one), so that
+  * the optimizer tail of a training step is two streaming kernels instead of ~10 multi-tensor
+    passes (clip_grad_norm_'s norms + scale, AdamW's foreach groups),
+  * data parallelism needs exactly ONE gradient all-reduce over RCCL on a contiguous buffer,
+  * every step-dependent scalar lives in a device array -> the whole step is hipGraph-capturable.
+Numerics: torch.optim.AdamW's update rule element for element (tests compare against it).
+"""
+import math
+
+import torch
+
+from .. import _lib
+
+_ALIGN = 64  # floats: every parameter view starts on a 256-byte boundary
+
+
+class FlatAdamW:
+    H_LR, H_BETA1, H_BETA2, H_EPS, H_WD, H_BC1, H_BC2_SQRT, H_MAX_NORM, H_GRAD_SCALE, H_COUNT = range(10)
+
+    def __init__(self, params, schedule, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, max_norm=0.0, grad_scale=1.0):
+        params = [p for p in params if p.requires_grad]
+        assert params, "no trainable parameters"
+        dev = params[0].device
+        if dev.type != "cuda":
+            raise _lib.PointopsLibraryError("FlatAdamW runs on the HIP device only (CPU runs use torch.optim.AdamW)")
+        assert all(p.dtype == torch.float32 and p.device == dev for p in params)
+        self.lib = _lib.load()
+        self.params = params
+        self.schedule = schedule
+        self.beta1, self.beta2, self.eps, self.weight_decay = betas[0], betas[1], eps, weight_decay
+        self.max_norm, self.grad_scale = float(max_norm or 0.0), float(grad_scale)
+        offs, total = [], 0
+        for p in params:
+            offs.append(total)
+            total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.numel = total
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, o in zip(params, offs):
+                view = self.flat_p[o : o + p.numel()].view_as(p)
+                view.copy_(p)
+                p.data = view
+                p.grad = self.flat_g[o : o + p.numel()].view_as(p)
+        self.offsets = offs
+        self.hyper = torch.zeros(self.H_COUNT, dtype=torch.float32, device=dev)
+        self._hyper_host = torch.zeros(self.H_COUNT, dtype=torch.float32).pin_memory()
+        self.partials = torch.zeros(self.lib.pcm_optim_partials_capacity(), dtype=torch.float32, device=dev)
+        self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.step_count = 0
+        self.last_lr = None
+
+    # ---- host side, between graph replays ------------------------------------------------------
+    def prepare_step(self):
+        """Write the hyper-parameters of the NEXT optimizer step (1-based t = step_count + 1) into
+        the device array: an asynchronous 40-byte copy on the current stream."""
+        lr, mom = self.schedule.at(self.step_count) if self.schedule is not None else (self._fixed_lr, None)
+        beta1 = self.beta1 if mom is None else mom
+        t = self.step_count + 1
+        h = self._hyper_host
+        h[self.H_LR], h[self.H_BETA1], h[self.H_BETA2], h[self.H_EPS], h[self.H_WD] = lr, beta1, self.beta2, self.eps, self.weight_decay
+        h[self.H_BC1] = 1.0 - beta1 ** t
+        h[self.H_BC2_SQRT] = math.sqrt(1.0 - self.beta2 ** t)
+        h[self.H_MAX_NORM], h[self.H_GRAD_SCALE] = self.max_norm, self.grad_scale
+        self.hyper.copy_(h, non_blocking=True)
+        self.last_lr = lr
+        self.step_count += 1
+
+    # ---- device side (capturable) -----------------------------------------------------------------
+    def zero_grad(self):
+        self.flat_g.zero_()
+
+    def launch_step(self):
+        """Enqueue norm + AdamW on the current stream.  No host reads: safe inside graph capture."""
+        st = torch.cuda.current_stream().cuda_stream
+        lib = self.lib
+        import ctypes
+
+        npart = ctypes.c_int(0)
+        rc = lib.pcm_grad_sumsq_hip(self.numel, self.flat_g.data_ptr(), self.partials.data_ptr(), ctypes.addressof(npart), st)
+        _lib.check(rc, "pcm_grad_sumsq_hip")
+        rc = lib.pcm_adamw_flat_hip(self.numel, self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(),
+                                    self.exp_avg_sq.data_ptr(), self.hyper.data_ptr(), self.partials.data_ptr(), npart.value,
+                                    self.grad_norm.data_ptr(), st)
+        _lib.check(rc, "pcm_adamw_flat_hip")
+
+    def step(self):
+        self.prepare_step()
+        self.launch_step()
+
+    def state_dict(self):
+        return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step_count": self.step_count}
+
+    def load_state_dict(self, sd):
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.step_count = int(sd["step_count"])

@@ -36,8 +36,18 @@ def freeze_unused_parameters(policy):
 
 
 class BCTrainer:
+    """mode:
+      "eager"  torch.optim.AdamW + OneCycleLR, DistributedDataParallel (+ SyncBatchNorm) when
+               distributed -- the literal Lightning recipe; also the CPU path.
+      "flat"   FlatAdamW (csrc/optim.hip) + host OneCycle; data parallel = ONE all-reduce of the flat
+               gradient buffer per optimizer step (no DDP wrapper, no bucket hooks).
+      "graph"  "flat" with forward+backward of a micro-batch captured ONCE into a hipGraph and
+               replayed (the step is launch-bound in eager mode: ~2400 launches); needs static
+               shapes (equal-size clouds) and per-rank BatchNorm statistics.
+    """
+
     def __init__(self, policy, total_steps, optim=None, precision="fp32", device=None, distributed=False,
-                 sync_batchnorm=True, bucket_cap_mb=32, log_every_n_steps=50):
+                 sync_batchnorm=True, bucket_cap_mb=32, log_every_n_steps=50, mode="eager"):
         o = dict(ACT_OPTIM)
         if optim:
             o.update(optim)
@@ -47,30 +57,52 @@ class BCTrainer:
         self.accumulate = int(o["accumulate_grad_batches"])
         self.clip = o["gradient_clip_val"]
         self.log_every_n_steps = log_every_n_steps
+        if mode not in ("eager", "flat", "graph"):
+            raise ValueError(mode)
+        if self.device.type != "cuda" and mode != "eager":
+            raise ValueError("flat/graph modes run on the HIP device only")
+        self.mode = mode
         freeze_unused_parameters(policy)
         self.policy = policy
         self.module = policy
         self.distributed = distributed and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-        if self.distributed:
-            if sync_batchnorm:
-                policy = nn.SyncBatchNorm.convert_sync_batchnorm(policy)
-                self.policy = policy
-            ids = [self.device.index] if self.device.type == "cuda" else None
-            self.module = nn.parallel.DistributedDataParallel(
-                policy, device_ids=ids, gradient_as_bucket_view=True, static_graph=True, bucket_cap_mb=bucket_cap_mb,
-            )
+        self.world = dist.get_world_size() if self.distributed else 1
+        total_steps = max(int(total_steps), int(2 / o["pct_start"]) + 1)
+        if self.distributed and sync_batchnorm and mode != "graph":
+            policy = nn.SyncBatchNorm.convert_sync_batchnorm(policy)
+            self.policy = self.module = policy
+        self.sync_batchnorm = bool(self.distributed and sync_batchnorm and mode != "graph")
         params = [p for p in self.policy.parameters() if p.requires_grad]
-        # build_optimizer(cfg, policy, None): one group, every parameter decayed (src/utils/optimizer.py:33-37)
-        self.optimizer = torch.optim.AdamW(params, lr=o["lr"], weight_decay=o["weight_decay"],
-                                           fused=self.device.type == "cuda")
-        self.scheduler = torch.optim.lr_scheduler.OneCycleLR(
-            self.optimizer, max_lr=o["lr"], total_steps=max(int(total_steps), int(2 / o["pct_start"]) + 1), pct_start=o["pct_start"],
-            anneal_strategy="cos", div_factor=o["div_factor"], final_div_factor=o["final_div_factor"],
-        )
+        if mode == "eager":
+            if self.distributed:
+                ids = [self.device.index] if self.device.type == "cuda" else None
+                self.module = nn.parallel.DistributedDataParallel(
+                    self.policy, device_ids=ids, gradient_as_bucket_view=True, static_graph=True, bucket_cap_mb=bucket_cap_mb,
+                )
+            # build_optimizer(cfg, policy, None): one group, every parameter decayed (src/utils/optimizer.py:33-37)
+            self.optimizer = torch.optim.AdamW(params, lr=o["lr"], weight_decay=o["weight_decay"],
+                                               fused=self.device.type == "cuda")
+            self.scheduler = torch.optim.lr_scheduler.OneCycleLR(
+                self.optimizer, max_lr=o["lr"], total_steps=total_steps, pct_start=o["pct_start"],
+                anneal_strategy="cos", div_factor=o["div_factor"], final_div_factor=o["final_div_factor"],
+            )
+        else:
+            from .flat_optim import FlatAdamW
+            from .schedule import OneCycle
+
+            sched = OneCycle(o["lr"], total_steps, o["pct_start"], o["div_factor"], o["final_div_factor"])
+            # grad_scale 1/world turns the all-reduce SUM into DDP's mean inside the Adam kernel
+            self.optimizer = FlatAdamW(params, sched, weight_decay=o["weight_decay"], max_norm=self.clip or 0.0,
+                                       grad_scale=1.0 / self.world)
+            self.scheduler = sched
         self.micro = 0
         self.optimizer_steps = 0
         self._sums = None
         self._count = 0
+        self._graph = None
+        self._static_batch = None
+        self._static_stats = None
+        self._static_sig = None
 
     # ------------------------------------------------------------------------------------------
     def _autocast(self):
@@ -78,29 +110,119 @@ class BCTrainer:
             return torch.autocast(device_type=self.device.type, dtype=torch.bfloat16)
         return contextlib.nullcontext()
 
+    def _forward_backward(self, batch):
+        with self._autocast():
+            out = self.module(batch)
+        loss = out["loss"]
+        (loss / self.accumulate).backward()
+        return torch.stack([loss.detach().float(), out["action_loss"].detach().float(),
+                            torch.as_tensor(out["kl_loss"], device=loss.device).detach().float()])
+
+    # ---- hipGraph capture of one micro-batch (forward + backward) -------------------------------
+    @staticmethod
+    def _signature(batch):
+        sig = []
+        for k in sorted(batch):
+            v = batch[k]
+            if isinstance(v, dict):
+                for kk in sorted(v):
+                    t = v[kk]
+                    sig.append((k, kk, tuple(t.shape), t.dtype, tuple(getattr(t, "_pcm_host", ()) or ())))
+            elif torch.is_tensor(v):
+                sig.append((k, tuple(v.shape), v.dtype))
+        return tuple(sig)
+
+    @staticmethod
+    def _clone_static(batch):
+        out = {}
+        for k, v in batch.items():
+            if isinstance(v, dict):
+                out[k] = {}
+                for kk, t in v.items():
+                    c = t.clone()
+                    if hasattr(t, "_pcm_host"):
+                        c._pcm_host = list(t._pcm_host)
+                    out[k][kk] = c
+            elif torch.is_tensor(v):
+                out[k] = v.clone()
+            else:
+                out[k] = v
+        return out
+
+    @staticmethod
+    def _copy_into(static, batch):
+        for k, v in batch.items():
+            if isinstance(v, dict):
+                for kk, t in v.items():
+                    if static[k][kk] is not t:
+                        static[k][kk].copy_(t, non_blocking=True)
+            elif torch.is_tensor(v) and static[k] is not v:
+                static[k].copy_(v, non_blocking=True)
+
+    def _capture(self, batch):
+        from .synthetic import clone_batch
+
+        self._static_sig = self._signature(batch)
+        self._static_batch = self._clone_static(batch)
+        buffers = {n: b.clone() for n, b in self.policy.named_buffers()}
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):  # warm-up off the capture stream: lazy inits, GEMM heuristics
+            for _ in range(3):
+                self._forward_backward(clone_batch(self._static_batch))
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+        with torch.no_grad():  # the warm-up must not count as training: restore BN statistics
+            for n, b in self.policy.named_buffers():
+                b.copy_(buffers[n])
+        self.optimizer.zero_grad()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._static_stats = self._forward_backward(clone_batch(self._static_batch))
+        self.optimizer.zero_grad()
+
     def training_step(self, batch):
         """One micro-batch: forward, loss, backward and -- on accumulation boundaries -- the
         optimizer step.  Returns the (detached, on-device) loss dict of this micro-batch."""
         self.module.train()
+        first = self.micro % self.accumulate == 0
         stepping = (self.micro + 1) % self.accumulate == 0
-        sync_ctx = contextlib.nullcontext()
-        if self.distributed and not stepping:
-            sync_ctx = self.module.no_sync()
-        with sync_ctx:
-            with self._autocast():
-                out = self.module(batch)
-            loss = out["loss"]
-            (loss / self.accumulate).backward()
-        if stepping:
-            if self.clip is not None and self.clip > 0:
-                torch.nn.utils.clip_grad_norm_([p for g in self.optimizer.param_groups for p in g["params"]], self.clip)
-            self.optimizer.step()
-            self.scheduler.step()
-            self.optimizer.zero_grad(set_to_none=True)
-            self.optimizer_steps += 1
+        if self.mode == "eager":
+            sync_ctx = contextlib.nullcontext()
+            if self.distributed and not stepping:
+                sync_ctx = self.module.no_sync()
+            with sync_ctx:
+                stats = self._forward_backward(batch)
+            if stepping:
+                if self.clip is not None and self.clip > 0:
+                    torch.nn.utils.clip_grad_norm_([p for g in self.optimizer.param_groups for p in g["params"]], self.clip)
+                self.optimizer.step()
+                self.scheduler.step()
+                self.optimizer.zero_grad(set_to_none=True)
+                self.optimizer_steps += 1
+        else:
+            if self.mode == "graph":
+                if self._graph is None:
+                    self._capture(batch)
+                elif self._signature(batch) != self._static_sig:
+                    raise ValueError("graph mode needs the captured batch layout (equal shapes and cloud offsets); "
+                                     "use mode='flat' for ragged batches")
+                if first:
+                    self.optimizer.zero_grad()
+                self._copy_into(self._static_batch, batch)
+                self._graph.replay()
+                stats = self._static_stats.clone()
+            else:
+                if first:
+                    self.optimizer.zero_grad()
+                stats = self._forward_backward(batch)
+            if stepping:
+                if self.distributed:
+                    dist.all_reduce(self.optimizer.flat_g)  # SUM; the 1/world is applied in the Adam kernel
+                self.optimizer.step()
+                self.optimizer_steps += 1
         self.micro += 1
-        stats = torch.stack([out["loss"].detach().float(), out["action_loss"].detach().float(),
-                             torch.as_tensor(out["kl_loss"], device=loss.device).detach().float()])
         self._sums = stats if self._sums is None else self._sums + stats
         self._count += 1
         return {"loss": stats[0], "action_loss": stats[1], "kl_loss": stats[2]}
@@ -120,12 +242,16 @@ class BCTrainer:
         return {"train/loss": vals[0], "train/action_loss": vals[1], "train/kl_loss": vals[2]}
 
     def state_dict(self):
-        return {"policy": self.policy.state_dict(), "optimizer": self.optimizer.state_dict(),
-                "scheduler": self.scheduler.state_dict(), "micro": self.micro, "optimizer_steps": self.optimizer_steps}
+        sd = {"policy": self.policy.state_dict(), "optimizer": self.optimizer.state_dict(), "micro": self.micro,
+              "optimizer_steps": self.optimizer_steps, "mode": self.mode}
+        if self.mode == "eager":
+            sd["scheduler"] = self.scheduler.state_dict()
+        return sd
 
     def load_state_dict(self, sd):
         self.policy.load_state_dict(sd["policy"])
         self.optimizer.load_state_dict(sd["optimizer"])
-        self.scheduler.load_state_dict(sd["scheduler"])
+        if self.mode == "eager" and "scheduler" in sd:
+            self.scheduler.load_state_dict(sd["scheduler"])
         self.micro = sd["micro"]
         self.optimizer_steps = sd["optimizer_steps"]

@@ -1,0 +1,148 @@
+// optim.hip -- gradient-norm clipping + AdamW over ONE flat fp32 parameter buffer (gfx950).
+//
+// Replaces, on the training step of the hot path, what Lightning/torch run as separate multi-tensor
+// passes in the reference:  clip_grad_norm_(0.5)  ->  AdamW.step()
+//   (/root/reference/configs/trainer/ddp.yaml:12 gradient_clip_val,
+//    /root/reference/src/models/maniskill2_act_bc_module.py:347-367 configure_optimizers,
+//    /root/reference/configs/model/maniskill2_act_pcd_model.yaml:11-14 AdamW lr 5e-5 wd 0.05).
+//
+// Layout: all trainable parameters live back to back in one HBM buffer p[n]; g, m, v mirror it.
+// Two launches per optimizer step, both HBM-streaming with 16-byte accesses:
+//   pcm_grad_sumsq  : per-block partial sums of g^2 (fixed grid -> deterministic), 4 B/elem read
+//   pcm_adamw_flat  : every block re-reduces the <=1024 partials (L2-resident, free), derives the
+//                     clip coefficient and applies decoupled-weight-decay Adam: 16 B read + 12 B
+//                     written per element.  Algorithmic bytes per step: 32 * n.
+// Every step-dependent scalar (lr, beta1 -- OneCycleLR cycles it --, bias corrections, gradient
+// scale) is read from a small DEVICE array, so the launches can sit inside a captured hipGraph and
+// the host only rewrites that array between replays.
+//
+// Update rule = torch.optim.AdamW (single-tensor form), per element, fp32:
+//   g   = grad * grad_scale * clip_coef          clip_coef = min(1, max_norm / (||grad*scale|| + 1e-6))
+//   p  *= 1 - lr * wd
+//   m  += (g - m) * (1 - beta1)                  (lerp)
+//   v   = v * beta2 + (1 - beta2) * g * g
+//   p  -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
+#include "pcm_common.hpp"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kMaxPartials = 1024;
+
+// hyper[] indices
+enum { H_LR = 0, H_BETA1, H_BETA2, H_EPS, H_WD, H_BC1, H_BC2_SQRT, H_MAX_NORM, H_GRAD_SCALE, H_COUNT };
+
+__device__ __forceinline__ float block_sum(float v, float *red)
+{
+    // wave reduce (DPP butterfly on the float bits is not associative-safe to share with u32 helpers; use shfl)
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int w = 0; w < kBlock / 64; ++w) s += red[w];  // same order in every thread
+    __syncthreads();
+    return s;
+}
+
+__global__ __launch_bounds__(kBlock) void pcm_grad_sumsq_kernel(long n4, long n, const float *__restrict__ g,
+                                                                float *__restrict__ partials)
+{
+    __shared__ float red[kBlock / 64];
+    float acc = 0.f;
+    const float4 *g4 = reinterpret_cast<const float4 *>(g);
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (long)gridDim.x * kBlock) {
+        const float4 x = g4[i];
+        acc += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+    }
+    if (blockIdx.x == 0) {  // tail (n not a multiple of 4)
+        for (long i = n4 * 4 + threadIdx.x; i < n; i += kBlock) acc += g[i] * g[i];
+    }
+    const float s = block_sum(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+__device__ __forceinline__ void adam_elem(float &p, float g, float &m, float &v, float lr, float b1, float b2, float eps,
+                                          float wd, float bc1, float bc2s, float gscale)
+{
+    g = g * gscale;
+    p = p * (1.f - lr * wd);
+    m = m + (g - m) * (1.f - b1);
+    v = v * b2 + (1.f - b2) * g * g;
+    const float denom = sqrtf(v) / bc2s + eps;
+    p = p - (lr / bc1) * (m / denom);
+}
+
+__global__ __launch_bounds__(kBlock) void pcm_adamw_flat_kernel(long n4, long n, float *__restrict__ p,
+                                                                const float *__restrict__ g, float *__restrict__ m,
+                                                                float *__restrict__ v, const float *__restrict__ hyper,
+                                                                const float *__restrict__ partials, int npartials,
+                                                                float *__restrict__ norm_out)
+{
+    __shared__ float red[kBlock / 64];
+    const float lr = hyper[H_LR], b1 = hyper[H_BETA1], b2 = hyper[H_BETA2], eps = hyper[H_EPS], wd = hyper[H_WD];
+    const float bc1 = hyper[H_BC1], bc2s = hyper[H_BC2_SQRT], max_norm = hyper[H_MAX_NORM], scale = hyper[H_GRAD_SCALE];
+    float gscale = scale;
+    if (npartials > 0) {
+        float acc = 0.f;
+        for (int i = threadIdx.x; i < npartials; i += kBlock) acc += partials[i];
+        const float total = sqrtf(block_sum(acc, red)) * fabsf(scale);  // ||grad * scale||_2
+        if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out) *norm_out = total;
+        if (max_norm > 0.f) {
+            const float coef = max_norm / (total + 1e-6f);
+            gscale = scale * (coef < 1.f ? coef : 1.f);
+        }
+    }
+    float4 *p4 = reinterpret_cast<float4 *>(p);
+    const float4 *g4 = reinterpret_cast<const float4 *>(g);
+    float4 *m4 = reinterpret_cast<float4 *>(m);
+    float4 *v4 = reinterpret_cast<float4 *>(v);
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (long)gridDim.x * kBlock) {
+        float4 pp = p4[i], mm = m4[i], vv = v4[i];
+        const float4 gg = g4[i];
+        adam_elem(pp.x, gg.x, mm.x, vv.x, lr, b1, b2, eps, wd, bc1, bc2s, gscale);
+        adam_elem(pp.y, gg.y, mm.y, vv.y, lr, b1, b2, eps, wd, bc1, bc2s, gscale);
+        adam_elem(pp.z, gg.z, mm.z, vv.z, lr, b1, b2, eps, wd, bc1, bc2s, gscale);
+        adam_elem(pp.w, gg.w, mm.w, vv.w, lr, b1, b2, eps, wd, bc1, bc2s, gscale);
+        p4[i] = pp;
+        m4[i] = mm;
+        v4[i] = vv;
+    }
+    if (blockIdx.x == 0) {
+        for (long i = n4 * 4 + threadIdx.x; i < n; i += kBlock)
+            adam_elem(p[i], g[i], m[i], v[i], lr, b1, b2, eps, wd, bc1, bc2s, gscale);
+    }
+}
+
+inline int stream_grid(long n4)
+{
+    long blocks = (n4 + kBlock - 1) / kBlock;
+    if (blocks > kMaxPartials) blocks = kMaxPartials;  // 4 workgroups per CU, grid-stride
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+}  // namespace
+
+extern "C" int pcm_optim_partials_capacity(void) { return kMaxPartials; }
+
+extern "C" int pcm_grad_sumsq_hip(long n, const float *g, float *partials, int *npartials_out, void *stream)
+{
+    if (n < 0 || ((uintptr_t)g % 16) != 0) return PCM_ERR_BAD_ARG;
+    const long n4 = n / 4;
+    const int grid = stream_grid(n4);
+    if (npartials_out) *npartials_out = grid;
+    hipLaunchKernelGGL(pcm_grad_sumsq_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, n4, n, g, partials);
+    return PCM_LAUNCH_STATUS();
+}
+
+extern "C" int pcm_adamw_flat_hip(long n, float *p, const float *g, float *m, float *v, const float *hyper,
+                                  const float *partials, int npartials, float *norm_out, void *stream)
+{
+    if (n < 0 || npartials < 0 || npartials > kMaxPartials) return PCM_ERR_BAD_ARG;
+    if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16) != 0) return PCM_ERR_BAD_ARG;
+    const long n4 = n / 4;
+    hipLaunchKernelGGL(pcm_adamw_flat_kernel, dim3(stream_grid(n4)), dim3(kBlock), 0, (hipStream_t)stream, n4, n, p, g, m, v,
+                       hyper, partials, npartials, norm_out);
+    return PCM_LAUNCH_STATUS();
+}

@@ -71,8 +71,9 @@ def sample_and_query(owner, pointops, p, o, n_o, overlap=False):
     with torch.cuda.stream(side):
         idx, n_p, knn_idx = run()
         event = side.record_event()
-    for t in (idx, n_p, knn_idx):
-        t.record_stream(main)
+    if not torch.cuda.is_current_stream_capturing():
+        for t in (idx, n_p, knn_idx):
+            t.record_stream(main)
     return {"idx": idx, "n_p": n_p, "knn_idx": knn_idx, "event": event}
 
 
@@ -84,6 +85,8 @@ def set_abstraction(owner, pointops, p, x, o, n_o, impl="reference", pre=None):
         torch.cuda.current_stream(p.device).wait_event(pre["event"])
     idx, n_p, knn_idx = pre["idx"], pre["n_p"], pre["knn_idx"]
     m, k = knn_idx.shape
+    if x.dtype != torch.float32:
+        x = x.float()  # pointops is fp32 (bf16 autocast applies to GEMM / attention only)
     if impl == "fused":
         from .sa_fused import sa_fused_forward
 

@@ -60,3 +60,74 @@ def test_gpu_step_matches_cpu_oracle_step(hip_device):
     sd_c, sd_g = cpu.state_dict(), gpu.state_dict()
     for k in ("linear.weight", "backbone.conv1.0.weight", "transformer.encoder.layers.0.linear1.weight", "action_head.weight"):
         torch.testing.assert_close(sd_g[k].cpu(), sd_c[k], rtol=1e-3, atol=1e-6)
+
+
+def _run_mode(mode, hip_device, steps=4, accumulate=1, precision="fp32"):
+    from pointcloudmatters_amd.bc import BCTrainer, build_act_policy, clone_batch, make_act_batch
+
+    torch.manual_seed(7)
+    pol = build_act_policy(pcd_npoints=64, dropout=0.0, hidden_dim=96, nhead=4, num_encoder_layers=2,
+                           num_decoder_layers=2, sa_impl="torch").to(hip_device)
+    tr = BCTrainer(pol, total_steps=50, precision=precision, device=hip_device, mode=mode,
+                   optim=dict(accumulate_grad_batches=accumulate, lr=1e-3))
+    batches = [make_act_batch(3, 256, seed=50 + i, device=hip_device) for i in range(2)]
+    eps = torch.randn(3, 32, generator=torch.Generator().manual_seed(1)).to(hip_device)
+    losses = []
+    for i in range(steps * accumulate):
+        b = clone_batch(batches[i % 2])
+        b["vae_eps"] = eps
+        losses.append(tr.training_step(b)["loss"].item())
+    return losses, {k: v.detach().clone() for k, v in pol.state_dict().items()}, tr
+
+
+@pytest.mark.parametrize("accumulate", [1, 2])
+def test_flat_and_graph_modes_match_torch_adamw(hip_device, accumulate):
+    """FlatAdamW (+ clip, + OneCycle incl. beta1 cycling) and the hipGraph-replayed step must follow
+    the same parameter trajectory as torch.optim.AdamW + clip_grad_norm_ + OneCycleLR."""
+    l_e, sd_e, _ = _run_mode("eager", hip_device, accumulate=accumulate)
+    l_f, sd_f, _ = _run_mode("flat", hip_device, accumulate=accumulate)
+    l_g, sd_g, tr = _run_mode("graph", hip_device, accumulate=accumulate)
+    assert tr._graph is not None
+    for a, b, c in zip(l_e, l_f, l_g):
+        assert abs(a - b) <= 2e-4 * abs(a) and abs(a - c) <= 2e-4 * abs(a), (l_e, l_f, l_g)
+    for k in sd_e:
+        if sd_e[k].dtype.is_floating_point:
+            # Adam turns noise-level gradient differences (e.g. the mathematically-zero key-bias
+            # gradient of softmax attention) into +-lr updates, so compare per tensor in L2, and bound
+            # every element by the largest possible drift (steps * lr).
+            ref = sd_e[k].float()
+            for other in (sd_f[k], sd_g[k]):
+                d = (other.float() - ref)
+                slack = 0.05 * 4 * 1e-3 * ref.numel() ** 0.5  # 5% of the total drift steps*lr per element
+                assert d.norm() <= 5e-3 * ref.norm() + slack, (k, float(d.norm()), float(ref.norm()))
+                assert d.abs().max() <= 2 * 4 * 1e-3 + 1e-6, k
+        else:
+            assert torch.equal(sd_g[k], sd_e[k]), k  # num_batches_tracked: warm-up must not count
+
+
+def test_flat_adamw_kernel_vs_torch(hip_device):
+    from pointcloudmatters_amd.bc.flat_optim import FlatAdamW
+    from pointcloudmatters_amd.bc.schedule import OneCycle
+
+    torch.manual_seed(0)
+    shapes = [(513, 7), (64,), (3, 5, 11), (1,), (1000, 33)]
+    ref = [torch.nn.Parameter(torch.randn(s, device=hip_device)) for s in shapes]
+    mine = [torch.nn.Parameter(p.detach().clone()) for p in ref]
+    opt_ref = torch.optim.AdamW(ref, lr=3e-3, weight_decay=0.05)
+    sch_ref = torch.optim.lr_scheduler.OneCycleLR(opt_ref, max_lr=3e-3, total_steps=40, pct_start=0.1, div_factor=100.0,
+                                                  final_div_factor=1000.0)
+    opt = FlatAdamW(mine, OneCycle(3e-3, 40, 0.1, 100.0, 1000.0), weight_decay=0.05, max_norm=0.5)
+    for it in range(12):
+        grads = [torch.randn(s, device=hip_device) * (3.0 if it % 3 == 0 else 0.01) for s in shapes]
+        for p, g in zip(ref, grads):
+            p.grad = g.clone()
+        opt.zero_grad()
+        for p, g in zip(mine, grads):
+            p.grad.add_(g)
+        norm = torch.nn.utils.clip_grad_norm_(ref, 0.5)
+        opt_ref.step()
+        sch_ref.step()
+        opt.step()
+        torch.testing.assert_close(opt.grad_norm[0], norm, rtol=1e-5, atol=1e-7)
+        for a, b in zip(mine, ref):
+            torch.testing.assert_close(a.detach(), b.detach(), rtol=2e-5, atol=2e-6)
