@@ -3,7 +3,7 @@ configs/model/maniskill2_act_pcd_model.yaml:27-68 in the reference)."""
 import torch.nn as nn
 
 from ..policy import ACTPCD, KLDivergence, PointNet, Transformer, TransformerEncoder
-from .configs import ACT_MODEL
+from .configs import ACT_MODEL, DP_MODEL
 
 
 def build_act_policy(pcd_npoints, pointops=None, sa_impl="reference", overlap_sampling=True, **overrides):
@@ -27,3 +27,30 @@ def build_act_policy(pcd_npoints, pointops=None, sa_impl="reference", overlap_sa
         pcd_nsample=c["pcd_nsample"], pcd_npoints=pcd_npoints, pointops=pointops, sa_impl=sa_impl,
         overlap_sampling=overlap_sampling,
     )
+
+
+def build_dp_policy(pcd_npoints, pointops=None, sa_impl="reference", overlap_sampling=True, **overrides):
+    """configs/exp_maniskill2_diffusion_policy/maniskill2_model/scratch_pointnet_pcd.yaml, instantiated."""
+    from ..policy.diffusion import DDPMSchedule, DiffusionUnetPcdPolicy, PCDObsEncoder
+
+    c = dict(DP_MODEL)
+    c.update(overrides)
+    shape_meta = {"obs": {"pcds": {"shape": [c["in_channels"]], "type": "pcd"},
+                          "qpos": {"shape": [c["qpos_dim"]], "type": "low_dim"}},
+                  "action": {"shape": [c["action_dim"]]}}
+    pcd_model = PointNet(in_channels=c["in_channels"], num_classes=c["pcd_num_classes"])
+    enc = PCDObsEncoder(shape_meta=shape_meta, pcd_model=pcd_model, share_pcd_model=True, n_obs_step=c["n_obs_steps"],
+                        pcd_nsample=c["pcd_nsample"], pcd_npoints=pcd_npoints, pcd_hidden_dim=c["pcd_hidden_dim"],
+                        projector_layers=c["projector_layers"], projector_channels=c["projector_channels"],
+                        pointops=pointops, sa_impl=sa_impl, overlap_sampling=overlap_sampling)
+    sched = DDPMSchedule(num_train_timesteps=c["num_train_timesteps"], beta_schedule="squaredcos_cap_v2",
+                         prediction_type="epsilon")
+    pol = DiffusionUnetPcdPolicy(shape_meta=shape_meta, noise_scheduler=sched, obs_encoder=enc, horizon=c["horizon"],
+                                 n_action_steps=c["n_action_steps"], n_obs_steps=c["n_obs_steps"],
+                                 diffusion_step_embed_dim=c["diffusion_step_embed_dim"], down_dims=c["down_dims"],
+                                 kernel_size=c["kernel_size"], n_groups=c["n_groups"],
+                                 cond_predict_scale=c["cond_predict_scale"])
+    # identity-range normaliser by default (synthetic data is already O(1)); datasets call policy.normalizer.fit
+    pol.normalizer.set_range("qpos", [-1.0] * c["qpos_dim"], [1.0] * c["qpos_dim"])
+    pol.normalizer.set_range("action", [-1.0] * c["action_dim"], [1.0] * c["action_dim"])
+    return pol

@@ -17,6 +17,19 @@ ACT_MODEL = dict(
 ACT_OPTIM = dict(lr=5e-5, weight_decay=0.05, pct_start=0.1, div_factor=100.0, final_div_factor=1000.0,
                  gradient_clip_val=0.5, accumulate_grad_batches=2)
 
+# Diffusion Policy: /root/reference/configs/model/maniskill2_diffusion_policy_model.yaml:10-60,
+# exp_maniskill2_diffusion_policy/maniskill2_model/scratch_pointnet_pcd.yaml:10-35 (PointNet num_classes 96,
+# SA hidden 96, projector [96,128,128] with 1 layer), data chunk_size 16, qpos 9-d.
+DP_MODEL = dict(
+    horizon=16, n_action_steps=8, n_obs_steps=2, num_train_timesteps=100, diffusion_step_embed_dim=128,
+    down_dims=(512, 1024, 2048), kernel_size=5, n_groups=8, cond_predict_scale=True, action_dim=7, qpos_dim=9,
+    in_channels=6, pcd_num_classes=96, pcd_hidden_dim=96, projector_layers=1, projector_channels=(96, 128, 128),
+    pcd_nsample=16,
+)
+
+DP_OPTIM = dict(lr=1e-4, weight_decay=1e-4, betas=(0.9, 0.95), pct_start=0.15, div_factor=100.0, final_div_factor=1000.0,
+                gradient_clip_val=0.5, accumulate_grad_batches=1, filter_bias_and_bn=True)
+
 # name -> per-GPU batch, points per cloud, tokens per cloud (pcd_npoints), compute dtype
 WORKLOADS = {
     # BASELINE.json configs[0]: CPU plumbing case
@@ -26,5 +39,9 @@ WORKLOADS = {
     # configs[3]: per-GPU shape of the 8-GPU ACT run
     "C4": dict(policy="act", batch=8, n_points=2048, pcd_npoints=1024, dtype="bf16", ragged=False),
     # the shipped ACT config (scratch_pointnet_pcd.yaml:10, maniskill2_act_pcd_model.yaml:67-68)
+    # configs[2]: StackCube, 1024-pt clouds, Diffusion Policy (B=64 samples x To=2 clouds)
+    "C3": dict(policy="dp", batch=64, n_points=1024, pcd_npoints=512, dtype="bf16", ragged=False),
+    # configs[4]: per-GPU shape of the RLBench 4096-pt Diffusion-Policy run
+    "C5": dict(policy="dp", batch=16, n_points=4096, pcd_npoints=2048, dtype="bf16", ragged=False),
     "REF": dict(policy="act", batch=8, n_points=4096, pcd_npoints=2048, dtype="bf16", ragged=True),
 }

@@ -21,7 +21,16 @@ class FlatAdamW:
     H_LR, H_BETA1, H_BETA2, H_EPS, H_WD, H_BC1, H_BC2_SQRT, H_MAX_NORM, H_GRAD_SCALE, H_COUNT = range(10)
 
     def __init__(self, params, schedule, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, max_norm=0.0, grad_scale=1.0):
-        params = [p for p in params if p.requires_grad]
+        """`params`: an iterable of parameters, or a list of {"params": [...], "weight_decay": wd}
+        groups (timm-style no-decay group for biases / norm weights, src/utils/optimizer.py:152-170).
+        Groups are laid out back to back; the norm runs over everything, Adam once per group."""
+        params = list(params)
+        if params and isinstance(params[0], dict):
+            groups = [([p for p in g["params"] if p.requires_grad], float(g.get("weight_decay", weight_decay))) for g in params]
+        else:
+            groups = [([p for p in params if p.requires_grad], float(weight_decay))]
+        groups = [g for g in groups if g[0]]
+        params = [p for g in groups for p in g[0]]
         assert params, "no trainable parameters"
         dev = params[0].device
         if dev.type != "cuda":
@@ -32,10 +41,13 @@ class FlatAdamW:
         self.schedule = schedule
         self.beta1, self.beta2, self.eps, self.weight_decay = betas[0], betas[1], eps, weight_decay
         self.max_norm, self.grad_scale = float(max_norm or 0.0), float(grad_scale)
-        offs, total = [], 0
-        for p in params:
-            offs.append(total)
-            total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        offs, total, self.segments = [], 0, []
+        for gp, wd in groups:
+            start = total
+            for p in gp:
+                offs.append(total)
+                total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+            self.segments.append((start, total - start, wd))
         self.numel = total
         self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -48,8 +60,8 @@ class FlatAdamW:
                 p.data = view
                 p.grad = self.flat_g[o : o + p.numel()].view_as(p)
         self.offsets = offs
-        self.hyper = torch.zeros(self.H_COUNT, dtype=torch.float32, device=dev)
-        self._hyper_host = torch.zeros(self.H_COUNT, dtype=torch.float32).pin_memory()
+        self.hyper = torch.zeros(len(self.segments), self.H_COUNT, dtype=torch.float32, device=dev)
+        self._hyper_host = torch.zeros(len(self.segments), self.H_COUNT, dtype=torch.float32).pin_memory()
         self.partials = torch.zeros(self.lib.pcm_optim_partials_capacity(), dtype=torch.float32, device=dev)
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
         self.step_count = 0
@@ -62,11 +74,12 @@ class FlatAdamW:
         lr, mom = self.schedule.at(self.step_count) if self.schedule is not None else (self._fixed_lr, None)
         beta1 = self.beta1 if mom is None else mom
         t = self.step_count + 1
-        h = self._hyper_host
-        h[self.H_LR], h[self.H_BETA1], h[self.H_BETA2], h[self.H_EPS], h[self.H_WD] = lr, beta1, self.beta2, self.eps, self.weight_decay
-        h[self.H_BC1] = 1.0 - beta1 ** t
-        h[self.H_BC2_SQRT] = math.sqrt(1.0 - self.beta2 ** t)
-        h[self.H_MAX_NORM], h[self.H_GRAD_SCALE] = self.max_norm, self.grad_scale
+        for gi, (_, _, wd) in enumerate(self.segments):
+            h = self._hyper_host[gi]
+            h[self.H_LR], h[self.H_BETA1], h[self.H_BETA2], h[self.H_EPS], h[self.H_WD] = lr, beta1, self.beta2, self.eps, wd
+            h[self.H_BC1] = 1.0 - beta1 ** t
+            h[self.H_BC2_SQRT] = math.sqrt(1.0 - self.beta2 ** t)
+            h[self.H_MAX_NORM], h[self.H_GRAD_SCALE] = self.max_norm, self.grad_scale
         self.hyper.copy_(h, non_blocking=True)
         self.last_lr = lr
         self.step_count += 1
@@ -84,10 +97,13 @@ class FlatAdamW:
         npart = ctypes.c_int(0)
         rc = lib.pcm_grad_sumsq_hip(self.numel, self.flat_g.data_ptr(), self.partials.data_ptr(), ctypes.addressof(npart), st)
         _lib.check(rc, "pcm_grad_sumsq_hip")
-        rc = lib.pcm_adamw_flat_hip(self.numel, self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(),
-                                    self.exp_avg_sq.data_ptr(), self.hyper.data_ptr(), self.partials.data_ptr(), npart.value,
-                                    self.grad_norm.data_ptr(), st)
-        _lib.check(rc, "pcm_adamw_flat_hip")
+        for gi, (start, count, _) in enumerate(self.segments):
+            o = start * 4
+            rc = lib.pcm_adamw_flat_hip(count, self.flat_p.data_ptr() + o, self.flat_g.data_ptr() + o,
+                                        self.exp_avg.data_ptr() + o, self.exp_avg_sq.data_ptr() + o,
+                                        self.hyper.data_ptr() + gi * self.H_COUNT * 4, self.partials.data_ptr(), npart.value,
+                                        self.grad_norm.data_ptr(), st)
+            _lib.check(rc, "pcm_adamw_flat_hip")
 
     def step(self):
         self.prepare_step()

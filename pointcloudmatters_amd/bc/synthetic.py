@@ -51,9 +51,24 @@ def make_act_batch(batch, n_points, seed=1000, ragged=False, num_queries=100, ac
     return batch_dict
 
 
+def make_dp_batch(batch, n_points, seed=1000, ragged=False, horizon=16, n_obs_steps=2, action_dim=7, qpos_dim=9,
+                  device="cpu"):
+    """Diffusion-Policy batch: B samples, each with n_obs_steps clouds flattened sample-major
+    (sparse_tensor_utils.py:74-75 -> b = B*To clouds), qpos window (B, horizon, qpos_dim), action (B, horizon, Da)."""
+    clouds = make_act_batch(batch * n_obs_steps, n_points, seed=seed, ragged=ragged, num_queries=1, action_dim=1,
+                            qpos_dim=1, goal_cond_dim=0, device=device)["pcds"]
+    rng = np.random.default_rng(seed + 1)
+    dev = torch.device(device)
+    return {
+        "obs": {"pcds": clouds,
+                "qpos": torch.from_numpy(rng.uniform(-1, 1, (batch, horizon, qpos_dim)).astype(np.float32)).to(dev)},
+        "action": torch.from_numpy(rng.uniform(-1, 1, (batch, horizon, action_dim)).astype(np.float32)).to(dev),
+    }
+
+
 def clone_batch(batch):
     """Shallow per-step copy: the policy writes intermediate results into the dict it is given."""
     out = {}
     for k, v in batch.items():
-        out[k] = dict(v) if isinstance(v, dict) else v
+        out[k] = clone_batch(v) if isinstance(v, dict) else v
     return out

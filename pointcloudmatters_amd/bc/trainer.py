@@ -73,6 +73,13 @@ class BCTrainer:
             self.policy = self.module = policy
         self.sync_batchnorm = bool(self.distributed and sync_batchnorm and mode != "graph")
         params = [p for p in self.policy.parameters() if p.requires_grad]
+        betas = tuple(o.get("betas", (0.9, 0.999)))
+        if o.get("filter_bias_and_bn", False) and o["weight_decay"]:
+            # build_optimizer_v2 -> param_groups_weight_decay (src/utils/optimizer.py:152-170, 296-300)
+            no_decay = [p for n, p in self.policy.named_parameters() if p.requires_grad and (p.ndim <= 1 or n.endswith(".bias"))]
+            ids = {id(p) for p in no_decay}
+            decay = [p for p in params if id(p) not in ids]
+            params = [{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": o["weight_decay"]}]
         if mode == "eager":
             if self.distributed:
                 ids = [self.device.index] if self.device.type == "cuda" else None
@@ -80,7 +87,7 @@ class BCTrainer:
                     self.policy, device_ids=ids, gradient_as_bucket_view=True, static_graph=True, bucket_cap_mb=bucket_cap_mb,
                 )
             # build_optimizer(cfg, policy, None): one group, every parameter decayed (src/utils/optimizer.py:33-37)
-            self.optimizer = torch.optim.AdamW(params, lr=o["lr"], weight_decay=o["weight_decay"],
+            self.optimizer = torch.optim.AdamW(params, lr=o["lr"], weight_decay=o["weight_decay"], betas=betas,
                                                fused=self.device.type == "cuda")
             self.scheduler = torch.optim.lr_scheduler.OneCycleLR(
                 self.optimizer, max_lr=o["lr"], total_steps=total_steps, pct_start=o["pct_start"],
@@ -92,7 +99,7 @@ class BCTrainer:
 
             sched = OneCycle(o["lr"], total_steps, o["pct_start"], o["div_factor"], o["final_div_factor"])
             # grad_scale 1/world turns the all-reduce SUM into DDP's mean inside the Adam kernel
-            self.optimizer = FlatAdamW(params, sched, weight_decay=o["weight_decay"], max_norm=self.clip or 0.0,
+            self.optimizer = FlatAdamW(params, sched, betas=betas, weight_decay=o["weight_decay"], max_norm=self.clip or 0.0,
                                        grad_scale=1.0 / self.world)
             self.scheduler = sched
         self.micro = 0
@@ -115,21 +122,21 @@ class BCTrainer:
             out = self.module(batch)
         loss = out["loss"]
         (loss / self.accumulate).backward()
-        return torch.stack([loss.detach().float(), out["action_loss"].detach().float(),
-                            torch.as_tensor(out["kl_loss"], device=loss.device).detach().float()])
+        aux1 = out.get("action_loss", loss)
+        aux2 = out.get("kl_loss", 0.0)
+        return torch.stack([loss.detach().float(), aux1.detach().float(),
+                            torch.as_tensor(aux2, device=loss.device).detach().float()])
 
     # ---- hipGraph capture of one micro-batch (forward + backward) -------------------------------
     @staticmethod
-    def _signature(batch):
+    def _signature(batch, prefix=()):
         sig = []
         for k in sorted(batch):
             v = batch[k]
             if isinstance(v, dict):
-                for kk in sorted(v):
-                    t = v[kk]
-                    sig.append((k, kk, tuple(t.shape), t.dtype, tuple(getattr(t, "_pcm_host", ()) or ())))
+                sig.extend(BCTrainer._signature(v, prefix + (k,)))
             elif torch.is_tensor(v):
-                sig.append((k, tuple(v.shape), v.dtype))
+                sig.append((prefix + (k,), tuple(v.shape), v.dtype, tuple(getattr(v, "_pcm_host", ()) or ())))
         return tuple(sig)
 
     @staticmethod
@@ -137,14 +144,12 @@ class BCTrainer:
         out = {}
         for k, v in batch.items():
             if isinstance(v, dict):
-                out[k] = {}
-                for kk, t in v.items():
-                    c = t.clone()
-                    if hasattr(t, "_pcm_host"):
-                        c._pcm_host = list(t._pcm_host)
-                    out[k][kk] = c
+                out[k] = BCTrainer._clone_static(v)
             elif torch.is_tensor(v):
-                out[k] = v.clone()
+                c = v.clone()
+                if hasattr(v, "_pcm_host"):
+                    c._pcm_host = list(v._pcm_host)
+                out[k] = c
             else:
                 out[k] = v
         return out
@@ -153,9 +158,7 @@ class BCTrainer:
     def _copy_into(static, batch):
         for k, v in batch.items():
             if isinstance(v, dict):
-                for kk, t in v.items():
-                    if static[k][kk] is not t:
-                        static[k][kk].copy_(t, non_blocking=True)
+                BCTrainer._copy_into(static[k], v)
             elif torch.is_tensor(v) and static[k] is not v:
                 static[k].copy_(v, non_blocking=True)
 

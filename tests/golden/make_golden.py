@@ -87,6 +87,28 @@ def install_reference():
     _pkg("pointops_ref", f"{REF}/libs/pointops/functions")
     sys.modules["pointops._C"] = fake_c
     ref.grouping = _load("pointops_ref.grouping", f"{REF}/libs/pointops/functions/grouping.py")
+    # ---- Diffusion-Policy pieces ----------------------------------------------------------------
+    import logging
+
+    class RankedLogger(logging.LoggerAdapter):  # src.utils.RankedLogger is only used for one info() line
+        def __init__(self, name, rank_zero_only=True):
+            super().__init__(logging.getLogger(name), {})
+
+    utils.RankedLogger = RankedLogger
+    _load("src.utils.pytorch_utils", f"{REF}/src/utils/pytorch_utils.py")
+    dpu = _pkg("src.utils.diffusion_policy", f"{REF}/src/utils/diffusion_policy")
+    mam = _load("src.utils.diffusion_policy.module_attr_mixin", f"{REF}/src/utils/diffusion_policy/module_attr_mixin.py")
+    dpu.ModuleAttrMixin = mam.ModuleAttrMixin
+    base = f"{REF}/src/models/components/diffusion_policy"
+    _pkg("src.models.components.diffusion_policy", base)
+    _pkg("src.models.components.diffusion_policy.diffusion", f"{base}/diffusion")
+    _pkg("src.models.components.diffusion_policy.vision", f"{base}/vision")
+    pfx = "src.models.components.diffusion_policy"
+    _load(f"{pfx}.diffusion.conv1d_components", f"{base}/diffusion/conv1d_components.py")
+    _load(f"{pfx}.diffusion.positional_embedding", f"{base}/diffusion/positional_embedding.py")
+    ref.unet = _load(f"{pfx}.diffusion.conditional_unet1d", f"{base}/diffusion/conditional_unet1d.py")
+    ref.maskgen = _load(f"{pfx}.diffusion.mask_generator", f"{base}/diffusion/mask_generator.py")
+    ref.pcd_enc = _load(f"{pfx}.vision.pcd_obs_encoder", f"{base}/vision/pcd_obs_encoder.py")
     return ref
 
 
@@ -204,6 +226,68 @@ def golden_misc(ref):
     print("misc_ref.npz ok")
 
 
+DP_SMALL = dict(down_dims=(16, 32, 64), diffusion_step_embed_dim=16, pcd_num_classes=24, pcd_hidden_dim=24,
+                projector_channels=(24, 40, 40), n_groups=8)
+
+
+def golden_dp(ref):
+    """Reference PCDObsEncoder + ConditionalUnet1D + LowdimMaskGenerator, composed as compute_loss
+    does (diffusion_unet_image_policy.py:233-313; that file itself needs diffusers and is not importable)."""
+    from oracle import pointops_cpu
+    from pointcloudmatters_amd.bc import build_dp_policy, make_dp_batch
+    from pointcloudmatters_amd.policy import PointNet
+
+    pcd_npoints = 32
+    torch.manual_seed(4321)
+    ours = build_dp_policy(pcd_npoints=pcd_npoints, pointops=pointops_cpu, sa_impl="reference", **DP_SMALL)
+    sd = ours.state_dict()
+    shape_meta = {"obs": {"pcds": {"shape": [6], "type": "pcd"}, "qpos": {"shape": [9], "type": "low_dim"}},
+                  "action": {"shape": [7]}}
+    enc = ref.pcd_enc.PCDObsEncoder(shape_meta=shape_meta, pcd_model=PointNet(in_channels=6, num_classes=24),
+                                    share_pcd_model=True, n_obs_step=2, pcd_nsample=16, pcd_npoints=pcd_npoints,
+                                    pcd_hidden_dim=24, projector_layers=1, projector_channels=[24, 40, 40])
+    enc.load_state_dict({k[len("obs_encoder."):]: v for k, v in sd.items() if k.startswith("obs_encoder.")}, strict=True)
+    unet = ref.unet.ConditionalUnet1D(input_dim=7, local_cond_dim=None, global_cond_dim=(40 + 9) * 2,
+                                      diffusion_step_embed_dim=16, down_dims=[16, 32, 64], kernel_size=5, n_groups=8,
+                                      cond_predict_scale=True)
+    unet.load_state_dict({k[len("model."):]: v for k, v in sd.items() if k.startswith("model.")}, strict=True)
+    mg = ref.maskgen.LowdimMaskGenerator(action_dim=7, obs_dim=0, max_n_obs_steps=2, fix_obs_steps=True, action_visible=False)
+    enc.train(), unet.train()
+    batch = make_dp_batch(3, 150, seed=11, ragged=True)
+    g = torch.Generator().manual_seed(8)
+    noise = torch.randn(3, 16, 7, generator=g)
+    timesteps = torch.tensor([3, 57, 99])
+    # --- compute_loss, with the identity-range normaliser the builder installs (scale 1, offset 0)
+    qpos, action = batch["obs"]["qpos"], batch["action"]
+    this_nobs = {"qpos": qpos[:, :2].reshape(-1, 9), "pcds": {k: v.clone() for k, v in batch["obs"]["pcds"].items()}}
+    feat = enc(this_nobs)
+    global_cond = feat.reshape(3, -1)
+    mask = mg((3, 16, 7))
+    acp = ours.noise_scheduler.alphas_cumprod[timesteps]  # diffusers absent: our restated schedule (parity unpinned)
+    noisy = acp.sqrt()[:, None, None] * action + (1 - acp).sqrt()[:, None, None] * noise
+    noisy[mask] = action[mask]
+    pred = unet(noisy, timesteps, local_cond=None, global_cond=global_cond)
+    loss = torch.nn.functional.mse_loss(pred, noise, reduction="none") * (~mask).float()
+    loss = loss.reshape(3, -1).mean(1).mean()
+    loss.backward()
+    fx = {"noise": noise.numpy(), "timesteps": timesteps.numpy(), "out.loss": loss.detach().numpy(),
+          "out.pred": pred.detach().numpy(), "out.global_cond": global_cond.detach().numpy(), "out.mask": mask.numpy()}
+    for k, v in batch["obs"]["pcds"].items():
+        fx[f"in.pcds.{k}"] = v.numpy()
+    fx["in.qpos"], fx["in.action"] = qpos.numpy(), action.numpy()
+    for k, v in sd.items():
+        fx[f"w.{k}"] = v.numpy()
+    g_enc = dict(enc.named_parameters())
+    g_unet = dict(unet.named_parameters())
+    for k in ("linear.weight", "projector.0.weight", "projector.4.weight", "key_model_map.pcd.conv1.0.weight", "key_model_map.pcd.final.weight"):
+        fx[f"grad.obs_encoder.{k}"] = g_enc[k].grad.numpy()
+    for k in ("diffusion_step_encoder.1.weight", "down_modules.0.0.blocks.0.block.0.weight", "mid_modules.1.cond_encoder.1.weight",
+              "up_modules.1.2.conv.weight", "final_conv.1.weight", "down_modules.1.2.conv.weight", "up_modules.0.0.residual_conv.weight"):
+        fx[f"grad.model.{k}"] = g_unet[k].grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "dp_pcd_small.npz"), **fx)
+    print("dp_pcd_small.npz: loss", float(loss))
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "run this in the build container (needs /root/reference)"
     torch.set_num_threads(1)
@@ -211,3 +295,4 @@ if __name__ == "__main__":
     golden_act(ref)
     golden_grouping(ref)
     golden_misc(ref)
+    golden_dp(ref)
