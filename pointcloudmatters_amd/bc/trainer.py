@@ -47,7 +47,7 @@ class BCTrainer:
     """
 
     def __init__(self, policy, total_steps, optim=None, precision="fp32", device=None, distributed=False,
-                 sync_batchnorm=True, bucket_cap_mb=32, log_every_n_steps=50, mode="eager"):
+                 sync_batchnorm=True, bucket_cap_mb=32, log_every_n_steps=50, mode="eager", flat_optimizer_cls=None):
         o = dict(ACT_OPTIM)
         if optim:
             o.update(optim)
@@ -59,7 +59,7 @@ class BCTrainer:
         self.log_every_n_steps = log_every_n_steps
         if mode not in ("eager", "flat", "graph"):
             raise ValueError(mode)
-        if self.device.type != "cuda" and mode != "eager":
+        if self.device.type != "cuda" and mode != "eager" and (flat_optimizer_cls is None or mode == "graph"):
             raise ValueError("flat/graph modes run on the HIP device only")
         self.mode = mode
         freeze_unused_parameters(policy)
@@ -84,7 +84,7 @@ class BCTrainer:
             if self.distributed:
                 ids = [self.device.index] if self.device.type == "cuda" else None
                 self.module = nn.parallel.DistributedDataParallel(
-                    self.policy, device_ids=ids, gradient_as_bucket_view=True, static_graph=True, bucket_cap_mb=bucket_cap_mb,
+                    self.policy, device_ids=ids, gradient_as_bucket_view=True, bucket_cap_mb=bucket_cap_mb,
                 )
             # build_optimizer(cfg, policy, None): one group, every parameter decayed (src/utils/optimizer.py:33-37)
             self.optimizer = torch.optim.AdamW(params, lr=o["lr"], weight_decay=o["weight_decay"], betas=betas,
@@ -94,8 +94,12 @@ class BCTrainer:
                 anneal_strategy="cos", div_factor=o["div_factor"], final_div_factor=o["final_div_factor"],
             )
         else:
-            from .flat_optim import FlatAdamW
             from .schedule import OneCycle
+
+            if flat_optimizer_cls is not None:  # tests inject a host stand-in to exercise the DP logic on gloo
+                FlatAdamW = flat_optimizer_cls
+            else:
+                from .flat_optim import FlatAdamW
 
             sched = OneCycle(o["lr"], total_steps, o["pct_start"], o["div_factor"], o["final_div_factor"])
             # grad_scale 1/world turns the all-reduce SUM into DDP's mean inside the Adam kernel

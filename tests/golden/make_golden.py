@@ -222,6 +222,29 @@ def golden_misc(ref):
     fx["o2b.offset"] = off.numpy()
     fx["o2b.batch"] = ref.collate.offset2batch(off).numpy()
     fx["b2o.offset"] = ref.collate.batch2offset(ref.collate.offset2batch(torch.tensor([5, 9, 14]))).numpy()
+    # pcd_collate_fn on two ACT-style samples and two DP-style samples (sparse_tensor_utils.py:36-82)
+    g2 = torch.Generator().manual_seed(21)
+
+    def cloud(n):
+        return {"coord": torch.randn(n, 3, generator=g2), "grid_coord": torch.randint(0, 50, (n, 3), generator=g2),
+                "feat": torch.randn(n, 6, generator=g2), "offset": torch.tensor([n])}
+
+    sizes = [5, 3, 4, 6]
+    clouds = [cloud(n) for n in sizes]
+    for i, c in enumerate(clouds):
+        for k, v in c.items():
+            fx[f"collate.in.{i}.{k}"] = v.numpy()
+    import copy
+    act_samples = [{"pcds": [copy.deepcopy(clouds[i])], "qpos": torch.full((9,), float(i))} for i in range(2)]
+    out = ref.collate.pcd_collate_fn(act_samples)
+    for k, v in out["pcds"].items():
+        fx[f"collate.act.pcds.{k}"] = v.numpy()
+    fx["collate.act.qpos"] = out["qpos"].numpy()
+    dp_samples = [{"obs": {"pcds": [copy.deepcopy(clouds[2 * i]), copy.deepcopy(clouds[2 * i + 1])], "qpos": torch.full((2, 9), float(i))},
+                   "action": torch.full((4, 7), float(i))} for i in range(2)]
+    out = ref.collate.pcd_collate_fn(dp_samples)
+    for k, v in out["obs"]["pcds"].items():
+        fx[f"collate.dp.pcds.{k}"] = v.numpy()
     np.savez_compressed(os.path.join(OUT, "misc_ref.npz"), **fx)
     print("misc_ref.npz ok")
 
