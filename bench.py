@@ -141,7 +141,7 @@ def main():
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     wl = WORKLOADS[args.workload]
-    sa_impl = "torch" if args.sa_impl == "auto" else args.sa_impl
+    sa_impl = "fused" if args.sa_impl == "auto" else args.sa_impl
     torch.manual_seed(1000 + rank)
     policy = build_act_policy(pcd_npoints=wl["pcd_npoints"], sa_impl=sa_impl).to(device)
     mode = args.mode

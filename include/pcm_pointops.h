@@ -159,6 +159,32 @@ int pcm_group_xyz_feat_backward_hip(int m, int nsample, int c, int with_xyz,
                                     const float *grad_output, const int *idx, float *grad_feat,
                                     void *stream);
 
+/* ---- fused set-abstraction layer ------------------------------------------------------------------
+ * replaces, after FPS + kNN, the framework ops of ACTPCD.pcd_sampling / PCDObsEncoder.pcd_sampling
+ * (src/models/components/act/act.py:446-460; diffusion_policy/vision/pcd_obs_encoder.py:174-190):
+ * grouping(with_xyz) -> Linear(3+C->H, no bias) -> BatchNorm1d(H) (training statistics over the m*K
+ * rows) -> ReLU -> max over K.  The caller supplies Gf = feat @ Wf^T (n,H) (fp32 or bf16, one GEMM on
+ * the n points); the xyz part Wp (p_j - q_i) is added in fp32 inside the gather.  Nothing of size
+ * m*K*H is ever written.  Workspaces are caller-allocated (sizes in policy/sa_fused.py):
+ *   forward : ymax,ymin (m,H) f32; amax,amin (m,H) u8; partial (slots,5,H); sums (2,H); stat (4,H) =
+ *             {mean, invstd, a, b}; z (m,H) the tokens.  running_mean/var updated in place (or NULL).
+ *   backward: D (n,H), cnt (n), S (n,3), RM (12) zeroed by the caller; red1 (5,H), red2 (3,H);
+ *             outputs dGf (n,H) in Gf's dtype, dWp (H,3), dgamma (H), dbeta (H). */
+int pcm_sa_fused_slots(int units, int H, int vec);
+int pcm_sa_fused_forward_hip(int m, int K, int H, int gf_is_bf16, const void *Gf, const float *p,
+                             const float *q, const int *idx, const float *Wp, const float *gamma,
+                             const float *beta, float eps, float momentum, float *running_mean,
+                             float *running_var, float *ymax, float *ymin, unsigned char *amax,
+                             unsigned char *amin, float *partial, float *sums, float *stat, float *z,
+                             void *stream);
+int pcm_sa_fused_backward_hip(int m, int n, int K, int H, int gf_is_bf16, const void *Gf,
+                              const float *p, const float *q, const int *idx, const float *Wp,
+                              const float *stat, const float *dz, const float *z, const float *ymax,
+                              const float *ymin, const unsigned char *amax, const unsigned char *amin,
+                              float *D, float *cnt, float *S, float *RM, float *partial, float *red1,
+                              float *red2, void *dGf, float *dWp, float *dgamma, float *dbeta,
+                              void *stream);
+
 /* ---- training-step tail: global-norm clip + AdamW over one flat fp32 buffer ---------------------
  * replaces the torch passes the reference runs per step: clip_grad_norm_ (configs/trainer/ddp.yaml:12)
  * and AdamW.step (src/models/maniskill2_act_bc_module.py:347-367).  p, g, m, v: n floats each,

@@ -85,13 +85,15 @@ def set_abstraction(owner, pointops, p, x, o, n_o, impl="reference", pre=None):
         torch.cuda.current_stream(p.device).wait_event(pre["event"])
     idx, n_p, knn_idx = pre["idx"], pre["n_p"], pre["knn_idx"]
     m, k = knn_idx.shape
+    if impl == "fused":
+        from .sa_fused import sa_fused_forward, supports
+
+        if supports(owner, x):
+            tokens = sa_fused_forward(owner, p, x, n_p, idx, knn_idx)
+            return n_p, tokens, idx
+        impl = "torch"  # eval mode / SyncBatchNorm / CPU: same maths through framework ops
     if x.dtype != torch.float32:
         x = x.float()  # pointops is fp32 (bf16 autocast applies to GEMM / attention only)
-    if impl == "fused":
-        from .sa_fused import sa_fused_forward
-
-        tokens = sa_fused_forward(owner, p, x, n_p, idx, knn_idx)
-        return n_p, tokens, idx
     grouped, _ = pointops.knn_query_and_group(x, p, offset=o, new_xyz=n_p, new_offset=n_o, idx=knn_idx,
                                               nsample=k, with_xyz=True)  # (m, K, 3+C)
     y = owner.linear(grouped)  # (m, K, H)

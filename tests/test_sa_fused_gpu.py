@@ -1,0 +1,91 @@
+"""GPU: the fused set-abstraction kernels against the reference-order composition (grouping ->
+Linear -> BatchNorm1d -> ReLU -> max) on the same inputs: tokens, running statistics and every
+gradient within 1e-4 relative (fp32 sums are re-associated; indices are shared and exact)."""
+import pytest
+import torch
+import torch.nn as nn
+
+from tests.util import make_clouds, new_offsets
+
+pytestmark = pytest.mark.gpu
+
+
+class Owner(nn.Module):
+    def __init__(self, c, h, k):
+        super().__init__()
+        self.linear = nn.Linear(3 + c, h, bias=False)
+        self.bn = nn.BatchNorm1d(h)
+        self.pool = nn.MaxPool1d(k)
+        self.relu = nn.ReLU(inplace=True)
+        self.pcd_nsample = k
+
+
+def _run(impl, owner, p, x, o, n_o, gout):
+    import pointcloudmatters_amd.pointops as po
+    from pointcloudmatters_amd.policy.sa_layer import set_abstraction
+
+    x = x.clone().requires_grad_(True)
+    owner.zero_grad()
+    n_p, tok, idx = set_abstraction(owner, po, p, x, o, n_o, impl=impl)
+    tok.backward(gout)
+    return tok.detach(), x.grad.detach(), {k: v.grad.detach().clone() for k, v in owner.named_parameters()}, \
+        owner.bn.running_mean.clone(), owner.bn.running_var.clone(), idx
+
+
+CASES = [
+    ([1024] * 4, [512] * 4, 64, 128, 16),
+    ([1024] * 2, [512] * 2, 512, 512, 16),     # ACT shape
+    ([700, 300, 20, 5], [64] * 4, 96, 96, 16),   # DP width (VEC 4, partial chunk), clouds smaller than K -> -1 slots
+    ([300], [100], 10, 30, 8),                  # H % 4 != 0 -> scalar path
+]
+
+
+@pytest.mark.parametrize("sizes,ms,c,h,k", CASES)
+def test_fused_matches_reference_order(hip_device, sizes, ms, c, h, k):
+    torch.manual_seed(0)
+    xyz, off = make_clouds(sizes, seed=3)
+    noff = new_offsets(ms)
+    p, o, n_o = xyz.to(hip_device), off.to(hip_device), noff.to(hip_device)
+    x = torch.randn(xyz.shape[0], c, device=hip_device)
+    ref_owner = Owner(c, h, k).to(hip_device).train()
+    with torch.no_grad():
+        ref_owner.bn.weight.uniform_(-1.0, 1.0)  # negative gammas exercise the min branch
+        ref_owner.bn.bias.uniform_(-0.5, 0.5)
+    fused_owner = Owner(c, h, k).to(hip_device).train()
+    fused_owner.load_state_dict(ref_owner.state_dict())
+    gout = torch.randn(sum(ms), h, device=hip_device)
+    t_r, gx_r, gp_r, rm_r, rv_r, idx_r = _run("reference", ref_owner, p, x, o, n_o, gout)
+    t_f, gx_f, gp_f, rm_f, rv_f, idx_f = _run("fused", fused_owner, p, x, o, n_o, gout)
+    assert torch.equal(idx_r, idx_f)
+
+    def close(a, b, name, tol=1e-4):
+        scale = b.abs().max().item() + 1e-12
+        assert (a - b).abs().max().item() <= tol * scale + 1e-6, (name, (a - b).abs().max().item(), scale)
+
+    close(t_f, t_r, "tokens")
+    close(rm_f, rm_r, "running_mean")
+    close(rv_f, rv_r, "running_var")
+    close(gx_f, gx_r, "grad_x", 2e-4)
+    for kname in gp_r:
+        close(gp_f[kname], gp_r[kname], kname, 2e-4)
+    assert fused_owner.bn.num_batches_tracked.item() == 1
+
+
+def test_fused_bf16_autocast_close_to_fp32(hip_device):
+    """Under bf16 autocast Gf is a bf16 GEMM output (as the reference's Linear would be); the xyz term
+    stays fp32.  Compare with the fp32 fused result at bf16 resolution."""
+    torch.manual_seed(1)
+    xyz, off = make_clouds([1024] * 2, seed=5)
+    noff = new_offsets([512] * 2)
+    p, o, n_o = xyz.to(hip_device), off.to(hip_device), noff.to(hip_device)
+    x = torch.randn(xyz.shape[0], 256, device=hip_device)
+    owner = Owner(256, 256, 16).to(hip_device).train()
+    other = Owner(256, 256, 16).to(hip_device).train()
+    other.load_state_dict(owner.state_dict())
+    gout = torch.randn(1024, 256, device=hip_device)
+    t32, gx32, gp32, *_ = _run("fused", owner, p, x, o, n_o, gout)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        t16, gx16, gp16, *_ = _run("fused", other, p, x, o, n_o, gout)
+    assert (t16.float() - t32).abs().max() <= 0.05 * t32.abs().max()
+    assert (gx16.float() - gx32).norm() <= 0.15 * gx32.norm()  # bf16 flips some arg-max choices
+    assert (gp16["linear.weight"] - gp32["linear.weight"]).norm() <= 0.15 * gp32["linear.weight"].norm()
