@@ -194,11 +194,13 @@ int pcm_sa_fused_backward_hip(int m, int n, int K, int H, int gf_is_bf16, const 
  *   pcm_grad_sumsq_hip  writes <= pcm_optim_partials_capacity() per-block sums of g^2 into
  *                       `partials` (fixed grid: deterministic) and their count into *npartials_out;
  *   pcm_adamw_flat_hip  reduces the partials, derives clip_coef = min(1, max_norm/(norm+1e-6)) and
- *                       applies torch.optim.AdamW's update; norm_out (optional) receives the norm. */
+ *                       applies torch.optim.AdamW's update; norm_out (optional) receives the norm;
+ *                       p_bf16 (optional, n bf16) receives a bf16 mirror of the updated weights. */
 int pcm_optim_partials_capacity(void);
 int pcm_grad_sumsq_hip(long n, const float *g, float *partials, int *npartials_out, void *stream);
 int pcm_adamw_flat_hip(long n, float *p, const float *g, float *m, float *v, const float *hyper,
-                       const float *partials, int npartials, float *norm_out, void *stream);
+                       const float *partials, int npartials, float *norm_out, void *p_bf16,
+                       void *stream);
 
 #ifdef __cplusplus
 }

@@ -60,6 +60,12 @@ class FlatAdamW:
                 p.data = view
                 p.grad = self.flat_g[o : o + p.numel()].view_as(p)
         self.offsets = offs
+        self.g_views = [p.grad for p in params]
+        # bf16 mirror of the weights (written by the Adam kernel) + gradient hand-off for shadowed params
+        self.flat_p_bf16 = None
+        self.shadow = [None] * len(params)
+        self._stash = [None] * len(params)
+        self.collect_mode = False
         self.hyper = torch.zeros(len(self.segments), self.H_COUNT, dtype=torch.float32, device=dev)
         self._hyper_host = torch.zeros(len(self.segments), self.H_COUNT, dtype=torch.float32).pin_memory()
         self.partials = torch.zeros(self.lib.pcm_optim_partials_capacity(), dtype=torch.float32, device=dev)
@@ -84,9 +90,49 @@ class FlatAdamW:
         self.last_lr = lr
         self.step_count += 1
 
+    # ---- bf16 weight mirror / gradient collection ("collect" mode) -------------------------------
+    def enable_bf16_mirror(self, shadowed):
+        """`shadowed`: set of parameter ids whose consumers run in bf16 (Linear / attention / conv
+        weights under autocast).  Their bf16 views are refreshed by the Adam kernel itself, so no
+        per-weight cast kernel runs in forward, and their bf16 gradients are handed over through
+        ``stash_grad`` and converted into the flat fp32 buffer by one multi-tensor copy."""
+        self.flat_p_bf16 = self.flat_p.to(torch.bfloat16)
+        for k, (p, o) in enumerate(zip(self.params, self.offsets)):
+            if id(p) in shadowed:
+                self.shadow[k] = self.flat_p_bf16[o : o + p.numel()].view_as(p)
+        self.collect_mode = True
+        for p in self.params:
+            p.grad = None
+
+    def stash_grad(self, k, g):
+        self._stash[k] = g if self._stash[k] is None else self._stash[k] + g
+
+    def collect(self, first):
+        """Move this micro-batch's gradients into the flat buffer: one multi-tensor copy (first
+        micro-batch of an accumulation window) or add per source dtype, instead of one accumulate
+        kernel per parameter."""
+        by_dtype = {}
+        for k, p in enumerate(self.params):
+            g = self._stash[k] if self.shadow[k] is not None else p.grad
+            if g is None:
+                if first:
+                    self.g_views[k].zero_()
+                continue
+            d, s_ = by_dtype.setdefault(g.dtype, ([], []))
+            d.append(self.g_views[k])
+            s_.append(g)
+            self._stash[k] = None
+            p.grad = None
+        for dsts, srcs in by_dtype.values():
+            if first:
+                torch._foreach_copy_(dsts, srcs)
+            else:
+                torch._foreach_add_(dsts, [s_.to(torch.float32) for s_ in srcs] if srcs[0].dtype != torch.float32 else srcs)
+
     # ---- device side (capturable) -----------------------------------------------------------------
     def zero_grad(self):
-        self.flat_g.zero_()
+        if not self.collect_mode:
+            self.flat_g.zero_()
 
     def launch_step(self):
         """Enqueue norm + AdamW on the current stream.  No host reads: safe inside graph capture."""
@@ -102,7 +148,8 @@ class FlatAdamW:
             rc = lib.pcm_adamw_flat_hip(count, self.flat_p.data_ptr() + o, self.flat_g.data_ptr() + o,
                                         self.exp_avg.data_ptr() + o, self.exp_avg_sq.data_ptr() + o,
                                         self.hyper.data_ptr() + gi * self.H_COUNT * 4, self.partials.data_ptr(), npart.value,
-                                        self.grad_norm.data_ptr(), st)
+                                        self.grad_norm.data_ptr(),
+                                        0 if self.flat_p_bf16 is None else self.flat_p_bf16.data_ptr() + start * 2, st)
             _lib.check(rc, "pcm_adamw_flat_hip")
 
     def step(self):

@@ -22,6 +22,36 @@ import torch.nn as nn
 from .configs import ACT_OPTIM
 
 
+class _ShadowParam(torch.autograd.Function):
+    """Forward: hand out the bf16 mirror of an fp32 master weight (no cast kernel).  Backward: pass
+    the bf16 gradient to the flat optimizer, which folds it into the fp32 gradient buffer."""
+
+    @staticmethod
+    def forward(ctx, master, shadow, opt, k):
+        ctx.opt, ctx.k = opt, k
+        return shadow.view_as(shadow)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.opt.stash_grad(ctx.k, g)
+        return None, None, None, None
+
+
+def bf16_consumed_parameters(policy):
+    """ids of the parameters that autocast would cast to bf16 on every use: weights / biases of Linear,
+    attention projections and 1-D convolutions.  The SA layer's own `linear` is excluded: its xyz
+    columns are consumed in fp32 by the fused kernel."""
+    ids = set()
+    for name, mod in policy.named_modules():
+        if isinstance(mod, (nn.Linear, nn.Conv1d, nn.ConvTranspose1d)):
+            if name.split(".")[-1] == "linear" and hasattr(policy.get_submodule(name.rsplit(".", 1)[0]) if "." in name else policy, "pcd_nsample"):
+                continue
+            ids.update(id(p) for p in mod.parameters(recurse=False))
+        elif isinstance(mod, nn.MultiheadAttention):
+            ids.update(id(p) for p in (mod.in_proj_weight, mod.in_proj_bias) if p is not None)
+    return ids
+
+
 def freeze_unused_parameters(policy):
     """``is_pad_head`` is evaluated (act.py:274) but never reaches the loss, so its
     parameters never receive a gradient -- AdamW skips them in the reference (grad is None) and plain
@@ -106,6 +136,12 @@ class BCTrainer:
             self.optimizer = FlatAdamW(params, sched, betas=betas, weight_decay=o["weight_decay"], max_norm=self.clip or 0.0,
                                        grad_scale=1.0 / self.world)
             self.scheduler = sched
+            self._shadow_names = None
+            if precision == "bf16" and hasattr(self.optimizer, "enable_bf16_mirror"):
+                self.optimizer.enable_bf16_mirror(bf16_consumed_parameters(self.policy))
+                index = {id(p): k for k, p in enumerate(self.optimizer.params)}
+                self._shadow_names = [(n, p, index[id(p)]) for n, p in self.policy.named_parameters()
+                                      if id(p) in index and self.optimizer.shadow[index[id(p)]] is not None]
         self.micro = 0
         self.optimizer_steps = 0
         self._sums = None
@@ -122,10 +158,18 @@ class BCTrainer:
         return contextlib.nullcontext()
 
     def _forward_backward(self, batch):
+        shadows = getattr(self, "_shadow_names", None)
         with self._autocast():
-            out = self.module(batch)
+            if shadows:
+                opt = self.optimizer
+                repl = {n: _ShadowParam.apply(p, opt.shadow[k], opt, k) for n, p, k in shadows}
+                out = torch.func.functional_call(self.policy, repl, (batch,))
+            else:
+                out = self.module(batch)
         loss = out["loss"]
         (loss / self.accumulate).backward()
+        if getattr(self.optimizer, "collect_mode", False):
+            self.optimizer.collect(first=self.micro % self.accumulate == 0)
         aux1 = out.get("action_loss", loss)
         aux2 = out.get("kl_loss", 0.0)
         return torch.stack([loss.detach().float(), aux1.detach().float(),

@@ -24,6 +24,8 @@
 //   p  -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
 #include "pcm_common.hpp"
 
+#include <hip/hip_bf16.h>
+
 namespace {
 
 constexpr int kBlock = 256;
@@ -77,7 +79,8 @@ __global__ __launch_bounds__(kBlock) void pcm_adamw_flat_kernel(long n4, long n,
                                                                 const float *__restrict__ g, float *__restrict__ m,
                                                                 float *__restrict__ v, const float *__restrict__ hyper,
                                                                 const float *__restrict__ partials, int npartials,
-                                                                float *__restrict__ norm_out)
+                                                                float *__restrict__ norm_out,
+                                                                __hip_bfloat16 *__restrict__ p_bf16)
 {
     __shared__ float red[kBlock / 64];
     const float lr = hyper[H_LR], b1 = hyper[H_BETA1], b2 = hyper[H_BETA2], eps = hyper[H_EPS], wd = hyper[H_WD];
@@ -107,10 +110,16 @@ __global__ __launch_bounds__(kBlock) void pcm_adamw_flat_kernel(long n4, long n,
         p4[i] = pp;
         m4[i] = mm;
         v4[i] = vv;
+        if (p_bf16) {  // bf16 mirror of the weights for the next step's GEMMs (no per-weight cast kernels)
+            __hip_bfloat16 o[4] = {__float2bfloat16(pp.x), __float2bfloat16(pp.y), __float2bfloat16(pp.z), __float2bfloat16(pp.w)};
+            *reinterpret_cast<uint2 *>(p_bf16 + i * 4) = *reinterpret_cast<const uint2 *>(o);
+        }
     }
     if (blockIdx.x == 0) {
-        for (long i = n4 * 4 + threadIdx.x; i < n; i += kBlock)
+        for (long i = n4 * 4 + threadIdx.x; i < n; i += kBlock) {
             adam_elem(p[i], g[i], m[i], v[i], lr, b1, b2, eps, wd, bc1, bc2s, gscale);
+            if (p_bf16) p_bf16[i] = __float2bfloat16(p[i]);
+        }
     }
 }
 
@@ -137,12 +146,12 @@ extern "C" int pcm_grad_sumsq_hip(long n, const float *g, float *partials, int *
 }
 
 extern "C" int pcm_adamw_flat_hip(long n, float *p, const float *g, float *m, float *v, const float *hyper,
-                                  const float *partials, int npartials, float *norm_out, void *stream)
+                                  const float *partials, int npartials, float *norm_out, void *p_bf16, void *stream)
 {
     if (n < 0 || npartials < 0 || npartials > kMaxPartials) return PCM_ERR_BAD_ARG;
     if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16) != 0) return PCM_ERR_BAD_ARG;
     const long n4 = n / 4;
     hipLaunchKernelGGL(pcm_adamw_flat_kernel, dim3(stream_grid(n4)), dim3(kBlock), 0, (hipStream_t)stream, n4, n, p, g, m, v,
-                       hyper, partials, npartials, norm_out);
+                       hyper, partials, npartials, norm_out, (__hip_bfloat16 *)p_bf16);
     return PCM_LAUNCH_STATUS();
 }

@@ -39,13 +39,18 @@ def attention(
     ``key_padding_mask`` (B, S) bool, True = ignore (nn.MultiheadAttention convention)."""
     e, h = mha.embed_dim, mha.num_heads
     w, b = mha.in_proj_weight, mha.in_proj_bias
+    # torch.split / unbind instead of slicing: their backward is ONE cat / stack kernel, whereas every
+    # slice's backward allocates a zero tensor of the full size and copies into it
     if query is key:
-        qk = F.linear(query, w[: 2 * e], b[: 2 * e])
-        q, k = qk[..., :e], qk[..., e:]
+        w_qk, w_v = torch.split(w, [2 * e, e], dim=0)
+        b_qk, b_v = torch.split(b, [2 * e, e], dim=0)
+        q, k = F.linear(query, w_qk, b_qk).unflatten(-1, (2, e)).unbind(-2)
     else:
-        q = F.linear(query, w[:e], b[:e])
-        k = F.linear(key, w[e : 2 * e], b[e : 2 * e])
-    v = F.linear(value, w[2 * e :], b[2 * e :])
+        w_q, w_k, w_v = torch.split(w, [e, e, e], dim=0)
+        b_q, b_k, b_v = torch.split(b, [e, e, e], dim=0)
+        q = F.linear(query, w_q, b_q)
+        k = F.linear(key, w_k, b_k)
+    v = F.linear(value, w_v, b_v)
     mask = None
     if key_padding_mask is not None:
         mask = (~key_padding_mask)[:, None, None, :]  # True = attend
