@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--mode", default="auto", help="auto | graph | flat | eager (eager = torch AdamW + DDP + SyncBN)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--kernels-only", action="store_true", help="only run the per-kernel timing leg (for rocprofv3 --pmc passes)")
     ap.add_argument("--cpu-steps", type=int, default=6)
     ap.add_argument("--cpu-threads", type=int, default=16)
     return ap.parse_args()
@@ -59,12 +60,17 @@ def timed_events(fn, iters, warmup=3):
 
 
 def kernel_rooflines(wl, device, c_feat=512, hidden=512):
-    """Time every hand-written hot-path kernel alone on this workload's shapes (HIP events on the
-    launch stream) and price it against its algorithmic HBM bytes (SURVEY.md 8d / DESIGN.md)."""
+    """Time every hand-written hot-path kernel ALONE on this workload's shapes (HIP events on the launch
+    stream = torch's current stream, which is the stream every pcm_* call is enqueued on) and price it
+    against its algorithmic HBM bytes.  Returns {kernel: {...}}."""
+    import ctypes
+
     import pointcloudmatters_amd.pointops as po
+    from pointcloudmatters_amd import _lib
     from pointcloudmatters_amd.bc import make_act_batch
     from pointcloudmatters_amd.pointops.query import knn_query_raw
 
+    L = _lib.load()
     b, n, m_per, k = wl["batch"], wl["n_points"], wl["pcd_npoints"], 16
     batch = make_act_batch(b, n, seed=4242, ragged=wl["ragged"], device=device)
     coord, off = batch["pcds"]["coord"], batch["pcds"]["offset"]
@@ -75,29 +81,113 @@ def kernel_rooflines(wl, device, c_feat=512, hidden=512):
     idx = po.farthest_point_sampling(coord, off, noff)
     n_p = coord[idx.long()].contiguous()
     knn_idx, _ = knn_query_raw(k, coord, off, n_p, noff)
-    feat = torch.randn(n_tot, c_feat, device=device).requires_grad_(True)
     res = {}
 
-    def add(name, ms, nbytes, note):
+    def add(name, ms, nbytes, bound, note):
         res[name] = {"ms": round(ms, 5), "algorithmic_bytes": int(nbytes), "achieved_GBs": round(nbytes / ms / 1e6, 3),
-                     "frac_of_hbm_peak": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 6), "note": note}
+                     "frac_of_hbm_peak": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 6), "bound": bound, "note": note}
 
-    add("fps", timed_events(lambda: po.farthest_point_sampling(coord, off, noff), 20), 12 * n_tot + 4 * m,
-        "serial-latency bound: %d dependent picks per cloud" % m_per)
-    add("knn", timed_events(lambda: knn_query_raw(k, coord, off, n_p, noff), 20), 12 * n_tot + 12 * m + 8 * m * k,
-        "ALU/LDS bound at this N: %.1f M distance evaluations" % (m * n / 1e6))
+    add("pcm_fps_reg_kernel", timed_events(lambda: po.farthest_point_sampling(coord, off, noff), 20), 12 * n_tot + 4 * m,
+        "latency", "%d dependent picks per cloud, one workgroup per cloud; off the critical path (side stream)" % m_per)
+    add("pcm_knn_fast_kernel(+exact)", timed_events(lambda: knn_query_raw(k, coord, off, n_p, noff), 20),
+        12 * n_tot + 12 * m + 8 * m * k, "alu", "%.1f M distance evaluations; side stream" % (m * n / 1e6))
+
+    # ---- fused set-abstraction layer, one kernel at a time (bf16 Gf as under autocast) ----------------
+    H = hidden
+    st = torch.cuda.current_stream().cuda_stream
+    f32 = dict(dtype=torch.float32, device=device)
+    gf = torch.randn(n_tot, H, **f32).to(torch.bfloat16)
+    wp, gamma, beta = torch.randn(H, 3, **f32) * 0.1, torch.rand(H, **f32) + 0.5, torch.zeros(H, **f32)
+    rm, rv = torch.zeros(H, **f32), torch.ones(H, **f32)
+    ymax, ymin = torch.empty(m, H, **f32), torch.empty(m, H, **f32)
+    amax = torch.empty(m, H, dtype=torch.uint8, device=device)
+    amin = torch.empty(m, H, dtype=torch.uint8, device=device)
+    slots = max(L.pcm_sa_fused_slots(m, H, 4), L.pcm_sa_fused_slots(n_tot, H, 4))
+    partial = torch.empty(slots * 5 * H, **f32)
+    sums, stat, z = torch.empty(2, H, **f32), torch.empty(4, H, **f32), torch.empty(m, H, **f32)
+    dz = torch.randn(m, H, **f32)
+    zeros = torch.zeros(n_tot * H + 4 * n_tot + 12, **f32)
+    D, cnt, S, RM = zeros[: n_tot * H], zeros[n_tot * H: n_tot * H + n_tot], zeros[n_tot * H + n_tot: n_tot * H + 4 * n_tot], zeros[n_tot * H + 4 * n_tot:]
+    red1, red2 = torch.empty(5, H, **f32), torch.empty(3, H, **f32)
+    dgf = torch.empty_like(gf)
+    dwp, dgamma, dbeta = torch.empty(H, 3, **f32), torch.empty(H, **f32), torch.empty(H, **f32)
+
+    def fwd(mask):
+        rc = L.pcm_sa_fused_forward_hip(m, k, H, 1, gf.data_ptr(), coord.data_ptr(), n_p.data_ptr(), knn_idx.data_ptr(),
+                                        wp.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.1, rm.data_ptr(), rv.data_ptr(),
+                                        ymax.data_ptr(), ymin.data_ptr(), amax.data_ptr(), amin.data_ptr(), partial.data_ptr(),
+                                        sums.data_ptr(), stat.data_ptr(), z.data_ptr(), mask, st)
+        assert rc == 0
+
+    def bwd(mask):
+        rc = L.pcm_sa_fused_backward_hip(m, n_tot, k, H, 1, gf.data_ptr(), coord.data_ptr(), n_p.data_ptr(), knn_idx.data_ptr(),
+                                         wp.data_ptr(), stat.data_ptr(), dz.data_ptr(), z.data_ptr(), ymax.data_ptr(), ymin.data_ptr(),
+                                         amax.data_ptr(), amin.data_ptr(), D.data_ptr(), cnt.data_ptr(), S.data_ptr(), RM.data_ptr(),
+                                         partial.data_ptr(), red1.data_ptr(), red2.data_ptr(), dgf.data_ptr(), dwp.data_ptr(),
+                                         dgamma.data_ptr(), dbeta.data_ptr(), mask, st)
+        assert rc == 0
+
+    fwd(0)
+    bwd(0)
     rows = m * k
+    add("pcm_sa_fwd_kernel<bf16,4>", timed_events(lambda: fwd(1), 30), n_tot * H * 2 + 4 * rows + 12 * n_tot + 12 * m + m * H * 10,
+        "hbm", "gather of %d rows x %d ch from the L2/MALL-resident Gf; algorithmic bytes count every Gf row once" % (rows, H))
+    add("pcm_sa_bwd1_kernel<4>", timed_events(lambda: bwd(2), 30), m * H * 18 + 4 * rows + m * H * 4,
+        "hbm", "m*H deltas: 18 B read each + one scattered fp32 atomic (fabric-transaction bound)")
+    add("pcm_sa_bwd2_kernel<bf16,4>", timed_events(lambda: bwd(8), 30), n_tot * H * (2 + 4 + 2) + 16 * n_tot, "hbm", "dense n*H pass")
+    add("pcm_sa_index_kernel", timed_events(lambda: bwd(1), 30), 4 * rows + 12 * n_tot + 12 * m + 16 * n_tot, "hbm", "index-only atomics")
+    add("pcm_sa_reduce_kernel", timed_events(lambda: bwd(4), 30), slots * 5 * H * 4, "hbm", "fp64 reduction of per-block partial rows")
+
+    # ---- optimizer tail on a flat buffer of the real parameter count ----------------------------------
+    n_par = 24_100_000 // 64 * 64
+    pbuf, gbuf = torch.randn(n_par, **f32), torch.randn(n_par, **f32) * 1e-3
+    mbuf, vbuf = torch.zeros(n_par, **f32), torch.zeros(n_par, **f32)
+    pb16 = torch.empty(n_par, dtype=torch.bfloat16, device=device)
+    hyper = torch.tensor([5e-5, 0.9, 0.999, 1e-8, 0.05, 0.1, 0.0316, 0.5, 1.0, 0.0], **f32)
+    parts = torch.zeros(L.pcm_optim_partials_capacity(), **f32)
+    npart = ctypes.c_int(0)
+    norm = torch.zeros(1, **f32)
+
+    def sumsq():
+        assert L.pcm_grad_sumsq_hip(n_par, gbuf.data_ptr(), parts.data_ptr(), ctypes.addressof(npart), st) == 0
+
+    def adam():
+        assert L.pcm_adamw_flat_hip(n_par, pbuf.data_ptr(), gbuf.data_ptr(), mbuf.data_ptr(), vbuf.data_ptr(), hyper.data_ptr(),
+                                    parts.data_ptr(), npart.value, norm.data_ptr(), pb16.data_ptr(), st) == 0
+
+    sumsq()
+    add("pcm_grad_sumsq_kernel", timed_events(sumsq, 30), 4 * n_par, "hbm", "24.1 M gradients, 4 B read each")
+    add("pcm_adamw_flat_kernel", timed_events(adam, 30), 30 * n_par, "hbm", "24.1 M parameters: 16 B read + 12 B fp32 + 2 B bf16 written each")
+
+    # ---- API kernels that materialise the grouped tensor (pointops.grouping; not on the fused path) ----
+    feat = torch.randn(n_tot, c_feat, device=device).requires_grad_(True)
     grouped = po.grouping(knn_idx, feat, coord, n_p, with_xyz=True)
     gbytes = 4 * rows + min(rows, n_tot) * (c_feat + 3) * 4 + 12 * m + rows * (c_feat + 3) * 4
-    add("group_fwd", timed_events(lambda: po.grouping(knn_idx, feat, coord, n_p, with_xyz=True), 20), gbytes, "HBM bound gather")
+    add("pcm_group_xyz_feat_fwd_kernel", timed_events(lambda: po.grouping(knn_idx, feat, coord, n_p, with_xyz=True), 20), gbytes,
+        "hbm", "API op (grouping()): writes the (m,K,3+C) tensor")
     gout = torch.randn_like(grouped)
 
-    def bwd():
+    def gbwd():
         feat.grad = None
         grouped.backward(gout, retain_graph=True)
 
-    add("group_bwd", timed_events(bwd, 20), rows * c_feat * 4 + 4 * rows + n_tot * c_feat * 4, "HBM bound atomic scatter")
+    add("pcm_group_xyz_feat_bwd_kernel", timed_events(gbwd, 20), rows * c_feat * 4 + 4 * rows + n_tot * c_feat * 4, "hbm",
+        "API op backward: coalesced fp32 atomics")
     return res
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json,
+    produced by tools/collect_profiles.sh with the FETCH_SIZE / WRITE_SIZE corrections of the guide), or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        table = json.load(f)
+    for name, rec in table.get("kernels", {}).items():
+        if name.split("<")[0] in kernel:
+            return rec.get("hbm_bytes_per_launch")
+    return None
 
 
 def cpu_baseline(wl, steps, threads=16):
@@ -141,6 +231,9 @@ def main():
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     wl = WORKLOADS[args.workload]
+    if args.kernels_only:
+        print(json.dumps({"kernels": kernel_rooflines(wl, device)}), flush=True)
+        return
     sa_impl = "fused" if args.sa_impl == "auto" else args.sa_impl
     torch.manual_seed(1000 + rank)
     policy = build_act_policy(pcd_npoints=wl["pcd_npoints"], sa_impl=sa_impl).to(device)
@@ -191,9 +284,11 @@ def main():
         }
         if not args.no_roofline:
             kr = kernel_rooflines(wl, device)
-            dom = max(kr, key=lambda k: kr[k]["ms"] if k.startswith("group") else -1.0)
+            # dominant = the longest-running hand-written HBM-bound kernel of the training step's critical path
+            on_path = [k for k in kr if kr[k]["bound"] == "hbm" and "group_xyz" not in k]
+            dom = max(on_path, key=lambda k: kr[k]["ms"])
             out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": kr[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": kr[dom]["frac_of_hbm_peak"], "traffic": None}
+                               "unit": "GB/s", "frac": kr[dom]["frac_of_hbm_peak"], "traffic": pmc_traffic(dom)}
             out["kernels"] = kr
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_steps, args.cpu_threads)

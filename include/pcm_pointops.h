@@ -169,21 +169,24 @@ int pcm_group_xyz_feat_backward_hip(int m, int nsample, int c, int with_xyz,
  *   forward : ymax,ymin (m,H) f32; amax,amin (m,H) u8; partial (slots,5,H); sums (2,H); stat (4,H) =
  *             {mean, invstd, a, b}; z (m,H) the tokens.  running_mean/var updated in place (or NULL).
  *   backward: D (n,H), cnt (n), S (n,3), RM (12) zeroed by the caller; red1 (5,H), red2 (3,H);
- *             outputs dGf (n,H) in Gf's dtype, dWp (H,3), dgamma (H), dbeta (H). */
+ *             outputs dGf (n,H) in Gf's dtype, dWp (H,3), dgamma (H), dbeta (H).
+ * stage_mask <= 0 runs every kernel of the call; a bit mask runs only the selected kernels (forward:
+ * 1 gather+stats, 2 reduce, 4 affine, 8 apply; backward: 1 index, 2 bwd1, 4 reduce, 8 bwd2, 16 reduce,
+ * 32 bwd3) -- used by bench.py to time one kernel at a time. */
 int pcm_sa_fused_slots(int units, int H, int vec);
 int pcm_sa_fused_forward_hip(int m, int K, int H, int gf_is_bf16, const void *Gf, const float *p,
                              const float *q, const int *idx, const float *Wp, const float *gamma,
                              const float *beta, float eps, float momentum, float *running_mean,
                              float *running_var, float *ymax, float *ymin, unsigned char *amax,
                              unsigned char *amin, float *partial, float *sums, float *stat, float *z,
-                             void *stream);
+                             int stage_mask, void *stream);
 int pcm_sa_fused_backward_hip(int m, int n, int K, int H, int gf_is_bf16, const void *Gf,
                               const float *p, const float *q, const int *idx, const float *Wp,
                               const float *stat, const float *dz, const float *z, const float *ymax,
                               const float *ymin, const unsigned char *amax, const unsigned char *amin,
                               float *D, float *cnt, float *S, float *RM, float *partial, float *red1,
                               float *red2, void *dGf, float *dWp, float *dgamma, float *dbeta,
-                              void *stream);
+                              int stage_mask, void *stream);
 
 /* ---- training-step tail: global-norm clip + AdamW over one flat fp32 buffer ---------------------
  * replaces the torch passes the reference runs per step: clip_grad_norm_ (configs/trainer/ddp.yaml:12)

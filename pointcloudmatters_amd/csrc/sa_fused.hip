@@ -443,16 +443,22 @@ extern "C" int pcm_sa_fused_forward_hip(int m, int K, int H, int gf_is_bf16, con
                                         const int *idx, const float *Wp, const float *gamma, const float *beta, float eps,
                                         float momentum, float *running_mean, float *running_var, float *ymax, float *ymin,
                                         unsigned char *amax, unsigned char *amin, float *partial, float *sums, float *stat,
-                                        float *z, void *stream)
+                                        float *z, int stage_mask, void *stream)
 {
+    // stage_mask: bit0 gather+stats, bit1 reduce, bit2 stats->affine, bit3 apply; <= 0 means all (used by
+    // bench.py to time each kernel alone with HIP events)
+    if (stage_mask <= 0) stage_mask = 0xF;
     if (m <= 0 || K <= 0 || K > kMaxK || H <= 0) return PCM_ERR_BAD_ARG;
     const int vec = (H % 4 == 0) ? 4 : 1;
     const int nchunk = (H + 64 * vec - 1) / (64 * vec);
     const int grid = waves_grid(m, nchunk);
     const int nslots = grid / nchunk;
 #define PCM_FWD(T, V)                                                                                                        \
-    hipLaunchKernelGGL((pcm_sa_fwd_kernel<T, V>), dim3(grid), dim3(kBlock), 0, PCM_SA_ST, m, K, H, nchunk, (const T *)Gf, p, q, \
-                       idx, Wp, ymax, ymin, amax, amin, partial)
+    do {                                                                                                                     \
+        if (stage_mask & 1)                                                                                                  \
+            hipLaunchKernelGGL((pcm_sa_fwd_kernel<T, V>), dim3(grid), dim3(kBlock), 0, PCM_SA_ST, m, K, H, nchunk,          \
+                               (const T *)Gf, p, q, idx, Wp, ymax, ymin, amax, amin, partial);                              \
+    } while (0)
     if (gf_is_bf16) {
         if (vec == 4) PCM_FWD(__hip_bfloat16, 4); else PCM_FWD(__hip_bfloat16, 1);
     } else {
@@ -461,13 +467,14 @@ extern "C" int pcm_sa_fused_forward_hip(int m, int K, int H, int gf_is_bf16, con
 #undef PCM_FWD
     int rc = PCM_LAUNCH_STATUS();
     if (rc) return rc;
-    hipLaunchKernelGGL(pcm_sa_reduce_kernel, dim3((2 * H + 63) / 64), dim3(64 * kRedWaves), 0, PCM_SA_ST, nslots, 2 * H, partial, sums);
-    hipLaunchKernelGGL(pcm_sa_stats_kernel, dim3((H + kBlock - 1) / kBlock), dim3(kBlock), 0, PCM_SA_ST, H, (double)m * K, eps,
+    if (stage_mask & 2)
+        hipLaunchKernelGGL(pcm_sa_reduce_kernel, dim3((2 * H + 63) / 64), dim3(64 * kRedWaves), 0, PCM_SA_ST, nslots, 2 * H, partial, sums);
+    if (stage_mask & 4) hipLaunchKernelGGL(pcm_sa_stats_kernel, dim3((H + kBlock - 1) / kBlock), dim3(kBlock), 0, PCM_SA_ST, H, (double)m * K, eps,
                        momentum, sums, gamma, beta, stat, running_mean, running_var);
     const long total = (long)m * H;
     long blocks = (total + kBlock - 1) / kBlock;
     if (blocks > 256L * 16) blocks = 256L * 16;
-    hipLaunchKernelGGL(pcm_sa_apply_kernel, dim3((int)blocks), dim3(kBlock), 0, PCM_SA_ST, total, H, ymax, ymin, stat, z);
+    if (stage_mask & 8) hipLaunchKernelGGL(pcm_sa_apply_kernel, dim3((int)blocks), dim3(kBlock), 0, PCM_SA_ST, total, H, ymax, ymin, stat, z);
     return PCM_LAUNCH_STATUS();
 }
 
@@ -476,8 +483,10 @@ extern "C" int pcm_sa_fused_backward_hip(int m, int n, int K, int H, int gf_is_b
                                          const float *z, const float *ymax, const float *ymin, const unsigned char *amax,
                                          const unsigned char *amin, float *D, float *cnt, float *S, float *RM, float *partial,
                                          float *red1, float *red2, void *dGf, float *dWp, float *dgamma, float *dbeta,
-                                         void *stream)
+                                         int stage_mask, void *stream)
 {
+    // stage_mask: bit0 index pass, bit1 bwd1, bit2 reduce1, bit3 bwd2, bit4 reduce2, bit5 bwd3; <= 0 means all
+    if (stage_mask <= 0) stage_mask = 0x3F;
     if (m <= 0 || n <= 0 || K <= 0 || K > kMaxK || H <= 0) return PCM_ERR_BAD_ARG;
     const int vec = (H % 4 == 0) ? 4 : 1;
     const int nchunk = (H + 64 * vec - 1) / (64 * vec);
@@ -486,33 +495,37 @@ extern "C" int pcm_sa_fused_backward_hip(int m, int n, int K, int H, int gf_is_b
     const long rows = (long)m * K;
     long iblocks = (rows + kBlock - 1) / kBlock;
     if (iblocks > 256) iblocks = 256;
-    hipLaunchKernelGGL(pcm_sa_index_kernel, dim3((int)iblocks), dim3(kBlock), 0, PCM_SA_ST, rows, K, p, q, idx, cnt, S, RM);
+    if (stage_mask & 1) hipLaunchKernelGGL(pcm_sa_index_kernel, dim3((int)iblocks), dim3(kBlock), 0, PCM_SA_ST, rows, K, p, q, idx, cnt, S, RM);
     {
         const int grid = waves_grid(m, nchunk);
         const int nslots = grid / nchunk;
-        if (vec == 4)
+        if (!(stage_mask & 2)) {
+        } else if (vec == 4)
             hipLaunchKernelGGL((pcm_sa_bwd1_kernel<4>), dim3(grid), dim3(kBlock), 0, PCM_SA_ST, m, K, H, nchunk, dz, z, ymax, ymin,
                                amax, amin, stat, p, q, idx, D, partial);
         else
             hipLaunchKernelGGL((pcm_sa_bwd1_kernel<1>), dim3(grid), dim3(kBlock), 0, PCM_SA_ST, m, K, H, nchunk, dz, z, ymax, ymin,
                                amax, amin, stat, p, q, idx, D, partial);
-        hipLaunchKernelGGL(pcm_sa_reduce_kernel, dim3((5 * H + 63) / 64), dim3(64 * kRedWaves), 0, PCM_SA_ST, nslots, 5 * H, partial, red1);
+        if (stage_mask & 4) hipLaunchKernelGGL(pcm_sa_reduce_kernel, dim3((5 * H + 63) / 64), dim3(64 * kRedWaves), 0, PCM_SA_ST, nslots, 5 * H, partial, red1);
     }
     {
         const int grid = waves_grid(n, nchunk);
         const int nslots = grid / nchunk;
 #define PCM_B2(T, V)                                                                                                         \
-    hipLaunchKernelGGL((pcm_sa_bwd2_kernel<T, V>), dim3(grid), dim3(kBlock), 0, PCM_SA_ST, n, H, nchunk, count, (const T *)Gf, D, \
-                       cnt, S, Wp, stat, red1, (T *)dGf, partial)
+    do {                                                                                                                     \
+        if (stage_mask & 8)                                                                                                  \
+            hipLaunchKernelGGL((pcm_sa_bwd2_kernel<T, V>), dim3(grid), dim3(kBlock), 0, PCM_SA_ST, n, H, nchunk, count,     \
+                               (const T *)Gf, D, cnt, S, Wp, stat, red1, (T *)dGf, partial);                                \
+    } while (0)
         if (gf_is_bf16) {
             if (vec == 4) PCM_B2(__hip_bfloat16, 4); else PCM_B2(__hip_bfloat16, 1);
         } else {
             if (vec == 4) PCM_B2(float, 4); else PCM_B2(float, 1);
         }
 #undef PCM_B2
-        hipLaunchKernelGGL(pcm_sa_reduce_kernel, dim3((3 * H + 63) / 64), dim3(64 * kRedWaves), 0, PCM_SA_ST, nslots, 3 * H, partial, red2);
+        if (stage_mask & 16) hipLaunchKernelGGL(pcm_sa_reduce_kernel, dim3((3 * H + 63) / 64), dim3(64 * kRedWaves), 0, PCM_SA_ST, nslots, 3 * H, partial, red2);
     }
-    hipLaunchKernelGGL(pcm_sa_bwd3_kernel, dim3((H + kBlock - 1) / kBlock), dim3(kBlock), 0, PCM_SA_ST, H, count, stat, red1, red2, RM,
+    if (stage_mask & 32) hipLaunchKernelGGL(pcm_sa_bwd3_kernel, dim3((H + kBlock - 1) / kBlock), dim3(kBlock), 0, PCM_SA_ST, H, count, stat, red1, red2, RM,
                        Wp, dWp, dgamma, dbeta);
     return PCM_LAUNCH_STATUS();
 }

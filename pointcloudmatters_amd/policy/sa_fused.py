@@ -43,7 +43,7 @@ class _SAFused(Function):
                 m, K, H, 1 if gf.dtype == torch.bfloat16 else 0, gf.data_ptr(), p.data_ptr(), q.data_ptr(), knn_idx.data_ptr(),
                 wp.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), float(momentum), _ptr(running_mean),
                 _ptr(running_var), ymax.data_ptr(), ymin.data_ptr(), amax.data_ptr(), amin.data_ptr(), partial.data_ptr(),
-                sums.data_ptr(), stat.data_ptr(), z.data_ptr(), st)
+                sums.data_ptr(), stat.data_ptr(), z.data_ptr(), 0, st)
         _lib.check(rc, "pcm_sa_fused_forward_hip")
         ctx.save_for_backward(gf, p, q, knn_idx, wp, stat, z, ymax, ymin, amax, amin)
         ctx.partial = partial
@@ -70,7 +70,7 @@ class _SAFused(Function):
                 m, n, K, H, 1 if gf.dtype == torch.bfloat16 else 0, gf.data_ptr(), p.data_ptr(), q.data_ptr(), knn_idx.data_ptr(),
                 wp.data_ptr(), stat.data_ptr(), dz.data_ptr(), z.data_ptr(), ymax.data_ptr(), ymin.data_ptr(), amax.data_ptr(),
                 amin.data_ptr(), D.data_ptr(), cnt.data_ptr(), S.data_ptr(), RM.data_ptr(), ctx.partial.data_ptr(),
-                red1.data_ptr(), red2.data_ptr(), dgf.data_ptr(), dwp.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), st)
+                red1.data_ptr(), red2.data_ptr(), dgf.data_ptr(), dwp.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), 0, st)
         _lib.check(rc, "pcm_sa_fused_backward_hip")
         return dgf, None, None, None, dwp, dgamma, dbeta, None, None, None, None
 
