@@ -92,3 +92,39 @@ def test_query_and_group_helpers(hip_device):
     assert torch.equal(gidx.cpu(), widx) and torch.equal(got.cpu(), want)
     assert torch.equal(po.offset2batch(off.to(d)).cpu(), ref.offset2batch(off))
     assert torch.equal(po.batch2offset(po.offset2batch(off.to(d))).cpu(), off)
+
+
+def test_pybind_surface_with_the_reference_wrapper_call_pattern(hip_device):
+    """pointops._C replacement: the 16 pybind names, called exactly like the reference wrappers do
+    (functions/sampling.py:14-23, query.py:17-23, grouping.py:16-18): caller-allocated outputs, tmp pre-filled."""
+    from oracle import pointops_cpu as ref
+    from pointcloudmatters_amd.pointops import _C
+    from tests.util import make_clouds, new_offsets
+
+    for name in ("knn_query_cuda", "ball_query_cuda", "random_ball_query_cuda", "farthest_point_sampling_cuda",
+                 "grouping_forward_cuda", "grouping_backward_cuda", "interpolation_forward_cuda", "interpolation_backward_cuda",
+                 "subtraction_forward_cuda", "subtraction_backward_cuda", "aggregation_forward_cuda", "aggregation_backward_cuda",
+                 "attention_relation_step_forward_cuda", "attention_relation_step_backward_cuda",
+                 "attention_fusion_step_forward_cuda", "attention_fusion_step_backward_cuda"):
+        assert callable(getattr(_C, name))  # pointops_api.cpp:16-31
+    xyz_c, off_c = make_clouds([900, 500], seed=2)
+    noff_c = new_offsets([256, 128])
+    xyz, offset, new_offset = xyz_c.to(hip_device), off_c.to(hip_device), noff_c.to(hip_device)
+    n, b, n_max = xyz.shape[0], offset.shape[0], 900
+    idx = torch.zeros(384, dtype=torch.int32, device=hip_device)
+    tmp = torch.full((n,), 1e10, dtype=torch.float32, device=hip_device)
+    _C.farthest_point_sampling_cuda(b, n_max, xyz, offset.int(), new_offset.int(), tmp, idx)
+    want = ref.farthest_point_sampling(xyz_c, off_c, noff_c)
+    assert torch.equal(idx.cpu(), want)
+    new_xyz = xyz[idx.long()].contiguous()
+    kidx = torch.zeros(384, 16, dtype=torch.int32, device=hip_device)
+    dist2 = torch.zeros(384, 16, dtype=torch.float32, device=hip_device)
+    _C.knn_query_cuda(384, 16, xyz, new_xyz, offset.int(), new_offset.int(), kidx, dist2)
+    wi, wd = ref.knn_query_raw(16, xyz_c, off_c, xyz_c[want.long()].contiguous(), noff_c)
+    assert torch.equal(kidx.cpu(), wi) and torch.equal(dist2.cpu(), wd)
+    feat = torch.randn(n, 24, device=hip_device)
+    out = torch.empty(384, 16, 24, device=hip_device)
+    _C.grouping_forward_cuda(384, 16, 24, feat, kidx, out)
+    assert torch.equal(out, feat[kidx.long()])
+    with pytest.raises(TypeError):
+        _C.knn_query_cuda(384, 16, xyz, new_xyz, offset.long(), new_offset.int(), kidx, dist2)  # int64 offsets, like data_ptr<int>()
