@@ -124,16 +124,18 @@ def kernel_rooflines(wl, device, c_feat=512, hidden=512):
                                          wp.data_ptr(), stat.data_ptr(), dz.data_ptr(), z.data_ptr(), ymax.data_ptr(), ymin.data_ptr(),
                                          amax.data_ptr(), amin.data_ptr(), D.data_ptr(), cnt.data_ptr(), S.data_ptr(), RM.data_ptr(),
                                          partial.data_ptr(), red1.data_ptr(), red2.data_ptr(), dgf.data_ptr(), dwp.data_ptr(),
-                                         dgamma.data_ptr(), dbeta.data_ptr(), mask, st)
+                                         dgamma.data_ptr(), dbeta.data_ptr(), o32.data_ptr(), noff.data_ptr(), b, max(sizes), mask, st)
         assert rc == 0
 
+    o32 = off.to(torch.int32)
+    sizes = [off._pcm_host[0]] + [off._pcm_host[i] - off._pcm_host[i - 1] for i in range(1, b)]
     fwd(0)
     bwd(0)
     rows = m * k
     add("pcm_sa_fwd_kernel<bf16,4>", timed_events(lambda: fwd(1), 30), n_tot * H * 2 + 4 * rows + 12 * n_tot + 12 * m + m * H * 10,
         "hbm", "gather of %d rows x %d ch from the L2/MALL-resident Gf; algorithmic bytes count every Gf row once" % (rows, H))
-    add("pcm_sa_bwd1_kernel<4>", timed_events(lambda: bwd(2), 30), m * H * 18 + 4 * rows + m * H * 4,
-        "hbm", "m*H deltas: 18 B read each + one scattered fp32 atomic (fabric-transaction bound)")
+    add("pcm_sa_bwd1_lds_kernel", timed_events(lambda: bwd(2), 30), m * H * 18 + 4 * rows + n_tot * H * 4,
+        "hbm", "m*H deltas (18 B read each) scattered with ds_add_f32 into an LDS tile per (cloud, channel chunk); D written once")
     add("pcm_sa_bwd2_kernel<bf16,4>", timed_events(lambda: bwd(8), 30), n_tot * H * (2 + 4 + 2) + 16 * n_tot, "hbm", "dense n*H pass")
     add("pcm_sa_index_kernel", timed_events(lambda: bwd(1), 30), 4 * rows + 12 * n_tot + 12 * m + 16 * n_tot, "hbm", "index-only atomics")
     add("pcm_sa_reduce_kernel", timed_events(lambda: bwd(4), 30), slots * 5 * H * 4, "hbm", "fp64 reduction of per-block partial rows")
@@ -217,7 +219,8 @@ def cpu_baseline(wl, steps, threads=16):
 
 def main():
     args = parse()
-    from pointcloudmatters_amd.bc import BCTrainer, WORKLOADS, build_act_policy, clone_batch, make_act_batch
+    from pointcloudmatters_amd.bc import (DP_OPTIM, BCTrainer, WORKLOADS, build_act_policy, build_dp_policy, clone_batch,
+                                          make_act_batch, make_dp_batch)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -236,13 +239,16 @@ def main():
         return
     sa_impl = "fused" if args.sa_impl == "auto" else args.sa_impl
     torch.manual_seed(1000 + rank)
-    policy = build_act_policy(pcd_npoints=wl["pcd_npoints"], sa_impl=sa_impl).to(device)
+    is_dp = wl["policy"] == "dp"
+    build = build_dp_policy if is_dp else build_act_policy
+    make_batch = make_dp_batch if is_dp else make_act_batch
+    policy = build(pcd_npoints=wl["pcd_npoints"], sa_impl=sa_impl).to(device)
     mode = args.mode
     if mode == "auto":  # hipGraph replay needs static shapes; ragged workloads use the flat optimizer eagerly
         mode = "flat" if wl["ragged"] else "graph"
     trainer = BCTrainer(policy, total_steps=max(args.steps + args.warmup, 100), precision=wl["dtype"], device=device,
-                        distributed=world > 1, optim=dict(accumulate_grad_batches=1), mode=mode)
-    batches = [make_act_batch(wl["batch"], wl["n_points"], seed=1000 + rank + 97 * i, ragged=wl["ragged"], device=device)
+                        distributed=world > 1, optim=dict(DP_OPTIM) if is_dp else dict(accumulate_grad_batches=1), mode=mode)
+    batches = [make_batch(wl["batch"], wl["n_points"], seed=1000 + rank + 97 * i, ragged=wl["ragged"], device=device)
                for i in range(4)]
 
     def step(i):
@@ -269,13 +275,14 @@ def main():
     if rank == 0:
         samples = wl["batch"] * world * args.steps
         out = {
-            "metric": "BC train samples/sec (obs->action), PointNet + SA tokenizer + ACT",
+            "metric": "BC train samples/sec (obs->action), PointNet + SA tokenizer + " + ("DiffusionPolicy" if is_dp else "ACT"),
             "value": round(samples / dt, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": wl["dtype"], "data": "synthetic",
             "config": {"workload": "%s: ManiSkill2-PickCube-shaped batch, B=%d clouds x %d pts per GPU -> %d tokens, K=16, "
-                                   "PointNet(6->512) + SA(515->512) + ACT(4 enc / 7 dec, d=512, 100 queries)"
-                                   % (args.workload, wl["batch"], wl["n_points"], wl["pcd_npoints"]),
+                                   "%s" % (args.workload, wl["batch"] * (2 if is_dp else 1), wl["n_points"], wl["pcd_npoints"],
+                                           "PointNet(6->512->96) + SA(99->96) + projector + U-Net(512/1024/2048, k=5) DDPM-100" if is_dp
+                                           else "PointNet(6->512) + SA(515->512) + ACT(4 enc / 7 dec, d=512, 100 queries)"),
                        "global_batch": wl["batch"] * world, "points_per_cloud": wl["n_points"],
                        "tokens_per_cloud": wl["pcd_npoints"], "parallelism": "dp%d" % world, "sa_impl": sa_impl, "step_mode": mode,
                        "batchnorm": "sync" if trainer.sync_batchnorm else "per-rank",
@@ -290,7 +297,7 @@ def main():
             out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": kr[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": kr[dom]["frac_of_hbm_peak"], "traffic": pmc_traffic(dom)}
             out["kernels"] = kr
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not is_dp:
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_steps, args.cpu_threads)
         print(json.dumps(out), flush=True)
     if world > 1:

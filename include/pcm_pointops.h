@@ -170,10 +170,14 @@ int pcm_group_xyz_feat_backward_hip(int m, int nsample, int c, int with_xyz,
  *             {mean, invstd, a, b}; z (m,H) the tokens.  running_mean/var updated in place (or NULL).
  *   backward: D (n,H), cnt (n), S (n,3), RM (12) zeroed by the caller; red1 (5,H), red2 (3,H);
  *             outputs dGf (n,H) in Gf's dtype, dWp (H,3), dgamma (H), dbeta (H).
+ * offset / new_offset (b) + n_max (largest cloud) select the LDS-staged scatter (one workgroup per cloud
+ * and channel chunk, ds_add_f32, no global atomics, D need not be zeroed); pass NULL / b = 0 for the
+ * global-atomic fallback (D zeroed by the caller).
  * stage_mask <= 0 runs every kernel of the call; a bit mask runs only the selected kernels (forward:
  * 1 gather+stats, 2 reduce, 4 affine, 8 apply; backward: 1 index, 2 bwd1, 4 reduce, 8 bwd2, 16 reduce,
  * 32 bwd3) -- used by bench.py to time one kernel at a time. */
 int pcm_sa_fused_slots(int units, int H, int vec);
+int pcm_sa_fused_bwd1_lds_channels(int H, int n_max);
 int pcm_sa_fused_forward_hip(int m, int K, int H, int gf_is_bf16, const void *Gf, const float *p,
                              const float *q, const int *idx, const float *Wp, const float *gamma,
                              const float *beta, float eps, float momentum, float *running_mean,
@@ -186,6 +190,7 @@ int pcm_sa_fused_backward_hip(int m, int n, int K, int H, int gf_is_bf16, const 
                               const float *ymin, const unsigned char *amax, const unsigned char *amin,
                               float *D, float *cnt, float *S, float *RM, float *partial, float *red1,
                               float *red2, void *dGf, float *dWp, float *dgamma, float *dbeta,
+                              const int *offset, const int *new_offset, int b, int n_max,
                               int stage_mask, void *stream);
 
 /* ---- training-step tail: global-norm clip + AdamW over one flat fp32 buffer ---------------------

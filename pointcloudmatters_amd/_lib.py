@@ -37,9 +37,10 @@ SIGNATURES = {
     "pcm_group_xyz_feat_forward_hip": [_i, _i, _i, _P, _P, _P, _P, _P, _P],
     "pcm_group_xyz_feat_backward_hip": [_i, _i, _i, _i, _P, _P, _P, _P],
     "pcm_sa_fused_slots": [_i, _i, _i],
+    "pcm_sa_fused_bwd1_lds_channels": [_i, _i],
     "pcm_sa_fused_forward_hip": [_i, _i, _i, _i, _P, _P, _P, _P, _P, _P, _P, _f, _f, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _i, _P],
     "pcm_sa_fused_backward_hip": [_i, _i, _i, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
-                                  _P, _P, _P, _P, _P, _P, _i, _P],
+                                  _P, _P, _P, _P, _P, _P, _P, _P, _i, _i, _i, _P],
     "pcm_optim_partials_capacity": [],
     "pcm_grad_sumsq_hip": [ctypes.c_long, _P, _P, _P, _P],
     "pcm_adamw_flat_hip": [ctypes.c_long, _P, _P, _P, _P, _P, _P, _i, _P, _P, _P],

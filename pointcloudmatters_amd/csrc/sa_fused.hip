@@ -350,6 +350,91 @@ __global__ __launch_bounds__(kBlock) void pcm_sa_bwd1_kernel(int m, int K, int H
     block_combine_store<5, VEC>(vals, partial, slot, H, c0, act, lds);
 }
 
+
+// backward pass 1, LDS-staged variant: one workgroup per (cloud, chunk of CH channels).  The D rows of
+// one cloud restricted to CH channels (N_c x CH floats <= 96 KiB) live in LDS, the m*H deltas are added
+// with ds_add_f32 (no global atomics, no memset of D, coalesced write-out), and the per-channel sums
+// { dbeta, dgamma, E0..2 } leave as ONE partial row per cloud.  partial layout [cloud][5][H].
+template <int CH>
+__global__ __launch_bounds__(kBlock) void pcm_sa_bwd1_lds_kernel(int K, int H, const float *__restrict__ dz,
+                                                                 const float *__restrict__ z, const float *__restrict__ ymax,
+                                                                 const float *__restrict__ ymin, const uint8_t *__restrict__ amax,
+                                                                 const uint8_t *__restrict__ amin, const float *__restrict__ stat,
+                                                                 const float *__restrict__ p, const float *__restrict__ q,
+                                                                 const int *__restrict__ idx, const int *__restrict__ offset,
+                                                                 const int *__restrict__ new_offset, float *__restrict__ D,
+                                                                 float *__restrict__ partial)
+{
+    extern __shared__ __attribute__((aligned(16))) float tile[];  // [N_c][CH] then [kBlock/LPQ][5][CH] scratch
+    constexpr int LPQ = CH / 4;        // lanes per query (4 channels per lane)
+    constexpr int QPB = kBlock / LPQ;  // queries per block pass
+    const int nchunks = H / CH;
+    const int cloud = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks;
+    const int start_n = cloud == 0 ? 0 : offset[cloud - 1], end_n = offset[cloud];
+    const int start_m = cloud == 0 ? 0 : new_offset[cloud - 1], end_m = new_offset[cloud];
+    const int N = end_n - start_n;
+    const int c0 = chunk * CH + (threadIdx.x % LPQ) * 4;  // this lane's 4 channels
+    const int lc = (threadIdx.x % LPQ) * 4;               // ... inside the chunk
+    for (int e = threadIdx.x; e < N * CH; e += kBlock) tile[e] = 0.f;
+    float mean[4], invstd[4], a[4], acc[4][5];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        mean[v] = stat[c0 + v], invstd[v] = stat[H + c0 + v], a[v] = stat[2 * H + c0 + v];
+#pragma unroll
+        for (int t = 0; t < 5; ++t) acc[v][t] = 0.f;
+    }
+    __syncthreads();
+    for (int i = start_m + threadIdx.x / LPQ; i < end_m; i += QPB) {
+        const size_t o0 = (size_t)i * H + c0;
+        const float4 zz = *reinterpret_cast<const float4 *>(z + o0), dd = *reinterpret_cast<const float4 *>(dz + o0);
+        const float4 mx = *reinterpret_cast<const float4 *>(ymax + o0), mn = *reinterpret_cast<const float4 *>(ymin + o0);
+        const uint32_t ua = *reinterpret_cast<const uint32_t *>(amax + o0), ub = *reinterpret_cast<const uint32_t *>(amin + o0);
+        const float zv[4] = {zz.x, zz.y, zz.z, zz.w}, dv[4] = {dd.x, dd.y, dd.z, dd.w};
+        const float xv[4] = {mx.x, mx.y, mx.z, mx.w}, nv[4] = {mn.x, mn.y, mn.z, mn.w};
+        const float qx = q[(size_t)i * 3 + 0], qy = q[(size_t)i * 3 + 1], qz = q[(size_t)i * 3 + 2];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float delta = zv[v] > 0.f ? dv[v] : 0.f;
+            if (delta == 0.f) continue;
+            const bool pos = a[v] >= 0.f;
+            const float sel = pos ? xv[v] : nv[v];
+            const int s = (int)(((pos ? ua : ub) >> (8 * v)) & 0xFF);
+            const int j = idx[(size_t)i * K + s];
+            acc[v][0] += delta;
+            acc[v][1] += delta * ((sel - mean[v]) * invstd[v]);
+            if (j >= 0) {
+                acc[v][2] += delta * (p[(size_t)j * 3 + 0] - qx);
+                acc[v][3] += delta * (p[(size_t)j * 3 + 1] - qy);
+                acc[v][4] += delta * (p[(size_t)j * 3 + 2] - qz);
+                atomicAdd(&tile[(j - start_n) * CH + lc + v], delta);  // ds_add_f32
+            }
+        }
+    }
+    __syncthreads();
+    // coalesced write-out of the cloud's D rows for this chunk (every element written: no memset needed)
+    for (int e = threadIdx.x; e < N * (CH / 4); e += kBlock) {
+        const int row = e / (CH / 4), c4 = (e % (CH / 4)) * 4;
+        *reinterpret_cast<float4 *>(D + (size_t)(start_n + row) * H + chunk * CH + c4) =
+            *reinterpret_cast<const float4 *>(tile + row * CH + c4);
+    }
+    __syncthreads();
+    // per-channel sums: QPB threads share each channel group -> LDS tree over the tile memory (N*CH >= ... not
+    // guaranteed), so use a dedicated scratch region after the tile
+    float *scr = tile + (size_t)N * CH;  // [QPB][LPQ*4*5] floats, sized by the launcher
+    const int qslot = threadIdx.x / LPQ;
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int t = 0; t < 5; ++t) scr[(qslot * 5 + t) * CH + lc + v] = acc[v][t];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 5 * CH; e += kBlock) {
+        const int t = e / CH, ch = e % CH;
+        float sum = 0.f;
+        for (int w = 0; w < QPB; ++w) sum += scr[(w * 5 + t) * CH + ch];
+        partial[((size_t)cloud * 5 + t) * H + chunk * CH + ch] = sum;
+    }
+}
+
 // backward pass 2 over (n,H): dGf, partial[slot][3][H] = T[c][h] = sum_j S_j[c] (Gf[j,h] - mean_h)
 // red1[5][H] = reduced { dbeta, dgamma, E0..2 }
 template <typename T, int VEC>
@@ -437,6 +522,15 @@ extern "C" int pcm_sa_fused_slots(int units, int H, int vec)
     return waves_grid(units, nchunk) / nchunk;
 }
 
+// channels per workgroup of the LDS-staged bwd1 (0: does not fit / not applicable -> global-atomic kernel)
+extern "C" int pcm_sa_fused_bwd1_lds_channels(int H, int n_max)
+{
+    if (H % 4 != 0 || n_max <= 0) return 0;
+    for (int c : {32, 16, 8, 4})
+        if (H % c == 0 && (size_t)n_max * c * 4 + (size_t)(kBlock / (c / 4)) * 5 * c * 4 <= 128 * 1024) return c;
+    return 0;
+}
+
 #define PCM_SA_ST ((hipStream_t)stream)
 
 extern "C" int pcm_sa_fused_forward_hip(int m, int K, int H, int gf_is_bf16, const void *Gf, const float *p, const float *q,
@@ -483,7 +577,8 @@ extern "C" int pcm_sa_fused_backward_hip(int m, int n, int K, int H, int gf_is_b
                                          const float *z, const float *ymax, const float *ymin, const unsigned char *amax,
                                          const unsigned char *amin, float *D, float *cnt, float *S, float *RM, float *partial,
                                          float *red1, float *red2, void *dGf, float *dWp, float *dgamma, float *dbeta,
-                                         int stage_mask, void *stream)
+                                         const int *offset, const int *new_offset, int b, int n_max, int stage_mask,
+                                         void *stream)
 {
     // stage_mask: bit0 index pass, bit1 bwd1, bit2 reduce1, bit3 bwd2, bit4 reduce2, bit5 bwd3; <= 0 means all
     if (stage_mask <= 0) stage_mask = 0x3F;
@@ -491,21 +586,40 @@ extern "C" int pcm_sa_fused_backward_hip(int m, int n, int K, int H, int gf_is_b
     const int vec = (H % 4 == 0) ? 4 : 1;
     const int nchunk = (H + 64 * vec - 1) / (64 * vec);
     const double count = (double)m * K;
-    // D, cnt, S, RM must be zero on entry (caller memsets them on the same stream)
+    // cnt, S, RM must be zero on entry; D too unless the LDS-staged bwd1 is taken (it writes every element)
     const long rows = (long)m * K;
     long iblocks = (rows + kBlock - 1) / kBlock;
     if (iblocks > 256) iblocks = 256;
     if (stage_mask & 1) hipLaunchKernelGGL(pcm_sa_index_kernel, dim3((int)iblocks), dim3(kBlock), 0, PCM_SA_ST, rows, K, p, q, idx, cnt, S, RM);
     {
-        const int grid = waves_grid(m, nchunk);
-        const int nslots = grid / nchunk;
-        if (!(stage_mask & 2)) {
-        } else if (vec == 4)
-            hipLaunchKernelGGL((pcm_sa_bwd1_kernel<4>), dim3(grid), dim3(kBlock), 0, PCM_SA_ST, m, K, H, nchunk, dz, z, ymax, ymin,
-                               amax, amin, stat, p, q, idx, D, partial);
-        else
-            hipLaunchKernelGGL((pcm_sa_bwd1_kernel<1>), dim3(grid), dim3(kBlock), 0, PCM_SA_ST, m, K, H, nchunk, dz, z, ymax, ymin,
-                               amax, amin, stat, p, q, idx, D, partial);
+        // LDS-staged variant when the cloud layout is known and a cloud's D rows for >= 4 channels fit in LDS
+        const int CH = (b > 0 && offset && new_offset) ? pcm_sa_fused_bwd1_lds_channels(H, n_max) : 0;
+        int nslots;
+        if (CH) {
+            nslots = b;
+            const size_t lds = (size_t)n_max * CH * 4 + (size_t)(kBlock / (CH / 4)) * 5 * CH * 4;
+            const int grid = b * (H / CH);
+#define PCM_B1L(C)                                                                                                            \
+    do {                                                                                                                     \
+        auto kfn = pcm_sa_bwd1_lds_kernel<C>;                                                                                 \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (stage_mask & 2)                                                                                                  \
+            hipLaunchKernelGGL(kfn, dim3(grid), dim3(kBlock), lds, PCM_SA_ST, K, H, dz, z, ymax, ymin, amax, amin, stat, p, q, \
+                               idx, offset, new_offset, D, partial);                                                          \
+    } while (0)
+            if (CH == 32) PCM_B1L(32); else if (CH == 16) PCM_B1L(16); else if (CH == 8) PCM_B1L(8); else PCM_B1L(4);
+#undef PCM_B1L
+        } else {
+            const int grid = waves_grid(m, nchunk);
+            nslots = grid / nchunk;
+            if (!(stage_mask & 2)) {
+            } else if (vec == 4)
+                hipLaunchKernelGGL((pcm_sa_bwd1_kernel<4>), dim3(grid), dim3(kBlock), 0, PCM_SA_ST, m, K, H, nchunk, dz, z, ymax, ymin,
+                                   amax, amin, stat, p, q, idx, D, partial);
+            else
+                hipLaunchKernelGGL((pcm_sa_bwd1_kernel<1>), dim3(grid), dim3(kBlock), 0, PCM_SA_ST, m, K, H, nchunk, dz, z, ymax, ymin,
+                                   amax, amin, stat, p, q, idx, D, partial);
+        }
         if (stage_mask & 4) hipLaunchKernelGGL(pcm_sa_reduce_kernel, dim3((5 * H + 63) / 64), dim3(64 * kRedWaves), 0, PCM_SA_ST, nslots, 5 * H, partial, red1);
     }
     {

@@ -21,14 +21,14 @@ def _ptr(t):
 
 class _SAFused(Function):
     @staticmethod
-    def forward(ctx, gf, p, q, knn_idx, wp, gamma, beta, running_mean, running_var, eps, momentum):
+    def forward(ctx, gf, p, q, knn_idx, wp, gamma, beta, running_mean, running_var, eps, momentum, o32, no32, n_max):
         L = _lib.load()
         assert gf.is_cuda and gf.is_contiguous() and gf.dtype in (torch.float32, torch.bfloat16)
         n, H = gf.shape
         m, K = knn_idx.shape
         dev = gf.device
         vec = 4 if H % 4 == 0 else 1
-        slots = max(L.pcm_sa_fused_slots(m, H, vec), L.pcm_sa_fused_slots(n, H, vec))
+        slots = max(L.pcm_sa_fused_slots(m, H, vec), L.pcm_sa_fused_slots(n, H, vec), int(o32.shape[0]) if o32 is not None else 0)
         st = torch.cuda.current_stream().cuda_stream
         with torch.cuda.device(dev):
             f32 = dict(dtype=torch.float32, device=dev)
@@ -47,6 +47,7 @@ class _SAFused(Function):
         _lib.check(rc, "pcm_sa_fused_forward_hip")
         ctx.save_for_backward(gf, p, q, knn_idx, wp, stat, z, ymax, ymin, amax, amin)
         ctx.partial = partial
+        ctx.layout = (o32, no32, int(n_max))
         ctx.mark_non_differentiable(stat)
         return z, stat
 
@@ -61,8 +62,16 @@ class _SAFused(Function):
         dz = dz.contiguous().float()
         with torch.cuda.device(dev):
             f32 = dict(dtype=torch.float32, device=dev)
-            zeros = torch.zeros(n * H + n + n * 3 + 12, **f32)  # D | cnt | S | RM in one memset
-            D, cnt, S, RM = zeros[: n * H], zeros[n * H : n * H + n], zeros[n * H + n : n * H + 4 * n], zeros[n * H + 4 * n :]
+            o32, no32, n_max = ctx.layout
+            b = int(o32.shape[0]) if o32 is not None else 0
+            lds_path = b > 0 and L.pcm_sa_fused_bwd1_lds_channels(H, n_max) > 0
+            if lds_path:  # the LDS-staged scatter writes every element of D itself
+                D = torch.empty(n * H, **f32)
+                zeros = torch.zeros(4 * n + 12, **f32)
+                cnt, S, RM = zeros[:n], zeros[n : 4 * n], zeros[4 * n :]
+            else:
+                zeros = torch.zeros(n * H + 4 * n + 12, **f32)  # D | cnt | S | RM in one memset
+                D, cnt, S, RM = zeros[: n * H], zeros[n * H : n * H + n], zeros[n * H + n : n * H + 4 * n], zeros[n * H + 4 * n :]
             red1, red2 = torch.empty(5, H, **f32), torch.empty(3, H, **f32)
             dgf = torch.empty_like(gf)
             dwp, dgamma, dbeta = torch.empty(H, 3, **f32), torch.empty(H, **f32), torch.empty(H, **f32)
@@ -70,9 +79,10 @@ class _SAFused(Function):
                 m, n, K, H, 1 if gf.dtype == torch.bfloat16 else 0, gf.data_ptr(), p.data_ptr(), q.data_ptr(), knn_idx.data_ptr(),
                 wp.data_ptr(), stat.data_ptr(), dz.data_ptr(), z.data_ptr(), ymax.data_ptr(), ymin.data_ptr(), amax.data_ptr(),
                 amin.data_ptr(), D.data_ptr(), cnt.data_ptr(), S.data_ptr(), RM.data_ptr(), ctx.partial.data_ptr(),
-                red1.data_ptr(), red2.data_ptr(), dgf.data_ptr(), dwp.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), 0, st)
+                red1.data_ptr(), red2.data_ptr(), dgf.data_ptr(), dwp.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                _ptr(o32) if lds_path else 0, _ptr(no32) if lds_path else 0, b if lds_path else 0, n_max, 0, st)
         _lib.check(rc, "pcm_sa_fused_backward_hip")
-        return dgf, None, None, None, dwp, dgamma, dbeta, None, None, None, None
+        return dgf, None, None, None, dwp, dgamma, dbeta, None, None, None, None, None, None, None
 
 
 def supports(owner, x):
@@ -81,15 +91,23 @@ def supports(owner, x):
             and bn.momentum is not None and bn.affine)
 
 
-def sa_fused_forward(owner, p, x, n_p, fps_idx, knn_idx):
-    """tokens (m, H) of the SA layer owned by `owner` (linear, bn) for features x (n, C)."""
+def sa_fused_forward(owner, p, x, n_p, fps_idx, knn_idx, o=None, n_o=None):
+    """tokens (m, H) of the SA layer owned by `owner` (linear, bn) for features x (n, C).  `o` / `n_o`
+    (cumulative offsets of points / queries per cloud) enable the LDS-staged backward scatter."""
+    from ..pointops import _common as C
+
+    o32 = no32 = None
+    n_max = 0
+    if o is not None and n_o is not None:
+        o32, no32 = C.i32c(o), C.i32c(n_o)
+        n_max = max(C.counts_from_offsets(C.host_offsets(o)))
     w = owner.linear.weight  # (H, 3 + C): xyz columns first (grouping.py:57 concatenates xyz before feat)
     gf = F.linear(x, w[:, 3:])  # (n, H); bf16 under autocast, fp32 otherwise
     if gf.dtype not in (torch.float32, torch.bfloat16):
         gf = gf.float()
     bn = owner.bn
     z, _ = _SAFused.apply(gf.contiguous(), p, n_p, knn_idx, w[:, :3], bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                          bn.eps, bn.momentum)
+                          bn.eps, bn.momentum, o32, no32, n_max)
     with torch.no_grad():
         bn.num_batches_tracked.add_(1)
     return z

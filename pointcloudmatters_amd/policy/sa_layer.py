@@ -89,7 +89,7 @@ def set_abstraction(owner, pointops, p, x, o, n_o, impl="reference", pre=None):
         from .sa_fused import sa_fused_forward, supports
 
         if supports(owner, x):
-            tokens = sa_fused_forward(owner, p, x, n_p, idx, knn_idx)
+            tokens = sa_fused_forward(owner, p, x, n_p, idx, knn_idx, o, n_o)
             return n_p, tokens, idx
         impl = "torch"  # eval mode / SyncBatchNorm / CPU: same maths through framework ops
     if x.dtype != torch.float32:
