@@ -253,8 +253,28 @@ class ACTPCD(nn.Module):
         return data_dict
 
     def forward(self, data_dict):
-        data_dict = self.forward_encoder(data_dict)
-        data_dict = self.forward_obs_embed(data_dict)
+        # The CVAE encoder (102 tokens) and the point-cloud tokenizer are independent until the decoder:
+        # on the GPU the former runs on a forked HIP stream (its backward follows on the same stream), so
+        # its ~200 small kernels fill the gaps of the PointNet / set-abstraction branch.
+        fork = self.overlap_sampling and data_dict["qpos"].is_cuda
+        if fork:
+            main = torch.cuda.current_stream(data_dict["qpos"].device)
+            side = self.__dict__.get("_cvae_stream")
+            if side is None:
+                side = self.__dict__["_cvae_stream"] = torch.cuda.Stream(device=data_dict["qpos"].device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                data_dict = self.forward_encoder(data_dict)
+            latent = data_dict["latent_input"]
+            data_dict = self.forward_obs_embed(data_dict)
+            main.wait_stream(side)
+            if not torch.cuda.is_current_stream_capturing():
+                for t in (latent, data_dict["mu"], data_dict["logvar"]):
+                    if t is not None:
+                        t.record_stream(main)
+        else:
+            data_dict = self.forward_encoder(data_dict)
+            data_dict = self.forward_obs_embed(data_dict)
         data_dict = self.forward_decoder(data_dict)
         if not data_dict["is_training"]:
             return data_dict

@@ -27,30 +27,45 @@ def _split_heads(x: Tensor, nhead: int) -> Tensor:
     return x.view(b, l, nhead, e // nhead).transpose(1, 2)  # (B, H, L, hd)
 
 
+def _residual(x: Tensor, y: Tensor) -> Tensor:
+    """x + y with the sub-layer output brought to the residual stream's dtype first: the mixed-dtype
+    (fp32 + bf16) elementwise kernel runs at <1 TB/s, a cast followed by a same-dtype add at ~5 TB/s."""
+    return x + (y if y.dtype == x.dtype else y.to(x.dtype))
+
+
 def attention(
     mha: nn.MultiheadAttention,
     query: Tensor,
-    key: Tensor,
-    value: Tensor,
+    key: Optional[Tensor],
+    value: Optional[Tensor],
     key_padding_mask: Optional[Tensor] = None,
     training: bool = False,
+    kv: Optional[tuple] = None,
 ) -> Tensor:
     """Multi-head attention with the parameters of ``mha``; inputs (B, L, E) / (B, S, E).
-    ``key_padding_mask`` (B, S) bool, True = ignore (nn.MultiheadAttention convention)."""
+    ``key_padding_mask`` (B, S) bool, True = ignore (nn.MultiheadAttention convention).
+    ``kv``: already-projected (k, v), each (B, S, E) -- the decoder projects the memory for all of its
+    layers with two GEMMs (TransformerDecoder.forward)."""
     e, h = mha.embed_dim, mha.num_heads
     w, b = mha.in_proj_weight, mha.in_proj_bias
     # torch.split / unbind instead of slicing: their backward is ONE cat / stack kernel, whereas every
     # slice's backward allocates a zero tensor of the full size and copies into it
-    if query is key:
+    if kv is not None:
+        w_q, _, _ = torch.split(w, [e, e, e], dim=0)
+        b_q, _, _ = torch.split(b, [e, e, e], dim=0)
+        q = F.linear(query, w_q, b_q)
+        k, v = kv
+    elif query is key:
         w_qk, w_v = torch.split(w, [2 * e, e], dim=0)
         b_qk, b_v = torch.split(b, [2 * e, e], dim=0)
         q, k = F.linear(query, w_qk, b_qk).unflatten(-1, (2, e)).unbind(-2)
+        v = F.linear(value, w_v, b_v)
     else:
         w_q, w_k, w_v = torch.split(w, [e, e, e], dim=0)
         b_q, b_k, b_v = torch.split(b, [e, e, e], dim=0)
         q = F.linear(query, w_q, b_q)
         k = F.linear(key, w_k, b_k)
-    v = F.linear(value, w_v, b_v)
+        v = F.linear(value, w_v, b_v)
     mask = None
     if key_padding_mask is not None:
         mask = (~key_padding_mask)[:, None, None, :]  # True = attend
@@ -99,11 +114,11 @@ class TransformerEncoderLayer(nn.Module):
         if self.normalize_before:
             y = self.norm1(src)
             qk = _add_pos(y, pos)
-            src = src + self.dropout1(attention(self.self_attn, qk, qk, y, src_key_padding_mask, self.training))
-            return src + self.dropout2(self._ffn(self.norm2(src)))
+            src = _residual(src, self.dropout1(attention(self.self_attn, qk, qk, y, src_key_padding_mask, self.training)))
+            return _residual(src, self.dropout2(self._ffn(self.norm2(src))))
         qk = _add_pos(src, pos)
-        src = self.norm1(src + self.dropout1(attention(self.self_attn, qk, qk, src, src_key_padding_mask, self.training)))
-        return self.norm2(src + self.dropout2(self._ffn(src)))
+        src = self.norm1(_residual(src, self.dropout1(attention(self.self_attn, qk, qk, src, src_key_padding_mask, self.training))))
+        return self.norm2(_residual(src, self.dropout2(self._ffn(src))))
 
 
 class TransformerDecoderLayer(nn.Module):
@@ -128,26 +143,23 @@ class TransformerDecoderLayer(nn.Module):
     def _ffn(self, x):
         return self.linear2(self.dropout(self.activation(self.linear1(x))))
 
-    def forward(self, tgt, memory, memory_pos, memory_key_padding_mask=None, query_pos=None):
-        """memory_pos = memory + pos (the cross-attention key input), shared by all layers."""
+    def forward(self, tgt, memory, memory_pos, memory_key_padding_mask=None, query_pos=None, kv=None):
+        """memory_pos = memory + pos (the cross-attention key input), shared by all layers; ``kv`` = this
+        layer's already-projected memory keys / values (or None: project here)."""
+        ca = self.multihead_attn
         if self.normalize_before:
             y = self.norm1(tgt)
             qk = _add_pos(y, query_pos)
-            tgt = tgt + self.dropout1(attention(self.self_attn, qk, qk, y, None, self.training))
+            tgt = _residual(tgt, self.dropout1(attention(self.self_attn, qk, qk, y, None, self.training)))
             y = self.norm2(tgt)
-            tgt = tgt + self.dropout2(
-                attention(self.multihead_attn, _add_pos(y, query_pos), memory_pos, memory, memory_key_padding_mask, self.training)
-            )
-            return tgt + self.dropout3(self._ffn(self.norm3(tgt)))
+            tgt = _residual(tgt, self.dropout2(
+                attention(ca, _add_pos(y, query_pos), memory_pos, memory, memory_key_padding_mask, self.training, kv=kv)))
+            return _residual(tgt, self.dropout3(self._ffn(self.norm3(tgt))))
         qk = _add_pos(tgt, query_pos)
-        tgt = self.norm1(tgt + self.dropout1(attention(self.self_attn, qk, qk, tgt, None, self.training)))
-        tgt = self.norm2(
-            tgt
-            + self.dropout2(
-                attention(self.multihead_attn, _add_pos(tgt, query_pos), memory_pos, memory, memory_key_padding_mask, self.training)
-            )
-        )
-        return self.norm3(tgt + self.dropout3(self._ffn(tgt)))
+        tgt = self.norm1(_residual(tgt, self.dropout1(attention(self.self_attn, qk, qk, tgt, None, self.training))))
+        tgt = self.norm2(_residual(tgt, self.dropout2(
+            attention(ca, _add_pos(tgt, query_pos), memory_pos, memory, memory_key_padding_mask, self.training, kv=kv))))
+        return self.norm3(_residual(tgt, self.dropout3(self._ffn(tgt))))
 
 
 def _clones(module, n):
@@ -181,13 +193,31 @@ class TransformerDecoder(nn.Module):
         self.num_layers = num_layers
         self.norm = norm
         self.return_intermediate = return_intermediate
+        self.batch_memory_kv = True
+
+    def _project_memory(self, memory, memory_pos):
+        """Keys / values of the memory for ALL layers with two GEMMs (S x E)(E x L*E) instead of 2L small
+        ones -- and, in backward, two input-gradient GEMMs instead of 2L plus 2L-2 accumulations of the
+        (B, S, E) memory gradient.  Same per-layer weights, same sums up to fp32 re-association."""
+        e = memory.shape[-1]
+        wk, wv, bk, bv = [], [], [], []
+        for layer in self.layers:
+            mha = layer.multihead_attn
+            _, w_k, w_v = torch.split(mha.in_proj_weight, [e, e, e], dim=0)
+            _, b_k, b_v = torch.split(mha.in_proj_bias, [e, e, e], dim=0)
+            wk.append(w_k), wv.append(w_v), bk.append(b_k), bv.append(b_v)
+        n = len(self.layers)
+        k_all = F.linear(memory_pos, torch.cat(wk, dim=0), torch.cat(bk, dim=0)).unflatten(-1, (n, e)).unbind(-2)
+        v_all = F.linear(memory, torch.cat(wv, dim=0), torch.cat(bv, dim=0)).unflatten(-1, (n, e)).unbind(-2)
+        return list(zip(k_all, v_all))
 
     def forward(self, tgt, memory, memory_key_padding_mask=None, pos=None, query_pos=None):
         out = tgt
         memory_pos = _add_pos(memory, pos)
+        kvs = self._project_memory(memory, memory_pos) if self.batch_memory_kv else [None] * len(self.layers)
         inter = []
-        for layer in self.layers:
-            out = layer(out, memory, memory_pos, memory_key_padding_mask=memory_key_padding_mask, query_pos=query_pos)
+        for layer, kv in zip(self.layers, kvs):
+            out = layer(out, memory, memory_pos, memory_key_padding_mask=memory_key_padding_mask, query_pos=query_pos, kv=kv)
             if self.return_intermediate:
                 inter.append(self.norm(out))
         if self.return_intermediate:
