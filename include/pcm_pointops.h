@@ -193,6 +193,23 @@ int pcm_sa_fused_backward_hip(int m, int n, int K, int H, int gf_is_bf16, const 
                               const int *offset, const int *new_offset, int b, int n_max,
                               int stage_mask, void *stream);
 
+/* ---- fused  out = LayerNorm(x + dropout(y))  ------------------------------------------------------------
+ * replaces the `x = x + dropout(y); x = norm(x)` tail of every post-norm transformer sub-layer
+ * (src/models/components/act/transformer.py:250-256, 330-345) -- 4 framework launches forward, 6+
+ * backward -- by one kernel each way.  x, out, s, dout, dx: (R,E) fp32; y, dy: (R,E) bf16 (y_is_bf16) or
+ * fp32; E % 256 == 0, E <= 1024 (else PCM_ERR_UNSUPPORTED).  The dropout mask is a counter-based hash of
+ * (*seed, site, element) recomputed in backward; `seed` is a DEVICE int64 so hipGraph replays draw new
+ * masks; p_drop = 0 disables dropout (seed may be NULL).  backward also reduces dgamma | dbeta (2,E) from
+ * `partial` (pcm_drln_blocks(R) x 2 x E floats of scratch). */
+int pcm_drln_blocks(long R);
+int pcm_drln_forward_hip(long R, int E, int y_is_bf16, const float *x, const void *y, const float *gamma,
+                         const float *beta, float eps, float p_drop, const long *seed, unsigned site,
+                         float *s, float *out, float *mean, float *rstd, void *stream);
+int pcm_drln_backward_hip(long R, int E, int y_is_bf16, const float *dout, const float *s,
+                          const float *mean, const float *rstd, const float *gamma, float p_drop,
+                          const long *seed, unsigned site, float *dx, void *dy, float *partial,
+                          float *dgamma_dbeta, void *stream);
+
 /* ---- training-step tail: global-norm clip + AdamW over one flat fp32 buffer ---------------------
  * replaces the torch passes the reference runs per step: clip_grad_norm_ (configs/trainer/ddp.yaml:12)
  * and AdamW.step (src/models/maniskill2_act_bc_module.py:347-367).  p, g, m, v: n floats each,

@@ -41,6 +41,9 @@ SIGNATURES = {
     "pcm_sa_fused_forward_hip": [_i, _i, _i, _i, _P, _P, _P, _P, _P, _P, _P, _f, _f, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _i, _P],
     "pcm_sa_fused_backward_hip": [_i, _i, _i, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                   _P, _P, _P, _P, _P, _P, _P, _P, _i, _i, _i, _P],
+    "pcm_drln_blocks": [ctypes.c_long],
+    "pcm_drln_forward_hip": [ctypes.c_long, _i, _i, _P, _P, _P, _P, _f, _f, _P, ctypes.c_uint, _P, _P, _P, _P, _P],
+    "pcm_drln_backward_hip": [ctypes.c_long, _i, _i, _P, _P, _P, _P, _P, _f, _P, ctypes.c_uint, _P, _P, _P, _P, _P],
     "pcm_optim_partials_capacity": [],
     "pcm_grad_sumsq_hip": [ctypes.c_long, _P, _P, _P, _P],
     "pcm_adamw_flat_hip": [ctypes.c_long, _P, _P, _P, _P, _P, _P, _i, _P, _P, _P],

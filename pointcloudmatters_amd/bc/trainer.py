@@ -142,6 +142,12 @@ class BCTrainer:
                 index = {id(p): k for k, p in enumerate(self.optimizer.params)}
                 self._shadow_names = [(n, p, index[id(p)]) for n, p in self.policy.named_parameters()
                                       if id(p) in index and self.optimizer.shadow[index[id(p)]] is not None]
+        # fused transformer tail ops (csrc/drln.hip) need a device-resident dropout seed: flat / graph modes only
+        self._fused_ctx = None
+        if mode != "eager" and self.device.type == "cuda":
+            from ..policy.fused_ops import FusedContext
+
+            self._fused_ctx = FusedContext(self.device)
         self.micro = 0
         self.optimizer_steps = 0
         self._sums = None
@@ -158,8 +164,10 @@ class BCTrainer:
         return contextlib.nullcontext()
 
     def _forward_backward(self, batch):
+        from ..policy import fused_ops
+
         shadows = getattr(self, "_shadow_names", None)
-        with self._autocast():
+        with fused_ops.activate(self._fused_ctx), self._autocast():
             if shadows:
                 opt = self.optimizer
                 repl = {n: _ShadowParam.apply(p, opt.shadow[k], opt, k) for n, p, k in shadows}
@@ -237,6 +245,8 @@ class BCTrainer:
         """One micro-batch: forward, loss, backward and -- on accumulation boundaries -- the
         optimizer step.  Returns the (detached, on-device) loss dict of this micro-batch."""
         self.module.train()
+        if self._fused_ctx is not None:
+            self._fused_ctx.set_step(self.micro)
         first = self.micro % self.accumulate == 0
         stepping = (self.micro + 1) % self.accumulate == 0
         if self.mode == "eager":

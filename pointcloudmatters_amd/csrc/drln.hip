@@ -1,0 +1,286 @@
+// drln.hip -- fused  out = LayerNorm(x + dropout(y))  forward / backward for gfx950 (MI355X).  HBM bound.
+//
+// Every post-norm sub-layer of the ACT transformer ends with this chain
+//   (/root/reference/src/models/components/act/transformer.py:250-256 encoder, :330-345 decoder:
+//    `src = src + self.dropout1(src2); src = self.norm1(src)`), which PyTorch runs as
+//    fused_dropout -> cast -> add -> layer_norm (4 launches forward, 6+ backward, 37 sub-layers per step).
+// Here: ONE forward kernel and ONE backward kernel (+ the shared fp64 partial-row reduction for the
+// affine gradients).
+//
+// Layout: x, out, s, dout, dx (R, E) fp32 row-major; y, dy (R, E) bf16 or fp32; gamma, beta (E).
+// One wave owns one row (E <= 1024, E % 256 == 0): a lane holds E/64 values as float4 chunks, row
+// statistics are two DPP/shuffle reductions, no LDS.  The dropout mask is never stored: it is
+// re-derived in backward from a counter-based hash of (seed, site, element index); `seed` lives in
+// device memory so a captured hipGraph draws fresh masks on every replay.
+//   forward : s = x + keep * y / (1-p);  mu, rstd per row;  out = (s - mu) * rstd * gamma + beta
+//   backward: g = dout * gamma;  dx = rstd * (g - mean(g) - xhat * mean(g * xhat));  dy = keep * dx / (1-p)
+//             dgamma = sum_rows dout * xhat,  dbeta = sum_rows dout   (per-block partial rows, fp64 reduce)
+// Algorithmic bytes per element: forward 4 (x) + 2 (y) + 4 (s) + 4 (out) = 14; backward 4 + 4 + 4 + 2 = 14.
+#include "pcm_common.hpp"
+
+#include <hip/hip_bf16.h>
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / 64;
+
+__device__ __forceinline__ uint32_t mix32(uint64_t z)
+{
+    // splitmix64 finaliser: a bijective avalanche of the 64-bit counter
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (uint32_t)(z >> 32);
+}
+
+// keep decision for element `e` of call site `site` under `seed`; threshold = p * 2^32
+__device__ __forceinline__ bool keep_elem(uint64_t seed, uint32_t site, uint64_t e, uint32_t threshold)
+{
+    return mix32(seed ^ ((uint64_t)site << 40) ^ e) >= threshold;
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+template <typename T>
+__device__ __forceinline__ void load4(const T *p, float (&o)[4]);
+template <>
+__device__ __forceinline__ void load4<float>(const float *p, float (&o)[4])
+{
+    const float4 v = *reinterpret_cast<const float4 *>(p);
+    o[0] = v.x, o[1] = v.y, o[2] = v.z, o[3] = v.w;
+}
+template <>
+__device__ __forceinline__ void load4<__hip_bfloat16>(const __hip_bfloat16 *p, float (&o)[4])
+{
+    const uint2 v = *reinterpret_cast<const uint2 *>(p);
+    o[0] = __uint_as_float(v.x << 16), o[1] = __uint_as_float(v.x & 0xFFFF0000u);
+    o[2] = __uint_as_float(v.y << 16), o[3] = __uint_as_float(v.y & 0xFFFF0000u);
+}
+template <typename T>
+__device__ __forceinline__ void store4(T *p, const float (&o)[4]);
+template <>
+__device__ __forceinline__ void store4<float>(float *p, const float (&o)[4])
+{
+    *reinterpret_cast<float4 *>(p) = make_float4(o[0], o[1], o[2], o[3]);
+}
+template <>
+__device__ __forceinline__ void store4<__hip_bfloat16>(__hip_bfloat16 *p, const float (&o)[4])
+{
+    __hip_bfloat16 t[4] = {__float2bfloat16(o[0]), __float2bfloat16(o[1]), __float2bfloat16(o[2]), __float2bfloat16(o[3])};
+    *reinterpret_cast<uint2 *>(p) = *reinterpret_cast<const uint2 *>(t);
+}
+
+template <typename T, int NCH>  // E = NCH * 256
+__global__ __launch_bounds__(kBlock) void pcm_drln_fwd_kernel(long R, const float *__restrict__ x, const T *__restrict__ y,
+                                                              const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                              float eps, float p_drop, const long *__restrict__ seed_ptr,
+                                                              unsigned site, float *__restrict__ s_out, float *__restrict__ out,
+                                                              float *__restrict__ mean_out, float *__restrict__ rstd_out)
+{
+    constexpr int E = NCH * 256;
+    const int lane = threadIdx.x & 63;
+    const long wave0 = (long)blockIdx.x * kWaves + (threadIdx.x >> 6), nwaves = (long)gridDim.x * kWaves;
+    const bool drop = p_drop > 0.f;
+    const uint64_t seed = drop ? (uint64_t)seed_ptr[0] : 0ull;
+    const uint32_t thr = drop ? (uint32_t)((double)p_drop * 4294967296.0) : 0u;
+    const float scale = drop ? 1.f / (1.f - p_drop) : 1.f;
+    float g[NCH][4], b[NCH][4];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        load4<float>(gamma + c * 256 + lane * 4, g[c]);
+        load4<float>(beta + c * 256 + lane * 4, b[c]);
+    }
+    for (long r = wave0; r < R; r += nwaves) {
+        float s[NCH][4];
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const long e0 = r * E + c * 256 + lane * 4;
+            float xv[4], yv[4];
+            load4<float>(x + e0, xv);
+            load4<T>(y + e0, yv);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float yy = (!drop || keep_elem(seed, site, (uint64_t)(e0 + v), thr)) ? yv[v] * scale : 0.f;
+                s[c][v] = xv[v] + yy;
+                sum += s[c][v];
+            }
+        }
+        const float mu = wave_sum(sum) * (1.f / E);
+        float sq = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float d = s[c][v] - mu;
+                sq += d * d;
+            }
+        const float rstd = rsqrtf(wave_sum(sq) * (1.f / E) + eps);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const long e0 = r * E + c * 256 + lane * 4;
+            float o[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) o[v] = (s[c][v] - mu) * rstd * g[c][v] + b[c][v];
+            store4<float>(s_out + e0, s[c]);
+            store4<float>(out + e0, o);
+        }
+        if (lane == 0) mean_out[r] = mu, rstd_out[r] = rstd;
+    }
+}
+
+// partial layout [block][2][E] = { dgamma, dbeta }
+template <typename T, int NCH>
+__global__ __launch_bounds__(kBlock) void pcm_drln_bwd_kernel(long R, const float *__restrict__ dout, const float *__restrict__ s,
+                                                              const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                              const float *__restrict__ gamma, float p_drop,
+                                                              const long *__restrict__ seed_ptr, unsigned site,
+                                                              float *__restrict__ dx, T *__restrict__ dy, float *__restrict__ partial)
+{
+    constexpr int E = NCH * 256;
+    __shared__ float lds[kWaves][2][E];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long wave0 = (long)blockIdx.x * kWaves + wave, nwaves = (long)gridDim.x * kWaves;
+    const bool drop = p_drop > 0.f;
+    const uint64_t seed = drop ? (uint64_t)seed_ptr[0] : 0ull;
+    const uint32_t thr = drop ? (uint32_t)((double)p_drop * 4294967296.0) : 0u;
+    const float scale = drop ? 1.f / (1.f - p_drop) : 1.f;
+    float g[NCH][4], dg[NCH][4], db[NCH][4];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        load4<float>(gamma + c * 256 + lane * 4, g[c]);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) dg[c][v] = 0.f, db[c][v] = 0.f;
+    }
+    for (long r = wave0; r < R; r += nwaves) {
+        const float mu = mean[r], rs = rstd[r];
+        float gd[NCH][4], xh[NCH][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const long e0 = r * E + c * 256 + lane * 4;
+            float dv[4], sv[4];
+            load4<float>(dout + e0, dv);
+            load4<float>(s + e0, sv);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                xh[c][v] = (sv[v] - mu) * rs;
+                gd[c][v] = dv[v] * g[c][v];
+                s1 += gd[c][v];
+                s2 += gd[c][v] * xh[c][v];
+                dg[c][v] += dv[v] * xh[c][v];
+                db[c][v] += dv[v];
+            }
+        }
+        const float m1 = wave_sum(s1) * (1.f / E), m2 = wave_sum(s2) * (1.f / E);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const long e0 = r * E + c * 256 + lane * 4;
+            float o[4], oy[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                o[v] = rs * (gd[c][v] - m1 - xh[c][v] * m2);
+                oy[v] = (!drop || keep_elem(seed, site, (uint64_t)(e0 + v), thr)) ? o[v] * scale : 0.f;
+            }
+            store4<float>(dx + e0, o);
+            store4<T>(dy + e0, oy);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            lds[wave][0][c * 256 + lane * 4 + v] = dg[c][v];
+            lds[wave][1][c * 256 + lane * 4 + v] = db[c][v];
+        }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * E; e += kBlock) {
+        const int t = e / E, h = e % E;
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) acc += lds[w][t][h];
+        partial[((size_t)blockIdx.x * 2 + t) * E + h] = acc;
+    }
+}
+
+// out[e] = sum over blocks of partial[block][e] in fp64 (same scheme as the SA layer's reduction)
+__global__ __launch_bounds__(512) void pcm_drln_reduce_kernel(int nslots, int VH, const float *__restrict__ partial,
+                                                              float *__restrict__ out)
+{
+    __shared__ double red[8][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    double acc = 0.0;
+    if (e < VH)
+        for (int s = wave; s < nslots; s += 8) acc += (double)partial[(size_t)s * VH + e];
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && e < VH) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) t += red[w][lane];
+        out[e] = (float)t;
+    }
+}
+
+inline int drln_grid(long R)
+{
+    long blocks = (R + kWaves - 1) / kWaves;
+    if (blocks > 512) blocks = 512;  // 2 workgroups per CU; waves stride over rows
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+}  // namespace
+
+extern "C" int pcm_drln_blocks(long R) { return drln_grid(R); }
+
+extern "C" int pcm_drln_forward_hip(long R, int E, int y_is_bf16, const float *x, const void *y, const float *gamma,
+                                    const float *beta, float eps, float p_drop, const long *seed, unsigned site, float *s,
+                                    float *out, float *mean, float *rstd, void *stream)
+{
+    if (R <= 0) return R == 0 ? PCM_OK : PCM_ERR_BAD_ARG;
+    if (E % 256 != 0 || E > 1024 || E <= 0) return PCM_ERR_UNSUPPORTED;
+    if (p_drop < 0.f || p_drop >= 1.f || (p_drop > 0.f && seed == nullptr)) return PCM_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = drln_grid(R);
+#define PCM_F(T, N)                                                                                                         \
+    hipLaunchKernelGGL((pcm_drln_fwd_kernel<T, N>), dim3(grid), dim3(kBlock), 0, st, R, x, (const T *)y, gamma, beta, eps,   \
+                       p_drop, seed, site, s, out, mean, rstd)
+    const int n = E / 256;
+    if (y_is_bf16) {
+        if (n == 1) PCM_F(__hip_bfloat16, 1); else if (n == 2) PCM_F(__hip_bfloat16, 2); else if (n == 3) PCM_F(__hip_bfloat16, 3); else PCM_F(__hip_bfloat16, 4);
+    } else {
+        if (n == 1) PCM_F(float, 1); else if (n == 2) PCM_F(float, 2); else if (n == 3) PCM_F(float, 3); else PCM_F(float, 4);
+    }
+#undef PCM_F
+    return PCM_LAUNCH_STATUS();
+}
+
+extern "C" int pcm_drln_backward_hip(long R, int E, int y_is_bf16, const float *dout, const float *s, const float *mean,
+                                     const float *rstd, const float *gamma, float p_drop, const long *seed, unsigned site,
+                                     float *dx, void *dy, float *partial, float *dgamma_dbeta, void *stream)
+{
+    if (R <= 0) return R == 0 ? PCM_OK : PCM_ERR_BAD_ARG;
+    if (E % 256 != 0 || E > 1024 || E <= 0) return PCM_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = drln_grid(R);
+#define PCM_B(T, N)                                                                                                         \
+    hipLaunchKernelGGL((pcm_drln_bwd_kernel<T, N>), dim3(grid), dim3(kBlock), 0, st, R, dout, s, mean, rstd, gamma, p_drop,  \
+                       seed, site, dx, (T *)dy, partial)
+    const int n = E / 256;
+    if (y_is_bf16) {
+        if (n == 1) PCM_B(__hip_bfloat16, 1); else if (n == 2) PCM_B(__hip_bfloat16, 2); else if (n == 3) PCM_B(__hip_bfloat16, 3); else PCM_B(__hip_bfloat16, 4);
+    } else {
+        if (n == 1) PCM_B(float, 1); else if (n == 2) PCM_B(float, 2); else if (n == 3) PCM_B(float, 3); else PCM_B(float, 4);
+    }
+#undef PCM_B
+    hipLaunchKernelGGL(pcm_drln_reduce_kernel, dim3((2 * E + 63) / 64), dim3(512), 0, st, grid, 2 * E, partial, dgamma_dbeta);
+    return PCM_LAUNCH_STATUS();
+}

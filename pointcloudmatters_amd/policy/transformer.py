@@ -33,6 +33,16 @@ def _residual(x: Tensor, y: Tensor) -> Tensor:
     return x + (y if y.dtype == x.dtype else y.to(x.dtype))
 
 
+def _add_norm(norm: nn.Module, dropout: nn.Module, x: Tensor, y: Tensor) -> Tensor:
+    """norm(x + dropout(y)): one fused HIP kernel each way when a FusedContext is active (training loop on
+    the GPU), the framework's dropout / cast / add / layer_norm chain otherwise."""
+    from . import fused_ops
+
+    if fused_ops.drln_supported(x, y, norm):
+        return fused_ops.drln(x, y, norm, dropout)
+    return norm(_residual(x, dropout(y)))
+
+
 def attention(
     mha: nn.MultiheadAttention,
     query: Tensor,
@@ -44,17 +54,16 @@ def attention(
 ) -> Tensor:
     """Multi-head attention with the parameters of ``mha``; inputs (B, L, E) / (B, S, E).
     ``key_padding_mask`` (B, S) bool, True = ignore (nn.MultiheadAttention convention).
-    ``kv``: already-projected (k, v), each (B, S, E) -- the decoder projects the memory for all of its
-    layers with two GEMMs (TransformerDecoder.forward)."""
+    ``kv``: (k, v, w_q, b_q) with already-projected k, v (B, S, E) -- the decoder projects the memory for all
+    of its layers with two GEMMs and splits every packed in_proj weight exactly once
+    (TransformerDecoder._project_memory)."""
     e, h = mha.embed_dim, mha.num_heads
     w, b = mha.in_proj_weight, mha.in_proj_bias
     # torch.split / unbind instead of slicing: their backward is ONE cat / stack kernel, whereas every
     # slice's backward allocates a zero tensor of the full size and copies into it
     if kv is not None:
-        w_q, _, _ = torch.split(w, [e, e, e], dim=0)
-        b_q, _, _ = torch.split(b, [e, e, e], dim=0)
+        k, v, w_q, b_q = kv  # projected memory + this layer's query projection (split once by the decoder)
         q = F.linear(query, w_q, b_q)
-        k, v = kv
     elif query is key:
         w_qk, w_v = torch.split(w, [2 * e, e], dim=0)
         b_qk, b_v = torch.split(b, [2 * e, e], dim=0)
@@ -117,8 +126,8 @@ class TransformerEncoderLayer(nn.Module):
             src = _residual(src, self.dropout1(attention(self.self_attn, qk, qk, y, src_key_padding_mask, self.training)))
             return _residual(src, self.dropout2(self._ffn(self.norm2(src))))
         qk = _add_pos(src, pos)
-        src = self.norm1(_residual(src, self.dropout1(attention(self.self_attn, qk, qk, src, src_key_padding_mask, self.training))))
-        return self.norm2(_residual(src, self.dropout2(self._ffn(src))))
+        src = _add_norm(self.norm1, self.dropout1, src, attention(self.self_attn, qk, qk, src, src_key_padding_mask, self.training))
+        return _add_norm(self.norm2, self.dropout2, src, self._ffn(src))
 
 
 class TransformerDecoderLayer(nn.Module):
@@ -156,10 +165,10 @@ class TransformerDecoderLayer(nn.Module):
                 attention(ca, _add_pos(y, query_pos), memory_pos, memory, memory_key_padding_mask, self.training, kv=kv)))
             return _residual(tgt, self.dropout3(self._ffn(self.norm3(tgt))))
         qk = _add_pos(tgt, query_pos)
-        tgt = self.norm1(_residual(tgt, self.dropout1(attention(self.self_attn, qk, qk, tgt, None, self.training))))
-        tgt = self.norm2(_residual(tgt, self.dropout2(
-            attention(ca, _add_pos(tgt, query_pos), memory_pos, memory, memory_key_padding_mask, self.training, kv=kv))))
-        return self.norm3(_residual(tgt, self.dropout3(self._ffn(tgt))))
+        tgt = _add_norm(self.norm1, self.dropout1, tgt, attention(self.self_attn, qk, qk, tgt, None, self.training))
+        tgt = _add_norm(self.norm2, self.dropout2, tgt,
+                        attention(ca, _add_pos(tgt, query_pos), memory_pos, memory, memory_key_padding_mask, self.training, kv=kv))
+        return _add_norm(self.norm3, self.dropout3, tgt, self._ffn(tgt))
 
 
 def _clones(module, n):
@@ -200,16 +209,16 @@ class TransformerDecoder(nn.Module):
         ones -- and, in backward, two input-gradient GEMMs instead of 2L plus 2L-2 accumulations of the
         (B, S, E) memory gradient.  Same per-layer weights, same sums up to fp32 re-association."""
         e = memory.shape[-1]
-        wk, wv, bk, bv = [], [], [], []
+        wq, wk, wv, bq, bk, bv = [], [], [], [], [], []
         for layer in self.layers:
             mha = layer.multihead_attn
-            _, w_k, w_v = torch.split(mha.in_proj_weight, [e, e, e], dim=0)
-            _, b_k, b_v = torch.split(mha.in_proj_bias, [e, e, e], dim=0)
-            wk.append(w_k), wv.append(w_v), bk.append(b_k), bv.append(b_v)
+            w_q, w_k, w_v = torch.split(mha.in_proj_weight, [e, e, e], dim=0)  # ONE split per weight: its
+            b_q, b_k, b_v = torch.split(mha.in_proj_bias, [e, e, e], dim=0)    # backward is a single cat
+            wq.append(w_q), wk.append(w_k), wv.append(w_v), bq.append(b_q), bk.append(b_k), bv.append(b_v)
         n = len(self.layers)
         k_all = F.linear(memory_pos, torch.cat(wk, dim=0), torch.cat(bk, dim=0)).unflatten(-1, (n, e)).unbind(-2)
         v_all = F.linear(memory, torch.cat(wv, dim=0), torch.cat(bv, dim=0)).unflatten(-1, (n, e)).unbind(-2)
-        return list(zip(k_all, v_all))
+        return list(zip(k_all, v_all, wq, bq))
 
     def forward(self, tgt, memory, memory_key_padding_mask=None, pos=None, query_pos=None):
         out = tgt

@@ -1,0 +1,70 @@
+"""GPU: fused LayerNorm(x + dropout(y)) (csrc/drln.hip) against the framework chain."""
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("E,ydtype", [(512, torch.bfloat16), (256, torch.float32), (768, torch.bfloat16), (1024, torch.float32)])
+def test_drln_matches_layernorm_without_dropout(hip_device, E, ydtype):
+    from pointcloudmatters_amd.policy import fused_ops
+
+    torch.manual_seed(0)
+    norm = nn.LayerNorm(E).to(hip_device)
+    with torch.no_grad():
+        norm.weight.uniform_(0.5, 1.5)
+        norm.bias.uniform_(-0.5, 0.5)
+    drop = nn.Dropout(0.0)
+    x = torch.randn(7, 103, E, device=hip_device, requires_grad=True)
+    y = torch.randn(7, 103, E, device=hip_device).to(ydtype).requires_grad_(True)
+    ref = norm(x + y.float())
+    gout = torch.randn_like(ref)
+    gx, gy, gw, gb = torch.autograd.grad(ref, (x, y, norm.weight, norm.bias), gout)
+    with fused_ops.activate(fused_ops.FusedContext(hip_device)):
+        assert fused_ops.drln_supported(x, y, norm)
+        out = fused_ops.drln(x, y, norm, drop)
+    fx, fy, fw, fb = torch.autograd.grad(out, (x, y, norm.weight, norm.bias), gout)
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(fx, gx, rtol=1e-4, atol=1e-5)
+    tol = dict(rtol=2e-2, atol=2e-2) if ydtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(fy.float(), gy.float(), **tol)
+    torch.testing.assert_close(fw, gw, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(fb, gb, rtol=1e-4, atol=1e-3)
+
+
+def test_drln_dropout_mask_is_consistent_and_fresh(hip_device):
+    from pointcloudmatters_amd.policy import fused_ops
+
+    E, p = 512, 0.1
+    norm = nn.LayerNorm(E).to(hip_device)
+    drop = nn.Dropout(p).train()
+    ctx = fused_ops.FusedContext(hip_device)
+    x = torch.zeros(64, 200, E, device=hip_device, requires_grad=True)
+    y = torch.randn(64, 200, E, device=hip_device).abs().add(0.5).to(torch.bfloat16).requires_grad_(True)
+
+    gout = torch.randn(64, 200, E, device=hip_device)
+
+    def run(step):
+        ctx.set_step(step)
+        with fused_ops.activate(ctx):
+            out = fused_ops.drln(x, y, norm, drop)
+        (gy,) = torch.autograd.grad(out, y, gout)
+        return out.detach(), gy.detach()
+
+    out0, gy0 = run(0)
+    out0b, gy0b = run(0)
+    out1, gy1 = run(1)
+    assert torch.equal(out0, out0b) and torch.equal(gy0, gy0b)          # same seed + site -> same mask (graph replay safety)
+    assert not torch.equal(out0, out1)                                  # new step -> new mask
+    dropped = (gy0 == 0).float().mean().item()                           # dy is exactly zero where y was dropped
+    assert abs(dropped - p) < 0.01, dropped
+    dropped1 = (gy1 == 0)
+    assert ((gy0 == 0) != dropped1).float().mean().item() > 0.1          # masks differ between steps
+    # forward and backward agree on the mask: re-create s = x + drop(y) from the normalised output statistics
+    ctx.set_step(0)
+    with fused_ops.activate(ctx):
+        out = fused_ops.drln(x, y, nn.LayerNorm(E, elementwise_affine=True).to(hip_device), drop)
+    # with x = 0 and y > 0, dropped entries are the row minimum of the pre-norm tensor -> the most negative outputs
+    row = out[0, 0]
+    assert torch.equal(row <= row.min() + 1e-6, gy0[0, 0] == 0)
