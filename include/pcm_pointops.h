@@ -210,6 +210,26 @@ int pcm_drln_backward_hip(long R, int E, int y_is_bf16, const float *dout, const
                           const long *seed, unsigned site, float *dx, void *dy, float *partial,
                           float *dgamma_dbeta, void *stream);
 
+/* ---- fused feed-forward sub-layer  out = LayerNorm(x + dropout(W2 dropout(relu(W1 x + b1)) + b2)) ------------
+ * replaces linear1 -> relu -> dropout -> linear2 -> dropout -> add -> norm of every transformer layer
+ * (src/models/components/act/transformer.py:253-256, 342-345) for the shipped dim_feedforward = 32
+ * (F == 32, E in {256, 512}; pcm_ffn_ln_supported).  All tensors fp32: x, s, out, dout, dx, dy (R,E);
+ * hd, dh (R,F); W1 (F,E), W2 (E,F).  backward writes dy and dh so the caller forms dW2 = dy^T hd and
+ * dW1 = dh^T x with two GEMMs, and reduces `partial` (pcm_ffn_ln_blocks(R) x (3E+F)) into
+ * sums = [dgamma(E) | dbeta(E) | db2(E) | db1(F)].  Dropout masks as in pcm_drln_* (device seed + site). */
+int pcm_ffn_ln_supported(int E, int F);
+int pcm_ffn_ln_blocks(long R);
+int pcm_ffn_ln_forward_hip(long R, int E, int F, const float *x, const float *W1, const float *b1,
+                           const float *W2, const float *b2, const float *gamma, const float *beta,
+                           float eps, float p_hidden, float p_out, const long *seed, unsigned site_a,
+                           unsigned site_b, float *hd, float *s, float *out, float *mean, float *rstd,
+                           void *stream);
+int pcm_ffn_ln_backward_hip(long R, int E, int F, const float *dout, const float *x, const float *s,
+                            const float *mean, const float *rstd, const float *hd, const float *W1,
+                            const float *W2, const float *gamma, float p_hidden, float p_out,
+                            const long *seed, unsigned site_b, float *dx, float *dy, float *dh,
+                            float *partial, float *sums, void *stream);
+
 /* ---- training-step tail: global-norm clip + AdamW over one flat fp32 buffer ---------------------
  * replaces the torch passes the reference runs per step: clip_grad_norm_ (configs/trainer/ddp.yaml:12)
  * and AdamW.step (src/models/maniskill2_act_bc_module.py:347-367).  p, g, m, v: n floats each,

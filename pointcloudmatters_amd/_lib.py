@@ -44,6 +44,12 @@ SIGNATURES = {
     "pcm_drln_blocks": [ctypes.c_long],
     "pcm_drln_forward_hip": [ctypes.c_long, _i, _i, _P, _P, _P, _P, _f, _f, _P, ctypes.c_uint, _P, _P, _P, _P, _P],
     "pcm_drln_backward_hip": [ctypes.c_long, _i, _i, _P, _P, _P, _P, _P, _f, _P, ctypes.c_uint, _P, _P, _P, _P, _P],
+    "pcm_ffn_ln_supported": [_i, _i],
+    "pcm_ffn_ln_blocks": [ctypes.c_long],
+    "pcm_ffn_ln_forward_hip": [ctypes.c_long, _i, _i, _P, _P, _P, _P, _P, _P, _P, _f, _f, _f, _P, ctypes.c_uint, ctypes.c_uint,
+                               _P, _P, _P, _P, _P, _P],
+    "pcm_ffn_ln_backward_hip": [ctypes.c_long, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P, _P, _f, _f, _P, ctypes.c_uint,
+                                _P, _P, _P, _P, _P, _P],
     "pcm_optim_partials_capacity": [],
     "pcm_grad_sumsq_hip": [ctypes.c_long, _P, _P, _P, _P],
     "pcm_adamw_flat_hip": [ctypes.c_long, _P, _P, _P, _P, _P, _P, _i, _P, _P, _P],

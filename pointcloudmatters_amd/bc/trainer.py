@@ -37,13 +37,23 @@ class _ShadowParam(torch.autograd.Function):
         return None, None, None, None
 
 
-def bf16_consumed_parameters(policy):
+def bf16_consumed_parameters(policy, fused_ffn=False):
     """ids of the parameters that autocast would cast to bf16 on every use: weights / biases of Linear,
     attention projections and 1-D convolutions.  The SA layer's own `linear` is excluded: its xyz
     columns are consumed in fp32 by the fused kernel."""
-    ids = set()
+    from .. import _lib
+    from ..policy.transformer import TransformerDecoderLayer, TransformerEncoderLayer
+
+    ids, skip = set(), set()
+    if fused_ffn:  # the fused feed-forward kernel (csrc/ffn.hip) consumes the fp32 masters directly
+        for mod in policy.modules():
+            if isinstance(mod, (TransformerEncoderLayer, TransformerDecoderLayer)) and mod.activation is torch.nn.functional.relu \
+                    and _lib.load().pcm_ffn_ln_supported(mod.linear1.in_features, mod.linear1.out_features) and not mod.normalize_before:
+                skip.update(id(p) for p in list(mod.linear1.parameters()) + list(mod.linear2.parameters()))
     for name, mod in policy.named_modules():
         if isinstance(mod, (nn.Linear, nn.Conv1d, nn.ConvTranspose1d)):
+            if any(id(p) in skip for p in mod.parameters(recurse=False)):
+                continue
             if name.split(".")[-1] == "linear" and hasattr(policy.get_submodule(name.rsplit(".", 1)[0]) if "." in name else policy, "pcd_nsample"):
                 continue
             ids.update(id(p) for p in mod.parameters(recurse=False))
@@ -102,6 +112,12 @@ class BCTrainer:
             policy = nn.SyncBatchNorm.convert_sync_batchnorm(policy)
             self.policy = self.module = policy
         self.sync_batchnorm = bool(self.distributed and sync_batchnorm and mode != "graph")
+        # fused transformer tail ops (csrc/drln.hip, ffn.hip) need a device-resident dropout seed: flat / graph modes
+        self._fused_ctx = None
+        if mode != "eager" and self.device.type == "cuda":
+            from ..policy.fused_ops import FusedContext
+
+            self._fused_ctx = FusedContext(self.device)
         params = [p for p in self.policy.parameters() if p.requires_grad]
         betas = tuple(o.get("betas", (0.9, 0.999)))
         if o.get("filter_bias_and_bn", False) and o["weight_decay"]:
@@ -138,16 +154,10 @@ class BCTrainer:
             self.scheduler = sched
             self._shadow_names = None
             if precision == "bf16" and hasattr(self.optimizer, "enable_bf16_mirror"):
-                self.optimizer.enable_bf16_mirror(bf16_consumed_parameters(self.policy))
+                self.optimizer.enable_bf16_mirror(bf16_consumed_parameters(self.policy, fused_ffn=self._fused_ctx is not None))
                 index = {id(p): k for k, p in enumerate(self.optimizer.params)}
                 self._shadow_names = [(n, p, index[id(p)]) for n, p in self.policy.named_parameters()
                                       if id(p) in index and self.optimizer.shadow[index[id(p)]] is not None]
-        # fused transformer tail ops (csrc/drln.hip) need a device-resident dropout seed: flat / graph modes only
-        self._fused_ctx = None
-        if mode != "eager" and self.device.type == "cuda":
-            from ..policy.fused_ops import FusedContext
-
-            self._fused_ctx = FusedContext(self.device)
         self.micro = 0
         self.optimizer_steps = 0
         self._sums = None

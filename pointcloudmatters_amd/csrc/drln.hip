@@ -16,65 +16,12 @@
 //   backward: g = dout * gamma;  dx = rstd * (g - mean(g) - xhat * mean(g * xhat));  dy = keep * dx / (1-p)
 //             dgamma = sum_rows dout * xhat,  dbeta = sum_rows dout   (per-block partial rows, fp64 reduce)
 // Algorithmic bytes per element: forward 4 (x) + 2 (y) + 4 (s) + 4 (out) = 14; backward 4 + 4 + 4 + 2 = 14.
-#include "pcm_common.hpp"
-
-#include <hip/hip_bf16.h>
+#include "pcm_elem.hpp"
 
 namespace {
 
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
-
-__device__ __forceinline__ uint32_t mix32(uint64_t z)
-{
-    // splitmix64 finaliser: a bijective avalanche of the 64-bit counter
-    z += 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    return (uint32_t)(z >> 32);
-}
-
-// keep decision for element `e` of call site `site` under `seed`; threshold = p * 2^32
-__device__ __forceinline__ bool keep_elem(uint64_t seed, uint32_t site, uint64_t e, uint32_t threshold)
-{
-    return mix32(seed ^ ((uint64_t)site << 40) ^ e) >= threshold;
-}
-
-__device__ __forceinline__ float wave_sum(float v)
-{
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
-}
-
-template <typename T>
-__device__ __forceinline__ void load4(const T *p, float (&o)[4]);
-template <>
-__device__ __forceinline__ void load4<float>(const float *p, float (&o)[4])
-{
-    const float4 v = *reinterpret_cast<const float4 *>(p);
-    o[0] = v.x, o[1] = v.y, o[2] = v.z, o[3] = v.w;
-}
-template <>
-__device__ __forceinline__ void load4<__hip_bfloat16>(const __hip_bfloat16 *p, float (&o)[4])
-{
-    const uint2 v = *reinterpret_cast<const uint2 *>(p);
-    o[0] = __uint_as_float(v.x << 16), o[1] = __uint_as_float(v.x & 0xFFFF0000u);
-    o[2] = __uint_as_float(v.y << 16), o[3] = __uint_as_float(v.y & 0xFFFF0000u);
-}
-template <typename T>
-__device__ __forceinline__ void store4(T *p, const float (&o)[4]);
-template <>
-__device__ __forceinline__ void store4<float>(float *p, const float (&o)[4])
-{
-    *reinterpret_cast<float4 *>(p) = make_float4(o[0], o[1], o[2], o[3]);
-}
-template <>
-__device__ __forceinline__ void store4<__hip_bfloat16>(__hip_bfloat16 *p, const float (&o)[4])
-{
-    __hip_bfloat16 t[4] = {__float2bfloat16(o[0]), __float2bfloat16(o[1]), __float2bfloat16(o[2]), __float2bfloat16(o[3])};
-    *reinterpret_cast<uint2 *>(p) = *reinterpret_cast<const uint2 *>(t);
-}
 
 template <typename T, int NCH>  // E = NCH * 256
 __global__ __launch_bounds__(kBlock) void pcm_drln_fwd_kernel(long R, const float *__restrict__ x, const T *__restrict__ y,
@@ -107,7 +54,7 @@ __global__ __launch_bounds__(kBlock) void pcm_drln_fwd_kernel(long R, const floa
             load4<T>(y + e0, yv);
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const float yy = (!drop || keep_elem(seed, site, (uint64_t)(e0 + v), thr)) ? yv[v] * scale : 0.f;
+                const float yy = (keep_elem(seed, site, (uint64_t)(e0 + v), thr)) ? yv[v] * scale : 0.f;
                 s[c][v] = xv[v] + yy;
                 sum += s[c][v];
             }
@@ -186,7 +133,7 @@ __global__ __launch_bounds__(kBlock) void pcm_drln_bwd_kernel(long R, const floa
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 o[v] = rs * (gd[c][v] - m1 - xh[c][v] * m2);
-                oy[v] = (!drop || keep_elem(seed, site, (uint64_t)(e0 + v), thr)) ? o[v] * scale : 0.f;
+                oy[v] = (keep_elem(seed, site, (uint64_t)(e0 + v), thr)) ? o[v] * scale : 0.f;
             }
             store4<float>(dx + e0, o);
             store4<T>(dy + e0, oy);
@@ -232,7 +179,7 @@ __global__ __launch_bounds__(512) void pcm_drln_reduce_kernel(int nslots, int VH
 inline int drln_grid(long R)
 {
     long blocks = (R + kWaves - 1) / kWaves;
-    if (blocks > 512) blocks = 512;  // 2 workgroups per CU; waves stride over rows
+    if (blocks > 128) blocks = 128;  // waves stride over rows; few blocks keep the dgamma/dbeta partial rows few
     if (blocks < 1) blocks = 1;
     return (int)blocks;
 }

@@ -113,3 +113,77 @@ def drln(x, y, norm, dropout):
     p = dropout.p if (dropout is not None and dropout.training) else 0.0
     ctx = _ACTIVE
     return _DRLN.apply(x, y, norm.weight, norm.bias, norm.eps, p, ctx.seed if p > 0 else None, ctx.next_site())
+
+
+class _FFNLN(Function):
+    """out = norm(x + dropout_out(linear2(dropout_hidden(relu(linear1(x)))))) -- csrc/ffn.hip."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, eps, p_hidden, p_out, seed, site_a, site_b):
+        L = _lib.load()
+        shape = x.shape
+        E, Fh = shape[-1], w1.shape[0]
+        x2 = x.reshape(-1, E)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        R = x2.shape[0]
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            hd, s, out = torch.empty(R, Fh, **f32), torch.empty(R, E, **f32), torch.empty(R, E, **f32)
+            mean, rstd = torch.empty(R, **f32), torch.empty(R, **f32)
+            sp = seed.data_ptr() if seed is not None else 0
+            rc = L.pcm_ffn_ln_forward_hip(R, E, Fh, x2.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                                          gamma.data_ptr(), beta.data_ptr(), float(eps), float(p_hidden), float(p_out), sp,
+                                          int(site_a), int(site_b), hd.data_ptr(), s.data_ptr(), out.data_ptr(), mean.data_ptr(),
+                                          rstd.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "pcm_ffn_ln_forward_hip")
+        ctx.save_for_backward(x2, w1, w2, gamma, hd, s, mean, rstd)
+        ctx.meta = (shape, float(p_hidden), float(p_out), seed, int(site_b))
+        return out.view(shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _lib.load()
+        x2, w1, w2, gamma, hd, s, mean, rstd = ctx.saved_tensors
+        shape, p_hidden, p_out, seed, site_b = ctx.meta
+        R, E = x2.shape
+        Fh = w1.shape[0]
+        dev = x2.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        d2 = dout.reshape(R, E)
+        if d2.dtype != torch.float32 or not d2.is_contiguous():
+            d2 = d2.float().contiguous()
+        with torch.cuda.device(dev):
+            dx, dy, dh = torch.empty(R, E, **f32), torch.empty(R, E, **f32), torch.empty(R, Fh, **f32)
+            pw = 3 * E + Fh
+            partial = torch.empty(L.pcm_ffn_ln_blocks(R) * pw, **f32)
+            sums = torch.empty(pw, **f32)
+            rc = L.pcm_ffn_ln_backward_hip(R, E, Fh, d2.data_ptr(), x2.data_ptr(), s.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                           hd.data_ptr(), w1.data_ptr(), w2.data_ptr(), gamma.data_ptr(), p_hidden, p_out,
+                                           seed.data_ptr() if seed is not None else 0, site_b, dx.data_ptr(), dy.data_ptr(),
+                                           dh.data_ptr(), partial.data_ptr(), sums.data_ptr(),
+                                           torch.cuda.current_stream().cuda_stream)
+            _lib.check(rc, "pcm_ffn_ln_backward_hip")
+            with torch.autocast(device_type="cuda", enabled=False):
+                dw2 = dy.t() @ hd  # (E, F)
+                dw1 = dh.t() @ x2  # (F, E)
+        dgamma, dbeta, db2, db1 = sums[:E], sums[E : 2 * E], sums[2 * E : 3 * E], sums[3 * E :]
+        return dx.view(shape), dw1, db1, dw2, db2, dgamma, dbeta, None, None, None, None, None, None
+
+
+def ffn_ln_supported(x, linear1, linear2, norm):
+    if _ACTIVE is None or not x.is_cuda or x.dtype != torch.float32:
+        return False
+    ws = (linear1.weight, linear1.bias, linear2.weight, linear2.bias, norm.weight, norm.bias)
+    if any(w is None or w.dtype != torch.float32 for w in ws) or type(norm) is not torch.nn.LayerNorm:
+        return False
+    return bool(_lib.load().pcm_ffn_ln_supported(int(x.shape[-1]), int(linear1.weight.shape[0])))
+
+
+def ffn_ln(x, linear1, linear2, norm, dropout_hidden, dropout_out):
+    pa = dropout_hidden.p if dropout_hidden.training else 0.0
+    pb = dropout_out.p if dropout_out.training else 0.0
+    ctx = _ACTIVE
+    return _FFNLN.apply(x, linear1.weight, linear1.bias, linear2.weight, linear2.bias, norm.weight, norm.bias, norm.eps, pa, pb,
+                        ctx.seed if (pa > 0 or pb > 0) else None, ctx.next_site(), ctx.next_site())

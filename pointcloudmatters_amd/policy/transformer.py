@@ -43,6 +43,16 @@ def _add_norm(norm: nn.Module, dropout: nn.Module, x: Tensor, y: Tensor) -> Tens
     return norm(_residual(x, dropout(y)))
 
 
+def _ffn_norm(layer, norm: nn.Module, dropout_out: nn.Module, x: Tensor) -> Tensor:
+    """norm(x + dropout_out(linear2(dropout(act(linear1(x)))))): one fused HIP kernel each way for the shipped
+    relu / dim_feedforward = 32 layers when a FusedContext is active, framework ops otherwise."""
+    from . import fused_ops
+
+    if layer.activation is F.relu and fused_ops.ffn_ln_supported(x, layer.linear1, layer.linear2, norm):
+        return fused_ops.ffn_ln(x, layer.linear1, layer.linear2, norm, layer.dropout, dropout_out)
+    return _add_norm(norm, dropout_out, x, layer._ffn(x))
+
+
 def attention(
     mha: nn.MultiheadAttention,
     query: Tensor,
@@ -127,7 +137,7 @@ class TransformerEncoderLayer(nn.Module):
             return _residual(src, self.dropout2(self._ffn(self.norm2(src))))
         qk = _add_pos(src, pos)
         src = _add_norm(self.norm1, self.dropout1, src, attention(self.self_attn, qk, qk, src, src_key_padding_mask, self.training))
-        return _add_norm(self.norm2, self.dropout2, src, self._ffn(src))
+        return _ffn_norm(self, self.norm2, self.dropout2, src)
 
 
 class TransformerDecoderLayer(nn.Module):
@@ -168,7 +178,7 @@ class TransformerDecoderLayer(nn.Module):
         tgt = _add_norm(self.norm1, self.dropout1, tgt, attention(self.self_attn, qk, qk, tgt, None, self.training))
         tgt = _add_norm(self.norm2, self.dropout2, tgt,
                         attention(ca, _add_pos(tgt, query_pos), memory_pos, memory, memory_key_padding_mask, self.training, kv=kv))
-        return _add_norm(self.norm3, self.dropout3, tgt, self._ffn(tgt))
+        return _ffn_norm(self, self.norm3, self.dropout3, tgt)
 
 
 def _clones(module, n):
