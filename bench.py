@@ -230,7 +230,7 @@ def main():
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)  # "nccl" is RCCL on ROCm
+        dist.init_process_group(backend="nccl")  # "nccl" is RCCL on ROCm; communicators are created lazily
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     wl = WORKLOADS[args.workload]
@@ -284,7 +284,7 @@ def main():
                                            "PointNet(6->512->96) + SA(99->96) + projector + U-Net(512/1024/2048, k=5) DDPM-100" if is_dp
                                            else "PointNet(6->512) + SA(515->512) + ACT(4 enc / 7 dec, d=512, 100 queries)"),
                        "global_batch": wl["batch"] * world, "points_per_cloud": wl["n_points"],
-                       "tokens_per_cloud": wl["pcd_npoints"], "parallelism": "dp%d" % world, "sa_impl": sa_impl, "step_mode": mode,
+                       "tokens_per_cloud": wl["pcd_npoints"], "parallelism": "dp%d" % world, "sa_impl": sa_impl, "step_mode": trainer.mode,
                        "batchnorm": "sync" if trainer.sync_batchnorm else "per-rank",
                        "accumulate_grad_batches": 1, "optimizer_step_every_step": True},
             "final_loss": round(metrics.get("train/loss", float("nan")), 4),

@@ -246,9 +246,11 @@ class BCTrainer:
             for n, b in self.policy.named_buffers():
                 b.copy_(buffers[n])
         self.optimizer.zero_grad()
-        self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
+        graph = torch.cuda.CUDAGraph()
+        # thread_local: RCCL's watchdog / other host threads may touch the HIP API while we capture
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             self._static_stats = self._forward_backward(clone_batch(self._static_batch))
+        self._graph = graph
         self.optimizer.zero_grad()
 
     def training_step(self, batch):
@@ -273,10 +275,19 @@ class BCTrainer:
                 self.optimizer.zero_grad(set_to_none=True)
                 self.optimizer_steps += 1
         else:
-            if self.mode == "graph":
-                if self._graph is None:
+            if self.mode == "graph" and self._graph is None:
+                try:
                     self._capture(batch)
-                elif self._signature(batch) != self._static_sig:
+                except Exception as e:  # capture is an optimisation: fall back to the same maths without replay
+                    import warnings
+
+                    warnings.warn(f"hipGraph capture failed ({type(e).__name__}: {e}); continuing in mode='flat'")
+                    torch.cuda.synchronize()
+                    self.mode, self._graph = "flat", None
+                    for p in self.optimizer.params:
+                        p.grad = None
+            if self.mode == "graph":
+                if self._signature(batch) != self._static_sig:
                     raise ValueError("graph mode needs the captured batch layout (equal shapes and cloud offsets); "
                                      "use mode='flat' for ragged batches")
                 if first:

@@ -160,3 +160,37 @@ def test_dp_training_step(hip_device, mode):
             first = tr.metrics()["train/loss"]
     last = tr.metrics()["train/loss"]
     assert last == last and last < first, (first, last)
+
+
+def test_graph_mode_coexists_with_rccl_process_group(hip_device):
+    """Single-rank RCCL group on the one GPU of this box: the communicator (and its watchdog thread) exists
+    while the step is captured into a hipGraph, and the flat-gradient all-reduce runs between replays --
+    the exact call sequence bench.py uses for N > 1 (the multi-GPU run itself belongs to the driver)."""
+    import os
+
+    import torch.distributed as dist
+
+    from pointcloudmatters_amd.bc import BCTrainer, build_act_policy, clone_batch, make_act_batch
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    try:
+        t = torch.ones(4, device=hip_device)
+        dist.all_reduce(t)  # forces communicator creation before the capture
+        torch.manual_seed(0)
+        pol = build_act_policy(pcd_npoints=64, sa_impl="fused", hidden_dim=768, nhead=4, num_encoder_layers=1,
+                               num_decoder_layers=2).to(hip_device)
+        tr = BCTrainer(pol, total_steps=100, precision="bf16", device=hip_device, mode="graph", optim=dict(accumulate_grad_batches=1))
+        tr.distributed, tr.world = True, 1  # exercise the all-reduce branch with a world of one
+        batch = make_act_batch(4, 256, seed=3, device=hip_device)
+        for _ in range(6):
+            tr.training_step(clone_batch(batch))
+        assert tr.mode == "graph" and tr._graph is not None
+        m = tr.metrics()
+        assert m["train/loss"] == m["train/loss"]
+    finally:
+        if created:
+            dist.destroy_process_group()
