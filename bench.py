@@ -140,6 +140,48 @@ def kernel_rooflines(wl, device, c_feat=512, hidden=512):
     add("pcm_sa_index_kernel", timed_events(lambda: bwd(1), 30), 4 * rows + 12 * n_tot + 12 * m + 16 * n_tot, "hbm", "index-only atomics")
     add("pcm_sa_reduce_kernel", timed_events(lambda: bwd(4), 30), slots * 5 * H * 4, "hbm", "fp64 reduction of per-block partial rows")
 
+    # ---- transformer tail kernels on the encoder's token matrix (B x 515 tokens x 512) ----------------------
+    R, E, Fh = b * (m_per + 3), hidden, 32
+    if E % 256 == 0 and E <= 1024:
+        xr, yr = torch.randn(R, E, **f32), torch.randn(R, E, **f32).to(torch.bfloat16)
+        g1, b1_ = torch.ones(E, **f32), torch.zeros(E, **f32)
+        seed = torch.zeros(1, dtype=torch.int64, device=device)
+        s_, o_, mu_, rs_ = torch.empty(R, E, **f32), torch.empty(R, E, **f32), torch.empty(R, **f32), torch.empty(R, **f32)
+        dx_, dy16 = torch.empty(R, E, **f32), torch.empty(R, E, dtype=torch.bfloat16, device=device)
+        part = torch.empty(max(L.pcm_drln_blocks(R) * 2 * E, L.pcm_ffn_ln_blocks(R) * (3 * E + Fh)), **f32)
+        dgb = torch.empty(3 * E + Fh, **f32)
+
+        def drln_f():
+            assert L.pcm_drln_forward_hip(R, E, 1, xr.data_ptr(), yr.data_ptr(), g1.data_ptr(), b1_.data_ptr(), 1e-5, 0.1,
+                                          seed.data_ptr(), 1, s_.data_ptr(), o_.data_ptr(), mu_.data_ptr(), rs_.data_ptr(), st) == 0
+
+        def drln_b():
+            assert L.pcm_drln_backward_hip(R, E, 1, o_.data_ptr(), s_.data_ptr(), mu_.data_ptr(), rs_.data_ptr(), g1.data_ptr(), 0.1,
+                                           seed.data_ptr(), 1, dx_.data_ptr(), dy16.data_ptr(), part.data_ptr(), dgb.data_ptr(), st) == 0
+
+        drln_f()
+        add("pcm_drln_fwd_kernel<bf16,2>", timed_events(drln_f, 30), R * E * 14, "hbm", "LayerNorm(x + dropout(y)): 6 B read, 8 B written per element")
+        add("pcm_drln_bwd_kernel<bf16,2>(+reduce)", timed_events(drln_b, 30), R * E * 14, "hbm", "8 B read, 6 B written per element")
+        if L.pcm_ffn_ln_supported(E, Fh):
+            w1, bb1 = torch.randn(Fh, E, **f32) * 0.05, torch.zeros(Fh, **f32)
+            w2, bb2 = torch.randn(E, Fh, **f32) * 0.05, torch.zeros(E, **f32)
+            hd_, dy_, dh_ = torch.empty(R, Fh, **f32), torch.empty(R, E, **f32), torch.empty(R, Fh, **f32)
+
+            def ffn_f():
+                assert L.pcm_ffn_ln_forward_hip(R, E, Fh, xr.data_ptr(), w1.data_ptr(), bb1.data_ptr(), w2.data_ptr(), bb2.data_ptr(),
+                                                g1.data_ptr(), b1_.data_ptr(), 1e-5, 0.1, 0.1, seed.data_ptr(), 1, 2, hd_.data_ptr(),
+                                                s_.data_ptr(), o_.data_ptr(), mu_.data_ptr(), rs_.data_ptr(), st) == 0
+
+            def ffn_b():
+                assert L.pcm_ffn_ln_backward_hip(R, E, Fh, o_.data_ptr(), xr.data_ptr(), s_.data_ptr(), mu_.data_ptr(), rs_.data_ptr(),
+                                                 hd_.data_ptr(), w1.data_ptr(), w2.data_ptr(), g1.data_ptr(), 0.1, 0.1, seed.data_ptr(), 2,
+                                                 dx_.data_ptr(), dy_.data_ptr(), dh_.data_ptr(), part.data_ptr(), dgb.data_ptr(), st) == 0
+
+            ffn_f()
+            add("pcm_ffn_ln_fwd_kernel<512,32>", timed_events(ffn_f, 30), R * E * 12 + R * Fh * 4, "lds",
+                "LDS-bandwidth bound: every row re-reads both 64 KiB weight matrices from LDS (%.0f MB of LDS reads)" % (R * 0.131))
+            add("pcm_ffn_ln_bwd_kernel<512,32>(+reduce)", timed_events(ffn_b, 30), R * E * 20 + R * Fh * 8, "lds", "as forward")
+
     # ---- optimizer tail on a flat buffer of the real parameter count ----------------------------------
     n_par = 24_100_000 // 64 * 64
     pbuf, gbuf = torch.randn(n_par, **f32), torch.randn(n_par, **f32) * 1e-3
