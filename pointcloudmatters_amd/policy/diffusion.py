@@ -25,6 +25,43 @@ from .sa_layer import set_abstraction
 
 
 # ----------------------------------------------------------------------------- U-Net pieces
+def conv1d_gemm(x, conv):
+    """``conv(x)`` for an ``nn.Conv1d`` as ONE im2col copy + ONE GEMM over the whole batch.
+
+    The U-Net works on horizons of 16 / 8 / 4 steps with 512-4096 channels: MIOpen serves these shapes with
+    per-sample im2col + GEMM loops (~900 Im2Col and ~200 small GEMM launches per training step at B=64);
+    here every convolution is a single (B*L_out, C_in*K) x (C_in*K, C_out) hipBLASLt GEMM (bf16 under
+    autocast), its backward two GEMMs.  Same arithmetic up to summation order."""
+    k, stride, pad = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+    b, cin, _ = x.shape
+    w = conv.weight  # (C_out, C_in, K)
+    if k == 1 and stride == 1 and pad == 0:
+        y = F.linear(x.transpose(1, 2), w[:, :, 0], conv.bias)  # (B, L, C_out)
+        return y.transpose(1, 2)
+    xp = F.pad(x, (pad, pad)) if pad else x
+    cols = xp.unfold(2, k, stride)  # (B, C_in, L_out, K) view
+    lout = cols.shape[2]
+    cols = cols.permute(0, 2, 1, 3).reshape(b * lout, cin * k)  # the one im2col copy
+    y = F.linear(cols, w.reshape(w.shape[0], cin * k), conv.bias)
+    return y.view(b, lout, -1).transpose(1, 2)
+
+
+def conv_transpose1d_gemm(x, conv):
+    """``conv(x)`` for ``nn.ConvTranspose1d(C, C, kernel_size=4, stride=2, padding=1)`` (the U-Net's Upsample1d):
+    one GEMM producing the (B, L, C_out, 4) taps, then the overlap-add of the two tap pairs."""
+    assert conv.kernel_size[0] == 4 and conv.stride[0] == 2 and conv.padding[0] == 1 and conv.output_padding[0] == 0
+    b, cin, l = x.shape
+    w = conv.weight  # (C_in, C_out, 4)
+    cout = w.shape[1]
+    taps = F.linear(x.transpose(1, 2).reshape(b * l, cin), w.reshape(cin, cout * 4).t()).view(b, l, cout, 4)
+    # full[o], o = 2*l + k: taps 0,1 land on rows (l, 0..1), taps 2,3 on rows (l+1, 0..1) of a (L+1, 2) grid
+    lo = F.pad(taps[..., 0:2], (0, 0, 0, 0, 0, 1))
+    hi = F.pad(taps[..., 2:4], (0, 0, 0, 0, 1, 0))
+    full = (lo + hi).permute(0, 2, 1, 3).reshape(b, cout, 2 * l + 2)  # (B, C_out, 2L+2)
+    y = full[:, :, 1:-1]
+    return y + conv.bias[None, :, None] if conv.bias is not None else y
+
+
 class SinusoidalPosEmb(nn.Module):
     def __init__(self, dim):
         super().__init__()
@@ -43,7 +80,7 @@ class Downsample1d(nn.Module):
         self.conv = nn.Conv1d(dim, dim, 3, 2, 1)
 
     def forward(self, x):
-        return self.conv(x)
+        return conv1d_gemm(x, self.conv)
 
 
 class Upsample1d(nn.Module):
@@ -52,7 +89,7 @@ class Upsample1d(nn.Module):
         self.conv = nn.ConvTranspose1d(dim, dim, 4, 2, 1)
 
     def forward(self, x):
-        return self.conv(x)
+        return conv_transpose1d_gemm(x, self.conv)
 
 
 class Conv1dBlock(nn.Module):
@@ -67,7 +104,8 @@ class Conv1dBlock(nn.Module):
         )
 
     def forward(self, x):
-        return self.block(x)
+        conv, norm, act = self.block[0], self.block[1], self.block[2]
+        return act(norm(conv1d_gemm(x, conv).contiguous()))
 
 
 class _AddTrailingDim(nn.Module):  # stands where the reference has einops Rearrange("batch t -> batch t 1")
@@ -99,7 +137,8 @@ class ConditionalResidualBlock1D(nn.Module):
         else:
             out = out + embed
         out = self.blocks[1](out)
-        return out + self.residual_conv(x)
+        res = conv1d_gemm(x, self.residual_conv) if isinstance(self.residual_conv, nn.Conv1d) else x
+        return out + res
 
 
 class ConditionalUnet1D(nn.Module):
@@ -152,7 +191,8 @@ class ConditionalUnet1D(nn.Module):
         for res1, res2, up in self.up_modules:
             x = torch.cat((x, skips.pop()), dim=1)
             x = up(res2(res1(x, cond), cond))
-        return self.final_conv(x).transpose(1, 2)
+        x = self.final_conv[0](x)
+        return conv1d_gemm(x, self.final_conv[1]).transpose(1, 2)
 
 
 # ----------------------------------------------------------------------------- DDPM forward process
@@ -349,7 +389,9 @@ class PCDObsEncoder(_AttrMixin):
         features = pcd_model(pcd_dict)
         _, x, _ = set_abstraction(self, self.pointops, coord, features, offset, n_o, impl=self.sa_impl, pre=pre)
         x = x.view(offset.shape[0], self.pcd_npoints, -1).transpose(1, 2)  # "(b n) c -> b c n"
-        return self.projector(x).squeeze(-1)
+        for layer in self.projector:  # 1x1 convolutions as GEMMs (MIOpen falls back to naive bf16 kernels here)
+            x = conv1d_gemm(x, layer) if isinstance(layer, nn.Conv1d) else layer(x.contiguous() if isinstance(layer, nn.BatchNorm1d) else x)
+        return x.squeeze(-1)
 
     def forward(self, obs_dict):
         feats, batch = [], None
