@@ -230,6 +230,44 @@ int pcm_ffn_ln_backward_hip(long R, int E, int F, const float *dout, const float
                             const long *seed, unsigned site_b, float *dx, float *dy, float *dh,
                             float *partial, float *sums, void *stream);
 
+/* ---- Diffusion-Policy sampler: one fused DDPM reverse step x_t -> x_{t-1} ------------------------------
+ * replaces diffusers' DDPMScheduler.step + the conditioning re-imposition inside `conditional_sample`
+ * (src/models/components/diffusion_policy/diffusion_unet_image_policy.py:130-141): epsilon prediction,
+ * fixed_small variance, clip_sample (configs/model/maniskill2_diffusion_policy_model.yaml:30-38).
+ *   x0 = (xt - sqrt_one_minus_abar*eps)/sqrt_abar; clamp to +-clip (clip > 0);
+ *   prev = coef_x0*x0 + coef_xt*xt (+ sigma*noise when noise != NULL and sigma != 0); prev = cond where cond_mask.
+ * n elements; eps bf16 (eps_is_bf16) or fp32; xt, noise, cond, prev fp32; cond_mask bytes (NULL: none).
+ * prev may alias xt.  fp32, un-contracted, in that order. */
+int pcm_ddpm_step_hip(long n, int eps_is_bf16, const void *eps, const float *xt, const float *noise,
+                      const unsigned char *cond_mask, const float *cond, float sqrt_abar,
+                      float sqrt_one_minus_abar, float coef_x0, float coef_xt, float sigma, float clip,
+                      float *prev, void *stream);
+
+/* ---- Diffusion-Policy U-Net blocks, channels-last --------------------------------------------------------
+ * replace Conv1dBlock = Conv1d -> GroupNorm -> Mish (+ FiLM, + residual add) of
+ * src/models/components/diffusion_policy/diffusion/conv1d_components.py:25-45 and conditional_unet1d.py:56-75.
+ * Activations are (B, T, C) row-major ("channels-last"); x / res / film may be bf16 (flags), y, dy are fp32.
+ *   pcm_im2col_cl_hip : cols (B*L_out, C*K), column c*K+k = x[b, l*stride+k-pad, c] or 0; L_out = (T+2*pad-K)/stride+1;
+ *                       the GEMM with nn.Conv1d's weight viewed (C_out, C_in*K) then IS the convolution.
+ *   pcm_col2im_cl_hip : adjoint (dx from dcols).
+ *   pcm_gn_mish_*     : y = mish(GroupNorm_G(x)); film_mode 1: y = film[b,0,c]*y + film[b,1,c] (film (B,2,C));
+ *                       film_mode 2: y += film[b,c]; res != NULL: y += res.  mean/rstd: (B*G).  backward writes dx
+ *                       (x's dtype), dgb_partial (B,2,C) = per-sample dgamma | dbeta (sum over B is the gradient) and
+ *                       dfilm (fp32, film's shape).  Supported when T*C/G <= 7168 and C/G <= 1024
+ *                       (pcm_gn_mish_supported; PCM_ERR_UNSUPPORTED otherwise). */
+int pcm_gn_mish_supported(int T, int C, int G);
+int pcm_gn_mish_forward_hip(int B, int T, int C, int G, int x_is_bf16, const void *x, const float *gamma,
+                            const float *beta, float eps, int film_mode, int film_is_bf16, const void *film,
+                            int res_is_bf16, const void *res, float *y, float *mean, float *rstd, void *stream);
+int pcm_gn_mish_backward_hip(int B, int T, int C, int G, int x_is_bf16, const void *x, const float *gamma,
+                             const float *beta, const float *mean, const float *rstd, int film_mode,
+                             int film_is_bf16, const void *film, const float *dy, void *dx, float *dgb_partial,
+                             float *dfilm, void *stream);
+int pcm_im2col_cl_hip(int B, int T, int C, int K, int stride, int pad, int x_is_bf16, const void *x,
+                      int out_is_bf16, void *cols, void *stream);
+int pcm_col2im_cl_hip(int B, int T, int C, int K, int stride, int pad, int cols_is_bf16, const void *dcols,
+                      int dx_is_bf16, void *dx, void *stream);
+
 /* ---- training-step tail: global-norm clip + AdamW over one flat fp32 buffer ---------------------
  * replaces the torch passes the reference runs per step: clip_grad_norm_ (configs/trainer/ddp.yaml:12)
  * and AdamW.step (src/models/maniskill2_act_bc_module.py:347-367).  p, g, m, v: n floats each,

@@ -50,6 +50,12 @@ SIGNATURES = {
                                _P, _P, _P, _P, _P, _P],
     "pcm_ffn_ln_backward_hip": [ctypes.c_long, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P, _P, _f, _f, _P, ctypes.c_uint,
                                 _P, _P, _P, _P, _P, _P],
+    "pcm_ddpm_step_hip": [ctypes.c_long, _i, _P, _P, _P, _P, _P, _f, _f, _f, _f, _f, _f, _P, _P],
+    "pcm_gn_mish_supported": [_i, _i, _i],
+    "pcm_gn_mish_forward_hip": [_i, _i, _i, _i, _i, _P, _P, _P, _f, _i, _i, _P, _i, _P, _P, _P, _P, _P],
+    "pcm_gn_mish_backward_hip": [_i, _i, _i, _i, _i, _P, _P, _P, _P, _P, _i, _i, _P, _P, _P, _P, _P, _P],
+    "pcm_im2col_cl_hip": [_i, _i, _i, _i, _i, _i, _i, _P, _i, _P, _P],
+    "pcm_col2im_cl_hip": [_i, _i, _i, _i, _i, _i, _i, _P, _i, _P, _P],
     "pcm_optim_partials_capacity": [],
     "pcm_grad_sumsq_hip": [ctypes.c_long, _P, _P, _P, _P],
     "pcm_adamw_flat_hip": [ctypes.c_long, _P, _P, _P, _P, _P, _P, _i, _P, _P, _P],

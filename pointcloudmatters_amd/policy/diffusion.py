@@ -22,6 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .sa_layer import set_abstraction
+from .unet_ops import conv1d_cl, conv_transpose1d_cl, gn_mish_cl
 
 
 # ----------------------------------------------------------------------------- U-Net pieces
@@ -46,22 +47,6 @@ def conv1d_gemm(x, conv):
     return y.view(b, lout, -1).transpose(1, 2)
 
 
-def conv_transpose1d_gemm(x, conv):
-    """``conv(x)`` for ``nn.ConvTranspose1d(C, C, kernel_size=4, stride=2, padding=1)`` (the U-Net's Upsample1d):
-    one GEMM producing the (B, L, C_out, 4) taps, then the overlap-add of the two tap pairs."""
-    assert conv.kernel_size[0] == 4 and conv.stride[0] == 2 and conv.padding[0] == 1 and conv.output_padding[0] == 0
-    b, cin, l = x.shape
-    w = conv.weight  # (C_in, C_out, 4)
-    cout = w.shape[1]
-    taps = F.linear(x.transpose(1, 2).reshape(b * l, cin), w.reshape(cin, cout * 4).t()).view(b, l, cout, 4)
-    # full[o], o = 2*l + k: taps 0,1 land on rows (l, 0..1), taps 2,3 on rows (l+1, 0..1) of a (L+1, 2) grid
-    lo = F.pad(taps[..., 0:2], (0, 0, 0, 0, 0, 1))
-    hi = F.pad(taps[..., 2:4], (0, 0, 0, 0, 1, 0))
-    full = (lo + hi).permute(0, 2, 1, 3).reshape(b, cout, 2 * l + 2)  # (B, C_out, 2L+2)
-    y = full[:, :, 1:-1]
-    return y + conv.bias[None, :, None] if conv.bias is not None else y
-
-
 class SinusoidalPosEmb(nn.Module):
     def __init__(self, dim):
         super().__init__()
@@ -79,8 +64,11 @@ class Downsample1d(nn.Module):
         super().__init__()
         self.conv = nn.Conv1d(dim, dim, 3, 2, 1)
 
-    def forward(self, x):
-        return conv1d_gemm(x, self.conv)
+    def forward_cl(self, x):
+        return conv1d_cl(x, self.conv)
+
+    def forward(self, x):  # (B, C, T) like the reference module
+        return self.forward_cl(x.transpose(1, 2)).transpose(1, 2)
 
 
 class Upsample1d(nn.Module):
@@ -88,12 +76,16 @@ class Upsample1d(nn.Module):
         super().__init__()
         self.conv = nn.ConvTranspose1d(dim, dim, 4, 2, 1)
 
+    def forward_cl(self, x):
+        return conv_transpose1d_cl(x, self.conv)
+
     def forward(self, x):
-        return conv_transpose1d_gemm(x, self.conv)
+        return self.forward_cl(x.transpose(1, 2)).transpose(1, 2)
 
 
 class Conv1dBlock(nn.Module):
-    """Conv1d -> GroupNorm -> Mish."""
+    """Conv1d -> GroupNorm -> Mish.  `forward_cl` is the channels-last form the U-Net runs: im2col + GEMM, then ONE
+    fused GroupNorm + Mish (+ FiLM, + residual) launch (csrc/gnmish.hip)."""
 
     def __init__(self, inp_channels, out_channels, kernel_size, n_groups=8):
         super().__init__()
@@ -103,9 +95,11 @@ class Conv1dBlock(nn.Module):
             nn.Mish(),
         )
 
+    def forward_cl(self, x, film=None, film_mode=0, res=None):
+        return gn_mish_cl(conv1d_cl(x, self.block[0]), self.block[1], film=film, film_mode=film_mode, res=res)
+
     def forward(self, x):
-        conv, norm, act = self.block[0], self.block[1], self.block[2]
-        return act(norm(conv1d_gemm(x, conv).contiguous()))
+        return self.forward_cl(x.transpose(1, 2)).transpose(1, 2)
 
 
 class _AddTrailingDim(nn.Module):  # stands where the reference has einops Rearrange("batch t -> batch t 1")
@@ -128,17 +122,16 @@ class ConditionalResidualBlock1D(nn.Module):
         self.cond_encoder = nn.Sequential(nn.Mish(), nn.Linear(cond_dim, film), _AddTrailingDim())
         self.residual_conv = nn.Conv1d(in_channels, out_channels, 1) if in_channels != out_channels else nn.Identity()
 
+    def forward_cl(self, x, mish_cond):
+        """x (B, T, C_in); mish_cond = Mish(cond), shared by every block of the U-Net (the reference recomputes it in
+        each cond_encoder).  FiLM rides in the first block's fused launch, the residual add in the second's."""
+        film = self.cond_encoder[1](mish_cond)  # (B, 2*C_out) = scale | bias, or (B, C_out) = bias
+        out = self.blocks[0].forward_cl(x, film=film, film_mode=1 if self.cond_predict_scale else 2)
+        res = conv1d_cl(x, self.residual_conv) if isinstance(self.residual_conv, nn.Conv1d) else x
+        return self.blocks[1].forward_cl(out, res=res)
+
     def forward(self, x, cond):
-        out = self.blocks[0](x)
-        embed = self.cond_encoder(cond)
-        if self.cond_predict_scale:
-            embed = embed.reshape(embed.shape[0], 2, self.out_channels, 1)
-            out = embed[:, 0] * out + embed[:, 1]
-        else:
-            out = out + embed
-        out = self.blocks[1](out)
-        res = conv1d_gemm(x, self.residual_conv) if isinstance(self.residual_conv, nn.Conv1d) else x
-        return out + res
+        return self.forward_cl(x.transpose(1, 2), F.mish(cond)).transpose(1, 2)
 
 
 class ConditionalUnet1D(nn.Module):
@@ -170,8 +163,9 @@ class ConditionalUnet1D(nn.Module):
                                         nn.Conv1d(down_dims[0], input_dim, 1))
 
     def forward(self, sample, timestep, local_cond=None, global_cond=None, **kwargs):
-        """sample (B, T, input_dim), timestep (B,) -> (B, T, input_dim)."""
-        x = sample.transpose(1, 2)  # (B, C, T)
+        """sample (B, T, input_dim), timestep (B,) -> (B, T, input_dim).  The reference moves to (B, C, T) and back
+        (conditional_unet1d.py:236, 295); here the activations stay (B, T, C) from end to end."""
+        x = sample
         t = timestep
         if not torch.is_tensor(t):
             t = torch.tensor([t], dtype=torch.long, device=sample.device)
@@ -181,18 +175,20 @@ class ConditionalUnet1D(nn.Module):
         cond = self.diffusion_step_encoder(t)
         if global_cond is not None:
             cond = torch.cat([cond, global_cond], dim=-1)
+        mish_cond = F.mish(cond)
         skips = []
         for res1, res2, down in self.down_modules:
-            x = res2(res1(x, cond), cond)
+            x = res2.forward_cl(res1.forward_cl(x, mish_cond), mish_cond)
             skips.append(x)
-            x = down(x)
+            if not isinstance(down, nn.Identity):
+                x = down.forward_cl(x)
         for mid in self.mid_modules:
-            x = mid(x, cond)
+            x = mid.forward_cl(x, mish_cond)
         for res1, res2, up in self.up_modules:
-            x = torch.cat((x, skips.pop()), dim=1)
-            x = up(res2(res1(x, cond), cond))
-        x = self.final_conv[0](x)
-        return conv1d_gemm(x, self.final_conv[1]).transpose(1, 2)
+            x = torch.cat((x, skips.pop()), dim=-1)
+            x = up.forward_cl(res2.forward_cl(res1.forward_cl(x, mish_cond), mish_cond))
+        x = self.final_conv[0].forward_cl(x)
+        return conv1d_cl(x, self.final_conv[1])
 
 
 # ----------------------------------------------------------------------------- DDPM forward process
@@ -201,7 +197,8 @@ class DDPMSchedule(nn.Module):
     float64 on the host then float32, and x_t = sqrt(abar_t) x_0 + sqrt(1-abar_t) eps."""
 
     def __init__(self, num_train_timesteps=100, beta_schedule="squaredcos_cap_v2", prediction_type="epsilon",
-                 beta_start=0.0001, beta_end=0.02, **unused):
+                 beta_start=0.0001, beta_end=0.02, clip_sample=True, clip_sample_range=1.0,
+                 variance_type="fixed_small", **unused):
         super().__init__()
         n = num_train_timesteps
         if beta_schedule == "squaredcos_cap_v2":
@@ -212,15 +209,101 @@ class DDPMSchedule(nn.Module):
             betas = torch.linspace(beta_start, beta_end, n, dtype=torch.float32)
         else:
             raise NotImplementedError(beta_schedule)
+        if prediction_type != "epsilon" or variance_type != "fixed_small":
+            raise NotImplementedError("only epsilon prediction with fixed_small variance is configured by the reference")
         self.num_train_timesteps = n
         self.prediction_type = prediction_type
+        self.clip_sample, self.clip_sample_range = bool(clip_sample), float(clip_sample_range)
         self.register_buffer("alphas_cumprod", torch.cumprod(1.0 - betas, dim=0), persistent=False)
+        self.set_timesteps(n)
 
     def add_noise(self, original, noise, timesteps):
         ac = self.alphas_cumprod.to(device=original.device, dtype=original.dtype)[timesteps]
         a = ac.sqrt().reshape(-1, *([1] * (original.dim() - 1)))
         s = (1 - ac).sqrt().reshape(-1, *([1] * (original.dim() - 1)))
         return a * original + s * noise
+
+    # ---- reverse process (rollout): DDPMScheduler.set_timesteps / step of diffusers 0.29, "leading" spacing
+    def set_timesteps(self, num_inference_steps):
+        n = self.num_train_timesteps
+        if not 0 < num_inference_steps <= n:
+            raise ValueError(f"num_inference_steps must be in 1..{n}")
+        self.num_inference_steps = int(num_inference_steps)
+        ratio = n // self.num_inference_steps
+        self.timesteps = [int(round(i * ratio)) for i in range(self.num_inference_steps)][::-1]
+        self._coef_cache, self._t_dev = {}, {}
+        for t in self.timesteps:  # all host-side scalars now: nothing left to compute (or copy) inside a graph capture
+            self.step_coefficients(t)
+
+    def timesteps_on(self, device):
+        """The timestep sequence as a device int64 tensor (cached): the sampler slices it instead of building a
+        one-element tensor from a Python int in every iteration (a pageable H2D copy, illegal under capture)."""
+        key = str(device)
+        if key not in self._t_dev:
+            self._t_dev[key] = torch.tensor(self.timesteps, dtype=torch.long, device=device)
+        return self._t_dev[key]
+
+    def step_coefficients(self, t):
+        """(sqrt(abar_t), sqrt(1-abar_t), coef_x0, coef_xt, sigma) as python floats holding fp32 values, computed with
+        fp32 tensor arithmetic in the order of DDPMScheduler.step / _get_variance."""
+        t = int(t)
+        hit = self._coef_cache.get(t)
+        if hit is not None:
+            return hit
+        ac = self.alphas_cumprod.detach().to("cpu", torch.float32)
+        prev_t = t - self.num_train_timesteps // self.num_inference_steps
+        a_t = ac[t]
+        a_prev = ac[prev_t] if prev_t >= 0 else torch.tensor(1.0)
+        b_t, b_prev = 1 - a_t, 1 - a_prev
+        cur_a = a_t / a_prev
+        cur_b = 1 - cur_a
+        coef_x0 = (a_prev ** 0.5 * cur_b) / b_t
+        coef_xt = cur_a ** 0.5 * b_prev / b_t
+        sigma = torch.tensor(0.0)
+        if t > 0:
+            sigma = torch.clamp(b_prev / b_t * cur_b, min=1e-20) ** 0.5
+        out = tuple(float(v) for v in (a_t ** 0.5, b_t ** 0.5, coef_x0, coef_xt, sigma))
+        self._coef_cache[t] = out
+        return out
+
+    def step(self, model_output, t, sample, noise=None, generator=None, cond_mask=None, cond=None, out=None):
+        """x_t -> x_{t-1}.  On the GPU this is ONE launch of pcm_ddpm_step_hip (csrc/ddpm.hip); host tensors take the
+        same fp32 chain through torch ops.  `noise` (variance noise, drawn here when None and t > 0) and the optional
+        conditioning are fused into the same launch."""
+        sa, sb, c0, ct, sigma = self.step_coefficients(t)
+        clip = self.clip_sample_range if self.clip_sample else 0.0
+        if noise is None and sigma != 0.0:
+            noise = torch.randn(sample.shape, device=sample.device, dtype=torch.float32, generator=generator)
+        if sample.is_cuda:
+            from .. import _lib
+
+            L = _lib.load()
+            eps = model_output.contiguous()
+            if eps.dtype not in (torch.float32, torch.bfloat16):
+                eps = eps.float()
+            xt = sample.contiguous()
+            assert xt.dtype == torch.float32 and eps.shape == xt.shape
+            prev = torch.empty_like(xt) if out is None else out
+            nz = noise.contiguous() if (noise is not None and sigma != 0.0) else None
+            mask8 = cond_mask.contiguous().view(torch.uint8) if cond_mask is not None else None
+            cnd = cond.contiguous() if cond_mask is not None else None
+            with torch.cuda.device(xt.device):
+                rc = L.pcm_ddpm_step_hip(xt.numel(), int(eps.dtype == torch.bfloat16), eps.data_ptr(), xt.data_ptr(),
+                                         nz.data_ptr() if nz is not None else 0,
+                                         mask8.data_ptr() if mask8 is not None else 0,
+                                         cnd.data_ptr() if cnd is not None else 0, sa, sb, c0, ct, sigma, clip,
+                                         prev.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            _lib.check(rc, "pcm_ddpm_step_hip")
+            return prev
+        x0 = (sample - sb * model_output.float()) / sa
+        if clip > 0:
+            x0 = x0.clamp(-clip, clip)
+        prev = c0 * x0 + ct * sample
+        if noise is not None and sigma != 0.0:
+            prev = prev + sigma * noise
+        if cond_mask is not None:
+            prev = torch.where(cond_mask, cond, prev)
+        return prev
 
 
 # ----------------------------------------------------------------------------- small helpers
@@ -438,6 +521,58 @@ class DiffusionUnetPcdPolicy(_AttrMixin):
 
     def set_normalizer(self, normalizer):
         self.normalizer.load_state_dict(normalizer.state_dict())
+
+    def reset(self):  # the reference module calls policy.reset() at the start of each rollout episode
+        pass
+
+    # ---- inference (diffusion_unet_image_policy.py:106-229)
+    def conditional_sample(self, condition_data, condition_mask, local_cond=None, global_cond=None, generator=None,
+                           noises=None, **kwargs):
+        """DDPM ancestral sampling of an action trajectory.  `noises` (optional list: initial trajectory, then one
+        variance-noise tensor per iteration) injects the random draws for parity tests."""
+        sched = self.noise_scheduler
+        if sched.num_inference_steps != self.num_inference_steps:
+            sched.set_timesteps(self.num_inference_steps)
+        dev = condition_data.device
+        if noises is not None:
+            trajectory = noises[0].to(dev, torch.float32).clone()
+        else:
+            trajectory = torch.randn(condition_data.shape, dtype=torch.float32, device=dev, generator=generator)
+        mask = condition_mask  # None = nothing is conditioned (no host sync to find out)
+        if mask is not None:
+            trajectory = torch.where(mask, condition_data, trajectory)
+        t_dev = sched.timesteps_on(dev)
+        for i, t in enumerate(sched.timesteps):
+            eps = self.model(trajectory, t_dev[i : i + 1], local_cond=local_cond, global_cond=global_cond)
+            noise = noises[1 + i].to(dev, torch.float32) if noises is not None else None
+            # conditioning is re-imposed inside the same launch (the reference does it at the top of the next iteration)
+            trajectory = sched.step(eps, t, trajectory, noise=noise, generator=generator, cond_mask=mask, cond=condition_data)
+        return trajectory
+
+    @torch.no_grad()
+    def predict_action(self, obs_dict, noises=None, generator=None):
+        """obs_dict = {"obs": {"pcds": packed clouds (B*To), <low-dim keys> (B, To, d)}} or the flat form; returns
+        {"action": (B, n_action_steps, Da), "action_pred": (B, T, Da)}."""
+        assert "past_action" not in obs_dict
+        obs = dict(obs_dict["obs"]) if "obs" in obs_dict else {k: v for k, v in obs_dict.items() if k != "goal"}
+        pcds = obs.pop("pcds", None)
+        nobs = self.normalizer.normalize(obs)
+        B = next(iter(nobs.values())).shape[0] if nobs else len(pcds["offset"]) // self.n_obs_steps
+        To, T, Da = self.n_obs_steps, self.horizon, self.action_dim
+        this_nobs = {k: v[:, :To].reshape(-1, *v.shape[2:]) for k, v in nobs.items()}
+        if pcds is not None:
+            this_nobs["pcds"] = pcds
+        global_cond = self.obs_encoder(this_nobs).reshape(B, -1)
+        goal = obs_dict.get("goal", None)
+        if goal is not None and "task_emb" in goal:
+            global_cond = torch.cat([global_cond, goal["task_emb"]], dim=-1)
+        dev = global_cond.device
+        # obs_as_global_cond: the reference's condition mask is all False (diffusion_unet_image_policy.py:196-198)
+        cond_data = torch.zeros(B, T, Da, device=dev, dtype=torch.float32)
+        nsample = self.conditional_sample(cond_data, None, global_cond=global_cond, generator=generator, noises=noises)
+        action_pred = self.normalizer["action"].unnormalize(nsample[..., :Da])
+        start = To - 1
+        return {"action": action_pred[:, start:start + self.n_action_steps], "action_pred": action_pred}
 
     def compute_loss(self, batch):
         """batch = {"obs": {"pcds": packed clouds (B*To of them), <low-dim keys> (B, T, d)}, "action": (B, T, Da)}.

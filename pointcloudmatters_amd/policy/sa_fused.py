@@ -87,8 +87,42 @@ class _SAFused(Function):
 
 def supports(owner, x):
     bn = owner.bn
-    return (x.is_cuda and owner.training and type(bn) is torch.nn.BatchNorm1d and bn.track_running_stats
-            and bn.momentum is not None and bn.affine)
+    if not (x.is_cuda and type(bn) is torch.nn.BatchNorm1d and bn.track_running_stats and bn.affine):
+        return False
+    if owner.training:
+        return bn.momentum is not None
+    # eval (rollout): running statistics, forward only
+    return not (torch.is_grad_enabled() and (x.requires_grad or owner.linear.weight.requires_grad))
+
+
+def _sa_fused_eval(owner, gf, p, n_p, knn_idx, wp):
+    """Inference form: the BatchNorm affine comes from the running statistics, so the batch-statistics stages of
+    the forward launcher are skipped (stage_mask = gather | apply) and nothing is saved for backward."""
+    L = _lib.load()
+    bn = owner.bn
+    n, H = gf.shape
+    m, K = knn_idx.shape
+    dev = gf.device
+    vec = 4 if H % 4 == 0 else 1
+    slots = L.pcm_sa_fused_slots(m, H, vec)
+    with torch.cuda.device(dev):
+        f32 = dict(dtype=torch.float32, device=dev)
+        invstd = torch.rsqrt(bn.running_var.float() + bn.eps)
+        a = bn.weight.float() * invstd
+        stat = torch.stack([bn.running_mean.float(), invstd, a, bn.bias.float() - a * bn.running_mean.float()]).contiguous()
+        ymax, ymin = torch.empty(m, H, **f32), torch.empty(m, H, **f32)
+        amax = torch.empty(m, H, dtype=torch.uint8, device=dev)
+        amin = torch.empty(m, H, dtype=torch.uint8, device=dev)
+        partial = torch.empty(slots * 5 * H, **f32)
+        z = torch.empty(m, H, **f32)
+        wp = wp.contiguous().float()
+        rc = L.pcm_sa_fused_forward_hip(
+            m, K, H, 1 if gf.dtype == torch.bfloat16 else 0, gf.data_ptr(), p.data_ptr(), n_p.data_ptr(), knn_idx.data_ptr(),
+            wp.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), float(bn.eps), 0.0, 0, 0, ymax.data_ptr(), ymin.data_ptr(),
+            amax.data_ptr(), amin.data_ptr(), partial.data_ptr(), 0, stat.data_ptr(), z.data_ptr(), 1 | 8,
+            torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "pcm_sa_fused_forward_hip")
+    return z
 
 
 def sa_fused_forward(owner, p, x, n_p, fps_idx, knn_idx, o=None, n_o=None):
@@ -106,6 +140,9 @@ def sa_fused_forward(owner, p, x, n_p, fps_idx, knn_idx, o=None, n_o=None):
     if gf.dtype not in (torch.float32, torch.bfloat16):
         gf = gf.float()
     bn = owner.bn
+    if not owner.training:
+        with torch.no_grad():
+            return _sa_fused_eval(owner, gf.contiguous(), p, n_p, knn_idx, w[:, :3])
     z, _ = _SAFused.apply(gf.contiguous(), p, n_p, knn_idx, w[:, :3], bn.weight, bn.bias, bn.running_mean, bn.running_var,
                           bn.eps, bn.momentum, o32, no32, n_max)
     with torch.no_grad():

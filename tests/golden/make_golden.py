@@ -311,11 +311,93 @@ def golden_dp(ref):
     print("dp_pcd_small.npz: loss", float(loss))
 
 
+def golden_rollout(ref):
+    """The policy side of a rollout step, from the reference's own Python:
+      * TemporalAgg (src/utils/misc.py:88-141) fed a seeded sequence of action chunks;
+      * ACTPCD in eval mode without "actions" (act.py:177-182: zero latent), weights = act_pcd_small.npz plus seeded
+        BatchNorm running statistics;
+      * the DDPM sampler: the reference ConditionalUnet1D + PCDObsEncoder in eval mode driven by the restated
+        scheduler (oracle/ddpm_cpu.py -- diffusers is absent, so the scheduler arithmetic itself is parity-unpinned),
+        composed as conditional_sample / predict_action do (diffusion_unet_image_policy.py:106-229).
+    Inputs and weights are those of act_pcd_small.npz / dp_pcd_small.npz; this fixture adds only the new draws and
+    the expected outputs."""
+    from oracle import ddpm_cpu
+    from pointcloudmatters_amd.policy import PointNet
+
+    fx = {}
+    # ---- TemporalAgg
+    misc = _load("src.utils.misc", f"{REF}/src/utils/misc.py")
+    rng = np.random.default_rng(17)
+    chunks = rng.normal(size=(17, 6, 3))
+    agg = misc.TemporalAgg(apply=True, action_dim=3, chunk_size=6, k=0.01)
+    outs = [agg(c) for c in chunks[:14]]
+    agg.reset()
+    outs += [agg(c) for c in chunks[14:]]
+    fx["tagg.chunks"], fx["tagg.out"], fx["tagg.reset_after"] = chunks, np.stack(outs), np.array(14)
+    fx["tagg.noapply"] = misc.TemporalAgg(apply=False)(chunks[0])
+
+    # ---- ACT, test-time branch
+    act = np.load(os.path.join(OUT, "act_pcd_small.npz"))
+    weights = {k[2:]: torch.from_numpy(act[k]) for k in act.files if k.startswith("w.")}
+    g = torch.Generator().manual_seed(31)
+    for k in list(weights):
+        if k.endswith("running_mean"):
+            weights[k] = 0.1 * torch.randn(weights[k].shape, generator=g)
+            fx[f"act.buf.{k}"] = weights[k].numpy()
+        elif k.endswith("running_var"):
+            weights[k] = 0.5 + torch.rand(weights[k].shape, generator=g)
+            fx[f"act.buf.{k}"] = weights[k].numpy()
+    holder = types.SimpleNamespace(state_dict=lambda: weights)
+    model = build_reference_actpcd(ref, holder, 32).eval()
+    pcds = {k[len("in.pcds."):]: torch.from_numpy(act[k]) for k in act.files if k.startswith("in.pcds.")}
+    with torch.no_grad():
+        out = model({"qpos": torch.from_numpy(act["in.qpos"]), "goal_cond": torch.from_numpy(act["in.goal_cond"]), "pcds": pcds})
+    assert out["mu"] is None and not out["is_training"]
+    fx["act.a_hat"], fx["act.is_pad_hat"] = out["a_hat"].numpy(), out["is_pad_hat"].numpy()
+
+    # ---- Diffusion Policy sampler
+    dp = np.load(os.path.join(OUT, "dp_pcd_small.npz"))
+    sd = {k[2:]: torch.from_numpy(dp[k]) for k in dp.files if k.startswith("w.")}
+    for k in list(sd):
+        if k.endswith("running_mean"):
+            sd[k] = 0.1 * torch.randn(sd[k].shape, generator=g)
+            fx[f"dp.buf.{k}"] = sd[k].numpy()
+        elif k.endswith("running_var"):
+            sd[k] = 0.5 + torch.rand(sd[k].shape, generator=g)
+            fx[f"dp.buf.{k}"] = sd[k].numpy()
+    shape_meta = {"obs": {"pcds": {"shape": [6], "type": "pcd"}, "qpos": {"shape": [9], "type": "low_dim"}},
+                  "action": {"shape": [7]}}
+    enc = ref.pcd_enc.PCDObsEncoder(shape_meta=shape_meta, pcd_model=PointNet(in_channels=6, num_classes=24),
+                                    share_pcd_model=True, n_obs_step=2, pcd_nsample=16, pcd_npoints=32,
+                                    pcd_hidden_dim=24, projector_layers=1, projector_channels=[24, 40, 40])
+    enc.load_state_dict({k[len("obs_encoder."):]: v for k, v in sd.items() if k.startswith("obs_encoder.")}, strict=True)
+    unet = ref.unet.ConditionalUnet1D(input_dim=7, local_cond_dim=None, global_cond_dim=(40 + 9) * 2,
+                                      diffusion_step_embed_dim=16, down_dims=[16, 32, 64], kernel_size=5, n_groups=8,
+                                      cond_predict_scale=True)
+    unet.load_state_dict({k[len("model."):]: v for k, v in sd.items() if k.startswith("model.")}, strict=True)
+    enc.eval(), unet.eval()
+    qpos = torch.from_numpy(dp["in.qpos"])
+    dpc = {k[len("in.pcds."):]: torch.from_numpy(dp[k]) for k in dp.files if k.startswith("in.pcds.")}
+    noises = torch.randn(101, 3, 16, 7, generator=g).numpy()
+    with torch.no_grad():
+        global_cond = enc({"qpos": qpos[:, :2].reshape(-1, 9), "pcds": dpc}).reshape(3, -1)
+
+        def eps_model(x, t):
+            return unet(torch.from_numpy(x), t, local_cond=None, global_cond=global_cond).numpy()
+
+        traj = ddpm_cpu.sample(eps_model, (3, 16, 7), noises, num_train=100, num_inference=100, clip=1.0)
+    fx["dp.noises"], fx["dp.global_cond"], fx["dp.action_pred"] = noises, global_cond.numpy(), traj
+    fx["dp.action"] = traj[:, 1:1 + 8]  # start = To - 1, n_action_steps = 8 (identity normaliser)
+    np.savez_compressed(os.path.join(OUT, "rollout_ref.npz"), **fx)
+    print("rollout_ref.npz ok; |action_pred| max", float(np.abs(traj).max()))
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "run this in the build container (needs /root/reference)"
     torch.set_num_threads(1)
     ref = install_reference()
-    golden_act(ref)
-    golden_grouping(ref)
-    golden_misc(ref)
-    golden_dp(ref)
+    only = set(sys.argv[1:])  # e.g. `make_golden.py rollout` regenerates one fixture
+    for name, fn in (("act", golden_act), ("grouping", golden_grouping), ("misc", golden_misc), ("dp", golden_dp),
+                     ("rollout", golden_rollout)):
+        if not only or name in only:
+            fn(ref)

@@ -1,0 +1,166 @@
+"""csrc/gnmish.hip through its Python wrappers (policy/unet_ops.py) against plain PyTorch fp32 references of the same
+ops, forward and backward: channels-last im2col / col2im and the fused GroupNorm + Mish (+ FiLM, + residual)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _ref_conv(x_cl, conv):
+    return conv(x_cl.transpose(1, 2)).transpose(1, 2)
+
+
+@pytest.mark.parametrize("k,stride,pad", [(5, 1, 2), (3, 1, 1), (3, 2, 1), (1, 1, 0), (4, 2, 0)])
+@pytest.mark.parametrize("shape", [(3, 16, 64), (2, 8, 7), (1, 4, 512)])
+def test_conv1d_cl_matches_nn_conv1d(k, stride, pad, shape):
+    from pointcloudmatters_amd.policy.unet_ops import conv1d_cl
+
+    b, t, c = shape
+    if t + 2 * pad < k:
+        pytest.skip("empty output")
+    torch.manual_seed(k * 100 + c)
+    conv = nn.Conv1d(c, 24, k, stride, pad).to(DEV)
+    x = torch.randn(b, t, c, device=DEV, requires_grad=True)
+    y = conv1d_cl(x, conv)
+    want = _ref_conv(x, conv)
+    torch.testing.assert_close(y, want, rtol=1e-4, atol=1e-4)
+    g = torch.randn_like(want)
+    gx, gw, gb = torch.autograd.grad(y, (x, conv.weight, conv.bias), g)
+    rx, rw, rb = torch.autograd.grad(want, (x, conv.weight, conv.bias), g)
+    torch.testing.assert_close(gx, rx, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(gw, rw, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(gb, rb, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("k,stride,pad", [(5, 1, 2), (3, 2, 1)])
+@pytest.mark.parametrize("xdt,odt", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16),
+                                     (torch.bfloat16, torch.bfloat16)])
+def test_im2col_cl_is_exact(k, stride, pad, xdt, odt):
+    """A pure gather: bit-exact against unfold (after the same cast), and col2im is its exact adjoint on integers."""
+    from pointcloudmatters_amd.policy.unet_ops import _Im2colCL
+
+    b, t, c = 3, 16, 40
+    x = torch.randint(-8, 9, (b, t, c), device=DEV).to(xdt).requires_grad_(True)
+    cols = _Im2colCL.apply(x, k, stride, pad, odt)
+    ref = F.pad(x.detach(), (0, 0, pad, pad)).unfold(1, k, stride).reshape(cols.shape).to(odt)
+    assert cols.dtype == odt and torch.equal(cols, ref)
+    g = torch.randint(-4, 5, cols.shape, device=DEV).to(odt)
+    (gx,) = torch.autograd.grad(cols, x, g)
+    xr = x.detach().float().requires_grad_(True)
+    (rx,) = torch.autograd.grad(F.pad(xr, (0, 0, pad, pad)).unfold(1, k, stride).reshape(cols.shape), xr, g.float())
+    assert gx.dtype == xdt and torch.equal(gx.float(), rx)
+
+
+def test_conv_transpose1d_cl_matches_nn():
+    from pointcloudmatters_amd.policy.unet_ops import conv_transpose1d_cl
+
+    torch.manual_seed(2)
+    conv = nn.ConvTranspose1d(48, 48, 4, 2, 1).to(DEV)
+    x = torch.randn(3, 8, 48, device=DEV, requires_grad=True)
+    y = conv_transpose1d_cl(x, conv)
+    want = conv(x.transpose(1, 2)).transpose(1, 2)
+    assert y.shape == (3, 16, 48)
+    torch.testing.assert_close(y, want, rtol=1e-4, atol=1e-4)
+    g = torch.randn_like(want)
+    for a, r in zip(torch.autograd.grad(y, (x, conv.weight, conv.bias), g), torch.autograd.grad(want, (x, conv.weight, conv.bias), g)):
+        torch.testing.assert_close(a, r, rtol=1e-4, atol=1e-4)
+
+
+def _ref_gn_mish(x, norm, film, film_mode, res):
+    y = F.mish(F.group_norm(x.float().transpose(1, 2), norm.num_groups, norm.weight, norm.bias, norm.eps)).transpose(1, 2)
+    c = x.shape[2]
+    if film is not None:
+        f = film.float()
+        y = f[:, None, :c] * y + f[:, None, c:] if film_mode == 1 else y + f[:, None, :]
+    if res is not None:
+        y = y + res.float()
+    return y
+
+
+@pytest.mark.parametrize("shape,groups", [((3, 16, 64), 8), ((2, 8, 1024), 8), ((2, 4, 2048), 8), ((2, 16, 24), 8),
+                                          ((1, 16, 2048), 8), ((5, 3, 6), 2), ((2, 2, 4096), 4)])
+@pytest.mark.parametrize("film_mode", [0, 1, 2])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_gn_mish_cl_matches_torch(shape, groups, film_mode, with_res):
+    from pointcloudmatters_amd.policy.unet_ops import gn_mish_cl, gn_mish_supported
+
+    b, t, c = shape
+    torch.manual_seed(c + film_mode)
+    norm = nn.GroupNorm(groups, c).to(DEV)
+    with torch.no_grad():
+        norm.weight.uniform_(0.5, 1.5)
+        norm.bias.uniform_(-0.5, 0.5)
+    x = (2 * torch.randn(b, t, c, device=DEV) + 0.3).requires_grad_(True)
+    assert gn_mish_supported(x, norm)
+    film = None
+    if film_mode == 1:
+        film = torch.randn(b, 2 * c, device=DEV, requires_grad=True)
+    elif film_mode == 2:
+        film = torch.randn(b, c, device=DEV, requires_grad=True)
+    res = torch.randn(b, t, c, device=DEV, requires_grad=True) if with_res else None
+    y = gn_mish_cl(x, norm, film=film, film_mode=film_mode, res=res)
+    want = _ref_gn_mish(x, norm, film, film_mode, res)
+    assert y.dtype == torch.float32
+    torch.testing.assert_close(y, want, rtol=1e-4, atol=1e-5)
+    g = torch.randn_like(want)
+    ins = [x, norm.weight, norm.bias] + ([film] if film is not None else []) + ([res] if res is not None else [])
+    got = torch.autograd.grad(y, ins, g)
+    ref = torch.autograd.grad(want, ins, g)
+    for a, r, name in zip(got, ref, ["x", "gamma", "beta", "film", "res"]):
+        scale = r.abs().max().item() + 1e-12
+        assert (a - r).abs().max().item() <= 1e-4 * scale + 1e-6, (name, (a - r).abs().max().item(), scale)
+
+
+def test_gn_mish_cl_bf16_inputs_and_determinism():
+    from pointcloudmatters_amd.policy.unet_ops import gn_mish_cl
+
+    torch.manual_seed(0)
+    b, t, c = 4, 16, 512
+    norm = nn.GroupNorm(8, c).to(DEV)
+    x = torch.randn(b, t, c, device=DEV).bfloat16().requires_grad_(True)
+    film = torch.randn(b, 2 * c, device=DEV).bfloat16().requires_grad_(True)
+    res = torch.randn(b, t, c, device=DEV).bfloat16().requires_grad_(True)
+    y = gn_mish_cl(x, norm, film=film, film_mode=1, res=res)
+    want = _ref_gn_mish(x, norm, film, 1, res)
+    torch.testing.assert_close(y, want, rtol=1e-4, atol=1e-5)
+    g = torch.randn_like(want)
+    got = torch.autograd.grad(y, (x, norm.weight, norm.bias, film, res), g, retain_graph=True)
+    again = torch.autograd.grad(y, (x, norm.weight, norm.bias, film, res), g)
+    ref = torch.autograd.grad(want, (x, norm.weight, norm.bias, film, res), g)
+    for a, a2, r in zip(got, again, ref):
+        assert a.dtype == r.dtype and torch.equal(a, a2)  # no atomics: bit-identical run to run
+        torch.testing.assert_close(a.float(), r.float(), rtol=2e-2, atol=2e-2)  # bf16-rounded gradients
+
+
+def test_gn_mish_unsupported_shape_falls_back_to_framework_ops():
+    from pointcloudmatters_amd.policy.unet_ops import gn_mish_cl, gn_mish_supported
+
+    norm = nn.GroupNorm(1, 64).to(DEV)
+    x = torch.randn(1, 128, 64, device=DEV)  # 8192 elements per group > LDS budget
+    assert not gn_mish_supported(x, norm)
+    torch.testing.assert_close(gn_mish_cl(x, norm), _ref_gn_mish(x, norm, None, 0, None))
+
+
+def test_unet_gpu_matches_cpu_fp32():
+    from pointcloudmatters_amd.policy.diffusion import ConditionalUnet1D
+
+    torch.manual_seed(5)
+    net = ConditionalUnet1D(input_dim=7, global_cond_dim=20, diffusion_step_embed_dim=16, down_dims=(32, 64, 128), kernel_size=5,
+                            n_groups=8, cond_predict_scale=True)
+    x, gc, t = torch.randn(3, 16, 7), torch.randn(3, 20), torch.tensor([1, 50, 99])
+    want = net(x, t, global_cond=gc)
+    want.square().mean().backward()
+    ref_grads = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+    net.zero_grad()
+    net = net.to(DEV)
+    got = net(x.to(DEV), t.to(DEV), global_cond=gc.to(DEV))
+    got.square().mean().backward()
+    torch.testing.assert_close(got.cpu(), want, rtol=1e-4, atol=1e-5)
+    for k, p in net.named_parameters():
+        if k in ref_grads:
+            r = ref_grads[k]
+            assert (p.grad.cpu() - r).abs().max() <= 1e-4 * r.abs().max() + 1e-7, k
