@@ -268,6 +268,21 @@ int pcm_im2col_cl_hip(int B, int T, int C, int K, int stride, int pad, int x_is_
 int pcm_col2im_cl_hip(int B, int T, int C, int K, int stride, int pad, int cols_is_bf16, const void *dcols,
                       int dx_is_bf16, void *dx, void *stream);
 
+/* ---- PointNet layer tail: BatchNorm1d (batch statistics) + ReLU over packed point features (n, C) ----------
+ * replaces the BatchNorm1d + ReLU of every PointNet layer (src/models/components/pcd_encoder/pointnet.py:25-56).
+ * y, z, dz, dy: (n, C) row-major, all bf16 (is_bf16) or all fp32; C % 4 == 0 and (C <= 1024 or C % 1024 == 0)
+ * (pcm_bn_relu_supported).  partial: pcm_bn_relu_slots(n, C) x 2 x C floats of scratch; sums: 2 x C; stat: 4 x C =
+ * { mean, invstd, a = gamma*invstd, b = beta - a*mean }.  forward updates running_mean / running_var (momentum,
+ * unbiased variance) unless they are NULL; use_given_stat != 0 skips the statistics and applies `stat` as given
+ * (eval mode: the caller fills it from the running statistics).  backward leaves sums = [dbeta | dgamma]. */
+int pcm_bn_relu_supported(long n, int C);
+int pcm_bn_relu_slots(long n, int C);
+int pcm_bn_relu_forward_hip(long n, int C, int is_bf16, const void *y, const float *gamma, const float *beta,
+                            float eps, float momentum, float *running_mean, float *running_var,
+                            int use_given_stat, float *partial, float *sums, float *stat, void *z, void *stream);
+int pcm_bn_relu_backward_hip(long n, int C, int is_bf16, const void *y, const void *dz, const float *stat,
+                             float *partial, float *sums, void *dy, void *stream);
+
 /* ---- training-step tail: global-norm clip + AdamW over one flat fp32 buffer ---------------------
  * replaces the torch passes the reference runs per step: clip_grad_norm_ (configs/trainer/ddp.yaml:12)
  * and AdamW.step (src/models/maniskill2_act_bc_module.py:347-367).  p, g, m, v: n floats each,

@@ -1,0 +1,86 @@
+"""Fused BatchNorm1d + ReLU over packed point features (csrc/bnrelu.hip) as an autograd function.
+
+``bn_relu(y, bn)`` == ``relu(bn(y))`` for y (n, C) on a HIP device: training mode uses batch statistics and updates
+the running ones exactly like ``nn.BatchNorm1d``; eval mode applies the running statistics.  Output dtype = input
+dtype (bf16 under autocast, as torch's batch_norm).  Host tensors and unsupported layouts take the module path.
+"""
+import torch
+from torch.autograd import Function
+
+from .. import _lib
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+class _BNReLU(Function):
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, eps, momentum):
+        L = _lib.load()
+        n, c = y.shape
+        y = y.contiguous()
+        dev = y.device
+        with torch.cuda.device(dev):
+            f32 = dict(dtype=torch.float32, device=dev)
+            partial = torch.empty(L.pcm_bn_relu_slots(n, c) * 2 * c, **f32)
+            sums, stat = torch.empty(2, c, **f32), torch.empty(4, c, **f32)
+            z = torch.empty_like(y)
+            rc = L.pcm_bn_relu_forward_hip(n, c, int(y.dtype == torch.bfloat16), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                           float(eps), float(momentum), _ptr(running_mean), _ptr(running_var), 0,
+                                           partial.data_ptr(), sums.data_ptr(), stat.data_ptr(), z.data_ptr(),
+                                           torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "pcm_bn_relu_forward_hip")
+        ctx.save_for_backward(y, stat)
+        ctx.partial = partial
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        L = _lib.load()
+        y, stat = ctx.saved_tensors
+        n, c = y.shape
+        dz = dz.contiguous()
+        if dz.dtype != y.dtype:
+            dz = dz.to(y.dtype)
+        dev = y.device
+        with torch.cuda.device(dev):
+            sums = torch.empty(2, c, dtype=torch.float32, device=dev)
+            dy = torch.empty_like(y)
+            rc = L.pcm_bn_relu_backward_hip(n, c, int(y.dtype == torch.bfloat16), y.data_ptr(), dz.data_ptr(), stat.data_ptr(),
+                                            ctx.partial.data_ptr(), sums.data_ptr(), dy.data_ptr(),
+                                            torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "pcm_bn_relu_backward_hip")
+        return dy, sums[1], sums[0], None, None, None, None
+
+
+def supported(y, bn):
+    return (y.is_cuda and y.dim() == 2 and y.dtype in (torch.float32, torch.bfloat16) and type(bn) is torch.nn.BatchNorm1d
+            and bn.affine and bn.track_running_stats and bn.weight.dtype == torch.float32
+            and (not bn.training or bn.momentum is not None)
+            and bool(_lib.load().pcm_bn_relu_supported(int(y.shape[0]), int(y.shape[1]))))
+
+
+def bn_relu(y, bn):
+    """relu(bn(y)); the caller checked ``supported(y, bn)``."""
+    if bn.training:
+        z = _BNReLU.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum)
+        with torch.no_grad():
+            bn.num_batches_tracked.add_(1)
+        return z
+    # eval: the affine comes from the running statistics; same apply kernel, differentiable through framework ops
+    if torch.is_grad_enabled() and (y.requires_grad or bn.weight.requires_grad):
+        return torch.relu(bn(y))
+    L = _lib.load()
+    n, c = y.shape
+    y = y.contiguous()
+    with torch.cuda.device(y.device), torch.no_grad():
+        invstd = torch.rsqrt(bn.running_var.float() + bn.eps)
+        a = bn.weight.float() * invstd
+        stat = torch.stack([bn.running_mean.float(), invstd, a, bn.bias.float() - a * bn.running_mean.float()]).contiguous()
+        z = torch.empty_like(y)
+        rc = L.pcm_bn_relu_forward_hip(n, c, int(y.dtype == torch.bfloat16), y.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(),
+                                       float(bn.eps), 0.0, 0, 0, 1, 0, 0, stat.data_ptr(), z.data_ptr(),
+                                       torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "pcm_bn_relu_forward_hip")
+    return z

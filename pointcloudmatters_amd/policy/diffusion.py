@@ -176,6 +176,8 @@ class ConditionalUnet1D(nn.Module):
         if global_cond is not None:
             cond = torch.cat([cond, global_cond], dim=-1)
         mish_cond = F.mish(cond)
+        if mish_cond.is_cuda and torch.is_autocast_enabled("cuda"):
+            mish_cond = mish_cond.to(torch.get_autocast_dtype("cuda"))  # one cast instead of one per cond_encoder
         skips = []
         for res1, res2, down in self.down_modules:
             x = res2.forward_cl(res1.forward_cl(x, mish_cond), mish_cond)

@@ -34,12 +34,20 @@ class PointNet(nn.Module):
     def forward(self, input_dict):
         """input_dict: feat (n, in_channels) [+ grid_coord, offset, unused by a k=1 conv] -> (n, C)."""
         x = input_dict["feat"]
-        x = self.conv1(x)
-        x = self.conv2(x)
-        x = self.conv3(x)
-        x = self.conv4(x)
-        x = self.conv5(x)
+        for block in (self.conv1, self.conv2, self.conv3, self.conv4, self.conv5):
+            x = self._layer(block, x)
         return self.final(x)
+
+    @staticmethod
+    def _layer(block, x):
+        """Linear -> BatchNorm1d -> ReLU; on the GPU the BN + ReLU tail is the fused kernel pair of csrc/bnrelu.hip."""
+        y = block[0](x)
+        if y.is_cuda:
+            from . import bn_relu as fused
+
+            if fused.supported(y, block[1]):
+                return fused.bn_relu(y, block[1])
+        return block[2](block[1](y))
 
     def load_reference_state_dict(self, state_dict, strict=True):
         """Accept a reference checkpoint: spconv stores SubMConv3d weights as (1,1,1,Cin,Cout)

@@ -84,6 +84,39 @@ def _copy_into(dst, src):
             _copy_into(d, s)
 
 
+class Bf16Weights:
+    """bf16 copies of the parameters that autocast would otherwise re-cast on EVERY use (autocast's weight cache is
+    off under no_grad): Linear / Conv1d / attention-projection weights and biases.  Inside the context the modules see
+    the copies; `refresh()` re-casts from the fp32 masters into the same storage (safe for a captured graph)."""
+
+    def __init__(self, policy):
+        from ..bc.trainer import bf16_consumed_parameters
+        from . import fused_ops
+
+        ids = bf16_consumed_parameters(policy, fused_ffn=fused_ops.current() is not None)
+        self.items = []
+        for mod in policy.modules():
+            for pname, p in list(mod._parameters.items()):
+                if p is not None and id(p) in ids and p.dtype == torch.float32 and p.is_cuda:
+                    shadow = torch.nn.Parameter(p.detach().to(torch.bfloat16), requires_grad=False)
+                    self.items.append((mod, pname, p, shadow))
+
+    def refresh(self):
+        with torch.no_grad():
+            for _, _, p, shadow in self.items:
+                shadow.copy_(p)
+
+    def __enter__(self):
+        for mod, pname, _, shadow in self.items:
+            mod._parameters[pname] = shadow
+        return self
+
+    def __exit__(self, *exc):
+        for mod, pname, p, _ in self.items:
+            mod._parameters[pname] = p
+        return False
+
+
 class GraphedPolicy:
     """Capture `fn(static_inputs)` once, then `__call__(inputs)` = copy inputs into the static buffers + one
     hipGraphLaunch.  Shapes (and the clouds' offsets) must stay those of the example: in a rollout they do -- every
@@ -92,22 +125,27 @@ class GraphedPolicy:
     fn must be free of host synchronisation (offsets carry their host copy, see pointops._common.host_offsets).
     """
 
-    def __init__(self, fn, example_inputs, warmup=2, autocast_dtype=torch.bfloat16):
+    def __init__(self, fn, example_inputs, warmup=2, autocast_dtype=torch.bfloat16, policy=None):
         dev = next(t for t in _flatten(example_inputs) if torch.is_tensor(t)).device
         if dev.type != "cuda":
             raise RuntimeError("GraphedPolicy needs a HIP device: there is no CPU path")
         self.static_in = _static_like(example_inputs)
         self._fn, self._dtype = fn, autocast_dtype
+        # bf16 weight copies made once (call .weights.refresh() after the fp32 masters change)
+        self.weights = Bf16Weights(policy) if (policy is not None and autocast_dtype == torch.bfloat16) else None
         self._stream = torch.cuda.Stream(device=dev)
         self._stream.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(self._stream):
-            for _ in range(warmup):
-                self._run()
-        torch.cuda.current_stream(dev).wait_stream(self._stream)
-        torch.cuda.synchronize(dev)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=self._stream, capture_error_mode="thread_local"):
-            self.static_out = self._run()
+        import contextlib
+
+        with (self.weights if self.weights is not None else contextlib.nullcontext()):
+            with torch.cuda.stream(self._stream):
+                for _ in range(warmup):
+                    self._run()
+            torch.cuda.current_stream(dev).wait_stream(self._stream)
+            torch.cuda.synchronize(dev)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=self._stream, capture_error_mode="thread_local"):
+                self.static_out = self._run()
 
     def _run(self):
         with torch.no_grad(), torch.autocast("cuda", dtype=self._dtype, enabled=self._dtype is not None):
@@ -138,7 +176,7 @@ def graphed_act(policy, example):
     def fn(d):
         return policy(dict(d, pcds=dict(d["pcds"])))["a_hat"]
 
-    return GraphedPolicy(fn, example)
+    return GraphedPolicy(fn, example, policy=policy)
 
 
 def graphed_dp(policy, example):
@@ -153,4 +191,4 @@ def graphed_dp(policy, example):
             obs["pcds"] = dict(obs["pcds"])
         return policy.predict_action({"obs": obs})
 
-    return GraphedPolicy(fn, example)
+    return GraphedPolicy(fn, example, policy=policy)
