@@ -21,6 +21,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .rows_linear import linear_rows
 from .sa_layer import set_abstraction
 from .unet_ops import conv1d_cl, conv_transpose1d_cl, gn_mish_cl
 
@@ -37,7 +38,7 @@ def conv1d_gemm(x, conv):
     b, cin, _ = x.shape
     w = conv.weight  # (C_out, C_in, K)
     if k == 1 and stride == 1 and pad == 0:
-        y = F.linear(x.transpose(1, 2), w[:, :, 0], conv.bias)  # (B, L, C_out)
+        y = linear_rows(x.transpose(1, 2), w[:, :, 0], conv.bias)  # (B, L, C_out)
         return y.transpose(1, 2)
     xp = F.pad(x, (pad, pad)) if pad else x
     cols = xp.unfold(2, k, stride)  # (B, C_in, L_out, K) view

@@ -12,6 +12,8 @@ CUDA library absent from the reference tree: parity of this restatement is unpin
 import torch
 import torch.nn as nn
 
+from .rows_linear import linear_rows
+
 
 def _block(cin, cout):
     return nn.Sequential(nn.Linear(cin, cout, bias=False), nn.BatchNorm1d(cout, eps=1e-3, momentum=0.01), nn.ReLU())
@@ -36,12 +38,12 @@ class PointNet(nn.Module):
         x = input_dict["feat"]
         for block in (self.conv1, self.conv2, self.conv3, self.conv4, self.conv5):
             x = self._layer(block, x)
-        return self.final(x)
+        return linear_rows(x, self.final.weight, self.final.bias) if isinstance(self.final, nn.Linear) else x
 
     @staticmethod
     def _layer(block, x):
         """Linear -> BatchNorm1d -> ReLU; on the GPU the BN + ReLU tail is the fused kernel pair of csrc/bnrelu.hip."""
-        y = block[0](x)
+        y = linear_rows(x, block[0].weight, block[0].bias)
         if y.is_cuda:
             from . import bn_relu as fused
 

@@ -13,6 +13,7 @@ import torch.nn.functional as F
 from torch.autograd import Function
 
 from .. import _lib
+from .rows_linear import linear_rows
 
 
 def _ptr(t):
@@ -136,7 +137,7 @@ def sa_fused_forward(owner, p, x, n_p, fps_idx, knn_idx, o=None, n_o=None):
         o32, no32 = C.i32c(o), C.i32c(n_o)
         n_max = max(C.counts_from_offsets(C.host_offsets(o)))
     w = owner.linear.weight  # (H, 3 + C): xyz columns first (grouping.py:57 concatenates xyz before feat)
-    gf = F.linear(x, w[:, 3:])  # (n, H); bf16 under autocast, fp32 otherwise
+    gf = linear_rows(x, w[:, 3:])  # (n, H); bf16 under autocast, fp32 otherwise
     if gf.dtype not in (torch.float32, torch.bfloat16):
         gf = gf.float()
     bn = owner.bn

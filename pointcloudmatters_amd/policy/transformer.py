@@ -19,6 +19,8 @@ from typing import Optional
 
 import torch
 import torch.nn.functional as F
+
+from .rows_linear import linear_rows
 from torch import Tensor, nn
 
 
@@ -73,18 +75,18 @@ def attention(
     # slice's backward allocates a zero tensor of the full size and copies into it
     if kv is not None:
         k, v, w_q, b_q = kv  # projected memory + this layer's query projection (split once by the decoder)
-        q = F.linear(query, w_q, b_q)
+        q = linear_rows(query, w_q, b_q)
     elif query is key:
         w_qk, w_v = torch.split(w, [2 * e, e], dim=0)
         b_qk, b_v = torch.split(b, [2 * e, e], dim=0)
-        q, k = F.linear(query, w_qk, b_qk).unflatten(-1, (2, e)).unbind(-2)
-        v = F.linear(value, w_v, b_v)
+        q, k = linear_rows(query, w_qk, b_qk).unflatten(-1, (2, e)).unbind(-2)
+        v = linear_rows(value, w_v, b_v)
     else:
         w_q, w_k, w_v = torch.split(w, [e, e, e], dim=0)
         b_q, b_k, b_v = torch.split(b, [e, e, e], dim=0)
-        q = F.linear(query, w_q, b_q)
-        k = F.linear(key, w_k, b_k)
-        v = F.linear(value, w_v, b_v)
+        q = linear_rows(query, w_q, b_q)
+        k = linear_rows(key, w_k, b_k)
+        v = linear_rows(value, w_v, b_v)
     mask = None
     if key_padding_mask is not None:
         mask = (~key_padding_mask)[:, None, None, :]  # True = attend
@@ -93,7 +95,7 @@ def attention(
         dropout_p=mha.dropout if training else 0.0,
     )
     out = out.transpose(1, 2).reshape(query.shape[0], query.shape[1], e)
-    return mha.out_proj(out)
+    return linear_rows(out, mha.out_proj.weight, mha.out_proj.bias)
 
 
 def _activation(name):
@@ -226,8 +228,8 @@ class TransformerDecoder(nn.Module):
             b_q, b_k, b_v = torch.split(mha.in_proj_bias, [e, e, e], dim=0)    # backward is a single cat
             wq.append(w_q), wk.append(w_k), wv.append(w_v), bq.append(b_q), bk.append(b_k), bv.append(b_v)
         n = len(self.layers)
-        k_all = F.linear(memory_pos, torch.cat(wk, dim=0), torch.cat(bk, dim=0)).unflatten(-1, (n, e)).unbind(-2)
-        v_all = F.linear(memory, torch.cat(wv, dim=0), torch.cat(bv, dim=0)).unflatten(-1, (n, e)).unbind(-2)
+        k_all = linear_rows(memory_pos, torch.cat(wk, dim=0), torch.cat(bk, dim=0)).unflatten(-1, (n, e)).unbind(-2)
+        v_all = linear_rows(memory, torch.cat(wv, dim=0), torch.cat(bv, dim=0)).unflatten(-1, (n, e)).unbind(-2)
         return list(zip(k_all, v_all, wq, bq))
 
     def forward(self, tgt, memory, memory_key_padding_mask=None, pos=None, query_pos=None):

@@ -13,6 +13,7 @@ import torch.nn.functional as F
 from torch.autograd import Function
 
 from .. import _lib
+from .rows_linear import linear_rows
 
 
 def _stream():
@@ -76,9 +77,9 @@ def conv1d_cl(x, conv):
     b, t, cin = x.shape
     w = conv.weight  # (C_out, C_in, K)
     if k == 1 and stride == 1 and pad == 0:
-        return F.linear(x, w[:, :, 0], conv.bias)
+        return linear_rows(x, w[:, :, 0], conv.bias)
     cols = im2col_cl(x, k, stride, pad)
-    y = F.linear(cols, w.reshape(w.shape[0], cin * k), conv.bias)
+    y = linear_rows(cols, w.reshape(w.shape[0], cin * k), conv.bias)
     return y.view(b, -1, w.shape[0])
 
 
