@@ -148,7 +148,7 @@ def kernel_rooflines(wl, device, c_feat=512, hidden=512):
         seed = torch.zeros(1, dtype=torch.int64, device=device)
         s_, o_, mu_, rs_ = torch.empty(R, E, **f32), torch.empty(R, E, **f32), torch.empty(R, **f32), torch.empty(R, **f32)
         dx_, dy16 = torch.empty(R, E, **f32), torch.empty(R, E, dtype=torch.bfloat16, device=device)
-        part = torch.empty(max(L.pcm_drln_blocks(R) * 2 * E, L.pcm_ffn_ln_blocks(R) * (3 * E + Fh)), **f32)
+        part = torch.empty(max(L.pcm_drln_blocks(R) * 3 * E, L.pcm_ffn_ln_blocks(R) * (3 * E + Fh)), **f32)
         dgb = torch.empty(3 * E + Fh, **f32)
 
         def drln_f():

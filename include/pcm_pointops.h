@@ -199,8 +199,9 @@ int pcm_sa_fused_backward_hip(int m, int n, int K, int H, int gf_is_bf16, const 
  * backward -- by one kernel each way.  x, out, s, dout, dx: (R,E) fp32; y, dy: (R,E) bf16 (y_is_bf16) or
  * fp32; E % 256 == 0, E <= 1024 (else PCM_ERR_UNSUPPORTED).  The dropout mask is a counter-based hash of
  * (*seed, site, element) recomputed in backward; `seed` is a DEVICE int64 so hipGraph replays draw new
- * masks; p_drop = 0 disables dropout (seed may be NULL).  backward also reduces dgamma | dbeta (2,E) from
- * `partial` (pcm_drln_blocks(R) x 2 x E floats of scratch). */
+ * masks; p_drop = 0 disables dropout (seed may be NULL).  backward also reduces dgamma | dbeta | dysum (3,E)
+ * from `partial` (pcm_drln_blocks(R) x 3 x E floats of scratch); dysum = column sums of dy, i.e. the bias
+ * gradient of the projection that produced y. */
 int pcm_drln_blocks(long R);
 int pcm_drln_forward_hip(long R, int E, int y_is_bf16, const float *x, const void *y, const float *gamma,
                          const float *beta, float eps, float p_drop, const long *seed, unsigned site,

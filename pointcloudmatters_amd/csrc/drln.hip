@@ -14,7 +14,8 @@
 // device memory so a captured hipGraph draws fresh masks on every replay.
 //   forward : s = x + keep * y / (1-p);  mu, rstd per row;  out = (s - mu) * rstd * gamma + beta
 //   backward: g = dout * gamma;  dx = rstd * (g - mean(g) - xhat * mean(g * xhat));  dy = keep * dx / (1-p)
-//             dgamma = sum_rows dout * xhat,  dbeta = sum_rows dout   (per-block partial rows, fp64 reduce)
+//             dgamma = sum_rows dout * xhat,  dbeta = sum_rows dout,  dysum = sum_rows dy  (per-block partial rows,
+//             fp64 reduce; dysum is the bias gradient of the projection that produced y)
 // Algorithmic bytes per element: forward 4 (x) + 2 (y) + 4 (s) + 4 (out) = 14; backward 4 + 4 + 4 + 2 = 14.
 #include "pcm_elem.hpp"
 
@@ -91,19 +92,19 @@ __global__ __launch_bounds__(kBlock) void pcm_drln_bwd_kernel(long R, const floa
                                                               float *__restrict__ dx, T *__restrict__ dy, float *__restrict__ partial)
 {
     constexpr int E = NCH * 256;
-    __shared__ float lds[kWaves][2][E];
+    __shared__ float lds[kWaves][3][E];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long wave0 = (long)blockIdx.x * kWaves + wave, nwaves = (long)gridDim.x * kWaves;
     const bool drop = p_drop > 0.f;
     const uint64_t seed = drop ? (uint64_t)seed_ptr[0] : 0ull;
     const uint32_t thr = drop ? (uint32_t)((double)p_drop * 4294967296.0) : 0u;
     const float scale = drop ? 1.f / (1.f - p_drop) : 1.f;
-    float g[NCH][4], dg[NCH][4], db[NCH][4];
+    float g[NCH][4], dg[NCH][4], db[NCH][4], dys[NCH][4];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         load4<float>(gamma + c * 256 + lane * 4, g[c]);
 #pragma unroll
-        for (int v = 0; v < 4; ++v) dg[c][v] = 0.f, db[c][v] = 0.f;
+        for (int v = 0; v < 4; ++v) dg[c][v] = 0.f, db[c][v] = 0.f, dys[c][v] = 0.f;
     }
     for (long r = wave0; r < R; r += nwaves) {
         const float mu = mean[r], rs = rstd[r];
@@ -134,6 +135,7 @@ __global__ __launch_bounds__(kBlock) void pcm_drln_bwd_kernel(long R, const floa
             for (int v = 0; v < 4; ++v) {
                 o[v] = rs * (gd[c][v] - m1 - xh[c][v] * m2);
                 oy[v] = (keep_elem(seed, site, (uint64_t)(e0 + v), thr)) ? o[v] * scale : 0.f;
+                dys[c][v] += oy[v];  // column sums of dy = the bias gradient of the projection that produced y
             }
             store4<float>(dx + e0, o);
             store4<T>(dy + e0, oy);
@@ -145,14 +147,15 @@ __global__ __launch_bounds__(kBlock) void pcm_drln_bwd_kernel(long R, const floa
         for (int v = 0; v < 4; ++v) {
             lds[wave][0][c * 256 + lane * 4 + v] = dg[c][v];
             lds[wave][1][c * 256 + lane * 4 + v] = db[c][v];
+            lds[wave][2][c * 256 + lane * 4 + v] = dys[c][v];
         }
     __syncthreads();
-    for (int e = threadIdx.x; e < 2 * E; e += kBlock) {
+    for (int e = threadIdx.x; e < 3 * E; e += kBlock) {
         const int t = e / E, h = e % E;
         float acc = 0.f;
 #pragma unroll
         for (int w = 0; w < kWaves; ++w) acc += lds[w][t][h];
-        partial[((size_t)blockIdx.x * 2 + t) * E + h] = acc;
+        partial[((size_t)blockIdx.x * 3 + t) * E + h] = acc;
     }
 }
 
@@ -228,6 +231,6 @@ extern "C" int pcm_drln_backward_hip(long R, int E, int y_is_bf16, const float *
         if (n == 1) PCM_B(float, 1); else if (n == 2) PCM_B(float, 2); else if (n == 3) PCM_B(float, 3); else PCM_B(float, 4);
     }
 #undef PCM_B
-    hipLaunchKernelGGL(pcm_drln_reduce_kernel, dim3((2 * E + 63) / 64), dim3(512), 0, st, grid, 2 * E, partial, dgamma_dbeta);
+    hipLaunchKernelGGL(pcm_drln_reduce_kernel, dim3((3 * E + 63) / 64), dim3(512), 0, st, grid, 3 * E, partial, dgamma_dbeta);
     return PCM_LAUNCH_STATUS();
 }

@@ -53,7 +53,6 @@ def current():
 class _DRLN(Function):
     @staticmethod
     def forward(ctx, x, y, gamma, beta, eps, p_drop, seed, site):
-        L = _lib.load()
         shape = x.shape
         E = shape[-1]
         x2 = x.reshape(-1, E)
@@ -62,43 +61,105 @@ class _DRLN(Function):
             x2 = x2.contiguous()
         if not y2.is_contiguous():
             y2 = y2.contiguous()
-        R = x2.shape[0]
-        dev = x.device
-        with torch.cuda.device(dev):
-            s = torch.empty_like(x2)
-            out = torch.empty_like(x2)
-            mean = torch.empty(R, dtype=torch.float32, device=dev)
-            rstd = torch.empty(R, dtype=torch.float32, device=dev)
-            rc = L.pcm_drln_forward_hip(R, E, 1 if y2.dtype == torch.bfloat16 else 0, x2.data_ptr(), y2.data_ptr(), gamma.data_ptr(),
-                                        beta.data_ptr(), float(eps), float(p_drop), seed.data_ptr() if seed is not None else 0,
-                                        int(site), s.data_ptr(), out.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                        torch.cuda.current_stream().cuda_stream)
-        _lib.check(rc, "pcm_drln_forward_hip")
+        out, s, mean, rstd = _drln_forward(x2, y2, gamma, beta, eps, p_drop, seed, site)
         ctx.save_for_backward(s, mean, rstd, gamma)
         ctx.meta = (shape, y.dtype, float(p_drop), seed, int(site))
         return out.view(shape)
 
     @staticmethod
     def backward(ctx, dout):
-        L = _lib.load()
         s, mean, rstd, gamma = ctx.saved_tensors
         shape, ydtype, p_drop, seed, site = ctx.meta
-        R, E = s.shape
-        dev = s.device
-        d2 = dout.reshape(R, E)
-        if d2.dtype != torch.float32 or not d2.is_contiguous():
-            d2 = d2.float().contiguous()
-        with torch.cuda.device(dev):
-            dx = torch.empty_like(s)
-            dy = torch.empty(R, E, dtype=ydtype, device=dev)
-            partial = torch.empty(L.pcm_drln_blocks(R) * 2 * E, dtype=torch.float32, device=dev)
-            dgb = torch.empty(2, E, dtype=torch.float32, device=dev)
-            rc = L.pcm_drln_backward_hip(R, E, 1 if ydtype == torch.bfloat16 else 0, d2.data_ptr(), s.data_ptr(), mean.data_ptr(),
-                                         rstd.data_ptr(), gamma.data_ptr(), p_drop, seed.data_ptr() if seed is not None else 0, site,
-                                         dx.data_ptr(), dy.data_ptr(), partial.data_ptr(), dgb.data_ptr(),
-                                         torch.cuda.current_stream().cuda_stream)
-        _lib.check(rc, "pcm_drln_backward_hip")
-        return dx.view(shape), dy.view(shape), dgb[0], dgb[1], None, None, None, None
+        dx, dy, sums = _drln_backward(dout, s, mean, rstd, gamma, ydtype, p_drop, seed, site)
+        return dx.view(shape), dy.view(shape), sums[0], sums[1], None, None, None, None
+
+
+def _drln_forward(x2, y2, gamma, beta, eps, p_drop, seed, site):
+    L = _lib.load()
+    R, E = x2.shape
+    dev = x2.device
+    with torch.cuda.device(dev):
+        s = torch.empty_like(x2)
+        out = torch.empty_like(x2)
+        mean = torch.empty(R, dtype=torch.float32, device=dev)
+        rstd = torch.empty(R, dtype=torch.float32, device=dev)
+        rc = L.pcm_drln_forward_hip(R, E, 1 if y2.dtype == torch.bfloat16 else 0, x2.data_ptr(), y2.data_ptr(), gamma.data_ptr(),
+                                    beta.data_ptr(), float(eps), float(p_drop), seed.data_ptr() if seed is not None else 0,
+                                    int(site), s.data_ptr(), out.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                    torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "pcm_drln_forward_hip")
+    return out, s, mean, rstd
+
+
+def _drln_backward(dout, s, mean, rstd, gamma, ydtype, p_drop, seed, site):
+    """-> dx (R,E) fp32, dy (R,E) in ydtype, sums (3,E) fp32 = dgamma | dbeta | column sums of dy."""
+    L = _lib.load()
+    R, E = s.shape
+    dev = s.device
+    d2 = dout.reshape(R, E)
+    if d2.dtype != torch.float32 or not d2.is_contiguous():
+        d2 = d2.float().contiguous()
+    with torch.cuda.device(dev):
+        dx = torch.empty_like(s)
+        dy = torch.empty(R, E, dtype=ydtype, device=dev)
+        partial = torch.empty(L.pcm_drln_blocks(R) * 3 * E, dtype=torch.float32, device=dev)
+        sums = torch.empty(3, E, dtype=torch.float32, device=dev)
+        rc = L.pcm_drln_backward_hip(R, E, 1 if ydtype == torch.bfloat16 else 0, d2.data_ptr(), s.data_ptr(), mean.data_ptr(),
+                                     rstd.data_ptr(), gamma.data_ptr(), p_drop, seed.data_ptr() if seed is not None else 0, site,
+                                     dx.data_ptr(), dy.data_ptr(), partial.data_ptr(), sums.data_ptr(),
+                                     torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "pcm_drln_backward_hip")
+    return dx, dy, sums
+
+
+class _ProjDRLN(Function):
+    """out = LayerNorm(x + dropout(a @ W^T + b)): the attention output projection, the residual add and the norm as one
+    autograd node.  Forward = one GEMM + the drln kernel; backward = the drln kernel (which also yields the column
+    sums of dy = the projection's bias gradient, saving the framework's strided reduction), one GEMM for da and a
+    split-K product for dW (rows_linear.weight_grad)."""
+
+    @staticmethod
+    def forward(ctx, a, weight, bias, x, gamma, beta, eps, p_drop, seed, site):
+        shape = x.shape
+        E = shape[-1]
+        if torch.is_autocast_enabled("cuda"):
+            dt = torch.get_autocast_dtype("cuda")
+            ac, wc, bc = a.to(dt), weight.to(dt), bias.to(dt)
+        else:
+            ac, wc, bc = a, weight, bias
+        a2 = ac.reshape(-1, ac.shape[-1])
+        with torch.autocast("cuda", enabled=False):
+            y2 = torch.nn.functional.linear(a2, wc, bc)
+        x2 = x.reshape(-1, E)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        out, s, mean, rstd = _drln_forward(x2, y2, gamma, beta, eps, p_drop, seed, site)
+        ctx.save_for_backward(a2, wc, s, mean, rstd, gamma)
+        ctx.meta = (shape, a.shape, a.dtype, weight.dtype, bias.dtype, y2.dtype, float(p_drop), seed, int(site))
+        return out.view(shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        from .rows_linear import weight_grad
+
+        a2, wc, s, mean, rstd, gamma = ctx.saved_tensors
+        shape, ashape, adt, wdt, bdt, ydt, p_drop, seed, site = ctx.meta
+        dx, dy, sums = _drln_backward(dout, s, mean, rstd, gamma, ydt, p_drop, seed, site)
+        with torch.autocast("cuda", enabled=False):
+            da = (dy @ wc).view(ashape)
+            if da.dtype != adt:
+                da = da.to(adt)
+            dw = weight_grad(dy, a2, wdt)
+            db = sums[2].to(bdt)
+        return da, dw, db, dx.view(shape), sums[0], sums[1], None, None, None, None
+
+
+def proj_drln(a, linear, x, norm, dropout):
+    """norm(x + dropout(linear(a))); the caller checked ``drln_supported(x, <linear output>, norm)``."""
+    p = dropout.p if (dropout is not None and dropout.training) else 0.0
+    ctx = _ACTIVE
+    return _ProjDRLN.apply(a, linear.weight, linear.bias, x, norm.weight, norm.bias, norm.eps, p,
+                           ctx.seed if p > 0 else None, ctx.next_site())
 
 
 def drln_supported(x, y, norm):

@@ -45,6 +45,26 @@ def _add_norm(norm: nn.Module, dropout: nn.Module, x: Tensor, y: Tensor) -> Tens
     return norm(_residual(x, dropout(y)))
 
 
+def _attn_add_norm(norm: nn.Module, dropout: nn.Module, x: Tensor, mha: nn.MultiheadAttention, *args, **kwargs) -> Tensor:
+    """norm(x + dropout(mha(...))): with a FusedContext active the output projection, the residual add and the norm
+    are one autograd node (fused_ops.proj_drln); otherwise the plain chain."""
+    from . import fused_ops
+
+    ctx_on = fused_ops.current() is not None and x.is_cuda and x.dtype == torch.float32
+    if ctx_on:
+        a = attention(mha, *args, project=False, **kwargs)
+        ydt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else a.dtype
+        if fused_ops.drln_supported(x, _FakeY(x.shape, ydt), norm) and mha.out_proj.bias is not None:
+            return fused_ops.proj_drln(a, mha.out_proj, x, norm, dropout)
+        return _add_norm(norm, dropout, x, linear_rows(a, mha.out_proj.weight, mha.out_proj.bias))
+    return _add_norm(norm, dropout, x, attention(mha, *args, **kwargs))
+
+
+class _FakeY:  # shape / dtype carrier for drln_supported
+    def __init__(self, shape, dtype):
+        self.shape, self.dtype = shape, dtype
+
+
 def _ffn_norm(layer, norm: nn.Module, dropout_out: nn.Module, x: Tensor) -> Tensor:
     """norm(x + dropout_out(linear2(dropout(act(linear1(x)))))): one fused HIP kernel each way for the shipped
     relu / dim_feedforward = 32 layers when a FusedContext is active, framework ops otherwise."""
@@ -63,6 +83,7 @@ def attention(
     key_padding_mask: Optional[Tensor] = None,
     training: bool = False,
     kv: Optional[tuple] = None,
+    project: bool = True,
 ) -> Tensor:
     """Multi-head attention with the parameters of ``mha``; inputs (B, L, E) / (B, S, E).
     ``key_padding_mask`` (B, S) bool, True = ignore (nn.MultiheadAttention convention).
@@ -95,6 +116,8 @@ def attention(
         dropout_p=mha.dropout if training else 0.0,
     )
     out = out.transpose(1, 2).reshape(query.shape[0], query.shape[1], e)
+    if not project:
+        return out  # the caller fuses out_proj with the residual add + norm (_attn_add_norm)
     return linear_rows(out, mha.out_proj.weight, mha.out_proj.bias)
 
 
@@ -138,7 +161,7 @@ class TransformerEncoderLayer(nn.Module):
             src = _residual(src, self.dropout1(attention(self.self_attn, qk, qk, y, src_key_padding_mask, self.training)))
             return _residual(src, self.dropout2(self._ffn(self.norm2(src))))
         qk = _add_pos(src, pos)
-        src = _add_norm(self.norm1, self.dropout1, src, attention(self.self_attn, qk, qk, src, src_key_padding_mask, self.training))
+        src = _attn_add_norm(self.norm1, self.dropout1, src, self.self_attn, qk, qk, src, src_key_padding_mask, self.training)
         return _ffn_norm(self, self.norm2, self.dropout2, src)
 
 
@@ -177,9 +200,9 @@ class TransformerDecoderLayer(nn.Module):
                 attention(ca, _add_pos(y, query_pos), memory_pos, memory, memory_key_padding_mask, self.training, kv=kv)))
             return _residual(tgt, self.dropout3(self._ffn(self.norm3(tgt))))
         qk = _add_pos(tgt, query_pos)
-        tgt = _add_norm(self.norm1, self.dropout1, tgt, attention(self.self_attn, qk, qk, tgt, None, self.training))
-        tgt = _add_norm(self.norm2, self.dropout2, tgt,
-                        attention(ca, _add_pos(tgt, query_pos), memory_pos, memory, memory_key_padding_mask, self.training, kv=kv))
+        tgt = _attn_add_norm(self.norm1, self.dropout1, tgt, self.self_attn, qk, qk, tgt, None, self.training)
+        tgt = _attn_add_norm(self.norm2, self.dropout2, tgt, ca, _add_pos(tgt, query_pos), memory_pos, memory,
+                             memory_key_padding_mask, self.training, kv=kv)
         return _ffn_norm(self, self.norm3, self.dropout3, tgt)
 
 
