@@ -284,6 +284,14 @@ int pcm_bn_relu_forward_hip(long n, int C, int is_bf16, const void *y, const flo
 int pcm_bn_relu_backward_hip(long n, int C, int is_bf16, const void *y, const void *dz, const float *stat,
                              float *partial, float *sums, void *dy, void *stream);
 
+/* ---- GPU-side GridSamplePCD keys (the data-path step before the hot path) --------------------------------
+ * replaces the per-cloud NumPy arithmetic of src/data/components/transformpcd.py:684-701, 776-790 for a packed
+ * batch: gmin (b,3) = per-cloud min of floor(coord / grid_size) (float64 division, as NumPy >= 2 promotes it);
+ * grid_coord (n,3) int64 = floor(...) - gmin[cloud]; key (n) = FNV-1a 64 of grid_coord (uint64 bit pattern);
+ * cloud (n) = cloud index of each point.  Bit-exact with the reference's functions. */
+int pcm_voxel_keys_hip(int n, int b, const float *coord, const int *offset, double grid_size, int *gmin,
+                       long *grid_coord, long *key, int *cloud, void *stream);
+
 /* ---- training-step tail: global-norm clip + AdamW over one flat fp32 buffer ---------------------
  * replaces the torch passes the reference runs per step: clip_grad_norm_ (configs/trainer/ddp.yaml:12)
  * and AdamW.step (src/models/maniskill2_act_bc_module.py:347-367).  p, g, m, v: n floats each,

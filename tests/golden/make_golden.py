@@ -392,12 +392,40 @@ def golden_rollout(ref):
     print("rollout_ref.npz ok; |action_pred| max", float(np.abs(traj).max()))
 
 
+def golden_gridsample(ref):
+    """GridSamplePCD (fnv, train, return_grid_coord) + NormalizeColorPCD from transformpcd.py, run as shipped on three
+    seeded clouds (NumPy 2.2.6 here: coord / np.array(grid_size) promotes to float64)."""
+    tp = _load("ref_transformpcd", f"{REF}/src/data/components/transformpcd.py")
+    rng = np.random.default_rng(123)
+    fx = {"grid_size": np.array(0.005)}
+    gs = tp.GridSamplePCD(grid_size=0.005, hash_type="fnv", mode="train", keys=("coord", "color"), return_grid_coord=True)
+    norm = tp.NormalizeColorPCD()
+    for i, n in enumerate((3000, 1777, 4096)):
+        coord = np.empty((n, 3), dtype=np.float32)
+        coord[:, :2] = rng.uniform(-0.12, 0.12, (n, 2))
+        coord[:, 2] = rng.uniform(0.005, 0.1, n)
+        coord[n // 2:] = coord[: n - n // 2] + rng.uniform(0, 0.004, (n - n // 2, 3)).astype(np.float32)  # crowd the voxels
+        color = rng.integers(0, 256, (n, 3)).astype(np.float32)
+        scaled = coord / np.array(0.005)
+        grid_all = np.floor(scaled).astype(int)
+        grid_all -= grid_all.min(0)
+        fx[f"{i}.coord"], fx[f"{i}.color"] = coord, color
+        fx[f"{i}.grid_all"] = grid_all.astype(np.int64)
+        fx[f"{i}.key_all"] = tp.GridSamplePCD.fnv_hash_vec(grid_all)
+        np.random.seed(1000 + i)
+        out = norm(gs({"coord": coord.copy(), "color": color.copy()}))
+        fx[f"{i}.out.coord"], fx[f"{i}.out.color"] = out["coord"], out["color"]
+        fx[f"{i}.out.grid_coord"] = out["grid_coord"].astype(np.int64)
+    np.savez_compressed(os.path.join(OUT, "gridsample_ref.npz"), **fx)
+    print("gridsample_ref.npz ok:", [int(fx[f"{i}.out.coord"].shape[0]) for i in range(3)], "voxels")
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "run this in the build container (needs /root/reference)"
     torch.set_num_threads(1)
     ref = install_reference()
     only = set(sys.argv[1:])  # e.g. `make_golden.py rollout` regenerates one fixture
     for name, fn in (("act", golden_act), ("grouping", golden_grouping), ("misc", golden_misc), ("dp", golden_dp),
-                     ("rollout", golden_rollout)):
+                     ("rollout", golden_rollout), ("gridsample", golden_gridsample)):
         if not only or name in only:
             fn(ref)
