@@ -292,6 +292,19 @@ int pcm_bn_relu_backward_hip(long n, int C, int is_bf16, const void *y, const vo
 int pcm_voxel_keys_hip(int n, int b, const float *coord, const int *offset, double grid_size, int *gmin,
                        long *grid_coord, long *key, int *cloud, void *stream);
 
+/* ---- glue around the attention in-projection (src/models/components/act/transformer.py:244-249, 318-323) ------
+ * pcm_add_cast2_hip : sum_bf16 = bf16(x + pos), x_bf16 = bf16(x) (x_bf16 may be NULL); x has n floats, pos has pos_n
+ *                     floats and is repeated (n % pos_n == 0: a position table broadcast over the batch);
+ * pcm_add2_cast_hip : out = f32(a) + f32(b) for two bf16 arrays of n elements;
+ * pcm_colsum_hip    : out[t*C + c] = sum over rows of g_t[row*ld_t + c] for ntensors <= 3 matrices of the same dtype
+ *                     (bias gradients of the q / k / v projections); `partial` = pcm_colsum_slots(rows, C) * ntensors * C
+ *                     floats; out is fp32 or bf16 (out_is_bf16).  C % 4 == 0, C <= 1024; n, pos_n multiples of 4. */
+int pcm_add_cast2_hip(long n, long pos_n, const float *x, const float *pos, void *sum_bf16, void *x_bf16, void *stream);
+int pcm_add2_cast_hip(long n, const void *a_bf16, const void *b_bf16, float *out, void *stream);
+int pcm_colsum_slots(long rows, int C);
+int pcm_colsum_hip(long rows, int C, int ntensors, int in_is_bf16, const void *g0, long ld0, const void *g1, long ld1,
+                   const void *g2, long ld2, float *partial, int out_is_bf16, void *out, void *stream);
+
 /* ---- training-step tail: global-norm clip + AdamW over one flat fp32 buffer ---------------------
  * replaces the torch passes the reference runs per step: clip_grad_norm_ (configs/trainer/ddp.yaml:12)
  * and AdamW.step (src/models/maniskill2_act_bc_module.py:347-367).  p, g, m, v: n floats each,

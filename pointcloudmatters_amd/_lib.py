@@ -61,6 +61,10 @@ SIGNATURES = {
     "pcm_bn_relu_forward_hip": [ctypes.c_long, _i, _i, _P, _P, _P, _f, _f, _P, _P, _i, _P, _P, _P, _P, _P],
     "pcm_bn_relu_backward_hip": [ctypes.c_long, _i, _i, _P, _P, _P, _P, _P, _P, _P],
     "pcm_voxel_keys_hip": [_i, _i, _P, _P, ctypes.c_double, _P, _P, _P, _P, _P],
+    "pcm_add_cast2_hip": [ctypes.c_long, ctypes.c_long, _P, _P, _P, _P, _P],
+    "pcm_add2_cast_hip": [ctypes.c_long, _P, _P, _P, _P],
+    "pcm_colsum_slots": [ctypes.c_long, _i],
+    "pcm_colsum_hip": [ctypes.c_long, _i, _i, _i, _P, ctypes.c_long, _P, ctypes.c_long, _P, ctypes.c_long, _P, _i, _P, _P],
     "pcm_optim_partials_capacity": [],
     "pcm_grad_sumsq_hip": [ctypes.c_long, _P, _P, _P, _P],
     "pcm_adamw_flat_hip": [ctypes.c_long, _P, _P, _P, _P, _P, _P, _i, _P, _P, _P],

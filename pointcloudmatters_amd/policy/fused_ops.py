@@ -248,3 +248,91 @@ def ffn_ln(x, linear1, linear2, norm, dropout_hidden, dropout_out):
     ctx = _ACTIVE
     return _FFNLN.apply(x, linear1.weight, linear1.bias, linear2.weight, linear2.bias, norm.weight, norm.bias, norm.eps, pa, pb,
                         ctx.seed if (pa > 0 or pb > 0) else None, ctx.next_site(), ctx.next_site())
+
+
+class _SelfAttnInProj(Function):
+    """q, k = split(linear(x + pos, W[:2E], b[:2E])), v = linear(x, W[2E:], b[2E:]) for a packed in_proj (3E, E) under
+    bf16 autocast, as ONE autograd node: csrc/tokens.hip does the add + casts (1 launch forward, 1 backward) and the
+    three bias gradients (2 launches); weight gradients are split-K products written straight into the packed (3E, E)
+    gradient, so no cat / split-backward kernels run."""
+
+    @staticmethod
+    def forward(ctx, x, pos, w, b):
+        L = _lib.load()
+        shape = x.shape
+        E = shape[-1]
+        x2 = x.reshape(-1, E)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        rows = x2.shape[0]
+        posc = pos.expand(pos.shape[0], *shape[1:]) if pos.dim() == x.dim() and pos.shape[1:] != shape[1:] else pos
+        posc = posc.contiguous()
+        dev = x.device
+        bf = torch.bfloat16
+        wc = w if w.dtype == bf else w.to(bf)
+        bc = b if b.dtype == bf else b.to(bf)
+        with torch.cuda.device(dev):
+            qk_in = torch.empty(rows, E, dtype=bf, device=dev)
+            v_in = torch.empty(rows, E, dtype=bf, device=dev)
+            rc = L.pcm_add_cast2_hip(x2.numel(), posc.numel(), x2.data_ptr(), posc.data_ptr(), qk_in.data_ptr(), v_in.data_ptr(),
+                                     torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "pcm_add_cast2_hip")
+        with torch.autocast("cuda", enabled=False):
+            qk = torch.nn.functional.linear(qk_in, wc[: 2 * E], bc[: 2 * E]).view(*shape[:-1], 2, E)
+            v = torch.nn.functional.linear(v_in, wc[2 * E:], bc[2 * E:]).view(shape)
+        ctx.save_for_backward(qk_in, v_in, wc)
+        ctx.meta = (shape, pos.shape, w.dtype, b.dtype, pos.requires_grad)
+        q, k = qk.unbind(-2)
+        return q, k, v
+
+    @staticmethod
+    def backward(ctx, dq, dk, dv):
+        from .rows_linear import weight_grad
+
+        L = _lib.load()
+        qk_in, v_in, wc = ctx.saved_tensors
+        shape, pos_shape, wdt, bdt, pos_grad = ctx.meta
+        E = shape[-1]
+        rows = qk_in.shape[0]
+        dev = qk_in.device
+        bf = torch.bfloat16
+        st = torch.cuda.current_stream().cuda_stream
+        with torch.cuda.device(dev), torch.autocast("cuda", enabled=False):
+            dqk = torch.stack((dq, dk), dim=-2).reshape(rows, 2 * E)
+            if dqk.dtype != bf:
+                dqk = dqk.to(bf)
+            dv2 = dv.reshape(rows, E)
+            if dv2.dtype != bf or not dv2.is_contiguous():
+                dv2 = dv2.to(bf).contiguous()
+            d_qk_in = dqk @ wc[: 2 * E]
+            d_v_in = dv2 @ wc[2 * E:]
+            dx = torch.empty(rows, E, dtype=torch.float32, device=dev)
+            rc = L.pcm_add2_cast_hip(dx.numel(), d_qk_in.data_ptr(), d_v_in.data_ptr(), dx.data_ptr(), st)
+            _lib.check(rc, "pcm_add2_cast_hip")
+            dw = torch.empty(3 * E, E, dtype=wdt, device=dev)
+            weight_grad(dqk, qk_in, wdt, out=dw[: 2 * E])
+            weight_grad(dv2, v_in, wdt, out=dw[2 * E:])
+            db = torch.empty(3 * E, dtype=bdt, device=dev)
+            partial = torch.empty(L.pcm_colsum_slots(rows, E) * 3 * E, dtype=torch.float32, device=dev)
+            es = dqk.element_size()
+            rc = L.pcm_colsum_hip(rows, E, 3, 1, dqk.data_ptr(), 2 * E, dqk.data_ptr() + E * es, 2 * E, dv2.data_ptr(), E,
+                                  partial.data_ptr(), int(bdt == bf), db.data_ptr(), st)
+            _lib.check(rc, "pcm_colsum_hip")
+            dpos = None
+            if pos_grad:
+                dpos = d_qk_in.float().view(shape).sum_to_size(pos_shape)
+        return dx.view(shape), dpos, dw, db
+
+
+def self_attn_in_proj_supported(x, pos, mha):
+    e = x.shape[-1]
+    return (_ACTIVE is not None and x.is_cuda and x.dtype == torch.float32 and pos is not None and pos.dtype == torch.float32
+            and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
+            and mha.in_proj_weight is not None and mha.in_proj_bias is not None and e % 4 == 0 and e <= 1024
+            and mha.in_proj_bias.dtype in (torch.float32, torch.bfloat16) and x.numel() % pos.numel() == 0 and pos.dim() == x.dim()
+            and (pos.shape[0] in (1, x.shape[0])) and pos.shape[1:] == x.shape[1:])
+
+
+def self_attn_in_proj(x, pos, mha):
+    """q, k, v (each (B, S, E) bf16) for self-attention with position-augmented queries / keys."""
+    return _SelfAttnInProj.apply(x, pos, mha.in_proj_weight, mha.in_proj_bias)

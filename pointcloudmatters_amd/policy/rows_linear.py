@@ -25,19 +25,29 @@ def _splits(rows):
     return s
 
 
-def weight_grad(go, x, out_dtype):
-    """dW = go^T @ x for go (rows, m), x (rows, k) -> (m, k) in `out_dtype`."""
+def weight_grad(go, x, out_dtype, out=None):
+    """dW = go^T @ x for go (rows, m), x (rows, k) -> (m, k) in `out_dtype` (written into `out`, a contiguous (m, k)
+    tensor or row-slice of a packed gradient, when given)."""
     rows, m = go.shape
     k = x.shape[1]
     if rows < MIN_ROWS or m * k > 1024 * 1024:
-        return (go.t() @ x).to(out_dtype)
+        dw = go.t() @ x
+        if out is not None:
+            return out.copy_(dw)
+        return dw.to(out_dtype)
     s = _splits(rows)
     chunk = rows // s
     main = s * chunk
     part = torch.bmm(go[:main].view(s, chunk, m).transpose(1, 2), x[:main].view(s, chunk, k))
+    if main == rows and out is not None:
+        return torch.sum(part, dim=0, out=out)  # fp32 accumulation inside the reduction, rounded once to out's dtype
+    if main == rows and out_dtype == part.dtype:
+        return part.sum(dim=0)
     dw = part.sum(dim=0, dtype=torch.float32)
     if main < rows:  # fewer than s leftover rows
         dw = dw + (go[main:].t() @ x[main:]).float()
+    if out is not None:
+        return out.copy_(dw)
     return dw.to(out_dtype)
 
 

@@ -84,6 +84,7 @@ def attention(
     training: bool = False,
     kv: Optional[tuple] = None,
     project: bool = True,
+    qk_parts: Optional[tuple] = None,
 ) -> Tensor:
     """Multi-head attention with the parameters of ``mha``; inputs (B, L, E) / (B, S, E).
     ``key_padding_mask`` (B, S) bool, True = ignore (nn.MultiheadAttention convention).
@@ -94,7 +95,20 @@ def attention(
     w, b = mha.in_proj_weight, mha.in_proj_bias
     # torch.split / unbind instead of slicing: their backward is ONE cat / stack kernel, whereas every
     # slice's backward allocates a zero tensor of the full size and copies into it
-    if kv is not None:
+    projected = False
+    if qk_parts is not None:  # self-attention with q = k = x + pos, v = x
+        from . import fused_ops
+
+        x_in, pos_in = qk_parts
+        if fused_ops.self_attn_in_proj_supported(x_in, pos_in, mha):
+            q, k, v = fused_ops.self_attn_in_proj(x_in, pos_in, mha)  # one autograd node (csrc/tokens.hip)
+            query, projected = x_in, True
+        else:
+            query = key = _add_pos(x_in, pos_in)
+            value = x_in
+    if projected:
+        pass
+    elif kv is not None:
         k, v, w_q, b_q = kv  # projected memory + this layer's query projection (split once by the decoder)
         q = linear_rows(query, w_q, b_q)
     elif query is key:
@@ -160,8 +174,8 @@ class TransformerEncoderLayer(nn.Module):
             qk = _add_pos(y, pos)
             src = _residual(src, self.dropout1(attention(self.self_attn, qk, qk, y, src_key_padding_mask, self.training)))
             return _residual(src, self.dropout2(self._ffn(self.norm2(src))))
-        qk = _add_pos(src, pos)
-        src = _attn_add_norm(self.norm1, self.dropout1, src, self.self_attn, qk, qk, src, src_key_padding_mask, self.training)
+        src = _attn_add_norm(self.norm1, self.dropout1, src, self.self_attn, None, None, None, src_key_padding_mask, self.training,
+                             qk_parts=(src, pos))
         return _ffn_norm(self, self.norm2, self.dropout2, src)
 
 
@@ -199,8 +213,8 @@ class TransformerDecoderLayer(nn.Module):
             tgt = _residual(tgt, self.dropout2(
                 attention(ca, _add_pos(y, query_pos), memory_pos, memory, memory_key_padding_mask, self.training, kv=kv)))
             return _residual(tgt, self.dropout3(self._ffn(self.norm3(tgt))))
-        qk = _add_pos(tgt, query_pos)
-        tgt = _attn_add_norm(self.norm1, self.dropout1, tgt, self.self_attn, qk, qk, tgt, None, self.training)
+        tgt = _attn_add_norm(self.norm1, self.dropout1, tgt, self.self_attn, None, None, None, None, self.training,
+                             qk_parts=(tgt, query_pos))
         tgt = _attn_add_norm(self.norm2, self.dropout2, tgt, ca, _add_pos(tgt, query_pos), memory_pos, memory,
                              memory_key_padding_mask, self.training, kv=kv)
         return _ffn_norm(self, self.norm3, self.dropout3, tgt)
