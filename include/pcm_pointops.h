@@ -305,6 +305,26 @@ int pcm_colsum_slots(long rows, int C);
 int pcm_colsum_hip(long rows, int C, int ntensors, int in_is_bf16, const void *g0, long ld0, const void *g1, long ld1,
                    const void *g2, long ld2, float *partial, int out_is_bf16, void *out, void *stream);
 
+/* ---- multi-head attention for short query sequences (L <= 128 queries, head_dim 64), MFMA -----------------------
+ * replaces nn.MultiheadAttention's scaled-dot-product core for the CVAE encoder and the decoder of
+ * src/models/components/act/transformer.py:225-262, 296-346 (100-102 queries; 18 of 22 attention calls per step).
+ * q (B,L,.), k, v (B,S,.): bf16, element strides *_bs (batch) / *_ls (row), head h occupies columns [64h, 64h+64);
+ * strides multiples of 8.  key_padding_mask (B,S) bytes, non-zero = ignore, or NULL.  out (B,L,H*64) bf16 contiguous,
+ * lse (B,H,L) fp32.  Dropout on the attention weights: p_drop with a DEVICE seed + call site (as pcm_drln_*).
+ * backward: dout (B,L,H*64) bf16 contiguous; dq/dk/dv bf16 with their own strides (multiples of 8), written fully; a (batch, head) whose dout is all zero
+ * takes a fast path that writes exact zeros. */
+int pcm_attn_small_supported(int L, int S, int head_dim);
+int pcm_attn_small_forward_hip(int B, int H, int L, int S, const void *q, long q_bs, long q_ls, const void *k,
+                               long k_bs, long k_ls, const void *v, long v_bs, long v_ls,
+                               const unsigned char *key_padding_mask, float scale, float p_drop, const long *seed,
+                               unsigned site, void *out, float *lse, void *stream);
+int pcm_attn_small_backward_hip(int B, int H, int L, int S, const void *q, long q_bs, long q_ls, const void *k,
+                                long k_bs, long k_ls, const void *v, long v_bs, long v_ls,
+                                const unsigned char *key_padding_mask, float scale, float p_drop, const long *seed,
+                                unsigned site, const void *out, const void *dout, const float *lse, void *dq,
+                                long dq_bs, long dq_ls, void *dk, long dk_bs, long dk_ls, void *dv, long dv_bs,
+                                long dv_ls, void *stream);
+
 /* ---- training-step tail: global-norm clip + AdamW over one flat fp32 buffer ---------------------
  * replaces the torch passes the reference runs per step: clip_grad_norm_ (configs/trainer/ddp.yaml:12)
  * and AdamW.step (src/models/maniskill2_act_bc_module.py:347-367).  p, g, m, v: n floats each,

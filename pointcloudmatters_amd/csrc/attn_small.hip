@@ -1,0 +1,551 @@
+// attn_small.hip -- multi-head attention for SHORT query sequences (L <= 128, head_dim 64), forward and backward, on the
+// gfx950 matrix cores.
+//
+// 18 of the 22 attention calls of an ACT training step have 100-102 queries: the CVAE encoder (102 tokens), the
+// decoder's self-attention (100 queries) and its cross-attention (100 queries x 515 memory tokens)
+// (/root/reference/src/models/components/act/transformer.py:225-262, 296-346 via nn.MultiheadAttention).  The
+// framework's flash kernels are sized for long sequences and spend 25 us forward / ~105 us backward on each of them;
+// the arithmetic is 0.16 GFLOP.  Here a workgroup owns 32 query columns of one (batch, head) -- 256+ workgroups -- and
+// its 4 waves split the key tiles (32 keys each, staged in wave-private LDS, next tile prefetched in registers) with
+// private online-softmax states that are merged once at the end; everything on v_mfma_f32_32x32x8_bf16_1k.
+//
+// Layout trick (no LDS round trip between the two GEMMs of a tile): scores are computed TRANSPOSED,
+//   S^T (keys x queries) = K_tile (A: lane = key row) . Q^T (B: lane = query column),
+// whose accumulator layout -- lane = query column, registers = key rows {8g + 4*(lane>>5) + i} -- is exactly the B
+// operand layout of the next MFMA over key slab g:  O^T (d x queries) += V^T (A: lane = d row) . P^T (B).
+// A lane therefore owns ONE query for the whole kernel: the online-softmax state (max, sum) and the rescale are
+// per-lane scalars.  Backward (one launch) uses the same trick twice: role-A workgroups (32 queries each) produce dQ,
+// role-B workgroups (32 keys each, scores un-transposed so that lane = key column) produce dK and dV; no atomics, no
+// cross-wave reductions.
+//
+// Dropout on the attention weights: counter-based hash of (device seed, call site, (b, h, q, key)) as in drln.hip,
+// recomputed in backward.  key_padding_mask: (B, S) bytes, non-zero = ignore.  P and dS are rounded to bf16 for the
+// second GEMM like every flash implementation.  q, k, v: bf16 with arbitrary batch / row strides and unit stride
+// along the 64 head channels (head h at column h*64); out, dout: (B, L, H*64) contiguous; lse: (B, H, L) fp32.
+#include "pcm_elem.hpp"
+
+#include <math.h>
+
+namespace {
+
+typedef short s4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef unsigned short u16;
+
+constexpr int HD = 64;    // head dim
+constexpr int KT = 32;    // keys (or queries) per tile = one MFMA tile edge
+constexpr int LMAX = 128; // most queries covered
+constexpr int RS = 68;    // row stride (u16) of the row-major (32 x 64) tiles: 136 B
+constexpr int NW = 4;     // waves per workgroup; they split the streamed dimension and meet once, at the end
+constexpr int WG = 64 * NW;
+constexpr int TILE_U16 = KT * RS;
+
+#define PCM_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a, b, c, 0, 0, 0)
+
+struct AttnParams {
+    const u16 *q, *k, *v;
+    long q_bs, q_ls, k_bs, k_ls, v_bs, v_ls;  // element strides: batch, row
+    const unsigned char *kpm;                 // (B, S) or NULL
+    int B, H, L, S;
+    float scale, p_drop;
+    const long *seed;
+    unsigned site;
+};
+
+__device__ __forceinline__ float bf2f(u16 v)
+{
+    return __uint_as_float((uint32_t)v << 16);
+}
+__device__ __forceinline__ s4 pack4(float a, float b, float c, float d)  // 2 x v_cvt_pk_bf16_f32
+{
+    const __hip_bfloat162 lo = __float22bfloat162_rn(make_float2(a, b)), hi = __float22bfloat162_rn(make_float2(c, d));
+    uint2 r = make_uint2(*reinterpret_cast<const uint32_t *>(&lo), *reinterpret_cast<const uint32_t *>(&hi));
+    return *reinterpret_cast<s4 *>(&r);
+}
+__device__ __forceinline__ s4 lds_s4(const u16 *p)
+{
+    return *reinterpret_cast<const s4 *>(p);
+}
+__device__ __forceinline__ s4 zero_s4()
+{
+    s4 z = {0, 0, 0, 0};
+    return z;
+}
+__device__ __forceinline__ s4 lds_col4(const u16 *p)  // 4 elements of one column, consecutive rows of a row-major tile
+{
+    s4 r = {(short)p[0], (short)p[RS], (short)p[2 * RS], (short)p[3 * RS]};
+    return r;
+}
+__device__ __forceinline__ int crow(int r, int lane)  // accumulator register r of `lane` -> tile row
+{
+    return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+}
+
+// dropout on the attention weights: keep(b, h, q, key) = mix32(rowbase(b, h, q) + key * C) >= p * 2^32
+__device__ __forceinline__ uint32_t attn_rowbase(uint64_t seed, uint32_t site, uint32_t rowid)
+{
+    const uint32_t k = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9E3779B9u) ^ (site * 0x85EBCA6Bu);
+    return mix32(k ^ rowid);
+}
+__device__ __forceinline__ bool attn_keep(uint32_t rowbase, uint32_t key, uint32_t thr)
+{
+    return mix32(rowbase + key * 0x9E3779B1u) >= thr;
+}
+
+// one (32 x 64) bf16 tile = 256 chunks of 16 B, 4 per lane of ONE wave: chunk c = lane + 64*i -> row c>>3, cols (c&7)*8..
+struct TileRegs {
+    uint4 v[4];
+};
+__device__ __forceinline__ void tile_fetch(TileRegs &t, const u16 *__restrict__ base, long row_stride, int row0, int nrows, int lane)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i, r = c >> 3, d0 = (c & 7) * 8;
+        t.v[i] = (row0 + r < nrows) ? *reinterpret_cast<const uint4 *>(base + (long)(row0 + r) * row_stride + d0) : make_uint4(0, 0, 0, 0);
+    }
+}
+__device__ __forceinline__ void tile_store(const TileRegs &t, u16 *rowmajor, int lane)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i, r = c >> 3, d0 = (c & 7) * 8;
+        uint2 *dst = reinterpret_cast<uint2 *>(rowmajor + r * RS + d0);
+        dst[0] = make_uint2(t.v[i].x, t.v[i].y);
+        dst[1] = make_uint2(t.v[i].z, t.v[i].w);
+    }
+}
+
+struct DropCfg {
+    bool on;
+    uint64_t seed;
+    uint32_t thr;
+    float inv_keep;
+    __device__ DropCfg(const AttnParams &P)
+    {
+        on = P.p_drop > 0.f;
+        seed = on ? (uint64_t)P.seed[0] : 0ull;
+        thr = on ? (uint32_t)((double)P.p_drop * 4294967296.0) : 0u;
+        inv_keep = on ? 1.f / (1.f - P.p_drop) : 1.f;
+    }
+};
+
+// write one wave's (64 x 32) fp32 accumulator pair into the combine buffer part[64][32] (row = channel, column = lane&31)
+__device__ __forceinline__ void spill_acc(float *part, const f16v &a0, const f16v &a1, int lane)
+{
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        part[crow(r, lane) * 32 + (lane & 31)] = a0[r];
+        part[(32 + crow(r, lane)) * 32 + (lane & 31)] = a1[r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+// grid (B*H, ceil(L/32)), 4 waves: all own the SAME 32 query columns; wave j takes key tiles j, j+4, ... with its own
+// online-softmax state and LDS tiles (no barrier in the loop); the four partial (m, l, O) meet once at the end.
+__global__ __launch_bounds__(WG) void pcm_attn_small_fwd_kernel(AttnParams P, u16 *__restrict__ out, float *__restrict__ lse)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NW * 2 * TILE_U16 * 2 > NW * (64 * 32 + 64) * 4 ? NW * 2 * TILE_U16 * 2
+                                                                                                         : NW * (64 * 32 + 64) * 4];
+    const int bh = blockIdx.x, b = bh / P.H, h = bh % P.H;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    u16 *Ks = reinterpret_cast<u16 *>(smem) + w * 2 * TILE_U16, *Vs = Ks + TILE_U16;
+    const int qi = blockIdx.y * 32 + (lane & 31);
+    const bool qok = qi < P.L;
+    s4 qf[8];
+    {
+        const u16 *qp = P.q + (long)b * P.q_bs + (long)qi * P.q_ls + h * HD + 4 * (lane >> 5);
+#pragma unroll
+        for (int sl = 0; sl < 8; ++sl) qf[sl] = qok ? *reinterpret_cast<const s4 *>(qp + sl * 8) : zero_s4();
+    }
+    const DropCfg dc(P);
+    const uint32_t rb = dc.on ? attn_rowbase(dc.seed, P.site, (uint32_t)(bh * P.L + qi)) : 0u;
+    f16v o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o0[r] = 0.f, o1[r] = 0.f;
+    float m = -INFINITY, lsum = 0.f;
+    const u16 *kb = P.k + (long)b * P.k_bs + h * HD;
+    const u16 *vb = P.v + (long)b * P.v_bs + h * HD;
+    const unsigned char *mask = P.kpm ? P.kpm + (long)b * P.S : nullptr;
+    const int ntiles = (P.S + KT - 1) / KT;
+    TileRegs kr, vr;
+    if (w < ntiles) {
+        tile_fetch(kr, kb, P.k_ls, w * KT, P.S, lane);
+        tile_fetch(vr, vb, P.v_ls, w * KT, P.S, lane);
+    }
+    for (int kt = w; kt < ntiles; kt += NW) {
+        tile_store(kr, Ks, lane);  // one wave owns these tiles: its LDS operations execute in order, no barrier needed
+        tile_store(vr, Vs, lane);
+        if (kt + NW < ntiles) {
+            tile_fetch(kr, kb, P.k_ls, (kt + NW) * KT, P.S, lane);
+            tile_fetch(vr, vb, P.v_ls, (kt + NW) * KT, P.S, lane);
+        }
+        f16v s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < 8; ++sl) s = PCM_MFMA(lds_s4(Ks + (lane & 31) * RS + sl * 8 + 4 * (lane >> 5)), qf[sl], s);
+        const bool edge = (kt + 1) * KT > P.S || mask != nullptr;
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] *= P.scale;
+            if (edge) {
+                const int key = kt * KT + crow(r, lane);
+                const bool vis = key < P.S && !(mask != nullptr && mask[key] != 0);
+                s[r] = vis ? s[r] : -INFINITY;
+            }
+            tmax = fmaxf(tmax, s[r]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float m_new = fmaxf(m, tmax);
+        const bool dead = m_new == -INFINITY;  // nothing visible yet for this query
+        const float alpha = dead ? 1.f : __expf(m - m_new);
+        float p[16], psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            p[r] = dead ? 0.f : __expf(s[r] - m_new);
+            psum += p[r];
+        }
+        psum += __shfl_xor(psum, 32);
+        lsum = lsum * alpha + psum;
+        m = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o0[r] *= alpha, o1[r] *= alpha;
+        if (dc.on) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) p[r] = attn_keep(rb, (uint32_t)(kt * KT + crow(r, lane)), dc.thr) ? p[r] * dc.inv_keep : 0.f;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const s4 pf = pack4(p[4 * g], p[4 * g + 1], p[4 * g + 2], p[4 * g + 3]);
+            const u16 *vcol = Vs + (8 * g + 4 * (lane >> 5)) * RS + (lane & 31);  // V^T fragment: lane = channel, 4 consecutive keys
+            o0 = PCM_MFMA(lds_col4(vcol), pf, o0);
+            o1 = PCM_MFMA(lds_col4(vcol + 32), pf, o1);
+        }
+    }
+    // ---- the four partial results meet: part[w] = O_w (64 x 32), ml[w] = (m_w, l_w) per query
+    __syncthreads();
+    float *part = reinterpret_cast<float *>(smem), *ml = part + NW * 64 * 32;
+    spill_acc(part + w * 64 * 32, o0, o1, lane);
+    if (lane < 32) ml[w * 64 + lane] = m, ml[w * 64 + 32 + lane] = lsum;
+    __syncthreads();
+    const int q = threadIdx.x & 31, dg = threadIdx.x >> 5;  // 8 channels per thread
+    const int qq = blockIdx.y * 32 + q;
+    float mt = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NW; ++j) mt = fmaxf(mt, ml[j * 64 + q]);
+    float sc[NW], lt = 0.f;
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+        const float mj = ml[j * 64 + q];
+        sc[j] = (mj == -INFINITY) ? 0.f : __expf(mj - mt);
+        lt += ml[j * 64 + 32 + q] * sc[j];
+    }
+    if (qq >= P.L) return;
+    const float inv = lt > 0.f ? 1.f / lt : 0.f;
+    float o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) acc += part[(j * 64 + dg * 8 + i) * 32 + q] * sc[j];
+        o[i] = acc * inv;
+    }
+    const s4 lo = pack4(o[0], o[1], o[2], o[3]), hi = pack4(o[4], o[5], o[6], o[7]);
+    uint4 pk;
+    pk.x = reinterpret_cast<const uint32_t *>(&lo)[0], pk.y = reinterpret_cast<const uint32_t *>(&lo)[1];
+    pk.z = reinterpret_cast<const uint32_t *>(&hi)[0], pk.w = reinterpret_cast<const uint32_t *>(&hi)[1];
+    *reinterpret_cast<uint4 *>(out + ((long)b * P.L + qq) * (P.H * HD) + h * HD + dg * 8) = pk;
+    if (dg == 0) lse[(long)bh * P.L + qq] = lt > 0.f ? mt + logf(lt) : INFINITY;
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+// ONE launch, grid (B*H, nqt + nkt), 4 waves:
+//   blockIdx.y <  nqt : role A -- dQ of query tile blockIdx.y; the waves split the KEY tiles, partial dQ summed at the end
+//   blockIdx.y >= nqt : role B -- dK, dV of key tile blockIdx.y - nqt; Q / dO staged in LDS once, the waves split the QUERY
+//                       tiles, partial dK / dV summed at the end
+constexpr int BWD_LDS_A = NW * 2 * TILE_U16 * 2;
+constexpr int BWD_LDS_B = 2 * LMAX * RS * 2 + 3 * LMAX * 4;
+constexpr int BWD_LDS_C = NW * 64 * 32 * 4;  // combine buffer (aliases the tiles)
+constexpr int BWD_LDS = (BWD_LDS_A > BWD_LDS_B ? (BWD_LDS_A > BWD_LDS_C ? BWD_LDS_A : BWD_LDS_C) : (BWD_LDS_B > BWD_LDS_C ? BWD_LDS_B : BWD_LDS_C));
+
+__device__ __forceinline__ void store_rows_bf16(u16 *dst, const float *part, int q, int dg)
+{
+    float o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) acc += part[(j * 64 + dg * 8 + i) * 32 + q];
+        o[i] = acc;
+    }
+    const s4 lo = pack4(o[0], o[1], o[2], o[3]), hi = pack4(o[4], o[5], o[6], o[7]);
+    uint2 a = *reinterpret_cast<const uint2 *>(&lo), c = *reinterpret_cast<const uint2 *>(&hi);
+    reinterpret_cast<uint2 *>(dst + dg * 8)[0] = a;
+    reinterpret_cast<uint2 *>(dst + dg * 8)[1] = c;
+}
+
+__global__ __launch_bounds__(WG) void pcm_attn_small_bwd_kernel(AttnParams P, const u16 *__restrict__ out,
+                                                                const u16 *__restrict__ dout, const float *__restrict__ lse,
+                                                                u16 *__restrict__ dq, long dq_bs, long dq_ls, u16 *__restrict__ dk,
+                                                                long dk_bs, long dk_ls, u16 *__restrict__ dv, long dv_bs, long dv_ls)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[BWD_LDS];
+    const int bh = blockIdx.x, b = bh / P.H, h = bh % P.H;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int E = P.H * HD;
+    const DropCfg dc(P);
+    const u16 *qb = P.q + (long)b * P.q_bs + h * HD;
+    const u16 *kb = P.k + (long)b * P.k_bs + h * HD;
+    const u16 *vb = P.v + (long)b * P.v_bs + h * HD;
+    const u16 *ob = out + (long)b * P.L * E + h * HD;
+    const u16 *gb = dout + (long)b * P.L * E + h * HD;
+    const unsigned char *mask = P.kpm ? P.kpm + (long)b * P.S : nullptr;
+    const int nqt = (P.L + 31) / 32, nkt = (P.S + KT - 1) / KT;
+    const int cq = threadIdx.x & 31, cdg = threadIdx.x >> 5;  // combine mapping: column, group of 8 channels
+    float *part = reinterpret_cast<float *>(smem);
+    if ((int)blockIdx.y < nqt) {
+        // ---------------------------------------------------------------- role A: dQ
+        u16 *Ks = reinterpret_cast<u16 *>(smem) + w * 2 * TILE_U16, *Vs = Ks + TILE_U16;
+        const int qi = blockIdx.y * 32 + (lane & 31);
+        const bool qok = qi < P.L;
+        s4 qf[8], gf[8];
+        float Dq = 0.f;
+        const long c0 = 4 * (lane >> 5);
+        // a zero upstream gradient gives a zero dQ: skip everything else (layers whose output never reaches the loss -- the
+        // decoder's intermediate outputs 1..6, transformer.py:190-206 + act.py:270 -- arrive here with dO == 0)
+        bool nz = false;
+#pragma unroll
+        for (int sl = 0; sl < 8; ++sl) {
+            gf[sl] = qok ? *reinterpret_cast<const s4 *>(gb + (long)qi * E + sl * 8 + c0) : zero_s4();
+            nz |= ((gf[sl][0] | gf[sl][1] | gf[sl][2] | gf[sl][3]) & 0x7FFF) != 0;
+        }
+        const bool live = __any(nz);
+        if (!live) {
+            if (w == 0 && qok) {
+                u16 *dz = dq + (long)b * dq_bs + (long)qi * dq_ls + h * HD + (lane >> 5) * 32;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) reinterpret_cast<uint4 *>(dz)[i] = make_uint4(0, 0, 0, 0);
+            }
+            return;
+        }
+        {
+#pragma unroll
+            for (int sl = 0; sl < 8; ++sl) {
+                qf[sl] = qok ? *reinterpret_cast<const s4 *>(qb + (long)qi * P.q_ls + sl * 8 + c0) : zero_s4();
+                const s4 of = qok ? *reinterpret_cast<const s4 *>(ob + (long)qi * E + sl * 8 + c0) : zero_s4();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) Dq += bf2f((u16)gf[sl][i]) * bf2f((u16)of[i]);
+            }
+            Dq += __shfl_xor(Dq, 32);  // the two half-waves hold complementary channels of the same query
+        }
+        const float lq = qok ? lse[(long)bh * P.L + qi] : INFINITY;
+        const uint32_t rb = dc.on ? attn_rowbase(dc.seed, P.site, (uint32_t)(bh * P.L + qi)) : 0u;
+        f16v a0, a1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a0[r] = 0.f, a1[r] = 0.f;
+        TileRegs kr, vr;
+        if (w < nkt) {
+            tile_fetch(kr, kb, P.k_ls, w * KT, P.S, lane);
+            tile_fetch(vr, vb, P.v_ls, w * KT, P.S, lane);
+        }
+        for (int kt = w; kt < nkt; kt += NW) {
+            tile_store(kr, Ks, lane);
+            tile_store(vr, Vs, lane);
+            if (kt + NW < nkt) {
+                tile_fetch(kr, kb, P.k_ls, (kt + NW) * KT, P.S, lane);
+                tile_fetch(vr, vb, P.v_ls, (kt + NW) * KT, P.S, lane);
+            }
+            f16v s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f, dp[r] = 0.f;
+#pragma unroll
+            for (int sl = 0; sl < 8; ++sl) {
+                const int off = (lane & 31) * RS + sl * 8 + 4 * (lane >> 5);
+                s = PCM_MFMA(lds_s4(Ks + off), qf[sl], s);
+                dp = PCM_MFMA(lds_s4(Vs + off), gf[sl], dp);
+            }
+            const bool edge = (kt + 1) * KT > P.S || mask != nullptr;
+            float ds[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float pr = __expf(s[r] * P.scale - lq);
+                const int key = kt * KT + crow(r, lane);
+                if (edge) {
+                    const bool vis = key < P.S && !(mask != nullptr && mask[key] != 0);
+                    pr = vis ? pr : 0.f;
+                }
+                float dpv = dp[r];
+                if (dc.on) dpv = attn_keep(rb, (uint32_t)key, dc.thr) ? dpv * dc.inv_keep : 0.f;
+                ds[r] = pr * (dpv - Dq) * P.scale;
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const s4 df = pack4(ds[4 * g], ds[4 * g + 1], ds[4 * g + 2], ds[4 * g + 3]);
+                const u16 *kcol = Ks + (8 * g + 4 * (lane >> 5)) * RS + (lane & 31);  // K^T fragment
+                a0 = PCM_MFMA(lds_col4(kcol), df, a0);
+                a1 = PCM_MFMA(lds_col4(kcol + 32), df, a1);
+            }
+        }
+        __syncthreads();
+        spill_acc(part + w * 64 * 32, a0, a1, lane);
+        __syncthreads();
+        const int qq = blockIdx.y * 32 + cq;
+        if (qq < P.L) store_rows_bf16(dq + (long)b * dq_bs + (long)qq * dq_ls + h * HD, part, cq, cdg);
+        return;
+    }
+    // -------------------------------------------------------------------- role B: dK, dV of one key tile
+    u16 *Qs = reinterpret_cast<u16 *>(smem), *dOs = Qs + LMAX * RS;
+    float *lse_s = reinterpret_cast<float *>(dOs + LMAX * RS), *D_s = lse_s + LMAX;
+    uint32_t *rb_s = reinterpret_cast<uint32_t *>(D_s + LMAX);
+    const int kt = blockIdx.y - nqt;
+    bool any_dout = false;
+    uint4 gpre[LMAX * 8 / WG];  // this thread's dO chunks (4 at most)
+#pragma unroll
+    for (int it = 0; it < LMAX * 8 / WG; ++it) {
+        const int idx = threadIdx.x + it * WG, row = idx >> 3, d0 = (idx & 7) * 8;
+        gpre[it] = (row < P.L) ? *reinterpret_cast<const uint4 *>(gb + (long)row * E + d0) : make_uint4(0, 0, 0, 0);
+        any_dout |= ((gpre[it].x | gpre[it].y | gpre[it].z | gpre[it].w) & 0x7FFF7FFFu) != 0;
+    }
+    const bool live = __syncthreads_or(any_dout) != 0;  // zero upstream gradient -> dK = dV = 0 (see role A)
+    if (!live) {
+        const int kz = (blockIdx.y - nqt) * KT + (threadIdx.x >> 3), dz = (threadIdx.x & 7) * 8;
+        if (kz < P.S) {
+            *reinterpret_cast<uint4 *>(dk + (long)b * dk_bs + (long)kz * dk_ls + h * HD + dz) = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4 *>(dv + (long)b * dv_bs + (long)kz * dv_ls + h * HD + dz) = make_uint4(0, 0, 0, 0);
+        }
+        return;
+    }
+#pragma unroll
+    for (int it = 0; it < LMAX * 8 / WG; ++it) {  // stage Q and dO rows (zero beyond L), D = rowsum(dO * O)
+        const int idx = threadIdx.x + it * WG;
+        if (idx >= nqt * 32 * 8) break;
+        const int row = idx >> 3, d0 = (idx & 7) * 8;  // 8 consecutive lanes share a row
+        uint4 qv = make_uint4(0, 0, 0, 0), ov = make_uint4(0, 0, 0, 0);
+        const uint4 gv = gpre[it];
+        if (row < P.L) {
+            qv = *reinterpret_cast<const uint4 *>(qb + (long)row * P.q_ls + d0);
+            ov = *reinterpret_cast<const uint4 *>(ob + (long)row * E + d0);
+        }
+        uint2 *a = reinterpret_cast<uint2 *>(Qs + row * RS + d0);
+        a[0] = make_uint2(qv.x, qv.y), a[1] = make_uint2(qv.z, qv.w);
+        uint2 *c = reinterpret_cast<uint2 *>(dOs + row * RS + d0);
+        c[0] = make_uint2(gv.x, gv.y), c[1] = make_uint2(gv.z, gv.w);
+        const u16 *oe = reinterpret_cast<const u16 *>(&ov), *ge = reinterpret_cast<const u16 *>(&gv);
+        float dsum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dsum += bf2f(oe[i]) * bf2f(ge[i]);
+        dsum += __shfl_xor(dsum, 1);
+        dsum += __shfl_xor(dsum, 2);
+        dsum += __shfl_xor(dsum, 4);
+        if ((idx & 7) == 0) {
+            D_s[row] = dsum;
+            lse_s[row] = row < P.L ? lse[(long)bh * P.L + row] : INFINITY;  // +inf lse silences padded queries
+            rb_s[row] = dc.on ? attn_rowbase(dc.seed, P.site, (uint32_t)(bh * P.L + row)) : 0u;
+        }
+    }
+    __syncthreads();
+    const int key = kt * KT + (lane & 31);
+    const bool kin = key < P.S;
+    const bool kok = kin && !(mask != nullptr && mask[key] != 0);
+    s4 kf[8], vf[8];
+#pragma unroll
+    for (int sl = 0; sl < 8; ++sl) {
+        kf[sl] = kin ? *reinterpret_cast<const s4 *>(kb + (long)key * P.k_ls + sl * 8 + 4 * (lane >> 5)) : zero_s4();
+        vf[sl] = kin ? *reinterpret_cast<const s4 *>(vb + (long)key * P.v_ls + sl * 8 + 4 * (lane >> 5)) : zero_s4();
+    }
+    f16v dk0, dk1, dv0, dv1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dk0[r] = 0.f, dk1[r] = 0.f, dv0[r] = 0.f, dv1[r] = 0.f;
+    for (int qt = w; qt < nqt; qt += NW) {
+        f16v s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f, dp[r] = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < 8; ++sl) {
+            const int off = (qt * 32 + (lane & 31)) * RS + sl * 8 + 4 * (lane >> 5);
+            s = PCM_MFMA(lds_s4(Qs + off), kf[sl], s);  // rows = queries, columns = keys
+            dp = PCM_MFMA(lds_s4(dOs + off), vf[sl], dp);
+        }
+        float pd[16], ds[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qr = qt * 32 + crow(r, lane);
+            const float pr = kok ? __expf(s[r] * P.scale - lse_s[qr]) : 0.f;
+            float dpv = dp[r];
+            pd[r] = pr;
+            if (dc.on) {
+                const bool keep = attn_keep(rb_s[qr], (uint32_t)key, dc.thr);
+                pd[r] = keep ? pr * dc.inv_keep : 0.f;
+                dpv = keep ? dpv * dc.inv_keep : 0.f;
+            }
+            ds[r] = pr * (dpv - D_s[qr]) * P.scale;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const s4 pf = pack4(pd[4 * g], pd[4 * g + 1], pd[4 * g + 2], pd[4 * g + 3]);
+            const s4 df = pack4(ds[4 * g], ds[4 * g + 1], ds[4 * g + 2], ds[4 * g + 3]);
+            // A operands = dO^T / Q^T: lane = channel row, 4 consecutive queries -> a column walk through the row-major tiles
+            const int qrow = qt * 32 + 8 * g + 4 * (lane >> 5);
+            const u16 *gcol = dOs + qrow * RS + (lane & 31), *qcol = Qs + qrow * RS + (lane & 31);
+            dv0 = PCM_MFMA(lds_col4(gcol), pf, dv0);
+            dv1 = PCM_MFMA(lds_col4(gcol + 32), pf, dv1);
+            dk0 = PCM_MFMA(lds_col4(qcol), df, dk0);
+            dk1 = PCM_MFMA(lds_col4(qcol + 32), df, dk1);
+        }
+    }
+    const int kk = kt * KT + cq;
+    __syncthreads();  // everybody is done with Qs / dOs: the combine buffer aliases them
+    spill_acc(part + w * 64 * 32, dk0, dk1, lane);
+    __syncthreads();
+    if (kk < P.S) store_rows_bf16(dk + (long)b * dk_bs + (long)kk * dk_ls + h * HD, part, cq, cdg);
+    __syncthreads();
+    spill_acc(part + w * 64 * 32, dv0, dv1, lane);
+    __syncthreads();
+    if (kk < P.S) store_rows_bf16(dv + (long)b * dv_bs + (long)kk * dv_ls + h * HD, part, cq, cdg);
+}
+
+inline bool strides_ok(long bs, long ls)
+{
+    return bs % 8 == 0 && ls % 8 == 0;  // 16-byte row loads
+}
+
+}  // namespace
+
+extern "C" int pcm_attn_small_supported(int L, int S, int head_dim)
+{
+    return (head_dim == HD && L >= 1 && L <= LMAX && S >= 1) ? 1 : 0;
+}
+
+extern "C" int pcm_attn_small_forward_hip(int B, int H, int L, int S, const void *q, long q_bs, long q_ls, const void *k,
+                                          long k_bs, long k_ls, const void *v, long v_bs, long v_ls,
+                                          const unsigned char *key_padding_mask, float scale, float p_drop, const long *seed,
+                                          unsigned site, void *out, float *lse, void *stream)
+{
+    if (B <= 0 || H <= 0) return B == 0 ? PCM_OK : PCM_ERR_BAD_ARG;
+    if (!pcm_attn_small_supported(L, S, HD)) return PCM_ERR_UNSUPPORTED;
+    if (!strides_ok(q_bs, q_ls) || !strides_ok(k_bs, k_ls) || !strides_ok(v_bs, v_ls)) return PCM_ERR_BAD_ARG;
+    if (p_drop < 0.f || p_drop >= 1.f || (p_drop > 0.f && seed == nullptr)) return PCM_ERR_BAD_ARG;
+    AttnParams P{(const u16 *)q, (const u16 *)k, (const u16 *)v, q_bs, q_ls, k_bs, k_ls, v_bs, v_ls, key_padding_mask,
+                 B, H, L, S, scale, p_drop, seed, site};
+    hipLaunchKernelGGL(pcm_attn_small_fwd_kernel, dim3(B * H, (L + 31) / 32), dim3(WG), 0, (hipStream_t)stream, P, (u16 *)out, lse);
+    return PCM_LAUNCH_STATUS();
+}
+
+extern "C" int pcm_attn_small_backward_hip(int B, int H, int L, int S, const void *q, long q_bs, long q_ls, const void *k,
+                                           long k_bs, long k_ls, const void *v, long v_bs, long v_ls,
+                                           const unsigned char *key_padding_mask, float scale, float p_drop, const long *seed,
+                                           unsigned site, const void *out, const void *dout, const float *lse, void *dq,
+                                           long dq_bs, long dq_ls, void *dk, long dk_bs, long dk_ls, void *dv, long dv_bs,
+                                           long dv_ls, void *stream)
+{
+    if (B <= 0 || H <= 0) return B == 0 ? PCM_OK : PCM_ERR_BAD_ARG;
+    if (!pcm_attn_small_supported(L, S, HD)) return PCM_ERR_UNSUPPORTED;
+    if (!strides_ok(q_bs, q_ls) || !strides_ok(k_bs, k_ls) || !strides_ok(v_bs, v_ls)) return PCM_ERR_BAD_ARG;
+    if (dq_ls % 8 || dk_ls % 8 || dv_ls % 8 || dq_bs % 8 || dk_bs % 8 || dv_bs % 8) return PCM_ERR_BAD_ARG;
+    AttnParams P{(const u16 *)q, (const u16 *)k, (const u16 *)v, q_bs, q_ls, k_bs, k_ls, v_bs, v_ls, key_padding_mask,
+                 B, H, L, S, scale, p_drop, seed, site};
+    hipLaunchKernelGGL(pcm_attn_small_bwd_kernel, dim3(B * H, (L + 31) / 32 + (S + KT - 1) / KT), dim3(WG), 0, (hipStream_t)stream, P, (const u16 *)out,
+                       (const u16 *)dout, lse, (u16 *)dq, dq_bs, dq_ls, (u16 *)dk, dk_bs, dk_ls, (u16 *)dv, dv_bs, dv_ls);
+    return PCM_LAUNCH_STATUS();
+}

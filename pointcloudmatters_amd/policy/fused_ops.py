@@ -298,9 +298,15 @@ class _SelfAttnInProj(Function):
         bf = torch.bfloat16
         st = torch.cuda.current_stream().cuda_stream
         with torch.cuda.device(dev), torch.autocast("cuda", enabled=False):
-            dqk = torch.stack((dq, dk), dim=-2).reshape(rows, 2 * E)
-            if dqk.dtype != bf:
-                dqk = dqk.to(bf)
+            if (dq.dtype == bf and dk.dtype == bf and dq.stride() == dk.stride() and dq.stride()[-2:] == (2 * E, 1)
+                    and dk.data_ptr() - dq.data_ptr() == 2 * E and dq.is_contiguous() is False
+                    and all(dq.stride(i) == dq.stride(i + 1) * dq.shape[i + 1] for i in range(dq.dim() - 2))):
+                # the small-attention backward already wrote dq | dk side by side: view them as one (rows, 2E) matrix
+                dqk = torch.as_strided(dq, (rows, 2 * E), (2 * E, 1))
+            else:
+                dqk = torch.stack((dq, dk), dim=-2).reshape(rows, 2 * E)
+                if dqk.dtype != bf:
+                    dqk = dqk.to(bf)
             dv2 = dv.reshape(rows, E)
             if dv2.dtype != bf or not dv2.is_contiguous():
                 dv2 = dv2.to(bf).contiguous()

@@ -1,0 +1,91 @@
+"""Attention core for short query sequences on the matrix cores (csrc/attn_small.hip) as an autograd function.
+
+``small_attention(q, k, v, key_padding_mask, heads, dropout_p)`` == softmax(q k^T / sqrt(d) + mask) (dropout) v per head
+for q (B, L, E), k / v (B, S, E) in bf16 with E = heads * 64 and L <= 128; returns (B, L, E) -- already in the layout
+the output projection wants (the SDPA path needs a transpose copy).  Used by policy/transformer.attention for the CVAE
+encoder and the decoder; the long encoder self-attention (S = M + 3 tokens) stays on the framework's flash kernel.
+"""
+import math
+
+import torch
+from torch.autograd import Function
+
+from .. import _lib
+
+
+def _st(t):
+    return t.stride(0), t.stride(1)
+
+
+class _SmallAttn(Function):
+    @staticmethod
+    def forward(ctx, q, k, v, kpm, heads, p_drop, seed, site):
+        L_ = _lib.load()
+        B, L, E = q.shape
+        S = k.shape[1]
+        q, k, v = (t if t.stride(-1) == 1 else t.contiguous() for t in (q, k, v))
+        dev = q.device
+        with torch.cuda.device(dev):
+            out = torch.empty(B, L, E, dtype=torch.bfloat16, device=dev)
+            lse = torch.empty(B, heads, L, dtype=torch.float32, device=dev)
+            rc = L_.pcm_attn_small_forward_hip(B, heads, L, S, q.data_ptr(), *_st(q), k.data_ptr(), *_st(k), v.data_ptr(), *_st(v),
+                                               kpm.data_ptr() if kpm is not None else 0, 1.0 / math.sqrt(E // heads), float(p_drop),
+                                               seed.data_ptr() if seed is not None else 0, int(site), out.data_ptr(),
+                                               lse.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "pcm_attn_small_forward_hip")
+        ctx.save_for_backward(q, k, v, out, lse, kpm)
+        ctx.meta = (heads, float(p_drop), seed, int(site))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L_ = _lib.load()
+        q, k, v, out, lse, kpm = ctx.saved_tensors
+        heads, p_drop, seed, site = ctx.meta
+        B, L, E = q.shape
+        S = k.shape[1]
+        dout = dout.to(torch.bfloat16).contiguous()
+        dev = q.device
+        with torch.cuda.device(dev):
+            if L == S:  # self-attention: dq | dk side by side, the layout the packed in-projection consumes without a copy
+                dqk = torch.empty(B, L, 2, E, dtype=torch.bfloat16, device=dev)
+                dq, dk = dqk[:, :, 0], dqk[:, :, 1]
+            else:
+                dq = torch.empty(B, L, E, dtype=torch.bfloat16, device=dev)
+                dk = torch.empty(B, S, E, dtype=torch.bfloat16, device=dev)
+            dv = torch.empty(B, S, E, dtype=torch.bfloat16, device=dev)
+            rc = L_.pcm_attn_small_backward_hip(B, heads, L, S, q.data_ptr(), *_st(q), k.data_ptr(), *_st(k), v.data_ptr(), *_st(v),
+                                                kpm.data_ptr() if kpm is not None else 0, 1.0 / math.sqrt(E // heads), p_drop,
+                                                seed.data_ptr() if seed is not None else 0, site, out.data_ptr(), dout.data_ptr(),
+                                                lse.data_ptr(), dq.data_ptr(), *_st(dq), dk.data_ptr(), *_st(dk), dv.data_ptr(),
+                                                *_st(dv), torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "pcm_attn_small_backward_hip")
+        return dq, dk, dv, None, None, None, None, None
+
+
+def supported(q, k, v, heads, dropout_p=0.0):
+    from . import fused_ops
+
+    if not (q.is_cuda and q.dtype == k.dtype == v.dtype == torch.bfloat16 and q.dim() == 3):
+        return False
+    e = q.shape[-1]
+    if e % heads or e // heads != 64 or q.shape[1] > 128 or q.shape[1] < 1 or k.shape[1] < 1:
+        return False
+    if dropout_p > 0 and fused_ops.current() is None:
+        return False  # the dropout seed lives in the training loop's FusedContext
+    for t in (q, k, v):
+        if t.stride(-1) == 1 and (t.stride(0) % 8 or t.stride(1) % 8):
+            return False
+    return True
+
+
+def small_attention(q, k, v, key_padding_mask, heads, dropout_p=0.0):
+    from . import fused_ops
+
+    kpm = None
+    if key_padding_mask is not None:
+        kpm = key_padding_mask.contiguous()
+        kpm = kpm.view(torch.uint8) if kpm.dtype == torch.bool else kpm.to(torch.uint8)
+    ctx = fused_ops.current()
+    seed, site = (ctx.seed, ctx.next_site()) if dropout_p > 0 else (None, 0)
+    return _SmallAttn.apply(q, k, v, kpm, heads, dropout_p, seed, site)

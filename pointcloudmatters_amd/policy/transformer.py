@@ -122,6 +122,14 @@ def attention(
         q = linear_rows(query, w_q, b_q)
         k = linear_rows(key, w_k, b_k)
         v = linear_rows(value, w_v, b_v)
+    from . import small_attn
+
+    p_attn = mha.dropout if training else 0.0
+    if small_attn.supported(q, k, v, h, p_attn):  # <= 128 queries: MFMA kernel of csrc/attn_small.hip, output already (B, L, E)
+        out = small_attn.small_attention(q, k, v, key_padding_mask, h, p_attn)
+        if not project:
+            return out
+        return linear_rows(out, mha.out_proj.weight, mha.out_proj.bias)
     mask = None
     if key_padding_mask is not None:
         mask = (~key_padding_mask)[:, None, None, :]  # True = attend
