@@ -36,6 +36,9 @@ def parse():
     ap.add_argument("--workload", default="C2", help="C2 (headline), C4, REF, C1")
     ap.add_argument("--sa-impl", default=os.environ.get("PCM_SA_IMPL", "auto"))
     ap.add_argument("--mode", default="auto", help="auto | graph | flat | eager (eager = torch AdamW + DDP + SyncBN)")
+    ap.add_argument("--dead-decoder-layers", default="keep", choices=["keep", "prune_backward", "skip"],
+                    help="ACT reads only decoder output [0] (act.py:270): keep = the reference's autograd graph (default, what "
+                         "`value` is quoted on); prune_backward / skip = dead-code elimination variants, reported separately")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--kernels-only", action="store_true", help="only run the per-kernel timing leg (for rocprofv3 --pmc passes)")
@@ -340,7 +343,8 @@ def main():
     is_dp = wl["policy"] == "dp"
     build = build_dp_policy if is_dp else build_act_policy
     make_batch = make_dp_batch if is_dp else make_act_batch
-    policy = build(pcd_npoints=wl["pcd_npoints"], sa_impl=sa_impl).to(device)
+    extra = {} if is_dp else {"dead_decoder_layers": args.dead_decoder_layers}
+    policy = build(pcd_npoints=wl["pcd_npoints"], sa_impl=sa_impl, **extra).to(device)
     mode = args.mode
     if mode == "auto":  # hipGraph replay needs static shapes; ragged workloads use the flat optimizer eagerly
         mode = "flat" if wl["ragged"] else "graph"
@@ -384,7 +388,8 @@ def main():
                        "global_batch": wl["batch"] * world, "points_per_cloud": wl["n_points"],
                        "tokens_per_cloud": wl["pcd_npoints"], "parallelism": "dp%d" % world, "sa_impl": sa_impl, "step_mode": trainer.mode,
                        "batchnorm": "sync" if trainer.sync_batchnorm else "per-rank",
-                       "accumulate_grad_batches": 1, "optimizer_step_every_step": True},
+                       "accumulate_grad_batches": 1, "optimizer_step_every_step": True,
+                       "dead_decoder_layers": "n/a" if is_dp else args.dead_decoder_layers},
             "final_loss": round(metrics.get("train/loss", float("nan")), 4),
         }
         if not args.no_roofline:

@@ -6,7 +6,8 @@ from ..policy import ACTPCD, KLDivergence, PointNet, Transformer, TransformerEnc
 from .configs import ACT_MODEL, DP_MODEL
 
 
-def build_act_policy(pcd_npoints, pointops=None, sa_impl="reference", overlap_sampling=True, **overrides):
+def build_act_policy(pcd_npoints, pointops=None, sa_impl="reference", overlap_sampling=True, dead_decoder_layers="keep",
+                     **overrides):
     c = dict(ACT_MODEL)
     c.update(overrides)
     backbone = PointNet(in_channels=c["in_channels"], num_classes=0)
@@ -25,7 +26,7 @@ def build_act_policy(pcd_npoints, pointops=None, sa_impl="reference", overlap_sa
         env_state_dim=0, latent_dim=c["latent_dim"], action_loss=nn.MSELoss(reduction="none"),
         klloss=KLDivergence(), kl_weight=c["kl_weight"], goal_cond_dim=c["goal_cond_dim"],
         pcd_nsample=c["pcd_nsample"], pcd_npoints=pcd_npoints, pointops=pointops, sa_impl=sa_impl,
-        overlap_sampling=overlap_sampling,
+        overlap_sampling=overlap_sampling, dead_decoder_layers=dead_decoder_layers,
     )
 
 

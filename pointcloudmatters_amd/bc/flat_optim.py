@@ -112,17 +112,26 @@ class FlatAdamW:
         micro-batch of an accumulation window) or add per source dtype, instead of one accumulate
         kernel per parameter."""
         by_dtype = {}
+        zero_from = zero_to = None  # run of adjacent gradient slots without a gradient this step: one fill for the run
         for k, p in enumerate(self.params):
             g = self._stash[k] if self.shadow[k] is not None else p.grad
             if g is None:
                 if first:
-                    self.g_views[k].zero_()
+                    o = self.offsets[k]
+                    if zero_to == o:
+                        zero_to = o + p.numel()
+                    else:
+                        if zero_from is not None:
+                            self.flat_g[zero_from:zero_to].zero_()
+                        zero_from, zero_to = o, o + p.numel()
                 continue
             d, s_ = by_dtype.setdefault(g.dtype, ([], []))
             d.append(self.g_views[k])
             s_.append(g)
             self._stash[k] = None
             p.grad = None
+        if zero_from is not None:
+            self.flat_g[zero_from:zero_to].zero_()
         for dsts, srcs in by_dtype.values():
             if first:
                 torch._foreach_copy_(dsts, srcs)

@@ -73,6 +73,7 @@ class ACTPCD(nn.Module):
         pointops=None,
         sa_impl="reference",
         overlap_sampling=True,
+        dead_decoder_layers="keep",
     ):
         super().__init__()
         if backbone is None:
@@ -91,6 +92,12 @@ class ACTPCD(nn.Module):
             pointops = _hip_pointops
         self._pointops = [pointops]  # in a list: not a submodule / not in the state dict
         self.sa_impl = sa_impl
+        # act.py:270 reads only the first decoder layer's output; see TransformerDecoder.first_only for the three ways
+        # to treat the other six ("keep" = the reference's autograd graph, the default)
+        if dead_decoder_layers not in ("keep", "prune_backward", "skip"):
+            raise ValueError(dead_decoder_layers)
+        self.dead_decoder_layers = dead_decoder_layers
+        transformer.decoder.first_only = dead_decoder_layers
         self.overlap_sampling = overlap_sampling
 
         self.backbone = backbone

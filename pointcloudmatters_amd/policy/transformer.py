@@ -277,16 +277,30 @@ class TransformerDecoder(nn.Module):
         v_all = linear_rows(memory, torch.cat(wv, dim=0), torch.cat(bv, dim=0)).unflatten(-1, (n, e)).unbind(-2)
         return list(zip(k_all, v_all, wq, bq))
 
+    # What a caller that reads only output [0] (ACT, act.py:270) may ask for:
+    #   "keep"            all layers forward, outputs stacked: autograd then pushes exact ZEROS through layers 1.. like
+    #                     the reference does (stack -> select backward);
+    #   "prune_backward"  all layers forward, but only output 0 is handed on, so the engine never visits layers 1..;
+    #                     their parameters keep receiving the same exact-zero gradients (zero-filled by the optimizer);
+    #   "skip"            layers 1.. are not evaluated at all (their outputs are unused).
+    first_only = "keep"
+
     def forward(self, tgt, memory, memory_key_padding_mask=None, pos=None, query_pos=None):
         out = tgt
         memory_pos = _add_pos(memory, pos)
-        kvs = self._project_memory(memory, memory_pos) if self.batch_memory_kv else [None] * len(self.layers)
+        layers = self.layers if not (self.return_intermediate and self.first_only == "skip") else self.layers[:1]
+        if self.batch_memory_kv and len(layers) == len(self.layers):
+            kvs = self._project_memory(memory, memory_pos)
+        else:
+            kvs = [None] * len(layers)
         inter = []
-        for layer, kv in zip(self.layers, kvs):
+        for layer, kv in zip(layers, kvs):
             out = layer(out, memory, memory_pos, memory_key_padding_mask=memory_key_padding_mask, query_pos=query_pos, kv=kv)
             if self.return_intermediate:
                 inter.append(self.norm(out))
         if self.return_intermediate:
+            if self.first_only != "keep":
+                return inter[0].unsqueeze(0)
             # the reference pops the last entry and re-appends norm(out): same tensor
             return torch.stack(inter)
         if self.norm is not None:

@@ -194,3 +194,41 @@ def test_graph_mode_coexists_with_rccl_process_group(hip_device):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("how", ["prune_backward", "skip"])
+def test_dead_decoder_layer_options_leave_every_parameter_update_unchanged(how, hip_device):
+    """ACT reads only decoder output [0]: pruning the backward of layers 1.. (or not evaluating them) must give the same
+    loss and the same parameters after optimizer steps as the reference's graph, in which those layers receive exact
+    zero gradients (and are still weight-decayed)."""
+    from pointcloudmatters_amd.bc import BCTrainer, build_act_policy, clone_batch, make_act_batch
+
+    small = dict(hidden_dim=768, nhead=12, dim_feedforward=32, num_encoder_layers=1, num_decoder_layers=3, dropout=0.0, latent_dim=8,
+                 num_queries=10)
+    batch = make_act_batch(2, 256, seed=5, device=hip_device, num_queries=10)
+    eps = torch.randn(2, 8, generator=torch.Generator().manual_seed(1)).to(hip_device)
+    results = {}
+    for mode in ("keep", how):
+        torch.manual_seed(0)
+        pol = build_act_policy(pcd_npoints=64, sa_impl="fused", dead_decoder_layers=mode, **small).to(hip_device)
+        tr = BCTrainer(pol, total_steps=20, precision="fp32", device=hip_device, mode="flat", optim=dict(accumulate_grad_batches=1, lr=1e-3))
+        b = clone_batch(batch)
+        b["vae_eps"] = eps
+        loss = tr.training_step(b)["loss"].item()
+        opt = tr.optimizer
+        grads = {n: opt.g_views[k].detach().clone() for (n, _), k in zip(pol.named_parameters(), range(10 ** 6)) if False}
+        index = {id(p): k for k, p in enumerate(opt.params)}
+        grads = {n: opt.g_views[index[id(p)]].detach().clone() for n, p in pol.named_parameters() if id(p) in index}
+        results[mode] = (loss, grads, {k: v.detach().clone() for k, v in pol.state_dict().items()})
+    la, ga, pa = results["keep"]
+    lb, gb, pb = results[how]
+    assert la == pytest.approx(lb, rel=1e-6)
+    assert ga.keys() == gb.keys()
+    for k in ga:  # the gradients the optimizer consumed (Adam would amplify noise-level differences: compare them, not weights)
+        ref = ga[k]
+        assert (gb[k] - ref).norm().item() <= 1e-5 * ref.norm().item() + 1e-9, k
+        if ".decoder.layers.1." in k or ".decoder.layers.2." in k:
+            assert torch.count_nonzero(ref) == 0 and torch.count_nonzero(gb[k]) == 0, k  # exact zeros either way
+    for k in pa:  # ... and those layers are still weight-decayed identically
+        if ".decoder.layers.1." in k or ".decoder.layers.2." in k:
+            torch.testing.assert_close(pb[k], pa[k], rtol=0, atol=0, msg=k)
