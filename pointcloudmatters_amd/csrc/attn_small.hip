@@ -1,5 +1,5 @@
-// attn_small.hip -- multi-head attention for SHORT query sequences (L <= 128, head_dim 64), forward and backward, on the
-// gfx950 matrix cores.
+// attn_small.hip -- multi-head attention for short sequences (head_dim 64; tuned for <= ~600 tokens), forward and
+// backward, on the gfx950 matrix cores.
 //
 // 18 of the 22 attention calls of an ACT training step have 100-102 queries: the CVAE encoder (102 tokens), the
 // decoder's self-attention (100 queries) and its cross-attention (100 queries x 515 memory tokens)
@@ -34,7 +34,7 @@ typedef unsigned short u16;
 
 constexpr int HD = 64;    // head dim
 constexpr int KT = 32;    // keys (or queries) per tile = one MFMA tile edge
-constexpr int LMAX = 128; // most queries covered
+constexpr int LMAX = 128; // queries staged in LDS at a time by the dK/dV role
 constexpr int RS = 68;    // row stride (u16) of the row-major (32 x 64) tiles: 136 B
 constexpr int NW = 4;     // waves per workgroup; they split the streamed dimension and meet once, at the end
 constexpr int WG = 64 * NW;
@@ -399,52 +399,26 @@ __global__ __launch_bounds__(WG) void pcm_attn_small_bwd_kernel(AttnParams P, co
     float *lse_s = reinterpret_cast<float *>(dOs + LMAX * RS), *D_s = lse_s + LMAX;
     uint32_t *rb_s = reinterpret_cast<uint32_t *>(D_s + LMAX);
     const int kt = blockIdx.y - nqt;
-    bool any_dout = false;
-    uint4 gpre[LMAX * 8 / WG];  // this thread's dO chunks (4 at most)
+    const int nchunk = (P.L + LMAX - 1) / LMAX;  // queries are staged LMAX rows at a time
+    uint4 gpre[LMAX * 8 / WG];  // this thread's dO chunks of the first (for L <= 128: the only) query chunk
+    if (nchunk == 1) {
+        bool any_dout = false;
 #pragma unroll
-    for (int it = 0; it < LMAX * 8 / WG; ++it) {
-        const int idx = threadIdx.x + it * WG, row = idx >> 3, d0 = (idx & 7) * 8;
-        gpre[it] = (row < P.L) ? *reinterpret_cast<const uint4 *>(gb + (long)row * E + d0) : make_uint4(0, 0, 0, 0);
-        any_dout |= ((gpre[it].x | gpre[it].y | gpre[it].z | gpre[it].w) & 0x7FFF7FFFu) != 0;
-    }
-    const bool live = __syncthreads_or(any_dout) != 0;  // zero upstream gradient -> dK = dV = 0 (see role A)
-    if (!live) {
-        const int kz = (blockIdx.y - nqt) * KT + (threadIdx.x >> 3), dz = (threadIdx.x & 7) * 8;
-        if (kz < P.S) {
-            *reinterpret_cast<uint4 *>(dk + (long)b * dk_bs + (long)kz * dk_ls + h * HD + dz) = make_uint4(0, 0, 0, 0);
-            *reinterpret_cast<uint4 *>(dv + (long)b * dv_bs + (long)kz * dv_ls + h * HD + dz) = make_uint4(0, 0, 0, 0);
+        for (int it = 0; it < LMAX * 8 / WG; ++it) {
+            const int idx = threadIdx.x + it * WG, row = idx >> 3, d0 = (idx & 7) * 8;
+            gpre[it] = (row < P.L) ? *reinterpret_cast<const uint4 *>(gb + (long)row * E + d0) : make_uint4(0, 0, 0, 0);
+            any_dout |= ((gpre[it].x | gpre[it].y | gpre[it].z | gpre[it].w) & 0x7FFF7FFFu) != 0;
         }
-        return;
-    }
-#pragma unroll
-    for (int it = 0; it < LMAX * 8 / WG; ++it) {  // stage Q and dO rows (zero beyond L), D = rowsum(dO * O)
-        const int idx = threadIdx.x + it * WG;
-        if (idx >= nqt * 32 * 8) break;
-        const int row = idx >> 3, d0 = (idx & 7) * 8;  // 8 consecutive lanes share a row
-        uint4 qv = make_uint4(0, 0, 0, 0), ov = make_uint4(0, 0, 0, 0);
-        const uint4 gv = gpre[it];
-        if (row < P.L) {
-            qv = *reinterpret_cast<const uint4 *>(qb + (long)row * P.q_ls + d0);
-            ov = *reinterpret_cast<const uint4 *>(ob + (long)row * E + d0);
-        }
-        uint2 *a = reinterpret_cast<uint2 *>(Qs + row * RS + d0);
-        a[0] = make_uint2(qv.x, qv.y), a[1] = make_uint2(qv.z, qv.w);
-        uint2 *c = reinterpret_cast<uint2 *>(dOs + row * RS + d0);
-        c[0] = make_uint2(gv.x, gv.y), c[1] = make_uint2(gv.z, gv.w);
-        const u16 *oe = reinterpret_cast<const u16 *>(&ov), *ge = reinterpret_cast<const u16 *>(&gv);
-        float dsum = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) dsum += bf2f(oe[i]) * bf2f(ge[i]);
-        dsum += __shfl_xor(dsum, 1);
-        dsum += __shfl_xor(dsum, 2);
-        dsum += __shfl_xor(dsum, 4);
-        if ((idx & 7) == 0) {
-            D_s[row] = dsum;
-            lse_s[row] = row < P.L ? lse[(long)bh * P.L + row] : INFINITY;  // +inf lse silences padded queries
-            rb_s[row] = dc.on ? attn_rowbase(dc.seed, P.site, (uint32_t)(bh * P.L + row)) : 0u;
+        const bool live = __syncthreads_or(any_dout) != 0;  // zero upstream gradient -> dK = dV = 0 (see role A)
+        if (!live) {
+            const int kz = kt * KT + (threadIdx.x >> 3), dz = (threadIdx.x & 7) * 8;
+            if (kz < P.S) {
+                *reinterpret_cast<uint4 *>(dk + (long)b * dk_bs + (long)kz * dk_ls + h * HD + dz) = make_uint4(0, 0, 0, 0);
+                *reinterpret_cast<uint4 *>(dv + (long)b * dv_bs + (long)kz * dv_ls + h * HD + dz) = make_uint4(0, 0, 0, 0);
+            }
+            return;
         }
     }
-    __syncthreads();
     const int key = kt * KT + (lane & 31);
     const bool kin = key < P.S;
     const bool kok = kin && !(mask != nullptr && mask[key] != 0);
@@ -457,41 +431,75 @@ __global__ __launch_bounds__(WG) void pcm_attn_small_bwd_kernel(AttnParams P, co
     f16v dk0, dk1, dv0, dv1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dk0[r] = 0.f, dk1[r] = 0.f, dv0[r] = 0.f, dv1[r] = 0.f;
-    for (int qt = w; qt < nqt; qt += NW) {
-        f16v s, dp;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int row0 = ch * LMAX;
+        const int tiles_here = ((P.L - row0 < LMAX ? P.L - row0 : LMAX) + 31) / 32;
+        if (ch > 0) __syncthreads();  // the previous chunk's tiles are no longer read
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = 0.f, dp[r] = 0.f;
-#pragma unroll
-        for (int sl = 0; sl < 8; ++sl) {
-            const int off = (qt * 32 + (lane & 31)) * RS + sl * 8 + 4 * (lane >> 5);
-            s = PCM_MFMA(lds_s4(Qs + off), kf[sl], s);  // rows = queries, columns = keys
-            dp = PCM_MFMA(lds_s4(dOs + off), vf[sl], dp);
-        }
-        float pd[16], ds[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int qr = qt * 32 + crow(r, lane);
-            const float pr = kok ? __expf(s[r] * P.scale - lse_s[qr]) : 0.f;
-            float dpv = dp[r];
-            pd[r] = pr;
-            if (dc.on) {
-                const bool keep = attn_keep(rb_s[qr], (uint32_t)key, dc.thr);
-                pd[r] = keep ? pr * dc.inv_keep : 0.f;
-                dpv = keep ? dpv * dc.inv_keep : 0.f;
+        for (int it = 0; it < LMAX * 8 / WG; ++it) {  // stage Q and dO rows (zero beyond L), D = rowsum(dO * O)
+            const int idx = threadIdx.x + it * WG;
+            if (idx >= tiles_here * 32 * 8) break;
+            const int lrow = idx >> 3, row = row0 + lrow, d0 = (idx & 7) * 8;  // 8 consecutive lanes share a row
+            uint4 qv = make_uint4(0, 0, 0, 0), ov = make_uint4(0, 0, 0, 0), gv = make_uint4(0, 0, 0, 0);
+            if (row < P.L) {
+                qv = *reinterpret_cast<const uint4 *>(qb + (long)row * P.q_ls + d0);
+                ov = *reinterpret_cast<const uint4 *>(ob + (long)row * E + d0);
+                gv = (nchunk == 1) ? gpre[it] : *reinterpret_cast<const uint4 *>(gb + (long)row * E + d0);
             }
-            ds[r] = pr * (dpv - D_s[qr]) * P.scale;
-        }
+            uint2 *a = reinterpret_cast<uint2 *>(Qs + lrow * RS + d0);
+            a[0] = make_uint2(qv.x, qv.y), a[1] = make_uint2(qv.z, qv.w);
+            uint2 *c = reinterpret_cast<uint2 *>(dOs + lrow * RS + d0);
+            c[0] = make_uint2(gv.x, gv.y), c[1] = make_uint2(gv.z, gv.w);
+            const u16 *oe = reinterpret_cast<const u16 *>(&ov), *ge = reinterpret_cast<const u16 *>(&gv);
+            float dsum = 0.f;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const s4 pf = pack4(pd[4 * g], pd[4 * g + 1], pd[4 * g + 2], pd[4 * g + 3]);
-            const s4 df = pack4(ds[4 * g], ds[4 * g + 1], ds[4 * g + 2], ds[4 * g + 3]);
-            // A operands = dO^T / Q^T: lane = channel row, 4 consecutive queries -> a column walk through the row-major tiles
-            const int qrow = qt * 32 + 8 * g + 4 * (lane >> 5);
-            const u16 *gcol = dOs + qrow * RS + (lane & 31), *qcol = Qs + qrow * RS + (lane & 31);
-            dv0 = PCM_MFMA(lds_col4(gcol), pf, dv0);
-            dv1 = PCM_MFMA(lds_col4(gcol + 32), pf, dv1);
-            dk0 = PCM_MFMA(lds_col4(qcol), df, dk0);
-            dk1 = PCM_MFMA(lds_col4(qcol + 32), df, dk1);
+            for (int i = 0; i < 8; ++i) dsum += bf2f(oe[i]) * bf2f(ge[i]);
+            dsum += __shfl_xor(dsum, 1);
+            dsum += __shfl_xor(dsum, 2);
+            dsum += __shfl_xor(dsum, 4);
+            if ((idx & 7) == 0) {
+                D_s[lrow] = dsum;
+                lse_s[lrow] = row < P.L ? lse[(long)bh * P.L + row] : INFINITY;  // +inf lse silences padded queries
+                rb_s[lrow] = dc.on ? attn_rowbase(dc.seed, P.site, (uint32_t)(bh * P.L + row)) : 0u;
+            }
+        }
+        __syncthreads();
+        for (int qt = w; qt < tiles_here; qt += NW) {
+            f16v s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f, dp[r] = 0.f;
+#pragma unroll
+            for (int sl = 0; sl < 8; ++sl) {
+                const int off = (qt * 32 + (lane & 31)) * RS + sl * 8 + 4 * (lane >> 5);
+                s = PCM_MFMA(lds_s4(Qs + off), kf[sl], s);  // rows = queries, columns = keys
+                dp = PCM_MFMA(lds_s4(dOs + off), vf[sl], dp);
+            }
+            float pd[16], ds[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qr = qt * 32 + crow(r, lane);  // row within the staged chunk
+                const float pr = kok ? __expf(s[r] * P.scale - lse_s[qr]) : 0.f;
+                float dpv = dp[r];
+                pd[r] = pr;
+                if (dc.on) {
+                    const bool keep = attn_keep(rb_s[qr], (uint32_t)key, dc.thr);
+                    pd[r] = keep ? pr * dc.inv_keep : 0.f;
+                    dpv = keep ? dpv * dc.inv_keep : 0.f;
+                }
+                ds[r] = pr * (dpv - D_s[qr]) * P.scale;
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const s4 pf = pack4(pd[4 * g], pd[4 * g + 1], pd[4 * g + 2], pd[4 * g + 3]);
+                const s4 df = pack4(ds[4 * g], ds[4 * g + 1], ds[4 * g + 2], ds[4 * g + 3]);
+                // A operands = dO^T / Q^T: lane = channel row, 4 consecutive queries -> a column walk through the row-major tiles
+                const int qrow = qt * 32 + 8 * g + 4 * (lane >> 5);
+                const u16 *gcol = dOs + qrow * RS + (lane & 31), *qcol = Qs + qrow * RS + (lane & 31);
+                dv0 = PCM_MFMA(lds_col4(gcol), pf, dv0);
+                dv1 = PCM_MFMA(lds_col4(gcol + 32), pf, dv1);
+                dk0 = PCM_MFMA(lds_col4(qcol), df, dk0);
+                dk1 = PCM_MFMA(lds_col4(qcol + 32), df, dk1);
+            }
         }
     }
     const int kk = kt * KT + cq;
@@ -514,7 +522,7 @@ inline bool strides_ok(long bs, long ls)
 
 extern "C" int pcm_attn_small_supported(int L, int S, int head_dim)
 {
-    return (head_dim == HD && L >= 1 && L <= LMAX && S >= 1) ? 1 : 0;
+    return (head_dim == HD && L >= 1 && S >= 1) ? 1 : 0;
 }
 
 extern "C" int pcm_attn_small_forward_hip(int B, int H, int L, int S, const void *q, long q_bs, long q_ls, const void *k,

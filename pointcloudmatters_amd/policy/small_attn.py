@@ -1,7 +1,7 @@
 """Attention core for short query sequences on the matrix cores (csrc/attn_small.hip) as an autograd function.
 
 ``small_attention(q, k, v, key_padding_mask, heads, dropout_p)`` == softmax(q k^T / sqrt(d) + mask) (dropout) v per head
-for q (B, L, E), k / v (B, S, E) in bf16 with E = heads * 64 and L <= 128; returns (B, L, E) -- already in the layout
+for q (B, L, E), k / v (B, S, E) in bf16 with E = heads * 64 (the policy uses it for L <= 128, S <= 1024); returns (B, L, E) -- already in the layout
 the output projection wants (the SDPA path needs a transpose copy).  Used by policy/transformer.attention for the CVAE
 encoder and the decoder; the long encoder self-attention (S = M + 3 tokens) stays on the framework's flash kernel.
 """
@@ -11,6 +11,13 @@ import torch
 from torch.autograd import Function
 
 from .. import _lib
+
+
+# The kernels handle any length (tests go to 515 x 515), but they win only for short query sets: measured on MI355X at
+# B*H = 64, 515 x 515 the forward ties the framework's flash kernel (45 us) and the backward loses (233 vs 128 us), so
+# the policy routes only <= 128 queries here (CVAE encoder, decoder self- and cross-attention).
+MAX_QUERIES = 128
+MAX_KEYS = 1024
 
 
 def _st(t):
@@ -69,7 +76,7 @@ def supported(q, k, v, heads, dropout_p=0.0):
     if not (q.is_cuda and q.dtype == k.dtype == v.dtype == torch.bfloat16 and q.dim() == 3):
         return False
     e = q.shape[-1]
-    if e % heads or e // heads != 64 or q.shape[1] > 128 or q.shape[1] < 1 or k.shape[1] < 1:
+    if e % heads or e // heads != 64 or q.shape[1] > MAX_QUERIES or q.shape[1] < 1 or k.shape[1] < 1 or k.shape[1] > MAX_KEYS:
         return False
     if dropout_p > 0 and fused_ops.current() is None:
         return False  # the dropout seed lives in the training loop's FusedContext
