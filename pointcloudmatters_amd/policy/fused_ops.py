@@ -226,9 +226,11 @@ class _FFNLN(Function):
                                            dh.data_ptr(), partial.data_ptr(), sums.data_ptr(),
                                            torch.cuda.current_stream().cuda_stream)
             _lib.check(rc, "pcm_ffn_ln_backward_hip")
+            from .rows_linear import weight_grad
+
             with torch.autocast(device_type="cuda", enabled=False):
-                dw2 = dy.t() @ hd  # (E, F)
-                dw1 = dh.t() @ x2  # (F, E)
+                dw2 = weight_grad(dy, hd, torch.float32)  # (E, F)   split-K over the rows when there are thousands
+                dw1 = weight_grad(dh, x2, torch.float32)  # (F, E)
         dgamma, dbeta, db2, db1 = sums[:E], sums[E : 2 * E], sums[2 * E : 3 * E], sums[3 * E :]
         return dx.view(shape), dw1, db1, dw2, db2, dgamma, dbeta, None, None, None, None, None, None
 
