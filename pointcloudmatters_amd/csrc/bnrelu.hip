@@ -97,17 +97,25 @@ __global__ __launch_bounds__(kBlock) void pcm_bn_colsum_kernel(long n, int C, in
 }
 
 // out[e] = sum over slots of partial[slot][e], e in [0, 2C), accumulated in fp64
-constexpr int kRedWaves = 8;
+constexpr int kRedWaves = 16;
 __global__ __launch_bounds__(64 * kRedWaves) void pcm_bn_reduce_kernel(int nslots, int VH, const float *__restrict__ partial,
                                                                          float *__restrict__ out)
 {
     __shared__ double red[kRedWaves][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + lane;
-    double acc = 0.0;
-    if (e < VH)
-        for (int s = wave; s < nslots; s += kRedWaves) acc += (double)partial[(size_t)s * VH + e];
-    red[wave][lane] = acc;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;  // four independent chains: four loads in flight per lane
+    if (e < VH) {
+        int s = wave;
+        for (; s + 3 * kRedWaves < nslots; s += 4 * kRedWaves) {
+            a0 += (double)partial[(size_t)s * VH + e];
+            a1 += (double)partial[(size_t)(s + kRedWaves) * VH + e];
+            a2 += (double)partial[(size_t)(s + 2 * kRedWaves) * VH + e];
+            a3 += (double)partial[(size_t)(s + 3 * kRedWaves) * VH + e];
+        }
+        for (; s < nslots; s += kRedWaves) a0 += (double)partial[(size_t)s * VH + e];
+    }
+    red[wave][lane] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     if (wave == 0 && e < VH) {
         double t = 0.0;
