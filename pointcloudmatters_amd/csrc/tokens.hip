@@ -142,6 +142,22 @@ extern "C" int pcm_add2_cast_hip(long n, const void *a_bf16, const void *b_bf16,
     return PCM_LAUNCH_STATUS();
 }
 
+extern "C" int pcm_slab_sum_hip(int nslabs, long n, const float *partial, int out_is_bf16, void *out, void *stream)
+{
+    // out[e] = sum_s partial[s][e]: the closing reduction of a split-K product (policy/rows_linear.py), fp64 accumulation in a
+    // fixed order, rounded ONCE to the output dtype
+    if (nslabs <= 0 || n < 0 || n > 0x7FFFFFFF) return PCM_ERR_BAD_ARG;
+    if (n == 0) return PCM_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int VH = (int)n;
+    if (out_is_bf16)
+        hipLaunchKernelGGL(pcm_colsum_reduce_kernel<__hip_bfloat16>, dim3((VH + 63) / 64), dim3(512), 0, s, nslabs, VH, partial,
+                           (__hip_bfloat16 *)out);
+    else
+        hipLaunchKernelGGL(pcm_colsum_reduce_kernel<float>, dim3((VH + 63) / 64), dim3(512), 0, s, nslabs, VH, partial, (float *)out);
+    return PCM_LAUNCH_STATUS();
+}
+
 extern "C" int pcm_colsum_slots(long rows, int C)
 {
     if (rows <= 0 || C <= 0 || C % 4 || C > 1024) return 0;

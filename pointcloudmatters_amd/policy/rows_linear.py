@@ -6,7 +6,8 @@ gradient dW = dY^T X is a GEMM with a small output (<= 1024 x 512) and a very lo
 shape with a single-pass kernel on a handful of workgroups (measured on MI355X, bf16: 51 us at 8 192 x 512 x 512,
 336 us at 131 072 x 64 x 64, against 10 us / 11 us for the forward GEMM of the same layer).  Here the reduction is cut
 into S row blocks -- one batched GEMM producing S partial products, then one fp32 sum over S -- which fills the chip
-(19 us and 18 us for the two shapes above) and is also more accurate (the partials are summed in fp32).
+(19 us and 18 us for the two shapes above) and is at least as accurate: the partials stay fp32 and are summed in a fixed
+order by pcm_slab_sum_hip with a single rounding to the gradient dtype.
 """
 import torch
 import torch.nn.functional as F
@@ -38,14 +39,22 @@ def weight_grad(go, x, out_dtype, out=None):
     s = _splits(rows)
     chunk = rows // s
     main = s * chunk
-    part = torch.bmm(go[:main].view(s, chunk, m).transpose(1, 2), x[:main].view(s, chunk, k))
-    if main == rows and out is not None:
-        return torch.sum(part, dim=0, out=out)  # fp32 accumulation inside the reduction, rounded once to out's dtype
-    if main == rows and out_dtype == part.dtype:
-        return part.sum(dim=0)
-    dw = part.sum(dim=0, dtype=torch.float32)
-    if main < rows:  # fewer than s leftover rows
-        dw = dw + (go[main:].t() @ x[main:]).float()
+    a, b = go[:main].view(s, chunk, m).transpose(1, 2), x[:main].view(s, chunk, k)
+    # fp32 partial products (bf16 inputs keep their fp32 accumulators), one fixed-order sum, ONE rounding to the output dtype
+    part = torch.bmm(a, b, out_dtype=torch.float32) if a.dtype != torch.float32 else torch.bmm(a, b)
+    tail = (go[main:].t() @ x[main:]).float() if main < rows else None
+    if tail is None and out_dtype in (torch.float32, torch.bfloat16) and (out is None or out.is_contiguous()):
+        from .. import _lib
+
+        dw = out if out is not None else torch.empty(m, k, dtype=out_dtype, device=go.device)
+        with torch.cuda.device(go.device):
+            rc = _lib.load().pcm_slab_sum_hip(s, m * k, part.data_ptr(), int(dw.dtype == torch.bfloat16), dw.data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "pcm_slab_sum_hip")
+        return dw
+    dw = part.sum(dim=0)
+    if tail is not None:  # fewer than s leftover rows
+        dw = dw + tail
     if out is not None:
         return out.copy_(dw)
     return dw.to(out_dtype)

@@ -1,0 +1,85 @@
+"""policy/rows_linear.py (split-K weight gradients) and fused_ops.proj_drln against plain framework ops."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("rows", [2048, 4120, 8192, 5003, 131072 + 17])  # exact splits, and leftovers handled by the tail GEMM
+@pytest.mark.parametrize("m,k,bias", [(64, 6, False), (512, 128, True), (96, 512, True)])
+def test_linear_rows_fp32_matches_f_linear(rows, m, k, bias):
+    from pointcloudmatters_amd.policy.rows_linear import linear_rows
+
+    torch.manual_seed(rows + m)
+    x = torch.randn(rows, k, device=DEV, requires_grad=True)
+    w = (torch.randn(m, k, device=DEV) * 0.1).requires_grad_(True)
+    b = torch.randn(m, device=DEV, requires_grad=True) if bias else None
+    y = linear_rows(x, w, b)
+    want = F.linear(x, w, b)
+    torch.testing.assert_close(y, want, rtol=1e-5, atol=1e-5)
+    g = torch.randn_like(want)
+    ins = [x, w] + ([b] if bias else [])
+    for a, r in zip(torch.autograd.grad(y, ins, g), torch.autograd.grad(want, ins, g)):
+        assert (a - r).norm().item() <= 1e-5 * r.norm().item() + 1e-6
+
+
+def test_linear_rows_autocast_three_dim_and_no_input_grad():
+    from pointcloudmatters_amd.policy.rows_linear import linear_rows
+
+    torch.manual_seed(0)
+    x = torch.randn(8, 515, 512, device=DEV)  # no grad on the input (first PointNet layer)
+    w16 = (torch.randn(1024, 512, device=DEV) * 0.05).bfloat16().requires_grad_(True)  # bf16 shadow weights
+    b16 = torch.randn(1024, device=DEV).bfloat16().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = linear_rows(x, w16, b16)
+        want = F.linear(x, w16, b16)
+    assert y.dtype == torch.bfloat16 and y.shape == (8, 515, 1024)
+    torch.testing.assert_close(y.float(), want.float(), rtol=1e-2, atol=1e-2)
+    g = torch.randn_like(want)
+    gw, gb = torch.autograd.grad(y, (w16, b16), g)
+    rw, rb = torch.autograd.grad(want, (w16, b16), g)
+    assert gw.dtype == torch.bfloat16 and gb.dtype == torch.bfloat16
+    # the split-K sum is accumulated in fp32 and rounded once: at least as close to the fp32 result as the framework's
+    exact = g.float().reshape(-1, 1024).t() @ x.reshape(-1, 512)
+    assert (gw.float() - exact).norm() <= 1.05 * (rw.float() - exact).norm() + 1e-3
+    torch.testing.assert_close(gb.float(), rb.float(), rtol=2e-2, atol=2e-1)
+
+
+def test_linear_rows_small_inputs_fall_back_to_f_linear():
+    from pointcloudmatters_amd.policy.rows_linear import MIN_ROWS, linear_rows
+
+    x = torch.randn(MIN_ROWS - 1, 32, device=DEV, requires_grad=True)
+    w = torch.randn(16, 32, device=DEV, requires_grad=True)
+    y = linear_rows(x, w)
+    assert type(y.grad_fn).__name__ != "_LinearRowsBackward"
+    xc = torch.randn(4000, 32, requires_grad=True)  # host tensors too
+    assert torch.equal(linear_rows(xc, w.cpu()), F.linear(xc, w.cpu()))
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_proj_drln_matches_the_plain_chain(p):
+    from pointcloudmatters_amd.policy import fused_ops
+
+    torch.manual_seed(1)
+    B, L, E = 4, 600, 512
+    proj = nn.Linear(E, E).to(DEV)
+    norm = nn.LayerNorm(E).to(DEV)
+    drop = nn.Dropout(p)
+    a = torch.randn(B, L, E, device=DEV, requires_grad=True)
+    x = torch.randn(B, L, E, device=DEV, requires_grad=True)
+    g = torch.randn(B, L, E, device=DEV)
+    ctx = fused_ops.FusedContext(DEV)
+    with fused_ops.activate(ctx):
+        out = fused_ops.proj_drln(a, proj, x, norm, drop)
+        if p == 0.0:
+            want = norm(x + proj(a))
+        else:  # same mask: run the un-fused drln on the projection's output at the same call site
+            with fused_ops.activate(ctx):
+                want = fused_ops.drln(x, proj(a), norm, drop)
+    torch.testing.assert_close(out, want, rtol=1e-4, atol=1e-4)
+    ins = [a, x, proj.weight, proj.bias, norm.weight, norm.bias]
+    for got, ref, name in zip(torch.autograd.grad(out, ins, g), torch.autograd.grad(want, ins, g), "a x W b gamma beta".split()):
+        assert (got - ref).norm().item() <= 1e-4 * ref.norm().item() + 1e-5, name
