@@ -58,43 +58,36 @@ def test_grid_sample_batch_matches_reference_voxels(shuffle):
 
 
 def test_grid_sample_batch_injected_pick_equals_oracle():
+    """With the random draw injected, the GPU path and the NumPy oracle keep exactly the same points.  The two order the
+    voxels differently (uint64 key vs its int64 bit pattern), so the injected numbers are attached to voxels through
+    their keys: voxel with key k of cloud i uses draw(i, k)."""
     from oracle import gridsample_cpu as G
     from pointcloudmatters_amd.bc.gpu_transforms import grid_sample_batch
 
     fx = np.load(GOLD)
     coord, _, offset, b = packed(fx)
-    for rand in (None, 13):
-        picks = []
-        for i in range(3):
-            _, _, key, count = G.grid_sample(fx[f"{i}.coord"], 0.005)
-            r = None if rand is None else np.arange(count.size) * rand + i
-            idx, _, key, _ = G.grid_sample(fx[f"{i}.coord"], 0.005, rand=r)
-            picks.append((idx + b[i], key[idx]))
-        inj = (lambda m: torch.zeros(m, dtype=torch.int64)) if rand is None else None
-        if rand is not None:
-            sizes = [p[0].shape[0] for p in picks]
-            # the oracle orders voxels by uint64 key, the GPU path by the int64 bit pattern: inject per voxel through the key
-            table = {}
-            for i, (idx, key) in enumerate(picks):
-                _, _, _, count = G.grid_sample(fx[f"{i}.coord"], 0.005)
-                for v, k in enumerate(np.unique(key)):
-                    table[(i, int(k))] = v * rand + i
-            out0 = grid_sample_batch(coord, offset, None, 0.005, rand=lambda m: torch.zeros(m, dtype=torch.int64), shuffle=False)
-            keys0 = fx_keys(fx, out0, b)
-            inj = torch.tensor([table[k] for k in keys0], dtype=torch.int64)
-        out = grid_sample_batch(coord, offset, None, 0.005, rand=inj, shuffle=False)
-        want = np.sort(np.concatenate([p[0] for p in picks]))
-        assert np.array_equal(np.sort(out["index"].cpu().numpy()), want), rand
 
+    def cloud_of(j):
+        return 0 if j < b[1] else (1 if j < b[2] else 2)
 
-def fx_keys(fx, out, b):
-    """(cloud, uint64 key) of every surviving voxel, in the GPU path's output order."""
-    idx = out["index"].cpu().numpy()
-    res = []
-    for j in idx.tolist():
-        i = 0 if j < b[1] else (1 if j < b[2] else 2)
-        res.append((i, int(fx[f"{i}.key_all"][j - b[i]])))
-    return res
+    def draw(i, key):
+        return (int(key) * 2654435761 + i) % 1000003
+
+    # rand = 0 everywhere: both sides keep the lowest original index of every voxel (stable sorts)
+    first = grid_sample_batch(coord, offset, None, 0.005, rand=lambda m: torch.zeros(m, dtype=torch.int64), shuffle=False)
+    want0 = np.concatenate([G.grid_sample(fx[f"{i}.coord"], 0.005)[0] + b[i] for i in range(3)])
+    assert np.array_equal(np.sort(first["index"].cpu().numpy()), np.sort(want0))
+    # arbitrary draws, tied to voxels by key
+    keys_gpu = [(cloud_of(j), fx[f"{cloud_of(j)}.key_all"][j - b[cloud_of(j)]]) for j in first["index"].cpu().tolist()]
+    inj = torch.tensor([draw(i, k) for i, k in keys_gpu], dtype=torch.int64)
+    got = grid_sample_batch(coord, offset, None, 0.005, rand=inj, shuffle=False)["index"].cpu().numpy()
+    want = []
+    for i in range(3):
+        key = G.grid_sample(fx[f"{i}.coord"], 0.005)[2]
+        r = np.array([draw(i, k) for k in np.unique(key)], dtype=np.int64)  # oracle order = ascending uint64 key
+        want.append(G.grid_sample(fx[f"{i}.coord"], 0.005, rand=r)[0] + b[i])
+    assert np.array_equal(np.sort(got), np.sort(np.concatenate(want)))
+    assert not np.array_equal(np.sort(got), np.sort(want0))  # the draws really changed the picks
 
 
 def test_pipeline_output_feeds_the_policy_layout():

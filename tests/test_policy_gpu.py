@@ -216,7 +216,6 @@ def test_dead_decoder_layer_options_leave_every_parameter_update_unchanged(how, 
         b["vae_eps"] = eps
         loss = tr.training_step(b)["loss"].item()
         opt = tr.optimizer
-        grads = {n: opt.g_views[k].detach().clone() for (n, _), k in zip(pol.named_parameters(), range(10 ** 6)) if False}
         index = {id(p): k for k, p in enumerate(opt.params)}
         grads = {n: opt.g_views[index[id(p)]].detach().clone() for n, p in pol.named_parameters() if id(p) in index}
         results[mode] = (loss, grads, {k: v.detach().clone() for k, v in pol.state_dict().items()})
