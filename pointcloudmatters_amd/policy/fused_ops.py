@@ -162,11 +162,13 @@ def proj_drln(a, linear, x, norm, dropout):
                            ctx.seed if p > 0 else None, ctx.next_site())
 
 
-def drln_supported(x, y, norm):
+def drln_supported(x, y, norm, y_dtype=None):
+    """`y` may be None when only its dtype is known yet (the projection that produces it is part of the fused node)."""
     e = x.shape[-1]
-    return (_ACTIVE is not None and x.is_cuda and x.dtype == torch.float32 and y.dtype in (torch.float32, torch.bfloat16)
+    ydt = y.dtype if y is not None else y_dtype
+    return (_ACTIVE is not None and x.is_cuda and x.dtype == torch.float32 and ydt in (torch.float32, torch.bfloat16)
             and type(norm) is torch.nn.LayerNorm and norm.elementwise_affine and norm.bias is not None
-            and e % 256 == 0 and e <= 1024 and x.shape == y.shape)
+            and e % 256 == 0 and e <= 1024 and (y is None or x.shape == y.shape))
 
 
 def drln(x, y, norm, dropout):

@@ -54,15 +54,10 @@ def _attn_add_norm(norm: nn.Module, dropout: nn.Module, x: Tensor, mha: nn.Multi
     if ctx_on:
         a = attention(mha, *args, project=False, **kwargs)
         ydt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else a.dtype
-        if fused_ops.drln_supported(x, _FakeY(x.shape, ydt), norm) and mha.out_proj.bias is not None:
+        if fused_ops.drln_supported(x, None, norm, y_dtype=ydt) and mha.out_proj.bias is not None:
             return fused_ops.proj_drln(a, mha.out_proj, x, norm, dropout)
         return _add_norm(norm, dropout, x, linear_rows(a, mha.out_proj.weight, mha.out_proj.bias))
     return _add_norm(norm, dropout, x, attention(mha, *args, **kwargs))
-
-
-class _FakeY:  # shape / dtype carrier for drln_supported
-    def __init__(self, shape, dtype):
-        self.shape, self.dtype = shape, dtype
 
 
 def _ffn_norm(layer, norm: nn.Module, dropout_out: nn.Module, x: Tensor) -> Tensor:
