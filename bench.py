@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default="C2", help="C2 (headline), C4, REF, C1")
     ap.add_argument("--sa-impl", default=os.environ.get("PCM_SA_IMPL", "auto"))
-    ap.add_argument("--mode", default="auto", help="auto | graph | flat | eager (eager = torch AdamW + DDP + SyncBN)")
+    ap.add_argument("--mode", default="auto", help="auto | graph | hybrid | flat | eager (eager = torch AdamW + DDP + SyncBN)")
     ap.add_argument("--dead-decoder-layers", default="keep", choices=["keep", "prune_backward", "skip"],
                     help="ACT reads only decoder output [0] (act.py:270): keep = the reference's autograd graph (default, what "
                          "`value` is quoted on); prune_backward / skip = dead-code elimination variants, reported separately")
@@ -347,7 +347,8 @@ def main():
     policy = build(pcd_npoints=wl["pcd_npoints"], sa_impl=sa_impl, **extra).to(device)
     mode = args.mode
     if mode == "auto":  # hipGraph replay needs static shapes; ragged workloads use the flat optimizer eagerly
-        mode = "flat" if wl["ragged"] else "graph"
+        # ragged clouds: the tokenizer runs eagerly, everything behind the fixed-size token matrix replays as one hipGraph
+        mode = ("hybrid" if wl["policy"] == "act" else "flat") if wl["ragged"] else "graph"
     trainer = BCTrainer(policy, total_steps=max(args.steps + args.warmup, 100), precision=wl["dtype"], device=device,
                         distributed=world > 1, optim=dict(DP_OPTIM) if is_dp else dict(accumulate_grad_batches=1), mode=mode)
     batches = [make_batch(wl["batch"], wl["n_points"], seed=1000 + rank + 97 * i, ragged=wl["ragged"], device=device)

@@ -107,13 +107,15 @@ class FlatAdamW:
     def stash_grad(self, k, g):
         self._stash[k] = g if self._stash[k] is None else self._stash[k] + g
 
-    def collect(self, first):
+    def collect(self, first, subset=None):
         """Move this micro-batch's gradients into the flat buffer: one multi-tensor copy (first
         micro-batch of an accumulation window) or add per source dtype, instead of one accumulate
-        kernel per parameter."""
+        kernel per parameter.  `subset` (ascending parameter indices) restricts the hand-off to those parameters (the
+        hybrid trainer collects the captured half and the eager half of a step separately)."""
         by_dtype = {}
         zero_from = zero_to = None  # run of adjacent gradient slots without a gradient this step: one fill for the run
-        for k, p in enumerate(self.params):
+        for k in (range(len(self.params)) if subset is None else subset):
+            p = self.params[k]
             g = self._stash[k] if self.shadow[k] is not None else p.grad
             if g is None:
                 if first:

@@ -97,7 +97,7 @@ class BCTrainer:
         self.accumulate = int(o["accumulate_grad_batches"])
         self.clip = o["gradient_clip_val"]
         self.log_every_n_steps = log_every_n_steps
-        if mode not in ("eager", "flat", "graph"):
+        if mode not in ("eager", "flat", "graph", "hybrid"):
             raise ValueError(mode)
         if self.device.type != "cuda" and mode != "eager" and (flat_optimizer_cls is None or mode == "graph"):
             raise ValueError("flat/graph modes run on the HIP device only")
@@ -172,6 +172,93 @@ class BCTrainer:
         if self.precision == "bf16":
             return torch.autocast(device_type=self.device.type, dtype=torch.bfloat16)
         return contextlib.nullcontext()
+
+    # ---- hybrid mode: eager tokenizer (ragged point clouds) + ONE hipGraph for everything behind the token matrix ------
+    def _shadow_repl(self, only=None):
+        shadows = getattr(self, "_shadow_names", None)
+        if not shadows:
+            return None
+        opt = self.optimizer
+        return {n: _ShadowParam.apply(p, opt.shadow[k], opt, k) for n, p, k in shadows if only is None or k in only}
+
+    def _call_policy(self, batch, only=None, **kwargs):
+        repl = self._shadow_repl(only)
+        if repl is not None:
+            return torch.func.functional_call(self.policy, repl, (batch,), kwargs)
+        return self.module(batch, **kwargs)
+
+    def _hybrid_setup(self, batch):
+        """Split the parameters by stage, build the static inputs of the captured half and capture it."""
+        from ..policy import fused_ops
+        from .synthetic import clone_batch
+
+        opt = self.optimizer
+        index = {id(p): k for k, p in enumerate(opt.params)}
+        tok = sorted(index[id(p)] for p in self.policy.tokenizer_parameters() if id(p) in index)
+        tok_set = set(tok)
+        self._subset_a, self._subset_b = tok, [k for k in range(len(opt.params)) if k not in tok_set]
+        self._subset_a_set = tok_set
+        buffers = {n: b.clone() for n, b in self.policy.named_buffers()}  # nothing below may count as training
+        with fused_ops.activate(self._fused_ctx), self._autocast(), torch.no_grad():
+            tokens, pos = self._call_policy(clone_batch(batch), stage="tokenize")  # shapes / dtypes of the boundary
+        rest = {k: v for k, v in batch.items() if k != "pcds"}
+        self._static_sig = self._signature(rest)
+        self._static_batch = self._clone_static(rest)
+        self._static_tokens = tokens.detach().clone().requires_grad_(True)
+        self._static_pos = pos.detach().clone()
+        self._static_dtokens = torch.zeros_like(self._static_tokens)
+
+        def stage_b():
+            with fused_ops.activate(self._fused_ctx), self._autocast():
+                data = clone_batch(self._static_batch)
+                data["pcd_embed"] = (self._static_tokens, self._static_pos)
+                out = self._call_policy(data)
+            loss = out["loss"]
+            self._static_tokens.grad = None
+            (loss / self.accumulate).backward()
+            self._static_dtokens.copy_(self._static_tokens.grad)
+            opt.collect(first=True, subset=self._subset_b)
+            opt_stats = torch.stack([loss.detach().float(), out.get("action_loss", loss).detach().float(),
+                                     torch.as_tensor(out.get("kl_loss", 0.0), device=loss.device).detach().float()])
+            return opt_stats
+
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                stage_b()
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            for n, b in self.policy.named_buffers():
+                b.copy_(buffers[n])
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            self._static_stats = stage_b()
+        self._graph = graph
+        for k in range(len(opt.params)):
+            opt._stash[k] = None
+            opt.params[k].grad = None
+
+    def _hybrid_step(self, batch):
+        from ..policy import fused_ops
+
+        if self._graph is None:
+            self._hybrid_setup(batch)
+        rest = {k: v for k, v in batch.items() if k != "pcds"}
+        if self._signature(rest) != self._static_sig:
+            raise ValueError("hybrid mode needs a fixed batch size / action layout (only the point clouds may be ragged)")
+        with fused_ops.activate(self._fused_ctx), self._autocast():
+            tokens, pos = self._call_policy(batch, only=self._subset_a_set, stage="tokenize")  # eager: shapes follow the clouds
+        with torch.no_grad():
+            self._static_tokens.copy_(tokens)
+            self._static_pos.copy_(pos)
+            self._copy_into(self._static_batch, rest)
+        self._graph.replay()
+        tokens.backward(self._static_dtokens)
+        self.optimizer.collect(first=True, subset=self._subset_a)
+        return self._static_stats.clone()
 
     def _forward_backward(self, batch):
         from ..policy import fused_ops
@@ -286,7 +373,11 @@ class BCTrainer:
                     self.mode, self._graph = "flat", None
                     for p in self.optimizer.params:
                         p.grad = None
-            if self.mode == "graph":
+            if self.mode == "hybrid":
+                if self.accumulate != 1:
+                    raise NotImplementedError("mode='hybrid' supports accumulate_grad_batches=1")
+                stats = self._hybrid_step(batch)
+            elif self.mode == "graph":
                 if self._signature(batch) != self._static_sig:
                     raise ValueError("graph mode needs the captured batch layout (equal shapes and cloud offsets); "
                                      "use mode='flat' for ragged batches")

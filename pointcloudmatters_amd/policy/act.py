@@ -230,7 +230,10 @@ class ACTPCD(nn.Module):
             if data_dict["goal_cond"].dim() > 2:
                 data_dict["goal_cond"] = data_dict["goal_cond"].reshape(data_dict["goal_cond"].shape[0], -1)
             goal_cond = self.proj_goal_cond_emb(data_dict["goal_cond"])
-        pcd_tokens, pcd_pos = self.forward_pcd_embed(data_dict["pcds"])
+        if "pcd_embed" in data_dict:  # tokens computed by an earlier stage (BCTrainer mode="hybrid")
+            pcd_tokens, pcd_pos = data_dict["pcd_embed"]
+        else:
+            pcd_tokens, pcd_pos = self.forward_pcd_embed(data_dict["pcds"])
         proprio_input = self.input_proj_robot_state(qpos).unsqueeze(0)
         if goal_cond is not None:
             proprio_input = torch.cat([proprio_input, goal_cond.unsqueeze(0)], dim=0)
@@ -259,7 +262,14 @@ class ACTPCD(nn.Module):
         data_dict["loss"] = action_loss + total_kld * self.kl_weight
         return data_dict
 
-    def forward(self, data_dict):
+    def tokenizer_parameters(self):
+        """Parameters used by `forward(..., stage="tokenize")` (PointNet + the SA layer): everything whose shapes follow
+        the number of points; the rest of the policy sees only the fixed-size token matrix."""
+        return list(self.backbone.parameters()) + list(self.linear.parameters()) + list(self.bn.parameters())
+
+    def forward(self, data_dict, stage=None):
+        if stage == "tokenize":  # point clouds -> (tokens (B, H, 1, M), position embedding): the ragged half of the step
+            return self.forward_pcd_embed(data_dict["pcds"])
         # The CVAE encoder (102 tokens) and the point-cloud tokenizer are independent until the decoder:
         # on the GPU the former runs on a forked HIP stream (its backward follows on the same stream), so
         # its ~200 small kernels fill the gaps of the PointNet / set-abstraction branch.

@@ -231,3 +231,34 @@ def test_dead_decoder_layer_options_leave_every_parameter_update_unchanged(how, 
     for k in pa:  # ... and those layers are still weight-decayed identically
         if ".decoder.layers.1." in k or ".decoder.layers.2." in k:
             torch.testing.assert_close(pb[k], pa[k], rtol=0, atol=0, msg=k)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_hybrid_mode_matches_flat_mode_on_ragged_batches(precision, hip_device):
+    """mode="hybrid": eager tokenizer (cloud sizes change every step) + one captured graph for the rest; same maths as
+    mode="flat" -- compared through the gradients the optimizer consumes and the losses."""
+    from pointcloudmatters_amd.bc import BCTrainer, build_act_policy, clone_batch, make_act_batch
+
+    small = dict(hidden_dim=768, nhead=12, dim_feedforward=32, num_encoder_layers=1, num_decoder_layers=2, dropout=0.0, latent_dim=8,
+                 num_queries=10)
+    batches = [make_act_batch(2, 300, seed=90 + i, ragged=True, device=hip_device, num_queries=10) for i in range(3)]
+    assert len({b["pcds"]["coord"].shape[0] for b in batches}) == 3  # really ragged
+    eps = torch.randn(2, 8, generator=torch.Generator().manual_seed(1)).to(hip_device)
+    runs = {}
+    for mode in ("flat", "hybrid"):
+        torch.manual_seed(0)
+        pol = build_act_policy(pcd_npoints=64, sa_impl="fused", **small).to(hip_device)
+        tr = BCTrainer(pol, total_steps=20, precision=precision, device=hip_device, mode=mode, optim=dict(accumulate_grad_batches=1, lr=1e-5))
+        losses, grads = [], []
+        for i in range(4):
+            b = clone_batch(batches[i % 3])
+            b["vae_eps"] = eps
+            losses.append(tr.training_step(b)["loss"].item())
+            grads.append(tr.optimizer.flat_g.detach().clone())
+        assert tr.mode == mode
+        runs[mode] = (losses, grads, pol.bn.running_mean.detach().clone())
+    tol = 1e-5 if precision == "fp32" else 2e-2
+    assert runs["flat"][0] == pytest.approx(runs["hybrid"][0], rel=tol)
+    for ga, gb in zip(runs["flat"][1], runs["hybrid"][1]):
+        assert (ga - gb).norm().item() <= (1e-4 if precision == "fp32" else 5e-2) * ga.norm().item() + 1e-8
+    torch.testing.assert_close(runs["flat"][2], runs["hybrid"][2], rtol=1e-4, atol=1e-6)
