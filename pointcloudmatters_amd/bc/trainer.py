@@ -208,7 +208,7 @@ class BCTrainer:
         self._static_pos = pos.detach().clone()
         self._static_dtokens = torch.zeros_like(self._static_tokens)
 
-        def stage_b():
+        def stage_b(first=True):
             with fused_ops.activate(self._fused_ctx), self._autocast():
                 data = clone_batch(self._static_batch)
                 data["pcd_embed"] = (self._static_tokens, self._static_pos)
@@ -217,7 +217,7 @@ class BCTrainer:
             self._static_tokens.grad = None
             (loss / self.accumulate).backward()
             self._static_dtokens.copy_(self._static_tokens.grad)
-            opt.collect(first=True, subset=self._subset_b)
+            opt.collect(first=first, subset=self._subset_b)
             opt_stats = torch.stack([loss.detach().float(), out.get("action_loss", loss).detach().float(),
                                      torch.as_tensor(out.get("kl_loss", 0.0), device=loss.device).detach().float()])
             return opt_stats
@@ -233,13 +233,22 @@ class BCTrainer:
         with torch.no_grad():
             for n, b in self.policy.named_buffers():
                 b.copy_(buffers[n])
+        def reset():
+            for k in range(len(opt.params)):
+                opt._stash[k] = None
+                opt.params[k].grad = None
+
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            self._static_stats = stage_b()
+            self._static_stats = stage_b(first=True)
         self._graph = graph
-        for k in range(len(opt.params)):
-            opt._stash[k] = None
-            opt.params[k].grad = None
+        reset()
+        self._graph_acc = None
+        if self.accumulate > 1:  # later micro-batches of an accumulation window ADD their gradients
+            self._graph_acc = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph_acc, capture_error_mode="thread_local"):
+                self._static_stats_acc = stage_b(first=False)
+            reset()
 
     def _hybrid_step(self, batch):
         from ..policy import fused_ops
@@ -255,10 +264,11 @@ class BCTrainer:
             self._static_tokens.copy_(tokens)
             self._static_pos.copy_(pos)
             self._copy_into(self._static_batch, rest)
-        self._graph.replay()
+        first = self.micro % self.accumulate == 0
+        (self._graph if first else self._graph_acc).replay()
         tokens.backward(self._static_dtokens)
-        self.optimizer.collect(first=True, subset=self._subset_a)
-        return self._static_stats.clone()
+        self.optimizer.collect(first=first, subset=self._subset_a)
+        return (self._static_stats if first else self._static_stats_acc).clone()
 
     def _forward_backward(self, batch):
         from ..policy import fused_ops
@@ -374,8 +384,6 @@ class BCTrainer:
                     for p in self.optimizer.params:
                         p.grad = None
             if self.mode == "hybrid":
-                if self.accumulate != 1:
-                    raise NotImplementedError("mode='hybrid' supports accumulate_grad_batches=1")
                 stats = self._hybrid_step(batch)
             elif self.mode == "graph":
                 if self._signature(batch) != self._static_sig:

@@ -233,8 +233,8 @@ def test_dead_decoder_layer_options_leave_every_parameter_update_unchanged(how, 
             torch.testing.assert_close(pb[k], pa[k], rtol=0, atol=0, msg=k)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
-def test_hybrid_mode_matches_flat_mode_on_ragged_batches(precision, hip_device):
+@pytest.mark.parametrize("precision,accumulate", [("fp32", 1), ("bf16", 1), ("fp32", 2)])
+def test_hybrid_mode_matches_flat_mode_on_ragged_batches(precision, accumulate, hip_device):
     """mode="hybrid": eager tokenizer (cloud sizes change every step) + one captured graph for the rest; same maths as
     mode="flat" -- compared through the gradients the optimizer consumes and the losses."""
     from pointcloudmatters_amd.bc import BCTrainer, build_act_policy, clone_batch, make_act_batch
@@ -248,9 +248,10 @@ def test_hybrid_mode_matches_flat_mode_on_ragged_batches(precision, hip_device):
     for mode in ("flat", "hybrid"):
         torch.manual_seed(0)
         pol = build_act_policy(pcd_npoints=64, sa_impl="fused", **small).to(hip_device)
-        tr = BCTrainer(pol, total_steps=20, precision=precision, device=hip_device, mode=mode, optim=dict(accumulate_grad_batches=1, lr=1e-5))
+        tr = BCTrainer(pol, total_steps=20, precision=precision, device=hip_device, mode=mode,
+                       optim=dict(accumulate_grad_batches=accumulate, lr=1e-5))
         losses, grads = [], []
-        for i in range(4):
+        for i in range(4 * accumulate):
             b = clone_batch(batches[i % 3])
             b["vae_eps"] = eps
             losses.append(tr.training_step(b)["loss"].item())
