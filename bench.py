@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--dead-decoder-layers", default="keep", choices=["keep", "prune_backward", "skip"],
                     help="ACT reads only decoder output [0] (act.py:270): keep = the reference's autograd graph (default, what "
                          "`value` is quoted on); prune_backward / skip = dead-code elimination variants, reported separately")
+    ap.add_argument("--no-prefetch", action="store_true", help="do not hand the next batch to the trainer early (hybrid / flat / eager modes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--kernels-only", action="store_true", help="only run the per-kernel timing leg (for rocprofv3 --pmc passes)")
@@ -355,7 +356,10 @@ def main():
                for i in range(4)]
 
     def step(i):
-        trainer.training_step(clone_batch(batches[i % len(batches)]))
+        # the next batch is handed over early, as a prefetching data loader would: outside graph mode its FPS + kNN run one
+        # step ahead on the side stream (graph mode ignores it: the sampling is inside the captured graph)
+        nxt = None if args.no_prefetch else batches[(i + 1) % len(batches)]
+        trainer.training_step(clone_batch(batches[i % len(batches)]), prefetch=nxt)
 
     for i in range(args.warmup):
         step(i)

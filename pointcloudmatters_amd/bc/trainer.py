@@ -350,10 +350,28 @@ class BCTrainer:
         self._graph = graph
         self.optimizer.zero_grad()
 
-    def training_step(self, batch):
+    def prefetch_sampling(self, next_batch):
+        """Hand the NEXT micro-batch over early (what a data loader's prefetch does): its FPS + kNN indices -- functions of
+        the input coordinates only -- are computed on the side stream while the current step runs.  Pays off in hybrid
+        mode, where the sampling otherwise sits in front of the captured graph; a no-op in graph mode (the sampling is
+        part of the captured graph there) and on the host."""
+        if self.mode == "graph" or next_batch is None:
+            return
+        pcds = next_batch["pcds"] if "pcds" in next_batch else next_batch.get("obs", {}).get("pcds")
+        if pcds is None or not pcds["coord"].is_cuda:
+            return
+        pol = self.policy
+        target = pol if hasattr(pol, "prefetch_sampling") else getattr(pol, "obs_encoder", None)
+        if target is not None and getattr(target, "overlap_sampling", False) and hasattr(target, "prefetch_sampling"):
+            target.prefetch_sampling(pcds)
+
+    def training_step(self, batch, prefetch=None):
         """One micro-batch: forward, loss, backward and -- on accumulation boundaries -- the
-        optimizer step.  Returns the (detached, on-device) loss dict of this micro-batch."""
+        optimizer step.  Returns the (detached, on-device) loss dict of this micro-batch.
+        `prefetch`: the next micro-batch, if it is already on the device (see prefetch_sampling)."""
         self.module.train()
+        if prefetch is not None:
+            self.prefetch_sampling(prefetch)
         if self._fused_ctx is not None:
             self._fused_ctx.set_step(self.micro)
         first = self.micro % self.accumulate == 0

@@ -206,6 +206,11 @@ class ACTPCD(nn.Module):
     def coord_embedding_sine(self, coord, temperature=10000, normalize=False, scale=None):
         return coord_embedding_sine(coord, self.hidden_dim, temperature, normalize, scale)
 
+    def prefetch_sampling(self, pcd_dict):
+        """Start FPS + kNN for a future batch's clouds on the side stream (see sa_layer.prefetch_sampling)."""
+        coord, offset = pcd_dict["coord"], pcd_dict["offset"]
+        set_abstraction.prefetch_sampling(self, self.pointops, coord, offset, self._new_offsets(offset))
+
     def forward_pcd_embed(self, pcd_dict):
         coord, offset = pcd_dict["coord"], pcd_dict["offset"]
         n_o = self._new_offsets(offset)

@@ -467,6 +467,10 @@ class PCDObsEncoder(_AttrMixin):
             cache[key] = t
         return cache[key]
 
+    def prefetch_sampling(self, pcd_dict):
+        coord, offset = pcd_dict["coord"], pcd_dict["offset"]
+        set_abstraction.prefetch_sampling(self, self.pointops, coord, offset, self._new_offsets(offset))
+
     def encode_pcd(self, pcd_model, pcd_dict):
         coord, offset = pcd_dict["coord"], pcd_dict["offset"]
         n_o = self._new_offsets(offset)

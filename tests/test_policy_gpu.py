@@ -263,3 +263,28 @@ def test_hybrid_mode_matches_flat_mode_on_ragged_batches(precision, accumulate, 
     for ga, gb in zip(runs["flat"][1], runs["hybrid"][1]):
         assert (ga - gb).norm().item() <= (1e-4 if precision == "fp32" else 5e-2) * ga.norm().item() + 1e-8
     torch.testing.assert_close(runs["flat"][2], runs["hybrid"][2], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("mode", ["flat", "hybrid"])
+def test_prefetched_sampling_gives_identical_steps(mode, hip_device):
+    """FPS + kNN computed one batch ahead (trainer.prefetch_sampling) must not change anything: same losses, and each
+    batch's indices are consumed exactly once."""
+    from pointcloudmatters_amd.bc import BCTrainer, build_act_policy, clone_batch, make_act_batch
+
+    small = dict(hidden_dim=768, nhead=12, dim_feedforward=32, num_encoder_layers=1, num_decoder_layers=1, dropout=0.0, latent_dim=8,
+                 num_queries=10)
+    batches = [make_act_batch(2, 300, seed=70 + i, ragged=True, device=hip_device, num_queries=10) for i in range(3)]
+    eps = torch.randn(2, 8, generator=torch.Generator().manual_seed(1)).to(hip_device)
+    runs = []
+    for use_prefetch in (False, True):
+        torch.manual_seed(0)
+        pol = build_act_policy(pcd_npoints=64, sa_impl="fused", **small).to(hip_device)
+        tr = BCTrainer(pol, total_steps=20, precision="fp32", device=hip_device, mode=mode, optim=dict(accumulate_grad_batches=1, lr=1e-3))
+        losses = []
+        for i in range(6):
+            b = clone_batch(batches[i % 3])
+            b["vae_eps"] = eps
+            losses.append(tr.training_step(b, prefetch=batches[(i + 1) % 3] if use_prefetch else None)["loss"].item())
+        runs.append(losses)
+        assert len(pol.__dict__.get("_prefetched", {})) == (1 if use_prefetch else 0)  # only the batch after the last step is pending
+    assert runs[0] == pytest.approx(runs[1], rel=1e-6)
