@@ -349,7 +349,7 @@ def main():
     mode = args.mode
     if mode == "auto":  # hipGraph replay needs static shapes; ragged workloads use the flat optimizer eagerly
         # ragged clouds: the tokenizer runs eagerly, everything behind the fixed-size token matrix replays as one hipGraph
-        mode = ("hybrid" if wl["policy"] == "act" else "flat") if wl["ragged"] else "graph"
+        mode = "hybrid" if wl["ragged"] else "graph"
     trainer = BCTrainer(policy, total_steps=max(args.steps + args.warmup, 100), precision=wl["dtype"], device=device,
                         distributed=world > 1, optim=dict(DP_OPTIM) if is_dp else dict(accumulate_grad_batches=1), mode=mode)
     batches = [make_batch(wl["batch"], wl["n_points"], seed=1000 + rank + 97 * i, ragged=wl["ragged"], device=device)

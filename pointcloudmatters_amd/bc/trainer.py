@@ -200,18 +200,18 @@ class BCTrainer:
         self._subset_a_set = tok_set
         buffers = {n: b.clone() for n, b in self.policy.named_buffers()}  # nothing below may count as training
         with fused_ops.activate(self._fused_ctx), self._autocast(), torch.no_grad():
-            tokens, pos = self._call_policy(clone_batch(batch), stage="tokenize")  # shapes / dtypes of the boundary
-        rest = {k: v for k, v in batch.items() if k != "pcds"}
+            ragged, rest = self.policy.hybrid_split(clone_batch(batch))
+            boundary = tuple(self._call_policy(ragged, stage="tokenize"))  # shapes / dtypes of the boundary
         self._static_sig = self._signature(rest)
         self._static_batch = self._clone_static(rest)
-        self._static_tokens = tokens.detach().clone().requires_grad_(True)
-        self._static_pos = pos.detach().clone()
+        # boundary[0] carries the gradient back to the tokenizer; the others (position embedding) are inputs only
+        self._static_tokens = boundary[0].detach().clone().requires_grad_(True)
+        self._static_extra = tuple(t.detach().clone() for t in boundary[1:])
         self._static_dtokens = torch.zeros_like(self._static_tokens)
 
         def stage_b(first=True):
             with fused_ops.activate(self._fused_ctx), self._autocast():
-                data = clone_batch(self._static_batch)
-                data["pcd_embed"] = (self._static_tokens, self._static_pos)
+                data = self.policy.hybrid_merge(clone_batch(self._static_batch), (self._static_tokens,) + self._static_extra)
                 out = self._call_policy(data)
             loss = out["loss"]
             self._static_tokens.grad = None
@@ -255,14 +255,16 @@ class BCTrainer:
 
         if self._graph is None:
             self._hybrid_setup(batch)
-        rest = {k: v for k, v in batch.items() if k != "pcds"}
+        ragged, rest = self.policy.hybrid_split(batch)
         if self._signature(rest) != self._static_sig:
             raise ValueError("hybrid mode needs a fixed batch size / action layout (only the point clouds may be ragged)")
         with fused_ops.activate(self._fused_ctx), self._autocast():
-            tokens, pos = self._call_policy(batch, only=self._subset_a_set, stage="tokenize")  # eager: shapes follow the clouds
+            boundary = tuple(self._call_policy(ragged, only=self._subset_a_set, stage="tokenize"))  # eager: shapes follow the clouds
+        tokens = boundary[0]
         with torch.no_grad():
             self._static_tokens.copy_(tokens)
-            self._static_pos.copy_(pos)
+            for dst, src in zip(self._static_extra, boundary[1:]):
+                dst.copy_(src)
             self._copy_into(self._static_batch, rest)
         first = self.micro % self.accumulate == 0
         (self._graph if first else self._graph_acc).replay()

@@ -272,6 +272,15 @@ class ACTPCD(nn.Module):
         the number of points; the rest of the policy sees only the fixed-size token matrix."""
         return list(self.backbone.parameters()) + list(self.linear.parameters()) + list(self.bn.parameters())
 
+    @staticmethod
+    def hybrid_split(batch):
+        """-> (the ragged part handed to stage "tokenize", the fixed-shape rest)."""
+        return {"pcds": batch["pcds"]}, {k: v for k, v in batch.items() if k != "pcds"}
+
+    @staticmethod
+    def hybrid_merge(rest, boundary):
+        return dict(rest, pcd_embed=boundary)
+
     def forward(self, data_dict, stage=None):
         if stage == "tokenize":  # point clouds -> (tokens (B, H, 1, M), position embedding): the ragged half of the step
             return self.forward_pcd_embed(data_dict["pcds"])

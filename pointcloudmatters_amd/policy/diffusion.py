@@ -471,14 +471,18 @@ class PCDObsEncoder(_AttrMixin):
         coord, offset = pcd_dict["coord"], pcd_dict["offset"]
         set_abstraction.prefetch_sampling(self, self.pointops, coord, offset, self._new_offsets(offset))
 
-    def encode_pcd(self, pcd_model, pcd_dict):
+    def sa_tokens(self, pcd_model, pcd_dict):
+        """The ragged half: PointNet + set abstraction -> (b*M, C) tokens (fixed shape whatever the cloud sizes)."""
         coord, offset = pcd_dict["coord"], pcd_dict["offset"]
         n_o = self._new_offsets(offset)
         pre = set_abstraction.sample_and_query(self, self.pointops, coord, offset, n_o,
                                                overlap=self.overlap_sampling and coord.is_cuda)
         features = pcd_model(pcd_dict)
-        _, x, _ = set_abstraction(self, self.pointops, coord, features, offset, n_o, impl=self.sa_impl, pre=pre)
-        x = x.view(offset.shape[0], self.pcd_npoints, -1).transpose(1, 2)  # "(b n) c -> b c n"
+        return set_abstraction(self, self.pointops, coord, features, offset, n_o, impl=self.sa_impl, pre=pre)[1]
+
+    def encode_pcd(self, pcd_model, pcd_dict):
+        x = pcd_dict["sa_tokens"] if "sa_tokens" in pcd_dict else self.sa_tokens(pcd_model, pcd_dict)
+        x = x.view(-1, self.pcd_npoints, x.shape[-1]).transpose(1, 2)  # "(b n) c -> b c n"
         for layer in self.projector:  # 1x1 convolutions as GEMMs (MIOpen falls back to naive bf16 kernels here)
             x = conv1d_gemm(x, layer) if isinstance(layer, nn.Conv1d) else layer(x.contiguous() if isinstance(layer, nn.BatchNorm1d) else x)
         return x.squeeze(-1)
@@ -487,9 +491,12 @@ class PCDObsEncoder(_AttrMixin):
         feats, batch = [], None
         for key in self.pcd_keys:
             pcd = obs_dict[key]
-            assert len(pcd["offset"]) % self.n_obs_step == 0
-            batch = len(pcd["offset"])
-            assert pcd["feat"].shape[1:] == self.key_shape_map[key]
+            if "sa_tokens" in pcd:  # tokens computed by an earlier stage (BCTrainer mode="hybrid")
+                batch = pcd["sa_tokens"].shape[0] // self.pcd_npoints
+            else:
+                assert len(pcd["offset"]) % self.n_obs_step == 0
+                batch = len(pcd["offset"])
+                assert pcd["feat"].shape[1:] == self.key_shape_map[key]
             feats.append(self.encode_pcd(self.key_model_map["pcd"], pcd).reshape(batch, -1))
         for key in self.low_dim_keys:
             data = obs_dict[key]
@@ -609,7 +616,24 @@ class DiffusionUnetPcdPolicy(_AttrMixin):
         loss = loss.reshape(bsz, -1).mean(dim=1).mean()
         return dict(loss=loss)
 
-    def forward(self, batch):
+    def tokenizer_parameters(self):
+        enc = self.obs_encoder
+        return list(enc.key_model_map.parameters()) + list(enc.linear.parameters()) + list(enc.bn.parameters())
+
+    @staticmethod
+    def hybrid_split(batch):
+        obs = batch["obs"]
+        rest = dict(batch, obs={k: v for k, v in obs.items() if k != "pcds"})
+        return {"obs": {"pcds": obs["pcds"]}}, rest
+
+    @staticmethod
+    def hybrid_merge(rest, boundary):
+        return dict(rest, obs=dict(rest["obs"], pcds={"sa_tokens": boundary[0]}))
+
+    def forward(self, batch, stage=None):
+        if stage == "tokenize":  # packed clouds -> SA tokens (b*M, C): the part whose shapes follow the cloud sizes
+            enc = self.obs_encoder
+            return (enc.sa_tokens(enc.key_model_map["pcd"], batch["obs"]["pcds"]),)
         out = self.compute_loss(batch)
         out.setdefault("action_loss", out["loss"])
         out.setdefault("kl_loss", out["loss"].new_zeros(()))

@@ -288,3 +288,30 @@ def test_prefetched_sampling_gives_identical_steps(mode, hip_device):
         runs.append(losses)
         assert len(pol.__dict__.get("_prefetched", {})) == (1 if use_prefetch else 0)  # only the batch after the last step is pending
     assert runs[0] == pytest.approx(runs[1], rel=1e-6)
+
+
+def test_hybrid_mode_matches_flat_mode_for_the_diffusion_policy(hip_device):
+    from pointcloudmatters_amd.bc import BCTrainer, build_dp_policy, clone_batch, make_dp_batch
+    from pointcloudmatters_amd.bc.configs import DP_OPTIM
+    from tests.golden.make_golden import DP_SMALL
+
+    batches = [make_dp_batch(3, 150, seed=40 + i, ragged=True, device=hip_device) for i in range(3)]
+    g = torch.Generator().manual_seed(3)
+    noise = torch.randn(3, 16, 7, generator=g).to(hip_device)
+    tsteps = torch.tensor([3, 57, 99], device=hip_device)
+    runs = {}
+    for mode in ("flat", "hybrid"):
+        torch.manual_seed(0)
+        pol = build_dp_policy(pcd_npoints=32, sa_impl="fused", **DP_SMALL).to(hip_device)
+        tr = BCTrainer(pol, total_steps=20, precision="fp32", device=hip_device, mode=mode, optim=dict(DP_OPTIM, lr=1e-5))
+        losses, grads = [], []
+        for i in range(4):
+            b = clone_batch(batches[i % 3])
+            b["noise"], b["timesteps"] = noise, tsteps
+            losses.append(tr.training_step(b)["loss"].item())
+            grads.append(tr.optimizer.flat_g.detach().clone())
+        assert tr.mode == mode
+        runs[mode] = (losses, grads)
+    assert runs["flat"][0] == pytest.approx(runs["hybrid"][0], rel=1e-5)
+    for ga, gb in zip(runs["flat"][1], runs["hybrid"][1]):
+        assert (ga - gb).norm().item() <= 1e-4 * ga.norm().item() + 1e-8
