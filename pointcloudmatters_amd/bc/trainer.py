@@ -456,3 +456,7 @@ class BCTrainer:
             self.scheduler.load_state_dict(sd["scheduler"])
         self.micro = sd["micro"]
         self.optimizer_steps = sd["optimizer_steps"]
+        mirror = getattr(self.optimizer, "flat_p_bf16", None)
+        if mirror is not None:  # the bf16 weight copies the forward reads are normally refreshed by the Adam kernel
+            with torch.no_grad():
+                mirror.copy_(self.optimizer.flat_p)
