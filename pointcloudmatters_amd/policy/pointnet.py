@@ -9,7 +9,6 @@ Module names are kept (``conv1.0`` = linear, ``conv1.1`` = BN) so state-dict key
 spconv weight layout differs (see ``load_reference_state_dict``).  spconv itself is a third-party
 CUDA library absent from the reference tree: parity of this restatement is unpinned.
 """
-import torch
 import torch.nn as nn
 
 from .rows_linear import linear_rows

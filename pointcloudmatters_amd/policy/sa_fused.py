@@ -9,7 +9,6 @@ Same result as ``sa_impl="reference"`` up to fp32 re-association (tests: 1e-4 re
 less HBM traffic and no (m, K, 3+C) / (m, H, K) intermediates.
 """
 import torch
-import torch.nn.functional as F
 from torch.autograd import Function
 
 from .. import _lib

@@ -3,7 +3,6 @@
 Bit-exact for FPS indices, kNN / ball-query neighbour lists and their dist2; fp32 gather outputs
 exact; atomic-scatter backward within 1e-5 relative (summation order is free in the reference too).
 """
-import numpy as np
 import pytest
 import torch
 

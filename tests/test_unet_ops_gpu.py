@@ -1,6 +1,5 @@
 """csrc/gnmish.hip through its Python wrappers (policy/unet_ops.py) against plain PyTorch fp32 references of the same
 ops, forward and backward: channels-last im2col / col2im and the fused GroupNorm + Mish (+ FiLM, + residual)."""
-import numpy as np
 import pytest
 import torch
 import torch.nn as nn
