@@ -179,11 +179,21 @@ __global__ __launch_bounds__(WG) void pcm_attn_small_fwd_kernel(AttnParams P, u1
             tile_fetch(kr, kb, P.k_ls, (kt + NW) * KT, P.S, lane);
             tile_fetch(vr, vb, P.v_ls, (kt + NW) * KT, P.S, lane);
         }
+        // every LDS operand of this tile is requested up front: the reads drain while the matrix cores and the softmax run
+        s4 ka[8], va0[4], va1[4];
+#pragma unroll
+        for (int sl = 0; sl < 8; ++sl) ka[sl] = lds_s4(Ks + (lane & 31) * RS + sl * 8 + 4 * (lane >> 5));
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const u16 *vcol = Vs + (8 * g + 4 * (lane >> 5)) * RS + (lane & 31);  // V^T fragment: lane = channel, 4 consecutive keys
+            va0[g] = lds_col4(vcol);
+            va1[g] = lds_col4(vcol + 32);
+        }
         f16v s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
-        for (int sl = 0; sl < 8; ++sl) s = PCM_MFMA(lds_s4(Ks + (lane & 31) * RS + sl * 8 + 4 * (lane >> 5)), qf[sl], s);
+        for (int sl = 0; sl < 8; ++sl) s = PCM_MFMA(ka[sl], qf[sl], s);
         const bool edge = (kt + 1) * KT > P.S || mask != nullptr;
         float tmax = -INFINITY;
 #pragma unroll
@@ -218,9 +228,8 @@ __global__ __launch_bounds__(WG) void pcm_attn_small_fwd_kernel(AttnParams P, u1
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const s4 pf = pack4(p[4 * g], p[4 * g + 1], p[4 * g + 2], p[4 * g + 3]);
-            const u16 *vcol = Vs + (8 * g + 4 * (lane >> 5)) * RS + (lane & 31);  // V^T fragment: lane = channel, 4 consecutive keys
-            o0 = PCM_MFMA(lds_col4(vcol), pf, o0);
-            o1 = PCM_MFMA(lds_col4(vcol + 32), pf, o1);
+            o0 = PCM_MFMA(va0[g], pf, o0);
+            o1 = PCM_MFMA(va1[g], pf, o1);
         }
     }
     // ---- the four partial results meet: part[w] = O_w (64 x 32), ml[w] = (m_w, l_w) per query
