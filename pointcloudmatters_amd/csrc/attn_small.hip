@@ -35,7 +35,7 @@ typedef unsigned short u16;
 constexpr int HD = 64;    // head dim
 constexpr int KT = 32;    // keys (or queries) per tile = one MFMA tile edge
 constexpr int LMAX = 128; // queries staged in LDS at a time by the dK/dV role
-constexpr int RS = 68;    // row stride (u16) of the row-major (32 x 64) tiles: 136 B
+constexpr int RS = 72;    // row stride (u16) of the row-major (32 x 64) tiles: 144 B (16-byte aligned rows)
 constexpr int NW = 4;     // waves per workgroup; they split the streamed dimension and meet once, at the end
 constexpr int WG = 64 * NW;
 constexpr int TILE_U16 = KT * RS;
@@ -62,6 +62,21 @@ __device__ __forceinline__ s4 pack4(float a, float b, float c, float d)  // 2 x 
     uint2 r = make_uint2(*reinterpret_cast<const uint32_t *>(&lo), *reinterpret_cast<const uint32_t *>(&hi));
     return *reinterpret_cast<s4 *>(&r);
 }
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+#define PCM_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+__device__ __forceinline__ bf8 as_bf8(const uint4 &v)
+{
+    return __builtin_bit_cast(bf8, v);
+}
+__device__ __forceinline__ bf8 cat8(const s4 &a, const s4 &b)  // (k 0..3 | k 4..7) of one lane's 32x32x16 operand
+{
+    const uint2 x = __builtin_bit_cast(uint2, a), y = __builtin_bit_cast(uint2, b);
+    return as_bf8(make_uint4(x.x, x.y, y.x, y.y));
+}
+__device__ __forceinline__ bf8 lds_bf8(const u16 *p)
+{
+    return as_bf8(*reinterpret_cast<const uint4 *>(p));
+}
 __device__ __forceinline__ s4 lds_s4(const u16 *p)
 {
     return *reinterpret_cast<const s4 *>(p);
@@ -81,15 +96,27 @@ __device__ __forceinline__ int crow(int r, int lane)  // accumulator register r 
     return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
 }
 
-// dropout on the attention weights: keep(b, h, q, key) = mix32(rowbase(b, h, q) + key * C) >= p * 2^32
+// dropout on the attention weights.  One 32-bit hash serves the PAIR of adjacent keys (2j, 2j+1) of a query:
+//   h = mixp(rowbase(b, h, q) + j * C);  keep(2j) = (h & 0xFFFF) >= thr16,  keep(2j+1) = (h >> 16) >= thr16,
+// thr16 = round(p * 65536) (|p_eff - p| < 8e-6).  mixp uses 24-bit multiplies (full-rate v_mul_u32_u24; the 32-bit
+// integer multiply is quarter rate) -- the mask generator used to cost as much VALU time as the softmax itself.
 __device__ __forceinline__ uint32_t attn_rowbase(uint64_t seed, uint32_t site, uint32_t rowid)
 {
     const uint32_t k = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9E3779B9u) ^ (site * 0x85EBCA6Bu);
     return mix32(k ^ rowid);
 }
-__device__ __forceinline__ bool attn_keep(uint32_t rowbase, uint32_t key, uint32_t thr)
+__device__ __forceinline__ uint32_t mixp(uint32_t x)
 {
-    return mix32(rowbase + key * 0x9E3779B1u) >= thr;
+    x ^= x >> 15;
+    x = __umul24(x, 0xD35A2Du) ^ (x >> 9);   // 24-bit multiplicands: low 24 bits of x, 24-bit odd constant
+    x ^= x >> 13;
+    x = __umul24(x, 0x6B4F29u) + (x >> 11);
+    x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t attn_pair_bits(uint32_t rowbase, uint32_t key_pair)
+{
+    return mixp(rowbase + key_pair * 0x9E3779B1u);
 }
 
 // one (32 x 64) bf16 tile = 256 chunks of 16 B, 4 per lane of ONE wave: chunk c = lane + 64*i -> row c>>3, cols (c&7)*8..
@@ -124,7 +151,7 @@ struct DropCfg {
     {
         on = P.p_drop > 0.f;
         seed = on ? (uint64_t)P.seed[0] : 0ull;
-        thr = on ? (uint32_t)((double)P.p_drop * 4294967296.0) : 0u;
+        thr = on ? (uint32_t)((double)P.p_drop * 65536.0 + 0.5) : 0u;  // 16-bit threshold, see attn_pair_bits
         inv_keep = on ? 1.f / (1.f - P.p_drop) : 1.f;
     }
 };
@@ -136,6 +163,77 @@ __device__ __forceinline__ void spill_acc(float *part, const f16v &a0, const f16
     for (int r = 0; r < 16; ++r) {
         part[crow(r, lane) * 32 + (lane & 31)] = a0[r];
         part[(32 + crow(r, lane)) * 32 + (lane & 31)] = a1[r];
+    }
+}
+
+// one (32 keys x 32 queries) step of the forward pass for the wave's query columns: scores, online softmax, dropout, PV.
+// v_mfma_f32_32x32x16_bf16: a lane holds 8 consecutive k per operand.  For S^T = K Q^T both operands are natural 16-byte
+// reads.  For O^T += V^T P^T the B operand comes straight from the S^T accumulator: registers 8j..8j+7 of lane-half h are
+// keys {16j+4h+i} and {16j+8+4h+i}; the A operand (V^T) is gathered with the SAME key order, so the k-sum is unchanged.
+__device__ __forceinline__ void fwd_tile(const u16 *Ks, const u16 *Vs, const bf8 (&qf)[4], f16v &o0, f16v &o1, float &m, float &lsum,
+                                         int kt, int lane, const AttnParams &P, const unsigned char *mask, const DropCfg &dc, uint32_t rb)
+{
+    const int h8 = 8 * (lane >> 5), h4 = 4 * (lane >> 5);
+    // every LDS operand of this tile is requested up front: the reads drain while the matrix cores and the softmax run
+    bf8 ka[4], va0[2], va1[2];
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) ka[sl] = lds_bf8(Ks + (lane & 31) * RS + sl * 16 + h8);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const u16 *lo = Vs + (16 * j + h4) * RS + (lane & 31), *hi = lo + 8 * RS;  // V^T: lane = channel, keys 16j+4h.. and 16j+8+4h..
+        va0[j] = cat8(lds_col4(lo), lds_col4(hi));
+        va1[j] = cat8(lds_col4(lo + 32), lds_col4(hi + 32));
+    }
+    f16v s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) s = PCM_MFMA16(ka[sl], qf[sl], s);
+    const bool edge = (kt + 1) * KT > P.S || mask != nullptr;
+    const float scale2 = P.scale * 1.44269504088896f;  // scores in the log2 domain: the exponentials are bare v_exp_f32
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        s[r] *= scale2;
+        if (edge) {
+            const int key = kt * KT + crow(r, lane);
+            const bool vis = key < P.S && !(mask != nullptr && mask[key] != 0);
+            s[r] = vis ? s[r] : -INFINITY;
+        }
+        tmax = fmaxf(tmax, s[r]);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float m_new = fmaxf(m, tmax);
+    const bool dead = m_new == -INFINITY;  // nothing visible yet for this query
+    float p[16], psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        p[r] = dead ? 0.f : __builtin_amdgcn_exp2f(s[r] - m_new);
+        psum += p[r];
+    }
+    psum += __shfl_xor(psum, 32);
+    if (__any(m_new != m)) {  // the running maximum moves in the first tiles only: skip the 32 rescales afterwards
+        const float alpha = (dead || m == -INFINITY) ? (dead ? 1.f : 0.f) : __builtin_amdgcn_exp2f(m - m_new);
+        lsum *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o0[r] *= alpha, o1[r] *= alpha;
+    }
+    lsum += psum;
+    m = m_new;
+    if (dc.on) {
+#pragma unroll
+        for (int gh = 0; gh < 8; ++gh) {  // registers 2gh, 2gh+1 hold adjacent keys: one hash for the pair
+            const uint32_t bits = attn_pair_bits(rb, (uint32_t)(kt * (KT / 2) + 4 * (gh >> 1) + 2 * (lane >> 5) + (gh & 1)));
+            p[2 * gh] = (bits & 0xFFFFu) >= dc.thr ? p[2 * gh] * dc.inv_keep : 0.f;
+            p[2 * gh + 1] = (bits >> 16) >= dc.thr ? p[2 * gh + 1] * dc.inv_keep : 0.f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const bf8 pf = cat8(pack4(p[8 * j], p[8 * j + 1], p[8 * j + 2], p[8 * j + 3]),
+                            pack4(p[8 * j + 4], p[8 * j + 5], p[8 * j + 6], p[8 * j + 7]));
+        o0 = PCM_MFMA16(va0[j], pf, o0);
+        o1 = PCM_MFMA16(va1[j], pf, o1);
     }
 }
 
@@ -151,11 +249,11 @@ __global__ __launch_bounds__(WG) void pcm_attn_small_fwd_kernel(AttnParams P, u1
     u16 *Ks = reinterpret_cast<u16 *>(smem) + w * 2 * TILE_U16, *Vs = Ks + TILE_U16;
     const int qi = blockIdx.y * 32 + (lane & 31);
     const bool qok = qi < P.L;
-    s4 qf[8];
+    bf8 qf[4];
     {
-        const u16 *qp = P.q + (long)b * P.q_bs + (long)qi * P.q_ls + h * HD + 4 * (lane >> 5);
+        const u16 *qp = P.q + (long)b * P.q_bs + (long)qi * P.q_ls + h * HD + 8 * (lane >> 5);
 #pragma unroll
-        for (int sl = 0; sl < 8; ++sl) qf[sl] = qok ? *reinterpret_cast<const s4 *>(qp + sl * 8) : zero_s4();
+        for (int sl = 0; sl < 4; ++sl) qf[sl] = as_bf8(qok ? *reinterpret_cast<const uint4 *>(qp + sl * 16) : make_uint4(0, 0, 0, 0));
     }
     const DropCfg dc(P);
     const uint32_t rb = dc.on ? attn_rowbase(dc.seed, P.site, (uint32_t)(bh * P.L + qi)) : 0u;
@@ -179,58 +277,7 @@ __global__ __launch_bounds__(WG) void pcm_attn_small_fwd_kernel(AttnParams P, u1
             tile_fetch(kr, kb, P.k_ls, (kt + NW) * KT, P.S, lane);
             tile_fetch(vr, vb, P.v_ls, (kt + NW) * KT, P.S, lane);
         }
-        // every LDS operand of this tile is requested up front: the reads drain while the matrix cores and the softmax run
-        s4 ka[8], va0[4], va1[4];
-#pragma unroll
-        for (int sl = 0; sl < 8; ++sl) ka[sl] = lds_s4(Ks + (lane & 31) * RS + sl * 8 + 4 * (lane >> 5));
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const u16 *vcol = Vs + (8 * g + 4 * (lane >> 5)) * RS + (lane & 31);  // V^T fragment: lane = channel, 4 consecutive keys
-            va0[g] = lds_col4(vcol);
-            va1[g] = lds_col4(vcol + 32);
-        }
-        f16v s;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = 0.f;
-#pragma unroll
-        for (int sl = 0; sl < 8; ++sl) s = PCM_MFMA(ka[sl], qf[sl], s);
-        const bool edge = (kt + 1) * KT > P.S || mask != nullptr;
-        float tmax = -INFINITY;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s[r] *= P.scale;
-            if (edge) {
-                const int key = kt * KT + crow(r, lane);
-                const bool vis = key < P.S && !(mask != nullptr && mask[key] != 0);
-                s[r] = vis ? s[r] : -INFINITY;
-            }
-            tmax = fmaxf(tmax, s[r]);
-        }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-        const float m_new = fmaxf(m, tmax);
-        const bool dead = m_new == -INFINITY;  // nothing visible yet for this query
-        const float alpha = dead ? 1.f : __expf(m - m_new);
-        float p[16], psum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            p[r] = dead ? 0.f : __expf(s[r] - m_new);
-            psum += p[r];
-        }
-        psum += __shfl_xor(psum, 32);
-        lsum = lsum * alpha + psum;
-        m = m_new;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o0[r] *= alpha, o1[r] *= alpha;
-        if (dc.on) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) p[r] = attn_keep(rb, (uint32_t)(kt * KT + crow(r, lane)), dc.thr) ? p[r] * dc.inv_keep : 0.f;
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const s4 pf = pack4(p[4 * g], p[4 * g + 1], p[4 * g + 2], p[4 * g + 3]);
-            o0 = PCM_MFMA(va0[g], pf, o0);
-            o1 = PCM_MFMA(va1[g], pf, o1);
-        }
+        fwd_tile(Ks, Vs, qf, o0, o1, m, lsum, kt, lane, P, mask, dc, rb);
     }
     // ---- the four partial results meet: part[w] = O_w (64 x 32), ml[w] = (m_w, l_w) per query
     __syncthreads();
@@ -247,7 +294,7 @@ __global__ __launch_bounds__(WG) void pcm_attn_small_fwd_kernel(AttnParams P, u1
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
         const float mj = ml[j * 64 + q];
-        sc[j] = (mj == -INFINITY) ? 0.f : __expf(mj - mt);
+        sc[j] = (mj == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mj - mt);
         lt += ml[j * 64 + 32 + q] * sc[j];
     }
     if (qq >= P.L) return;
@@ -265,7 +312,66 @@ __global__ __launch_bounds__(WG) void pcm_attn_small_fwd_kernel(AttnParams P, u1
     pk.x = reinterpret_cast<const uint32_t *>(&lo)[0], pk.y = reinterpret_cast<const uint32_t *>(&lo)[1];
     pk.z = reinterpret_cast<const uint32_t *>(&hi)[0], pk.w = reinterpret_cast<const uint32_t *>(&hi)[1];
     *reinterpret_cast<uint4 *>(out + ((long)b * P.L + qq) * (P.H * HD) + h * HD + dg * 8) = pk;
-    if (dg == 0) lse[(long)bh * P.L + qq] = lt > 0.f ? mt + logf(lt) : INFINITY;
+    if (dg == 0) lse[(long)bh * P.L + qq] = lt > 0.f ? mt * 0.693147180559945f + logf(lt) : INFINITY;  // m is in the log2 domain
+}
+
+// Long query sets (L > 128): grid (B*H, ceil(L/128)); wave w owns queries [128*by + 32w, +32) and ALL waves walk ALL key
+// tiles, which are loaded once per workgroup into double-buffered LDS (one barrier per tile): 4x less L2 traffic per query
+// than the split-key kernel above and no final merge.
+__global__ __launch_bounds__(WG) void pcm_attn_long_fwd_kernel(AttnParams P, u16 *__restrict__ out, float *__restrict__ lse)
+{
+    __shared__ __attribute__((aligned(16))) u16 tiles[2][2][TILE_U16];
+    const int bh = blockIdx.x, b = bh / P.H, h = bh % P.H;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int qi = blockIdx.y * (32 * NW) + w * 32 + (lane & 31);
+    const bool qok = qi < P.L;
+    bf8 qf[4];
+    {
+        const u16 *qp = P.q + (long)b * P.q_bs + (long)qi * P.q_ls + h * HD + 8 * (lane >> 5);
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) qf[sl] = as_bf8(qok ? *reinterpret_cast<const uint4 *>(qp + sl * 16) : make_uint4(0, 0, 0, 0));
+    }
+    const DropCfg dc(P);
+    const uint32_t rb = dc.on ? attn_rowbase(dc.seed, P.site, (uint32_t)(bh * P.L + qi)) : 0u;
+    f16v o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o0[r] = 0.f, o1[r] = 0.f;
+    float m = -INFINITY, lsum = 0.f;
+    const u16 *kb = P.k + (long)b * P.k_bs + h * HD;
+    const u16 *vb = P.v + (long)b * P.v_bs + h * HD;
+    const unsigned char *mask = P.kpm ? P.kpm + (long)b * P.S : nullptr;
+    const int ntiles = (P.S + KT - 1) / KT;
+    const int lr = threadIdx.x >> 3, ld0 = (threadIdx.x & 7) * 8;  // this thread's 16-byte chunk of a (32 x 64) tile
+    auto fetch = [&](const u16 *base, long ls, int kt) -> uint4 {
+        const int row = kt * KT + lr;
+        return row < P.S ? *reinterpret_cast<const uint4 *>(base + (long)row * ls + ld0) : make_uint4(0, 0, 0, 0);
+    };
+    auto stash = [&](u16 *tile, const uint4 &v) {
+        uint2 *dst = reinterpret_cast<uint2 *>(tile + lr * RS + ld0);
+        dst[0] = make_uint2(v.x, v.y);
+        dst[1] = make_uint2(v.z, v.w);
+    };
+    uint4 kr = fetch(kb, P.k_ls, 0), vr = fetch(vb, P.v_ls, 0);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int buf = kt & 1;
+        stash(tiles[buf][0], kr);
+        stash(tiles[buf][1], vr);
+        __syncthreads();  // tile kt visible; everybody left tile kt-2 (same buffer) before reaching the previous barrier
+        if (kt + 1 < ntiles) kr = fetch(kb, P.k_ls, kt + 1), vr = fetch(vb, P.v_ls, kt + 1);
+        fwd_tile(tiles[buf][0], tiles[buf][1], qf, o0, o1, m, lsum, kt, lane, P, mask, dc, rb);
+    }
+    if (!qok) return;
+    const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
+    u16 *op = out + ((long)b * P.L + qi) * (P.H * HD) + h * HD;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int d = 8 * g + 4 * (lane >> 5);
+        const s4 a = pack4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+        const s4 c = pack4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+        *reinterpret_cast<uint2 *>(op + d) = *reinterpret_cast<const uint2 *>(&a);
+        *reinterpret_cast<uint2 *>(op + 32 + d) = *reinterpret_cast<const uint2 *>(&c);
+    }
+    if ((lane >> 5) == 0) lse[(long)bh * P.L + qi] = lsum > 0.f ? m * 0.693147180559945f + logf(lsum) : INFINITY;
 }
 
 // ------------------------------------------------------------------------------------------------ backward
@@ -348,7 +454,8 @@ __global__ __launch_bounds__(WG) void pcm_attn_small_bwd_kernel(AttnParams P, co
             }
             Dq += __shfl_xor(Dq, 32);  // the two half-waves hold complementary channels of the same query
         }
-        const float lq = qok ? lse[(long)bh * P.L + qi] : INFINITY;
+        const float scale2 = P.scale * 1.44269504088896f;
+        const float lq2 = qok ? lse[(long)bh * P.L + qi] * 1.44269504088896f : INFINITY;  // log2 domain
         const uint32_t rb = dc.on ? attn_rowbase(dc.seed, P.site, (uint32_t)(bh * P.L + qi)) : 0u;
         f16v a0, a1;
 #pragma unroll
@@ -376,17 +483,23 @@ __global__ __launch_bounds__(WG) void pcm_attn_small_bwd_kernel(AttnParams P, co
             }
             const bool edge = (kt + 1) * KT > P.S || mask != nullptr;
             float ds[16];
+            if (dc.on) {
+#pragma unroll
+                for (int gh = 0; gh < 8; ++gh) {
+                    const uint32_t bits = attn_pair_bits(rb, (uint32_t)(kt * (KT / 2) + 4 * (gh >> 1) + 2 * (lane >> 5) + (gh & 1)));
+                    dp[2 * gh] = (bits & 0xFFFFu) >= dc.thr ? dp[2 * gh] * dc.inv_keep : 0.f;
+                    dp[2 * gh + 1] = (bits >> 16) >= dc.thr ? dp[2 * gh + 1] * dc.inv_keep : 0.f;
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float pr = __expf(s[r] * P.scale - lq);
-                const int key = kt * KT + crow(r, lane);
+                float pr = __builtin_amdgcn_exp2f(s[r] * scale2 - lq2);
                 if (edge) {
+                    const int key = kt * KT + crow(r, lane);
                     const bool vis = key < P.S && !(mask != nullptr && mask[key] != 0);
                     pr = vis ? pr : 0.f;
                 }
-                float dpv = dp[r];
-                if (dc.on) dpv = attn_keep(rb, (uint32_t)key, dc.thr) ? dpv * dc.inv_keep : 0.f;
-                ds[r] = pr * (dpv - Dq) * P.scale;
+                ds[r] = pr * (dp[r] - Dq) * P.scale;
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -428,6 +541,7 @@ __global__ __launch_bounds__(WG) void pcm_attn_small_bwd_kernel(AttnParams P, co
             return;
         }
     }
+    const float scale2 = P.scale * 1.44269504088896f;
     const int key = kt * KT + (lane & 31);
     const bool kin = key < P.S;
     const bool kok = kin && !(mask != nullptr && mask[key] != 0);
@@ -468,7 +582,7 @@ __global__ __launch_bounds__(WG) void pcm_attn_small_bwd_kernel(AttnParams P, co
             dsum += __shfl_xor(dsum, 4);
             if ((idx & 7) == 0) {
                 D_s[lrow] = dsum;
-                lse_s[lrow] = row < P.L ? lse[(long)bh * P.L + row] : INFINITY;  // +inf lse silences padded queries
+                lse_s[lrow] = row < P.L ? lse[(long)bh * P.L + row] * 1.44269504088896f : INFINITY;  // log2 domain; +inf silences padded queries
                 rb_s[lrow] = dc.on ? attn_rowbase(dc.seed, P.site, (uint32_t)(bh * P.L + row)) : 0u;
             }
         }
@@ -487,11 +601,12 @@ __global__ __launch_bounds__(WG) void pcm_attn_small_bwd_kernel(AttnParams P, co
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int qr = qt * 32 + crow(r, lane);  // row within the staged chunk
-                const float pr = kok ? __expf(s[r] * P.scale - lse_s[qr]) : 0.f;
+                const float pr = kok ? __builtin_amdgcn_exp2f(s[r] * scale2 - lse_s[qr]) : 0.f;  // lse_s holds lse * log2(e)
                 float dpv = dp[r];
                 pd[r] = pr;
                 if (dc.on) {
-                    const bool keep = attn_keep(rb_s[qr], (uint32_t)key, dc.thr);
+                    const uint32_t bits = attn_pair_bits(rb_s[qr], (uint32_t)key >> 1);
+                    const bool keep = ((key & 1) ? (bits >> 16) : (bits & 0xFFFFu)) >= dc.thr;
                     pd[r] = keep ? pr * dc.inv_keep : 0.f;
                     dpv = keep ? dpv * dc.inv_keep : 0.f;
                 }
@@ -545,7 +660,11 @@ extern "C" int pcm_attn_small_forward_hip(int B, int H, int L, int S, const void
     if (p_drop < 0.f || p_drop >= 1.f || (p_drop > 0.f && seed == nullptr)) return PCM_ERR_BAD_ARG;
     AttnParams P{(const u16 *)q, (const u16 *)k, (const u16 *)v, q_bs, q_ls, k_bs, k_ls, v_bs, v_ls, key_padding_mask,
                  B, H, L, S, scale, p_drop, seed, site};
-    hipLaunchKernelGGL(pcm_attn_small_fwd_kernel, dim3(B * H, (L + 31) / 32), dim3(WG), 0, (hipStream_t)stream, P, (u16 *)out, lse);
+    if (L > 4 * 32 * NW)  // long query sets: shared key / value tiles
+        hipLaunchKernelGGL(pcm_attn_long_fwd_kernel, dim3(B * H, (L + 32 * NW - 1) / (32 * NW)), dim3(WG), 0, (hipStream_t)stream, P,
+                           (u16 *)out, lse);
+    else
+        hipLaunchKernelGGL(pcm_attn_small_fwd_kernel, dim3(B * H, (L + 31) / 32), dim3(WG), 0, (hipStream_t)stream, P, (u16 *)out, lse);
     return PCM_LAUNCH_STATUS();
 }
 

@@ -18,14 +18,25 @@ def mix32(h):
     return h ^ (h >> 16)
 
 
+def mixp(x):
+    """mixp of csrc/attn_small.hip: 24-bit multiplies (v_mul_u32_u24 keeps the low 32 bits of the 48-bit product)."""
+    x = x ^ (x >> 15)
+    x = ((((x & 0xFFFFFF) * 0xD35A2D) & M32) ^ (x >> 9)) & M32
+    x = x ^ (x >> 13)
+    x = ((((x & 0xFFFFFF) * 0x6B4F29) & M32) + (x >> 11)) & M32
+    return x ^ (x >> 16)
+
+
 def keep_mask(seed, site, B, H, L, S, p):
-    """attn_keep of csrc/attn_small.hip: mix32(rowbase(b, h, q) + key * C) >= p * 2^32, as int64 tensor arithmetic."""
+    """The attention-dropout mask of csrc/attn_small.hip, as int64 tensor arithmetic: one hash per pair of adjacent keys,
+    low / high 16 bits against thr16 = round(p * 65536)."""
     rowid = torch.arange(B * H * L, dtype=torch.int64, device=DEV)
     k = (seed & M32) ^ (((seed >> 32) * 0x9E3779B9) & M32) ^ ((site * 0x85EBCA6B) & M32)
     rowbase = mix32((k ^ rowid) & M32)
     key = torch.arange(S, dtype=torch.int64, device=DEV)
-    thr = int(p * 4294967296.0)
-    return (mix32((rowbase[:, None] + key[None, :] * 0x9E3779B1) & M32) >= thr).view(B, H, L, S)
+    bits = mixp((rowbase[:, None] + (key >> 1)[None, :] * 0x9E3779B1) & M32)
+    half = torch.where((key & 1)[None, :] == 1, bits >> 16, bits & 0xFFFF)
+    return (half >= int(p * 65536.0 + 0.5)).view(B, H, L, S)
 
 
 def reference(q, k, v, kpm, heads, keep=None, p=0.0):
