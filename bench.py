@@ -218,7 +218,7 @@ def kernel_rooflines(wl, device, c_feat=512, hidden=512):
     film = torch.randn(Bu, 2 * Cu, **f32).to(torch.bfloat16)
     gu, bu_ = torch.ones(Cu, **f32), torch.zeros(Cu, **f32)
     ou, mu_u, rs_u = torch.empty(Bu, Tu, Cu, **f32), torch.empty(Bu * 8, **f32), torch.empty(Bu * 8, **f32)
-    dxu16, dgbp, dfilm = torch.empty_like(yu16), torch.empty(Bu, 2, Cu, **f32), torch.empty(Bu, 2 * Cu, **f32)
+    dxu16, dgbp, dfilm = torch.empty_like(yu16), torch.empty(Bu, 3, Cu, **f32), torch.empty(Bu, 2 * Cu, **f32)
 
     def i2c():
         assert L.pcm_im2col_cl_hip(Bu, Tu, Cu, Ku, 1, 2, 0, xu.data_ptr(), 1, cols.data_ptr(), st) == 0
@@ -228,11 +228,11 @@ def kernel_rooflines(wl, device, c_feat=512, hidden=512):
 
     def gn_f():
         assert L.pcm_gn_mish_forward_hip(Bu, Tu, Cu, 8, 1, yu16.data_ptr(), gu.data_ptr(), bu_.data_ptr(), 1e-5, 1, 1, film.data_ptr(),
-                                         0, 0, ou.data_ptr(), mu_u.data_ptr(), rs_u.data_ptr(), st) == 0
+                                         0, 0, 0, ou.data_ptr(), mu_u.data_ptr(), rs_u.data_ptr(), st) == 0
 
     def gn_b():
         assert L.pcm_gn_mish_backward_hip(Bu, Tu, Cu, 8, 1, yu16.data_ptr(), gu.data_ptr(), bu_.data_ptr(), mu_u.data_ptr(),
-                                          rs_u.data_ptr(), 1, 1, film.data_ptr(), ou.data_ptr(), dxu16.data_ptr(), dgbp.data_ptr(),
+                                          rs_u.data_ptr(), 1, 1, film.data_ptr(), 0, ou.data_ptr(), dxu16.data_ptr(), dgbp.data_ptr(),
                                           dfilm.data_ptr(), st) == 0
 
     gn_f()

@@ -253,17 +253,20 @@ int pcm_ddpm_step_hip(long n, int eps_is_bf16, const void *eps, const float *xt,
  *   pcm_col2im_cl_hip : adjoint (dx from dcols).
  *   pcm_gn_mish_*     : y = mish(GroupNorm_G(x)); film_mode 1: y = film[b,0,c]*y + film[b,1,c] (film (B,2,C));
  *                       film_mode 2: y += film[b,c]; res != NULL: y += res.  mean/rstd: (B*G).  backward writes dx
- *                       (x's dtype), dgb_partial (B,2,C) = per-sample dgamma | dbeta (sum over B is the gradient) and
- *                       dfilm (fp32, film's shape).  Supported when T*C/G <= 7168 and C/G <= 1024
+ *                       (x's dtype), dgb_partial (B,3,C) = per-sample dgamma | dbeta | dconv_bias (sum over B is the
+ *                       gradient) and dfilm (fp32, film's shape).  conv_bias (C, or NULL) is added to x on load: the
+ *                       bias of the convolution that produced x, whose gradient (sum of dx) then comes for free.
+ *                       Supported when T*C/G <= 6656 and C/G <= 1024
  *                       (pcm_gn_mish_supported; PCM_ERR_UNSUPPORTED otherwise). */
 int pcm_gn_mish_supported(int T, int C, int G);
 int pcm_gn_mish_forward_hip(int B, int T, int C, int G, int x_is_bf16, const void *x, const float *gamma,
                             const float *beta, float eps, int film_mode, int film_is_bf16, const void *film,
-                            int res_is_bf16, const void *res, float *y, float *mean, float *rstd, void *stream);
+                            int res_is_bf16, const void *res, const float *conv_bias, float *y, float *mean,
+                            float *rstd, void *stream);
 int pcm_gn_mish_backward_hip(int B, int T, int C, int G, int x_is_bf16, const void *x, const float *gamma,
                              const float *beta, const float *mean, const float *rstd, int film_mode,
-                             int film_is_bf16, const void *film, const float *dy, void *dx, float *dgb_partial,
-                             float *dfilm, void *stream);
+                             int film_is_bf16, const void *film, const float *conv_bias, const float *dy, void *dx,
+                             float *dgb_partial, float *dfilm, void *stream);
 int pcm_im2col_cl_hip(int B, int T, int C, int K, int stride, int pad, int x_is_bf16, const void *x,
                       int out_is_bf16, void *cols, void *stream);
 int pcm_col2im_cl_hip(int B, int T, int C, int K, int stride, int pad, int cols_is_bf16, const void *dcols,

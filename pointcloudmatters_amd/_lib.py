@@ -52,8 +52,8 @@ SIGNATURES = {
                                 _P, _P, _P, _P, _P, _P],
     "pcm_ddpm_step_hip": [ctypes.c_long, _i, _P, _P, _P, _P, _P, _f, _f, _f, _f, _f, _f, _P, _P],
     "pcm_gn_mish_supported": [_i, _i, _i],
-    "pcm_gn_mish_forward_hip": [_i, _i, _i, _i, _i, _P, _P, _P, _f, _i, _i, _P, _i, _P, _P, _P, _P, _P],
-    "pcm_gn_mish_backward_hip": [_i, _i, _i, _i, _i, _P, _P, _P, _P, _P, _i, _i, _P, _P, _P, _P, _P, _P],
+    "pcm_gn_mish_forward_hip": [_i, _i, _i, _i, _i, _P, _P, _P, _f, _i, _i, _P, _i, _P, _P, _P, _P, _P, _P],
+    "pcm_gn_mish_backward_hip": [_i, _i, _i, _i, _i, _P, _P, _P, _P, _P, _i, _i, _P, _P, _P, _P, _P, _P, _P],
     "pcm_im2col_cl_hip": [_i, _i, _i, _i, _i, _i, _i, _P, _i, _P, _P],
     "pcm_col2im_cl_hip": [_i, _i, _i, _i, _i, _i, _i, _P, _i, _P, _P],
     "pcm_bn_relu_supported": [ctypes.c_long, _i],

@@ -23,7 +23,7 @@
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kMaxGroupElems = 7168;  // T * C/G floats staged in LDS (x2 + 4 KiB of accumulators in backward < 64 KiB)
+constexpr int kMaxGroupElems = 6656;  // T * C/G floats staged in LDS (x2 + accumulators + 2 per channel in backward < 64 KiB)
 
 template <typename T>
 __device__ __forceinline__ float ldf(const T *p);
@@ -85,8 +85,9 @@ template <typename TX, typename TF, typename TR>
 __global__ __launch_bounds__(kBlock) void pcm_gn_mish_fwd_kernel(int T, int C, int G, const TX *__restrict__ x,
                                                                  const float *__restrict__ gamma, const float *__restrict__ beta,
                                                                  float eps, int film_mode, const TF *__restrict__ film,
-                                                                 const TR *__restrict__ res, float *__restrict__ y,
-                                                                 float *__restrict__ mean_out, float *__restrict__ rstd_out)
+                                                                 const TR *__restrict__ res, const float *__restrict__ cbias,
+                                                                 float *__restrict__ y, float *__restrict__ mean_out,
+                                                                 float *__restrict__ rstd_out)
 {
     extern __shared__ float lds[];  // [T*cg] group values, then 4 floats for reductions
     const int cg = C / G, n = T * cg;
@@ -96,12 +97,14 @@ __global__ __launch_bounds__(kBlock) void pcm_gn_mish_fwd_kernel(int T, int C, i
     const long base = (long)b * T * C + (long)g * cg;
     float s = 0.f;
     if (mp.active)
-        for (int j = mp.j0; j < cg; j += mp.W)
+        for (int j = mp.j0; j < cg; j += mp.W) {
+            const float cb = cbias ? cbias[g * cg + j] : 0.f;  // the producing convolution's bias, folded in here
             for (int t = mp.t0; t < T; t += mp.R) {
-                const float v = ldf<TX>(x + base + (long)t * C + j);
+                const float v = ldf<TX>(x + base + (long)t * C + j) + cb;
                 vals[t * cg + j] = v;  // read back only by this thread
                 s += v;
             }
+        }
     const float mean = block_sum(s, red) / (float)n;
     float q = 0.f;
     if (mp.active)
@@ -144,12 +147,13 @@ __global__ __launch_bounds__(kBlock) void pcm_gn_mish_bwd_kernel(int T, int C, i
                                                                  const float *__restrict__ gamma, const float *__restrict__ beta,
                                                                  const float *__restrict__ mean_in, const float *__restrict__ rstd_in,
                                                                  int film_mode, const TF *__restrict__ film,
-                                                                 const float *__restrict__ dy, TX *__restrict__ dx,
-                                                                 float *__restrict__ dgb_partial, float *__restrict__ dfilm)
+                                                                 const float *__restrict__ cbias, const float *__restrict__ dy,
+                                                                 TX *__restrict__ dx, float *__restrict__ dgb_partial,
+                                                                 float *__restrict__ dfilm)
 {
-    extern __shared__ float lds[];  // xhat[n] | dxhat[n] | acc[4][256] | red[4]
+    extern __shared__ float lds[];  // xhat[n] | dxhat[n] | acc[5][256] | red[4] | chan[2][cg]
     const int cg = C / G, n = T * cg;
-    float *xh = lds, *dxh = lds + n, *acc = lds + 2 * n, *red = acc + 4 * kBlock;
+    float *xh = lds, *dxh = lds + n, *acc = lds + 2 * n, *red = acc + 5 * kBlock, *chan = red + 4;
     const int b = blockIdx.x / G, g = blockIdx.x % G;
     const GroupMap mp(cg);
     const long base = (long)b * T * C + (long)g * cg;
@@ -159,14 +163,15 @@ __global__ __launch_bounds__(kBlock) void pcm_gn_mish_bwd_kernel(int T, int C, i
     for (int it = 0; it < jiters; ++it) {
         const int j = mp.j0 + it * mp.W;
         const bool live = mp.active && j < cg;
-        float a_dg = 0.f, a_db = 0.f, a_ds = 0.f, a_dbi = 0.f;
+        float a_dg = 0.f, a_db = 0.f, a_ds = 0.f, a_dbi = 0.f, a_xh = 0.f;
         if (live) {
             const int c = g * cg + j;
             const float ga = gamma[c], be = beta[c];
             const float sc = film_mode == 1 ? ldf<TF>(film + (long)b * 2 * C + c) : 1.f;
+            const float cb = cbias ? cbias[c] : 0.f;
             for (int t = mp.t0; t < T; t += mp.R) {
                 const long e = base + (long)t * C + j;
-                const float xhat = (ldf<TX>(x + e) - mean) * rstd;
+                const float xhat = (ldf<TX>(x + e) + cb - mean) * rstd;
                 const float z = xhat * ga + be;
                 const float ts = tanhf(log1pf(expf(z)));
                 const float sig = 1.f / (1.f + expf(-z));
@@ -177,6 +182,7 @@ __global__ __launch_bounds__(kBlock) void pcm_gn_mish_bwd_kernel(int T, int C, i
                 const float dz = (g_out * sc) * dmdz;
                 a_dg += dz * xhat;
                 a_db += dz;
+                a_xh += xhat;
                 const float d = dz * ga;
                 xh[t * cg + j] = xhat;
                 dxh[t * cg + j] = d;
@@ -190,15 +196,18 @@ __global__ __launch_bounds__(kBlock) void pcm_gn_mish_bwd_kernel(int T, int C, i
         acc[1 * kBlock + threadIdx.x] = a_db;
         acc[2 * kBlock + threadIdx.x] = a_ds;
         acc[3 * kBlock + threadIdx.x] = a_dbi;
+        acc[4 * kBlock + threadIdx.x] = a_xh;
         __syncthreads();
         if (live && mp.t0 == 0) {
-            float r[4] = {0.f, 0.f, 0.f, 0.f};
+            float r[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
             for (int rr = 0; rr < mp.R; ++rr)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) r[k] += acc[k * kBlock + rr * mp.W + mp.j0];
+                for (int k = 0; k < 5; ++k) r[k] += acc[k * kBlock + rr * mp.W + mp.j0];
             const int c = g * cg + j;
-            dgb_partial[(long)b * 2 * C + c] = r[0];
-            dgb_partial[(long)b * 2 * C + C + c] = r[1];
+            chan[j] = gamma[c] * r[1];  // sum_t dxhat for this channel
+            chan[cg + j] = r[4];        // sum_t xhat
+            dgb_partial[(long)b * 3 * C + c] = r[0];
+            dgb_partial[(long)b * 3 * C + C + c] = r[1];
             if (film_mode == 1) {
                 dfilm[(long)b * 2 * C + c] = r[2];
                 dfilm[(long)b * 2 * C + C + c] = r[3];
@@ -209,6 +218,9 @@ __global__ __launch_bounds__(kBlock) void pcm_gn_mish_bwd_kernel(int T, int C, i
     }
     const float c1 = block_sum(s1, red) / (float)n;
     const float c2 = block_sum(s2, red) / (float)n;
+    // sum_t dx of each channel = the gradient of a bias added in front of the normalisation (the convolution's bias)
+    for (int j = threadIdx.x; j < cg; j += kBlock)
+        dgb_partial[(long)b * 3 * C + 2 * C + g * cg + j] = rstd * (chan[j] - (float)T * c1 - c2 * chan[cg + j]);
     if (!mp.active) return;
     for (int j = mp.j0; j < cg; j += mp.W)
         for (int t = mp.t0; t < T; t += mp.R) {
@@ -284,7 +296,8 @@ extern "C" int pcm_gn_mish_supported(int T, int C, int G)
 
 extern "C" int pcm_gn_mish_forward_hip(int B, int T, int C, int G, int x_is_bf16, const void *x, const float *gamma,
                                        const float *beta, float eps, int film_mode, int film_is_bf16, const void *film,
-                                       int res_is_bf16, const void *res, float *y, float *mean, float *rstd, void *stream)
+                                       int res_is_bf16, const void *res, const float *conv_bias, float *y, float *mean, float *rstd,
+                                       void *stream)
 {
     if (B <= 0) return PCM_OK;
     if (film_mode < 0 || film_mode > 2 || (film_mode && !film)) return PCM_ERR_BAD_ARG;
@@ -294,7 +307,7 @@ extern "C" int pcm_gn_mish_forward_hip(int B, int T, int C, int G, int x_is_bf16
     using bf = __hip_bfloat16;
 #define PCM_GN_FWD(TX, TF, TR)                                                                                               \
     hipLaunchKernelGGL((pcm_gn_mish_fwd_kernel<TX, TF, TR>), dim3(B * G), dim3(kBlock), lds, s, T, C, G, (const TX *)x, gamma, \
-                       beta, eps, film_mode, (const TF *)film, (const TR *)res, y, mean, rstd)
+                       beta, eps, film_mode, (const TF *)film, (const TR *)res, conv_bias, y, mean, rstd)
     const int key = (x_is_bf16 ? 4 : 0) | (film_is_bf16 ? 2 : 0) | (res_is_bf16 ? 1 : 0);
     switch (key) {
     case 0: PCM_GN_FWD(float, float, float); break;
@@ -312,18 +325,18 @@ extern "C" int pcm_gn_mish_forward_hip(int B, int T, int C, int G, int x_is_bf16
 
 extern "C" int pcm_gn_mish_backward_hip(int B, int T, int C, int G, int x_is_bf16, const void *x, const float *gamma,
                                         const float *beta, const float *mean, const float *rstd, int film_mode,
-                                        int film_is_bf16, const void *film, const float *dy, void *dx, float *dgb_partial,
-                                        float *dfilm, void *stream)
+                                        int film_is_bf16, const void *film, const float *conv_bias, const float *dy, void *dx,
+                                        float *dgb_partial, float *dfilm, void *stream)
 {
     if (B <= 0) return PCM_OK;
     if (film_mode < 0 || film_mode > 2 || (film_mode && (!film || !dfilm))) return PCM_ERR_BAD_ARG;
     if (!pcm_gn_mish_supported(T, C, G)) return PCM_ERR_UNSUPPORTED;
-    const size_t lds = ((size_t)2 * T * (C / G) + 4 * kBlock + 4) * sizeof(float);
+    const size_t lds = ((size_t)2 * T * (C / G) + 5 * kBlock + 4 + 2 * (C / G)) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     using bf = __hip_bfloat16;
 #define PCM_GN_BWD(TX, TF)                                                                                                   \
     hipLaunchKernelGGL((pcm_gn_mish_bwd_kernel<TX, TF>), dim3(B * G), dim3(kBlock), lds, s, T, C, G, (const TX *)x, gamma,   \
-                       beta, mean, rstd, film_mode, (const TF *)film, dy, (TX *)dx, dgb_partial, dfilm)
+                       beta, mean, rstd, film_mode, (const TF *)film, conv_bias, dy, (TX *)dx, dgb_partial, dfilm)
     if (x_is_bf16) {
         if (film_is_bf16) PCM_GN_BWD(bf, bf); else PCM_GN_BWD(bf, float);
     } else {

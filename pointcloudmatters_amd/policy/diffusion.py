@@ -97,7 +97,9 @@ class Conv1dBlock(nn.Module):
         )
 
     def forward_cl(self, x, film=None, film_mode=0, res=None):
-        return gn_mish_cl(conv1d_cl(x, self.block[0]), self.block[1], film=film, film_mode=film_mode, res=res)
+        conv = self.block[0]  # its bias rides in the fused launch: added in front of the norm, gradient from the same backward
+        return gn_mish_cl(conv1d_cl(x, conv, with_bias=False), self.block[1], film=film, film_mode=film_mode, res=res,
+                          conv_bias=conv.bias)
 
     def forward(self, x):
         return self.forward_cl(x.transpose(1, 2)).transpose(1, 2)

@@ -71,15 +71,17 @@ def im2col_cl(x, k, stride, pad):
     return cols.reshape(b * cols.shape[1], c * k)
 
 
-def conv1d_cl(x, conv):
-    """nn.Conv1d on channels-last activations: (B, T, C_in) -> (B, L_out, C_out)."""
+def conv1d_cl(x, conv, with_bias=True):
+    """nn.Conv1d on channels-last activations: (B, T, C_in) -> (B, L_out, C_out).  with_bias=False leaves the bias to the
+    consumer (gn_mish_cl(conv_bias=...))."""
     k, stride, pad = conv.kernel_size[0], conv.stride[0], conv.padding[0]
     b, t, cin = x.shape
     w = conv.weight  # (C_out, C_in, K)
+    bias = conv.bias if with_bias else None
     if k == 1 and stride == 1 and pad == 0:
-        return linear_rows(x, w[:, :, 0], conv.bias)
+        return linear_rows(x, w[:, :, 0], bias)
     cols = im2col_cl(x, k, stride, pad)
-    y = linear_rows(cols, w.reshape(w.shape[0], cin * k), conv.bias)
+    y = linear_rows(cols, w.reshape(w.shape[0], cin * k), bias)
     return y.view(b, -1, w.shape[0])
 
 
@@ -101,50 +103,54 @@ def conv_transpose1d_cl(x, conv):
 
 class _GNMish(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, film, res, groups, eps, film_mode):
+    def forward(ctx, x, gamma, beta, film, res, conv_bias, groups, eps, film_mode):
         L = _lib.load()
         b, t, c = x.shape
         x = x.contiguous()
         film_c = film.contiguous() if film is not None else None
         res_c = res.contiguous() if res is not None else None
+        cb = conv_bias.float().contiguous() if conv_bias is not None else None
         dev = x.device
         with torch.cuda.device(dev):
             y = torch.empty(b, t, c, dtype=torch.float32, device=dev)
             stats = torch.empty(2, b * groups, dtype=torch.float32, device=dev)
             rc = L.pcm_gn_mish_forward_hip(b, t, c, groups, _bf(x), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps),
                                            int(film_mode), _bf(film_c) if film_c is not None else 0, _ptr(film_c),
-                                           _bf(res_c) if res_c is not None else 0, _ptr(res_c), y.data_ptr(),
+                                           _bf(res_c) if res_c is not None else 0, _ptr(res_c), _ptr(cb), y.data_ptr(),
                                            stats[0].data_ptr(), stats[1].data_ptr(), _stream())
         _lib.check(rc, "pcm_gn_mish_forward_hip")
-        ctx.save_for_backward(x, gamma, beta, film_c, stats)
+        ctx.save_for_backward(x, gamma, beta, film_c, cb, stats)
         ctx.meta = (groups, int(film_mode), film.dtype if film is not None else None, film.shape if film is not None else None,
-                    res.dtype if res is not None else None)
+                    res.dtype if res is not None else None, conv_bias.dtype if conv_bias is not None else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         L = _lib.load()
-        x, gamma, beta, film, stats = ctx.saved_tensors
-        groups, film_mode, film_dtype, film_shape, res_dtype = ctx.meta
+        x, gamma, beta, film, cb, stats = ctx.saved_tensors
+        groups, film_mode, film_dtype, film_shape, res_dtype, cb_dtype = ctx.meta
         b, t, c = x.shape
         dy = dy.contiguous().float()
         dev = x.device
         with torch.cuda.device(dev):
             dx = torch.empty_like(x)
-            dgb = torch.empty(b, 2, c, dtype=torch.float32, device=dev)
+            dgb = torch.empty(b, 3, c, dtype=torch.float32, device=dev)
             dfilm = torch.empty(film_shape, dtype=torch.float32, device=dev) if film is not None else None
             rc = L.pcm_gn_mish_backward_hip(b, t, c, groups, _bf(x), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                             stats[0].data_ptr(), stats[1].data_ptr(), film_mode,
-                                            _bf(film) if film is not None else 0, _ptr(film), dy.data_ptr(), dx.data_ptr(),
+                                            _bf(film) if film is not None else 0, _ptr(film), _ptr(cb), dy.data_ptr(), dx.data_ptr(),
                                             dgb.data_ptr(), _ptr(dfilm), _stream())
         _lib.check(rc, "pcm_gn_mish_backward_hip")
-        dgb = dgb.sum(dim=0)  # (2, C)
+        dgb = dgb.sum(dim=0)  # (3, C): dgamma | dbeta | d(conv bias)
         if dfilm is not None and film_dtype != torch.float32:
             dfilm = dfilm.to(film_dtype)
         dres = None
         if res_dtype is not None:
             dres = dy if res_dtype == torch.float32 else dy.to(res_dtype)
-        return dx, dgb[0], dgb[1], dfilm, dres, None, None, None
+        dcb = None
+        if cb_dtype is not None:
+            dcb = dgb[2] if cb_dtype == torch.float32 else dgb[2].to(cb_dtype)
+        return dx, dgb[0], dgb[1], dfilm, dres, dcb, None, None, None
 
 
 def gn_mish_supported(x, norm):
@@ -154,12 +160,17 @@ def gn_mish_supported(x, norm):
     return bool(_lib.load().pcm_gn_mish_supported(int(x.shape[1]), int(x.shape[2]), int(norm.num_groups)))
 
 
-def gn_mish_cl(x, norm, film=None, film_mode=0, res=None):
-    """x (B, T, C) -> mish(GroupNorm(x)), then FiLM (film_mode 1: film (B, 2C) = scale | bias; 2: film (B, C) = bias),
-    then ``+ res``.  fp32 output (autocast runs group_norm in fp32 too)."""
+def gn_mish_cl(x, norm, film=None, film_mode=0, res=None, conv_bias=None):
+    """x (B, T, C) -> mish(GroupNorm(x [+ conv_bias])), then FiLM (film_mode 1: film (B, 2C) = scale | bias; 2: film (B, C) =
+    bias), then ``+ res``.  fp32 output (autocast runs group_norm in fp32 too).  `conv_bias` (C): the bias of the
+    convolution that produced x, left out of its GEMM and added here instead, so that its gradient falls out of the same
+    backward launch (no separate reduction over B*T rows)."""
     if gn_mish_supported(x, norm) and (film is None or film.dtype in (torch.float32, torch.bfloat16)) \
             and (res is None or res.dtype in (torch.float32, torch.bfloat16)):
-        return _GNMish.apply(x, norm.weight, norm.bias, film, res, norm.num_groups, norm.eps, film_mode if film is not None else 0)
+        return _GNMish.apply(x, norm.weight, norm.bias, film, res, conv_bias, norm.num_groups, norm.eps,
+                             film_mode if film is not None else 0)
+    if conv_bias is not None:
+        x = x + conv_bias.to(x.dtype)
     y = F.mish(F.group_norm(x.transpose(1, 2), norm.num_groups, norm.weight, norm.bias, norm.eps)).transpose(1, 2)
     if film is not None:
         c = x.shape[2]

@@ -69,8 +69,9 @@ def test_conv_transpose1d_cl_matches_nn():
         torch.testing.assert_close(a, r, rtol=1e-4, atol=1e-4)
 
 
-def _ref_gn_mish(x, norm, film, film_mode, res):
-    y = F.mish(F.group_norm(x.float().transpose(1, 2), norm.num_groups, norm.weight, norm.bias, norm.eps)).transpose(1, 2)
+def _ref_gn_mish(x, norm, film, film_mode, res, conv_bias=None):
+    xin = x.float() if conv_bias is None else x.float() + conv_bias.float()
+    y = F.mish(F.group_norm(xin.transpose(1, 2), norm.num_groups, norm.weight, norm.bias, norm.eps)).transpose(1, 2)
     c = x.shape[2]
     if film is not None:
         f = film.float()
@@ -83,8 +84,8 @@ def _ref_gn_mish(x, norm, film, film_mode, res):
 @pytest.mark.parametrize("shape,groups", [((3, 16, 64), 8), ((2, 8, 1024), 8), ((2, 4, 2048), 8), ((2, 16, 24), 8),
                                           ((1, 16, 2048), 8), ((5, 3, 6), 2), ((2, 2, 4096), 4)])
 @pytest.mark.parametrize("film_mode", [0, 1, 2])
-@pytest.mark.parametrize("with_res", [False, True])
-def test_gn_mish_cl_matches_torch(shape, groups, film_mode, with_res):
+@pytest.mark.parametrize("with_res,with_cb", [(False, False), (True, False), (True, True), (False, True)])
+def test_gn_mish_cl_matches_torch(shape, groups, film_mode, with_res, with_cb):
     from pointcloudmatters_amd.policy.unet_ops import gn_mish_cl, gn_mish_supported
 
     b, t, c = shape
@@ -101,15 +102,19 @@ def test_gn_mish_cl_matches_torch(shape, groups, film_mode, with_res):
     elif film_mode == 2:
         film = torch.randn(b, c, device=DEV, requires_grad=True)
     res = torch.randn(b, t, c, device=DEV, requires_grad=True) if with_res else None
-    y = gn_mish_cl(x, norm, film=film, film_mode=film_mode, res=res)
-    want = _ref_gn_mish(x, norm, film, film_mode, res)
+    cb = torch.randn(c, device=DEV, requires_grad=True) if with_cb else None
+    y = gn_mish_cl(x, norm, film=film, film_mode=film_mode, res=res, conv_bias=cb)
+    want = _ref_gn_mish(x, norm, film, film_mode, res, cb)
     assert y.dtype == torch.float32
     torch.testing.assert_close(y, want, rtol=1e-4, atol=1e-5)
     g = torch.randn_like(want)
-    ins = [x, norm.weight, norm.bias] + ([film] if film is not None else []) + ([res] if res is not None else [])
+    ins = [x, norm.weight, norm.bias] + ([film] if film is not None else []) + ([res] if res is not None else []) \
+        + ([cb] if cb is not None else [])
+    names = ["x", "gamma", "beta"] + (["film"] if film is not None else []) + (["res"] if res is not None else []) \
+        + (["conv_bias"] if cb is not None else [])
     got = torch.autograd.grad(y, ins, g)
     ref = torch.autograd.grad(want, ins, g)
-    for a, r, name in zip(got, ref, ["x", "gamma", "beta", "film", "res"]):
+    for a, r, name in zip(got, ref, names):
         scale = r.abs().max().item() + 1e-12
         assert (a - r).abs().max().item() <= 1e-4 * scale + 1e-6, (name, (a - r).abs().max().item(), scale)
 
