@@ -44,6 +44,8 @@ WORKLOADS = {
     # configs[4]: per-GPU shape of the RLBench 4096-pt Diffusion-Policy run
     "C5": dict(policy="dp", batch=16, n_points=4096, pcd_npoints=2048, dtype="bf16", ragged=False),
     "REF": dict(policy="act", batch=8, n_points=4096, pcd_npoints=2048, dtype="bf16", ragged=True),
+    # C2 with ragged clouds: the headline shape as real data delivers it (mode="hybrid")
+    "C2R": dict(policy="act", batch=8, n_points=1024, pcd_npoints=512, dtype="bf16", ragged=True),
     # C3 with ragged clouds (what GridSamplePCD really delivers): exercises mode="hybrid" for the Diffusion-Policy trainer
     "C3R": dict(policy="dp", batch=64, n_points=1024, pcd_npoints=512, dtype="bf16", ragged=True),
 }
