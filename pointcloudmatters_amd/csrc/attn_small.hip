@@ -315,65 +315,6 @@ __global__ __launch_bounds__(WG) void pcm_attn_small_fwd_kernel(AttnParams P, u1
     if (dg == 0) lse[(long)bh * P.L + qq] = lt > 0.f ? mt * 0.693147180559945f + logf(lt) : INFINITY;  // m is in the log2 domain
 }
 
-// Long query sets (L > 128): grid (B*H, ceil(L/128)); wave w owns queries [128*by + 32w, +32) and ALL waves walk ALL key
-// tiles, which are loaded once per workgroup into double-buffered LDS (one barrier per tile): 4x less L2 traffic per query
-// than the split-key kernel above and no final merge.
-__global__ __launch_bounds__(WG) void pcm_attn_long_fwd_kernel(AttnParams P, u16 *__restrict__ out, float *__restrict__ lse)
-{
-    __shared__ __attribute__((aligned(16))) u16 tiles[2][2][TILE_U16];
-    const int bh = blockIdx.x, b = bh / P.H, h = bh % P.H;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int qi = blockIdx.y * (32 * NW) + w * 32 + (lane & 31);
-    const bool qok = qi < P.L;
-    bf8 qf[4];
-    {
-        const u16 *qp = P.q + (long)b * P.q_bs + (long)qi * P.q_ls + h * HD + 8 * (lane >> 5);
-#pragma unroll
-        for (int sl = 0; sl < 4; ++sl) qf[sl] = as_bf8(qok ? *reinterpret_cast<const uint4 *>(qp + sl * 16) : make_uint4(0, 0, 0, 0));
-    }
-    const DropCfg dc(P);
-    const uint32_t rb = dc.on ? attn_rowbase(dc.seed, P.site, (uint32_t)(bh * P.L + qi)) : 0u;
-    f16v o0, o1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o0[r] = 0.f, o1[r] = 0.f;
-    float m = -INFINITY, lsum = 0.f;
-    const u16 *kb = P.k + (long)b * P.k_bs + h * HD;
-    const u16 *vb = P.v + (long)b * P.v_bs + h * HD;
-    const unsigned char *mask = P.kpm ? P.kpm + (long)b * P.S : nullptr;
-    const int ntiles = (P.S + KT - 1) / KT;
-    const int lr = threadIdx.x >> 3, ld0 = (threadIdx.x & 7) * 8;  // this thread's 16-byte chunk of a (32 x 64) tile
-    auto fetch = [&](const u16 *base, long ls, int kt) -> uint4 {
-        const int row = kt * KT + lr;
-        return row < P.S ? *reinterpret_cast<const uint4 *>(base + (long)row * ls + ld0) : make_uint4(0, 0, 0, 0);
-    };
-    auto stash = [&](u16 *tile, const uint4 &v) {
-        uint2 *dst = reinterpret_cast<uint2 *>(tile + lr * RS + ld0);
-        dst[0] = make_uint2(v.x, v.y);
-        dst[1] = make_uint2(v.z, v.w);
-    };
-    uint4 kr = fetch(kb, P.k_ls, 0), vr = fetch(vb, P.v_ls, 0);
-    for (int kt = 0; kt < ntiles; ++kt) {
-        const int buf = kt & 1;
-        stash(tiles[buf][0], kr);
-        stash(tiles[buf][1], vr);
-        __syncthreads();  // tile kt visible; everybody left tile kt-2 (same buffer) before reaching the previous barrier
-        if (kt + 1 < ntiles) kr = fetch(kb, P.k_ls, kt + 1), vr = fetch(vb, P.v_ls, kt + 1);
-        fwd_tile(tiles[buf][0], tiles[buf][1], qf, o0, o1, m, lsum, kt, lane, P, mask, dc, rb);
-    }
-    if (!qok) return;
-    const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
-    u16 *op = out + ((long)b * P.L + qi) * (P.H * HD) + h * HD;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int d = 8 * g + 4 * (lane >> 5);
-        const s4 a = pack4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
-        const s4 c = pack4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
-        *reinterpret_cast<uint2 *>(op + d) = *reinterpret_cast<const uint2 *>(&a);
-        *reinterpret_cast<uint2 *>(op + 32 + d) = *reinterpret_cast<const uint2 *>(&c);
-    }
-    if ((lane >> 5) == 0) lse[(long)bh * P.L + qi] = lsum > 0.f ? m * 0.693147180559945f + logf(lsum) : INFINITY;
-}
-
 // ------------------------------------------------------------------------------------------------ backward
 // ONE launch, grid (B*H, nqt + nkt), 4 waves:
 //   blockIdx.y <  nqt : role A -- dQ of query tile blockIdx.y; the waves split the KEY tiles, partial dQ summed at the end
@@ -660,11 +601,7 @@ extern "C" int pcm_attn_small_forward_hip(int B, int H, int L, int S, const void
     if (p_drop < 0.f || p_drop >= 1.f || (p_drop > 0.f && seed == nullptr)) return PCM_ERR_BAD_ARG;
     AttnParams P{(const u16 *)q, (const u16 *)k, (const u16 *)v, q_bs, q_ls, k_bs, k_ls, v_bs, v_ls, key_padding_mask,
                  B, H, L, S, scale, p_drop, seed, site};
-    if (L > 4 * 32 * NW)  // long query sets: shared key / value tiles
-        hipLaunchKernelGGL(pcm_attn_long_fwd_kernel, dim3(B * H, (L + 32 * NW - 1) / (32 * NW)), dim3(WG), 0, (hipStream_t)stream, P,
-                           (u16 *)out, lse);
-    else
-        hipLaunchKernelGGL(pcm_attn_small_fwd_kernel, dim3(B * H, (L + 31) / 32), dim3(WG), 0, (hipStream_t)stream, P, (u16 *)out, lse);
+    hipLaunchKernelGGL(pcm_attn_small_fwd_kernel, dim3(B * H, (L + 31) / 32), dim3(WG), 0, (hipStream_t)stream, P, (u16 *)out, lse);
     return PCM_LAUNCH_STATUS();
 }
 
