@@ -108,8 +108,15 @@ __global__ __launch_bounds__(kBlock) void pcm_sa_fwd_kernel(int m, int K, int H,
                                                             float *__restrict__ partial)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int chunk = blockIdx.x % nchunk;  // gridDim.x is a multiple of nchunk (launcher guarantees)
-    const int slot = blockIdx.x / nchunk, nslots = gridDim.x / nchunk;
+    // XCD-aware block -> work mapping.  Consecutive workgroup ids are dealt round-robin to the 8 XCDs (observed: block b
+    // runs on XCD b % 8), each with a private 4 MiB L2.  Queries are therefore split into 8 CONTIGUOUS ranges, one per
+    // XCD: neighbours live in the query's own cloud, so an XCD's L2 only ever holds the Gf rows of "its" clouds instead
+    // of every XCD streaming the whole (n, H) matrix.  gridDim.x is a multiple of 8 * nchunk (launcher guarantees).
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const int chunk = local % nchunk;
+    const int slot_local = local / nchunk, slots_per_xcd = per_xcd / nchunk;
+    const int slot = xcd * slots_per_xcd + slot_local;  // row of `partial` written by this block
+    const int q_begin = (int)((long)m * xcd / 8), q_end = (int)((long)m * (xcd + 1) / 8);
     const int c0 = chunk * 64 * VEC + lane * VEC;
     const bool act = c0 < H;  // H % VEC == 0
     __shared__ float lds[kWaves * 64 * 2 * VEC];
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(kBlock) void pcm_sa_fwd_kernel(int m, int K, int H,
         wz[v] = act ? Wp[(c0 + v) * 3 + 2] : 0.f;
         sum[v] = 0.f, sq[v] = 0.f;
     }
-    for (int i = slot * kWaves + wave; i < m; i += nslots * kWaves) {
+    for (int i = q_begin + slot_local * kWaves + wave; i < q_end; i += slots_per_xcd * kWaves) {
         // lane s < K fetches neighbour s of query i and its relative coordinates
         int j = -1;
         float rx = 0.f, ry = 0.f, rz = 0.f;
@@ -509,7 +516,8 @@ inline int waves_grid(long units, int nchunk)
     long blocks = (units + kWaves - 1) / kWaves * nchunk;  // one unit per wave, one chunk per block
     const long cap = 256L * 4;                             // 4 workgroups per CU; waves walk several units
     if (blocks > cap) blocks = cap;
-    blocks = (blocks + nchunk - 1) / nchunk * nchunk;
+    const long unit = 8L * nchunk;  // whole chunk sets on each of the 8 XCDs (pcm_sa_fwd_kernel's mapping)
+    blocks = (blocks + unit - 1) / unit * unit;
     return (int)blocks;
 }
 
