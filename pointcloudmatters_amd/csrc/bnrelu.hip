@@ -6,7 +6,8 @@
 // BatchNorm with its channels-last kernels at ~0.6 TB/s (rocprofv3: 2.8 ms of a 15 ms step at n = 131072) plus a
 // separate ReLU each way.  Here, per layer:
 //
-//   forward : colsum (sum y, sum y^2 per column; per-slot fp32 partials) -> fp64 reduce -> stats (mean, invstd,
+//   forward : colsum (sum (y-y0), sum (y-y0)^2 per column, y0 = row 0: no cancellation when |mean| >> std; per-slot fp32
+//             partials) -> fp64 reduce -> stats (mean, invstd,
 //             a = gamma*invstd, b = beta - a*mean, running-stat update) -> apply  z = max(a*y + b, 0)
 //   backward: colsum (sum g, sum g*xhat with g = dz * [a*y+b > 0], xhat = (y-mean)*invstd) -> reduce ->
 //             apply  dy = a * (g - mean(g) - xhat * mean(g*xhat));   dbeta = sum g, dgamma = sum g*xhat
@@ -57,14 +58,17 @@ __global__ __launch_bounds__(kBlock) void pcm_bn_colsum_kernel(long n, int C, in
             load4<float>(stat + 2 * C + c0, a);
             load4<float>(stat + 3 * C + c0, b);
         }
+        float sh[4] = {0.f, 0.f, 0.f, 0.f};
+        if (MODE == 0) load4<T>(y + c0, sh);  // shift by row 0: sum (y - sh), sum (y - sh)^2 do not cancel when |mean| >> std
         for (long r = r_begin + mp.rsub; r < r_end; r += mp.rpp) {
             float v[4];
             load4<T>(y + r * C + c0, v);
             if (MODE == 0) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    s0[u] += v[u];
-                    s1[u] += v[u] * v[u];
+                    const float d = v[u] - sh[u];
+                    s0[u] += d;
+                    s1[u] += d * d;
                 }
             } else {
                 float d[4];
@@ -126,15 +130,20 @@ __global__ __launch_bounds__(64 * kRedWaves) void pcm_bn_reduce_kernel(int nslot
 }
 
 // sums[2][C] -> stat[4][C] = { mean, invstd, a = gamma*invstd, b = beta - a*mean } and the running-stat update
-__global__ __launch_bounds__(kBlock) void pcm_bn_stats_kernel(int C, double count, float eps, float momentum,
+template <typename T>
+__global__ __launch_bounds__(kBlock) void pcm_bn_stats_kernel(int C, double count, float eps, float momentum, const T *__restrict__ y,
                                                               const float *__restrict__ sums, const float *__restrict__ gamma,
                                                               const float *__restrict__ beta, float *__restrict__ stat,
                                                               float *__restrict__ running_mean, float *__restrict__ running_var)
 {
     const int c = blockIdx.x * kBlock + threadIdx.x;
     if (c >= C) return;
-    const double mean = (double)sums[c] / count;
-    double var = (double)sums[C + c] / count - mean * mean;  // biased: what the normalisation uses
+    float shv;
+    if constexpr (sizeof(T) == 2) shv = __uint_as_float((uint32_t)reinterpret_cast<const uint16_t *>(y)[c] << 16);
+    else shv = (float)y[c];
+    const double dm = (double)sums[c] / count;  // mean of (y - shift), shift = row 0 of y (see pcm_bn_colsum_kernel)
+    const double mean = (double)shv + dm;
+    double var = (double)sums[C + c] / count - dm * dm;  // biased: what the normalisation uses
     if (var < 0.0) var = 0.0;
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
     const float a = gamma[c] * invstd;
@@ -254,8 +263,12 @@ extern "C" int pcm_bn_relu_forward_hip(long n, int C, int is_bf16, const void *y
             hipLaunchKernelGGL((pcm_bn_colsum_kernel<float, 0>), grid, dim3(kBlock), 0, s, n, C, p.chunkW, p.rows_per_slot,
                                (const float *)y, (const float *)nullptr, (const float *)nullptr, partial);
         hipLaunchKernelGGL(pcm_bn_reduce_kernel, dim3((2 * C + 63) / 64), dim3(64 * kRedWaves), 0, s, p.nslots, 2 * C, partial, sums);
-        hipLaunchKernelGGL(pcm_bn_stats_kernel, dim3((C + kBlock - 1) / kBlock), dim3(kBlock), 0, s, C, (double)n, eps, momentum,
-                           sums, gamma, beta, stat, running_mean, running_var);
+        if (is_bf16)
+            hipLaunchKernelGGL(pcm_bn_stats_kernel<bf>, dim3((C + kBlock - 1) / kBlock), dim3(kBlock), 0, s, C, (double)n, eps, momentum,
+                               (const bf *)y, sums, gamma, beta, stat, running_mean, running_var);
+        else
+            hipLaunchKernelGGL(pcm_bn_stats_kernel<float>, dim3((C + kBlock - 1) / kBlock), dim3(kBlock), 0, s, C, (double)n, eps,
+                               momentum, (const float *)y, sums, gamma, beta, stat, running_mean, running_var);
     }
     const long total4 = n * C / 4;
     if (is_bf16)

@@ -82,7 +82,8 @@ def run_case(B, H, L, S, masked, packed, p=0.0):
         with fused_ops.activate(ctx):
             out = small_attn.small_attention(q, k, v, kpm, H, p)
         keep = keep_mask(int(ctx.seed.item()), 1, B, H, L, S, p).float()
-        assert abs(keep.mean().item() - (1 - p)) < 0.02
+        if keep.numel() >= 100_000:  # a statistical check: only meaningful with enough samples
+            assert abs(keep.mean().item() - (1 - p)) < 0.02
     else:
         out = small_attn.small_attention(q, k, v, kpm, H, 0.0)
     want = reference(q, k, v, kpm, H, keep, p)
