@@ -128,6 +128,15 @@ __global__ __launch_bounds__(kBlock) void pcm_sa_fwd_kernel(int m, int K, int H,
         wz[v] = act ? Wp[(c0 + v) * 3 + 2] : 0.f;
         sum[v] = 0.f, sq[v] = 0.f;
     }
+    // BatchNorm statistics are accumulated around a per-channel constant close to the mean (the Gf row of the very first
+    // neighbour): sum (y - sh), sum (y - sh)^2 do not cancel when |mean| >> std.  pcm_sa_stats_kernel adds sh back.
+    float sh[VEC];
+    {
+        const int j0 = idx[0];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) sh[v] = 0.f;
+        if (j0 >= 0 && act) load_vec<T, VEC>(Gf + (size_t)j0 * H + c0, sh);
+    }
     for (int i = q_begin + slot_local * kWaves + wave; i < q_end; i += slots_per_xcd * kWaves) {
         // lane s < K fetches neighbour s of query i and its relative coordinates
         int j = -1;
@@ -160,8 +169,9 @@ __global__ __launch_bounds__(kBlock) void pcm_sa_fwd_kernel(int m, int K, int H,
             }
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
-                sum[v] += y[v];
-                sq[v] += y[v] * y[v];
+                const float d = y[v] - sh[v];
+                sum[v] += d;
+                sq[v] += d * d;
                 if (y[v] > mx[v]) mx[v] = y[v], ax[v] = s;  // strict: first maximum, like MaxPool1d
                 if (y[v] < mn[v]) mn[v] = y[v], an[v] = s;
             }
@@ -213,15 +223,20 @@ __global__ __launch_bounds__(64 * kRedWaves) void pcm_sa_reduce_kernel(int nslot
 }
 
 // stats: sums[2][H] -> stat[4][H] = { mean, invstd, a = gamma*invstd, b = beta - a*mean }, running stats update
-__global__ __launch_bounds__(kBlock) void pcm_sa_stats_kernel(int H, double count, float eps, float momentum,
-                                                              const float *__restrict__ sums, const float *__restrict__ gamma,
+template <typename T>
+__global__ __launch_bounds__(kBlock) void pcm_sa_stats_kernel(int H, double count, float eps, float momentum, const T *__restrict__ Gf,
+                                                              const int *__restrict__ idx, const float *__restrict__ sums,
+                                                              const float *__restrict__ gamma,
                                                               const float *__restrict__ beta, float *__restrict__ stat,
                                                               float *__restrict__ running_mean, float *__restrict__ running_var)
 {
     const int h = blockIdx.x * kBlock + threadIdx.x;
     if (h >= H) return;
-    const double mean = (double)sums[h] / count;
-    double var = (double)sums[H + h] / count - mean * mean;  // biased, like BatchNorm's normalisation
+    const int j0 = idx[0];
+    const double shift = j0 >= 0 ? (double)Elem<T>::ld(Gf + (size_t)j0 * H + h) : 0.0;  // see pcm_sa_fwd_kernel
+    const double dm = (double)sums[h] / count;
+    const double mean = shift + dm;
+    double var = (double)sums[H + h] / count - dm * dm;  // biased, like BatchNorm's normalisation
     if (var < 0.0) var = 0.0;
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
     const float a = gamma[h] * invstd;
@@ -571,8 +586,15 @@ extern "C" int pcm_sa_fused_forward_hip(int m, int K, int H, int gf_is_bf16, con
     if (rc) return rc;
     if (stage_mask & 2)
         hipLaunchKernelGGL(pcm_sa_reduce_kernel, dim3((2 * H + 63) / 64), dim3(64 * kRedWaves), 0, PCM_SA_ST, nslots, 2 * H, partial, sums);
-    if (stage_mask & 4) hipLaunchKernelGGL(pcm_sa_stats_kernel, dim3((H + kBlock - 1) / kBlock), dim3(kBlock), 0, PCM_SA_ST, H, (double)m * K, eps,
-                       momentum, sums, gamma, beta, stat, running_mean, running_var);
+    if (stage_mask & 4) {
+        if (gf_is_bf16)
+            hipLaunchKernelGGL(pcm_sa_stats_kernel<__hip_bfloat16>, dim3((H + kBlock - 1) / kBlock), dim3(kBlock), 0, PCM_SA_ST, H,
+                               (double)m * K, eps, momentum, (const __hip_bfloat16 *)Gf, idx, sums, gamma, beta, stat, running_mean,
+                               running_var);
+        else
+            hipLaunchKernelGGL(pcm_sa_stats_kernel<float>, dim3((H + kBlock - 1) / kBlock), dim3(kBlock), 0, PCM_SA_ST, H, (double)m * K,
+                               eps, momentum, (const float *)Gf, idx, sums, gamma, beta, stat, running_mean, running_var);
+    }
     const long total = (long)m * H;
     long blocks = (total + kBlock - 1) / kBlock;
     if (blocks > 256L * 16) blocks = 256L * 16;

@@ -89,3 +89,24 @@ def test_fused_bf16_autocast_close_to_fp32(hip_device):
     assert (t16.float() - t32).abs().max() <= 0.05 * t32.abs().max()
     assert (gx16.float() - gx32).norm() <= 0.15 * gx32.norm()  # bf16 flips some arg-max choices
     assert (gp16["linear.weight"] - gp32["linear.weight"]).norm() <= 0.15 * gp32["linear.weight"].norm()
+
+
+def test_fused_statistics_survive_a_large_feature_offset(hip_device):
+    """Features with |mean| >> std (a constant offset of 30 on unit-variance features): BatchNorm statistics accumulated as
+    plain sum / sum-of-squares would lose the variance to cancellation; the kernel accumulates around a reference row."""
+    torch.manual_seed(1)
+    sizes, ms, c, h, k = [600, 400], [128, 128], 32, 64, 16
+    xyz, off = make_clouds(sizes, seed=5)
+    noff = new_offsets(ms)
+    p, o, n_o = xyz.to(hip_device), off.to(hip_device), noff.to(hip_device)
+    x = 30.0 + torch.randn(xyz.shape[0], c, device=hip_device)
+    ref_owner = Owner(c, h, k).to(hip_device).train()
+    with torch.no_grad():
+        ref_owner.linear.weight.abs_()  # all-positive weights: the offset survives the projection (|mean| ~ 30 * sum|w| >> std)
+    fused_owner = Owner(c, h, k).to(hip_device).train()
+    fused_owner.load_state_dict(ref_owner.state_dict())
+    gout = torch.randn(sum(ms), h, device=hip_device)
+    t_r, gx_r, gp_r, rm_r, rv_r, _ = _run("reference", ref_owner, p, x, o, n_o, gout)
+    t_f, gx_f, gp_f, rm_f, rv_f, _ = _run("fused", fused_owner, p, x, o, n_o, gout)
+    assert (rv_f - rv_r).abs().max().item() <= 1e-3 * rv_r.abs().max().item()
+    assert (t_f - t_r).abs().max().item() <= 2e-3 * t_r.abs().max().item() + 1e-4
