@@ -13,6 +13,7 @@ import math
 import torch
 
 from .. import _lib
+from .._host import PinnedRing
 
 _ALIGN = 64  # floats: every parameter view starts on a 256-byte boundary
 
@@ -67,7 +68,7 @@ class FlatAdamW:
         self._stash = [None] * len(params)
         self.collect_mode = False
         self.hyper = torch.zeros(len(self.segments), self.H_COUNT, dtype=torch.float32, device=dev)
-        self._hyper_host = torch.zeros(len(self.segments), self.H_COUNT, dtype=torch.float32).pin_memory()
+        self._hyper_ring = PinnedRing((len(self.segments), self.H_COUNT), torch.float32, dev)
         self.partials = torch.zeros(self.lib.pcm_optim_partials_capacity(), dtype=torch.float32, device=dev)
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
         self.step_count = 0
@@ -80,13 +81,14 @@ class FlatAdamW:
         lr, mom = self.schedule.at(self.step_count) if self.schedule is not None else (self._fixed_lr, None)
         beta1 = self.beta1 if mom is None else mom
         t = self.step_count + 1
+        host = self._hyper_ring.next()
         for gi, (_, _, wd) in enumerate(self.segments):
-            h = self._hyper_host[gi]
+            h = host[gi]
             h[self.H_LR], h[self.H_BETA1], h[self.H_BETA2], h[self.H_EPS], h[self.H_WD] = lr, beta1, self.beta2, self.eps, wd
             h[self.H_BC1] = 1.0 - beta1 ** t
             h[self.H_BC2_SQRT] = math.sqrt(1.0 - self.beta2 ** t)
             h[self.H_MAX_NORM], h[self.H_GRAD_SCALE] = self.max_norm, self.grad_scale
-        self.hyper.copy_(h, non_blocking=True)
+        self._hyper_ring.push(self.hyper)  # every group's own row (weight decay differs between groups)
         self.last_lr = lr
         self.step_count += 1
 

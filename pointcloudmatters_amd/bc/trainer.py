@@ -163,6 +163,7 @@ class BCTrainer:
         self._sums = None
         self._count = 0
         self._graph = None
+        self._graph_acc = None
         self._static_batch = None
         self._static_stats = None
         self._static_sig = None
@@ -272,8 +273,13 @@ class BCTrainer:
         self.optimizer.collect(first=first, subset=self._subset_a)
         return (self._static_stats if first else self._static_stats_acc).clone()
 
-    def _forward_backward(self, batch):
+    def _forward_backward(self, batch, first=None):
+        """`first`: is this the first micro-batch of an accumulation window (gradients overwrite the flat buffer) or a
+        later one (they add)?  Must be passed explicitly when capturing: the choice is baked into the hipGraph."""
         from ..policy import fused_ops
+
+        if first is None:
+            first = self.micro % self.accumulate == 0
 
         shadows = getattr(self, "_shadow_names", None)
         with fused_ops.activate(self._fused_ctx), self._autocast():
@@ -286,7 +292,7 @@ class BCTrainer:
         loss = out["loss"]
         (loss / self.accumulate).backward()
         if getattr(self.optimizer, "collect_mode", False):
-            self.optimizer.collect(first=self.micro % self.accumulate == 0)
+            self.optimizer.collect(first=first)
         aux1 = out.get("action_loss", loss)
         aux2 = out.get("kl_loss", 0.0)
         return torch.stack([loss.detach().float(), aux1.detach().float(),
@@ -348,8 +354,16 @@ class BCTrainer:
         graph = torch.cuda.CUDAGraph()
         # thread_local: RCCL's watchdog / other host threads may touch the HIP API while we capture
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            self._static_stats = self._forward_backward(clone_batch(self._static_batch))
+            self._static_stats = self._forward_backward(clone_batch(self._static_batch), first=True)
         self._graph = graph
+        self._graph_acc = None
+        if self.accumulate > 1 and getattr(self.optimizer, "collect_mode", False):
+            # bf16 hand-off: "overwrite" vs "add into" the flat gradient buffer is decided in Python, i.e. at capture
+            # time -- the later micro-batches of an accumulation window need their own graph (fp32 mode accumulates
+            # through the .grad views and zeroes the buffer outside the graph, one graph serves both)
+            self._graph_acc = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph_acc, capture_error_mode="thread_local"):
+                self._static_stats_acc = self._forward_backward(clone_batch(self._static_batch), first=False)
         self.optimizer.zero_grad()
 
     def prefetch_sampling(self, next_batch):
@@ -401,8 +415,13 @@ class BCTrainer:
                     warnings.warn(f"hipGraph capture failed ({type(e).__name__}: {e}); continuing in mode='flat'")
                     torch.cuda.synchronize()
                     self.mode, self._graph = "flat", None
-                    for p in self.optimizer.params:
-                        p.grad = None
+                    opt = self.optimizer
+                    for k, p in enumerate(opt.params):
+                        # fp32 (non-collect) mode: autograd must keep accumulating INTO the flat buffer's views
+                        p.grad = None if getattr(opt, "collect_mode", False) else opt.g_views[k]
+                        if hasattr(opt, "_stash"):
+                            opt._stash[k] = None
+                    opt.flat_g.zero_()
             if self.mode == "hybrid":
                 stats = self._hybrid_step(batch)
             elif self.mode == "graph":
@@ -412,8 +431,12 @@ class BCTrainer:
                 if first:
                     self.optimizer.zero_grad()
                 self._copy_into(self._static_batch, batch)
-                self._graph.replay()
-                stats = self._static_stats.clone()
+                if first or self._graph_acc is None:
+                    self._graph.replay()
+                    stats = self._static_stats.clone()
+                else:
+                    self._graph_acc.replay()
+                    stats = self._static_stats_acc.clone()
             else:
                 if first:
                     self.optimizer.zero_grad()

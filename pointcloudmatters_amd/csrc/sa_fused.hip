@@ -632,7 +632,10 @@ extern "C" int pcm_sa_fused_backward_hip(int m, int n, int K, int H, int gf_is_b
 #define PCM_B1L(C)                                                                                                            \
     do {                                                                                                                     \
         auto kfn = pcm_sa_bwd1_lds_kernel<C>;                                                                                 \
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (lds > 64 * 1024) {                                                                                               \
+            const hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e_ != hipSuccess) return pcm_status(e_);                                                                     \
+        }                                                                                                                    \
         if (stage_mask & 2)                                                                                                  \
             hipLaunchKernelGGL(kfn, dim3(grid), dim3(kBlock), lds, PCM_SA_ST, K, H, dz, z, ymax, ymin, amax, amin, stat, p, q, \
                                idx, offset, new_offset, D, partial);                                                          \

@@ -523,7 +523,16 @@ class DiffusionUnetPcdPolicy(_AttrMixin):
             raise NotImplementedError("obs_as_global_cond=False is not used by any point-cloud config")
         action_dim = shape_meta["action"]["shape"][0]
         feat_dim = obs_encoder.output_shape()[0]
-        self.model = ConditionalUnet1D(input_dim=action_dim, local_cond_dim=None, global_cond_dim=feat_dim * n_obs_steps,
+        global_cond_dim = feat_dim * n_obs_steps
+        goal_meta = shape_meta.get("goal")
+        if goal_meta is not None:
+            # diffusion_unet_image_policy.py:58-68: a task embedding (goal_pos in the PickCube / Fill / Hang / Excavate
+            # configs) widens the global condition; it is concatenated in compute_loss AND predict_action (:197-201, :262-266)
+            if "task_emb" not in goal_meta:
+                raise NotImplementedError("image goals (agentview_rgb / depth) belong to the image policy, not the point-cloud path")
+            global_cond_dim += int(goal_meta["task_emb"]["shape"][0])
+        self.goal_dim = global_cond_dim - feat_dim * n_obs_steps
+        self.model = ConditionalUnet1D(input_dim=action_dim, local_cond_dim=None, global_cond_dim=global_cond_dim,
                                        diffusion_step_embed_dim=diffusion_step_embed_dim, down_dims=down_dims,
                                        kernel_size=kernel_size, n_groups=n_groups, cond_predict_scale=cond_predict_scale)
         self.obs_encoder = obs_encoder
@@ -534,6 +543,18 @@ class DiffusionUnetPcdPolicy(_AttrMixin):
         self.horizon, self.obs_feature_dim, self.action_dim = horizon, feat_dim, action_dim
         self.n_action_steps, self.n_obs_steps = n_action_steps, n_obs_steps
         self.num_inference_steps = num_inference_steps or noise_scheduler.num_train_timesteps
+
+    def _with_goal(self, global_cond, goal):
+        """Append goal["task_emb"] exactly when the model was built with one (shape_meta["goal"]); anything else is a
+        configuration error caught here instead of as a shape mismatch inside the U-Net's condition encoder."""
+        has = goal is not None and "task_emb" in goal
+        if has != (self.goal_dim > 0):
+            raise ValueError("goal conditioning mismatch: model built with goal_dim=%d, batch %s a task_emb"
+                             % (self.goal_dim, "carries" if has else "lacks"))
+        if not has:
+            return global_cond
+        emb = goal["task_emb"].to(global_cond.dtype)
+        return torch.cat([global_cond, emb.reshape(global_cond.shape[0], -1)], dim=-1)
 
     def set_normalizer(self, normalizer):
         self.normalizer.load_state_dict(normalizer.state_dict())
@@ -579,9 +600,7 @@ class DiffusionUnetPcdPolicy(_AttrMixin):
         if pcds is not None:
             this_nobs["pcds"] = pcds
         global_cond = self.obs_encoder(this_nobs).reshape(B, -1)
-        goal = obs_dict.get("goal", None)
-        if goal is not None and "task_emb" in goal:
-            global_cond = torch.cat([global_cond, goal["task_emb"]], dim=-1)
+        global_cond = self._with_goal(global_cond, obs_dict.get("goal", None))
         dev = global_cond.device
         # obs_as_global_cond: the reference's condition mask is all False (diffusion_unet_image_policy.py:196-198)
         cond_data = torch.zeros(B, T, Da, device=dev, dtype=torch.float32)
@@ -601,7 +620,7 @@ class DiffusionUnetPcdPolicy(_AttrMixin):
         this_nobs = {k: v[:, : self.n_obs_steps].reshape(-1, *v.shape[2:]) for k, v in nobs.items()}
         if pcds is not None:
             this_nobs["pcds"] = pcds
-        global_cond = self.obs_encoder(this_nobs).reshape(bsz, -1)
+        global_cond = self._with_goal(self.obs_encoder(this_nobs).reshape(bsz, -1), batch.get("goal", None))
         trajectory = nactions
         cond_mask = self.mask_generator(trajectory.shape, device=trajectory.device)  # all False for obs_dim == 0
         noise = batch.get("noise", None)

@@ -20,14 +20,16 @@ class FusedContext:
     def __init__(self, device, base_seed=0x5EED):
         self.device = torch.device(device)
         self.seed = torch.zeros(1, dtype=torch.int64, device=self.device)
-        self._host = torch.zeros(1, dtype=torch.int64).pin_memory() if self.device.type == "cuda" else torch.zeros(1, dtype=torch.int64)
+        from .._host import PinnedRing
+
+        self._ring = PinnedRing((1,), torch.int64, self.device)  # a single pinned word rewritten every step would race its DMA
         self.base_seed = int(base_seed)
         self.site = 0
 
     def set_step(self, step):
         """Host side, between steps / graph replays: an asynchronous 8-byte copy on the current stream."""
-        self._host[0] = self.base_seed + 1000003 * int(step)
-        self.seed.copy_(self._host, non_blocking=True)
+        self._ring.next()[0] = self.base_seed + 1000003 * int(step)
+        self._ring.push(self.seed)
 
     def next_site(self):
         self.site += 1

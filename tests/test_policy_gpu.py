@@ -8,7 +8,7 @@ from tests.test_golden_cpu import build_small_policy, check_against_fixture, loa
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("sa_impl", ["reference", "torch"])
+@pytest.mark.parametrize("sa_impl", ["reference", "torch", "fused"])
 def test_policy_matches_reference_actpcd_gpu(hip_device, sa_impl):
     import pointcloudmatters_amd.pointops as po
 
@@ -133,7 +133,7 @@ def test_flat_adamw_kernel_vs_torch(hip_device):
             torch.testing.assert_close(a.detach(), b.detach(), rtol=2e-5, atol=2e-6)
 
 
-@pytest.mark.parametrize("sa_impl", ["reference", "torch"])
+@pytest.mark.parametrize("sa_impl", ["reference", "torch", "fused"])
 def test_dp_policy_matches_reference_modules_gpu(hip_device, sa_impl):
     import pointcloudmatters_amd.pointops as po
     from tests.test_golden_cpu import build_small_dp, check_dp_against_fixture, load_dp_fixture
@@ -355,3 +355,169 @@ def test_checkpoint_resume_continues_the_same_trajectory(mode, precision, hip_de
     tol = 1e-5 if precision == "fp32" else 2e-2
     assert head == pytest.approx(full[:3], rel=tol)
     assert tail == pytest.approx(full[3:], rel=tol)
+
+
+def _flat_grads(opt):
+    return torch.cat([opt.g_views[k].detach().float().reshape(-1) for k in range(len(opt.params))])
+
+
+@pytest.mark.parametrize("mode,accumulate", [("graph", 1), ("graph", 2), ("hybrid", 1), ("flat", 1)])
+def test_benchmarked_path_end_to_end_against_fp32_eager(mode, accumulate, hip_device):
+    """The path bench.py times -- bf16 autocast, fused SA layer, every fused transformer kernel engaged (hidden 512,
+    dim_feedforward 32, 8 heads: drln / ffn / small-attention / packed in-projection / bf16 weight mirror), hipGraph
+    replay -- against the SAME weights run the reference's way: fp32, eager, reference-order SA layer, framework ops only.
+    Indices come from the HIP FPS / kNN in both runs and are checked against the oracle on this batch.  Loss within
+    2e-2, gradient direction cosine > 0.999 (bf16 resolution), and graph mode must really have captured."""
+    import pointcloudmatters_amd.pointops as po
+    from oracle import pointops_cpu
+    from pointcloudmatters_amd.bc import BCTrainer, build_act_policy, clone_batch, make_act_batch
+    from pointcloudmatters_amd.pointops.query import knn_query_raw
+
+    kw = dict(pcd_npoints=256, dropout=0.0, hidden_dim=512, nhead=8, dim_feedforward=32, num_encoder_layers=2,
+              num_decoder_layers=2)
+    batches = [make_act_batch(4, 512, seed=200 + i, device=hip_device) for i in range(accumulate)]
+    cpu_batches = [make_act_batch(4, 512, seed=200 + i) for i in range(accumulate)]
+    eps = torch.randn(4, 32, generator=torch.Generator().manual_seed(1)).to(hip_device)
+    # index parity of this very batch: HIP == oracle, bit for bit
+    for bg, bc in zip(batches, cpu_batches):
+        noff = torch.tensor([256 * (i + 1) for i in range(4)], dtype=torch.int32)
+        want = pointops_cpu.farthest_point_sampling(bc["pcds"]["coord"], bc["pcds"]["offset"], noff)
+        got = po.farthest_point_sampling(bg["pcds"]["coord"], bg["pcds"]["offset"], noff.to(hip_device))
+        assert torch.equal(got.cpu(), want)
+        n_p = bc["pcds"]["coord"][want.long()].contiguous()
+        wi, _ = pointops_cpu.knn_query_raw(16, bc["pcds"]["coord"], bc["pcds"]["offset"], n_p, noff)
+        gi, _ = knn_query_raw(16, bg["pcds"]["coord"], bg["pcds"]["offset"], n_p.to(hip_device), noff.to(hip_device))
+        assert torch.equal(gi.cpu(), wi)
+
+    torch.manual_seed(11)
+    ref = build_act_policy(sa_impl="reference", **kw).to(hip_device).train()
+    torch.manual_seed(11)
+    fast = build_act_policy(sa_impl="fused", **kw).to(hip_device).train()
+    fast.load_state_dict(ref.state_dict())
+
+    # reference recipe: fp32, eager autograd, gradients of the accumulation window summed with the 1/accumulate loss scale
+    from pointcloudmatters_amd.bc.trainer import freeze_unused_parameters
+
+    freeze_unused_parameters(ref)
+    ref_losses = []
+    for b in batches:
+        bb = clone_batch(b)
+        bb["vae_eps"] = eps
+        out = ref(bb)
+        (out["loss"] / accumulate).backward()
+        ref_losses.append(out["loss"].item())
+    ref_grads = {n: p.grad.detach().float() for n, p in ref.named_parameters() if p.grad is not None}
+
+    tr = BCTrainer(fast, total_steps=100, precision="bf16", device=hip_device, mode=mode,
+                   optim=dict(accumulate_grad_batches=accumulate, lr=1e-7))
+    losses = []
+    for b in batches:
+        bb = clone_batch(b)
+        bb["vae_eps"] = eps
+        losses.append(tr.training_step(bb)["loss"].item())
+    assert tr.mode == mode
+    if mode in ("graph", "hybrid"):
+        assert tr._graph is not None, "the step was not captured into a hipGraph"
+        if accumulate > 1:
+            assert tr._graph_acc is not None
+    for a, b in zip(losses, ref_losses):
+        assert abs(a - b) <= 2e-2 * abs(b), (losses, ref_losses)
+    opt = tr.optimizer
+    index = {id(p): k for k, p in enumerate(opt.params)}
+    dot = na = nb = 0.0
+    for n, p in fast.named_parameters():
+        if id(p) not in index:
+            continue
+        g = opt.g_views[index[id(p)]].detach().float()
+        r = ref_grads.get(n)
+        if r is None:
+            assert torch.count_nonzero(g) == 0, n
+            continue
+        dot += float((g * r).sum())
+        na += float((g * g).sum())
+        nb += float((r * r).sum())
+    cos = dot / (na ** 0.5 * nb ** 0.5)
+    assert cos > 0.999, cos
+    assert abs(na ** 0.5 / nb ** 0.5 - 1.0) < 2e-2, (na, nb)
+
+
+def test_two_group_flat_adamw_vs_torch(hip_device):
+    """timm-style parameter groups (biases / norm weights undecayed): every group must get ITS OWN hyper-parameter row."""
+    from pointcloudmatters_amd.bc.flat_optim import FlatAdamW
+    from pointcloudmatters_amd.bc.schedule import OneCycle
+
+    torch.manual_seed(0)
+    shapes_nd, shapes_d = [(64,), (7,)], [(33, 17), (5, 3, 2)]
+    ref_nd = [torch.nn.Parameter(torch.randn(s, device=hip_device)) for s in shapes_nd]
+    ref_d = [torch.nn.Parameter(torch.randn(s, device=hip_device)) for s in shapes_d]
+    mine_nd = [torch.nn.Parameter(p.detach().clone()) for p in ref_nd]
+    mine_d = [torch.nn.Parameter(p.detach().clone()) for p in ref_d]
+    opt_ref = torch.optim.AdamW([{"params": ref_nd, "weight_decay": 0.0}, {"params": ref_d, "weight_decay": 0.3}], lr=3e-2,
+                                betas=(0.9, 0.95))
+    sch_ref = torch.optim.lr_scheduler.OneCycleLR(opt_ref, max_lr=3e-2, total_steps=40, pct_start=0.15, div_factor=100.0,
+                                                  final_div_factor=1000.0)
+    opt = FlatAdamW([{"params": mine_nd, "weight_decay": 0.0}, {"params": mine_d, "weight_decay": 0.3}],
+                    OneCycle(3e-2, 40, 0.15, 100.0, 1000.0), betas=(0.9, 0.95), weight_decay=0.3, max_norm=0.5)
+    for it in range(10):
+        grads = [torch.randn_like(p) * 0.01 for p in ref_nd + ref_d]
+        for p, g in zip(ref_nd + ref_d, grads):
+            p.grad = g.clone()
+        opt.zero_grad()
+        for p, g in zip(mine_nd + mine_d, grads):
+            p.grad.add_(g)
+        torch.nn.utils.clip_grad_norm_(ref_nd + ref_d, 0.5)
+        opt_ref.step()
+        sch_ref.step()
+        opt.step()
+    for a, b in zip(mine_nd + mine_d, ref_nd + ref_d):
+        torch.testing.assert_close(a.detach(), b.detach(), rtol=2e-5, atol=2e-6)
+    # the undecayed group really is undecayed: with zero gradients its parameters must not move
+    before = [p.detach().clone() for p in mine_nd]
+    opt.zero_grad()
+    opt.step()
+    for a, b in zip(mine_nd, before):
+        assert torch.equal(a.detach(), b)
+
+
+def test_graph_bf16_accumulation_adds_the_micro_batches(hip_device):
+    """graph mode + bf16 hand-off + accumulate_grad_batches=2 (the ACT default): the second micro-batch must ADD its
+    gradients to the flat buffer (its own captured graph), not overwrite the first one's."""
+    from pointcloudmatters_amd.bc import BCTrainer, build_act_policy, clone_batch, make_act_batch
+
+    small = dict(hidden_dim=768, nhead=12, dim_feedforward=32, num_encoder_layers=1, num_decoder_layers=1, dropout=0.0, latent_dim=8,
+                 num_queries=10)
+    batches = [make_act_batch(2, 256, seed=31 + i, device=hip_device, num_queries=10) for i in range(2)]
+    eps = torch.randn(2, 8, generator=torch.Generator().manual_seed(1)).to(hip_device)
+    grads = {}
+    for mode in ("flat", "graph"):
+        torch.manual_seed(0)
+        pol = build_act_policy(pcd_npoints=64, sa_impl="fused", **small).to(hip_device)
+        tr = BCTrainer(pol, total_steps=20, precision="bf16", device=hip_device, mode=mode,
+                       optim=dict(accumulate_grad_batches=2, lr=1e-7))
+        for b in batches:
+            bb = clone_batch(b)
+            bb["vae_eps"] = eps
+            tr.training_step(bb)
+        assert tr.mode == mode
+        grads[mode] = tr.optimizer.flat_g.detach().clone()
+    assert (grads["graph"] - grads["flat"]).norm().item() <= 2e-2 * grads["flat"].norm().item()
+
+
+def test_dp_hybrid_bf16_full_batch_stays_finite(hip_device):
+    """Workload C3R (Diffusion Policy, B=64 x 2 ragged 1024-pt clouds, hybrid mode, bf16): a round-1 bench line recorded
+    a NaN loss for it before BatchNorm statistics were accumulated around a reference row; keep it pinned."""
+    from pointcloudmatters_amd.bc import DP_OPTIM, BCTrainer, WORKLOADS, build_dp_policy, clone_batch, make_dp_batch
+
+    wl = WORKLOADS["C3R"]
+    torch.manual_seed(1000)
+    pol = build_dp_policy(pcd_npoints=wl["pcd_npoints"], sa_impl="fused", down_dims=(128, 256, 512)).to(hip_device)
+    tr = BCTrainer(pol, total_steps=100, precision="bf16", device=hip_device, mode="hybrid", optim=dict(DP_OPTIM))
+    batches = [make_dp_batch(wl["batch"], wl["n_points"], seed=1000 + 97 * i, ragged=True, device=hip_device) for i in range(4)]
+    for i in range(24):
+        out = tr.training_step(clone_batch(batches[i % 4]))
+        if i % 6 == 5:
+            assert torch.isfinite(out["loss"]).item(), i
+    m = tr.metrics()
+    assert m["train/loss"] == m["train/loss"] and m["train/loss"] < 10.0, m
+    for n, p in pol.named_parameters():
+        assert torch.isfinite(p).all().item(), n

@@ -37,6 +37,15 @@ CASES = [
     ([1024] * 2, [512] * 2, 512, 512, 16),     # ACT shape
     ([700, 300, 20, 5], [64] * 4, 96, 96, 16),   # DP width (VEC 4, partial chunk), clouds smaller than K -> -1 slots
     ([300], [100], 10, 30, 8),                  # H % 4 != 0 -> scalar path
+    # BASELINE configs[3] / configs[4] / the shipped REF shape: every size class of the backward scatter
+    ([2048] * 4, [1024] * 4, 512, 512, 16),             # C4: 2048-pt clouds (ACT width)
+    ([2048] * 4, [1024] * 4, 96, 96, 16),               # C4-sized clouds at the Diffusion-Policy width
+    ([4096] * 4, [2048] * 4, 512, 512, 16),             # C5 / REF cloud size, ACT width
+    ([4096] * 4, [2048] * 4, 96, 96, 16),               # C5: 4096-pt clouds, DP width
+    ([3100, 4096, 5000, 3600], [2048] * 4, 96, 96, 16),  # ragged REF-like batch (GridSamplePCD output sizes)
+    ([3100, 4096, 5000, 3600], [2048] * 4, 512, 512, 16),
+    ([9000], [512], 96, 96, 16),                        # a cloud too large for any LDS tile -> global-atomic scatter
+    ([20000, 300], [512, 64], 64, 512, 16),             # ... mixed with a small one, ACT width
 ]
 
 
@@ -71,18 +80,28 @@ def test_fused_matches_reference_order(hip_device, sizes, ms, c, h, k):
     assert fused_owner.bn.num_batches_tracked.item() == 1
 
 
-def test_fused_bf16_autocast_close_to_fp32(hip_device):
+BF16_CASES = [
+    ([1024] * 2, [512] * 2, 256, 256),
+    ([2048] * 4, [1024] * 4, 512, 512),                 # C4
+    ([4096] * 4, [2048] * 4, 96, 96),                   # C5
+    ([3100, 4096, 5000, 3600], [2048] * 4, 512, 512),   # REF (ragged)
+    ([9000], [512], 96, 96),                            # global-atomic scatter
+]
+
+
+@pytest.mark.parametrize("sizes,ms,c,h", BF16_CASES)
+def test_fused_bf16_autocast_close_to_fp32(hip_device, sizes, ms, c, h):
     """Under bf16 autocast Gf is a bf16 GEMM output (as the reference's Linear would be); the xyz term
     stays fp32.  Compare with the fp32 fused result at bf16 resolution."""
     torch.manual_seed(1)
-    xyz, off = make_clouds([1024] * 2, seed=5)
-    noff = new_offsets([512] * 2)
+    xyz, off = make_clouds(sizes, seed=5)
+    noff = new_offsets(ms)
     p, o, n_o = xyz.to(hip_device), off.to(hip_device), noff.to(hip_device)
-    x = torch.randn(xyz.shape[0], 256, device=hip_device)
-    owner = Owner(256, 256, 16).to(hip_device).train()
-    other = Owner(256, 256, 16).to(hip_device).train()
+    x = torch.randn(xyz.shape[0], c, device=hip_device)
+    owner = Owner(c, h, 16).to(hip_device).train()
+    other = Owner(c, h, 16).to(hip_device).train()
     other.load_state_dict(owner.state_dict())
-    gout = torch.randn(1024, 256, device=hip_device)
+    gout = torch.randn(sum(ms), h, device=hip_device)
     t32, gx32, gp32, *_ = _run("fused", owner, p, x, o, n_o, gout)
     with torch.autocast("cuda", dtype=torch.bfloat16):
         t16, gx16, gp16, *_ = _run("fused", other, p, x, o, n_o, gout)
