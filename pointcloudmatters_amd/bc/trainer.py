@@ -239,16 +239,13 @@ class BCTrainer:
                 opt._stash[k] = None
                 opt.params[k].grad = None
 
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            self._static_stats = stage_b(first=True)
-        self._graph = graph
+        from .._graphs import captured
+
+        self._graph, self._static_stats = captured(lambda: stage_b(first=True))
         reset()
         self._graph_acc = None
         if self.accumulate > 1:  # later micro-batches of an accumulation window ADD their gradients
-            self._graph_acc = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph_acc, capture_error_mode="thread_local"):
-                self._static_stats_acc = stage_b(first=False)
+            self._graph_acc, self._static_stats_acc = captured(lambda: stage_b(first=False))
             reset()
 
     def _hybrid_step(self, batch):
@@ -351,19 +348,17 @@ class BCTrainer:
             for n, b in self.policy.named_buffers():
                 b.copy_(buffers[n])
         self.optimizer.zero_grad()
-        graph = torch.cuda.CUDAGraph()
-        # thread_local: RCCL's watchdog / other host threads may touch the HIP API while we capture
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            self._static_stats = self._forward_backward(clone_batch(self._static_batch), first=True)
-        self._graph = graph
+        from .._graphs import captured
+
+        # (thread_local error mode: RCCL's watchdog / other host threads may touch the HIP API while we capture)
+        self._graph, self._static_stats = captured(lambda: self._forward_backward(clone_batch(self._static_batch), first=True))
         self._graph_acc = None
         if self.accumulate > 1 and getattr(self.optimizer, "collect_mode", False):
             # bf16 hand-off: "overwrite" vs "add into" the flat gradient buffer is decided in Python, i.e. at capture
             # time -- the later micro-batches of an accumulation window need their own graph (fp32 mode accumulates
             # through the .grad views and zeroes the buffer outside the graph, one graph serves both)
-            self._graph_acc = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph_acc, capture_error_mode="thread_local"):
-                self._static_stats_acc = self._forward_backward(clone_batch(self._static_batch), first=False)
+            self._graph_acc, self._static_stats_acc = captured(
+                lambda: self._forward_backward(clone_batch(self._static_batch), first=False))
         self.optimizer.zero_grad()
 
     def prefetch_sampling(self, next_batch):

@@ -143,9 +143,12 @@ class GraphedPolicy:
                     self._run()
             torch.cuda.current_stream(dev).wait_stream(self._stream)
             torch.cuda.synchronize(dev)
-            self.graph = torch.cuda.CUDAGraph()
+            from .._graphs import finalize, new_graph
+
+            self.graph = new_graph()
             with torch.cuda.graph(self.graph, stream=self._stream, capture_error_mode="thread_local"):
                 self.static_out = self._run()
+            finalize(self.graph)  # memset nodes -> kernel nodes (see _graphs.py), then instantiate
 
     def _run(self):
         with torch.no_grad(), torch.autocast("cuda", dtype=self._dtype, enabled=self._dtype is not None):
