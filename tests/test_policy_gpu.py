@@ -471,12 +471,19 @@ def test_two_group_flat_adamw_vs_torch(hip_device):
         opt.step()
     for a, b in zip(mine_nd + mine_d, ref_nd + ref_d):
         torch.testing.assert_close(a.detach(), b.detach(), rtol=2e-5, atol=2e-6)
-    # the undecayed group really is undecayed: with zero gradients its parameters must not move
-    before = [p.detach().clone() for p in mine_nd]
-    opt.zero_grad()
-    opt.step()
-    for a, b in zip(mine_nd, before):
+    # the undecayed group really is undecayed: a fresh optimizer (zero moments) stepping on zero gradients must leave it
+    # untouched while the decayed group shrinks by exactly (1 - lr * wd)
+    nd = [torch.nn.Parameter(torch.randn(s, device=hip_device)) for s in shapes_nd]
+    dd = [torch.nn.Parameter(torch.randn(s, device=hip_device)) for s in shapes_d]
+    before_nd, before_d = [p.detach().clone() for p in nd], [p.detach().clone() for p in dd]
+    opt2 = FlatAdamW([{"params": nd, "weight_decay": 0.0}, {"params": dd, "weight_decay": 0.3}],
+                     OneCycle(3e-2, 40, 0.15, 100.0, 1000.0), betas=(0.9, 0.95), weight_decay=0.3, max_norm=0.5)
+    opt2.zero_grad()
+    opt2.step()
+    for a, b in zip(nd, before_nd):
         assert torch.equal(a.detach(), b)
+    for a, b in zip(dd, before_d):
+        torch.testing.assert_close(a.detach(), b * (1.0 - opt2.last_lr * 0.3), rtol=1e-6, atol=1e-7)
 
 
 def test_graph_bf16_accumulation_adds_the_micro_batches(hip_device):

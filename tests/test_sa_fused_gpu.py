@@ -20,13 +20,13 @@ class Owner(nn.Module):
         self.pcd_nsample = k
 
 
-def _run(impl, owner, p, x, o, n_o, gout):
+def _run(impl, owner, p, x, o, n_o, gout, pre=None):
     import pointcloudmatters_amd.pointops as po
     from pointcloudmatters_amd.policy.sa_layer import set_abstraction
 
     x = x.clone().requires_grad_(True)
     owner.zero_grad()
-    n_p, tok, idx = set_abstraction(owner, po, p, x, o, n_o, impl=impl)
+    n_p, tok, idx = set_abstraction(owner, po, p, x, o, n_o, impl=impl, pre=pre)
     tok.backward(gout)
     return tok.detach(), x.grad.detach(), {k: v.grad.detach().clone() for k, v in owner.named_parameters()}, \
         owner.bn.running_mean.clone(), owner.bn.running_var.clone(), idx
@@ -63,8 +63,34 @@ def test_fused_matches_reference_order(hip_device, sizes, ms, c, h, k):
     fused_owner = Owner(c, h, k).to(hip_device).train()
     fused_owner.load_state_dict(ref_owner.state_dict())
     gout = torch.randn(sum(ms), h, device=hip_device)
-    t_r, gx_r, gp_r, rm_r, rv_r, idx_r = _run("reference", ref_owner, p, x, o, n_o, gout)
-    t_f, gx_f, gp_f, rm_f, rv_f, idx_f = _run("fused", fused_owner, p, x, o, n_o, gout)
+    # The max over the K neighbours is a selection: where the two best candidates of a (query, channel) pair are closer
+    # than fp32 re-association noise, "reference order" and "fused algebra" may legitimately pick different neighbours
+    # (either is a valid subgradient; tokens agree, the gradient lands on another row).  With up to 4 M pairs per case
+    # a handful of such near-ties exist, so the upstream gradient is masked exactly there (found in fp64); everything
+    # else -- including exact ties, which both sides break towards the first neighbour -- is compared at 1e-4.
+    import pointcloudmatters_amd.pointops as po
+    from pointcloudmatters_amd.policy.sa_layer import sample_and_query
+
+    pre = sample_and_query(ref_owner, po, p, o, n_o)
+    with torch.no_grad():
+        grouped, _ = po.knn_query_and_group(x, p, offset=o, new_xyz=pre["n_p"], new_offset=n_o, idx=pre["knn_idx"], nsample=k,
+                                            with_xyz=True)
+        y64 = grouped.double() @ ref_owner.linear.weight.double().t()  # (m, K, H)
+        del grouped
+        scale = y64.abs().amax(dim=1)
+        if k > 1:
+            hi = y64.topk(2, dim=1).values
+            lo = (-y64).topk(2, dim=1).values
+            gap = torch.where(ref_owner.bn.weight >= 0, hi[:, 0] - hi[:, 1], lo[:, 0] - lo[:, 1])
+            ambiguous = (gap > 0) & (gap < 2e-5 * scale + 1e-7)
+            del hi, lo, gap
+        else:
+            ambiguous = torch.zeros_like(scale, dtype=torch.bool)
+        del y64
+        assert ambiguous.float().mean().item() < 1e-3
+        gout = gout * (~ambiguous)
+    t_r, gx_r, gp_r, rm_r, rv_r, idx_r = _run("reference", ref_owner, p, x, o, n_o, gout, pre=pre)
+    t_f, gx_f, gp_f, rm_f, rv_f, idx_f = _run("fused", fused_owner, p, x, o, n_o, gout, pre=pre)
     assert torch.equal(idx_r, idx_f)
 
     def close(a, b, name, tol=1e-4):
