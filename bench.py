@@ -102,46 +102,65 @@ def kernel_rooflines(wl, device, c_feat=512, hidden=512):
     f32 = dict(dtype=torch.float32, device=device)
     gf = torch.randn(n_tot, H, **f32).to(torch.bfloat16)
     wp, gamma, beta = torch.randn(H, 3, **f32) * 0.1, torch.rand(H, **f32) + 0.5, torch.zeros(H, **f32)
+    gamma[::3] *= -1.0  # a third of the channels take the min branch
     rm, rv = torch.zeros(H, **f32), torch.ones(H, **f32)
-    ymax, ymin = torch.empty(m, H, **f32), torch.empty(m, H, **f32)
-    amax = torch.empty(m, H, dtype=torch.uint8, device=device)
-    amin = torch.empty(m, H, dtype=torch.uint8, device=device)
-    slots = max(L.pcm_sa_fused_slots(m, H, 4), L.pcm_sa_fused_slots(n_tot, H, 4))
+    sel = torch.empty(m, H, **f32)
+    asel = torch.empty(m, H, dtype=torch.uint8, device=device)
+    slots = max(L.pcm_sa_fused_slots(m, H, 1, k), L.pcm_sa_fused_slots(m, H, 0, 1), L.pcm_sa_fused_slots(n_tot, H, 1, 1), b)
     partial = torch.empty(slots * 5 * H, **f32)
     sums, stat, z = torch.empty(2, H, **f32), torch.empty(4, H, **f32), torch.empty(m, H, **f32)
     dz = torch.randn(m, H, **f32)
-    zeros = torch.zeros(n_tot * H + 4 * n_tot + 12, **f32)
-    D, cnt, S, RM = zeros[: n_tot * H], zeros[n_tot * H: n_tot * H + n_tot], zeros[n_tot * H + n_tot: n_tot * H + 4 * n_tot], zeros[n_tot * H + 4 * n_tot:]
+    D = torch.empty(n_tot * H, **f32)
+    istats = torch.zeros(4 * n_tot + 12, **f32)
+    cnt, S, RM = istats[:n_tot], istats[n_tot: 4 * n_tot], istats[4 * n_tot:]
+    ent = torch.empty(m, k, 4, **f32)
     red1, red2 = torch.empty(5, H, **f32), torch.empty(3, H, **f32)
     dgf = torch.empty_like(gf)
     dwp, dgamma, dbeta = torch.empty(H, 3, **f32), torch.empty(H, **f32), torch.empty(H, **f32)
+    o32 = off.to(torch.int32)
+    sizes = [off._pcm_host[0]] + [off._pcm_host[i] - off._pcm_host[i - 1] for i in range(1, b)]
+    n_max = max(sizes)
 
     def fwd(mask):
-        rc = L.pcm_sa_fused_forward_hip(m, k, H, 1, gf.data_ptr(), coord.data_ptr(), n_p.data_ptr(), knn_idx.data_ptr(),
+        rc = L.pcm_sa_fused_forward_hip(m, k, H, 1, gf.data_ptr(), ent.data_ptr(),
                                         wp.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.1, rm.data_ptr(), rv.data_ptr(),
-                                        ymax.data_ptr(), ymin.data_ptr(), amax.data_ptr(), amin.data_ptr(), partial.data_ptr(),
+                                        sel.data_ptr(), asel.data_ptr(), partial.data_ptr(),
                                         sums.data_ptr(), stat.data_ptr(), z.data_ptr(), mask, st)
         assert rc == 0
 
-    def bwd(mask):
-        rc = L.pcm_sa_fused_backward_hip(m, n_tot, k, H, 1, gf.data_ptr(), coord.data_ptr(), n_p.data_ptr(), knn_idx.data_ptr(),
-                                         wp.data_ptr(), stat.data_ptr(), dz.data_ptr(), z.data_ptr(), ymax.data_ptr(), ymin.data_ptr(),
-                                         amax.data_ptr(), amin.data_ptr(), D.data_ptr(), cnt.data_ptr(), S.data_ptr(), RM.data_ptr(),
-                                         partial.data_ptr(), red1.data_ptr(), red2.data_ptr(), dgf.data_ptr(), dwp.data_ptr(),
-                                         dgamma.data_ptr(), dbeta.data_ptr(), o32.data_ptr(), noff.data_ptr(), b, max(sizes), mask, st)
+    def index():
+        istats.zero_()
+        rc = L.pcm_sa_index_hip(m, k, coord.data_ptr(), n_p.data_ptr(), knn_idx.data_ptr(), o32.data_ptr(), noff.data_ptr(), b, n_max,
+                                ent.data_ptr(), cnt.data_ptr(), S.data_ptr(), RM.data_ptr(), st)
         assert rc == 0
 
-    o32 = off.to(torch.int32)
-    sizes = [off._pcm_host[0]] + [off._pcm_host[i] - off._pcm_host[i - 1] for i in range(1, b)]
+    lds_ch = L.pcm_sa_fused_bwd1_lds_channels(H, n_max)
+
+    def bwd(mask):
+        if not lds_ch and (mask & 2):
+            D.zero_()
+        rc = L.pcm_sa_fused_backward_hip(m, n_tot, k, H, 1, gf.data_ptr(), ent.data_ptr(),
+                                         wp.data_ptr(), stat.data_ptr(), dz.data_ptr(), sel.data_ptr(), asel.data_ptr(),
+                                         D.data_ptr(), cnt.data_ptr(), S.data_ptr(), RM.data_ptr(),
+                                         partial.data_ptr(), red1.data_ptr(), red2.data_ptr(), dgf.data_ptr(), dwp.data_ptr(),
+                                         dgamma.data_ptr(), dbeta.data_ptr(), o32.data_ptr() if lds_ch else 0,
+                                         noff.data_ptr() if lds_ch else 0, b if lds_ch else 0, n_max, mask, st)
+        assert rc == 0
+
+    index()
     fwd(0)
     bwd(0)
     rows = m * k
-    add("pcm_sa_fwd_kernel<bf16,4>", timed_events(lambda: fwd(1), 30), n_tot * H * 2 + 4 * rows + 12 * n_tot + 12 * m + m * H * 10,
-        "hbm", "gather of %d rows x %d ch from the L2/MALL-resident Gf; algorithmic bytes count every Gf row once" % (rows, H))
-    add("pcm_sa_bwd1_lds_kernel", timed_events(lambda: bwd(2), 30), m * H * 18 + 4 * rows + n_tot * H * 4,
-        "hbm", "m*H deltas (18 B read each) scattered with ds_add_f32 into an LDS tile per (cloud, channel chunk); D written once")
-    add("pcm_sa_bwd2_kernel<bf16,4>", timed_events(lambda: bwd(8), 30), n_tot * H * (2 + 4 + 2) + 16 * n_tot, "hbm", "dense n*H pass")
-    add("pcm_sa_index_kernel", timed_events(lambda: bwd(1), 30), 4 * rows + 12 * n_tot + 12 * m + 16 * n_tot, "hbm", "index-only atomics")
+    add("pcm_sa_fwd_kernel<bf16>", timed_events(lambda: fwd(1), 30), n_tot * H * 2 + 16 * rows + m * H * 5,
+        "hbm", "gather of %d rows x %d ch (every Gf row counted once); writes the selected extremum (4 B) + its slot (1 B) per "
+               "(query, channel)" % (rows, H))
+    add("pcm_sa_apply_kernel", timed_events(lambda: fwd(8), 30), m * H * 8, "hbm", "z = relu(a*sel + b): 4 B read, 4 B written")
+    add("pcm_sa_entries+index kernels", timed_events(index, 30), 4 * rows + 12 * n_tot + 12 * m + 2 * 16 * rows + 16 * n_tot, "hbm",
+        "index-only passes (16-byte neighbour records, cnt, S, RM) incl. the memset; they run on the sampling side stream")
+    add("pcm_sa_bwd1_lds_kernel<CH=%d>" % lds_ch if lds_ch else "pcm_sa_bwd1_kernel(global atomics)", timed_events(lambda: bwd(2), 30),
+        m * H * 9 + 16 * rows + n_tot * H * 4, "hbm",
+        "m*H deltas (dz 4 B + sel 4 B + slot 1 B read) scattered with ds_add_f32 into an LDS tile per (cloud, channel chunk); D written once")
+    add("pcm_sa_bwd2_kernel<bf16>", timed_events(lambda: bwd(8), 30), n_tot * H * (2 + 4 + 2) + 16 * n_tot, "hbm", "dense n*H pass")
     add("pcm_sa_reduce_kernel", timed_events(lambda: bwd(4), 30), slots * 5 * H * 4, "hbm", "fp64 reduction of per-block partial rows")
 
     # ---- transformer tail kernels on the encoder's token matrix (B x 515 tokens x 512) ----------------------

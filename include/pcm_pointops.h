@@ -165,33 +165,48 @@ int pcm_group_xyz_feat_backward_hip(int m, int nsample, int c, int with_xyz,
  * grouping(with_xyz) -> Linear(3+C->H, no bias) -> BatchNorm1d(H) (training statistics over the m*K
  * rows) -> ReLU -> max over K.  The caller supplies Gf = feat @ Wf^T (n,H) (fp32 or bf16, one GEMM on
  * the n points); the xyz part Wp (p_j - q_i) is added in fp32 inside the gather.  Nothing of size
- * m*K*H is ever written.  Workspaces are caller-allocated (sizes in policy/sa_fused.py):
- *   forward : ymax,ymin (m,H) f32; amax,amin (m,H) u8; partial (slots,5,H); sums (2,H); stat (4,H) =
- *             {mean, invstd, a, b}; z (m,H) the tokens.  running_mean/var updated in place (or NULL).
- *   backward: D (n,H), cnt (n), S (n,3), RM (12) zeroed by the caller; red1 (5,H), red2 (3,H);
+ * m*K*H is ever written.  sign(a) = sign(gamma) is known before the statistics, so the gather keeps ONE extremum per
+ * (query, channel): sel = (gamma >= 0 ? max_s y_s : min_s y_s) and its slot asel.  Workspaces are caller-allocated
+ * (sizes in policy/sa_fused.py):
+ *   forward : sel (m,H) f32; asel (m,H) u8; partial (slots,5,H); sums (2,H); stat (4,H) = {mean, invstd, a, b};
+ *             z (m,H) the tokens.  running_mean/var updated in place (or NULL).
+ *   index   : pcm_sa_index_hip -> ent (m,K) 16-byte records (j, p_j - q_i) [j = -1: (-1,0,0,0)], cnt (n), S (n,3),
+ *             RM (12): occurrence count / summed relative coordinates of every point and the 3 + 9 global moments.
+ *             A function of (idx, p, q) only, so it runs next to the kNN query; cnt / S / RM zeroed by the caller.
+ *             The gather and the backward read `ent` instead of chasing idx -> p / q.
+ *   backward: D (n,H) scratch (zeroed by the caller only for the global-atomic fallback); red1 (5,H), red2 (3,H);
  *             outputs dGf (n,H) in Gf's dtype, dWp (H,3), dgamma (H), dbeta (H).
  * offset / new_offset (b) + n_max (largest cloud) select the LDS-staged scatter (one workgroup per cloud
  * and channel chunk, ds_add_f32, no global atomics, D need not be zeroed); pass NULL / b = 0 for the
  * global-atomic fallback (D zeroed by the caller).
  * stage_mask <= 0 runs every kernel of the call; a bit mask runs only the selected kernels (forward:
- * 1 gather+stats, 2 reduce, 4 affine, 8 apply; backward: 1 index, 2 bwd1, 4 reduce, 8 bwd2, 16 reduce,
- * 32 bwd3) -- used by bench.py to time one kernel at a time. */
-int pcm_sa_fused_slots(int units, int H, int vec);
+ * 1 gather+stats, 2 reduce, 4 affine, 8 apply; backward: 2 bwd1, 4 reduce, 8 bwd2, 16 reduce,
+ * 32 bwd3) -- used by bench.py to time one kernel at a time.
+ * pcm_sa_fused_slots(rows, H, bf16, K): partial-row slots a row-streaming kernel over `rows` rows writes. */
+int pcm_sa_fused_slots(int units, int H, int bf16, int K);
 int pcm_sa_fused_bwd1_lds_channels(int H, int n_max);
-int pcm_sa_fused_forward_hip(int m, int K, int H, int gf_is_bf16, const void *Gf, const float *p,
-                             const float *q, const int *idx, const float *Wp, const float *gamma,
-                             const float *beta, float eps, float momentum, float *running_mean,
-                             float *running_var, float *ymax, float *ymin, unsigned char *amax,
-                             unsigned char *amin, float *partial, float *sums, float *stat, float *z,
+int pcm_sa_fused_forward_hip(int m, int K, int H, int gf_is_bf16, const void *Gf, const void *ent,
+                             const float *Wp, const float *gamma, const float *beta, float eps,
+                             float momentum, float *running_mean, float *running_var, float *sel,
+                             unsigned char *asel, float *partial, float *sums, float *stat, float *z,
                              int stage_mask, void *stream);
+int pcm_sa_index_hip(int m, int K, const float *p, const float *q, const int *idx, const int *offset,
+                     const int *new_offset, int b, int n_max, void *ent, float *cnt, float *S, float *RM,
+                     void *stream);
 int pcm_sa_fused_backward_hip(int m, int n, int K, int H, int gf_is_bf16, const void *Gf,
-                              const float *p, const float *q, const int *idx, const float *Wp,
-                              const float *stat, const float *dz, const float *z, const float *ymax,
-                              const float *ymin, const unsigned char *amax, const unsigned char *amin,
-                              float *D, float *cnt, float *S, float *RM, float *partial, float *red1,
-                              float *red2, void *dGf, float *dWp, float *dgamma, float *dbeta,
-                              const int *offset, const int *new_offset, int b, int n_max,
-                              int stage_mask, void *stream);
+                              const void *ent, const float *Wp,
+                              const float *stat, const float *dz, const float *sel,
+                              const unsigned char *asel, float *D, const float *cnt, const float *S,
+                              const float *RM, float *partial, float *red1, float *red2, void *dGf,
+                              float *dWp, float *dgamma, float *dbeta, const int *offset,
+                              const int *new_offset, int b, int n_max, int stage_mask, void *stream);
+
+/* ---- hipGraph surgery -----------------------------------------------------------------------------------
+ * Replace every MEMSET node of a captured, not yet instantiated hipGraph_t by a fill-kernel node with the same
+ * destination, value, extent and dependencies (csrc/graph_fix.hip: memset nodes created by stream capture replay
+ * with a garbage pattern on ROCm 7.2; ATen reductions zero their semaphores with one).  *n_replaced (may be NULL)
+ * receives the number of nodes replaced. */
+int pcm_graph_replace_memsets(void *graph, int *n_replaced);
 
 /* ---- fused  out = LayerNorm(x + dropout(y))  ------------------------------------------------------------
  * replaces the `x = x + dropout(y); x = norm(x)` tail of every post-norm transformer sub-layer

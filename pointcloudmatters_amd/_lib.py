@@ -36,11 +36,12 @@ SIGNATURES = {
     "pcm_attention_fusion_step_backward_hip": [_i, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P],
     "pcm_group_xyz_feat_forward_hip": [_i, _i, _i, _P, _P, _P, _P, _P, _P],
     "pcm_group_xyz_feat_backward_hip": [_i, _i, _i, _i, _P, _P, _P, _P],
-    "pcm_sa_fused_slots": [_i, _i, _i],
+    "pcm_sa_fused_slots": [_i, _i, _i, _i],
     "pcm_sa_fused_bwd1_lds_channels": [_i, _i],
-    "pcm_sa_fused_forward_hip": [_i, _i, _i, _i, _P, _P, _P, _P, _P, _P, _P, _f, _f, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _i, _P],
+    "pcm_sa_fused_forward_hip": [_i, _i, _i, _i, _P, _P, _P, _P, _P, _f, _f, _P, _P, _P, _P, _P, _P, _P, _P, _i, _P],
+    "pcm_sa_index_hip": [_i, _i, _P, _P, _P, _P, _P, _i, _i, _P, _P, _P, _P, _P],
     "pcm_sa_fused_backward_hip": [_i, _i, _i, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
-                                  _P, _P, _P, _P, _P, _P, _P, _P, _i, _i, _i, _P],
+                                  _P, _P, _P, _i, _i, _i, _P],
     "pcm_drln_blocks": [ctypes.c_long],
     "pcm_drln_forward_hip": [ctypes.c_long, _i, _i, _P, _P, _P, _P, _f, _f, _P, ctypes.c_uint, _P, _P, _P, _P, _P],
     "pcm_drln_backward_hip": [ctypes.c_long, _i, _i, _P, _P, _P, _P, _P, _f, _P, ctypes.c_uint, _P, _P, _P, _P, _P],

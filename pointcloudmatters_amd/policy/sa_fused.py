@@ -19,33 +19,54 @@ def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
+def index_stats(p, q, knn_idx, o32=None, no32=None, n_max=0):
+    """cnt (n), S (n,3), RM (12) of the neighbour lists -- the index-only part of the backward (occurrence count and summed
+    relative coordinates of every point, global moments).  A function of the coordinates alone: sample_and_query runs it
+    right behind the kNN query on the side stream, off the critical path."""
+    L = _lib.load()
+    n = p.shape[0]
+    m, K = knn_idx.shape
+    b = int(o32.shape[0]) if o32 is not None else 0
+    with torch.cuda.device(p.device):
+        buf = torch.zeros(4 * n + 12, dtype=torch.float32, device=p.device)
+        ent = torch.empty(m, K, 4, dtype=torch.float32, device=p.device)  # (j bits, rel x, rel y, rel z) per neighbour slot
+        cnt, S, RM = buf[:n], buf[n: 4 * n], buf[4 * n:]
+        rc = L.pcm_sa_index_hip(m, K, p.data_ptr(), q.data_ptr(), knn_idx.data_ptr(), _ptr(o32), _ptr(no32), b, int(n_max),
+                                ent.data_ptr(), cnt.data_ptr(), S.data_ptr(), RM.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "pcm_sa_index_hip")
+    return ent, buf
+
+
+def _slots(L, m, n, H, bf, K, b):
+    return max(L.pcm_sa_fused_slots(m, H, bf, K), L.pcm_sa_fused_slots(m, H, 0, 1), L.pcm_sa_fused_slots(n, H, bf, 1), b, 1)
+
+
 class _SAFused(Function):
     @staticmethod
-    def forward(ctx, gf, p, q, knn_idx, wp, gamma, beta, running_mean, running_var, eps, momentum, o32, no32, n_max):
+    def forward(ctx, gf, ent, wp, gamma, beta, running_mean, running_var, eps, momentum, o32, no32, n_max, istats):
         L = _lib.load()
         assert gf.is_cuda and gf.is_contiguous() and gf.dtype in (torch.float32, torch.bfloat16)
         n, H = gf.shape
-        m, K = knn_idx.shape
+        m, K = ent.shape[:2]
         dev = gf.device
-        vec = 4 if H % 4 == 0 else 1
-        slots = max(L.pcm_sa_fused_slots(m, H, vec), L.pcm_sa_fused_slots(n, H, vec), int(o32.shape[0]) if o32 is not None else 0)
+        bf = 1 if gf.dtype == torch.bfloat16 else 0
+        slots = _slots(L, m, n, H, bf, K, int(o32.shape[0]) if o32 is not None else 0)
         st = torch.cuda.current_stream().cuda_stream
         with torch.cuda.device(dev):
             f32 = dict(dtype=torch.float32, device=dev)
-            ymax, ymin = torch.empty(m, H, **f32), torch.empty(m, H, **f32)
-            amax = torch.empty(m, H, dtype=torch.uint8, device=dev)
-            amin = torch.empty(m, H, dtype=torch.uint8, device=dev)
+            sel = torch.empty(m, H, **f32)
+            asel = torch.empty(m, H, dtype=torch.uint8, device=dev)
             partial = torch.empty(slots * 5 * H, **f32)
             sums, stat, z = torch.empty(2, H, **f32), torch.empty(4, H, **f32), torch.empty(m, H, **f32)
             wp = wp.contiguous().float()
             gamma, beta = gamma.contiguous().float(), beta.contiguous().float()
             rc = L.pcm_sa_fused_forward_hip(
-                m, K, H, 1 if gf.dtype == torch.bfloat16 else 0, gf.data_ptr(), p.data_ptr(), q.data_ptr(), knn_idx.data_ptr(),
+                m, K, H, bf, gf.data_ptr(), ent.data_ptr(),
                 wp.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), float(momentum), _ptr(running_mean),
-                _ptr(running_var), ymax.data_ptr(), ymin.data_ptr(), amax.data_ptr(), amin.data_ptr(), partial.data_ptr(),
+                _ptr(running_var), sel.data_ptr(), asel.data_ptr(), partial.data_ptr(),
                 sums.data_ptr(), stat.data_ptr(), z.data_ptr(), 0, st)
         _lib.check(rc, "pcm_sa_fused_forward_hip")
-        ctx.save_for_backward(gf, p, q, knn_idx, wp, stat, z, ymax, ymin, amax, amin)
+        ctx.save_for_backward(gf, ent, wp, stat, sel, asel, istats)
         ctx.partial = partial
         ctx.layout = (o32, no32, int(n_max))
         ctx.mark_non_differentiable(stat)
@@ -54,9 +75,9 @@ class _SAFused(Function):
     @staticmethod
     def backward(ctx, dz, _dstat):
         L = _lib.load()
-        gf, p, q, knn_idx, wp, stat, z, ymax, ymin, amax, amin = ctx.saved_tensors
+        gf, ent, wp, stat, sel, asel, istats = ctx.saved_tensors
         n, H = gf.shape
-        m, K = knn_idx.shape
+        m, K = ent.shape[:2]
         dev = gf.device
         st = torch.cuda.current_stream().cuda_stream
         dz = dz.contiguous().float()
@@ -65,24 +86,20 @@ class _SAFused(Function):
             o32, no32, n_max = ctx.layout
             b = int(o32.shape[0]) if o32 is not None else 0
             lds_path = b > 0 and L.pcm_sa_fused_bwd1_lds_channels(H, n_max) > 0
-            if lds_path:  # the LDS-staged scatter writes every element of D itself
-                D = torch.empty(n * H, **f32)
-                zeros = torch.zeros(4 * n + 12, **f32)
-                cnt, S, RM = zeros[:n], zeros[n : 4 * n], zeros[4 * n :]
-            else:
-                zeros = torch.zeros(n * H + 4 * n + 12, **f32)  # D | cnt | S | RM in one memset
-                D, cnt, S, RM = zeros[: n * H], zeros[n * H : n * H + n], zeros[n * H + n : n * H + 4 * n], zeros[n * H + 4 * n :]
+            # the LDS-staged scatter writes every element of D itself; the global-atomic fallback adds into zeros
+            D = torch.empty(n * H, **f32) if lds_path else torch.zeros(n * H, **f32)
+            cnt, S, RM = istats[:n], istats[n: 4 * n], istats[4 * n:]
             red1, red2 = torch.empty(5, H, **f32), torch.empty(3, H, **f32)
             dgf = torch.empty_like(gf)
             dwp, dgamma, dbeta = torch.empty(H, 3, **f32), torch.empty(H, **f32), torch.empty(H, **f32)
             rc = L.pcm_sa_fused_backward_hip(
-                m, n, K, H, 1 if gf.dtype == torch.bfloat16 else 0, gf.data_ptr(), p.data_ptr(), q.data_ptr(), knn_idx.data_ptr(),
-                wp.data_ptr(), stat.data_ptr(), dz.data_ptr(), z.data_ptr(), ymax.data_ptr(), ymin.data_ptr(), amax.data_ptr(),
-                amin.data_ptr(), D.data_ptr(), cnt.data_ptr(), S.data_ptr(), RM.data_ptr(), ctx.partial.data_ptr(),
-                red1.data_ptr(), red2.data_ptr(), dgf.data_ptr(), dwp.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
-                _ptr(o32) if lds_path else 0, _ptr(no32) if lds_path else 0, b if lds_path else 0, n_max, 0, st)
+                m, n, K, H, 1 if gf.dtype == torch.bfloat16 else 0, gf.data_ptr(), ent.data_ptr(),
+                wp.data_ptr(), stat.data_ptr(), dz.data_ptr(), sel.data_ptr(), asel.data_ptr(), D.data_ptr(), cnt.data_ptr(),
+                S.data_ptr(), RM.data_ptr(), ctx.partial.data_ptr(), red1.data_ptr(), red2.data_ptr(), dgf.data_ptr(),
+                dwp.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _ptr(o32) if lds_path else 0,
+                _ptr(no32) if lds_path else 0, b if lds_path else 0, n_max, 0, st)
         _lib.check(rc, "pcm_sa_fused_backward_hip")
-        return dgf, None, None, None, dwp, dgamma, dbeta, None, None, None, None, None, None, None
+        return dgf, None, dwp, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 def supports(owner, x):
@@ -95,56 +112,64 @@ def supports(owner, x):
     return not (torch.is_grad_enabled() and (x.requires_grad or owner.linear.weight.requires_grad))
 
 
-def _sa_fused_eval(owner, gf, p, n_p, knn_idx, wp):
+def _sa_fused_eval(owner, gf, ent, wp):
     """Inference form: the BatchNorm affine comes from the running statistics, so the batch-statistics stages of
     the forward launcher are skipped (stage_mask = gather | apply) and nothing is saved for backward."""
     L = _lib.load()
     bn = owner.bn
     n, H = gf.shape
-    m, K = knn_idx.shape
+    m, K = ent.shape[:2]
     dev = gf.device
-    vec = 4 if H % 4 == 0 else 1
-    slots = L.pcm_sa_fused_slots(m, H, vec)
+    bf = 1 if gf.dtype == torch.bfloat16 else 0
+    slots = L.pcm_sa_fused_slots(m, H, bf, K)
     with torch.cuda.device(dev):
         f32 = dict(dtype=torch.float32, device=dev)
         invstd = torch.rsqrt(bn.running_var.float() + bn.eps)
         a = bn.weight.float() * invstd
         stat = torch.stack([bn.running_mean.float(), invstd, a, bn.bias.float() - a * bn.running_mean.float()]).contiguous()
-        ymax, ymin = torch.empty(m, H, **f32), torch.empty(m, H, **f32)
-        amax = torch.empty(m, H, dtype=torch.uint8, device=dev)
-        amin = torch.empty(m, H, dtype=torch.uint8, device=dev)
+        sel = torch.empty(m, H, **f32)
+        asel = torch.empty(m, H, dtype=torch.uint8, device=dev)
         partial = torch.empty(slots * 5 * H, **f32)
         z = torch.empty(m, H, **f32)
         wp = wp.contiguous().float()
+        gamma = bn.weight.contiguous().float()
         rc = L.pcm_sa_fused_forward_hip(
-            m, K, H, 1 if gf.dtype == torch.bfloat16 else 0, gf.data_ptr(), p.data_ptr(), n_p.data_ptr(), knn_idx.data_ptr(),
-            wp.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), float(bn.eps), 0.0, 0, 0, ymax.data_ptr(), ymin.data_ptr(),
-            amax.data_ptr(), amin.data_ptr(), partial.data_ptr(), 0, stat.data_ptr(), z.data_ptr(), 1 | 8,
+            m, K, H, bf, gf.data_ptr(), ent.data_ptr(),
+            wp.data_ptr(), gamma.data_ptr(), bn.bias.data_ptr(), float(bn.eps), 0.0, 0, 0, sel.data_ptr(),
+            asel.data_ptr(), partial.data_ptr(), 0, stat.data_ptr(), z.data_ptr(), 1 | 8,
             torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "pcm_sa_fused_forward_hip")
     return z
 
 
-def sa_fused_forward(owner, p, x, n_p, fps_idx, knn_idx, o=None, n_o=None):
-    """tokens (m, H) of the SA layer owned by `owner` (linear, bn) for features x (n, C).  `o` / `n_o`
-    (cumulative offsets of points / queries per cloud) enable the LDS-staged backward scatter."""
+def layout_of(o, n_o):
+    """(offset int32, new_offset int32, largest cloud) of a packed batch, or (None, None, 0)."""
     from ..pointops import _common as C
 
-    o32 = no32 = None
-    n_max = 0
-    if o is not None and n_o is not None:
-        o32, no32 = C.i32c(o), C.i32c(n_o)
-        n_max = max(C.counts_from_offsets(C.host_offsets(o)))
+    if o is None or n_o is None:
+        return None, None, 0
+    return C.i32c(o), C.i32c(n_o), max(C.counts_from_offsets(C.host_offsets(o)))
+
+
+def sa_fused_forward(owner, p, x, n_p, fps_idx, knn_idx, o=None, n_o=None, istats=None):
+    """tokens (m, H) of the SA layer owned by `owner` (linear, bn) for features x (n, C).  `o` / `n_o`
+    (cumulative offsets of points / queries per cloud) enable the LDS-staged backward scatter; `istats` = the
+    index_stats() buffer of these neighbour lists when it was computed ahead of time."""
+    o32, no32, n_max = layout_of(o, n_o)
     w = owner.linear.weight  # (H, 3 + C): xyz columns first (grouping.py:57 concatenates xyz before feat)
     gf = linear_rows(x, w[:, 3:])  # (n, H); bf16 under autocast, fp32 otherwise
     if gf.dtype not in (torch.float32, torch.bfloat16):
         gf = gf.float()
     bn = owner.bn
+    if istats is None:
+        with torch.no_grad():
+            istats = index_stats(p, n_p, knn_idx, o32, no32, n_max)
+    ent, stats = istats
     if not owner.training:
         with torch.no_grad():
-            return _sa_fused_eval(owner, gf.contiguous(), p, n_p, knn_idx, w[:, :3])
-    z, _ = _SAFused.apply(gf.contiguous(), p, n_p, knn_idx, w[:, :3], bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                          bn.eps, bn.momentum, o32, no32, n_max)
+            return _sa_fused_eval(owner, gf.contiguous(), ent, w[:, :3])
+    z, _ = _SAFused.apply(gf.contiguous(), ent, w[:, :3], bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                          bn.eps, bn.momentum, o32, no32, n_max, stats)
     with torch.no_grad():
         bn.num_batches_tracked.add_(1)
     return z

@@ -57,16 +57,23 @@ def sample_and_query(owner, pointops, p, o, n_o, overlap=False):
         if hit is not None:
             return hit[0]
 
+    want_stats = getattr(owner, "sa_impl", None) == "fused" and p.is_cuda
+
     def run():
         with torch.no_grad():
             idx = pointops.farthest_point_sampling(p, o, n_o)  # (m) int32
             n_p = p[idx.long(), :]  # (m, 3)
             knn_idx, _ = pointops.knn_query(nsample, p, o, n_p, n_o)
-        return idx, n_p, knn_idx
+            istats = None
+            if want_stats:  # index-only half of the fused layer's backward: coordinates only, so it rides along here
+                from .sa_fused import index_stats, layout_of
+
+                istats = index_stats(p, n_p, knn_idx, *layout_of(o, n_o))
+        return idx, n_p, knn_idx, istats
 
     if not (overlap and p.is_cuda):
-        idx, n_p, knn_idx = run()
-        return {"idx": idx, "n_p": n_p, "knn_idx": knn_idx, "event": None}
+        idx, n_p, knn_idx, istats = run()
+        return {"idx": idx, "n_p": n_p, "knn_idx": knn_idx, "istats": istats, "event": None}
     main = torch.cuda.current_stream(p.device)
     side = getattr(owner, "_side_stream", None)
     if side is None:
@@ -74,12 +81,12 @@ def sample_and_query(owner, pointops, p, o, n_o, overlap=False):
         owner._side_stream = side
     side.wait_stream(main)  # coordinates must be materialised
     with torch.cuda.stream(side):
-        idx, n_p, knn_idx = run()
+        idx, n_p, knn_idx, istats = run()
         event = side.record_event()
     if not torch.cuda.is_current_stream_capturing():
-        for t in (idx, n_p, knn_idx):
+        for t in (idx, n_p, knn_idx) + (istats or ()):
             t.record_stream(main)
-    return {"idx": idx, "n_p": n_p, "knn_idx": knn_idx, "event": event}
+    return {"idx": idx, "n_p": n_p, "knn_idx": knn_idx, "istats": istats, "event": event}
 
 
 def prefetch_sampling(owner, pointops, p, o, n_o):
@@ -107,7 +114,7 @@ def set_abstraction(owner, pointops, p, x, o, n_o, impl="reference", pre=None):
         from .sa_fused import sa_fused_forward, supports
 
         if supports(owner, x):
-            tokens = sa_fused_forward(owner, p, x, n_p, idx, knn_idx, o, n_o)
+            tokens = sa_fused_forward(owner, p, x, n_p, idx, knn_idx, o, n_o, istats=pre.get("istats"))
             return n_p, tokens, idx
         impl = "torch"  # eval mode / SyncBatchNorm / CPU: same maths through framework ops
     if x.dtype != torch.float32:

@@ -287,7 +287,8 @@ def test_prefetched_sampling_gives_identical_steps(mode, hip_device):
             losses.append(tr.training_step(b, prefetch=batches[(i + 1) % 3] if use_prefetch else None)["loss"].item())
         runs.append(losses)
         assert len(pol.__dict__.get("_prefetched", {})) == (1 if use_prefetch else 0)  # only the batch after the last step is pending
-    assert runs[0] == pytest.approx(runs[1], rel=1e-6)
+    # float atomics (scatter of the deltas, neighbour statistics) land in a different order from run to run
+    assert runs[0] == pytest.approx(runs[1], rel=2e-5)
 
 
 def test_hybrid_mode_matches_flat_mode_for_the_diffusion_policy(hip_device):
