@@ -9,8 +9,16 @@ A "step" is one full training step on one synthetic batch per GPU: forward (Poin
 group -> Linear/BN/ReLU/max -> ACT CVAE + transformer) -> loss -> backward -> clip 0.5 -> AdamW ->
 OneCycleLR, with the inputs already resident in HBM.  Workload at N=1: BASELINE.json configs[1]
 ("C2": B=8 clouds of 1024 points, 512 tokens, bf16 autocast for GEMM/attention, pointops fp32).
-Data parallel: one process per GPU, batch sharded (weak scaling: B per GPU fixed), gradient
-all-reduce over RCCL overlapped with backward.  Prints ONE JSON line on rank 0.
+Data parallel: one process per GPU, batch sharded (weak scaling: B per GPU fixed), the flat gradient
+all-reduced over RCCL in backward-ordered slabs that overlap the rest of backward (bc/trainer.py).
+Prints ONE JSON line on rank 0.
+
+What the JSON line carries besides the contract fields:
+  step_trace   composition of the timed step from a torch.profiler (roctracer) kernel trace of a few extra steps
+  roofline     the hand-written kernel with the LARGEST total time in that trace, priced against its bound
+  kernels      every hand-written kernel timed alone with HIP events at the workload's shapes
+  kernels_hbm  the gather / scatter / sampling kernels at shapes whose operands exceed the caches (C3, C5, REF)
+  cpu_baseline the reference path restated on the host cores;  extra: an fp32 GPU line and the shipped REF shape
 """
 import argparse
 import json
@@ -25,7 +33,16 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak, same guide
+CLOCK_MHZ = 2400.0          # peak engine clock: converts FPS pick latency to clocks
+
+# shapes whose gather / scatter operands exceed L2 (and mostly the 256 MiB Infinity Cache lines they touch per launch)
+HBM_SHAPES = {
+    "C3": dict(batch=128, n_points=1024, pcd_npoints=512, ragged=False, c_feat=96, hidden=96),    # configs[2]: 64 samples x 2 clouds
+    "C5": dict(batch=32, n_points=4096, pcd_npoints=2048, ragged=False, c_feat=96, hidden=96),    # configs[4] per GPU
+    "REF": dict(batch=8, n_points=4096, pcd_npoints=2048, ragged=True, c_feat=512, hidden=512),   # the shipped ACT config
+}
 
 
 def parse():
@@ -33,7 +50,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--workload", default="C2", help="C2 (headline), C4, REF, C1")
+    ap.add_argument("--workload", default="C2", help="C2 (headline), C2R, C3, C3R, C4, C5, REF, C1")
     ap.add_argument("--sa-impl", default=os.environ.get("PCM_SA_IMPL", "auto"))
     ap.add_argument("--mode", default="auto", help="auto | graph | hybrid | flat | eager (eager = torch AdamW + DDP + SyncBN)")
     ap.add_argument("--dead-decoder-layers", default="keep", choices=["keep", "prune_backward", "skip"],
@@ -41,15 +58,18 @@ def parse():
                          "`value` is quoted on); prune_backward / skip = dead-code elimination variants, reported separately")
     ap.add_argument("--no-prefetch", action="store_true", help="do not hand the next batch to the trainer early (hybrid / flat / eager modes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel legs (kernels, kernels_hbm, step_trace, roofline)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra lines (fp32 GPU run, REF shape)")
     ap.add_argument("--kernels-only", action="store_true", help="only run the per-kernel timing leg (for rocprofv3 --pmc passes)")
+    ap.add_argument("--kernel-shape", default=None, help="with --kernels-only: C2 (default = the workload) | C3 | C5 | REF")
     ap.add_argument("--cpu-steps", type=int, default=6)
     ap.add_argument("--cpu-threads", type=int, default=16)
     return ap.parse_args()
 
 
 def timed_events(fn, iters, warmup=3):
-    """Average duration (ms) of fn() measured with HIP events on the current stream."""
+    """Average duration (ms) of fn() measured with HIP events on the current stream (= the stream every pcm_* launch
+    below is enqueued on)."""
     for _ in range(warmup):
         fn()
     start = torch.cuda.Event(enable_timing=True)
@@ -63,20 +83,34 @@ def timed_events(fn, iters, warmup=3):
     return start.elapsed_time(end) / iters
 
 
-def kernel_rooflines(wl, device, c_feat=512, hidden=512):
-    """Time every hand-written hot-path kernel ALONE on this workload's shapes (HIP events on the launch
-    stream = torch's current stream, which is the stream every pcm_* call is enqueued on) and price it
-    against its algorithmic HBM bytes.  Returns {kernel: {...}}."""
-    import ctypes
+class KernelTable:
+    def __init__(self):
+        self.rows = {}
 
+    def add(self, name, ms, nbytes, bound, note, flops=None, extra=None):
+        rec = {"ms": round(ms, 5), "bound": bound, "note": note}
+        if nbytes is not None:
+            rec.update(algorithmic_bytes=int(nbytes), achieved_GBs=round(nbytes / ms / 1e6, 3),
+                       frac_of_hbm_peak=round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 6))
+        if flops is not None:
+            rec.update(algorithmic_flops=int(flops), achieved_TFLOPs=round(flops / ms / 1e9, 3),
+                       frac_of_mfma_peak=round(flops / ms / 1e9 / MFMA_BF16_PEAK_TF, 6))
+        if extra:
+            rec.update(extra)
+        self.rows[name] = rec
+
+
+def pointops_and_sa_kernels(t, shape, device):
+    """FPS / kNN / fused set-abstraction kernels (+ the grouped-tensor API kernels) alone, at `shape`."""
     import pointcloudmatters_amd.pointops as po
     from pointcloudmatters_amd import _lib
     from pointcloudmatters_amd.bc import make_act_batch
     from pointcloudmatters_amd.pointops.query import knn_query_raw
 
     L = _lib.load()
-    b, n, m_per, k = wl["batch"], wl["n_points"], wl["pcd_npoints"], 16
-    batch = make_act_batch(b, n, seed=4242, ragged=wl["ragged"], device=device)
+    b, n, m_per, k = shape["batch"], shape["n_points"], shape["pcd_npoints"], 16
+    c_feat, H = shape.get("c_feat", 512), shape.get("hidden", 512)
+    batch = make_act_batch(b, n, seed=4242, ragged=shape["ragged"], device=device)
     coord, off = batch["pcds"]["coord"], batch["pcds"]["offset"]
     n_tot = coord.shape[0]
     noff = torch.tensor([m_per * (i + 1) for i in range(b)], dtype=torch.int32, device=device)
@@ -85,19 +119,22 @@ def kernel_rooflines(wl, device, c_feat=512, hidden=512):
     idx = po.farthest_point_sampling(coord, off, noff)
     n_p = coord[idx.long()].contiguous()
     knn_idx, _ = knn_query_raw(k, coord, off, n_p, noff)
-    res = {}
+    sizes = [off._pcm_host[0]] + [off._pcm_host[i] - off._pcm_host[i - 1] for i in range(1, b)]
+    n_max = max(sizes)
 
-    def add(name, ms, nbytes, bound, note):
-        res[name] = {"ms": round(ms, 5), "algorithmic_bytes": int(nbytes), "achieved_GBs": round(nbytes / ms / 1e6, 3),
-                     "frac_of_hbm_peak": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 6), "bound": bound, "note": note}
-
-    add("pcm_fps_reg_kernel", timed_events(lambda: po.farthest_point_sampling(coord, off, noff), 20), 12 * n_tot + 4 * m,
-        "latency", "%d dependent picks per cloud, one workgroup per cloud; off the critical path (side stream)" % m_per)
-    add("pcm_knn_fast_kernel(+exact)", timed_events(lambda: knn_query_raw(k, coord, off, n_p, noff), 20),
-        12 * n_tot + 12 * m + 8 * m * k, "alu", "%.1f M distance evaluations; side stream" % (m * n / 1e6))
+    ms = timed_events(lambda: po.farthest_point_sampling(coord, off, noff), 10 if n_max > 2048 else 20)
+    picks = m_per - 1
+    t.add("pcm_fps_reg_kernel", ms, 12 * n_tot + 4 * m, "latency",
+          "%d dependent picks per cloud, one workgroup per cloud; runs on the sampling side stream" % picks,
+          extra={"picks_per_s_per_cloud": round(picks / ms * 1e3, 1), "ns_per_pick": round(ms * 1e6 / picks, 2),
+                 "clocks_per_pick_at_%dMHz" % int(CLOCK_MHZ): round(ms * 1e3 / picks * CLOCK_MHZ, 1),
+                 "dist_evals_per_s": round(sum(sizes) * picks / ms * 1e3, 1)})
+    ms = timed_events(lambda: knn_query_raw(k, coord, off, n_p, noff), 20)
+    evals = sum(sz * m_per for sz in sizes)
+    t.add("pcm_knn_fast_kernel(+exact)", ms, 12 * n_tot + 12 * m + 8 * m * k, "alu",
+          "%.1f M distance evaluations; sampling side stream" % (evals / 1e6), extra={"dist_evals_per_s": round(evals / ms * 1e3, 1)})
 
     # ---- fused set-abstraction layer, one kernel at a time (bf16 Gf as under autocast) ----------------
-    H = hidden
     st = torch.cuda.current_stream().cuda_stream
     f32 = dict(dtype=torch.float32, device=device)
     gf = torch.randn(n_tot, H, **f32).to(torch.bfloat16)
@@ -118,8 +155,6 @@ def kernel_rooflines(wl, device, c_feat=512, hidden=512):
     dgf = torch.empty_like(gf)
     dwp, dgamma, dbeta = torch.empty(H, 3, **f32), torch.empty(H, **f32), torch.empty(H, **f32)
     o32 = off.to(torch.int32)
-    sizes = [off._pcm_host[0]] + [off._pcm_host[i] - off._pcm_host[i - 1] for i in range(1, b)]
-    n_max = max(sizes)
 
     def fwd(mask):
         rc = L.pcm_sa_fused_forward_hip(m, k, H, 1, gf.data_ptr(), ent.data_ptr(),
@@ -151,19 +186,75 @@ def kernel_rooflines(wl, device, c_feat=512, hidden=512):
     fwd(0)
     bwd(0)
     rows = m * k
-    add("pcm_sa_fwd_kernel<bf16>", timed_events(lambda: fwd(1), 30), n_tot * H * 2 + 16 * rows + m * H * 5,
-        "hbm", "gather of %d rows x %d ch (every Gf row counted once); writes the selected extremum (4 B) + its slot (1 B) per "
-               "(query, channel)" % (rows, H))
-    add("pcm_sa_apply_kernel", timed_events(lambda: fwd(8), 30), m * H * 8, "hbm", "z = relu(a*sel + b): 4 B read, 4 B written")
-    add("pcm_sa_entries+index kernels", timed_events(index, 30), 4 * rows + 12 * n_tot + 12 * m + 2 * 16 * rows + 16 * n_tot, "hbm",
-        "index-only passes (16-byte neighbour records, cnt, S, RM) incl. the memset; they run on the sampling side stream")
-    add("pcm_sa_bwd1_lds_kernel<CH=%d>" % lds_ch if lds_ch else "pcm_sa_bwd1_kernel(global atomics)", timed_events(lambda: bwd(2), 30),
-        m * H * 9 + 16 * rows + n_tot * H * 4, "hbm",
-        "m*H deltas (dz 4 B + sel 4 B + slot 1 B read) scattered with ds_add_f32 into an LDS tile per (cloud, channel chunk); D written once")
-    add("pcm_sa_bwd2_kernel<bf16>", timed_events(lambda: bwd(8), 30), n_tot * H * (2 + 4 + 2) + 16 * n_tot, "hbm", "dense n*H pass")
-    add("pcm_sa_reduce_kernel", timed_events(lambda: bwd(4), 30), slots * 5 * H * 4, "hbm", "fp64 reduction of per-block partial rows")
+    t.add("pcm_sa_fwd_kernel<bf16>", timed_events(lambda: fwd(1), 30), n_tot * H * 2 + 16 * rows + m * H * 5, "hbm",
+          "gather of %d rows x %d ch (every Gf row counted once; VALU-bound: ~9 fp32 ops per gathered element); writes the "
+          "selected extremum (4 B) + its slot (1 B) per (query, channel)" % (rows, H))
+    t.add("pcm_sa_apply_kernel", timed_events(lambda: fwd(8), 30), m * H * 8, "hbm", "z = relu(a*sel + b): 4 B read, 4 B written")
+    t.add("pcm_sa_entries+index kernels", timed_events(index, 30), 4 * rows + 12 * n_tot + 12 * m + 2 * 16 * rows + 16 * n_tot, "hbm",
+          "index-only passes (16-byte neighbour records, cnt, S, RM) incl. the memset; they run on the sampling side stream")
+    t.add("pcm_sa_bwd1_lds_kernel<CH=%d>" % lds_ch if lds_ch else "pcm_sa_bwd1_kernel(global atomics)", timed_events(lambda: bwd(2), 30),
+          m * H * 9 + 16 * rows + n_tot * H * 4, "hbm",
+          "m*H deltas (dz 4 B + sel 4 B + slot 1 B read) scattered with ds_add_f32 into an LDS tile per (cloud, channel chunk); D written once")
+    t.add("pcm_sa_bwd2_kernel<bf16>", timed_events(lambda: bwd(8), 30), n_tot * H * (2 + 4 + 2) + 16 * n_tot, "hbm", "dense n*H pass")
+    t.add("pcm_sa_reduce_kernel", timed_events(lambda: bwd(4), 30), slots * 5 * H * 4, "hbm", "fp64 reduction of per-block partial rows")
 
-    # ---- transformer tail kernels on the encoder's token matrix (B x 515 tokens x 512) ----------------------
+    # ---- API kernels that materialise the grouped tensor (pointops.grouping; not on the fused path) ----
+    feat = torch.randn(n_tot, c_feat, device=device).requires_grad_(True)
+    grouped = po.grouping(knn_idx, feat, coord, n_p, with_xyz=True)
+    gbytes = 4 * rows + min(rows, n_tot) * (c_feat + 3) * 4 + 12 * m + rows * (c_feat + 3) * 4
+    t.add("pcm_group_xyz_feat_fwd_kernel", timed_events(lambda: po.grouping(knn_idx, feat, coord, n_p, with_xyz=True), 20), gbytes,
+          "hbm", "API op (grouping()): writes the (m,K,3+C) tensor")
+    gout = torch.randn_like(grouped)
+
+    def gbwd():
+        feat.grad = None
+        grouped.backward(gout, retain_graph=True)
+
+    t.add("pcm_group_xyz_feat_bwd_kernel", timed_events(gbwd, 20), rows * c_feat * 4 + 4 * rows + n_tot * c_feat * 4, "hbm",
+          "API op backward: coalesced fp32 atomics")
+    del grouped, gout
+    # ---- interpolation (kNN k=3 weights + gather) and ball query, API ops ----------------------------------
+    try:
+        from pointcloudmatters_amd.pointops.interpolation import interpolation
+
+        featm = torch.randn(m, c_feat, device=device).requires_grad_(True)
+        out = interpolation(n_p, coord, featm, noff, off, k=3)
+        t.add("pcm_interpolation (knn3 + fwd)", timed_events(lambda: interpolation(n_p, coord, featm, noff, off, k=3), 10),
+              n_tot * 3 * 8 + min(n_tot * 3, m) * c_feat * 4 + n_tot * c_feat * 4, "hbm",
+              "API op: 3-NN inverse-distance interpolation of (m, C) features onto the n points")
+        go = torch.randn_like(out)
+
+        def ibwd():
+            featm.grad = None
+            out.backward(go, retain_graph=True)
+
+        t.add("pcm_interpolation_bwd_kernel", timed_events(ibwd, 10), n_tot * c_feat * 4 + n_tot * 3 * 8 + m * c_feat * 4, "hbm",
+              "API op backward: scatter of n*C gradients onto m rows")
+        msb = timed_events(lambda: po.ball_query(k, 0.1, 0.0, coord, off, n_p, noff), 10)
+        t.add("pcm_ball_query_kernel", msb, 12 * n_tot + 12 * m + 8 * m * k, "alu",
+              "API op: radius 0.1, nsample 16; %.1f M distance evaluations" % (evals / 1e6),
+              extra={"dist_evals_per_s": round(evals / msb * 1e3, 1)})
+    except Exception as e:  # API ops: never let them break the headline
+        t.rows["api_ops_error"] = {"error": "%s: %s" % (type(e).__name__, e)}
+
+
+def small_attention_nograd(small_attn, q, k, v, nh):
+    with torch.no_grad():
+        return small_attn.small_attention(q, k, v, None, nh, 0.0)
+
+
+def policy_kernels(t, wl, device, hidden=512):
+    """Transformer-tail / attention / PointNet / U-Net / optimizer kernels alone, at the shapes of `wl`."""
+    import ctypes
+
+    from pointcloudmatters_amd import _lib
+
+    L = _lib.load()
+    b, m_per = wl["batch"], wl["pcd_npoints"]
+    n_tot = b * wl["n_points"]
+    st = torch.cuda.current_stream().cuda_stream
+    f32 = dict(dtype=torch.float32, device=device)
+    # ---- transformer tail kernels on the encoder's token matrix (B x (M+3) tokens x 512) ----------------------
     R, E, Fh = b * (m_per + 3), hidden, 32
     if E % 256 == 0 and E <= 1024:
         xr, yr = torch.randn(R, E, **f32), torch.randn(R, E, **f32).to(torch.bfloat16)
@@ -183,8 +274,8 @@ def kernel_rooflines(wl, device, c_feat=512, hidden=512):
                                            seed.data_ptr(), 1, dx_.data_ptr(), dy16.data_ptr(), part.data_ptr(), dgb.data_ptr(), st) == 0
 
         drln_f()
-        add("pcm_drln_fwd_kernel<bf16,2>", timed_events(drln_f, 30), R * E * 14, "hbm", "LayerNorm(x + dropout(y)): 6 B read, 8 B written per element")
-        add("pcm_drln_bwd_kernel<bf16,2>(+reduce)", timed_events(drln_b, 30), R * E * 14, "hbm", "8 B read, 6 B written per element")
+        t.add("pcm_drln_fwd_kernel<bf16,2>", timed_events(drln_f, 30), R * E * 14, "hbm", "LayerNorm(x + dropout(y)): 6 B read, 8 B written per element")
+        t.add("pcm_drln_bwd_kernel<bf16,2>(+reduce)", timed_events(drln_b, 30), R * E * 14, "hbm", "8 B read, 6 B written per element")
         if L.pcm_ffn_ln_supported(E, Fh):
             w1, bb1 = torch.randn(Fh, E, **f32) * 0.05, torch.zeros(Fh, **f32)
             w2, bb2 = torch.randn(E, Fh, **f32) * 0.05, torch.zeros(E, **f32)
@@ -201,9 +292,31 @@ def kernel_rooflines(wl, device, c_feat=512, hidden=512):
                                                  dx_.data_ptr(), dy_.data_ptr(), dh_.data_ptr(), part.data_ptr(), dgb.data_ptr(), st) == 0
 
             ffn_f()
-            add("pcm_ffn_ln_fwd_kernel<512,32>", timed_events(ffn_f, 30), R * E * 12 + R * Fh * 4, "lds",
-                "LDS-bandwidth bound: every row re-reads both 64 KiB weight matrices from LDS (%.0f MB of LDS reads)" % (R * 0.131))
-            add("pcm_ffn_ln_bwd_kernel<512,32>(+reduce)", timed_events(ffn_b, 30), R * E * 20 + R * Fh * 8, "lds", "as forward")
+            t.add("pcm_ffn_ln_fwd_kernel<512,32>", timed_events(ffn_f, 30), R * E * 12 + R * Fh * 4, "lds",
+                  "LDS-bandwidth bound: every row re-reads both 64 KiB weight matrices from LDS (%.0f MB of LDS reads)" % (R * 0.131))
+            t.add("pcm_ffn_ln_bwd_kernel<512,32>(+reduce)", timed_events(ffn_b, 30), R * E * 20 + R * Fh * 8, "lds", "as forward")
+
+    # ---- MFMA attention for short query sets: decoder cross-attention shape (100 queries x (M+3) keys, 8 heads x 64) ----
+    from pointcloudmatters_amd.policy import small_attn
+
+    Lq, Sk, nh = 100, min(m_per + 3, small_attn.MAX_KEYS), hidden // 64
+    q = torch.randn(b, Lq, hidden, **f32).to(torch.bfloat16).requires_grad_(True)
+    kk = torch.randn(b, Sk, hidden, **f32).to(torch.bfloat16).requires_grad_(True)
+    vv = torch.randn(b, Sk, hidden, **f32).to(torch.bfloat16).requires_grad_(True)
+    if small_attn.supported(q, kk, vv, nh, 0.0):
+        o = small_attn.small_attention(q, kk, vv, None, nh, 0.0)
+        go = torch.randn_like(o)
+        flops_f = 4 * b * nh * Lq * Sk * 64
+
+        def attn_b():
+            q.grad = kk.grad = vv.grad = None
+            o.backward(go, retain_graph=True)
+
+        t.add("pcm_attn_small_fwd_kernel", timed_events(lambda: small_attention_nograd(small_attn, q, kk, vv, nh), 30), None, "mfma",
+              "decoder cross-attention core, %d queries x %d keys x %d (batch, head) pairs; softmax VALU work ~2x the MFMA time at "
+              "head_dim 64" % (Lq, Sk, b * nh), flops=flops_f)
+        t.add("pcm_attn_small_bwd_kernel", timed_events(attn_b, 30), None, "mfma", "same shape, dQ and dK/dV roles in one launch",
+              flops=flops_f * 5 // 2)
 
     # ---- PointNet layer tail: BatchNorm1d + ReLU over the packed point features (widest layer: n x 512, bf16) ----
     Cb = 512
@@ -223,10 +336,10 @@ def kernel_rooflines(wl, device, c_feat=512, hidden=512):
                                           dyb.data_ptr(), st) == 0
 
     bn_f()
-    add("pcm_bn_relu forward (colsum+reduce+stats+apply)", timed_events(bn_f, 30), n_tot * Cb * 6, "hbm",
-        "BatchNorm1d(batch stats)+ReLU on (n, 512) bf16: y read twice, z written once")
-    add("pcm_bn_relu backward (colsum+reduce+apply)", timed_events(bn_b, 30), n_tot * Cb * 10, "hbm",
-        "y and dz read twice, dy written once")
+    t.add("pcm_bn_relu forward (colsum+reduce+stats+apply)", timed_events(bn_f, 30), n_tot * Cb * 6, "hbm",
+          "BatchNorm1d(batch stats)+ReLU on (n, 512) bf16: y read twice, z written once")
+    t.add("pcm_bn_relu backward (colsum+reduce+apply)", timed_events(bn_b, 30), n_tot * Cb * 10, "hbm",
+          "y and dz read twice, dy written once")
 
     # ---- Diffusion-Policy U-Net blocks, channels-last (C3 shape: 64 samples x 16 steps x 1024 channels) ----------
     Bu, Tu, Cu, Ku = 64, 16, 1024, 5
@@ -256,10 +369,10 @@ def kernel_rooflines(wl, device, c_feat=512, hidden=512):
 
     gn_f()
     eu = Bu * Tu * Cu
-    add("pcm_im2col_cl_kernel<f32,bf16,4>", timed_events(i2c, 30), eu * 4 + eu * Ku * 2, "hbm", "k=5 im2col with the bf16 cast fused")
-    add("pcm_col2im_cl_kernel<bf16,f32>", timed_events(c2i, 30), eu * Ku * 2 + eu * 4, "hbm", "adjoint gather")
-    add("pcm_gn_mish_fwd_kernel<bf16,bf16,f32>", timed_events(gn_f, 30), eu * 6, "hbm", "GroupNorm(8)+Mish+FiLM: 2 B read, 4 B written")
-    add("pcm_gn_mish_bwd_kernel<bf16,bf16>", timed_events(gn_b, 30), eu * 8, "hbm", "4 B dy + 2 B x read, 2 B dx written")
+    t.add("pcm_im2col_cl_kernel<f32,bf16,4>", timed_events(i2c, 30), eu * 4 + eu * Ku * 2, "hbm", "k=5 im2col with the bf16 cast fused")
+    t.add("pcm_col2im_cl_kernel<bf16,f32>", timed_events(c2i, 30), eu * Ku * 2 + eu * 4, "hbm", "adjoint gather")
+    t.add("pcm_gn_mish_fwd_kernel<bf16,bf16,f32>", timed_events(gn_f, 30), eu * 6, "hbm", "GroupNorm(8)+Mish+FiLM: 2 B read, 4 B written")
+    t.add("pcm_gn_mish_bwd_kernel<bf16,bf16>", timed_events(gn_b, 30), eu * 8, "hbm", "4 B dy + 2 B x read, 2 B dx written")
 
     # ---- optimizer tail on a flat buffer of the real parameter count ----------------------------------
     n_par = 24_100_000 // 64 * 64
@@ -279,27 +392,138 @@ def kernel_rooflines(wl, device, c_feat=512, hidden=512):
                                     parts.data_ptr(), npart.value, norm.data_ptr(), pb16.data_ptr(), st) == 0
 
     sumsq()
-    add("pcm_grad_sumsq_kernel", timed_events(sumsq, 30), 4 * n_par, "hbm", "24.1 M gradients, 4 B read each")
-    add("pcm_adamw_flat_kernel", timed_events(adam, 30), 30 * n_par, "hbm", "24.1 M parameters: 16 B read + 12 B fp32 + 2 B bf16 written each")
-
-    # ---- API kernels that materialise the grouped tensor (pointops.grouping; not on the fused path) ----
-    feat = torch.randn(n_tot, c_feat, device=device).requires_grad_(True)
-    grouped = po.grouping(knn_idx, feat, coord, n_p, with_xyz=True)
-    gbytes = 4 * rows + min(rows, n_tot) * (c_feat + 3) * 4 + 12 * m + rows * (c_feat + 3) * 4
-    add("pcm_group_xyz_feat_fwd_kernel", timed_events(lambda: po.grouping(knn_idx, feat, coord, n_p, with_xyz=True), 20), gbytes,
-        "hbm", "API op (grouping()): writes the (m,K,3+C) tensor")
-    gout = torch.randn_like(grouped)
-
-    def gbwd():
-        feat.grad = None
-        grouped.backward(gout, retain_graph=True)
-
-    add("pcm_group_xyz_feat_bwd_kernel", timed_events(gbwd, 20), rows * c_feat * 4 + 4 * rows + n_tot * c_feat * 4, "hbm",
-        "API op backward: coalesced fp32 atomics")
-    return res
+    t.add("pcm_grad_sumsq_kernel", timed_events(sumsq, 30), 4 * n_par, "hbm", "24.1 M gradients, 4 B read each")
+    t.add("pcm_adamw_flat_kernel", timed_events(adam, 30), 30 * n_par, "hbm", "24.1 M parameters: 16 B read + 12 B fp32 + 2 B bf16 written each")
 
 
-def pmc_traffic(kernel):
+def kernel_rooflines(wl, device, c_feat=512, hidden=512):
+    """Every hand-written hot-path kernel ALONE on this workload's shapes, priced against its algorithmic HBM bytes (or MFMA
+    flops) -- DESIGN.md section 4.  Returns {kernel: {...}}."""
+    t = KernelTable()
+    shape = dict(wl, c_feat=c_feat, hidden=hidden)
+    pointops_and_sa_kernels(t, shape, device)
+    policy_kernels(t, wl, device, hidden=512)
+    return t.rows
+
+
+def kernel_rooflines_hbm(device, names=None):
+    out = {}
+    for name, shape in HBM_SHAPES.items():
+        if names and name not in names:
+            continue
+        t = KernelTable()
+        pointops_and_sa_kernels(t, shape, device)
+        out[name] = {"shape": dict(shape), "kernels": t.rows}
+        torch.cuda.empty_cache()
+    return out
+
+
+# trace kernel name (substring) -> key prefix in the `kernels` table
+TRACE_TO_TABLE = [
+    ("pcm_fps", "pcm_fps_reg_kernel"), ("pcm_knn", "pcm_knn_fast_kernel"), ("pcm_sa_fwd", "pcm_sa_fwd_kernel"),
+    ("pcm_sa_apply", "pcm_sa_apply_kernel"), ("pcm_sa_entries", "pcm_sa_entries+index"), ("pcm_sa_index", "pcm_sa_entries+index"),
+    ("pcm_sa_bwd1", "pcm_sa_bwd1"), ("pcm_sa_bwd2", "pcm_sa_bwd2_kernel"), ("pcm_sa_reduce", "pcm_sa_reduce_kernel"),
+    ("pcm_drln_fwd", "pcm_drln_fwd_kernel"), ("pcm_drln_bwd", "pcm_drln_bwd_kernel"), ("pcm_drln_reduce", "pcm_drln_bwd_kernel"),
+    ("pcm_ffn_ln_fwd", "pcm_ffn_ln_fwd_kernel"), ("pcm_ffn_ln_bwd", "pcm_ffn_ln_bwd_kernel"), ("pcm_ffn_reduce", "pcm_ffn_ln_bwd_kernel"),
+    ("pcm_attn_small_fwd", "pcm_attn_small_fwd_kernel"), ("pcm_attn_small_bwd", "pcm_attn_small_bwd_kernel"),
+    ("pcm_bn_", "pcm_bn_relu"), ("pcm_im2col", "pcm_im2col_cl_kernel"), ("pcm_col2im", "pcm_col2im_cl_kernel"),
+    ("pcm_gn_mish_fwd", "pcm_gn_mish_fwd_kernel"), ("pcm_gn_mish_bwd", "pcm_gn_mish_bwd_kernel"),
+    ("pcm_grad_sumsq", "pcm_grad_sumsq_kernel"), ("pcm_adamw", "pcm_adamw_flat_kernel"),
+]
+
+
+def _family(name):
+    if "pcm_" in name:
+        return "pcm_handwritten"
+    if "Cijk_" in name:
+        return "hipblaslt_gemm"
+    if name in ("attn_fwd", "bwd_kernel_dk_dv", "bwd_kernel_dq", "bwd_preprocess") or "flash" in name.lower():
+        return "framework_attention"
+    if "Memcpy" in name or "Memset" in name:
+        return "memcpy_memset"
+    if "nccl" in name.lower() or "rccl" in name.lower():
+        return "rccl"
+    return "torch_elementwise_reduce_other"
+
+
+def step_trace(step_fn, steps):
+    """Kernel-level composition of the timed step: torch.profiler (roctracer) over `steps` extra steps -- graph replays
+    report every replayed kernel.  Returns {"error": ...} when the profiler is unavailable."""
+    try:
+        from torch.profiler import ProfilerActivity, profile
+
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+            for i in range(steps):
+                step_fn(i)
+            torch.cuda.synchronize()
+        rows = []
+        for e in prof.key_averages():
+            dt = getattr(e, "self_device_time_total", None)
+            if dt is None:
+                dt = getattr(e, "self_cuda_time_total", 0)
+            if dt and dt > 0 and "CUDA" in str(getattr(e, "device_type", "DeviceType.CUDA")):
+                rows.append((float(dt), int(e.count), e.key))
+    except Exception as e:  # depends on the box
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+    if not rows:
+        return {"error": "the profiler returned no device events"}
+    rows.sort(reverse=True)
+    total = sum(r[0] for r in rows)
+    fam, hand = {}, {}
+    for dt, cnt, name in rows:
+        f = fam.setdefault(_family(name), [0.0, 0])
+        f[0] += dt
+        f[1] += cnt
+        if "pcm_" in name:
+            short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+            h = hand.setdefault(short, [0.0, 0])
+            h[0] += dt
+            h[1] += cnt
+    return {
+        "how": "torch.profiler (roctracer) kernel trace of %d extra steps right after the timed region, same trainer and mode" % steps,
+        "steps": steps, "launches_per_step": round(sum(r[1] for r in rows) / steps, 1),
+        "device_ms_per_step": round(total / steps / 1e3, 3),
+        "by_family": {k: {"share": round(v[0] / total, 4), "launches_per_step": round(v[1] / steps, 1)} for k, v in
+                      sorted(fam.items(), key=lambda kv: -kv[1][0])},
+        "top": [{"kernel": n.replace("(anonymous namespace)::", "")[:100], "us_per_step": round(dt / steps, 1),
+                 "launches_per_step": round(cnt / steps, 1), "share": round(dt / total, 4)} for dt, cnt, n in rows[:12]],
+        "handwritten": {k: {"us_per_step": round(v[0] / steps, 1), "launches_per_step": round(v[1] / steps, 2),
+                            "avg_us": round(v[0] / v[1], 2), "share": round(v[0] / total, 4)}
+                        for k, v in sorted(hand.items(), key=lambda kv: -kv[1][0])},
+    }
+
+
+def pick_roofline(trace, kernels):
+    """The hand-written kernel with the largest total device time in the step trace, priced with its isolated HIP-event
+    timing from `kernels` (same shapes)."""
+    hand = (trace or {}).get("handwritten") or {}
+    for tname, rec in hand.items():  # already sorted by total time
+        key = None
+        for sub, prefix in TRACE_TO_TABLE:
+            if sub in tname:
+                key = next((k for k in kernels if k.startswith(prefix)), None)
+                break
+        if key is None:
+            continue
+        kr = kernels[key]
+        out = {"kernel": key, "trace_kernel": tname, "selected_by": "largest total device time among the hand-written (pcm_*) kernels "
+               "in the step trace", "share_of_step": rec["share"], "us_per_step_in_trace": rec["us_per_step"],
+               "avg_us_in_trace": rec["avg_us"], "launches_per_step": rec["launches_per_step"], "ms_alone": kr["ms"], "note": kr["note"]}
+        if kr["bound"] == "mfma":
+            out.update(bound="mfma", achieved=kr["achieved_TFLOPs"], peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s", frac=kr["frac_of_mfma_peak"],
+                       traffic=None)
+        else:
+            out.update(bound="hbm", limited_by=kr["bound"], achieved=kr["achieved_GBs"], peak=HBM_PEAK_GBS, unit="GB/s",
+                       frac=kr["frac_of_hbm_peak"], traffic=pmc_traffic(key))
+            for extra_key in kr:
+                if extra_key.startswith("clocks_per_pick") or extra_key in ("ns_per_pick", "dist_evals_per_s", "picks_per_s_per_cloud"):
+                    out[extra_key] = kr[extra_key]
+        return out
+    return None
+
+
+def pmc_traffic(kernel, shape=None):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json,
     produced by tools/collect_profiles.sh with the FETCH_SIZE / WRITE_SIZE corrections of the guide), or None."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -307,10 +531,15 @@ def pmc_traffic(kernel):
         return None
     with open(path) as f:
         table = json.load(f)
-    for name, rec in table.get("kernels", {}).items():
-        if name.split("<")[0] in kernel:
-            return rec.get("hbm_bytes_per_launch")
-    return None
+    kernels = table.get("shapes", {}).get(shape or "C2", None)
+    if kernels is None:
+        kernels = table.get("kernels", {}) if shape is None else {}
+    best = None
+    for name, rec in kernels.items():
+        base = name.split("<")[0]
+        if base and base in kernel and (best is None or len(base) > len(best[0])):
+            best = (base, rec.get("hbm_bytes_per_launch"))
+    return best[1] if best else None
 
 
 def cpu_baseline(wl, steps, threads=16):
@@ -321,9 +550,10 @@ def cpu_baseline(wl, steps, threads=16):
 
     # more host threads are SLOWER on this path (measured on the 256-core GPU box at C2: 16 threads
     # 1.76 s/step, 64 threads 3.3 s/step, 256 threads > 100 s/step), so the baseline uses 16.
-    cores = min(os.cpu_count() or 1, threads)
-    torch.set_num_threads(cores)
-    os.environ["OMP_NUM_THREADS"] = str(cores)
+    host_cores = os.cpu_count() or 1
+    used = min(host_cores, threads)
+    torch.set_num_threads(used)
+    os.environ["OMP_NUM_THREADS"] = str(used)
     torch.manual_seed(0)
     policy = build_act_policy(pcd_npoints=wl["pcd_npoints"], pointops=pointops_cpu, sa_impl="reference")
     trainer = BCTrainer(policy, total_steps=1000, precision="fp32", device="cpu", optim=dict(accumulate_grad_batches=1))
@@ -333,15 +563,64 @@ def cpu_baseline(wl, steps, threads=16):
     for _ in range(steps):
         trainer.training_step(clone_batch(batch))
     dt = time.perf_counter() - t0
-    return {"value": round(wl["batch"] * steps / dt, 4), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": "%d optimizer steps of the same workload (B=%d, N=%d, M=%d, fp32) after 1 warm-up; %.1f s"
-                      % (steps, wl["batch"], wl["n_points"], wl["pcd_npoints"], dt)}
+    return {"value": round(wl["batch"] * steps / dt, 4), "unit": "samples/s", "cores": used, "threads": used, "host_cores": host_cores,
+            "kind": "port", "dtype": "fp32",
+            "sample": "%d optimizer steps of the same workload (B=%d, N=%d, M=%d, fp32) after 1 warm-up; %.1f s; %d of the box's %d "
+                      "host cores (more threads are slower on this path)" % (steps, wl["batch"], wl["n_points"], wl["pcd_npoints"], dt, used,
+                                                                              host_cores)}
+
+
+def run_workload(name, args, device, world, rank, steps, warmup, precision=None, mode="auto", trace_steps=0):
+    """Build the policy + trainer of workload `name`, run warm-up + `steps` timed steps."""
+    from pointcloudmatters_amd.bc import (DP_OPTIM, BCTrainer, WORKLOADS, build_act_policy, build_dp_policy, clone_batch,
+                                          make_act_batch, make_dp_batch)
+
+    wl = dict(WORKLOADS[name])
+    if precision is not None:
+        wl["dtype"] = precision
+    sa_impl = "fused" if args.sa_impl == "auto" else args.sa_impl
+    torch.manual_seed(1000 + rank)
+    is_dp = wl["policy"] == "dp"
+    build = build_dp_policy if is_dp else build_act_policy
+    make_batch = make_dp_batch if is_dp else make_act_batch
+    extra = {} if is_dp else {"dead_decoder_layers": args.dead_decoder_layers}
+    policy = build(pcd_npoints=wl["pcd_npoints"], sa_impl=sa_impl, **extra).to(device)
+    if mode == "auto":
+        # ragged clouds: the tokenizer runs eagerly, everything behind the fixed-size token matrix replays as one hipGraph
+        mode = "hybrid" if wl["ragged"] else "graph"
+    trainer = BCTrainer(policy, total_steps=max(steps + warmup + trace_steps, 100), precision=wl["dtype"], device=device,
+                        distributed=world > 1, optim=dict(DP_OPTIM) if is_dp else dict(accumulate_grad_batches=1), mode=mode)
+    batches = [make_batch(wl["batch"], wl["n_points"], seed=1000 + rank + 97 * i, ragged=wl["ragged"], device=device)
+               for i in range(4)]
+
+    def step(i):
+        # the next batch is handed over early, as a prefetching data loader would: outside graph mode its FPS + kNN run one
+        # step ahead on the side stream (graph mode ignores it: the sampling is inside the captured graph)
+        nxt = None if args.no_prefetch else batches[(i + 1) % len(batches)]
+        trainer.training_step(clone_batch(batches[i % len(batches)]), prefetch=nxt)
+
+    for i in range(warmup):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    return dt, trainer, step, wl, sa_impl
 
 
 def main():
     args = parse()
-    from pointcloudmatters_amd.bc import (DP_OPTIM, BCTrainer, WORKLOADS, build_act_policy, build_dp_policy, clone_batch,
-                                          make_act_batch, make_dp_batch)
+    from pointcloudmatters_amd.bc import WORKLOADS
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -354,49 +633,17 @@ def main():
         dist.init_process_group(backend="nccl")  # "nccl" is RCCL on ROCm; communicators are created lazily
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    wl = WORKLOADS[args.workload]
     if args.kernels_only:
-        print(json.dumps({"kernels": kernel_rooflines(wl, device)}), flush=True)
+        if args.kernel_shape and args.kernel_shape in HBM_SHAPES:
+            print(json.dumps({"kernels_hbm": kernel_rooflines_hbm(device, [args.kernel_shape])}), flush=True)
+        else:
+            print(json.dumps({"kernels": kernel_rooflines(WORKLOADS[args.workload], device)}), flush=True)
         return
-    sa_impl = "fused" if args.sa_impl == "auto" else args.sa_impl
-    torch.manual_seed(1000 + rank)
-    is_dp = wl["policy"] == "dp"
-    build = build_dp_policy if is_dp else build_act_policy
-    make_batch = make_dp_batch if is_dp else make_act_batch
-    extra = {} if is_dp else {"dead_decoder_layers": args.dead_decoder_layers}
-    policy = build(pcd_npoints=wl["pcd_npoints"], sa_impl=sa_impl, **extra).to(device)
-    mode = args.mode
-    if mode == "auto":  # hipGraph replay needs static shapes; ragged workloads use the flat optimizer eagerly
-        # ragged clouds: the tokenizer runs eagerly, everything behind the fixed-size token matrix replays as one hipGraph
-        mode = "hybrid" if wl["ragged"] else "graph"
-    trainer = BCTrainer(policy, total_steps=max(args.steps + args.warmup, 100), precision=wl["dtype"], device=device,
-                        distributed=world > 1, optim=dict(DP_OPTIM) if is_dp else dict(accumulate_grad_batches=1), mode=mode)
-    batches = [make_batch(wl["batch"], wl["n_points"], seed=1000 + rank + 97 * i, ragged=wl["ragged"], device=device)
-               for i in range(4)]
 
-    def step(i):
-        # the next batch is handed over early, as a prefetching data loader would: outside graph mode its FPS + kNN run one
-        # step ahead on the side stream (graph mode ignores it: the sampling is inside the captured graph)
-        nxt = None if args.no_prefetch else batches[(i + 1) % len(batches)]
-        trainer.training_step(clone_batch(batches[i % len(batches)]), prefetch=nxt)
-
-    for i in range(args.warmup):
-        step(i)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, trainer, step, wl, sa_impl = run_workload(args.workload, args, device, world, rank, args.steps, args.warmup, mode=args.mode,
+                                                  trace_steps=8)
     metrics = trainer.metrics()
+    is_dp = wl["policy"] == "dp"
 
     if rank == 0:
         samples = wl["batch"] * world * args.steps
@@ -412,19 +659,48 @@ def main():
                        "global_batch": wl["batch"] * world, "points_per_cloud": wl["n_points"],
                        "tokens_per_cloud": wl["pcd_npoints"], "parallelism": "dp%d" % world, "sa_impl": sa_impl, "step_mode": trainer.mode,
                        "batchnorm": "sync" if trainer.sync_batchnorm else "per-rank",
+                       "gradient_exchange": getattr(trainer, "exchange_description", "one all-reduce after backward") if world > 1 else "single GPU",
                        "accumulate_grad_batches": 1, "optimizer_step_every_step": True,
                        "dead_decoder_layers": "n/a" if is_dp else args.dead_decoder_layers},
             "final_loss": round(metrics.get("train/loss", float("nan")), 4),
         }
         if not args.no_roofline:
-            kr = kernel_rooflines(wl, device)
-            # dominant = the longest-running hand-written HBM-bound kernel of the training step's critical path
-            dp_only = ("im2col", "col2im", "gn_mish")  # Diffusion-Policy U-Net kernels: not launched by an ACT step
-            on_path = [k for k in kr if kr[k]["bound"] == "hbm" and "group_xyz" not in k and (is_dp or not any(t in k for t in dp_only))]
-            dom = max(on_path, key=lambda k: kr[k]["ms"])
-            out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": kr[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": kr[dom]["frac_of_hbm_peak"], "traffic": pmc_traffic(dom)}
+            trace = step_trace(step, 6)
+            kr = kernel_rooflines(wl, device, c_feat=96 if is_dp else 512, hidden=96 if is_dp else 512)
+            out["step_trace"] = trace
+            rl = pick_roofline(trace, kr)
+            if rl is None:  # no trace on this box: fall back to the longest isolated hand-written kernel
+                dom = max((k for k in kr if "ms" in kr[k] and not any(s in k for s in ("group_xyz", "interpolation", "ball_query"))),
+                          key=lambda k: kr[k]["ms"])
+                rl = {"kernel": dom, "selected_by": "longest isolated hand-written kernel (no step trace available)", "bound": "hbm",
+                      "achieved": kr[dom].get("achieved_GBs"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": kr[dom].get("frac_of_hbm_peak"), "traffic": pmc_traffic(dom)}
+            out["roofline"] = rl
             out["kernels"] = kr
+            del trainer, step
+            torch.cuda.empty_cache()
+            hb = kernel_rooflines_hbm(device)
+            for shape_name, rec in hb.items():
+                for kname, krec in rec["kernels"].items():
+                    tr = pmc_traffic(kname, shape_name)
+                    if tr is not None and krec.get("algorithmic_bytes"):
+                        krec["pmc_hbm_bytes"] = tr
+                        krec["traffic_over_algorithmic"] = round(tr / krec["algorithmic_bytes"], 3)
+            out["kernels_hbm"] = hb
+        if not args.no_extra and world == 1 and args.workload == "C2":
+            extra = {}
+            for tag, wname, prec, nsteps in (("fp32_C2", "C2", "fp32", 15), ("REF_bf16", "REF", None, 15)):
+                try:
+                    torch.cuda.empty_cache()
+                    d2, tr2, _, wl2, _ = run_workload(wname, args, device, 1, 0, nsteps, 5, precision=prec)
+                    extra[tag] = {"workload": wname, "dtype": wl2["dtype"], "step_mode": tr2.mode,
+                                  "value": round(wl2["batch"] * nsteps / d2, 3), "unit": "samples/s",
+                                  "ms_per_step": round(d2 / nsteps * 1e3, 3), "steps": nsteps,
+                                  "final_loss": round(tr2.metrics().get("train/loss", float("nan")), 4)}
+                    del tr2
+                except Exception as e:  # the extra lines must never break the headline
+                    extra[tag] = {"error": "%s: %s" % (type(e).__name__, e)}
+            out["extra"] = extra
         if not args.no_cpu_baseline and world == 1 and not is_dp:
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_steps, args.cpu_threads)
         print(json.dumps(out), flush=True)
