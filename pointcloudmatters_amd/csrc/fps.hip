@@ -31,14 +31,21 @@ constexpr int kMaxRegPoints = 1024 * 16;
 // slot -> i mapping.  Thread u holds local points j = u + i*T.  With q = BS/T = 2^LOGQ reference
 // threads folded into one of ours, ascending prio inside the thread means ordering by
 // (bitrev_LOGQ(i mod q), i / q); slot s = c' * (PPT/q) + r  <->  i = r*q + bitrev_LOGQ(c').
+template <int NB>
+__host__ __device__ constexpr int bitrev_n(int v)
+{
+    int r = 0;
+    for (int b = 0; b < NB; ++b) r |= ((v >> b) & 1) << (NB - 1 - b);
+    return r;
+}
+
 template <int PPT, int LOGQ>
 __host__ __device__ constexpr int slot_to_i(int s)
 {
     constexpr int Q = 1 << LOGQ;
     constexpr int RP = PPT / Q;
     const int cp = s / RP, r = s % RP;
-    const int c = LOGQ == 2 ? (((cp & 1) << 1) | (cp >> 1)) : cp;  // 2-bit reversal; 0/1 bits: identity
-    return r * Q + c;
+    return r * Q + bitrev_n<LOGQ>(cp);
 }
 
 __device__ __forceinline__ uint32_t fps_prio(uint32_t j, uint32_t bs_mask, int L)
@@ -55,7 +62,7 @@ __device__ __forceinline__ uint32_t fps_unprio(uint32_t prio, int L)
 }
 
 // Workgroup arg-max over (bits, prio): wave DPP reduce -> one LDS slot per wave -> one barrier.
-// Returns the winning local point index j (identical in every thread).
+// Returns the winning local point index j (identical in every thread).  (any-size kernel)
 template <int W>
 __device__ __forceinline__ uint32_t fps_block_argmax(uint32_t bits, uint32_t prio, bool valid,
                                                     unsigned long long *slots, int it, int wave,
@@ -76,8 +83,44 @@ __device__ __forceinline__ uint32_t fps_block_argmax(uint32_t bits, uint32_t pri
     return fps_unprio(~(uint32_t)key, L);
 }
 
+typedef float fps_f2 __attribute__((ext_vector_type(2)));  // v_pk_add_f32 / v_pk_mul_f32 operands (no FMA: contract off)
+
+// Wave-wide unsigned max in 6 DPP-fused instructions + 1 readlane (the builtin form costs a v_mov + s_nop + v_mov_dpp +
+// v_max per step and 4 readlanes): quad swaps, row_half_mirror, row_mirror leave every row's maximum in all of its lanes,
+// row_bcast:15 / row_bcast:31 (GFX9 DPP, present on gfx950) fold the four rows into lane 63.
+__device__ __forceinline__ uint32_t fps_wave_max_fast(uint32_t v)
+{
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_max_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // ---------------------------------------------------------------------------------------------
-// Register-resident kernel: N_i <= T*PPT for every cloud.
+// Register-resident kernel: N_i <= T*PPT for every cloud.  The pick loop is bound by instruction issue of ONE wave per
+// SIMD (~6 clocks per dependent instruction), so it is written to be short:
+//  (a) distance update on point PAIRS with packed fp32 math (same roundings as the scalar chain: sub, mul, add, mul, add,
+//      one at a time), v_min for the running distance, one compare + two selects for the thread's candidate;
+//  (b) wave maximum of the candidates' distance bits: 6 fused DPP instructions + 1 readlane;
+//  (c) a ballot finds the owning lane; only an exact tie inside the wave (wave-uniform branch, rare) computes the
+//      reference's tie order (prio) and reduces it;
+//  (d) the OWNING LANE publishes {distance key} and {local index, x, y, z} in the wave's LDS slot -- ONE s_barrier --
+//  (e) every thread takes the maximum of the W keys; a unique maximum (usual) selects the slot directly, an exact tie
+//      across waves compares the reference's prio of the tied candidates; one more broadcast read fetches index + xyz.
+// The cloud itself stays in registers (PPT <= 4: the candidate's xyz comes out of registers in the owning lane; larger
+// PPT: the owning lane reads it from the LDS copy), so nothing is ever re-read from HBM.
 // ---------------------------------------------------------------------------------------------
 template <int T, int PPT, int LOGQ, bool LDS_XYZ>
 __global__ __launch_bounds__(T) void pcm_fps_reg_kernel(const float *__restrict__ xyz,
@@ -86,9 +129,14 @@ __global__ __launch_bounds__(T) void pcm_fps_reg_kernel(const float *__restrict_
                                                         int *__restrict__ idx, int L)
 {
     constexpr int W = T / PCM_WAVE;
+    constexpr bool TRACK = PPT <= 4;               // candidate xyz taken from registers
+    constexpr bool STAGE = LDS_XYZ && !TRACK;      // float4 copy of the cloud in LDS for the owning lane
+    constexpr int NP = (PPT + 1) / 2;              // point pairs per thread
+    constexpr int WP = (W + 3) / 4 * 4;            // keys padded to whole 16-byte reads
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    unsigned long long *slots = reinterpret_cast<unsigned long long *>(smem);  // 2*W entries
-    float4 *lxyz = reinterpret_cast<float4 *>(smem + ((2 * W * 8 + 15) / 16) * 16);
+    uint32_t *keys = reinterpret_cast<uint32_t *>(smem);                 // [2][WP]   0 = wave without candidate, else bits + 1
+    float4 *cand = reinterpret_cast<float4 *>(smem + 2 * WP * 4);        // [2][W]    (local index, x, y, z)
+    float4 *lxyz = cand + 2 * W;                                         // [N] when STAGE
 
     const int bid = blockIdx.x;
     const int u = threadIdx.x, lane = u & 63, wave = u >> 6;
@@ -103,41 +151,53 @@ __global__ __launch_bounds__(T) void pcm_fps_reg_kernel(const float *__restrict_
         return;
     }
     if (u == 0) idx[start_m] = start_n;
+    if (u < 2 * WP) keys[u] = 0u;  // padding slots never win
 
-    float px[PPT], py[PPT], pz[PPT], md[PPT];
+    fps_f2 px[NP], py[NP], pz[NP];
+    float md[2 * NP];
     const float *cloud = xyz + (size_t)start_n * 3;
 #pragma unroll
-    for (int s = 0; s < PPT; ++s) {
-        const int j = u + slot_to_i<PPT, LOGQ>(s) * T;
+    for (int s = 0; s < 2 * NP; ++s) {
+        const int j = s < PPT ? u + slot_to_i<PPT, LOGQ>(s < PPT ? s : 0) * T : N;
+        float x = 0.f, y = 0.f, z = 0.f;
+        md[s] = -1.f;  // min(d, -1) = -1 is never > best
         if (j < N) {
-            px[s] = cloud[j * 3 + 0];
-            py[s] = cloud[j * 3 + 1];
-            pz[s] = cloud[j * 3 + 2];
+            x = cloud[j * 3 + 0], y = cloud[j * 3 + 1], z = cloud[j * 3 + 2];
             md[s] = 1e10f;  // functions/sampling.py:18 pre-fill
-            if (LDS_XYZ) lxyz[j] = make_float4(px[s], py[s], pz[s], 0.f);
-        } else {
-            px[s] = py[s] = pz[s] = 0.f;
-            md[s] = -1.f;  // min(d, -1) = -1 is never > best
+            if (STAGE) lxyz[j] = make_float4(x, y, z, 0.f);
         }
+        px[s / 2][s % 2] = x, py[s / 2][s % 2] = y, pz[s / 2][s % 2] = z;
     }
     float ox = cloud[0], oy = cloud[1], oz = cloud[2];
-    if (LDS_XYZ) __syncthreads();
+    __syncthreads();
 
     const uint32_t bs_mask = (1u << L) - 1u;
+    int *out = idx + start_m;
     for (int it = 1; it < M; ++it) {
         float best = -1.f;
         int bs = 0;
+        const fps_f2 o2x = (fps_f2)(ox), o2y = (fps_f2)(oy), o2z = (fps_f2)(oz);
 #pragma unroll
-        for (int s = 0; s < PPT; ++s) {
-            const float d = pcm_sqdist(px[s], py[s], pz[s], ox, oy, oz);
-            const float d2 = d < md[s] ? d : md[s];
-            md[s] = d2;
-            const bool g = d2 > best;
-            best = g ? d2 : best;
-            bs = g ? s : bs;
+        for (int k = 0; k < NP; ++k) {
+            // pcm_sqdist on two points at once: (a-b)*(a-b) for x, y, z summed left to right, every op rounded on its own
+            const fps_f2 dx = px[k] - o2x, dy = py[k] - o2y, dz = pz[k] - o2z;
+            fps_f2 d = dx * dx;
+            d = d + dy * dy;
+            d = d + dz * dz;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int s = 2 * k + h;
+                if (s >= PPT) break;
+                const float d2 = __builtin_fminf(d[h], md[s]);  // no NaNs here: same value as d < md ? d : md
+                md[s] = d2;
+                const bool g = d2 > best;
+                best = g ? d2 : best;
+                bs = g ? s : bs;
+            }
         }
         const bool valid = best >= 0.f;
-        // bs -> i: same closed form as slot_to_i, on a runtime slot
+        const uint32_t key = valid ? __float_as_uint(best) + 1u : 0u;  // d2 >= +0: unsigned order == float order; 0 = no candidate
+        // bs -> local index j: same closed form as slot_to_i, on a runtime slot
         int i;
         if (LOGQ == 0) {
             i = bs;
@@ -145,19 +205,65 @@ __global__ __launch_bounds__(T) void pcm_fps_reg_kernel(const float *__restrict_
             constexpr int Q = 1 << LOGQ;
             constexpr int RP = PPT / Q;
             const int cp = bs / RP, r = bs % RP;
-            const int c = LOGQ == 2 ? (((cp & 1) << 1) | (cp >> 1)) : cp;
-            i = r * Q + c;
+            i = r * Q + bitrev_n<LOGQ>(cp);
         }
         const uint32_t j = (uint32_t)(u + i * T);
-        const uint32_t bits = valid ? __float_as_uint(best) : 0u;
-        const uint32_t jw = fps_block_argmax<W>(bits, fps_prio(j, bs_mask, L), valid, slots, it, wave, lane, L);
-        if (LDS_XYZ) {
-            const float4 o = lxyz[jw];
-            ox = o.x, oy = o.y, oz = o.z;
-        } else {
-            ox = cloud[(size_t)jw * 3 + 0], oy = cloud[(size_t)jw * 3 + 1], oz = cloud[(size_t)jw * 3 + 2];
+        // ---- wave level: maximum, then its owner
+        const uint32_t m1 = fps_wave_max_fast(key);
+        unsigned long long own = __ballot(key == m1);
+        if (m1 != 0u && __popcll(own) > 1) {  // exact distance tie inside the wave: the reference's order decides
+            const uint32_t prio = (key == m1) ? fps_prio(j, bs_mask, L) : 0xFFFFFFFFu;
+            const uint32_t p1 = pcm_wave_min_u32(prio);
+            own = __ballot(prio == p1);
         }
-        if (u == 0) idx[start_m + it] = start_n + (int)jw;
+        const int buf = it & 1;  // double-buffered slots: one barrier per pick
+        if (lane == (int)__builtin_ctzll(own)) {
+            float bx = 0.f, by = 0.f, bz = 0.f;
+            if (TRACK) {
+#pragma unroll
+                for (int s = 0; s < PPT; ++s)
+                    if (s == bs) bx = px[s / 2][s % 2], by = py[s / 2][s % 2], bz = pz[s / 2][s % 2];
+            } else if (STAGE) {
+                const float4 o = lxyz[j];
+                bx = o.x, by = o.y, bz = o.z;
+            } else {
+                bx = cloud[(size_t)j * 3 + 0], by = cloud[(size_t)j * 3 + 1], bz = cloud[(size_t)j * 3 + 2];
+            }
+            keys[buf * WP + wave] = m1;
+            cand[buf * W + wave] = make_float4(__uint_as_float(j), bx, by, bz);
+        }
+        __syncthreads();
+        // ---- workgroup level: maximum of the W keys (broadcast reads), then the winning slot
+        uint32_t kw[WP];
+#pragma unroll
+        for (int w4 = 0; w4 < WP; w4 += 4) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(keys + buf * WP + w4);
+            kw[w4] = q.x, kw[w4 + 1] = q.y, kw[w4 + 2] = q.z, kw[w4 + 3] = q.w;
+        }
+        uint32_t gmax = kw[0];
+#pragma unroll
+        for (int w = 1; w < W; ++w) gmax = kw[w] > gmax ? kw[w] : gmax;
+        int wsel = 0, nmatch = 0;
+#pragma unroll
+        for (int w = W - 1; w >= 0; --w) {
+            const bool e = kw[w] == gmax;
+            wsel = e ? w : wsel;
+            nmatch += e ? 1 : 0;
+        }
+        // (fetching all W candidates together with the keys and selecting in registers was measured slower: 1381 vs 1234
+        //  clocks per pick at N = 1024 -- the extra broadcast reads cost more than the dependent one saves)
+        float4 o = cand[buf * W + wsel];
+        if (nmatch > 1) {  // exact tie across waves (wave-uniform: every lane read the same keys): smallest prio wins
+            uint32_t bestp = fps_prio(__float_as_uint(o.x), bs_mask, L);
+            for (int w = wsel + 1; w < W; ++w) {
+                if (kw[w] != gmax) continue;
+                const float4 c = cand[buf * W + w];
+                const uint32_t pw = fps_prio(__float_as_uint(c.x), bs_mask, L);
+                if (pw < bestp) bestp = pw, o = c;
+            }
+        }
+        ox = o.y, oy = o.z, oz = o.w;
+        if (u == 0) out[it] = start_n + (int)__float_as_uint(o.x);
     }
 }
 
@@ -215,7 +321,7 @@ template <int T, int PPT, int LOGQ, bool LDS_XYZ>
 int launch_reg(int b, const float *xyz, const int *offset, const int *new_offset, int *idx, int L, hipStream_t st)
 {
     constexpr int W = T / PCM_WAVE;
-    const size_t lds = ((2 * W * 8 + 15) / 16) * 16 + (LDS_XYZ ? (size_t)T * PPT * 16 : 0);
+    const size_t lds = (size_t)2 * ((W + 3) / 4 * 4) * 4 + (size_t)2 * W * 16 + ((LDS_XYZ && PPT > 4) ? (size_t)T * PPT * 16 : 0);
     auto k = pcm_fps_reg_kernel<T, PPT, LOGQ, LDS_XYZ>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
