@@ -271,7 +271,7 @@ def policy_kernels(t, wl, device, hidden=512):
 
         def drln_b():
             assert L.pcm_drln_backward_hip(R, E, 1, o_.data_ptr(), s_.data_ptr(), mu_.data_ptr(), rs_.data_ptr(), g1.data_ptr(), 0.1,
-                                           seed.data_ptr(), 1, dx_.data_ptr(), dy16.data_ptr(), part.data_ptr(), dgb.data_ptr(), st) == 0
+                                           seed.data_ptr(), 1, dx_.data_ptr(), dy16.data_ptr(), part.data_ptr(), dgb.data_ptr(), 0, st) == 0
 
         drln_f()
         t.add("pcm_drln_fwd_kernel<bf16,2>", timed_events(drln_f, 30), R * E * 14, "hbm", "LayerNorm(x + dropout(y)): 6 B read, 8 B written per element")

@@ -216,7 +216,7 @@ int pcm_graph_replace_memsets(void *graph, int *n_replaced);
  * (*seed, site, element) recomputed in backward; `seed` is a DEVICE int64 so hipGraph replays draw new
  * masks; p_drop = 0 disables dropout (seed may be NULL).  backward also reduces dgamma | dbeta | dysum (3,E)
  * from `partial` (pcm_drln_blocks(R) x 3 x E floats of scratch); dysum = column sums of dy, i.e. the bias
- * gradient of the projection that produced y. */
+ * gradient of the projection that produced y; dysum_bf16 (E, may be NULL) receives the same sums rounded to bf16. */
 int pcm_drln_blocks(long R);
 int pcm_drln_forward_hip(long R, int E, int y_is_bf16, const float *x, const void *y, const float *gamma,
                          const float *beta, float eps, float p_drop, const long *seed, unsigned site,
@@ -224,7 +224,7 @@ int pcm_drln_forward_hip(long R, int E, int y_is_bf16, const float *x, const voi
 int pcm_drln_backward_hip(long R, int E, int y_is_bf16, const float *dout, const float *s,
                           const float *mean, const float *rstd, const float *gamma, float p_drop,
                           const long *seed, unsigned site, float *dx, void *dy, float *partial,
-                          float *dgamma_dbeta, void *stream);
+                          float *dgamma_dbeta, void *dysum_bf16, void *stream);
 
 /* ---- fused feed-forward sub-layer  out = LayerNorm(x + dropout(W2 dropout(relu(W1 x + b1)) + b2)) ------------
  * replaces linear1 -> relu -> dropout -> linear2 -> dropout -> add -> norm of every transformer layer

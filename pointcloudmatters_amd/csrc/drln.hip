@@ -161,7 +161,7 @@ __global__ __launch_bounds__(kBlock) void pcm_drln_bwd_kernel(long R, const floa
 
 // out[e] = sum over blocks of partial[block][e] in fp64 (same scheme as the SA layer's reduction)
 __global__ __launch_bounds__(512) void pcm_drln_reduce_kernel(int nslots, int VH, const float *__restrict__ partial,
-                                                              float *__restrict__ out)
+                                                              float *__restrict__ out, __hip_bfloat16 *__restrict__ tail_bf16, int tail_from)
 {
     __shared__ double red[8][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -176,6 +176,8 @@ __global__ __launch_bounds__(512) void pcm_drln_reduce_kernel(int nslots, int VH
 #pragma unroll
         for (int w = 0; w < 8; ++w) t += red[w][lane];
         out[e] = (float)t;
+        // the column sums of dy are the bias gradient of a bf16 projection: emit them in bf16 too (saves a cast launch)
+        if (tail_bf16 && e >= tail_from) tail_bf16[e - tail_from] = __float2bfloat16((float)t);
     }
 }
 
@@ -215,7 +217,7 @@ extern "C" int pcm_drln_forward_hip(long R, int E, int y_is_bf16, const float *x
 
 extern "C" int pcm_drln_backward_hip(long R, int E, int y_is_bf16, const float *dout, const float *s, const float *mean,
                                      const float *rstd, const float *gamma, float p_drop, const long *seed, unsigned site,
-                                     float *dx, void *dy, float *partial, float *dgamma_dbeta, void *stream)
+                                     float *dx, void *dy, float *partial, float *dgamma_dbeta, void *dysum_bf16, void *stream)
 {
     if (R <= 0) return R == 0 ? PCM_OK : PCM_ERR_BAD_ARG;
     if (E % 256 != 0 || E > 1024 || E <= 0) return PCM_ERR_UNSUPPORTED;
@@ -231,6 +233,7 @@ extern "C" int pcm_drln_backward_hip(long R, int E, int y_is_bf16, const float *
         if (n == 1) PCM_B(float, 1); else if (n == 2) PCM_B(float, 2); else if (n == 3) PCM_B(float, 3); else PCM_B(float, 4);
     }
 #undef PCM_B
-    hipLaunchKernelGGL(pcm_drln_reduce_kernel, dim3((3 * E + 63) / 64), dim3(512), 0, st, grid, 3 * E, partial, dgamma_dbeta);
+    hipLaunchKernelGGL(pcm_drln_reduce_kernel, dim3((3 * E + 63) / 64), dim3(512), 0, st, grid, 3 * E, partial, dgamma_dbeta,
+                       (__hip_bfloat16 *)dysum_bf16, 2 * E);
     return PCM_LAUNCH_STATUS();
 }

@@ -93,8 +93,8 @@ def _drln_forward(x2, y2, gamma, beta, eps, p_drop, seed, site):
     return out, s, mean, rstd
 
 
-def _drln_backward(dout, s, mean, rstd, gamma, ydtype, p_drop, seed, site):
-    """-> dx (R,E) fp32, dy (R,E) in ydtype, sums (3,E) fp32 = dgamma | dbeta | column sums of dy."""
+def _drln_backward(dout, s, mean, rstd, gamma, ydtype, p_drop, seed, site, dysum_bf16=False):
+    """-> dx (R,E) fp32, dy (R,E) in ydtype, sums (3,E) fp32 = dgamma | dbeta | column sums of dy (+ those sums in bf16)."""
     L = _lib.load()
     R, E = s.shape
     dev = s.device
@@ -106,11 +106,14 @@ def _drln_backward(dout, s, mean, rstd, gamma, ydtype, p_drop, seed, site):
         dy = torch.empty(R, E, dtype=ydtype, device=dev)
         partial = torch.empty(L.pcm_drln_blocks(R) * 3 * E, dtype=torch.float32, device=dev)
         sums = torch.empty(3, E, dtype=torch.float32, device=dev)
+        db16 = torch.empty(E, dtype=torch.bfloat16, device=dev) if dysum_bf16 else None
         rc = L.pcm_drln_backward_hip(R, E, 1 if ydtype == torch.bfloat16 else 0, d2.data_ptr(), s.data_ptr(), mean.data_ptr(),
                                      rstd.data_ptr(), gamma.data_ptr(), p_drop, seed.data_ptr() if seed is not None else 0, site,
                                      dx.data_ptr(), dy.data_ptr(), partial.data_ptr(), sums.data_ptr(),
-                                     torch.cuda.current_stream().cuda_stream)
+                                     db16.data_ptr() if db16 is not None else 0, torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "pcm_drln_backward_hip")
+    if dysum_bf16:
+        return dx, dy, sums, db16
     return dx, dy, sums
 
 
@@ -146,13 +149,15 @@ class _ProjDRLN(Function):
 
         a2, wc, s, mean, rstd, gamma = ctx.saved_tensors
         shape, ashape, adt, wdt, bdt, ydt, p_drop, seed, site = ctx.meta
-        dx, dy, sums = _drln_backward(dout, s, mean, rstd, gamma, ydt, p_drop, seed, site)
+        want16 = bdt == torch.bfloat16
+        res = _drln_backward(dout, s, mean, rstd, gamma, ydt, p_drop, seed, site, dysum_bf16=want16)
+        dx, dy, sums = res[:3]
         with torch.autocast("cuda", enabled=False):
             da = (dy @ wc).view(ashape)
             if da.dtype != adt:
                 da = da.to(adt)
             dw = weight_grad(dy, a2, wdt)
-            db = sums[2].to(bdt)
+            db = res[3] if want16 else sums[2].to(bdt)
         return da, dw, db, dx.view(shape), sums[0], sums[1], None, None, None, None
 
 

@@ -32,6 +32,8 @@ def weight_grad(go, x, out_dtype, out=None):
     rows, m = go.shape
     k = x.shape[1]
     if rows < MIN_ROWS or m * k > 1024 * 1024:
+        if out is not None and out.dtype == go.dtype and out.is_contiguous():
+            return torch.mm(go.t(), x, out=out)  # straight into the (slice of the) packed gradient: no copy kernel
         dw = go.t() @ x
         if out is not None:
             return out.copy_(dw)

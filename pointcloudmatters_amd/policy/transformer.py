@@ -292,12 +292,14 @@ class TransformerDecoder(nn.Module):
         for layer, kv in zip(layers, kvs):
             out = layer(out, memory, memory_pos, memory_key_padding_mask=memory_key_padding_mask, query_pos=query_pos, kv=kv)
             if self.return_intermediate:
-                inter.append(self.norm(out))
+                inter.append(out)
         if self.return_intermediate:
             if self.first_only != "keep":
-                return inter[0].unsqueeze(0)
-            # the reference pops the last entry and re-appends norm(out): same tensor
-            return torch.stack(inter)
+                return self.norm(inter[0]).unsqueeze(0)
+            # stack(norm(out_l)) == norm(stack(out_l)): LayerNorm is row-wise with shared parameters, so the L norms (and
+            # their 3 L backward kernels) are ONE launch each way on the stacked tensor.  (The reference pops the last
+            # entry and re-appends norm(out): same tensor.)
+            return self.norm(torch.stack(inter))
         if self.norm is not None:
             out = self.norm(out)
         return out.unsqueeze(0)

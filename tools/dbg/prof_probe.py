@@ -26,5 +26,5 @@ for e in ka:
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
 print("total device us", tot, "events", len(rows), "launches", sum(r[1] for r in rows))
-for r in rows[:25]:
-    print("%9.1f us %5d  %s  %s" % (r[0], r[1], r[2][:90], r[3]))
+for r in rows[:70]:
+    print("%9.1f us %5d  %s  %s" % (r[0], r[1], r[2][:130], r[3]))
