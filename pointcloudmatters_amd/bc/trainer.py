@@ -7,9 +7,12 @@ and ``configure_optimizers`` (:347-367) under ``configs/trainer/ddp.yaml``:
     loss = policy(batch)["loss"] / accumulate_grad_batches ; backward            (every micro-batch)
     every `accumulate` micro-batches: clip_grad_norm_(0.5) ; AdamW.step ; OneCycleLR.step ; zero_grad
 
-Data parallel = one process per GPU, ``torch.distributed`` over RCCL (backend "nccl" on ROCm),
-DistributedDataParallel with gradient buckets overlapped with backward, ``no_sync()`` on the
-non-stepping micro-batches and optional SyncBatchNorm (``sync_batchnorm: true`` in ddp.yaml:9).
+Data parallel = one process per GPU, ``torch.distributed`` over RCCL (backend "nccl" on ROCm).  The reference gets
+"gradient all-reduce overlapped with backward" from DistributedDataParallel's bucket hooks (mode="eager" keeps exactly
+that).  The flat / graph / hybrid modes own their gradients in ONE flat buffer laid out in backward order, run backward
+in STAGES (policy.backward_stages(), policy/staging.py) and start the all-reduce of a stage's contiguous gradient slab
+on RCCL's stream while the next stage still computes -- with hipGraph replay each stage is its own graph, so the
+collectives are launched between replays and never captured.
 Metrics stay on the device and are only read every ``log_every_n_steps`` (ddp.yaml:15) -- the
 per-step ``.item()`` would serialise host and GPU.
 """
@@ -75,19 +78,31 @@ def freeze_unused_parameters(policy):
     return frozen
 
 
+class _Stage:
+    """One backward stage: `lower` = name of the staging.cut that bounds it from below (None: runs to the inputs),
+    `indices` = its parameters in the flat optimizer, `slab` = [start, end) floats of the flat gradient exchanged when
+    the stage is done."""
+
+    def __init__(self, lower, indices, slab):
+        self.lower, self.indices, self.slab = lower, indices, slab
+        self.index_set = set(indices)
+
+
 class BCTrainer:
     """mode:
       "eager"  torch.optim.AdamW + OneCycleLR, DistributedDataParallel (+ SyncBatchNorm) when
                distributed -- the literal Lightning recipe; also the CPU path.
-      "flat"   FlatAdamW (csrc/optim.hip) + host OneCycle; data parallel = ONE all-reduce of the flat
-               gradient buffer per optimizer step (no DDP wrapper, no bucket hooks).
-      "graph"  "flat" with forward+backward of a micro-batch captured ONCE into a hipGraph and
+      "flat"   FlatAdamW (csrc/optim.hip) + host OneCycle; data parallel = the flat gradient buffer all-reduced in
+               backward-ordered slabs that overlap the rest of backward (no DDP wrapper, no bucket hooks).
+      "graph"  "flat" with forward+backward of a micro-batch captured ONCE into hipGraphs (one per backward stage) and
                replayed (the step is launch-bound in eager mode: ~2400 launches); needs static
-               shapes (equal-size clouds) and per-rank BatchNorm statistics.
+               shapes (equal-size clouds); BatchNorm statistics are per rank.
+      "hybrid" eager tokenizer (ragged clouds, synchronised BatchNorm) + hipGraphs for everything behind the token matrix.
+    `staged`: None = backward stages when data parallel (the exchange needs them); True forces them on one GPU (tests).
     """
 
     def __init__(self, policy, total_steps, optim=None, precision="fp32", device=None, distributed=False,
-                 sync_batchnorm=True, bucket_cap_mb=32, log_every_n_steps=50, mode="eager", flat_optimizer_cls=None):
+                 sync_batchnorm=True, bucket_cap_mb=32, log_every_n_steps=50, mode="eager", flat_optimizer_cls=None, staged=None):
         o = dict(ACT_OPTIM)
         if optim:
             o.update(optim)
@@ -108,24 +123,50 @@ class BCTrainer:
         self.distributed = distributed and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         self.world = dist.get_world_size() if self.distributed else 1
         total_steps = max(int(total_steps), int(2 / o["pct_start"]) + 1)
-        if self.distributed and sync_batchnorm and mode != "graph":
-            policy = nn.SyncBatchNorm.convert_sync_batchnorm(policy)
-            self.policy = self.module = policy
+        # ---- synchronised BatchNorm (configs/trainer/ddp.yaml:9).  eager: torch's SyncBatchNorm.  flat / hybrid: the
+        # BatchNorm layers the fused kernels own exchange their statistics themselves (policy/sync_bn.py), every other
+        # BatchNorm module becomes a torch SyncBatchNorm -- all of them run OUTSIDE the captured graphs in hybrid mode.
+        # graph mode captures the whole step incl. the tokenizer: per-rank statistics (bench.py uses hybrid for N > 1).
         self.sync_batchnorm = bool(self.distributed and sync_batchnorm and mode != "graph")
+        if self.sync_batchnorm:
+            if mode == "eager":
+                policy = nn.SyncBatchNorm.convert_sync_batchnorm(policy)
+                self.policy = self.module = policy
+            else:
+                from ..policy.sync_bn import enable_sync_batchnorm
+
+                enable_sync_batchnorm(policy)
         # fused transformer tail ops (csrc/drln.hip, ffn.hip) need a device-resident dropout seed: flat / graph modes
         self._fused_ctx = None
         if mode != "eager" and self.device.type == "cuda":
             from ..policy.fused_ops import FusedContext
 
             self._fused_ctx = FusedContext(self.device)
-        params = [p for p in self.policy.parameters() if p.requires_grad]
+        trainable = [p for p in self.policy.parameters() if p.requires_grad]
+        # ---- backward stages: parameters ordered by when their gradient is complete (latest-used first)
+        want_stages = (self.distributed and mode != "eager") if staged is None else bool(staged)
+        stage_defs = [(None, trainable)]
+        if want_stages and mode != "eager" and hasattr(self.policy, "backward_stages"):
+            seen, stage_defs = set(), []
+            for lower, ps in self.policy.backward_stages():
+                ps = [p for p in ps if p.requires_grad and id(p) not in seen]
+                seen.update(id(p) for p in ps)
+                stage_defs.append((lower, ps))
+            assert all(id(p) in seen for p in trainable), "backward_stages() must cover every trainable parameter"
+            if mode == "hybrid":
+                tok = {id(p) for p in self.policy.tokenizer_parameters() if p.requires_grad}
+                assert {id(p) for p in stage_defs[-1][1]} == tok, "hybrid mode: the last backward stage must be exactly the tokenizer"
+        ordered = [p for _, ps in stage_defs for p in ps]
         betas = tuple(o.get("betas", (0.9, 0.999)))
+        params = ordered
         if o.get("filter_bias_and_bn", False) and o["weight_decay"]:
             # build_optimizer_v2 -> param_groups_weight_decay (src/utils/optimizer.py:152-170, 296-300)
-            no_decay = [p for n, p in self.policy.named_parameters() if p.requires_grad and (p.ndim <= 1 or n.endswith(".bias"))]
-            ids = {id(p) for p in no_decay}
-            decay = [p for p in params if id(p) not in ids]
-            params = [{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": o["weight_decay"]}]
+            nd_ids = {id(p) for n, p in self.policy.named_parameters() if p.requires_grad and (p.ndim <= 1 or n.endswith(".bias"))}
+            decay = [p for p in ordered if id(p) not in nd_ids]
+            no_decay = [p for p in ordered if id(p) in nd_ids]
+            # decayed group first and in backward order: its stage slabs are what the exchange overlaps; the small
+            # undecayed group (biases, norm weights) rides with the last slab
+            params = [{"params": decay, "weight_decay": o["weight_decay"]}, {"params": no_decay, "weight_decay": 0.0}]
         if mode == "eager":
             if self.distributed:
                 ids = [self.device.index] if self.device.type == "cuda" else None
@@ -139,6 +180,7 @@ class BCTrainer:
                 self.optimizer, max_lr=o["lr"], total_steps=total_steps, pct_start=o["pct_start"],
                 anneal_strategy="cos", div_factor=o["div_factor"], final_div_factor=o["final_div_factor"],
             )
+            self._stages = []
         else:
             from .schedule import OneCycle
 
@@ -158,15 +200,73 @@ class BCTrainer:
                 index = {id(p): k for k, p in enumerate(self.optimizer.params)}
                 self._shadow_names = [(n, p, index[id(p)]) for n, p in self.policy.named_parameters()
                                       if id(p) in index and self.optimizer.shadow[index[id(p)]] is not None]
+            self._stages = self._plan_stages(stage_defs)
+            if self.distributed:  # DDP would broadcast rank 0's weights and buffers at construction: same here
+                with torch.no_grad():
+                    flat_p = getattr(self.optimizer, "flat_p", None)
+                    if flat_p is not None:
+                        dist.broadcast(flat_p, src=0)
+                        if getattr(self.optimizer, "flat_p_bf16", None) is not None:
+                            self.optimizer.flat_p_bf16.copy_(flat_p)
+                    else:
+                        for p in self.optimizer.params:
+                            dist.broadcast(p.data, src=0)
+                    for b in self.policy.buffers():
+                        dist.broadcast(b, src=0)
+        self.exchange_description = (
+            "flat gradient all-reduced over RCCL in %d backward-ordered slab(s) (%s MB), each launched when its stage's backward is "
+            "done and overlapping the following stages" % (len(self._stages), " + ".join("%.0f" % ((s.slab[1] - s.slab[0]) * 4 / 1e6)
+                                                                                      for s in self._stages))
+            if mode != "eager" else "DistributedDataParallel bucket hooks (%d MB buckets)" % bucket_cap_mb)
         self.micro = 0
         self.optimizer_steps = 0
         self._sums = None
         self._count = 0
-        self._graph = None
+        self._graph = None       # graph mode: one graph per backward stage; hybrid mode: graphs of the captured stages
         self._graph_acc = None
         self._static_batch = None
         self._static_stats = None
         self._static_sig = None
+        self._works = []
+        self._stepping = True
+
+    # ------------------------------------------------------------------------------------------ stages / exchange
+    def _plan_stages(self, stage_defs):
+        opt = self.optimizer
+        index = {id(p): k for k, p in enumerate(opt.params)}
+        offsets = getattr(opt, "offsets", None)
+        if offsets is None:  # host stand-in: parameters packed back to back
+            offsets, o = [], 0
+            for p in opt.params:
+                offsets.append(o)
+                o += p.numel()
+        numel = getattr(opt, "numel", None) or int(opt.flat_g.numel())
+        idxs = [sorted(index[id(p)] for p in ps) for _, ps in stage_defs]
+        # a stage's slab starts at its first parameter (stages are contiguous and ascending inside the leading group)
+        starts = [offsets[ix[0]] if ix else None for ix in idxs]
+        stages, cursor = [], 0
+        for si, (lower, _) in enumerate(stage_defs):
+            start = cursor
+            nxt = next((s for s in starts[si + 1:] if s is not None and s >= start), None)
+            end = numel if (si == len(stage_defs) - 1 or nxt is None) else nxt
+            stages.append(_Stage(lower, idxs[si], (start, end)))
+            cursor = end
+        stages[-1].slab = (stages[-1].slab[0], numel)
+        return stages
+
+    def _exchange(self, si):
+        """Stage `si` of the stepping micro-batch is done: start the all-reduce of its gradient slab (asynchronous: it runs
+        on the process group's own stream behind everything enqueued so far and beside whatever is enqueued next)."""
+        if not (self.distributed and self._stepping):
+            return
+        a, b = self._stages[si].slab
+        if b > a:
+            self._works.append(dist.all_reduce(self.optimizer.flat_g[a:b], async_op=True))  # SUM; 1/world is applied by Adam
+
+    def _finish_exchange(self):
+        for w in self._works:
+            w.wait()
+        self._works = []
 
     # ------------------------------------------------------------------------------------------
     def _autocast(self):
@@ -174,7 +274,6 @@ class BCTrainer:
             return torch.autocast(device_type=self.device.type, dtype=torch.bfloat16)
         return contextlib.nullcontext()
 
-    # ---- hybrid mode: eager tokenizer (ragged point clouds) + ONE hipGraph for everything behind the token matrix ------
     def _shadow_repl(self, only=None):
         shadows = getattr(self, "_shadow_names", None)
         if not shadows:
@@ -188,114 +287,89 @@ class BCTrainer:
             return torch.func.functional_call(self.policy, repl, (batch,), kwargs)
         return self.module(batch, **kwargs)
 
-    def _hybrid_setup(self, batch):
-        """Split the parameters by stage, build the static inputs of the captured half and capture it."""
-        from ..policy import fused_ops
-        from .synthetic import clone_batch
+    @staticmethod
+    def _stats_of(out):
+        loss = out["loss"]
+        return torch.stack([loss.detach().float(), out.get("action_loss", loss).detach().float(),
+                            torch.as_tensor(out.get("kl_loss", 0.0), device=loss.device).detach().float()])
+
+    def _segments(self, make_out, first, stages, leaf=None):
+        """Generator over the backward stages of one micro-batch.  The first next() runs the forward pass (make_out) and
+        stage 0's backward; every further next() runs one more stage.  Yields (stage index, stats).  `leaf`: a leaf tensor
+        below the last stage whose gradient is wanted as well (hybrid: the static token matrix)."""
+        from ..policy import staging
 
         opt = self.optimizer
-        index = {id(p): k for k, p in enumerate(opt.params)}
-        tok = sorted(index[id(p)] for p in self.policy.tokenizer_parameters() if id(p) in index)
-        tok_set = set(tok)
-        self._subset_a, self._subset_b = tok, [k for k in range(len(opt.params)) if k not in tok_set]
-        self._subset_a_set = tok_set
-        buffers = {n: b.clone() for n, b in self.policy.named_buffers()}  # nothing below may count as training
-        with fused_ops.activate(self._fused_ctx), self._autocast(), torch.no_grad():
-            ragged, rest = self.policy.hybrid_split(clone_batch(batch))
-            boundary = tuple(self._call_policy(ragged, stage="tokenize"))  # shapes / dtypes of the boundary
-        self._static_sig = self._signature(rest)
-        self._static_batch = self._clone_static(rest)
-        # boundary[0] carries the gradient back to the tokenizer; the others (position embedding) are inputs only
-        self._static_tokens = boundary[0].detach().clone().requires_grad_(True)
-        self._static_extra = tuple(t.detach().clone() for t in boundary[1:])
-        self._static_dtokens = torch.zeros_like(self._static_tokens)
-
-        def stage_b(first=True):
-            with fused_ops.activate(self._fused_ctx), self._autocast():
-                data = self.policy.hybrid_merge(clone_batch(self._static_batch), (self._static_tokens,) + self._static_extra)
-                out = self._call_policy(data)
-            loss = out["loss"]
-            self._static_tokens.grad = None
-            (loss / self.accumulate).backward()
-            self._static_dtokens.copy_(self._static_tokens.grad)
-            opt.collect(first=first, subset=self._subset_b)
-            opt_stats = torch.stack([loss.detach().float(), out.get("action_loss", loss).detach().float(),
-                                     torch.as_tensor(out.get("kl_loss", 0.0), device=loss.device).detach().float()])
-            return opt_stats
-
-        cur = torch.cuda.current_stream()
-        side = torch.cuda.Stream()
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                stage_b()
-        cur.wait_stream(side)
-        torch.cuda.synchronize()
-        with torch.no_grad():
-            for n, b in self.policy.named_buffers():
-                b.copy_(buffers[n])
-        def reset():
-            for k in range(len(opt.params)):
-                opt._stash[k] = None
-                opt.params[k].grad = None
-
-        from .._graphs import captured
-
-        self._graph, self._static_stats = captured(lambda: stage_b(first=True))
-        reset()
-        self._graph_acc = None
-        if self.accumulate > 1:  # later micro-batches of an accumulation window ADD their gradients
-            self._graph_acc, self._static_stats_acc = captured(lambda: stage_b(first=False))
-            reset()
-
-    def _hybrid_step(self, batch):
-        from ..policy import fused_ops
-
-        if self._graph is None:
-            self._hybrid_setup(batch)
-        ragged, rest = self.policy.hybrid_split(batch)
-        if self._signature(rest) != self._static_sig:
-            raise ValueError("hybrid mode needs a fixed batch size / action layout (only the point clouds may be ragged)")
-        with fused_ops.activate(self._fused_ctx), self._autocast():
-            boundary = tuple(self._call_policy(ragged, only=self._subset_a_set, stage="tokenize"))  # eager: shapes follow the clouds
-        tokens = boundary[0]
-        with torch.no_grad():
-            self._static_tokens.copy_(tokens)
-            for dst, src in zip(self._static_extra, boundary[1:]):
-                dst.copy_(src)
-            self._copy_into(self._static_batch, rest)
-        first = self.micro % self.accumulate == 0
-        (self._graph if first else self._graph_acc).replay()
-        tokens.backward(self._static_dtokens)
-        self.optimizer.collect(first=first, subset=self._subset_a)
-        return (self._static_stats if first else self._static_stats_acc).clone()
+        collect = getattr(opt, "collect_mode", False)
+        if len(stages) == 1:
+            out = make_out()
+            (out["loss"] / self.accumulate).backward()
+            if collect:
+                opt.collect(first=first, subset=None if len(stages[0].indices) == len(opt.params) else stages[0].indices)
+            yield 0, self._stats_of(out)
+            return
+        with staging.record() as rec:
+            out = make_out()
+        stats = self._stats_of(out)
+        roots, grads = [out["loss"] / self.accumulate], [None]
+        for si, st in enumerate(stages):
+            inputs = rec.requested(st.lower) + [opt.params[k] for k in st.indices]
+            last = si == len(stages) - 1
+            if last and st.lower is None and leaf is not None:
+                inputs = inputs + [leaf]
+            if roots:
+                torch.autograd.backward(roots, grads, inputs=inputs)
+            if collect:
+                opt.collect(first=first, subset=st.indices)
+            if st.lower is not None:
+                roots = rec.roots(st.lower)
+                grads = [t.grad for t in roots]
+                for t in roots:
+                    t.grad = None
+                if last and leaf is not None and roots:  # the short way from the last cut down to the leaf, same segment
+                    torch.autograd.backward(roots, grads, inputs=[leaf])
+            yield si, stats
 
     def _forward_backward(self, batch, first=None):
-        """`first`: is this the first micro-batch of an accumulation window (gradients overwrite the flat buffer) or a
-        later one (they add)?  Must be passed explicitly when capturing: the choice is baked into the hipGraph."""
+        """One micro-batch, eagerly: forward, staged backward, gradient hand-off; exchanges every finished stage."""
         from ..policy import fused_ops
 
         if first is None:
             first = self.micro % self.accumulate == 0
 
-        shadows = getattr(self, "_shadow_names", None)
-        with fused_ops.activate(self._fused_ctx), self._autocast():
-            if shadows:
-                opt = self.optimizer
-                repl = {n: _ShadowParam.apply(p, opt.shadow[k], opt, k) for n, p, k in shadows}
-                out = torch.func.functional_call(self.policy, repl, (batch,))
-            else:
-                out = self.module(batch)
-        loss = out["loss"]
-        (loss / self.accumulate).backward()
-        if getattr(self.optimizer, "collect_mode", False):
-            self.optimizer.collect(first=first)
-        aux1 = out.get("action_loss", loss)
-        aux2 = out.get("kl_loss", 0.0)
-        return torch.stack([loss.detach().float(), aux1.detach().float(),
-                            torch.as_tensor(aux2, device=loss.device).detach().float()])
+        def make_out():
+            with fused_ops.activate(self._fused_ctx), self._autocast():
+                return self._call_policy(batch)
 
-    # ---- hipGraph capture of one micro-batch (forward + backward) -------------------------------
+        if self.mode == "eager":
+            out = make_out()
+            (out["loss"] / self.accumulate).backward()
+            return self._stats_of(out)
+        stats = None
+        for si, stats in self._segments(make_out, first, self._stages):
+            self._exchange(si)
+        return stats
+
+    # ---- hipGraph capture helpers ---------------------------------------------------------------
+    def _capture_segments(self, make_gen, nseg):
+        """Capture the `nseg` segments of a generator into one hipGraph each (shared memory pool: the later graphs use
+        what the earlier ones saved for backward).  Returns (graphs, stats tensor)."""
+        from .._graphs import finalize, new_graph
+
+        gen = make_gen()
+        graphs, stats, pool = [], None, None
+        for _ in range(nseg):
+            g = new_graph()
+            kw = {} if pool is None else {"pool": pool}
+            with torch.cuda.graph(g, capture_error_mode="thread_local", **kw):
+                _, stats = next(gen)
+            finalize(g)  # memset nodes -> kernel nodes (see _graphs.py), then instantiate
+            pool = g.pool()
+            graphs.append(g)
+        for _ in gen:  # nothing left to run: lets the generator finish
+            pass
+        return graphs, stats
+
     @staticmethod
     def _signature(batch, prefix=()):
         sig = []
@@ -330,36 +404,137 @@ class BCTrainer:
             elif torch.is_tensor(v) and static[k] is not v:
                 static[k].copy_(v, non_blocking=True)
 
-    def _capture(self, batch):
-        from .synthetic import clone_batch
+    def _reset_grads(self):
+        opt = self.optimizer
+        for k in range(len(opt.params)):
+            if hasattr(opt, "_stash"):
+                opt._stash[k] = None
+            if getattr(opt, "collect_mode", False):
+                opt.params[k].grad = None
 
-        self._static_sig = self._signature(batch)
-        self._static_batch = self._clone_static(batch)
+    def _warm_up(self, gen):
+        """Three un-captured runs off the capture stream (lazy inits, GEMM heuristics); BatchNorm buffers are restored:
+        the warm-up must not count as training."""
         buffers = {n: b.clone() for n, b in self.policy.named_buffers()}
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
-        with torch.cuda.stream(side):  # warm-up off the capture stream: lazy inits, GEMM heuristics
+        with torch.cuda.stream(side):
             for _ in range(3):
-                self._forward_backward(clone_batch(self._static_batch))
+                for _ in gen(True):
+                    pass
         cur.wait_stream(side)
         torch.cuda.synchronize()
-        with torch.no_grad():  # the warm-up must not count as training: restore BN statistics
+        with torch.no_grad():
             for n, b in self.policy.named_buffers():
                 b.copy_(buffers[n])
-        self.optimizer.zero_grad()
-        from .._graphs import captured
 
-        # (thread_local error mode: RCCL's watchdog / other host threads may touch the HIP API while we capture)
-        self._graph, self._static_stats = captured(lambda: self._forward_backward(clone_batch(self._static_batch), first=True))
+    # ---- graph mode: the whole micro-batch, one hipGraph per backward stage -------------------------
+    def _capture(self, batch):
+        from ..policy import fused_ops
+        from .synthetic import clone_batch
+
+        self._static_sig = self._signature(batch)
+        self._static_batch = self._clone_static(batch)
+        stages = self._stages
+
+        def gen(first):
+            def make_out():
+                with fused_ops.activate(self._fused_ctx), self._autocast():
+                    return self._call_policy(clone_batch(self._static_batch))
+
+            return self._segments(make_out, first, stages)
+
+        self._warm_up(gen)
+        self.optimizer.zero_grad()
+        self._reset_grads()
+        self._graph, self._static_stats = self._capture_segments(lambda: gen(True), len(stages))
         self._graph_acc = None
         if self.accumulate > 1 and getattr(self.optimizer, "collect_mode", False):
             # bf16 hand-off: "overwrite" vs "add into" the flat gradient buffer is decided in Python, i.e. at capture
-            # time -- the later micro-batches of an accumulation window need their own graph (fp32 mode accumulates
-            # through the .grad views and zeroes the buffer outside the graph, one graph serves both)
-            self._graph_acc, self._static_stats_acc = captured(
-                lambda: self._forward_backward(clone_batch(self._static_batch), first=False))
+            # time -- the later micro-batches of an accumulation window need their own graphs (fp32 mode accumulates
+            # through the .grad views and zeroes the buffer outside the graph, one set serves both)
+            self._reset_grads()
+            self._graph_acc, self._static_stats_acc = self._capture_segments(lambda: gen(False), len(stages))
         self.optimizer.zero_grad()
+        self._reset_grads()
+
+    # ---- hybrid mode: eager tokenizer (ragged point clouds) + hipGraphs for everything behind the token matrix ------
+    def _hybrid_setup(self, batch):
+        """Split the parameters by stage, build the static inputs of the captured half and capture it."""
+        from ..policy import fused_ops
+        from .synthetic import clone_batch
+
+        opt = self.optimizer
+        index = {id(p): k for k, p in enumerate(opt.params)}
+        tok = sorted(index[id(p)] for p in self.policy.tokenizer_parameters() if id(p) in index)
+        tok_set = set(tok)
+        self._subset_a, self._subset_a_set = tok, tok_set
+        if len(self._stages) > 1:
+            assert self._stages[-1].index_set == tok_set  # the last stage is the tokenizer (checked in __init__)
+            self._stages_b = self._stages[:-1]
+        else:
+            self._stages_b = [_Stage(None, [k for k in range(len(opt.params)) if k not in tok_set], self._stages[0].slab)]
+        with fused_ops.activate(self._fused_ctx), self._autocast(), torch.no_grad():
+            ragged, rest = self.policy.hybrid_split(clone_batch(batch))
+            buffers = {n: b.clone() for n, b in self.policy.named_buffers()}  # this probe must not count as training
+            boundary = tuple(self._call_policy(ragged, stage="tokenize"))  # shapes / dtypes of the boundary
+            for n, b in self.policy.named_buffers():
+                b.copy_(buffers[n])
+        self._static_sig = self._signature(rest)
+        self._static_batch = self._clone_static(rest)
+        # boundary[0] carries the gradient back to the tokenizer; the others (position embedding) are inputs only
+        self._static_tokens = boundary[0].detach().clone().requires_grad_(True)
+        self._static_extra = tuple(t.detach().clone() for t in boundary[1:])
+        self._static_dtokens = torch.zeros_like(self._static_tokens)
+        stages_b = self._stages_b
+
+        def gen(first):
+            def make_out():
+                with fused_ops.activate(self._fused_ctx), self._autocast():
+                    data = self.policy.hybrid_merge(clone_batch(self._static_batch), (self._static_tokens,) + self._static_extra)
+                    return self._call_policy(data)
+
+            self._static_tokens.grad = None
+            for si, stats in self._segments(make_out, first, stages_b, leaf=self._static_tokens):
+                if si == len(stages_b) - 1:  # the captured half ends at the static token matrix: hand its gradient over
+                    self._static_dtokens.copy_(self._static_tokens.grad)
+                yield si, stats
+
+        self._warm_up(gen)
+        self._reset_grads()
+        self._graph, self._static_stats = self._capture_segments(lambda: gen(True), len(stages_b))
+        self._reset_grads()
+        self._graph_acc = None
+        if self.accumulate > 1:  # later micro-batches of an accumulation window ADD their gradients
+            self._graph_acc, self._static_stats_acc = self._capture_segments(lambda: gen(False), len(stages_b))
+            self._reset_grads()
+
+    def _hybrid_step(self, batch):
+        from ..policy import fused_ops
+
+        if self._graph is None:
+            self._hybrid_setup(batch)
+        ragged, rest = self.policy.hybrid_split(batch)
+        if self._signature(rest) != self._static_sig:
+            raise ValueError("hybrid mode needs a fixed batch size / action layout (only the point clouds may be ragged)")
+        with fused_ops.activate(self._fused_ctx), self._autocast():
+            boundary = tuple(self._call_policy(ragged, only=self._subset_a_set, stage="tokenize"))  # eager: shapes follow the clouds
+        tokens = boundary[0]
+        with torch.no_grad():
+            self._static_tokens.copy_(tokens)
+            for dst, src in zip(self._static_extra, boundary[1:]):
+                dst.copy_(src)
+            self._copy_into(self._static_batch, rest)
+        first = self.micro % self.accumulate == 0
+        for si, g in enumerate(self._graph if first else self._graph_acc):
+            g.replay()
+            if len(self._stages) > 1:
+                self._exchange(si)
+        tokens.backward(self._static_dtokens)
+        self.optimizer.collect(first=first, subset=self._subset_a)
+        self._exchange(len(self._stages) - 1)
+        return (self._static_stats if first else self._static_stats_acc).clone()
 
     def prefetch_sampling(self, next_batch):
         """Hand the NEXT micro-batch over early (what a data loader's prefetch does): its FPS + kNN indices -- functions of
@@ -386,7 +561,7 @@ class BCTrainer:
         if self._fused_ctx is not None:
             self._fused_ctx.set_step(self.micro)
         first = self.micro % self.accumulate == 0
-        stepping = (self.micro + 1) % self.accumulate == 0
+        stepping = self._stepping = (self.micro + 1) % self.accumulate == 0
         if self.mode == "eager":
             sync_ctx = contextlib.nullcontext()
             if self.distributed and not stepping:
@@ -426,19 +601,17 @@ class BCTrainer:
                 if first:
                     self.optimizer.zero_grad()
                 self._copy_into(self._static_batch, batch)
-                if first or self._graph_acc is None:
-                    self._graph.replay()
-                    stats = self._static_stats.clone()
-                else:
-                    self._graph_acc.replay()
-                    stats = self._static_stats_acc.clone()
+                use_acc = not (first or self._graph_acc is None)
+                for si, g in enumerate(self._graph_acc if use_acc else self._graph):
+                    g.replay()
+                    self._exchange(si)
+                stats = (self._static_stats_acc if use_acc else self._static_stats).clone()
             else:
                 if first:
                     self.optimizer.zero_grad()
                 stats = self._forward_backward(batch)
             if stepping:
-                if self.distributed:
-                    dist.all_reduce(self.optimizer.flat_g)  # SUM; the 1/world is applied in the Adam kernel
+                self._finish_exchange()
                 self.optimizer.step()
                 self.optimizer_steps += 1
         self.micro += 1

@@ -239,6 +239,9 @@ class ACTPCD(nn.Module):
             pcd_tokens, pcd_pos = data_dict["pcd_embed"]
         else:
             pcd_tokens, pcd_pos = self.forward_pcd_embed(data_dict["pcds"])
+        from . import staging
+
+        pcd_tokens = staging.cut("tokens", pcd_tokens)  # the tokenizer's backward is the last stage
         proprio_input = self.input_proj_robot_state(qpos).unsqueeze(0)
         if goal_cond is not None:
             proprio_input = torch.cat([proprio_input, goal_cond.unsqueeze(0)], dim=0)
@@ -259,13 +262,29 @@ class ACTPCD(nn.Module):
         return data_dict
 
     def forward_loss(self, data_dict):
-        total_kld = self.klloss(data_dict["mu"], data_dict["logvar"])
+        from . import staging
+
+        # produced by the CVAE encoder (the stage under the "transformer.encoder" boundary), consumed here at the top
+        mu, logvar = staging.cut("transformer.encoder", data_dict["mu"], data_dict["logvar"], consumed_above="transformer.decoder")
+        total_kld = self.klloss(mu, logvar)
         action_loss = self.action_loss(data_dict["a_hat"].float(), data_dict["actions"])
         action_loss = (action_loss * ~data_dict["is_pad"].unsqueeze(-1)).mean()
         data_dict["action_loss"] = action_loss
         data_dict["kl_loss"] = total_kld
         data_dict["loss"] = action_loss + total_kld * self.kl_weight
         return data_dict
+
+    def backward_stages(self):
+        """Parameters grouped by WHEN their gradient is complete in backward (latest-used first), each with the name of the
+        staging.cut that bounds the stage from below (None: runs to the inputs).  Used by the trainer to exchange a
+        stage's gradients while the next stage still computes."""
+        dec = [self.query_embed.weight] + list(self.action_head.parameters()) + list(self.is_pad_head.parameters()) + \
+            list(self.transformer.decoder.parameters())
+        enc = list(self.transformer.encoder.parameters())
+        tok = self.tokenizer_parameters()
+        seen = {id(p) for p in dec + enc + tok}
+        rest = [p for p in self.parameters() if id(p) not in seen]  # CVAE encoder, input / latent projections, embeddings
+        return [("transformer.decoder", dec), ("transformer.encoder", enc), ("tokens", rest), (None, tok)]
 
     def tokenizer_parameters(self):
         """Parameters used by `forward(..., stage="tokenize")` (PointNet + the SA layer): everything whose shapes follow

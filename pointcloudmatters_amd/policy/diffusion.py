@@ -181,14 +181,18 @@ class ConditionalUnet1D(nn.Module):
         mish_cond = F.mish(cond)
         if mish_cond.is_cuda and torch.is_autocast_enabled("cuda"):
             mish_cond = mish_cond.to(torch.get_autocast_dtype("cuda"))  # one cast instead of one per cond_encoder
+        from . import staging  # backward-stage boundaries for the overlapped gradient exchange (identity otherwise)
+
         skips = []
         for res1, res2, down in self.down_modules:
             x = res2.forward_cl(res1.forward_cl(x, mish_cond), mish_cond)
             skips.append(x)
             if not isinstance(down, nn.Identity):
                 x = down.forward_cl(x)
+        x, mish_cond, *skips = staging.cut("unet.mid", x, mish_cond, *skips)
         for mid in self.mid_modules:
             x = mid.forward_cl(x, mish_cond)
+        x, mish_cond, *skips = staging.cut("unet.up", x, mish_cond, *skips)
         for res1, res2, up in self.up_modules:
             x = torch.cat((x, skips.pop()), dim=-1)
             x = up.forward_cl(res2.forward_cl(res1.forward_cl(x, mish_cond), mish_cond))
@@ -493,7 +497,11 @@ class PCDObsEncoder(_AttrMixin):
         feats, batch = [], None
         for key in self.pcd_keys:
             pcd = obs_dict[key]
-            if "sa_tokens" in pcd:  # tokens computed by an earlier stage (BCTrainer mode="hybrid")
+            if "pcd_feat" in pcd:  # the cloud features computed by an earlier stage (BCTrainer mode="hybrid")
+                batch = pcd["pcd_feat"].shape[0]
+                feats.append(pcd["pcd_feat"].reshape(batch, -1))
+                continue
+            if "sa_tokens" in pcd:
                 batch = pcd["sa_tokens"].shape[0] // self.pcd_npoints
             else:
                 assert len(pcd["offset"]) % self.n_obs_step == 0
@@ -621,6 +629,9 @@ class DiffusionUnetPcdPolicy(_AttrMixin):
         if pcds is not None:
             this_nobs["pcds"] = pcds
         global_cond = self._with_goal(self.obs_encoder(this_nobs).reshape(bsz, -1), batch.get("goal", None))
+        from . import staging
+
+        global_cond = staging.cut("unet.in", global_cond)
         trajectory = nactions
         cond_mask = self.mask_generator(trajectory.shape, device=trajectory.device)  # all False for obs_dim == 0
         noise = batch.get("noise", None)
@@ -637,9 +648,22 @@ class DiffusionUnetPcdPolicy(_AttrMixin):
         loss = loss.reshape(bsz, -1).mean(dim=1).mean()
         return dict(loss=loss)
 
+    def backward_stages(self):
+        """See ACTPCD.backward_stages: U-Net up path (+ final conv) | middle | down path and condition encoders | observation
+        encoder -- the 1 GB gradient of the 255.6 M-parameter U-Net leaves in three slabs while backward continues."""
+        m = self.model
+        up = list(m.final_conv.parameters()) + list(m.up_modules.parameters())
+        mid = list(m.mid_modules.parameters())
+        seen = {id(p) for p in up + mid}
+        down = [p for p in m.parameters() if id(p) not in seen]
+        seen |= {id(p) for p in down}
+        rest = [p for p in self.parameters() if id(p) not in seen]
+        return [("unet.up", up), ("unet.mid", mid), ("unet.in", down), (None, rest)]
+
     def tokenizer_parameters(self):
-        enc = self.obs_encoder
-        return list(enc.key_model_map.parameters()) + list(enc.linear.parameters()) + list(enc.bn.parameters())
+        """The eager half of mode="hybrid": the whole observation encoder (PointNet, SA layer, projector) -- every
+        BatchNorm of the policy lives here, outside the captured graphs, so synchronised statistics stay plain collectives."""
+        return list(self.obs_encoder.parameters())
 
     @staticmethod
     def hybrid_split(batch):
@@ -649,12 +673,12 @@ class DiffusionUnetPcdPolicy(_AttrMixin):
 
     @staticmethod
     def hybrid_merge(rest, boundary):
-        return dict(rest, obs=dict(rest["obs"], pcds={"sa_tokens": boundary[0]}))
+        return dict(rest, obs=dict(rest["obs"], pcds={"pcd_feat": boundary[0]}))
 
     def forward(self, batch, stage=None):
-        if stage == "tokenize":  # packed clouds -> SA tokens (b*M, C): the part whose shapes follow the cloud sizes
+        if stage == "tokenize":  # packed clouds -> per-cloud features (b, C): the part whose shapes follow the cloud sizes
             enc = self.obs_encoder
-            return (enc.sa_tokens(enc.key_model_map["pcd"], batch["obs"]["pcds"]),)
+            return (enc.encode_pcd(enc.key_model_map["pcd"], batch["obs"]["pcds"]),)
         out = self.compute_loss(batch)
         out.setdefault("action_loss", out["loss"])
         out.setdefault("kl_loss", out["loss"].new_zeros(()))

@@ -1,0 +1,82 @@
+"""Synchronised BatchNorm for the flat / hybrid trainer modes (``sync_batchnorm: true`` of configs/trainer/ddp.yaml:9).
+
+The BatchNorm layers on the hot path are owned by fused HIP kernels (policy/bn_relu.py: PointNet's Linear -> BN -> ReLU;
+policy/sa_fused.py: the set-abstraction layer's BN): those kernels produce LOCAL sums, the statistics of all ranks are
+combined here with the same algebra as torch's SyncBatchNorm --
+
+    forward : all_gather [mean_r, M2_r, n_r]  ->  Chan's parallel combination  ->  global mean / biased variance
+    backward: all_reduce [sum dy, sum dy * xhat]  ->  the input gradient uses the global sums and the global count;
+              the weight / bias gradients stay local (the gradient exchange averages them like every other parameter)
+
+-- and handed back to the kernels' apply stages.  Every other BatchNorm module becomes a ``torch.nn.SyncBatchNorm``.
+The collectives are plain eager calls: in hybrid mode the tokenizer (the only part with BatchNorm) runs outside the
+captured graphs."""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+
+def enable_sync_batchnorm(policy, process_group=None):
+    """Mark the BatchNorm1d layers the fused kernels own (`policy.fused_batchnorms()`) for statistic exchange and convert
+    every other BatchNorm module to torch's SyncBatchNorm in place."""
+    fused = set()
+    for owner in ([policy] + [m for m in policy.modules() if m is not policy]):
+        get = getattr(owner, "fused_batchnorms", None)
+        if get is not None:
+            fused.update(id(m) for m in get())
+    for m in policy.modules():
+        if id(m) in fused:
+            m._pcm_sync = process_group if process_group is not None else True
+
+    def convert(module):
+        for name, child in list(module.named_children()):
+            if isinstance(child, nn.modules.batchnorm._BatchNorm) and id(child) not in fused:
+                setattr(module, name, nn.SyncBatchNorm.convert_sync_batchnorm(child, process_group))
+            else:
+                convert(child)
+
+    convert(policy)
+    return policy
+
+
+def wants_sync(bn):
+    return bool(getattr(bn, "_pcm_sync", False)) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def _group(bn):
+    g = getattr(bn, "_pcm_sync", None)
+    return None if g is True else g
+
+
+def combine_forward(bn, mean_loc, m2_loc, count_loc):
+    """Local per-channel mean (C) and sum of squared deviations M2 (C) over `count_loc` rows -> stat (4, C) =
+    {mean, invstd, a = gamma * invstd, b = beta - a * mean} of the GLOBAL batch; updates the running statistics like
+    BatchNorm (momentum, unbiased variance) -- identically on every rank."""
+    C = mean_loc.shape[0]
+    pack = torch.cat([mean_loc.float(), m2_loc.float(), mean_loc.new_full((1,), float(count_loc), dtype=torch.float32)])
+    world = dist.get_world_size(_group(bn))
+    allp = torch.empty(world, 2 * C + 1, dtype=torch.float32, device=pack.device)
+    dist.all_gather_into_tensor(allp, pack, group=_group(bn))
+    n_r = allp[:, 2 * C:].double()                    # (W, 1)
+    mean_r, m2_r = allp[:, :C].double(), allp[:, C: 2 * C].double()
+    n = n_r.sum()
+    mean = (mean_r * n_r).sum(0) / n
+    m2 = (m2_r + n_r * (mean_r - mean) ** 2).sum(0)
+    var = (m2 / n).clamp_min(0.0)
+    invstd = torch.rsqrt(var + bn.eps)
+    a = bn.weight.double() * invstd
+    stat = torch.stack([mean, invstd, a, bn.bias.double() - a * mean]).float().contiguous()
+    if bn.track_running_stats and bn.momentum is not None:
+        with torch.no_grad():
+            mom = bn.momentum
+            unbiased = var * (n / (n - 1.0).clamp_min(1.0))
+            bn.running_mean.mul_(1.0 - mom).add_(mean.float(), alpha=mom)
+            bn.running_var.mul_(1.0 - mom).add_(unbiased.float(), alpha=mom)
+    return stat, n
+
+
+def reduce_backward(bn, sums_loc):
+    """(2, C) local {sum dy, sum dy * xhat} -> the same sums over all ranks (the local copy stays untouched)."""
+    g = sums_loc.clone()
+    dist.all_reduce(g, group=_group(bn))
+    return g

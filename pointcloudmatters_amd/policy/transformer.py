@@ -338,7 +338,11 @@ class Transformer(nn.Module):
         else:
             extra = torch.cat([latent_input, proprio_input], dim=0).transpose(0, 1)
         tokens = torch.cat([extra, tokens], dim=1)
+        from . import staging  # backward-stage boundaries for the overlapped gradient exchange (identity otherwise)
+
+        tokens, pos = staging.cut("transformer.encoder", tokens, pos)
         memory = self.encoder(tokens, src_key_padding_mask=mask, pos=pos)
+        memory, pos_dec = staging.cut("transformer.decoder", memory, pos)
         query_pos = query_embed.unsqueeze(0).expand(bs, -1, -1)
         tgt = torch.zeros_like(query_pos)
-        return self.decoder(tgt, memory, memory_key_padding_mask=mask, pos=pos, query_pos=query_pos)
+        return self.decoder(tgt, memory, memory_key_padding_mask=mask, pos=pos_dec, query_pos=query_pos)

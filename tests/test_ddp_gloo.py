@@ -59,7 +59,7 @@ class HostFlatAdamW:
         return {}
 
 
-def _worker(rank, world, port, mode, same_data, out_q):
+def _worker(rank, world, port, mode, same_data, out_q, staged=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -72,8 +72,13 @@ def _worker(rank, world, port, mode, same_data, out_q):
                                nhead=4, num_encoder_layers=1, num_decoder_layers=2, num_queries=10)
         tr = BCTrainer(pol, total_steps=50, device="cpu", distributed=True, sync_batchnorm=False, mode=mode,
                        optim=dict(accumulate_grad_batches=2, lr=1e-3),
-                       flat_optimizer_cls=HostFlatAdamW if mode == "flat" else None)
+                       flat_optimizer_cls=HostFlatAdamW if mode == "flat" else None, staged=staged)
         assert tr.distributed and tr.world == world
+        if mode == "flat":
+            assert len(tr._stages) == (1 if staged is False else 4)  # decoder | encoder | CVAE + projections | tokenizer
+            slabs = [s.slab for s in tr._stages]
+            assert slabs[0][0] == 0 and slabs[-1][1] == tr.optimizer.flat_g.numel()
+            assert all(a[1] == b[0] for a, b in zip(slabs, slabs[1:]))  # contiguous, in backward order
         eps = torch.randn(2, 32, generator=torch.Generator().manual_seed(3))
         for it in range(4):  # 2 optimizer steps, accumulate 2
             seed = 100 + it if same_data else 100 + it * world + rank
@@ -91,11 +96,11 @@ def _worker(rank, world, port, mode, same_data, out_q):
         dist.destroy_process_group()
 
 
-def _run(mode, same_data):
+def _run(mode, same_data, staged=None):
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, same_data, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, same_data, q, staged)) for r in range(2)]
     for p in procs:
         p.start()
     res = None
@@ -145,3 +150,13 @@ def test_two_ranks_same_data_match_single_process(mode):
     assert abs(r["loss"] - loss) <= 1e-5 * abs(loss)
     d = (torch.from_numpy(r["params"]) - want)
     assert d.norm() <= 1e-4 * want.norm(), float(d.norm() / want.norm())
+
+
+def test_slabbed_exchange_equals_one_all_reduce_bit_for_bit():
+    """The backward-staged path (4 partial backward passes, 4 asynchronous slab all-reduces) against ONE all-reduce of the
+    whole flat gradient after a plain backward: same operands per element, hence identical parameters on world_size 2."""
+    a = _run("flat", same_data=False, staged=True)
+    b = _run("flat", same_data=False, staged=False)
+    assert a["replicas_equal"] and b["replicas_equal"] and a["opt_steps"] == b["opt_steps"] == 2
+    assert (a["params"] == b["params"]).all()
+    assert a["loss"] == b["loss"]

@@ -529,3 +529,74 @@ def test_dp_hybrid_bf16_full_batch_stays_finite(hip_device):
     assert m["train/loss"] == m["train/loss"] and m["train/loss"] < 10.0, m
     for n, p in pol.named_parameters():
         assert torch.isfinite(p).all().item(), n
+
+
+@pytest.mark.parametrize("mode,precision,accumulate", [("flat", "fp32", 1), ("graph", "bf16", 1), ("graph", "bf16", 2), ("hybrid", "bf16", 1),
+                                                       ("graph", "fp32", 2)])
+def test_backward_stages_give_the_same_gradients(mode, precision, accumulate, hip_device):
+    """staged=True (what data-parallel runs use: one partial backward -- and one hipGraph -- per stage, gradient slabs in
+    backward order) against the plain single-stage path on one GPU: same losses, same flat gradient (through the
+    parameter order, which differs), and in graph / hybrid mode one captured graph per stage."""
+    from pointcloudmatters_amd.bc import BCTrainer, build_act_policy, clone_batch, make_act_batch
+
+    small = dict(hidden_dim=512, nhead=8, dim_feedforward=32, num_encoder_layers=2, num_decoder_layers=2, dropout=0.0, latent_dim=8,
+                 num_queries=10)
+    ragged = mode == "hybrid"
+    batches = [make_act_batch(2, 300, seed=60 + i, ragged=ragged, device=hip_device, num_queries=10) for i in range(3)]
+    eps = torch.randn(2, 8, generator=torch.Generator().manual_seed(1)).to(hip_device)
+    runs = {}
+    for staged in (False, True):
+        torch.manual_seed(0)
+        pol = build_act_policy(pcd_npoints=64, sa_impl="fused", **small).to(hip_device)
+        tr = BCTrainer(pol, total_steps=20, precision=precision, device=hip_device, mode=mode, staged=staged,
+                       optim=dict(accumulate_grad_batches=accumulate, lr=1e-6))
+        assert len(tr._stages) == (4 if staged else 1)
+        losses, grads = [], []
+        for i in range(3 * accumulate):
+            b = clone_batch(batches[i % 3])
+            b["vae_eps"] = eps
+            losses.append(tr.training_step(b)["loss"].item())
+            opt = tr.optimizer
+            index = {id(p): k for k, p in enumerate(opt.params)}
+            grads.append(torch.cat([opt.g_views[index[id(p)]].detach().reshape(-1).clone() for n, p in pol.named_parameters() if id(p) in index]))
+        assert tr.mode == mode
+        if mode == "graph":
+            assert len(tr._graph) == len(tr._stages)
+        if mode == "hybrid":
+            assert len(tr._graph) == (3 if staged else 1)
+        runs[staged] = (losses, grads)
+    tol = 1e-5 if precision == "fp32" else 2e-2
+    assert runs[False][0] == pytest.approx(runs[True][0], rel=tol)
+    for ga, gb in zip(runs[False][1], runs[True][1]):
+        assert (ga - gb).norm().item() <= (1e-4 if precision == "fp32" else 5e-2) * ga.norm().item() + 1e-8
+
+
+def test_backward_stages_for_the_diffusion_policy(hip_device):
+    from pointcloudmatters_amd.bc import BCTrainer, build_dp_policy, clone_batch, make_dp_batch
+    from pointcloudmatters_amd.bc.configs import DP_OPTIM
+    from tests.golden.make_golden import DP_SMALL
+
+    batches = [make_dp_batch(3, 150, seed=40 + i, ragged=True, device=hip_device) for i in range(3)]
+    g = torch.Generator().manual_seed(3)
+    noise = torch.randn(3, 16, 7, generator=g).to(hip_device)
+    tsteps = torch.tensor([3, 57, 99], device=hip_device)
+    runs = {}
+    for mode, staged in (("flat", False), ("flat", True), ("hybrid", True)):
+        torch.manual_seed(0)
+        pol = build_dp_policy(pcd_npoints=32, sa_impl="fused", **DP_SMALL).to(hip_device)
+        tr = BCTrainer(pol, total_steps=20, precision="fp32", device=hip_device, mode=mode, staged=staged, optim=dict(DP_OPTIM, lr=1e-6))
+        assert len(tr._stages) == (4 if staged else 1)
+        losses, grads = [], []
+        for i in range(4):
+            b = clone_batch(batches[i % 3])
+            b["noise"], b["timesteps"] = noise, tsteps
+            losses.append(tr.training_step(b)["loss"].item())
+            opt = tr.optimizer
+            index = {id(p): k for k, p in enumerate(opt.params)}
+            grads.append(torch.cat([opt.g_views[index[id(p)]].detach().reshape(-1).clone() for n, p in pol.named_parameters() if id(p) in index]))
+        runs[(mode, staged)] = (losses, grads)
+    ref = runs[("flat", False)]
+    for key in (("flat", True), ("hybrid", True)):
+        assert ref[0] == pytest.approx(runs[key][0], rel=1e-5)
+        for ga, gb in zip(ref[1], runs[key][1]):
+            assert (ga - gb).norm().item() <= 1e-4 * ga.norm().item() + 1e-8, key
