@@ -300,7 +300,9 @@ class BCTrainer:
         from ..policy import staging
 
         opt = self.optimizer
-        collect = getattr(opt, "collect_mode", False)
+        # hybrid mode always hands gradients over explicitly (its two halves write disjoint parts of the flat buffer at
+        # different times); the other modes do so only for the bf16 mirror, fp32 accumulates through the .grad views
+        collect = getattr(opt, "collect_mode", False) or self.mode == "hybrid"
         if len(stages) == 1:
             out = make_out()
             (out["loss"] / self.accumulate).backward()
@@ -409,7 +411,7 @@ class BCTrainer:
         for k in range(len(opt.params)):
             if hasattr(opt, "_stash"):
                 opt._stash[k] = None
-            if getattr(opt, "collect_mode", False):
+            if getattr(opt, "collect_mode", False) or self.mode == "hybrid":
                 opt.params[k].grad = None
 
     def _warm_up(self, gen):
