@@ -179,7 +179,7 @@ def pointops_and_sa_kernels(t, shape, device):
                                          D.data_ptr(), cnt.data_ptr(), S.data_ptr(), RM.data_ptr(),
                                          partial.data_ptr(), red1.data_ptr(), red2.data_ptr(), dgf.data_ptr(), dwp.data_ptr(),
                                          dgamma.data_ptr(), dbeta.data_ptr(), o32.data_ptr() if lds_ch else 0,
-                                         noff.data_ptr() if lds_ch else 0, b if lds_ch else 0, n_max, mask, st)
+                                         noff.data_ptr() if lds_ch else 0, b if lds_ch else 0, n_max, 0, 0.0, mask, st)
         assert rc == 0
 
     index()
@@ -333,7 +333,7 @@ def policy_kernels(t, wl, device, hidden=512):
 
     def bn_b():
         assert L.pcm_bn_relu_backward_hip(n_tot, Cb, 1, yb.data_ptr(), dzb.data_ptr(), stb.data_ptr(), pb.data_ptr(), sb.data_ptr(),
-                                          dyb.data_ptr(), st) == 0
+                                          dyb.data_ptr(), 0, 0.0, st) == 0
 
     bn_f()
     t.add("pcm_bn_relu forward (colsum+reduce+stats+apply)", timed_events(bn_f, 30), n_tot * Cb * 6, "hbm",
@@ -586,8 +586,11 @@ def run_workload(name, args, device, world, rank, steps, warmup, precision=None,
     extra = {} if is_dp else {"dead_decoder_layers": args.dead_decoder_layers}
     policy = build(pcd_npoints=wl["pcd_npoints"], sa_impl=sa_impl, **extra).to(device)
     if mode == "auto":
-        # ragged clouds: the tokenizer runs eagerly, everything behind the fixed-size token matrix replays as one hipGraph
-        mode = "hybrid" if wl["ragged"] else "graph"
+        # ragged clouds: the tokenizer runs eagerly, everything behind the fixed-size token matrix replays as hipGraphs.
+        # Data parallel runs take the same mode: every BatchNorm lives in the eager tokenizer, so its statistics are
+        # synchronised across ranks (configs/trainer/ddp.yaml:9) with plain collectives, and the gradient slabs of the
+        # captured stages are exchanged between graph replays, overlapping the rest of backward.
+        mode = "hybrid" if (wl["ragged"] or world > 1) else "graph"
     trainer = BCTrainer(policy, total_steps=max(steps + warmup + trace_steps, 100), precision=wl["dtype"], device=device,
                         distributed=world > 1, optim=dict(DP_OPTIM) if is_dp else dict(accumulate_grad_batches=1), mode=mode)
     batches = [make_batch(wl["batch"], wl["n_points"], seed=1000 + rank + 97 * i, ragged=wl["ragged"], device=device)

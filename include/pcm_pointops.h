@@ -181,7 +181,10 @@ int pcm_group_xyz_feat_backward_hip(int m, int nsample, int c, int with_xyz,
  * global-atomic fallback (D zeroed by the caller).
  * stage_mask <= 0 runs every kernel of the call; a bit mask runs only the selected kernels (forward:
  * 1 gather+stats, 2 reduce, 4 affine, 8 apply; backward: 2 bwd1, 4 reduce, 8 bwd2, 16 reduce,
- * 32 bwd3) -- used by bench.py to time one kernel at a time.
+ * 32 bwd3) -- used by bench.py to time one kernel at a time, and by synchronised BatchNorm: forward 1|2 yields the local
+ * sums, the caller combines the statistics of all ranks into `stat` and runs stage 8; backward 2|4 yields red1, the
+ * caller all-reduces its first two rows into red_global (2,H) = {sum delta, sum delta * yhat} and runs 8|16|32 with
+ * `count` = m*K of the global batch (red_global NULL / count <= 0: single rank).
  * pcm_sa_fused_slots(rows, H, bf16, K): partial-row slots a row-streaming kernel over `rows` rows writes. */
 int pcm_sa_fused_slots(int units, int H, int bf16, int K);
 int pcm_sa_fused_bwd1_lds_channels(int H, int n_max);
@@ -199,7 +202,8 @@ int pcm_sa_fused_backward_hip(int m, int n, int K, int H, int gf_is_bf16, const 
                               const unsigned char *asel, float *D, const float *cnt, const float *S,
                               const float *RM, float *partial, float *red1, float *red2, void *dGf,
                               float *dWp, float *dgamma, float *dbeta, const int *offset,
-                              const int *new_offset, int b, int n_max, int stage_mask, void *stream);
+                              const int *new_offset, int b, int n_max, const float *red_global, double count,
+                              int stage_mask, void *stream);
 
 /* ---- hipGraph surgery -----------------------------------------------------------------------------------
  * Replace every MEMSET node of a captured, not yet instantiated hipGraph_t by a fill-kernel node with the same
@@ -292,15 +296,18 @@ int pcm_col2im_cl_hip(int B, int T, int C, int K, int stride, int pad, int cols_
  * y, z, dz, dy: (n, C) row-major, all bf16 (is_bf16) or all fp32; C % 4 == 0 and (C <= 1024 or C % 1024 == 0)
  * (pcm_bn_relu_supported).  partial: pcm_bn_relu_slots(n, C) x 2 x C floats of scratch; sums: 2 x C; stat: 4 x C =
  * { mean, invstd, a = gamma*invstd, b = beta - a*mean }.  forward updates running_mean / running_var (momentum,
- * unbiased variance) unless they are NULL; use_given_stat != 0 skips the statistics and applies `stat` as given
- * (eval mode: the caller fills it from the running statistics).  backward leaves sums = [dbeta | dgamma]. */
+ * unbiased variance) unless they are NULL; use_given_stat = 1 skips the statistics and applies `stat` as given
+ * (eval mode: the caller fills it from the running statistics; synchronised BatchNorm: from the statistics of all ranks),
+ * use_given_stat = 2 stops after the local sums (sums[0] = sum (y - y[0]), sums[1] = sum (y - y[0])^2).
+ * backward leaves sums = [dbeta | dgamma]; phase 1 stops after those local sums, phase 2 only applies given (all-reduced)
+ * sums with `count` = rows of the global batch (<= 0: n). */
 int pcm_bn_relu_supported(long n, int C);
 int pcm_bn_relu_slots(long n, int C);
 int pcm_bn_relu_forward_hip(long n, int C, int is_bf16, const void *y, const float *gamma, const float *beta,
                             float eps, float momentum, float *running_mean, float *running_var,
                             int use_given_stat, float *partial, float *sums, float *stat, void *z, void *stream);
 int pcm_bn_relu_backward_hip(long n, int C, int is_bf16, const void *y, const void *dz, const float *stat,
-                             float *partial, float *sums, void *dy, void *stream);
+                             float *partial, float *sums, void *dy, int phase, double count, void *stream);
 
 /* ---- GPU-side GridSamplePCD keys (the data-path step before the hot path) --------------------------------
  * replaces the per-cloud NumPy arithmetic of src/data/components/transformpcd.py:684-701, 776-790 for a packed

@@ -41,7 +41,7 @@ SIGNATURES = {
     "pcm_sa_fused_forward_hip": [_i, _i, _i, _i, _P, _P, _P, _P, _P, _f, _f, _P, _P, _P, _P, _P, _P, _P, _P, _i, _P],
     "pcm_sa_index_hip": [_i, _i, _P, _P, _P, _P, _P, _i, _i, _P, _P, _P, _P, _P],
     "pcm_sa_fused_backward_hip": [_i, _i, _i, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
-                                  _P, _P, _P, _i, _i, _i, _P],
+                                  _P, _P, _P, _i, _i, _P, ctypes.c_double, _i, _P],
     "pcm_drln_blocks": [ctypes.c_long],
     "pcm_drln_forward_hip": [ctypes.c_long, _i, _i, _P, _P, _P, _P, _f, _f, _P, ctypes.c_uint, _P, _P, _P, _P, _P],
     "pcm_drln_backward_hip": [ctypes.c_long, _i, _i, _P, _P, _P, _P, _P, _f, _P, ctypes.c_uint, _P, _P, _P, _P, _P, _P],
@@ -60,7 +60,7 @@ SIGNATURES = {
     "pcm_bn_relu_supported": [ctypes.c_long, _i],
     "pcm_bn_relu_slots": [ctypes.c_long, _i],
     "pcm_bn_relu_forward_hip": [ctypes.c_long, _i, _i, _P, _P, _P, _f, _f, _P, _P, _i, _P, _P, _P, _P, _P],
-    "pcm_bn_relu_backward_hip": [ctypes.c_long, _i, _i, _P, _P, _P, _P, _P, _P, _P],
+    "pcm_bn_relu_backward_hip": [ctypes.c_long, _i, _i, _P, _P, _P, _P, _P, _P, _i, ctypes.c_double, _P],
     "pcm_voxel_keys_hip": [_i, _i, _P, _P, ctypes.c_double, _P, _P, _P, _P, _P],
     "pcm_add_cast2_hip": [ctypes.c_long, ctypes.c_long, _P, _P, _P, _P, _P],
     "pcm_add2_cast_hip": [ctypes.c_long, _P, _P, _P, _P],

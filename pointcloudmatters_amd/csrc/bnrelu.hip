@@ -253,7 +253,9 @@ extern "C" int pcm_bn_relu_forward_hip(long n, int C, int is_bf16, const void *y
     hipStream_t s = (hipStream_t)stream;
     using bf = __hip_bfloat16;
     const Plan p = plan_for(n, C);
-    if (!use_given_stat) {
+    // use_given_stat: 0 = whole layer; 1 = apply only (stat given: eval mode, or statistics combined across ranks);
+    // 2 = local sums only (sums[0] = sum (y - y[0]), sums[1] = sum (y - y[0])^2: the caller combines them across ranks)
+    if (use_given_stat != 1) {
         if (!partial || !sums) return PCM_ERR_BAD_ARG;
         const dim3 grid(p.nslots, p.nchunk);
         if (is_bf16)
@@ -263,6 +265,7 @@ extern "C" int pcm_bn_relu_forward_hip(long n, int C, int is_bf16, const void *y
             hipLaunchKernelGGL((pcm_bn_colsum_kernel<float, 0>), grid, dim3(kBlock), 0, s, n, C, p.chunkW, p.rows_per_slot,
                                (const float *)y, (const float *)nullptr, (const float *)nullptr, partial);
         hipLaunchKernelGGL(pcm_bn_reduce_kernel, dim3((2 * C + 63) / 64), dim3(64 * kRedWaves), 0, s, p.nslots, 2 * C, partial, sums);
+        if (use_given_stat == 2) return PCM_LAUNCH_STATUS();
         if (is_bf16)
             hipLaunchKernelGGL(pcm_bn_stats_kernel<bf>, dim3((C + kBlock - 1) / kBlock), dim3(kBlock), 0, s, C, (double)n, eps, momentum,
                                (const bf *)y, sums, gamma, beta, stat, running_mean, running_var);
@@ -280,8 +283,10 @@ extern "C" int pcm_bn_relu_forward_hip(long n, int C, int is_bf16, const void *y
 }
 
 extern "C" int pcm_bn_relu_backward_hip(long n, int C, int is_bf16, const void *y, const void *dz, const float *stat,
-                                        float *partial, float *sums, void *dy, void *stream)
+                                        float *partial, float *sums, void *dy, int phase, double count, void *stream)
 {
+    // phase: 0 = whole backward; 1 = local sums only (sums = {sum g, sum g * xhat}); 2 = apply only with the given sums
+    // (all-reduced across ranks by the caller) and `count` = rows of the GLOBAL batch (<= 0: n)
     if (n == 0) return PCM_OK;
     if (!pcm_bn_relu_supported(n, C)) return PCM_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
@@ -289,19 +294,25 @@ extern "C" int pcm_bn_relu_backward_hip(long n, int C, int is_bf16, const void *
     const Plan p = plan_for(n, C);
     const dim3 grid(p.nslots, p.nchunk);
     const long total4 = n * C / 4;
-    const float inv_n = (float)(1.0 / (double)n);
+    const float inv_n = (float)(1.0 / (count > 0.0 ? count : (double)n));
     if (is_bf16) {
-        hipLaunchKernelGGL((pcm_bn_colsum_kernel<bf, 1>), grid, dim3(kBlock), 0, s, n, C, p.chunkW, p.rows_per_slot, (const bf *)y,
-                           (const bf *)dz, stat, partial);
-        hipLaunchKernelGGL(pcm_bn_reduce_kernel, dim3((2 * C + 63) / 64), dim3(64 * kRedWaves), 0, s, p.nslots, 2 * C, partial, sums);
-        hipLaunchKernelGGL(pcm_bn_relu_bwd_apply_kernel<bf>, dim3(ew_grid(total4)), dim3(kBlock), 0, s, total4, C, inv_n, (const bf *)y,
-                           (const bf *)dz, stat, sums, (bf *)dy);
+        if (phase != 2) {
+            hipLaunchKernelGGL((pcm_bn_colsum_kernel<bf, 1>), grid, dim3(kBlock), 0, s, n, C, p.chunkW, p.rows_per_slot, (const bf *)y,
+                               (const bf *)dz, stat, partial);
+            hipLaunchKernelGGL(pcm_bn_reduce_kernel, dim3((2 * C + 63) / 64), dim3(64 * kRedWaves), 0, s, p.nslots, 2 * C, partial, sums);
+        }
+        if (phase != 1)
+            hipLaunchKernelGGL(pcm_bn_relu_bwd_apply_kernel<bf>, dim3(ew_grid(total4)), dim3(kBlock), 0, s, total4, C, inv_n, (const bf *)y,
+                               (const bf *)dz, stat, sums, (bf *)dy);
     } else {
-        hipLaunchKernelGGL((pcm_bn_colsum_kernel<float, 1>), grid, dim3(kBlock), 0, s, n, C, p.chunkW, p.rows_per_slot,
-                           (const float *)y, (const float *)dz, stat, partial);
-        hipLaunchKernelGGL(pcm_bn_reduce_kernel, dim3((2 * C + 63) / 64), dim3(64 * kRedWaves), 0, s, p.nslots, 2 * C, partial, sums);
-        hipLaunchKernelGGL(pcm_bn_relu_bwd_apply_kernel<float>, dim3(ew_grid(total4)), dim3(kBlock), 0, s, total4, C, inv_n,
-                           (const float *)y, (const float *)dz, stat, sums, (float *)dy);
+        if (phase != 2) {
+            hipLaunchKernelGGL((pcm_bn_colsum_kernel<float, 1>), grid, dim3(kBlock), 0, s, n, C, p.chunkW, p.rows_per_slot,
+                               (const float *)y, (const float *)dz, stat, partial);
+            hipLaunchKernelGGL(pcm_bn_reduce_kernel, dim3((2 * C + 63) / 64), dim3(64 * kRedWaves), 0, s, p.nslots, 2 * C, partial, sums);
+        }
+        if (phase != 1)
+            hipLaunchKernelGGL(pcm_bn_relu_bwd_apply_kernel<float>, dim3(ew_grid(total4)), dim3(kBlock), 0, s, total4, C, inv_n,
+                               (const float *)y, (const float *)dz, stat, sums, (float *)dy);
     }
     return PCM_LAUNCH_STATUS();
 }

@@ -753,7 +753,8 @@ __global__ __launch_bounds__(kBlock) void pcm_sa_bwd2_kernel(int n, int H, int l
 
 // dWp[h][c], dgamma[h], dbeta[h] from the reduced sums
 __global__ __launch_bounds__(kBlock) void pcm_sa_bwd3_kernel(int H, double count, const float *__restrict__ stat,
-                                                             const float *__restrict__ red1, const float *__restrict__ red2,
+                                                             const float *__restrict__ red1, const float *__restrict__ redn,
+                                                             const float *__restrict__ red2,
                                                              const float *__restrict__ RM, const float *__restrict__ Wp,
                                                              float *__restrict__ dWp, float *__restrict__ dgamma,
                                                              float *__restrict__ dbeta)
@@ -762,9 +763,9 @@ __global__ __launch_bounds__(kBlock) void pcm_sa_bwd3_kernel(int H, double count
     if (h >= H) return;
     const float invN = (float)(1.0 / count);
     const float r = stat[H + h], a = stat[2 * H + h];
-    const float db = red1[h], dg = red1[H + h];
-    dbeta[h] = db;
-    dgamma[h] = dg;
+    dbeta[h] = red1[h];      // parameter gradients: this rank's sums (the gradient exchange averages them)
+    dgamma[h] = red1[H + h];
+    const float db = redn[h], dg = redn[H + h];  // normalisation terms: sums over the whole (global) batch
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float E = red1[(2 + c) * H + h];
@@ -930,13 +931,17 @@ extern "C" int pcm_sa_fused_backward_hip(int m, int n, int K, int H, int gf_is_b
                                          const float *sel, const unsigned char *asel, float *D, const float *cnt,
                                          const float *S, const float *RM, float *partial, float *red1, float *red2, void *dGf,
                                          float *dWp, float *dgamma, float *dbeta, const int *offset, const int *new_offset,
-                                         int b, int n_max, int stage_mask, void *stream)
+                                         int b, int n_max, const float *red_global, double count_override, int stage_mask,
+                                         void *stream)
 {
     // stage_mask: bit1 bwd1, bit2 reduce1, bit3 bwd2, bit4 reduce2, bit5 bwd3; <= 0 means all.  cnt / S / RM come from
     // pcm_sa_index_hip (same neighbour lists).
     if (stage_mask <= 0) stage_mask = 0x3E;
     if (m <= 0 || n <= 0 || K <= 0 || K > kMaxK || H <= 0) return PCM_ERR_BAD_ARG;
-    const double count = (double)m * K;
+    // synchronised BatchNorm: the normalisation terms of the input gradient use the sums and the row count of ALL ranks
+    // (red_global = all-reduced {sum delta, sum delta * yhat}); dgamma / dbeta stay the local sums of red1
+    const double count = count_override > 0.0 ? count_override : (double)m * K;
+    const float *redn = red_global ? red_global : red1;
     {
         // LDS-staged variant when the cloud layout is known and a cloud's D rows for >= 4 channels fit in LDS
         const int CH = (b > 0 && offset && new_offset) ? pcm_sa_fused_bwd1_lds_channels(H, n_max) : 0;
@@ -982,7 +987,7 @@ extern "C" int pcm_sa_fused_backward_hip(int m, int n, int K, int H, int gf_is_b
     do {                                                                                                                     \
         if (stage_mask & 8)                                                                                                  \
             hipLaunchKernelGGL((pcm_sa_bwd2_kernel<T, V>), dim3(grid), dim3(kBlock), smem, PCM_SA_ST, n, H, mp.lpq, mp.qpw, \
-                               mp.nchunk, count, (const T *)Gf, D, cnt, S, Wp, stat, red1, (T *)dGf, partial);              \
+                               mp.nchunk, count, (const T *)Gf, D, cnt, S, Wp, stat, redn, (T *)dGf, partial);              \
     } while (0)
         if (gf_is_bf16) {
             if (mp.vec == 8) PCM_B2(__hip_bfloat16, 8); else if (mp.vec == 4) PCM_B2(__hip_bfloat16, 4); else PCM_B2(__hip_bfloat16, 1);
@@ -992,7 +997,7 @@ extern "C" int pcm_sa_fused_backward_hip(int m, int n, int K, int H, int gf_is_b
 #undef PCM_B2
         if (stage_mask & 16) hipLaunchKernelGGL(pcm_sa_reduce_kernel, dim3((3 * H + 63) / 64), dim3(64 * kRedWaves), 0, PCM_SA_ST, nslots, 3 * H, partial, red2);
     }
-    if (stage_mask & 32) hipLaunchKernelGGL(pcm_sa_bwd3_kernel, dim3((H + kBlock - 1) / kBlock), dim3(kBlock), 0, PCM_SA_ST, H, count, stat, red1, red2, RM,
-                       Wp, dWp, dgamma, dbeta);
+    if (stage_mask & 32) hipLaunchKernelGGL(pcm_sa_bwd3_kernel, dim3((H + kBlock - 1) / kBlock), dim3(kBlock), 0, PCM_SA_ST, H, count, stat, red1, redn,
+                       red2, RM, Wp, dWp, dgamma, dbeta);
     return PCM_LAUNCH_STATUS();
 }

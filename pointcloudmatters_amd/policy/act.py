@@ -286,6 +286,9 @@ class ACTPCD(nn.Module):
         rest = [p for p in self.parameters() if id(p) not in seen]  # CVAE encoder, input / latent projections, embeddings
         return [("transformer.decoder", dec), ("transformer.encoder", enc), ("tokens", rest), (None, tok)]
 
+    def fused_batchnorms(self):
+        return [self.bn] if self.sa_impl == "fused" else []
+
     def tokenizer_parameters(self):
         """Parameters used by `forward(..., stage="tokenize")` (PointNet + the SA layer): everything whose shapes follow
         the number of points; the rest of the policy sees only the fixed-size token matrix."""

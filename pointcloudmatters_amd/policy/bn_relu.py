@@ -16,23 +16,35 @@ def _ptr(t):
 
 class _BNReLU(Function):
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, eps, momentum):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, eps, momentum, sync_bn):
         L = _lib.load()
         n, c = y.shape
         y = y.contiguous()
         dev = y.device
+        st = torch.cuda.current_stream().cuda_stream
+        count = None
         with torch.cuda.device(dev):
             f32 = dict(dtype=torch.float32, device=dev)
             partial = torch.empty(L.pcm_bn_relu_slots(n, c) * 2 * c, **f32)
             sums, stat = torch.empty(2, c, **f32), torch.empty(4, c, **f32)
             z = torch.empty_like(y)
-            rc = L.pcm_bn_relu_forward_hip(n, c, int(y.dtype == torch.bfloat16), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                           float(eps), float(momentum), _ptr(running_mean), _ptr(running_var), 0,
-                                           partial.data_ptr(), sums.data_ptr(), stat.data_ptr(), z.data_ptr(),
-                                           torch.cuda.current_stream().cuda_stream)
+            args = (n, c, int(y.dtype == torch.bfloat16), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), float(momentum))
+            if sync_bn is None:
+                rc = L.pcm_bn_relu_forward_hip(*args, _ptr(running_mean), _ptr(running_var), 0, partial.data_ptr(), sums.data_ptr(),
+                                               stat.data_ptr(), z.data_ptr(), st)
+            else:  # synchronised BatchNorm (policy/sync_bn.py): local sums -> statistics of all ranks -> apply
+                from . import sync_bn as S
+
+                rc = L.pcm_bn_relu_forward_hip(*args, 0, 0, 2, partial.data_ptr(), sums.data_ptr(), 0, 0, st)
+                _lib.check(rc, "pcm_bn_relu_forward_hip")
+                shift = y[0].float()  # the kernel accumulates around the first row
+                d = sums[0] / n
+                stat, count = S.combine_forward(sync_bn, shift + d, sums[1] - sums[0] * d, n)
+                rc = L.pcm_bn_relu_forward_hip(*args, 0, 0, 1, 0, 0, stat.data_ptr(), z.data_ptr(), st)
         _lib.check(rc, "pcm_bn_relu_forward_hip")
         ctx.save_for_backward(y, stat)
         ctx.partial = partial
+        ctx.sync = (sync_bn, count)
         return z
 
     @staticmethod
@@ -47,11 +59,20 @@ class _BNReLU(Function):
         with torch.cuda.device(dev):
             sums = torch.empty(2, c, dtype=torch.float32, device=dev)
             dy = torch.empty_like(y)
-            rc = L.pcm_bn_relu_backward_hip(n, c, int(y.dtype == torch.bfloat16), y.data_ptr(), dz.data_ptr(), stat.data_ptr(),
-                                            ctx.partial.data_ptr(), sums.data_ptr(), dy.data_ptr(),
-                                            torch.cuda.current_stream().cuda_stream)
+            st = torch.cuda.current_stream().cuda_stream
+            args = (n, c, int(y.dtype == torch.bfloat16), y.data_ptr(), dz.data_ptr(), stat.data_ptr(), ctx.partial.data_ptr())
+            sync_bn, count = ctx.sync
+            if sync_bn is None:
+                rc = L.pcm_bn_relu_backward_hip(*args, sums.data_ptr(), dy.data_ptr(), 0, 0.0, st)
+            else:  # local sums stay the parameter gradients; the input gradient uses the sums / count of all ranks
+                from . import sync_bn as S
+
+                rc = L.pcm_bn_relu_backward_hip(*args, sums.data_ptr(), 0, 1, 0.0, st)
+                _lib.check(rc, "pcm_bn_relu_backward_hip")
+                gsums = S.reduce_backward(sync_bn, sums, count)  # count = n_loc / N: the kernel's 1 / n_loc becomes 1 / N
+                rc = L.pcm_bn_relu_backward_hip(*args, gsums.data_ptr(), dy.data_ptr(), 2, 0.0, st)
         _lib.check(rc, "pcm_bn_relu_backward_hip")
-        return dy, sums[1], sums[0], None, None, None, None
+        return dy, sums[1], sums[0], None, None, None, None, None
 
 
 def supported(y, bn):
@@ -64,7 +85,9 @@ def supported(y, bn):
 def bn_relu(y, bn):
     """relu(bn(y)); the caller checked ``supported(y, bn)``."""
     if bn.training:
-        z = _BNReLU.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum)
+        from .sync_bn import wants_sync
+
+        z = _BNReLU.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, bn if wants_sync(bn) else None)
         with torch.no_grad():
             bn.num_batches_tracked.add_(1)
         return z

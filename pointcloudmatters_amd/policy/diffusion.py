@@ -477,6 +477,9 @@ class PCDObsEncoder(_AttrMixin):
         coord, offset = pcd_dict["coord"], pcd_dict["offset"]
         set_abstraction.prefetch_sampling(self, self.pointops, coord, offset, self._new_offsets(offset))
 
+    def fused_batchnorms(self):
+        return [self.bn] if self.sa_impl == "fused" else []
+
     def sa_tokens(self, pcd_model, pcd_dict):
         """The ragged half: PointNet + set abstraction -> (b*M, C) tokens (fixed shape whatever the cloud sizes)."""
         coord, offset = pcd_dict["coord"], pcd_dict["offset"]

@@ -48,7 +48,15 @@ class PointNet(nn.Module):
 
             if fused.supported(y, block[1]):
                 return fused.bn_relu(y, block[1])
+        if getattr(block[1], "_pcm_sync", False) and block[1].training:
+            raise RuntimeError("this BatchNorm is marked for synchronised statistics, which only the fused HIP path implements "
+                               "(policy/sync_bn.py); its input does not qualify for that path")
         return block[2](block[1](y))
+
+    def fused_batchnorms(self):
+        """BatchNorm layers whose training-mode forward / backward run in the fused kernels (they exchange their statistics
+        themselves when synchronised BatchNorm is on, see policy/sync_bn.py)."""
+        return [blk[1] for blk in (self.conv1, self.conv2, self.conv3, self.conv4, self.conv5)]
 
     def load_reference_state_dict(self, state_dict, strict=True):
         """Accept a reference checkpoint: spconv stores SubMConv3d weights as (1,1,1,Cin,Cout)

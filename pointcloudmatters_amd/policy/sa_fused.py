@@ -43,7 +43,7 @@ def _slots(L, m, n, H, bf, K, b):
 
 class _SAFused(Function):
     @staticmethod
-    def forward(ctx, gf, ent, wp, gamma, beta, running_mean, running_var, eps, momentum, o32, no32, n_max, istats):
+    def forward(ctx, gf, ent, wp, gamma, beta, running_mean, running_var, eps, momentum, o32, no32, n_max, istats, sync_bn):
         L = _lib.load()
         assert gf.is_cuda and gf.is_contiguous() and gf.dtype in (torch.float32, torch.bfloat16)
         n, H = gf.shape
@@ -60,15 +60,33 @@ class _SAFused(Function):
             sums, stat, z = torch.empty(2, H, **f32), torch.empty(4, H, **f32), torch.empty(m, H, **f32)
             wp = wp.contiguous().float()
             gamma, beta = gamma.contiguous().float(), beta.contiguous().float()
-            rc = L.pcm_sa_fused_forward_hip(
-                m, K, H, bf, gf.data_ptr(), ent.data_ptr(),
-                wp.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), float(momentum), _ptr(running_mean),
-                _ptr(running_var), sel.data_ptr(), asel.data_ptr(), partial.data_ptr(),
-                sums.data_ptr(), stat.data_ptr(), z.data_ptr(), 0, st)
-        _lib.check(rc, "pcm_sa_fused_forward_hip")
+            count = None
+
+            def launch(mask, stat_t, rm=None, rv=None):
+                rc_ = L.pcm_sa_fused_forward_hip(
+                    m, K, H, bf, gf.data_ptr(), ent.data_ptr(),
+                    wp.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), float(momentum), _ptr(rm),
+                    _ptr(rv), sel.data_ptr(), asel.data_ptr(), partial.data_ptr(),
+                    sums.data_ptr(), stat_t.data_ptr(), z.data_ptr(), mask, st)
+                _lib.check(rc_, "pcm_sa_fused_forward_hip")
+
+            if sync_bn is None:
+                launch(0, stat, running_mean, running_var)
+            else:  # synchronised BatchNorm: local sums (around the first neighbour's Gf row) -> all ranks -> apply
+                from . import sync_bn as S
+
+                launch(1 | 2, stat)
+                j0 = ent.view(torch.int32)[0, 0, 0]
+                shift = torch.where(j0 >= 0, gf.index_select(0, j0.clamp(min=0).long().reshape(1))[0].float(),
+                                    torch.zeros(H, **f32))
+                rows = float(m) * K
+                d = sums[0] / rows
+                stat, count = S.combine_forward(sync_bn, shift + d, sums[1] - sums[0] * d, rows)
+                launch(8, stat)
         ctx.save_for_backward(gf, ent, wp, stat, sel, asel, istats)
         ctx.partial = partial
         ctx.layout = (o32, no32, int(n_max))
+        ctx.sync = (sync_bn, count)
         ctx.mark_non_differentiable(stat)
         return z, stat
 
@@ -92,14 +110,26 @@ class _SAFused(Function):
             red1, red2 = torch.empty(5, H, **f32), torch.empty(3, H, **f32)
             dgf = torch.empty_like(gf)
             dwp, dgamma, dbeta = torch.empty(H, 3, **f32), torch.empty(H, **f32), torch.empty(H, **f32)
-            rc = L.pcm_sa_fused_backward_hip(
-                m, n, K, H, 1 if gf.dtype == torch.bfloat16 else 0, gf.data_ptr(), ent.data_ptr(),
-                wp.data_ptr(), stat.data_ptr(), dz.data_ptr(), sel.data_ptr(), asel.data_ptr(), D.data_ptr(), cnt.data_ptr(),
-                S.data_ptr(), RM.data_ptr(), ctx.partial.data_ptr(), red1.data_ptr(), red2.data_ptr(), dgf.data_ptr(),
-                dwp.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _ptr(o32) if lds_path else 0,
-                _ptr(no32) if lds_path else 0, b if lds_path else 0, n_max, 0, st)
-        _lib.check(rc, "pcm_sa_fused_backward_hip")
-        return dgf, None, dwp, dgamma, dbeta, None, None, None, None, None, None, None, None
+            sync_bn, count = ctx.sync
+
+            def launch(mask, red_g=None):
+                rc_ = L.pcm_sa_fused_backward_hip(
+                    m, n, K, H, 1 if gf.dtype == torch.bfloat16 else 0, gf.data_ptr(), ent.data_ptr(),
+                    wp.data_ptr(), stat.data_ptr(), dz.data_ptr(), sel.data_ptr(), asel.data_ptr(), D.data_ptr(), cnt.data_ptr(),
+                    S.data_ptr(), RM.data_ptr(), ctx.partial.data_ptr(), red1.data_ptr(), red2.data_ptr(), dgf.data_ptr(),
+                    dwp.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _ptr(o32) if lds_path else 0,
+                    _ptr(no32) if lds_path else 0, b if lds_path else 0, n_max, _ptr(red_g), 0.0, mask, st)
+                _lib.check(rc_, "pcm_sa_fused_backward_hip")
+
+            if sync_bn is None:
+                launch(0)
+            else:  # {sum delta, sum delta * yhat} of all ranks enter the input gradient; dgamma / dbeta stay local
+                from . import sync_bn as SB
+
+                launch(2 | 4)
+                red_g = SB.reduce_backward(sync_bn, red1[:2], count)  # count = rows_loc / N_global (device scalar)
+                launch(8 | 16 | 32, red_g)
+        return dgf, None, dwp, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
 def supports(owner, x):
@@ -168,8 +198,10 @@ def sa_fused_forward(owner, p, x, n_p, fps_idx, knn_idx, o=None, n_o=None, istat
     if not owner.training:
         with torch.no_grad():
             return _sa_fused_eval(owner, gf.contiguous(), ent, w[:, :3])
+    from .sync_bn import wants_sync
+
     z, _ = _SAFused.apply(gf.contiguous(), ent, w[:, :3], bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                          bn.eps, bn.momentum, o32, no32, n_max, stats)
+                          bn.eps, bn.momentum, o32, no32, n_max, stats, bn if wants_sync(bn) else None)
     with torch.no_grad():
         bn.num_batches_tracked.add_(1)
     return z

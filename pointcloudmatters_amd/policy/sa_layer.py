@@ -116,6 +116,9 @@ def set_abstraction(owner, pointops, p, x, o, n_o, impl="reference", pre=None):
         if supports(owner, x):
             tokens = sa_fused_forward(owner, p, x, n_p, idx, knn_idx, o, n_o, istats=pre.get("istats"))
             return n_p, tokens, idx
+        if getattr(owner.bn, "_pcm_sync", False) and owner.training:
+            raise RuntimeError("this set-abstraction layer's BatchNorm is marked for synchronised statistics, which only the "
+                               "fused HIP path implements (policy/sync_bn.py)")
         impl = "torch"  # eval mode / SyncBatchNorm / CPU: same maths through framework ops
     if x.dtype != torch.float32:
         x = x.float()  # pointops is fp32 (bf16 autocast applies to GEMM / attention only)

@@ -50,13 +50,14 @@ def _group(bn):
 
 def combine_forward(bn, mean_loc, m2_loc, count_loc):
     """Local per-channel mean (C) and sum of squared deviations M2 (C) over `count_loc` rows -> stat (4, C) =
-    {mean, invstd, a = gamma * invstd, b = beta - a * mean} of the GLOBAL batch; updates the running statistics like
-    BatchNorm (momentum, unbiased variance) -- identically on every rank."""
+    {mean, invstd, a = gamma * invstd, b = beta - a * mean} of the GLOBAL batch, and n_loc / N; updates the running
+    statistics like BatchNorm (momentum, unbiased variance) -- identically on every rank."""
     C = mean_loc.shape[0]
     pack = torch.cat([mean_loc.float(), m2_loc.float(), mean_loc.new_full((1,), float(count_loc), dtype=torch.float32)])
     world = dist.get_world_size(_group(bn))
-    allp = torch.empty(world, 2 * C + 1, dtype=torch.float32, device=pack.device)
-    dist.all_gather_into_tensor(allp, pack, group=_group(bn))
+    parts = [torch.empty_like(pack) for _ in range(world)]
+    dist.all_gather(parts, pack, group=_group(bn))
+    allp = torch.stack(parts)
     n_r = allp[:, 2 * C:].double()                    # (W, 1)
     mean_r, m2_r = allp[:, :C].double(), allp[:, C: 2 * C].double()
     n = n_r.sum()
@@ -72,11 +73,15 @@ def combine_forward(bn, mean_loc, m2_loc, count_loc):
             unbiased = var * (n / (n - 1.0).clamp_min(1.0))
             bn.running_mean.mul_(1.0 - mom).add_(mean.float(), alpha=mom)
             bn.running_var.mul_(1.0 - mom).add_(unbiased.float(), alpha=mom)
-    return stat, n
+    # the kernels divide by the LOCAL row count (a host scalar); n_loc / N as a device scalar turns that into 1 / N
+    # without reading the global count back to the host
+    ratio = (float(count_loc) / n).float()
+    return stat, ratio
 
 
-def reduce_backward(bn, sums_loc):
-    """(2, C) local {sum dy, sum dy * xhat} -> the same sums over all ranks (the local copy stays untouched)."""
+def reduce_backward(bn, sums_loc, ratio):
+    """(2, C) local {sum dy, sum dy * xhat} -> the same sums over all ranks, pre-scaled by n_loc / N (see combine_forward);
+    the local copy stays untouched (it is the weight / bias gradient)."""
     g = sums_loc.clone()
     dist.all_reduce(g, group=_group(bn))
-    return g
+    return g * ratio

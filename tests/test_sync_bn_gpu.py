@@ -1,0 +1,126 @@
+"""GPU, two processes sharing the one device (gloo carries the collectives): synchronised BatchNorm inside the fused HIP
+kernels (policy/sync_bn.py).  Each rank runs PointNet + the fused set-abstraction layer on HALF of a batch; tokens,
+running statistics and every gradient must equal the single-process run on the WHOLE batch (gradients summed over the
+ranks = the whole-batch gradient: the loss below is a plain sum)."""
+import os
+import socket
+import time
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _build(dev):
+    from pointcloudmatters_amd.policy.pointnet import PointNet
+    from tests.test_sa_fused_gpu import Owner
+
+    torch.manual_seed(0)
+    net = PointNet(in_channels=6, num_classes=0).to(dev).train()
+    own = Owner(512, 96, 16).to(dev).train()
+    own.sa_impl = "fused"
+    with torch.no_grad():
+        own.bn.weight.uniform_(-1.0, 1.0)
+    return net, own
+
+
+def _run_part(net, own, clouds, dev):
+    """clouds: list of (coord (N,3), feat (N,6)); returns tokens, sum-loss gradients and running statistics."""
+    import pointcloudmatters_amd.pointops as po
+    from pointcloudmatters_amd.policy.sa_layer import set_abstraction
+
+    coord = torch.cat([c for c, _ in clouds]).to(dev)
+    feat = torch.cat([f for _, f in clouds]).to(dev)
+    sizes = [c.shape[0] for c, _ in clouds]
+    off = torch.tensor(sizes).cumsum(0).to(torch.int32)
+    off._pcm_host = off.tolist()
+    noff = (torch.arange(len(sizes)) + 1).mul(64).to(torch.int32)
+    noff._pcm_host = noff.tolist()
+    off, noff = off.to(dev), noff.to(dev)
+    off._pcm_host, noff._pcm_host = off.tolist(), noff.tolist()
+    x = net({"feat": feat})
+    _, tok, _ = set_abstraction(own, po, coord, x, off, noff, impl="fused")
+    w = torch.linspace(0.5, 1.5, tok.shape[1], device=dev)
+    (tok * w).sum().backward()
+    grads = {n: p.grad.detach().clone() for n, p in list(net.named_parameters()) + [("sa." + k, v) for k, v in own.named_parameters()]}
+    stats = {"pn.rm": net.conv5[1].running_mean.clone(), "pn.rv": net.conv5[1].running_var.clone(),
+             "sa.rm": own.bn.running_mean.clone(), "sa.rv": own.bn.running_var.clone()}
+    return tok.detach(), grads, stats
+
+
+def _clouds():
+    g = torch.Generator().manual_seed(5)
+    out = []
+    for n in (300, 420, 260, 380):
+        out.append((torch.rand(n, 3, generator=g) * 0.8 - 0.4, torch.randn(n, 6, generator=g)))
+    return out
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pointcloudmatters_amd.policy.sync_bn import enable_sync_batchnorm
+
+        dev = torch.device("cuda:0")
+        net, own = _build(dev)
+        holder = torch.nn.ModuleDict({"net": net, "own": own})
+        own.fused_batchnorms = lambda: [own.bn]
+        enable_sync_batchnorm(holder)
+        assert getattr(own.bn, "_pcm_sync", False) and getattr(net.conv1[1], "_pcm_sync", False)
+        clouds = _clouds()
+        mine = clouds[:2] if rank == 0 else clouds[2:]  # ragged split: 720 vs 640 points
+        tok, grads, stats = _run_part(net, own, mine, dev)
+        for k in grads:
+            dist.all_reduce(grads[k])
+        # numpy payloads: a tensor in a queue is a shared-memory handle that dies with this process
+        if rank == 0:
+            q.put({"tok": tok.cpu().numpy(), "grads": {k: v.cpu().numpy() for k, v in grads.items()},
+                   "stats": {k: v.cpu().numpy() for k, v in stats.items()}})
+        else:
+            q.put({"tok1": tok.cpu().numpy(), "stats1": {k: v.cpu().numpy() for k, v in stats.items()}})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fused_batchnorm_statistics_are_exchanged(hip_device):
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(3000):
+        while not q.empty():
+            got.update(q.get())
+        if len(got) >= 5 or any(p.exitcode not in (None, 0) for p in procs):
+            break
+        time.sleep(0.1)
+    for p in procs:
+        p.join(120)
+        if p.is_alive():
+            p.kill()
+        assert p.exitcode == 0
+    assert "tok" in got and "tok1" in got
+    net, own = _build(hip_device)
+    tok, grads, stats = _run_part(net, own, _clouds(), hip_device)  # the whole batch on one process
+    tok2 = torch.cat([torch.from_numpy(got["tok"]), torch.from_numpy(got["tok1"])])
+    assert (tok2 - tok.cpu()).abs().max() <= 1e-4 * tok.abs().max().item() + 1e-5
+    for k, v in stats.items():  # identical running statistics on both ranks == whole-batch statistics
+        torch.testing.assert_close(torch.from_numpy(got["stats"][k]), v.cpu(), rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(torch.from_numpy(got["stats1"][k]), v.cpu(), rtol=1e-4, atol=1e-5)
+    for k, v in grads.items():
+        ref = v.cpu()
+        assert (torch.from_numpy(got["grads"][k]) - ref).norm() <= 2e-3 * ref.norm() + 1e-5, k
