@@ -162,10 +162,12 @@ def test_dp_training_step(hip_device, mode):
     assert last == last and last < first, (first, last)
 
 
-def test_graph_mode_coexists_with_rccl_process_group(hip_device):
+@pytest.mark.parametrize("mode", ["graph", "hybrid"])
+def test_graph_mode_coexists_with_rccl_process_group(mode, hip_device):
     """Single-rank RCCL group on the one GPU of this box: the communicator (and its watchdog thread) exists
-    while the step is captured into a hipGraph, and the flat-gradient all-reduce runs between replays --
-    the exact call sequence bench.py uses for N > 1 (the multi-GPU run itself belongs to the driver)."""
+    while the step is captured into hipGraphs (one per backward stage), and the asynchronous slab all-reduces run
+    between the replays -- the exact call sequence bench.py uses for N > 1 (the multi-GPU run itself belongs to the
+    driver)."""
     import os
 
     import torch.distributed as dist
@@ -183,12 +185,25 @@ def test_graph_mode_coexists_with_rccl_process_group(hip_device):
         torch.manual_seed(0)
         pol = build_act_policy(pcd_npoints=64, sa_impl="fused", hidden_dim=768, nhead=4, num_encoder_layers=1,
                                num_decoder_layers=2).to(hip_device)
-        tr = BCTrainer(pol, total_steps=100, precision="bf16", device=hip_device, mode="graph", optim=dict(accumulate_grad_batches=1))
-        tr.distributed, tr.world = True, 1  # exercise the all-reduce branch with a world of one
-        batch = make_act_batch(4, 256, seed=3, device=hip_device)
-        for _ in range(6):
-            tr.training_step(clone_batch(batch))
-        assert tr.mode == "graph" and tr._graph is not None
+        tr = BCTrainer(pol, total_steps=100, precision="bf16", device=hip_device, mode=mode, staged=True,
+                       optim=dict(accumulate_grad_batches=1))
+        tr.distributed, tr.world = True, 1  # exercise the exchange branch with a world of one
+        calls = []
+        real = dist.all_reduce
+
+        def counting(t, *a, **k):
+            calls.append(t.numel())
+            return real(t, *a, **k)
+
+        dist.all_reduce = counting
+        try:
+            batch = make_act_batch(4, 256, seed=3, device=hip_device)
+            for _ in range(6):
+                tr.training_step(clone_batch(batch))
+        finally:
+            dist.all_reduce = real
+        assert tr.mode == mode and tr._graph is not None and len(tr._stages) == 4
+        assert len(calls) == 6 * 4 and sum(calls[:4]) == tr.optimizer.flat_g.numel()  # four slabs per step cover the buffer
         m = tr.metrics()
         assert m["train/loss"] == m["train/loss"]
     finally:
