@@ -572,8 +572,8 @@ def cpu_baseline(wl, steps, threads=16):
 
 def run_workload(name, args, device, world, rank, steps, warmup, precision=None, mode="auto", trace_steps=0):
     """Build the policy + trainer of workload `name`, run warm-up + `steps` timed steps."""
-    from pointcloudmatters_amd.bc import (DP_OPTIM, BCTrainer, WORKLOADS, build_act_policy, build_dp_policy, clone_batch,
-                                          make_act_batch, make_dp_batch)
+    from pointcloudmatters_amd.bc import (DP_OPTIM, RLBENCH_ACT_MODEL, RLBENCH_ACT_OPTIM, BCTrainer, WORKLOADS, build_act_policy,
+                                          build_dp_policy, build_rlbench_act_policy, clone_batch, make_act_batch, make_dp_batch)
 
     wl = dict(WORKLOADS[name])
     if precision is not None:
@@ -581,8 +581,16 @@ def run_workload(name, args, device, world, rank, steps, warmup, precision=None,
     sa_impl = "fused" if args.sa_impl == "auto" else args.sa_impl
     torch.manual_seed(1000 + rank)
     is_dp = wl["policy"] == "dp"
-    build = build_dp_policy if is_dp else build_act_policy
+    is_rlb = wl["policy"] == "act_rlbench"
+    build = build_dp_policy if is_dp else (build_rlbench_act_policy if is_rlb else build_act_policy)
     make_batch = make_dp_batch if is_dp else make_act_batch
+    if is_rlb:  # RLBench ACT: 11-d action / proprioception, 512-d task embedding (configs/model/rlbench_act_pcd_model.yaml)
+        m = RLBENCH_ACT_MODEL
+
+        def make_batch(b, n, **kw):  # noqa: F811
+            out = make_act_batch(b, n, action_dim=m["action_dim"], qpos_dim=m["qpos_dim"], goal_cond_dim=m["goal_cond_dim"], **kw)
+            out["actions"][..., -2:] = (out["actions"][..., -2:] > 0).float()
+            return out
     extra = {} if is_dp else {"dead_decoder_layers": args.dead_decoder_layers}
     policy = build(pcd_npoints=wl["pcd_npoints"], sa_impl=sa_impl, **extra).to(device)
     if mode == "auto":
@@ -592,7 +600,8 @@ def run_workload(name, args, device, world, rank, steps, warmup, precision=None,
         # captured stages are exchanged between graph replays, overlapping the rest of backward.
         mode = "hybrid" if (wl["ragged"] or world > 1) else "graph"
     trainer = BCTrainer(policy, total_steps=max(steps + warmup + trace_steps, 100), precision=wl["dtype"], device=device,
-                        distributed=world > 1, optim=dict(DP_OPTIM) if is_dp else dict(accumulate_grad_batches=1), mode=mode)
+                        distributed=world > 1, mode=mode,
+                        optim=dict(DP_OPTIM) if is_dp else (dict(RLBENCH_ACT_OPTIM) if is_rlb else dict(accumulate_grad_batches=1)))
     batches = [make_batch(wl["batch"], wl["n_points"], seed=1000 + rank + 97 * i, ragged=wl["ragged"], device=device)
                for i in range(4)]
 
@@ -651,7 +660,8 @@ def main():
     if rank == 0:
         samples = wl["batch"] * world * args.steps
         out = {
-            "metric": "BC train samples/sec (obs->action), PointNet + SA tokenizer + " + ("DiffusionPolicy" if is_dp else "ACT"),
+            "metric": "BC train samples/sec (obs->action), PointNet + SA tokenizer + " + (
+                "DiffusionPolicy" if is_dp else ("ACT (RLBench head)" if wl["policy"] == "act_rlbench" else "ACT")),
             "value": round(samples / dt, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": wl["dtype"], "data": "synthetic",

@@ -3,12 +3,17 @@ configs/model/maniskill2_act_pcd_model.yaml:27-68 in the reference)."""
 import torch.nn as nn
 
 from ..policy import ACTPCD, KLDivergence, PointNet, Transformer, TransformerEncoder
-from .configs import ACT_MODEL, DP_MODEL
+from .configs import ACT_MODEL, DP_MODEL, RLBENCH_ACT_MODEL
+
+
+def build_rlbench_act_policy(pcd_npoints, **kw):
+    """ACTRLBenchPCD as configs/model/rlbench_act_pcd_model.yaml instantiates it."""
+    return build_act_policy(pcd_npoints, _base=RLBENCH_ACT_MODEL, **kw)
 
 
 def build_act_policy(pcd_npoints, pointops=None, sa_impl="reference", overlap_sampling=True, dead_decoder_layers="keep",
-                     **overrides):
-    c = dict(ACT_MODEL)
+                     _base=None, **overrides):
+    c = dict(ACT_MODEL if _base is None else _base)
     c.update(overrides)
     backbone = PointNet(in_channels=c["in_channels"], num_classes=0)
     transformer = Transformer(
@@ -20,13 +25,19 @@ def build_act_policy(pcd_npoints, pointops=None, sa_impl="reference", overlap_sa
         d_model=c["hidden_dim"], dropout=c["dropout"], nhead=c["nhead"], dim_feedforward=c["dim_feedforward"],
         num_layers=c["num_encoder_layers"], normalize_before=c["normalize_before"], activation="relu",
     )
-    return ACTPCD(
+    cls, extra = ACTPCD, {}
+    if "rot_type" in c:
+        from ..policy import ACTRLBenchPCD
+
+        cls = ACTRLBenchPCD
+        extra = dict(rot_type=c["rot_type"], collision=c["collision"], position_loss_weight=c["position_loss_weight"])
+    return cls(
         backbone=backbone, transformer=transformer, encoder=encoder, hidden_dim=c["hidden_dim"],
         num_queries=c["num_queries"], num_cameras=1, action_dim=c["action_dim"], qpos_dim=c["qpos_dim"],
         env_state_dim=0, latent_dim=c["latent_dim"], action_loss=nn.MSELoss(reduction="none"),
         klloss=KLDivergence(), kl_weight=c["kl_weight"], goal_cond_dim=c["goal_cond_dim"],
         pcd_nsample=c["pcd_nsample"], pcd_npoints=pcd_npoints, pointops=pointops, sa_impl=sa_impl,
-        overlap_sampling=overlap_sampling, dead_decoder_layers=dead_decoder_layers,
+        overlap_sampling=overlap_sampling, dead_decoder_layers=dead_decoder_layers, **extra,
     )
 
 

@@ -17,6 +17,12 @@ ACT_MODEL = dict(
 ACT_OPTIM = dict(lr=5e-5, weight_decay=0.05, pct_start=0.1, div_factor=100.0, final_div_factor=1000.0,
                  gradient_clip_val=0.5, accumulate_grad_batches=2)
 
+# RLBench ACT: /root/reference/configs/model/rlbench_act_pcd_model.yaml:4-65, configs/data/rlbench_act_pcd_dataset.yaml:13-19
+# (chunk_size 100, action_dim = qpos_dim = 11: position 3 + 6-D rotation + gripper + collision; 512-d task embedding)
+RLBENCH_ACT_MODEL = dict(ACT_MODEL, action_dim=11, qpos_dim=11, goal_cond_dim=512, kl_weight=10.0, rot_type="6d", collision=True,
+                         position_loss_weight=10.0)
+RLBENCH_ACT_OPTIM = dict(ACT_OPTIM, lr=1e-4, pct_start=0.15, accumulate_grad_batches=1)
+
 # Diffusion Policy: /root/reference/configs/model/maniskill2_diffusion_policy_model.yaml:10-60,
 # exp_maniskill2_diffusion_policy/maniskill2_model/scratch_pointnet_pcd.yaml:10-35 (PointNet num_classes 96,
 # SA hidden 96, projector [96,128,128] with 1 layer), data chunk_size 16, qpos 9-d.
@@ -44,6 +50,8 @@ WORKLOADS = {
     # configs[4]: per-GPU shape of the RLBench 4096-pt Diffusion-Policy run
     "C5": dict(policy="dp", batch=16, n_points=4096, pcd_npoints=2048, dtype="bf16", ragged=False),
     "REF": dict(policy="act", batch=8, n_points=4096, pcd_npoints=2048, dtype="bf16", ragged=True),
+    # configs[4]-shaped ACT: RLBench multi-view fused cloud (ragged ~4096 points) -> 2048 tokens, ACTRLBenchPCD head
+    "RLB": dict(policy="act_rlbench", batch=8, n_points=4096, pcd_npoints=2048, dtype="bf16", ragged=True),
     # C2 with ragged clouds: the headline shape as real data delivers it (mode="hybrid")
     "C2R": dict(policy="act", batch=8, n_points=1024, pcd_npoints=512, dtype="bf16", ragged=True),
     # C3 with ragged clouds (what GridSamplePCD really delivers): exercises mode="hybrid" for the Diffusion-Policy trainer

@@ -1,5 +1,5 @@
 """Policies and point-cloud tokenizers of the BC path (reference: src/models/components/)."""
-from .act import ACTPCD
+from .act import ACTPCD, ACTRLBenchPCD
 from .losses import KLDivergence
 from .pointnet import PointNet
 from .transformer import Transformer, TransformerEncoder

@@ -332,3 +332,62 @@ class ACTPCD(nn.Module):
         if not data_dict["is_training"]:
             return data_dict
         return self.forward_loss(data_dict)
+
+
+class ACTRLBenchPCD(ACTPCD):
+    """RLBench variant of the point-cloud ACT (/root/reference/src/models/components/act/act.py:707-825): the action is
+    (position 3, rotation in the 6-D representation, gripper open, [collision flag]); gripper / collision go through a
+    sigmoid, the position error is weighted, and at rollout time the rotation leaves as a quaternion.  Same constructor
+    arguments and state-dict keys as the reference class (configs/model/rlbench_act_pcd_model.yaml:20-65)."""
+
+    def __init__(self, backbone, transformer, encoder, hidden_dim, num_queries, num_cameras=0, action_dim=8, qpos_dim=9,
+                 env_state_dim=0, latent_dim=32, action_loss=None, klloss=None, kl_weight=20.0, goal_cond_dim=0,
+                 obs_feature_pos_embedding=None, freeze_backbone=False, pcd_nsample=16, pcd_npoints=1024, sampling="fps",
+                 heatmap_th=0.1, ignore_vae=False, rot_type="6d", collision=False, position_loss_weight=1.0, use_mask=False,
+                 bg_ratio=0.0, **kwargs):
+        super().__init__(backbone=backbone, transformer=transformer, encoder=encoder, hidden_dim=hidden_dim,
+                         num_queries=num_queries, num_cameras=0, action_dim=action_dim, qpos_dim=qpos_dim,
+                         env_state_dim=env_state_dim, latent_dim=latent_dim, action_loss=action_loss, klloss=klloss,
+                         kl_weight=kl_weight, goal_cond_dim=goal_cond_dim, obs_feature_pos_embedding=None,
+                         freeze_backbone=freeze_backbone, pcd_nsample=pcd_nsample, pcd_npoints=pcd_npoints, sampling=sampling,
+                         heatmap_th=heatmap_th, ignore_vae=ignore_vae, use_mask=use_mask, bg_ratio=bg_ratio, **kwargs)
+        if rot_type != "6d":
+            raise NotImplementedError(rot_type)  # the reference's rollout branch raises for anything else (act.py:790-794)
+        self.rot_type = rot_type
+        self.collision = collision
+        self.position_loss_weight = position_loss_weight
+
+    def forward_decoder(self, data_dict):
+        hs = self.transformer(
+            data_dict["src"], None, self.query_embed.weight, data_dict["pos"], data_dict["latent_input"],
+            data_dict["proprio_input"], self.additional_pos_embed.weight,
+        )[0]
+        a_hat = self.action_head(hs)  # (B, num_queries, action_dim)
+        position = a_hat[..., :3]
+        if self.collision:  # (..., gripper, collision) are the last two entries
+            gripper = torch.sigmoid(a_hat[..., -2:])
+            rot = a_hat[..., 3:-2]
+        else:
+            gripper = torch.sigmoid(a_hat[..., -1:])
+            rot = a_hat[..., 3:-1]
+        if not data_dict["is_training"]:
+            from .rotations import matrix_to_quaternion, rotation_6d_to_matrix
+
+            rot = matrix_to_quaternion(rotation_6d_to_matrix(rot.float()))
+        data_dict["a_hat"] = torch.cat([position, rot, gripper], dim=-1)
+        data_dict["is_pad_hat"] = self.is_pad_head(hs)
+        return data_dict
+
+    def forward_loss(self, data_dict):
+        from . import staging
+
+        mu, logvar = staging.cut("transformer.encoder", data_dict["mu"], data_dict["logvar"], consumed_above="transformer.decoder")
+        total_kld = self.klloss(mu, logvar)
+        action_loss = self.action_loss(data_dict["a_hat"].float(), data_dict["actions"])
+        weight = action_loss.new_ones(action_loss.shape[-1])
+        weight[:3] = self.position_loss_weight  # act.py:816: the position error counts position_loss_weight times
+        action_loss = (action_loss * weight * ~data_dict["is_pad"].unsqueeze(-1)).mean()
+        data_dict["action_loss"] = action_loss
+        data_dict["kl_loss"] = total_kld
+        data_dict["loss"] = action_loss + total_kld * self.kl_weight
+        return data_dict

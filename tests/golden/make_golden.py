@@ -188,6 +188,75 @@ def golden_act(ref):
     print("act_pcd_small.npz: loss", float(out["loss"]), "action", float(out["action_loss"]), "kl", float(out["kl_loss"]))
 
 
+RLB_SMALL = dict(SMALL, action_dim=11, qpos_dim=11, goal_cond_dim=16, rot_type="6d", collision=True, position_loss_weight=10.0)
+
+
+def golden_rlbench(ref):
+    """Reference ACTRLBenchPCD (act.py:707-825): training forward / backward with the weighted position loss and the sigmoid
+    gripper / collision outputs, and the rollout branch (6-D rotation -> quaternion through rotation_conversions.py)."""
+    from oracle import pointops_cpu
+    from pointcloudmatters_amd.bc import build_rlbench_act_policy, make_act_batch
+    from pointcloudmatters_amd.policy import PointNet
+
+    c = RLB_SMALL
+    pcd_npoints = 32
+    torch.manual_seed(4321)
+    kw = {k: v for k, v in c.items() if k not in ("rot_type", "collision", "position_loss_weight")}
+    ours = build_rlbench_act_policy(pcd_npoints=pcd_npoints, pointops=pointops_cpu, sa_impl="reference", **kw)
+    transformer = ref.transformer.Transformer(
+        d_model=c["hidden_dim"], dropout=c["dropout"], nhead=c["nhead"], dim_feedforward=c["dim_feedforward"],
+        num_encoder_layers=c["num_encoder_layers"], num_decoder_layers=c["num_decoder_layers"], normalize_before=False,
+        return_intermediate_dec=True)
+    encoder = ref.transformer.TransformerEncoder(
+        d_model=c["hidden_dim"], dropout=c["dropout"], nhead=c["nhead"], dim_feedforward=c["dim_feedforward"],
+        num_layers=c["num_encoder_layers"], normalize_before=False, activation="relu")
+    model = ref.act.ACTRLBenchPCD(
+        backbone=PointNet(in_channels=6, num_classes=0), transformer=transformer, encoder=encoder, hidden_dim=c["hidden_dim"],
+        num_queries=c["num_queries"], num_cameras=1, action_dim=c["action_dim"], qpos_dim=c["qpos_dim"], env_state_dim=0,
+        latent_dim=c["latent_dim"], action_loss=torch.nn.MSELoss(reduction="none"), klloss=ref.loss.KLDivergence(),
+        kl_weight=c["kl_weight"], goal_cond_dim=c["goal_cond_dim"], pcd_nsample=c["pcd_nsample"], pcd_npoints=pcd_npoints,
+        rot_type="6d", collision=True, position_loss_weight=c["position_loss_weight"])
+    model.load_state_dict(ours.state_dict(), strict=True)
+    model.train()
+    batch = make_act_batch(3, 160, seed=88, ragged=True, num_queries=c["num_queries"], action_dim=c["action_dim"],
+                           qpos_dim=c["qpos_dim"], goal_cond_dim=c["goal_cond_dim"])
+    batch["actions"][..., -2:] = (batch["actions"][..., -2:] > 0).float()  # gripper / collision targets are 0 / 1
+    eps = torch.randn(3, c["latent_dim"], generator=torch.Generator().manual_seed(6))
+    orig = ref.act.reparametrize
+    ref.act.reparametrize = lambda mu, logvar: mu + logvar.div(2).exp() * eps
+    try:
+        dd = {k: (dict(v) if isinstance(v, dict) else v) for k, v in batch.items()}
+        out = model(dd)
+        out["loss"].backward()
+    finally:
+        ref.act.reparametrize = orig
+    grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    fx = {"eps": eps.numpy()}
+    for k, v in batch.items():
+        if isinstance(v, dict):
+            for kk, vv in v.items():
+                fx[f"in.pcds.{kk}"] = vv.numpy()
+        else:
+            fx[f"in.{k}"] = v.numpy()
+    for k, v in ours.state_dict().items():
+        fx[f"w.{k}"] = v.numpy()
+    for k in ("a_hat", "mu", "logvar", "loss", "action_loss", "kl_loss"):
+        fx[f"out.{k}"] = out[k].detach().numpy()
+    for k in ("action_head.weight", "action_head.bias", "linear.weight", "backbone.conv1.0.weight", "latent_proj.weight",
+              "transformer.decoder.layers.0.multihead_attn.out_proj.weight", "proj_goal_cond_emb.weight"):
+        fx[f"grad.{k}"] = grads[k].numpy()
+    # rollout branch: no actions -> zero latent, quaternion output
+    model.eval()
+    ev = make_act_batch(3, 160, seed=88, ragged=True, num_queries=c["num_queries"], action_dim=c["action_dim"],
+                        qpos_dim=c["qpos_dim"], goal_cond_dim=c["goal_cond_dim"])
+    ev.pop("actions"), ev.pop("is_pad")
+    with torch.no_grad():
+        eo = model(ev)
+    fx["eval.a_hat"] = eo["a_hat"].numpy()
+    np.savez_compressed(os.path.join(OUT, "act_rlbench_small.npz"), **fx)
+    print("act_rlbench_small.npz: loss", float(out["loss"]), "eval a_hat", tuple(eo["a_hat"].shape))
+
+
 def golden_grouping(ref):
     g = torch.Generator().manual_seed(3)
     n, m, k, c = 50, 12, 16, 5
@@ -426,6 +495,6 @@ if __name__ == "__main__":
     ref = install_reference()
     only = set(sys.argv[1:])  # e.g. `make_golden.py rollout` regenerates one fixture
     for name, fn in (("act", golden_act), ("grouping", golden_grouping), ("misc", golden_misc), ("dp", golden_dp),
-                     ("rollout", golden_rollout), ("gridsample", golden_gridsample)):
+                     ("rollout", golden_rollout), ("gridsample", golden_gridsample), ("rlbench", golden_rlbench)):
         if not only or name in only:
             fn(ref)
