@@ -592,6 +592,9 @@ def run_workload(name, args, device, world, rank, steps, warmup, precision=None,
             out["actions"][..., -2:] = (out["actions"][..., -2:] > 0).float()
             return out
     extra = {} if is_dp else {"dead_decoder_layers": args.dead_decoder_layers}
+    for opt_key in ("backbone", "obs_encoder"):  # the hierarchical encoders of policy/pointnet2.py (C4N, C5B)
+        if opt_key in wl:
+            extra[opt_key] = wl[opt_key]
     policy = build(pcd_npoints=wl["pcd_npoints"], sa_impl=sa_impl, **extra).to(device)
     if mode == "auto":
         # ragged clouds: the tokenizer runs eagerly, everything behind the fixed-size token matrix replays as hipGraphs.

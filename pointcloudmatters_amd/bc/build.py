@@ -12,10 +12,18 @@ def build_rlbench_act_policy(pcd_npoints, **kw):
 
 
 def build_act_policy(pcd_npoints, pointops=None, sa_impl="reference", overlap_sampling=True, dead_decoder_layers="keep",
-                     _base=None, **overrides):
+                     _base=None, backbone="pointnet", **overrides):
+    """backbone: "pointnet" (the reference's per-point MLP) or "pointnext" (policy/pointnet2.PointNeXtBackbone: InvResMLP
+    blocks in front of the same SA tokenizer -- no reference counterpart, BASELINE configs[3])."""
     c = dict(ACT_MODEL if _base is None else _base)
     c.update(overrides)
-    backbone = PointNet(in_channels=c["in_channels"], num_classes=0)
+    if backbone == "pointnext":
+        from ..policy.pointnet2 import PointNeXtBackbone
+
+        backbone = PointNeXtBackbone(in_channels=c["in_channels"], width=c.get("pointnext_width", 64), blocks=c.get("pointnext_blocks", 2),
+                                     nsample=c["pcd_nsample"], out_channels=512, pointops=pointops, sa_impl=sa_impl)
+    else:
+        backbone = PointNet(in_channels=c["in_channels"], num_classes=0)
     transformer = Transformer(
         d_model=c["hidden_dim"], dropout=c["dropout"], nhead=c["nhead"], dim_feedforward=c["dim_feedforward"],
         num_encoder_layers=c["num_encoder_layers"], num_decoder_layers=c["num_decoder_layers"],
@@ -41,8 +49,10 @@ def build_act_policy(pcd_npoints, pointops=None, sa_impl="reference", overlap_sa
     )
 
 
-def build_dp_policy(pcd_npoints, pointops=None, sa_impl="reference", overlap_sampling=True, **overrides):
-    """configs/exp_maniskill2_diffusion_policy/maniskill2_model/scratch_pointnet_pcd.yaml, instantiated."""
+def build_dp_policy(pcd_npoints, pointops=None, sa_impl="reference", overlap_sampling=True, obs_encoder="pointnet_sa", **overrides):
+    """configs/exp_maniskill2_diffusion_policy/maniskill2_model/scratch_pointnet_pcd.yaml, instantiated.
+    obs_encoder: "pointnet_sa" (the reference's PCDObsEncoder) or "patchbert" (policy/pointnet2.PatchBertObsEncoder: patch
+    tokens + transformer encoder -- no reference counterpart, BASELINE configs[4]; pcd_npoints = number of patches)."""
     from ..policy.diffusion import DDPMSchedule, DiffusionUnetPcdPolicy, PCDObsEncoder
 
     c = dict(DP_MODEL)
@@ -50,11 +60,19 @@ def build_dp_policy(pcd_npoints, pointops=None, sa_impl="reference", overlap_sam
     shape_meta = {"obs": {"pcds": {"shape": [c["in_channels"]], "type": "pcd"},
                           "qpos": {"shape": [c["qpos_dim"]], "type": "low_dim"}},
                   "action": {"shape": [c["action_dim"]]}}
-    pcd_model = PointNet(in_channels=c["in_channels"], num_classes=c["pcd_num_classes"])
-    enc = PCDObsEncoder(shape_meta=shape_meta, pcd_model=pcd_model, share_pcd_model=True, n_obs_step=c["n_obs_steps"],
-                        pcd_nsample=c["pcd_nsample"], pcd_npoints=pcd_npoints, pcd_hidden_dim=c["pcd_hidden_dim"],
-                        projector_layers=c["projector_layers"], projector_channels=c["projector_channels"],
-                        pointops=pointops, sa_impl=sa_impl, overlap_sampling=overlap_sampling)
+    if obs_encoder == "patchbert":
+        from ..policy.pointnet2 import PatchBertObsEncoder
+
+        enc = PatchBertObsEncoder(shape_meta, num_groups=pcd_npoints, group_size=c.get("patch_size", 32),
+                                  hidden_dim=c.get("bert_dim", 384), depth=c.get("bert_depth", 4), nhead=c.get("bert_heads", 6),
+                                  out_channels=c["projector_channels"][-1], n_obs_step=c["n_obs_steps"], pointops=pointops,
+                                  sa_impl=sa_impl)
+    else:
+        pcd_model = PointNet(in_channels=c["in_channels"], num_classes=c["pcd_num_classes"])
+        enc = PCDObsEncoder(shape_meta=shape_meta, pcd_model=pcd_model, share_pcd_model=True, n_obs_step=c["n_obs_steps"],
+                            pcd_nsample=c["pcd_nsample"], pcd_npoints=pcd_npoints, pcd_hidden_dim=c["pcd_hidden_dim"],
+                            projector_layers=c["projector_layers"], projector_channels=c["projector_channels"],
+                            pointops=pointops, sa_impl=sa_impl, overlap_sampling=overlap_sampling)
     sched = DDPMSchedule(num_train_timesteps=c["num_train_timesteps"], beta_schedule="squaredcos_cap_v2",
                          prediction_type="epsilon")
     pol = DiffusionUnetPcdPolicy(shape_meta=shape_meta, noise_scheduler=sched, obs_encoder=enc, horizon=c["horizon"],

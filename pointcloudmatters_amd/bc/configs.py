@@ -50,6 +50,10 @@ WORKLOADS = {
     # configs[4]: per-GPU shape of the RLBench 4096-pt Diffusion-Policy run
     "C5": dict(policy="dp", batch=16, n_points=4096, pcd_npoints=2048, dtype="bf16", ragged=False),
     "REF": dict(policy="act", batch=8, n_points=4096, pcd_npoints=2048, dtype="bf16", ragged=True),
+    # configs[3] with the backbone it names: PointNeXt (InvResMLP blocks, policy/pointnet2.py) in front of the SA tokenizer
+    "C4N": dict(policy="act", batch=8, n_points=2048, pcd_npoints=1024, dtype="bf16", ragged=False, backbone="pointnext"),
+    # configs[4] with the encoder it names: PointBERT-style patch tokens + transformer encoder -> Diffusion Policy
+    "C5B": dict(policy="dp", batch=16, n_points=4096, pcd_npoints=128, dtype="bf16", ragged=False, obs_encoder="patchbert"),
     # configs[4]-shaped ACT: RLBench multi-view fused cloud (ragged ~4096 points) -> 2048 tokens, ACTRLBenchPCD head
     "RLB": dict(policy="act_rlbench", batch=8, n_points=4096, pcd_npoints=2048, dtype="bf16", ragged=True),
     # C2 with ragged clouds: the headline shape as real data delivers it (mode="hybrid")

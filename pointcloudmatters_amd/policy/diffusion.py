@@ -496,6 +496,10 @@ class PCDObsEncoder(_AttrMixin):
             x = conv1d_gemm(x, layer) if isinstance(layer, nn.Conv1d) else layer(x.contiguous() if isinstance(layer, nn.BatchNorm1d) else x)
         return x.squeeze(-1)
 
+    def pcd_features(self, pcd_dict):
+        """packed clouds -> (b, C) features: the eager half of the hybrid trainer mode."""
+        return self.encode_pcd(self.key_model_map["pcd"], pcd_dict)
+
     def forward(self, obs_dict):
         feats, batch = [], None
         for key in self.pcd_keys:
@@ -680,8 +684,7 @@ class DiffusionUnetPcdPolicy(_AttrMixin):
 
     def forward(self, batch, stage=None):
         if stage == "tokenize":  # packed clouds -> per-cloud features (b, C): the part whose shapes follow the cloud sizes
-            enc = self.obs_encoder
-            return (enc.encode_pcd(enc.key_model_map["pcd"], batch["obs"]["pcds"]),)
+            return (self.obs_encoder.pcd_features(batch["obs"]["pcds"]),)
         out = self.compute_loss(batch)
         out.setdefault("action_loss", out["loss"])
         out.setdefault("kl_loss", out["loss"].new_zeros(()))
