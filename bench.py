@@ -210,8 +210,9 @@ def pointops_and_sa_kernels(t, shape, device):
         feat.grad = None
         grouped.backward(gout, retain_graph=True)
 
-    t.add("pcm_group_xyz_feat_bwd_kernel", timed_events(gbwd, 20), rows * c_feat * 4 + 4 * rows + n_tot * c_feat * 4, "hbm",
-          "API op backward: coalesced fp32 atomics")
+    t.add("pcm_group_xyz_feat backward (plan + pcm_segment_sum_kernel)", timed_events(gbwd, 20),
+          rows * (c_feat + 3) * 4 + 12 * rows + n_tot * c_feat * 4, "hbm",
+          "API op backward: idx inverted to a CSR (5 small launches), then every feature row summed once, no atomics")
     del grouped, gout
     # ---- interpolation (kNN k=3 weights + gather) and ball query, API ops ----------------------------------
     try:
@@ -219,17 +220,28 @@ def pointops_and_sa_kernels(t, shape, device):
 
         featm = torch.randn(m, c_feat, device=device).requires_grad_(True)
         out = interpolation(n_p, coord, featm, noff, off, k=3)
-        t.add("pcm_interpolation (knn3 + fwd)", timed_events(lambda: interpolation(n_p, coord, featm, noff, off, k=3), 10),
+        t.add("pcm_interpolation (knn3 + weights + forward)", timed_events(lambda: interpolation(n_p, coord, featm, noff, off, k=3), 10),
               n_tot * 3 * 8 + min(n_tot * 3, m) * c_feat * 4 + n_tot * c_feat * 4, "hbm",
               "API op: 3-NN inverse-distance interpolation of (m, C) features onto the n points")
+        idx3, _ = po.knn_query(3, n_p, noff, coord, off)
+        w3 = torch.rand(n_tot, 3, device=device)
+        o3 = torch.empty(n_tot, c_feat, device=device)
+        L, st = _lib.load(), torch.cuda.current_stream().cuda_stream
+        fm = featm.detach()
+        t.add("pcm_interpolation forward (pcm_segment_sum_kernel)",
+              timed_events(lambda: L.pcm_interpolation_forward_hip(n_tot, c_feat, 3, fm.data_ptr(), idx3.data_ptr(), w3.data_ptr(),
+                                                                   o3.data_ptr(), st), 20),
+              n_tot * 3 * 8 + m * c_feat * 4 + n_tot * c_feat * 4, "hbm",
+              "the gather alone: one lane group per output row, 16-byte loads, (idx, weight) fetched once per group")
         go = torch.randn_like(out)
 
         def ibwd():
             featm.grad = None
             out.backward(go, retain_graph=True)
 
-        t.add("pcm_interpolation_bwd_kernel", timed_events(ibwd, 10), n_tot * c_feat * 4 + n_tot * 3 * 8 + m * c_feat * 4, "hbm",
-              "API op backward: scatter of n*C gradients onto m rows")
+        t.add("pcm_interpolation backward (plan + pcm_segment_sum_kernel)", timed_events(ibwd, 10),
+              n_tot * c_feat * 4 + n_tot * 3 * 16 + m * c_feat * 4, "hbm",
+              "API op backward: n*3 (idx, weight) pairs inverted to a CSR, every coarse row summed once, no atomics")
         msb = timed_events(lambda: po.ball_query(k, 0.1, 0.0, coord, off, n_p, noff), 10)
         t.add("pcm_ball_query_kernel", msb, 12 * n_tot + 12 * m + 8 * m * k, "alu",
               "API op: radius 0.1, nsample 16; %.1f M distance evaluations" % (evals / 1e6),

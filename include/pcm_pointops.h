@@ -67,6 +67,11 @@ int pcm_knn_query_hip(int m, int nsample, const float *xyz, const float *new_xyz
 int pcm_ball_query_hip(int m, int nsample, float min_radius, float max_radius, const float *xyz,
                        const float *new_xyz, const int *offset, const int *new_offset, int *idx,
                        float *dist2, void *stream);
+/* Same, with the number of clouds b (offset / new_offset length): the owning cloud of a query is found by bisection
+ * instead of the reference's linear scan of new_offset (:64-71 get_bt_idx), which costs up to b dependent loads. */
+int pcm_ball_query_b_hip(int b, int m, int nsample, float min_radius, float max_radius, const float *xyz,
+                         const float *new_xyz, const int *offset, const int *new_offset, int *idx,
+                         float *dist2, void *stream);
 
 /* ---- K4 random ball query -------------------------------------------------------------------
  * replaces random_ball_query_cuda_launcher   random_ball_query/random_ball_query_cuda_kernel.h
@@ -76,6 +81,10 @@ int pcm_random_ball_query_hip(int m, int nsample, float min_radius, float max_ra
                               const int *order, const float *xyz, const float *new_xyz,
                               const int *offset, const int *new_offset, int *idx, float *dist2,
                               void *stream);
+int pcm_random_ball_query_b_hip(int b, int m, int nsample, float min_radius, float max_radius,
+                                const int *order, const float *xyz, const float *new_xyz,
+                                const int *offset, const int *new_offset, int *idx, float *dist2,
+                                void *stream);
 
 /* ---- K5 grouping ----------------------------------------------------------------------------
  * replaces grouping_{forward,backward}_cuda_launcher   grouping/grouping_cuda_kernel.h
@@ -90,14 +99,19 @@ int pcm_grouping_backward_hip(int m, int nsample, int c, const float *grad_outpu
 /* ---- K6 interpolation -----------------------------------------------------------------------
  * replaces interpolation_{forward,backward}_cuda_launcher   interpolation/interpolation_cuda_kernel.h
  *          (kernels: interpolation_cuda_kernel.cu:5-47; wrapper: functions/interpolation.py:25-59)
- * forward: output(n,c) += sum_k input[idx[n,k]] * weight[n,k] (k ascending; output pre-zeroed). */
+ * forward: output(n,c) = sum_k input[idx[n,k]] * weight[n,k] (k ascending; written, not accumulated -- the
+ *          reference adds into the caller's zeroed buffer, same result).
+ * backward: one atomic per element (the reference's form; grad_input pre-zeroed).  The atomic-free form is
+ *          pcm_scatter_plan_hip(n*k, m, idx) + pcm_segment_sum_hip(rowdiv = k, scale = weight), below. */
 int pcm_interpolation_forward_hip(int n, int c, int k, const float *input, const int *idx,
                                   const float *weight, float *output, void *stream);
 int pcm_interpolation_backward_hip(int n, int c, int k, const float *grad_output, const int *idx,
                                    const float *weight, float *grad_input, void *stream);
 
 /* ---- K7 subtraction -------------------------------------------------------------------------
- * replaces subtraction_{forward,backward}_cuda_launcher   subtraction/subtraction_cuda_kernel.h */
+ * replaces subtraction_{forward,backward}_cuda_launcher   subtraction/subtraction_cuda_kernel.h
+ * backward: grad_input1 is WRITTEN (segmented sum over the nsample rows of each query, no atomics); grad_input2
+ *          receives one atomic per element (pre-zeroed), or pass grad_input2 = NULL and scatter through a plan. */
 int pcm_subtraction_forward_hip(int n, int nsample, int c, const float *input1,
                                 const float *input2, const int *idx, float *output, void *stream);
 int pcm_subtraction_backward_hip(int n, int nsample, int c, const int *idx,
@@ -105,7 +119,10 @@ int pcm_subtraction_backward_hip(int n, int nsample, int c, const int *idx,
                                  void *stream);
 
 /* ---- K8 aggregation -------------------------------------------------------------------------
- * replaces aggregation_{forward,backward}_cuda_launcher   aggregation/aggregation_cuda_kernel.h */
+ * replaces aggregation_{forward,backward}_cuda_launcher   aggregation/aggregation_cuda_kernel.h
+ * backward: grad_position written, grad_weight accumulated (pre-zeroed) by one thread per (row, w_c) in a fixed
+ *          order; grad_input receives one atomic per element (pre-zeroed), or pass grad_input = NULL and scatter
+ *          through a plan (pcm_segment_sum_hip with scale_mode 2, rowdiv = nsample). */
 int pcm_aggregation_forward_hip(int n, int nsample, int c, int w_c, const float *input,
                                 const float *position, const float *weight, const int *idx,
                                 float *output, void *stream);
@@ -113,6 +130,22 @@ int pcm_aggregation_backward_hip(int n, int nsample, int c, int w_c, const float
                                  const float *position, const float *weight, const int *idx,
                                  const float *grad_output, float *grad_input, float *grad_position,
                                  float *grad_weight, void *stream);
+
+/* ---- segmented gather-sum: the atomic-free form of the scatter-adds above (csrc/segsum.hip) ----------------
+ * No reference counterpart: the reference scatters with atomicAdd (grouping_cuda_kernel.cu:24,
+ * interpolation_cuda_kernel.cu:35-40, subtraction_cuda_kernel.cu:36-38, aggregation_cuda_kernel.cu:42-46).
+ * pcm_scatter_plan_hip inverts idx (rows entries with values in [0, n_dst), negatives skipped) into a CSR held in
+ * `ws` (pcm_scatter_plan_ws_ints(rows, n_dst) ints): *start_out (n_dst + 1) and *list_out (the entries of each
+ * destination row).  pcm_segment_sum_hip then writes
+ *     dst[j, col] = sign * sum_{t in segment j} src[s(e_t) * src_stride + src_off + col] * scale(e_t, col)
+ * with segment j = [start[j], start[j+1]) (start == NULL: [j*seglen, (j+1)*seglen)), e_t = list ? list[t] : t,
+ * s(e) = map ? map[e] : e / rowdiv (negative: skipped), scale_mode 0 none | 1 scale[e] | 2 scale[e*w_c + col % w_c]. */
+int pcm_scatter_plan_ws_ints(long rows, int n_dst);
+int pcm_scatter_plan_hip(long rows, int n_dst, const int *idx, int *ws, const int **start_out,
+                         const int **list_out, void *stream);
+int pcm_segment_sum_hip(long n_dst, int c, const int *start, int seglen, const int *list, const int *map,
+                        int rowdiv, const float *scale, int scale_mode, int w_c, float sign,
+                        const float *src, int src_stride, int src_off, float *dst, void *stream);
 
 /* ---- K9 attention steps ---------------------------------------------------------------------
  * replaces attention_{relation,fusion}_step_{forward,backward}_cuda_launcher

@@ -22,6 +22,8 @@ SIGNATURES = {
     "pcm_knn_query_b_hip": [_i, _i, _i, _P, _P, _P, _P, _P, _P, _P],
     "pcm_ball_query_hip": [_i, _i, _f, _f, _P, _P, _P, _P, _P, _P, _P],
     "pcm_random_ball_query_hip": [_i, _i, _f, _f, _P, _P, _P, _P, _P, _P, _P, _P],
+    "pcm_ball_query_b_hip": [_i, _i, _i, _f, _f, _P, _P, _P, _P, _P, _P, _P],
+    "pcm_random_ball_query_b_hip": [_i, _i, _i, _f, _f, _P, _P, _P, _P, _P, _P, _P, _P],
     "pcm_grouping_forward_hip": [_i, _i, _i, _P, _P, _P, _P],
     "pcm_grouping_backward_hip": [_i, _i, _i, _P, _P, _P, _P],
     "pcm_interpolation_forward_hip": [_i, _i, _i, _P, _P, _P, _P, _P],
@@ -30,6 +32,9 @@ SIGNATURES = {
     "pcm_subtraction_backward_hip": [_i, _i, _i, _P, _P, _P, _P, _P],
     "pcm_aggregation_forward_hip": [_i, _i, _i, _i, _P, _P, _P, _P, _P, _P],
     "pcm_aggregation_backward_hip": [_i, _i, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "pcm_scatter_plan_ws_ints": [ctypes.c_long, _i],
+    "pcm_scatter_plan_hip": [ctypes.c_long, _i, _P, _P, _P, _P, _P],
+    "pcm_segment_sum_hip": [ctypes.c_long, _i, _P, _i, _P, _P, _i, _P, _i, _i, _f, _P, _i, _i, _P, _P],
     "pcm_attention_relation_step_forward_hip": [_i, _i, _i, _P, _P, _P, _P, _P, _P, _P],
     "pcm_attention_relation_step_backward_hip": [_i, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "pcm_attention_fusion_step_forward_hip": [_i, _i, _i, _P, _P, _P, _P, _P, _P],

@@ -25,8 +25,8 @@ __global__ __launch_bounds__(64) void pcm_ball_query_kernel(int m, int nsample, 
                                                            const float *__restrict__ xyz,
                                                            const float *__restrict__ new_xyz,
                                                            const int *__restrict__ offset,
-                                                           const int *__restrict__ new_offset, int *__restrict__ idx,
-                                                           float *__restrict__ dist2)
+                                                           const int *__restrict__ new_offset, int b,
+                                                           int *__restrict__ idx, float *__restrict__ dist2)
 {
     __shared__ float cd[PCM_BALL_MAX_CAND];
     __shared__ int ci[PCM_BALL_MAX_CAND];
@@ -36,33 +36,88 @@ __global__ __launch_bounds__(64) void pcm_ball_query_kernel(int m, int nsample, 
     const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
 
     for (int q = blockIdx.x; q < m; q += gridDim.x) {
-        const int bt = pcm_cloud_of(q, new_offset, 0);
+        const int bt = pcm_cloud_of(q, new_offset, b);
         const int start = bt == 0 ? 0 : offset[bt - 1];
         const int end = offset[bt];
         const float qx = new_xyz[(size_t)q * 3 + 0];
         const float qy = new_xyz[(size_t)q * 3 + 1];
         const float qz = new_xyz[(size_t)q * 3 + 2];
         int cnt = 0;
-        for (int base = start; base < end; base += 64) {
-            const int p = base + lane;
-            bool in = false;
-            float d2 = 0.f;
-            if (p < end) {
-                d2 = pcm_sqdist(qx, qy, qz, xyz[(size_t)p * 3 + 0], xyz[(size_t)p * 3 + 1], xyz[(size_t)p * 3 + 2]);
-                in = in_ball(d2, min_r2, max_r2);
+        // The scan is a chain of dependent (load -> ballot -> LDS append) rounds on ONE wave per workgroup: latency-
+        // bound.  Eight chunks of coordinates are loaded before the first ballot, so eight rounds share one memory wait.
+        constexpr int UN = 8;
+        for (int base = start; base < end; base += 64 * UN) {
+            float d2[UN];
+            bool in[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int p = base + u * 64 + lane;
+                in[u] = false;
+                d2[u] = 0.f;
+                if (p < end) {
+                    d2[u] = pcm_sqdist(qx, qy, qz, xyz[(size_t)p * 3 + 0], xyz[(size_t)p * 3 + 1], xyz[(size_t)p * 3 + 2]);
+                    in[u] = in_ball(d2[u], min_r2, max_r2);
+                }
             }
-            const unsigned long long mask = __ballot(in);
-            const int pos = cnt + __builtin_popcountll(mask & lt_mask);
-            if (in && pos < PCM_BALL_MAX_CAND) {
-                cd[pos] = d2;
-                ci[pos] = p;
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const unsigned long long mask = __ballot(in[u]);
+                const int pos = cnt + __builtin_popcountll(mask & lt_mask);
+                if (in[u] && pos < PCM_BALL_MAX_CAND) {
+                    cd[pos] = d2[u];
+                    ci[pos] = base + u * 64 + lane;
+                }
+                cnt += __builtin_popcountll(mask);
             }
-            cnt += __builtin_popcountll(mask);
         }
         __syncthreads();
         const bool overflow = cnt > PCM_BALL_MAX_CAND;  // UB in the reference; we emit an empty row
-        if (!overflow && lane == 0) {
-            // heap_sort(:33-42) on the un-heapified array, literal
+        if (!overflow && cnt > 1 && cnt <= 64) {
+            // heap_sort(:33-42) on the un-heapified array, replayed literally with the array held one element per
+            // lane: every index below is wave-uniform, so each access is a v_readlane or a v_cndmask (a few cycles)
+            // instead of a dependent LDS round trip (the serial LDS replay below was ~90 % of this kernel's time at
+            // 10-20 candidates per query).
+            float d = lane < cnt ? cd[lane] : 0.f;
+            int ix = lane < cnt ? ci[lane] : 0;
+#define PCM_RL_F(v, l) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l))
+#define PCM_WL(v, val, l) ((lane == (l)) ? (val) : (v))  // v_cmp + v_cndmask against a uniform lane id
+            for (int i = cnt - 1; i > 0; --i) {
+                const float d0 = PCM_RL_F(d, 0), di = PCM_RL_F(d, i);
+                const int x0 = __builtin_amdgcn_readlane(ix, 0), xi = __builtin_amdgcn_readlane(ix, i);
+                d = PCM_WL(d, di, 0);
+                d = PCM_WL(d, d0, i);
+                ix = PCM_WL(ix, xi, 0);
+                ix = PCM_WL(ix, x0, i);
+                int root = 0, child = 1;
+                float dr = di;  // value now at the root
+                int xr = xi;
+                while (child < i) {
+                    float dc = PCM_RL_F(d, child);
+                    if (child + 1 < i) {
+                        const float dc1 = PCM_RL_F(d, child + 1);
+                        if (dc1 > dc) {
+                            child++;
+                            dc = dc1;
+                        }
+                    }
+                    if (dr > dc) break;
+                    const int xc = __builtin_amdgcn_readlane(ix, child);
+                    d = PCM_WL(d, dc, root);
+                    d = PCM_WL(d, dr, child);
+                    ix = PCM_WL(ix, xc, root);
+                    ix = PCM_WL(ix, xr, child);
+                    root = child;  // dr / xr travel down with the root
+                    child = root * 2 + 1;
+                }
+            }
+#undef PCM_RL_F
+#undef PCM_WL
+            if (lane < cnt) {
+                cd[lane] = d;
+                ci[lane] = ix;
+            }
+        } else if (!overflow && lane == 0) {
+            // more than 64 candidates: the same replay, serially in LDS
             for (int i = cnt - 1; i > 0; --i) {
                 float td = cd[0];
                 int ti = ci[0];
@@ -111,7 +166,7 @@ __global__ __launch_bounds__(256) void pcm_random_ball_query_kernel(int m, int n
                                                                     const float *__restrict__ xyz,
                                                                     const float *__restrict__ new_xyz,
                                                                     const int *__restrict__ offset,
-                                                                    const int *__restrict__ new_offset,
+                                                                    const int *__restrict__ new_offset, int b,
                                                                     int *__restrict__ idx, float *__restrict__ dist2)
 {
     const int lane = threadIdx.x & 63;
@@ -121,7 +176,7 @@ __global__ __launch_bounds__(256) void pcm_random_ball_query_kernel(int m, int n
     const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
 
     for (int q = blockIdx.x * waves_per_block + (threadIdx.x >> 6); q < m; q += gridDim.x * waves_per_block) {
-        const int bt = pcm_cloud_of(q, new_offset, 0);
+        const int bt = pcm_cloud_of(q, new_offset, b);
         const int start = bt == 0 ? 0 : offset[bt - 1];
         const int end = offset[bt];
         const float qx = new_xyz[(size_t)q * 3 + 0];
@@ -158,15 +213,37 @@ __global__ __launch_bounds__(256) void pcm_random_ball_query_kernel(int m, int n
 
 }  // namespace
 
+// b > 0: number of clouds (the reference ABI does not carry it, so its entry points scan new_offset linearly -- up to
+// b dependent loads per query, the dominant cost at b = 128; with b the owning cloud is found by bisection).
+extern "C" int pcm_ball_query_b_hip(int b, int m, int nsample, float min_radius, float max_radius, const float *xyz,
+                                    const float *new_xyz, const int *offset, const int *new_offset, int *idx,
+                                    float *dist2, void *stream)
+{
+    if (m < 0 || nsample < 1 || b < 0) return PCM_ERR_BAD_ARG;
+    if (m == 0) return PCM_OK;
+    int blocks = m < 256 * 16 ? m : 256 * 16;
+    hipLaunchKernelGGL(pcm_ball_query_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, m, nsample, min_radius,
+                       max_radius, xyz, new_xyz, offset, new_offset, b, idx, dist2);
+    return PCM_LAUNCH_STATUS();
+}
+
 extern "C" int pcm_ball_query_hip(int m, int nsample, float min_radius, float max_radius, const float *xyz,
                                   const float *new_xyz, const int *offset, const int *new_offset, int *idx,
                                   float *dist2, void *stream)
 {
-    if (m < 0 || nsample < 1) return PCM_ERR_BAD_ARG;
+    return pcm_ball_query_b_hip(0, m, nsample, min_radius, max_radius, xyz, new_xyz, offset, new_offset, idx, dist2, stream);
+}
+
+extern "C" int pcm_random_ball_query_b_hip(int b, int m, int nsample, float min_radius, float max_radius, const int *order,
+                                           const float *xyz, const float *new_xyz, const int *offset,
+                                           const int *new_offset, int *idx, float *dist2, void *stream)
+{
+    if (m < 0 || nsample < 1 || b < 0) return PCM_ERR_BAD_ARG;
     if (m == 0) return PCM_OK;
-    int blocks = m < 256 * 16 ? m : 256 * 16;
-    hipLaunchKernelGGL(pcm_ball_query_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, m, nsample, min_radius,
-                       max_radius, xyz, new_xyz, offset, new_offset, idx, dist2);
+    int blocks = (m + 3) / 4;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(pcm_random_ball_query_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, m, nsample,
+                       min_radius, max_radius, order, xyz, new_xyz, offset, new_offset, b, idx, dist2);
     return PCM_LAUNCH_STATUS();
 }
 
@@ -174,11 +251,6 @@ extern "C" int pcm_random_ball_query_hip(int m, int nsample, float min_radius, f
                                          const float *xyz, const float *new_xyz, const int *offset,
                                          const int *new_offset, int *idx, float *dist2, void *stream)
 {
-    if (m < 0 || nsample < 1) return PCM_ERR_BAD_ARG;
-    if (m == 0) return PCM_OK;
-    int blocks = (m + 3) / 4;
-    if (blocks > 256 * 8) blocks = 256 * 8;
-    hipLaunchKernelGGL(pcm_random_ball_query_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, m, nsample,
-                       min_radius, max_radius, order, xyz, new_xyz, offset, new_offset, idx, dist2);
-    return PCM_LAUNCH_STATUS();
+    return pcm_random_ball_query_b_hip(0, m, nsample, min_radius, max_radius, order, xyz, new_xyz, offset, new_offset, idx, dist2,
+                                       stream);
 }

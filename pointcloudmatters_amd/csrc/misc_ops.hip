@@ -7,7 +7,12 @@
 //   interpolation/interpolation_cuda_kernel.cu:5-47, subtraction/subtraction_cuda_kernel.cu:5-44,
 //   aggregation/aggregation_cuda_kernel.cu:5-53, attention/attention_cuda_kernel.cu:9-147.
 // Thread mapping: channel index fastest (coalesced along c), 64-bit element indices (the
-// reference's int32 index math overflows past 2^31 elements).
+// reference's int32 index math overflows past 2^31 elements).  The k-neighbour weighted sums (interpolation forward,
+// the per-query half of subtraction backward) run on the segmented gather-sum of segsum.hip: one group of lanes per
+// output row, 16-byte loads, the (idx, weight) pairs of the row fetched once per group.  The scatter halves have two
+// forms: the reference-ABI entry points below keep one atomic per element (no workspace in that ABI); the planned
+// form (pcm_scatter_plan_hip + pcm_segment_sum_hip, what pointops/*.py calls) inverts idx once and sums each
+// destination row without atomics.
 #include "pcm_common.hpp"
 
 namespace {
@@ -27,24 +32,6 @@ inline int grid_for(long total)
     for (long e = (long)blockIdx.x * kBlock + threadIdx.x; e < (total); e += (long)gridDim.x * kBlock)
 
 // ---- K6 ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void interp_fwd(long total, int c, int k, const float *__restrict__ input,
-                                                      const int *__restrict__ idx, const float *__restrict__ weight,
-                                                      float *__restrict__ output)
-{
-    PCM_GRID_STRIDE(e, total)
-    {
-        const int c_idx = (int)(e % c);
-        const long n_idx = e / c;
-        float acc = output[e];  // reference accumulates into the caller's (zeroed) buffer
-        for (int i = 0; i < k; ++i) {
-            const long ii = n_idx * k + i;
-            const float p = input[(long)idx[ii] * c + c_idx] * weight[ii];
-            acc = acc + p;
-        }
-        output[e] = acc;
-    }
-}
-
 __global__ __launch_bounds__(kBlock) void interp_bwd(long total, int c, int k, const float *__restrict__ grad_output,
                                                       const int *__restrict__ idx, const float *__restrict__ weight,
                                                       float *__restrict__ grad_input)
@@ -75,18 +62,15 @@ __global__ __launch_bounds__(kBlock) void sub_fwd(long total, int nsample, int c
     }
 }
 
-__global__ __launch_bounds__(kBlock) void sub_bwd(long total, int nsample, int c, const int *__restrict__ idx,
-                                                   const float *__restrict__ grad_output, float *__restrict__ grad_input1,
-                                                   float *__restrict__ grad_input2)
+// grad_input2 scatter of the reference ABI; grad_input1 (a sum over the nsample rows of one query) is a segmented sum.
+__global__ __launch_bounds__(kBlock) void sub_bwd_scatter(long total, int c, const int *__restrict__ idx,
+                                                           const float *__restrict__ grad_output, float *__restrict__ grad_input2)
 {
     PCM_GRID_STRIDE(e, total)
     {
         const int c_idx = (int)(e % c);
         const long row = e / c;
-        const long n_idx = row / nsample;
-        const float g = grad_output[e];
-        unsafeAtomicAdd(grad_input1 + n_idx * c + c_idx, g);
-        unsafeAtomicAdd(grad_input2 + (long)idx[row] * c + c_idx, -g);
+        unsafeAtomicAdd(grad_input2 + (long)idx[row] * c + c_idx, -grad_output[e]);
     }
 }
 
@@ -113,11 +97,64 @@ __global__ __launch_bounds__(kBlock) void agg_fwd(long total, int nsample, int c
     }
 }
 
-__global__ __launch_bounds__(kBlock) void agg_bwd(long total, int nsample, int c, int w_c, const float *__restrict__ input,
-                                                   const float *__restrict__ position, const float *__restrict__ weight,
-                                                   const int *__restrict__ idx, const float *__restrict__ grad_output,
-                                                   float *__restrict__ grad_input, float *__restrict__ grad_position,
-                                                   float *__restrict__ grad_weight)
+// float4 form of agg_fwd for c % 4 == 0 and w_c % 4 == 0: same per-element arithmetic, a quarter of the loads.
+__global__ __launch_bounds__(kBlock) void agg_fwd4(long total4, int nsample, int c, int w_c, const float *__restrict__ input,
+                                                    const float *__restrict__ position, const float *__restrict__ weight,
+                                                    const int *__restrict__ idx, float *__restrict__ output)
+{
+    const int c4 = c >> 2;
+    PCM_GRID_STRIDE(e4, total4)
+    {
+        const int c_idx = (int)(e4 % c4) << 2;
+        const long n_idx = e4 / c4;
+        const int w_c_idx = c_idx % w_c;
+        float4 acc = *reinterpret_cast<const float4 *>(output + n_idx * c + c_idx);
+        for (int s = 0; s < nsample; ++s) {
+            const long ii = n_idx * nsample + s;
+            const float4 in = *reinterpret_cast<const float4 *>(input + (long)idx[ii] * c + c_idx);
+            const float4 pos = *reinterpret_cast<const float4 *>(position + ii * c + c_idx);
+            const float4 w = *reinterpret_cast<const float4 *>(weight + ii * w_c + w_c_idx);
+            acc.x = acc.x + (in.x + pos.x) * w.x;
+            acc.y = acc.y + (in.y + pos.y) * w.y;
+            acc.z = acc.z + (in.z + pos.z) * w.z;
+            acc.w = acc.w + (in.w + pos.w) * w.w;
+        }
+        *reinterpret_cast<float4 *>(output + n_idx * c + c_idx) = acc;
+    }
+}
+
+// The two gradients of aggregation that need no scatter: grad_position[ii, c] = g[n, c] * w[ii, c % w_c] and
+// grad_weight[ii, wc] = sum over the c / w_c channels with c % w_c == wc of g[n, c] * (in[idx[ii], c] + pos[ii, c]).
+// One thread per (ii, wc) walks its channels in ascending order: coalesced along wc, a fixed order, no atomics
+// (the reference issues one atomicAdd per (ii, c): aggregation_cuda_kernel.cu:44).
+__global__ __launch_bounds__(kBlock) void agg_bwd_local(long total, int nsample, int c, int w_c, const float *__restrict__ input,
+                                                         const float *__restrict__ position, const float *__restrict__ weight,
+                                                         const int *__restrict__ idx, const float *__restrict__ grad_output,
+                                                         float *__restrict__ grad_position, float *__restrict__ grad_weight,
+                                                         int accumulate_weight)
+{
+    PCM_GRID_STRIDE(e, total)
+    {
+        const int wc = (int)(e % w_c);
+        const long ii = e / w_c;
+        const long n_idx = ii / nsample;
+        const float w = weight[e];
+        const long src = (long)idx[ii] * c;
+        float acc = accumulate_weight ? grad_weight[e] : 0.f;
+        for (int c_idx = wc; c_idx < c; c_idx += w_c) {
+            const float g = grad_output[n_idx * c + c_idx];
+            grad_position[ii * c + c_idx] = g * w;
+            const float sum = input[src + c_idx] + position[ii * c + c_idx];
+            acc = acc + g * sum;
+        }
+        grad_weight[e] = acc;
+    }
+}
+
+// grad_input scatter of the reference ABI (one atomic per (ii, c)); the planned form is pcm_segment_sum_hip, scale mode 2.
+__global__ __launch_bounds__(kBlock) void agg_bwd_scatter(long total, int nsample, int c, int w_c, const float *__restrict__ weight,
+                                                           const int *__restrict__ idx, const float *__restrict__ grad_output,
+                                                           float *__restrict__ grad_input)
 {
     PCM_GRID_STRIDE(e, total)
     {
@@ -127,14 +164,7 @@ __global__ __launch_bounds__(kBlock) void agg_bwd(long total, int nsample, int c
         const float g = grad_output[e];
         for (int s = 0; s < nsample; ++s) {
             const long ii = n_idx * nsample + s;
-            const long in_i = (long)idx[ii] * c + c_idx;
-            const long pos_i = ii * c + c_idx;
-            const long w_i = ii * w_c + w_c_idx;
-            const float gw = g * weight[w_i];
-            unsafeAtomicAdd(grad_input + in_i, gw);
-            grad_position[pos_i] = gw;
-            const float sum = input[in_i] + position[pos_i];
-            unsafeAtomicAdd(grad_weight + w_i, g * sum);
+            unsafeAtomicAdd(grad_input + (long)idx[ii] * c + c_idx, g * weight[ii * w_c + w_c_idx]);
         }
     }
 }
@@ -236,8 +266,8 @@ extern "C" int pcm_interpolation_forward_hip(int n, int c, int k, const float *i
     if (n < 0 || c < 0 || k < 0) return PCM_ERR_BAD_ARG;
     const long total = (long)n * c;
     if (total == 0) return PCM_OK;
-    hipLaunchKernelGGL(interp_fwd, dim3(grid_for(total)), dim3(kBlock), 0, PCM_ST, total, c, k, input, idx, weight, output);
-    return PCM_LAUNCH_STATUS();
+    // output[n, :] = sum_i input[idx[n, i], :] * weight[n, i], i ascending (written, not accumulated)
+    return pcm_segment_sum_hip(n, c, nullptr, k, nullptr, idx, 1, weight, 1, 1, 1.f, input, c, 0, output, stream);
 }
 
 extern "C" int pcm_interpolation_backward_hip(int n, int c, int k, const float *grad_output, const int *idx,
@@ -266,7 +296,9 @@ extern "C" int pcm_subtraction_backward_hip(int n, int nsample, int c, const int
     if (n < 0 || c < 0 || nsample < 0) return PCM_ERR_BAD_ARG;
     const long total = (long)n * nsample * c;
     if (total == 0) return PCM_OK;
-    hipLaunchKernelGGL(sub_bwd, dim3(grid_for(total)), dim3(kBlock), 0, PCM_ST, total, nsample, c, idx, grad_output, grad_input1, grad_input2);
+    const int rc = pcm_segment_sum_hip(n, c, nullptr, nsample, nullptr, nullptr, 1, nullptr, 0, 1, 1.f, grad_output, c, 0, grad_input1, stream);
+    if (rc != PCM_OK || grad_input2 == nullptr) return rc;  // grad_input2 == nullptr: the caller scatters through a plan
+    hipLaunchKernelGGL(sub_bwd_scatter, dim3(grid_for(total)), dim3(kBlock), 0, PCM_ST, total, c, idx, grad_output, grad_input2);
     return PCM_LAUNCH_STATUS();
 }
 
@@ -276,7 +308,14 @@ extern "C" int pcm_aggregation_forward_hip(int n, int nsample, int c, int w_c, c
     if (n < 0 || c < 0 || nsample < 0 || w_c < 1) return PCM_ERR_BAD_ARG;
     const long total = (long)n * c;
     if (total == 0) return PCM_OK;
-    hipLaunchKernelGGL(agg_fwd, dim3(grid_for(total)), dim3(kBlock), 0, PCM_ST, total, nsample, c, w_c, input, position, weight, idx, output);
+    const bool vec4 = c % 4 == 0 && w_c % 4 == 0 &&
+                      (((uintptr_t)input | (uintptr_t)position | (uintptr_t)weight | (uintptr_t)output) % 16 == 0);
+    if (vec4)
+        hipLaunchKernelGGL(agg_fwd4, dim3(grid_for(total / 4)), dim3(kBlock), 0, PCM_ST, total / 4, nsample, c, w_c, input, position,
+                           weight, idx, output);
+    else
+        hipLaunchKernelGGL(agg_fwd, dim3(grid_for(total)), dim3(kBlock), 0, PCM_ST, total, nsample, c, w_c, input, position, weight,
+                           idx, output);
     return PCM_LAUNCH_STATUS();
 }
 
@@ -287,8 +326,14 @@ extern "C" int pcm_aggregation_backward_hip(int n, int nsample, int c, int w_c, 
     if (n < 0 || c < 0 || nsample < 0 || w_c < 1) return PCM_ERR_BAD_ARG;
     const long total = (long)n * c;
     if (total == 0) return PCM_OK;
-    hipLaunchKernelGGL(agg_bwd, dim3(grid_for(total)), dim3(kBlock), 0, PCM_ST, total, nsample, c, w_c, input, position, weight, idx,
-                       grad_output, grad_input, grad_position, grad_weight);
+    // grad_weight is accumulated into (the reference adds into the caller's zeroed buffer), grad_position written
+    const long locals = (long)n * nsample * w_c;
+    if (locals > 0)
+        hipLaunchKernelGGL(agg_bwd_local, dim3(grid_for(locals)), dim3(kBlock), 0, PCM_ST, locals, nsample, c, w_c, input, position,
+                           weight, idx, grad_output, grad_position, grad_weight, 1);
+    if (grad_input != nullptr && nsample > 0)  // nullptr: the caller scatters through a plan (pcm_segment_sum_hip, scale mode 2)
+        hipLaunchKernelGGL(agg_bwd_scatter, dim3(grid_for(total)), dim3(kBlock), 0, PCM_ST, total, nsample, c, w_c, weight, idx,
+                           grad_output, grad_input);
     return PCM_LAUNCH_STATUS();
 }
 

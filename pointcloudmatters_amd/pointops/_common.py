@@ -66,3 +66,35 @@ def with_host(offset, host):
 
 def counts_from_offsets(host):
     return [host[0]] + [host[i] - host[i - 1] for i in range(1, len(host))]
+
+
+class ScatterPlan:
+    """CSR inverse of an index list (csrc/segsum.hip): which entries of ``idx`` land on each of the ``n_dst``
+    destination rows.  Built once per backward with five small launches; the scatter-adds of grouping /
+    interpolation / subtraction / aggregation backward then become atomic-free segmented sums."""
+
+    def __init__(self, idx, n_dst):
+        import ctypes
+
+        L = lib()
+        self.rows, self.n_dst = idx.numel(), int(n_dst)
+        self.idx = idx
+        with torch.cuda.device(idx.device):
+            self.ws = torch.empty(L.pcm_scatter_plan_ws_ints(self.rows, self.n_dst), dtype=torch.int32, device=idx.device)
+            start, lst = ctypes.c_void_p(), ctypes.c_void_p()
+            rc = L.pcm_scatter_plan_hip(self.rows, self.n_dst, ptr(idx), ptr(self.ws), ctypes.byref(start), ctypes.byref(lst), stream())
+        _lib.check(rc, "pcm_scatter_plan_hip")
+        self.start, self.list = start.value or 0, lst.value or 0
+
+
+def segment_sum(dst, src, *, src_stride=None, src_off=0, plan=None, seglen=0, map=None, rowdiv=1, scale=None, scale_mode=0,
+                w_c=1, sign=1.0):
+    """dst (n_dst, c) = sign * segmented sum of rows of ``src`` (see include/pcm_pointops.h, pcm_segment_sum_hip)."""
+    n_dst, c = dst.shape
+    with torch.cuda.device(dst.device):
+        rc = lib().pcm_segment_sum_hip(
+            n_dst, c, plan.start if plan is not None else 0, int(seglen), plan.list if plan is not None else 0, ptr(map),
+            int(rowdiv), ptr(scale), int(scale_mode), int(w_c), float(sign), ptr(src),
+            int(src_stride if src_stride is not None else c), int(src_off), ptr(dst), stream())
+    _lib.check(rc, "pcm_segment_sum_hip")
+    return dst

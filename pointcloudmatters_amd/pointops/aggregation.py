@@ -32,14 +32,16 @@ class _Aggregation(Function):
         w_c = weight.shape[-1]
         dev = grad_output.device
         with torch.cuda.device(dev):
-            gi = torch.zeros(n, c, dtype=torch.float32, device=dev)
-            gp = torch.zeros(n, nsample, c, dtype=torch.float32, device=dev)
+            gi = torch.empty(input.shape[0], c, dtype=torch.float32, device=dev)
+            gp = torch.empty(n, nsample, c, dtype=torch.float32, device=dev)
             gw = torch.zeros(n, nsample, w_c, dtype=torch.float32, device=dev)
             rc = L.pcm_aggregation_backward_hip(
                 n, nsample, c, w_c, C.ptr(input), C.ptr(position), C.ptr(weight), C.ptr(idx), C.ptr(grad_output),
-                C.ptr(gi), C.ptr(gp), C.ptr(gw), C.stream(),
-            )
-        C._lib.check(rc, "pcm_aggregation_backward_hip")
+                0, C.ptr(gp), C.ptr(gw), C.stream(),
+            )  # grad_position and grad_weight: per-row, no scatter
+            C._lib.check(rc, "pcm_aggregation_backward_hip")
+            # grad_input[j, c] = sum over the (n, s) pairs with idx[n, s] == j of grad_output[n, c] * weight[n, s, c % w_c]
+            C.segment_sum(gi, grad_output, plan=C.ScatterPlan(idx, input.shape[0]), rowdiv=nsample, scale=weight, scale_mode=2, w_c=w_c)
         return gi, gp, gw, None
 
 

@@ -6,7 +6,8 @@ from . import _common as C
 
 
 class _Grouping2(Function):
-    """grouping.py:6-32 (Grouping): plain gather (no -1 handling), atomic scatter backward."""
+    """grouping.py:6-32 (Grouping): plain gather (no -1 handling); the backward scatter is a planned segmented sum
+    (csrc/segsum.hip) instead of the reference's one atomicAdd per element."""
 
     @staticmethod
     def forward(ctx, input, idx):
@@ -30,9 +31,8 @@ class _Grouping2(Function):
         grad_output = grad_output.contiguous()
         m, nsample, c = grad_output.shape
         with torch.cuda.device(grad_output.device):
-            grad_input = torch.zeros(ctx.n, c, dtype=torch.float32, device=grad_output.device)
-            rc = L.pcm_grouping_backward_hip(m, nsample, c, C.ptr(grad_output), C.ptr(idx), C.ptr(grad_input), C.stream())
-        C._lib.check(rc, "pcm_grouping_backward_hip")
+            grad_input = torch.empty(ctx.n, c, dtype=torch.float32, device=grad_output.device)
+            C.segment_sum(grad_input, grad_output, plan=C.ScatterPlan(idx, ctx.n))
         return grad_input, None
 
 
@@ -71,11 +71,9 @@ class _GroupXYZFeat(Function):
         grad_feat = grad_xyz = grad_new_xyz = None
         with torch.cuda.device(grad_out.device):
             if ctx.needs_input_grad[0]:
-                grad_feat = torch.zeros(ctx.n, c, dtype=torch.float32, device=grad_out.device)
-                rc = L.pcm_group_xyz_feat_backward_hip(
-                    m, nsample, c, 1 if ctx.with_xyz else 0, C.ptr(grad_out), C.ptr(idx), C.ptr(grad_feat), C.stream()
-                )
-                C._lib.check(rc, "pcm_group_xyz_feat_backward_hip")
+                # rows with idx == -1 are skipped by the plan; every feature row is written exactly once
+                grad_feat = torch.empty(ctx.n, c, dtype=torch.float32, device=grad_out.device)
+                C.segment_sum(grad_feat, grad_out, src_stride=w, src_off=w - c, plan=C.ScatterPlan(idx, ctx.n))
             if ctx.with_xyz and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
                 # coordinates rarely need gradients (never on the BC path); plain torch ops
                 valid = (idx >= 0).to(grad_out.dtype).unsqueeze(-1)

@@ -23,7 +23,7 @@ class _Interpolation(Function):
         idx, weight = _weights(xyz, new_xyz, offset, new_offset, k)
         n, c, m = new_xyz.shape[0], input.shape[1], input.shape[0]
         with torch.cuda.device(input.device):
-            output = torch.zeros(n, c, dtype=torch.float32, device=input.device)
+            output = torch.empty(n, c, dtype=torch.float32, device=input.device)
             rc = L.pcm_interpolation_forward_hip(n, c, k, C.ptr(input), C.ptr(idx), C.ptr(weight), C.ptr(output), C.stream())
         C._lib.check(rc, "pcm_interpolation_forward_hip")
         ctx.m, ctx.k = m, k
@@ -37,11 +37,9 @@ class _Interpolation(Function):
         grad_output = grad_output.contiguous()
         n, c = grad_output.shape
         with torch.cuda.device(grad_output.device):
-            grad_input = torch.zeros(ctx.m, c, dtype=torch.float32, device=grad_output.device)
-            rc = L.pcm_interpolation_backward_hip(
-                n, c, ctx.k, C.ptr(grad_output), C.ptr(idx), C.ptr(weight), C.ptr(grad_input), C.stream()
-            )
-        C._lib.check(rc, "pcm_interpolation_backward_hip")
+            # grad_input[j] = sum over the (n, i) pairs with idx[n, i] == j of grad_output[n] * weight[n, i]
+            grad_input = torch.empty(ctx.m, c, dtype=torch.float32, device=grad_output.device)
+            C.segment_sum(grad_input, grad_output, plan=C.ScatterPlan(idx, ctx.m), rowdiv=ctx.k, scale=weight, scale_mode=1)
         return None, None, grad_input, None, None, None
 
 

@@ -47,11 +47,11 @@ def ball_query_raw(nsample, max_radius, min_radius, xyz, offset, new_xyz=None, n
         idx = torch.empty(m, nsample, dtype=torch.int32, device=xyz.device)
         dist2 = torch.empty(m, nsample, dtype=torch.float32, device=xyz.device)
         o32, no32 = C.i32c(offset), C.i32c(new_offset)
-        rc = L.pcm_ball_query_hip(
-            m, nsample, float(min_radius), float(max_radius), C.ptr(xyz), C.ptr(new_xyz), C.ptr(o32), C.ptr(no32),
+        rc = L.pcm_ball_query_b_hip(
+            int(no32.shape[0]), m, nsample, float(min_radius), float(max_radius), C.ptr(xyz), C.ptr(new_xyz), C.ptr(o32), C.ptr(no32),
             C.ptr(idx), C.ptr(dist2), C.stream(),
         )
-    C._lib.check(rc, "pcm_ball_query_hip")
+    C._lib.check(rc, "pcm_ball_query_b_hip")
     return idx, dist2
 
 
@@ -83,11 +83,11 @@ def random_ball_query_raw(nsample, max_radius, min_radius, xyz, offset, new_xyz=
         idx = torch.empty(m, nsample, dtype=torch.int32, device=xyz.device)
         dist2 = torch.empty(m, nsample, dtype=torch.float32, device=xyz.device)
         o32, no32 = C.i32c(offset), C.i32c(new_offset)
-        rc = L.pcm_random_ball_query_hip(
-            m, nsample, float(min_radius), float(max_radius), C.ptr(order), C.ptr(xyz), C.ptr(new_xyz), C.ptr(o32),
+        rc = L.pcm_random_ball_query_b_hip(
+            int(no32.shape[0]), m, nsample, float(min_radius), float(max_radius), C.ptr(order), C.ptr(xyz), C.ptr(new_xyz), C.ptr(o32),
             C.ptr(no32), C.ptr(idx), C.ptr(dist2), C.stream(),
         )
-    C._lib.check(rc, "pcm_random_ball_query_hip")
+    C._lib.check(rc, "pcm_random_ball_query_b_hip")
     return idx, dist2
 
 

@@ -20,6 +20,7 @@ class _Subtraction(Function):
             output = torch.empty(n, nsample, c, dtype=torch.float32, device=input1.device)
             rc = L.pcm_subtraction_forward_hip(n, nsample, c, C.ptr(input1), C.ptr(input2), C.ptr(idx), C.ptr(output), C.stream())
         C._lib.check(rc, "pcm_subtraction_forward_hip")
+        ctx.n2 = input2.shape[0]
         ctx.save_for_backward(idx)
         return output
 
@@ -30,10 +31,11 @@ class _Subtraction(Function):
         grad_output = grad_output.contiguous()
         n, nsample, c = grad_output.shape
         with torch.cuda.device(grad_output.device):
-            g1 = torch.zeros(n, c, dtype=torch.float32, device=grad_output.device)
-            g2 = torch.zeros(n, c, dtype=torch.float32, device=grad_output.device)
-            rc = L.pcm_subtraction_backward_hip(n, nsample, c, C.ptr(idx), C.ptr(grad_output), C.ptr(g1), C.ptr(g2), C.stream())
-        C._lib.check(rc, "pcm_subtraction_backward_hip")
+            g1 = torch.empty(n, c, dtype=torch.float32, device=grad_output.device)
+            g2 = torch.empty(ctx.n2, c, dtype=torch.float32, device=grad_output.device)
+            rc = L.pcm_subtraction_backward_hip(n, nsample, c, C.ptr(idx), C.ptr(grad_output), C.ptr(g1), 0, C.stream())
+            C._lib.check(rc, "pcm_subtraction_backward_hip")
+            C.segment_sum(g2, grad_output.view(n * nsample, c), plan=C.ScatterPlan(idx, ctx.n2), sign=-1.0)
         return g1, g2, None
 
 

@@ -1,0 +1,179 @@
+"""The scatter plan + segmented gather-sum (csrc/segsum.hip) against plain index arithmetic, the reference-ABI atomic
+entry points against the planned form, the grouping forward at odd widths, and the ball queries with / without the cloud count."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _idx(rows, n_dst, seed, holes=True, hub=False):
+    g = torch.Generator().manual_seed(seed)
+    idx = torch.randint(0, max(n_dst, 1), (rows,), generator=g, dtype=torch.int32)
+    if hub and rows:
+        idx[: rows // 3] = 7 % max(n_dst, 1)  # one destination row with a very long segment
+    if holes and rows:
+        idx[torch.rand(rows, generator=g) < 0.05] = -1
+    return idx
+
+
+@pytest.mark.parametrize("rows,n_dst", [(0, 5), (7, 1), (1000, 37), (5000, 4096), (70000, 9001), (300000, 131072)])
+def test_scatter_plan_is_the_csr_inverse(hip_device, rows, n_dst):
+    from pointcloudmatters_amd.pointops import _common as C
+
+    idx = _idx(rows, n_dst, seed=rows + n_dst, hub=rows > 100)
+    plan = C.ScatterPlan(idx.to(hip_device), n_dst)
+    torch.cuda.synchronize()
+    ws = plan.ws.cpu().numpy()
+    base = plan.ws.data_ptr()
+    start = ws[(plan.start - base) // 4:][: n_dst + 1]
+    lst = ws[(plan.list - base) // 4:] if plan.list else np.zeros(0, np.int32)
+    h = idx.numpy()
+    counts = np.bincount(h[h >= 0], minlength=n_dst)
+    assert np.array_equal(start, np.concatenate([[0], np.cumsum(counts)]))
+    for j in ([0, n_dst - 1, 7 % n_dst] + list(np.random.default_rng(0).integers(0, n_dst, 50))):
+        seg = np.sort(lst[start[j]:start[j + 1]])
+        assert np.array_equal(seg, np.nonzero(h == j)[0])
+
+
+@pytest.mark.parametrize("c,stride,off", [(96, 99, 3), (32, 32, 0), (5, 8, 2), (256, 256, 0), (260, 260, 0)])
+def test_planned_scatter_equals_index_add(hip_device, c, stride, off):
+    from pointcloudmatters_amd.pointops import _common as C
+
+    rows, n_dst = 20000, 3001
+    idx = _idx(rows, n_dst, seed=c, hub=True)
+    src = torch.randn(rows, stride, generator=torch.Generator().manual_seed(1))
+    want = torch.zeros(n_dst, c, dtype=torch.float64)
+    keep = idx >= 0
+    want.index_add_(0, idx[keep].long(), src[keep][:, off:off + c].double())
+    dst = torch.full((n_dst, c), float("nan"), device=hip_device)
+    C.segment_sum(dst, src.to(hip_device), src_stride=stride, src_off=off, plan=C.ScatterPlan(idx.to(hip_device), n_dst), sign=-1.0)
+    torch.testing.assert_close(dst.cpu().double(), -want, rtol=1e-5, atol=1e-3)  # hub row: ~6 700 fp32 terms summed serially
+
+
+def test_scaled_modes_and_implicit_segments(hip_device):
+    from pointcloudmatters_amd.pointops import _common as C
+
+    g = torch.Generator().manual_seed(3)
+    n, k, c, m, w_c = 4000, 3, 64, 700, 8
+    idx = torch.randint(0, m, (n, k), generator=g, dtype=torch.int32)
+    w = torch.rand(n, k, generator=g)
+    feat = torch.randn(m, c, generator=g)
+    # forward interpolation = implicit segments of k entries, map = idx, per-entry scale; k ascending like the reference
+    want = torch.zeros(n, c)
+    for i in range(k):
+        want = want + feat[idx[:, i].long()] * w[:, i:i + 1]
+    out = torch.empty(n, c, device=hip_device)
+    C.segment_sum(out, feat.to(hip_device), seglen=k, map=idx.to(hip_device), scale=w.to(hip_device), scale_mode=1)
+    assert torch.equal(out.cpu(), want)
+    # scale mode 2 with rowdiv: aggregation's grad_input
+    gout = torch.randn(n, c, generator=g)
+    wt = torch.rand(n, k, w_c, generator=g)
+    want2 = torch.zeros(m, c, dtype=torch.float64)
+    contrib = gout.double()[:, None, :] * wt.double().repeat(1, 1, c // w_c)  # (n, k, c): weight index = c % w_c
+    want2.index_add_(0, idx.reshape(-1).long(), contrib.reshape(n * k, c))
+    gi = torch.empty(m, c, device=hip_device)
+    C.segment_sum(gi, gout.to(hip_device), plan=C.ScatterPlan(idx.to(hip_device), m), rowdiv=k, scale=wt.to(hip_device),
+                  scale_mode=2, w_c=w_c)
+    torch.testing.assert_close(gi.cpu().double(), want2, rtol=1e-5, atol=1e-5)
+
+
+def test_reference_abi_atomic_entry_points_agree_with_the_planned_form(hip_device):
+    """include/pcm_pointops.h keeps the reference's backward signatures (no workspace): one atomic per element."""
+    import pointcloudmatters_amd.pointops as po
+    from pointcloudmatters_amd import _lib
+    from pointcloudmatters_amd.pointops import _common as C
+
+    L, st = _lib.load(), torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(5)
+    n, k, c, m = 3000, 3, 48, 400
+    idx = torch.randint(0, m, (n, k), generator=g, dtype=torch.int32).to(hip_device)
+    w = torch.rand(n, k, generator=g).to(hip_device)
+    go = torch.randn(n, c, generator=g).to(hip_device)
+    atomic = torch.zeros(m, c, device=hip_device)
+    _lib.check(L.pcm_interpolation_backward_hip(n, c, k, go.data_ptr(), idx.data_ptr(), w.data_ptr(), atomic.data_ptr(), st), "interp bwd")
+    planned = torch.empty(m, c, device=hip_device)
+    C.segment_sum(planned, go, plan=C.ScatterPlan(idx, m), rowdiv=k, scale=w, scale_mode=1)
+    torch.testing.assert_close(atomic, planned, rtol=1e-5, atol=1e-5)
+    # grouping / subtraction / aggregation: reference-ABI calls with every output pointer given
+    gout = torch.randn(n, k, c, generator=g).to(hip_device)
+    a = torch.zeros(m, c, device=hip_device)
+    _lib.check(L.pcm_grouping_backward_hip(n, k, c, gout.data_ptr(), idx.data_ptr(), a.data_ptr(), st), "grouping bwd")
+    b = torch.empty(m, c, device=hip_device)
+    C.segment_sum(b, gout, plan=C.ScatterPlan(idx, m))
+    torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5)
+    idxn = torch.randint(0, n, (n, k), generator=g, dtype=torch.int32).to(hip_device)
+    g1, g2 = torch.zeros(n, c, device=hip_device), torch.zeros(n, c, device=hip_device)
+    _lib.check(L.pcm_subtraction_backward_hip(n, k, c, idxn.data_ptr(), gout.data_ptr(), g1.data_ptr(), g2.data_ptr(), st), "sub bwd")
+    x1 = torch.randn(n, c, generator=g).to(hip_device).requires_grad_(True)
+    x2 = torch.randn(n, c, generator=g).to(hip_device).requires_grad_(True)
+    po.subtraction(x1, x2, idxn).backward(gout)
+    torch.testing.assert_close(g1, x1.grad, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(g2, x2.grad, rtol=1e-5, atol=1e-5)
+    w_c = 8
+    pos = torch.randn(n, k, c, generator=g).to(hip_device).requires_grad_(True)
+    wt = torch.rand(n, k, w_c, generator=g).to(hip_device).requires_grad_(True)
+    xin = torch.randn(n, c, generator=g).to(hip_device).requires_grad_(True)
+    gi, gp, gw = torch.zeros(n, c, device=hip_device), torch.zeros(n, k, c, device=hip_device), torch.zeros(n, k, w_c, device=hip_device)
+    _lib.check(L.pcm_aggregation_backward_hip(n, k, c, w_c, xin.data_ptr(), pos.data_ptr(), wt.data_ptr(), idxn.data_ptr(),
+                                              go.data_ptr(), gi.data_ptr(), gp.data_ptr(), gw.data_ptr(), st), "agg bwd")
+    po.aggregation(xin, pos, wt, idxn).backward(go)
+    torch.testing.assert_close(gi, xin.grad, rtol=1e-5, atol=1e-5)
+    assert torch.equal(gp, pos.grad)
+    assert torch.equal(gw, wt.grad)  # fixed-order sums: identical
+
+
+@pytest.mark.parametrize("c,with_xyz", [(96, True), (1, True), (2, False), (7, True), (64, False)])
+def test_grouping_forward_at_odd_widths(hip_device, c, with_xyz):
+    import pointcloudmatters_amd.pointops as po
+
+    g = torch.Generator().manual_seed(c)
+    n, m, k = 1000, 333, 5
+    xyz = torch.rand(n, 3, generator=g)
+    new_xyz = torch.rand(m, 3, generator=g)
+    feat = torch.randn(n, c, generator=g)
+    idx = torch.randint(-1, n, (m, k), generator=g, dtype=torch.int32)
+    got = po.grouping(idx.to(hip_device), feat.to(hip_device), xyz.to(hip_device), new_xyz.to(hip_device), with_xyz=with_xyz).cpu()
+    valid = (idx >= 0).float().unsqueeze(-1)
+    gf = feat[idx.clamp_min(0).long()] * valid
+    if with_xyz:
+        rel = (xyz[idx.clamp_min(0).long()] * valid - new_xyz[:, None, :]) * valid
+        want = torch.cat([rel, gf], dim=-1)
+    else:
+        want = gf
+    assert torch.equal(got, want)
+
+
+def test_ball_queries_with_and_without_the_cloud_count(hip_device):
+    """pcm_*ball_query_hip (reference ABI: linear scan of new_offset) and the _b forms (bisection) give the same rows."""
+    from pointcloudmatters_amd import _lib
+    from tests.util import make_clouds
+
+    L, st = _lib.load(), torch.cuda.current_stream().cuda_stream
+    xyz, off = make_clouds([300, 1, 200, 64, 700], seed=4)
+    new_xyz, noff = make_clouds([40, 3, 1, 20, 90], seed=5)
+    xyz, new_xyz = xyz.to(hip_device), new_xyz.to(hip_device)
+    o32, no32 = off.int().to(hip_device), noff.int().to(hip_device)
+    m, ns, b = new_xyz.shape[0], 12, 5
+    order = torch.cat([torch.randperm(c, generator=torch.Generator().manual_seed(i)) + s for i, (s, c) in
+                       enumerate(zip([0, 300, 301, 501, 565], [300, 1, 200, 64, 700]))]).int().to(hip_device)
+    outs = []
+    for use_b in (False, True):
+        i1, d1 = torch.empty(m, ns, dtype=torch.int32, device=hip_device), torch.empty(m, ns, device=hip_device)
+        i2, d2 = torch.empty_like(i1), torch.empty_like(d1)
+        if use_b:
+            _lib.check(L.pcm_ball_query_b_hip(b, m, ns, 0.0, 0.3, xyz.data_ptr(), new_xyz.data_ptr(), o32.data_ptr(), no32.data_ptr(),
+                                              i1.data_ptr(), d1.data_ptr(), st), "ball b")
+            _lib.check(L.pcm_random_ball_query_b_hip(b, m, ns, 0.0, 0.3, order.data_ptr(), xyz.data_ptr(), new_xyz.data_ptr(),
+                                                     o32.data_ptr(), no32.data_ptr(), i2.data_ptr(), d2.data_ptr(), st), "rball b")
+        else:
+            _lib.check(L.pcm_ball_query_hip(m, ns, 0.0, 0.3, xyz.data_ptr(), new_xyz.data_ptr(), o32.data_ptr(), no32.data_ptr(),
+                                            i1.data_ptr(), d1.data_ptr(), st), "ball")
+            _lib.check(L.pcm_random_ball_query_hip(m, ns, 0.0, 0.3, order.data_ptr(), xyz.data_ptr(), new_xyz.data_ptr(),
+                                                   o32.data_ptr(), no32.data_ptr(), i2.data_ptr(), d2.data_ptr(), st), "rball")
+        outs.append((i1, d1, i2, d2))
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+    assert (outs[0][0] >= 0).any()
