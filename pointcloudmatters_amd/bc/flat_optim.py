@@ -107,7 +107,13 @@ class FlatAdamW:
             p.grad = None
 
     def stash_grad(self, k, g):
-        self._stash[k] = g if self._stash[k] is None else self._stash[k] + g
+        if self._stash[k] is None:
+            self._stash[k] = g
+            return
+        from ..policy import rows_linear
+
+        rows_linear.join_side()  # a second gradient for the same weight: the sum reads both, possibly side-stream products
+        self._stash[k] = self._stash[k] + g
 
     def collect(self, first, subset=None):
         """Move this micro-batch's gradients into the flat buffer: one multi-tensor copy (first

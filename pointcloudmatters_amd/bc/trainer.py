@@ -102,8 +102,10 @@ class BCTrainer:
     """
 
     def __init__(self, policy, total_steps, optim=None, precision="fp32", device=None, distributed=False,
-                 sync_batchnorm=True, bucket_cap_mb=32, log_every_n_steps=50, mode="eager", flat_optimizer_cls=None, staged=None):
+                 sync_batchnorm=True, bucket_cap_mb=32, log_every_n_steps=50, mode="eager", flat_optimizer_cls=None, staged=None,
+                 side_weight_grads=False):
         o = dict(ACT_OPTIM)
+        self.side_weight_grads = bool(side_weight_grads)
         if optim:
             o.update(optim)
         self.cfg = o
@@ -303,9 +305,27 @@ class BCTrainer:
         # hybrid mode always hands gradients over explicitly (its two halves write disjoint parts of the flat buffer at
         # different times); the other modes do so only for the bf16 mirror, fp32 accumulates through the .grad views
         collect = getattr(opt, "collect_mode", False) or self.mode == "hybrid"
+        from ..policy import rows_linear
+
+        # weight-gradient products on a second stream (rows_linear._SideQueue): only where gradients are handed over
+        # explicitly (nothing reads a dW before `collect`) and the step is replayed as a hipGraph (parallel branches).
+        # OFF by default: measured on MI355X / ROCm 7.2 at C2 the replayed step gets SLOWER with the extra branches
+        # (7.55 -> 7.93 ms with every dW on the side stream, 8.1 ms with only the 8192-row ones): DESIGN.md section 9
+        rows_linear.SIDE.active = bool(collect and self.side_weight_grads and self.mode in ("graph", "hybrid"))
+        try:
+            yield from self._segments_inner(make_out, first, stages, leaf, collect)
+        finally:
+            rows_linear.join_side()
+            rows_linear.SIDE.active = False
+
+    def _segments_inner(self, make_out, first, stages, leaf, collect):
+        from ..policy import rows_linear, staging
+
+        opt = self.optimizer
         if len(stages) == 1:
             out = make_out()
             (out["loss"] / self.accumulate).backward()
+            rows_linear.join_side()
             if collect:
                 opt.collect(first=first, subset=None if len(stages[0].indices) == len(opt.params) else stages[0].indices)
             yield 0, self._stats_of(out)
@@ -321,6 +341,7 @@ class BCTrainer:
                 inputs = inputs + [leaf]
             if roots:
                 torch.autograd.backward(roots, grads, inputs=inputs)
+            rows_linear.join_side()
             if collect:
                 opt.collect(first=first, subset=st.indices)
             if st.lower is not None:

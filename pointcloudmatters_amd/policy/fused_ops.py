@@ -12,6 +12,7 @@ import torch
 from torch.autograd import Function
 
 from .. import _lib
+from .rows_linear import goes_to_optimizer as _goes_to_optimizer
 
 _ACTIVE = None
 
@@ -141,6 +142,7 @@ class _ProjDRLN(Function):
         out, s, mean, rstd = _drln_forward(x2, y2, gamma, beta, eps, p_drop, seed, site)
         ctx.save_for_backward(a2, wc, s, mean, rstd, gamma)
         ctx.meta = (shape, a.shape, a.dtype, weight.dtype, bias.dtype, y2.dtype, float(p_drop), seed, int(site))
+        ctx.side_ok = _goes_to_optimizer(weight)
         return out.view(shape)
 
     @staticmethod
@@ -156,7 +158,7 @@ class _ProjDRLN(Function):
             da = (dy @ wc).view(ashape)
             if da.dtype != adt:
                 da = da.to(adt)
-            dw = weight_grad(dy, a2, wdt)
+            dw = weight_grad(dy, a2, wdt, side=ctx.side_ok)
             db = res[3] if want16 else sums[2].to(bdt)
         return da, dw, db, dx.view(shape), sums[0], sums[1], None, None, None, None
 
@@ -210,6 +212,7 @@ class _FFNLN(Function):
         _lib.check(rc, "pcm_ffn_ln_forward_hip")
         ctx.save_for_backward(x2, w1, w2, gamma, hd, s, mean, rstd)
         ctx.meta = (shape, float(p_hidden), float(p_out), seed, int(site_b))
+        ctx.side_ok = _goes_to_optimizer(w1) and _goes_to_optimizer(w2)
         return out.view(shape)
 
     @staticmethod
@@ -238,8 +241,8 @@ class _FFNLN(Function):
             from .rows_linear import weight_grad
 
             with torch.autocast(device_type="cuda", enabled=False):
-                dw2 = weight_grad(dy, hd, torch.float32)  # (E, F)   split-K over the rows when there are thousands
-                dw1 = weight_grad(dh, x2, torch.float32)  # (F, E)
+                dw2 = weight_grad(dy, hd, torch.float32, side=ctx.side_ok)  # (E, F)   split-K over the rows when there are thousands
+                dw1 = weight_grad(dh, x2, torch.float32, side=ctx.side_ok)  # (F, E)
         dgamma, dbeta, db2, db1 = sums[:E], sums[E : 2 * E], sums[2 * E : 3 * E], sums[3 * E :]
         return dx.view(shape), dw1, db1, dw2, db2, dgamma, dbeta, None, None, None, None, None, None
 
@@ -293,6 +296,7 @@ class _SelfAttnInProj(Function):
             v = torch.nn.functional.linear(v_in, wc[2 * E:], bc[2 * E:]).view(shape)
         ctx.save_for_backward(qk_in, v_in, wc)
         ctx.meta = (shape, pos.shape, w.dtype, b.dtype, pos.requires_grad)
+        ctx.side_ok = _goes_to_optimizer(w)
         q, k = qk.unbind(-2)
         return q, k, v
 
@@ -327,8 +331,8 @@ class _SelfAttnInProj(Function):
             rc = L.pcm_add2_cast_hip(dx.numel(), d_qk_in.data_ptr(), d_v_in.data_ptr(), dx.data_ptr(), st)
             _lib.check(rc, "pcm_add2_cast_hip")
             dw = torch.empty(3 * E, E, dtype=wdt, device=dev)
-            weight_grad(dqk, qk_in, wdt, out=dw[: 2 * E])
-            weight_grad(dv2, v_in, wdt, out=dw[2 * E:])
+            weight_grad(dqk, qk_in, wdt, out=dw[: 2 * E], side=ctx.side_ok)
+            weight_grad(dv2, v_in, wdt, out=dw[2 * E:], side=ctx.side_ok)
             db = torch.empty(3 * E, dtype=bdt, device=dev)
             partial = torch.empty(L.pcm_colsum_slots(rows, E) * 3 * E, dtype=torch.float32, device=dev)
             es = dqk.element_size()
