@@ -1,7 +1,7 @@
 """Attention core for short query sequences on the matrix cores (csrc/attn_small.hip) as an autograd function.
 
 ``small_attention(q, k, v, key_padding_mask, heads, dropout_p)`` == softmax(q k^T / sqrt(d) + mask) (dropout) v per head
-for q (B, L, E), k / v (B, S, E) in bf16 with E = heads * 64 (the policy uses it for L <= 128, S <= 1024); returns (B, L, E) -- already in the layout
+for q (B, L, E), k / v (B, S, E) in bf16 with E = heads * 64 (the policy uses it for L <= 128, S <= 4096); returns (B, L, E) -- already in the layout
 the output projection wants (the SDPA path needs a transpose copy).  Used by policy/transformer.attention for the CVAE
 encoder and the decoder; the long encoder self-attention (S = M + 3 tokens) stays on the framework's flash kernel.
 """
@@ -17,7 +17,7 @@ from .. import _lib
 # B*H = 64, 515 x 515 the forward ties the framework's flash kernel (45 us) and the backward loses (233 vs 128 us), so
 # the policy routes only <= 128 queries here (CVAE encoder, decoder self- and cross-attention).
 MAX_QUERIES = 128
-MAX_KEYS = 1024
+MAX_KEYS = 4096  # cross-attention over the REF memory (2051 tokens): forward 28 us vs 61 us for the flash kernel, backward on par
 
 
 def _st(t):

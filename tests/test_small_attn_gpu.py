@@ -99,7 +99,7 @@ def run_case(B, H, L, S, masked, packed, p=0.0):
 
 
 @pytest.mark.parametrize("B,H,L,S", [(2, 8, 100, 100), (3, 8, 102, 102), (2, 8, 100, 515), (1, 2, 1, 5), (2, 4, 128, 33),
-                                     (8, 8, 100, 100), (2, 1, 33, 64), (1, 8, 128, 128), (2, 8, 515, 515), (1, 2, 129, 40), (1, 1, 300, 257)])
+                                     (8, 8, 100, 100), (2, 1, 33, 64), (1, 8, 128, 128), (2, 8, 515, 515), (1, 2, 129, 40), (1, 1, 300, 257), (2, 8, 100, 2051)])
 @pytest.mark.parametrize("masked", [False, True])
 def test_small_attention_matches_fp32_reference(B, H, L, S, masked):
     run_case(B, H, L, S, masked, packed=False)
