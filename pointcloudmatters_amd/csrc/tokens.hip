@@ -41,7 +41,8 @@ __global__ __launch_bounds__(kBlock) void pcm_add_cast2_kernel(long n4, long pos
 }
 
 __global__ __launch_bounds__(kBlock) void pcm_add2_cast_kernel(long n4, const __hip_bfloat16 *__restrict__ a,
-                                                               const __hip_bfloat16 *__restrict__ b, float *__restrict__ out)
+                                                               const __hip_bfloat16 *__restrict__ b, float *__restrict__ out,
+                                                               float *__restrict__ a32)
 {
     for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (long)gridDim.x * kBlock) {
         float x[4], y[4], o[4];
@@ -50,6 +51,7 @@ __global__ __launch_bounds__(kBlock) void pcm_add2_cast_kernel(long n4, const __
 #pragma unroll
         for (int u = 0; u < 4; ++u) o[u] = x[u] + y[u];
         store4<float>(out + i * 4, o);
+        if (a32 != nullptr) store4<float>(a32 + i * 4, x);  // the first addend alone, widened (the position gradient)
     }
 }
 
@@ -133,13 +135,18 @@ extern "C" int pcm_add_cast2_hip(long n, long pos_n, const float *x, const float
     return PCM_LAUNCH_STATUS();
 }
 
-extern "C" int pcm_add2_cast_hip(long n, const void *a_bf16, const void *b_bf16, float *out, void *stream)
+extern "C" int pcm_add2_cast2_hip(long n, const void *a_bf16, const void *b_bf16, float *out, float *a_f32, void *stream)
 {
     if (n == 0) return PCM_OK;
     if (n < 0 || n % 4) return PCM_ERR_BAD_ARG;
     hipLaunchKernelGGL(pcm_add2_cast_kernel, dim3(ew_grid(n / 4)), dim3(kBlock), 0, (hipStream_t)stream, n / 4,
-                       (const __hip_bfloat16 *)a_bf16, (const __hip_bfloat16 *)b_bf16, out);
+                       (const __hip_bfloat16 *)a_bf16, (const __hip_bfloat16 *)b_bf16, out, a_f32);
     return PCM_LAUNCH_STATUS();
+}
+
+extern "C" int pcm_add2_cast_hip(long n, const void *a_bf16, const void *b_bf16, float *out, void *stream)
+{
+    return pcm_add2_cast2_hip(n, a_bf16, b_bf16, out, nullptr, stream);
 }
 
 extern "C" int pcm_slab_sum_hip(int nslabs, long n, const float *partial, int out_is_bf16, void *out, void *stream)

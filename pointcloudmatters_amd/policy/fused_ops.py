@@ -280,6 +280,8 @@ class _SelfAttnInProj(Function):
             x2 = x2.contiguous()
         rows = x2.shape[0]
         posc = pos.expand(pos.shape[0], *shape[1:]) if pos.dim() == x.dim() and pos.shape[1:] != shape[1:] else pos
+        if posc.dim() == x.dim() and posc.shape[0] > 1 and posc.stride(0) == 0:
+            posc = posc[:1]  # a batch-broadcast view (query_pos): the kernel broadcasts by index, no materialised copy
         posc = posc.contiguous()
         dev = x.device
         bf = torch.bfloat16
@@ -328,8 +330,11 @@ class _SelfAttnInProj(Function):
             d_qk_in = dqk @ wc[: 2 * E]
             d_v_in = dv2 @ wc[2 * E:]
             dx = torch.empty(rows, E, dtype=torch.float32, device=dev)
-            rc = L.pcm_add2_cast_hip(dx.numel(), d_qk_in.data_ptr(), d_v_in.data_ptr(), dx.data_ptr(), st)
-            _lib.check(rc, "pcm_add2_cast_hip")
+            # the position gradient is d_qk_in alone: widened by the same launch when it has the shape of x (query_pos)
+            dpos32 = torch.empty(rows, E, dtype=torch.float32, device=dev) if (pos_grad and tuple(pos_shape) == tuple(shape)) else None
+            rc = L.pcm_add2_cast2_hip(dx.numel(), d_qk_in.data_ptr(), d_v_in.data_ptr(), dx.data_ptr(),
+                                      dpos32.data_ptr() if dpos32 is not None else 0, st)
+            _lib.check(rc, "pcm_add2_cast2_hip")
             dw = torch.empty(3 * E, E, dtype=wdt, device=dev)
             weight_grad(dqk, qk_in, wdt, out=dw[: 2 * E], side=ctx.side_ok)
             weight_grad(dv2, v_in, wdt, out=dw[2 * E:], side=ctx.side_ok)
@@ -340,9 +345,77 @@ class _SelfAttnInProj(Function):
                                   partial.data_ptr(), int(bdt == bf), db.data_ptr(), st)
             _lib.check(rc, "pcm_colsum_hip")
             dpos = None
-            if pos_grad:
+            if dpos32 is not None:
+                dpos = dpos32.view(shape)
+            elif pos_grad:
                 dpos = d_qk_in.float().view(shape).sum_to_size(pos_shape)
         return dx.view(shape), dpos, dw, db
+
+
+class _AddPosLinear(Function):
+    """y = linear(x + pos, w, b) under bf16 autocast as ONE autograd node (the decoder's cross-attention query
+    projection): csrc/tokens.hip adds and casts in one launch; backward writes the input gradient in fp32 straight from
+    the GEMM (no cast launches either way) and hands the SAME tensor to x and pos (they enter as a sum)."""
+
+    @staticmethod
+    def forward(ctx, x, pos, w, b):
+        L = _lib.load()
+        shape = x.shape
+        E = shape[-1]
+        x2 = x.reshape(-1, E)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        posc = pos
+        if posc.dim() == x.dim() and posc.shape[0] > 1 and posc.stride(0) == 0:
+            posc = posc[:1]
+        posc = posc.contiguous()
+        bf = torch.bfloat16
+        wc = w if w.dtype == bf else w.to(bf)
+        bc = b if b.dtype == bf else b.to(bf)
+        with torch.cuda.device(x.device):
+            s_in = torch.empty(x2.shape, dtype=bf, device=x.device)
+            rc = L.pcm_add_cast2_hip(x2.numel(), posc.numel(), x2.data_ptr(), posc.data_ptr(), s_in.data_ptr(), 0,
+                                     torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "pcm_add_cast2_hip")
+        with torch.autocast("cuda", enabled=False):
+            y = torch.nn.functional.linear(s_in, wc, bc).view(*shape[:-1], wc.shape[0])
+        ctx.save_for_backward(s_in, wc)
+        ctx.meta = (shape, pos.shape, w.dtype, b.dtype)
+        ctx.side_ok = _goes_to_optimizer(w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .rows_linear import weight_grad
+
+        s_in, wc = ctx.saved_tensors
+        shape, pos_shape, wdt, bdt = ctx.meta
+        bf = torch.bfloat16
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if dy2.dtype != bf or not dy2.is_contiguous():
+            dy2 = dy2.to(bf).contiguous()
+        dx = dpos = dw = db = None
+        with torch.cuda.device(dy.device), torch.autocast("cuda", enabled=False):
+            if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+                d_in = torch.mm(dy2, wc, out_dtype=torch.float32).view(shape)  # fp32 out of the bf16 GEMM: no cast kernel
+                dx = d_in if ctx.needs_input_grad[0] else None
+                dpos = d_in.sum_to_size(pos_shape) if ctx.needs_input_grad[1] else None
+            if ctx.needs_input_grad[2]:
+                dw = weight_grad(dy2, s_in, wdt, side=ctx.side_ok)
+            if ctx.needs_input_grad[3]:
+                db = dy2.sum(dim=0).to(bdt)
+        return dx, dpos, dw, db
+
+
+def add_pos_linear_supported(x, pos, w, b):
+    return (_ACTIVE is not None and x.is_cuda and x.dtype == torch.float32 and pos is not None and pos.dtype == torch.float32
+            and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16 and b is not None
+            and x.shape[-1] % 4 == 0 and pos.dim() == x.dim() and pos.shape[1:] == x.shape[1:] and pos.shape[0] in (1, x.shape[0])
+            and w.dtype in (torch.float32, torch.bfloat16) and torch.is_grad_enabled())
+
+
+def add_pos_linear(x, pos, w, b):
+    return _AddPosLinear.apply(x, pos, w, b)
 
 
 def self_attn_in_proj_supported(x, pos, mha):

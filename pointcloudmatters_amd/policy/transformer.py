@@ -80,6 +80,7 @@ def attention(
     kv: Optional[tuple] = None,
     project: bool = True,
     qk_parts: Optional[tuple] = None,
+    q_parts: Optional[tuple] = None,
 ) -> Tensor:
     """Multi-head attention with the parameters of ``mha``; inputs (B, L, E) / (B, S, E).
     ``key_padding_mask`` (B, S) bool, True = ignore (nn.MultiheadAttention convention).
@@ -105,7 +106,15 @@ def attention(
         pass
     elif kv is not None:
         k, v, w_q, b_q = kv  # projected memory + this layer's query projection (split once by the decoder)
-        q = linear_rows(query, w_q, b_q)
+        if q_parts is not None:
+            from . import fused_ops
+
+            if fused_ops.add_pos_linear_supported(q_parts[0], q_parts[1], w_q, b_q):
+                q = fused_ops.add_pos_linear(q_parts[0], q_parts[1], w_q, b_q)  # add + cast + GEMM, one autograd node
+            else:
+                q = linear_rows(_add_pos(*q_parts), w_q, b_q)
+        else:
+            q = linear_rows(query, w_q, b_q)
     elif query is key:
         w_qk, w_v = torch.split(w, [2 * e, e], dim=0)
         b_qk, b_v = torch.split(b, [2 * e, e], dim=0)
@@ -218,8 +227,12 @@ class TransformerDecoderLayer(nn.Module):
             return _residual(tgt, self.dropout3(self._ffn(self.norm3(tgt))))
         tgt = _attn_add_norm(self.norm1, self.dropout1, tgt, self.self_attn, None, None, None, None, self.training,
                              qk_parts=(tgt, query_pos))
-        tgt = _attn_add_norm(self.norm2, self.dropout2, tgt, ca, _add_pos(tgt, query_pos), memory_pos, memory,
-                             memory_key_padding_mask, self.training, kv=kv)
+        if kv is not None and query_pos is not None:  # query = tgt + query_pos is formed inside the projection's node
+            tgt = _attn_add_norm(self.norm2, self.dropout2, tgt, ca, tgt, memory_pos, memory, memory_key_padding_mask,
+                                 self.training, kv=kv, q_parts=(tgt, query_pos))
+        else:
+            tgt = _attn_add_norm(self.norm2, self.dropout2, tgt, ca, _add_pos(tgt, query_pos), memory_pos, memory,
+                                 memory_key_padding_mask, self.training, kv=kv)
         return _ffn_norm(self, self.norm3, self.dropout3, tgt)
 
 
