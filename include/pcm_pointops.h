@@ -361,6 +361,9 @@ int pcm_add_cast2_hip(long n, long pos_n, const float *x, const float *pos, void
 int pcm_add2_cast_hip(long n, const void *a_bf16, const void *b_bf16, float *out, void *stream);
 /* same, and a_f32 (nullable) = f32(a): the first addend alone, widened in the same pass */
 int pcm_add2_cast2_hip(long n, const void *a_bf16, const void *b_bf16, float *out, float *a_f32, void *stream);
+/* same with a third, fp32 addend c (nullable): out = f32(a) + f32(b) + c */
+int pcm_add3_cast2_hip(long n, const void *a_bf16, const void *b_bf16, const float *c_f32, float *out, float *a_f32,
+                       void *stream);
 int pcm_colsum_slots(long rows, int C);
 /* out[e] = sum over nslabs of partial[s*n + e] (fp64, fixed order), written as fp32 or bf16: closes a split-K product */
 int pcm_slab_sum_hip(int nslabs, long n, const float *partial, int out_is_bf16, void *out, void *stream);

@@ -144,6 +144,7 @@ class BCTrainer:
             from ..policy.fused_ops import FusedContext
 
             self._fused_ctx = FusedContext(self.device)
+            self._fused_ctx.defer_pos_grads = True  # this loop flushes the sinks after every backward call (_segments_inner)
         trainable = [p for p in self.policy.parameters() if p.requires_grad]
         # ---- backward stages: parameters ordered by when their gradient is complete (latest-used first)
         want_stages = (self.distributed and mode != "eager") if staged is None else bool(staged)
@@ -325,6 +326,8 @@ class BCTrainer:
         if len(stages) == 1:
             out = make_out()
             (out["loss"] / self.accumulate).backward()
+            if self._fused_ctx is not None:
+                self._fused_ctx.flush_sinks()
             rows_linear.join_side()
             if collect:
                 opt.collect(first=first, subset=None if len(stages[0].indices) == len(opt.params) else stages[0].indices)
@@ -341,6 +344,8 @@ class BCTrainer:
                 inputs = inputs + [leaf]
             if roots:
                 torch.autograd.backward(roots, grads, inputs=inputs)
+            if self._fused_ctx is not None:
+                self._fused_ctx.flush_sinks()  # deferred position-embedding gradients of this stage (fused_ops.GradSink)
             rows_linear.join_side()
             if collect:
                 opt.collect(first=first, subset=st.indices)

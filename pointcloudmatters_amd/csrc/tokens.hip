@@ -42,7 +42,7 @@ __global__ __launch_bounds__(kBlock) void pcm_add_cast2_kernel(long n4, long pos
 
 __global__ __launch_bounds__(kBlock) void pcm_add2_cast_kernel(long n4, const __hip_bfloat16 *__restrict__ a,
                                                                const __hip_bfloat16 *__restrict__ b, float *__restrict__ out,
-                                                               float *__restrict__ a32)
+                                                               float *__restrict__ a32, const float *__restrict__ c32)
 {
     for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (long)gridDim.x * kBlock) {
         float x[4], y[4], o[4];
@@ -50,6 +50,12 @@ __global__ __launch_bounds__(kBlock) void pcm_add2_cast_kernel(long n4, const __
         load4<__hip_bfloat16>(b + i * 4, y);
 #pragma unroll
         for (int u = 0; u < 4; ++u) o[u] = x[u] + y[u];
+        if (c32 != nullptr) {  // a third, fp32 addend: the residual branch's gradient of the same tensor
+            float z[4];
+            load4<float>(c32 + i * 4, z);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) o[u] += z[u];
+        }
         store4<float>(out + i * 4, o);
         if (a32 != nullptr) store4<float>(a32 + i * 4, x);  // the first addend alone, widened (the position gradient)
     }
@@ -135,13 +141,19 @@ extern "C" int pcm_add_cast2_hip(long n, long pos_n, const float *x, const float
     return PCM_LAUNCH_STATUS();
 }
 
-extern "C" int pcm_add2_cast2_hip(long n, const void *a_bf16, const void *b_bf16, float *out, float *a_f32, void *stream)
+extern "C" int pcm_add3_cast2_hip(long n, const void *a_bf16, const void *b_bf16, const float *c_f32, float *out, float *a_f32,
+                                  void *stream)
 {
     if (n == 0) return PCM_OK;
     if (n < 0 || n % 4) return PCM_ERR_BAD_ARG;
     hipLaunchKernelGGL(pcm_add2_cast_kernel, dim3(ew_grid(n / 4)), dim3(kBlock), 0, (hipStream_t)stream, n / 4,
-                       (const __hip_bfloat16 *)a_bf16, (const __hip_bfloat16 *)b_bf16, out, a_f32);
+                       (const __hip_bfloat16 *)a_bf16, (const __hip_bfloat16 *)b_bf16, out, a_f32, c_f32);
     return PCM_LAUNCH_STATUS();
+}
+
+extern "C" int pcm_add2_cast2_hip(long n, const void *a_bf16, const void *b_bf16, float *out, float *a_f32, void *stream)
+{
+    return pcm_add3_cast2_hip(n, a_bf16, b_bf16, nullptr, out, a_f32, stream);
 }
 
 extern "C" int pcm_add2_cast_hip(long n, const void *a_bf16, const void *b_bf16, float *out, void *stream)

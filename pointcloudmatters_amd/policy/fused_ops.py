@@ -26,6 +26,14 @@ class FusedContext:
         self._ring = PinnedRing((1,), torch.int64, self.device)  # a single pinned word rewritten every step would race its DMA
         self.base_seed = int(base_seed)
         self.site = 0
+        # set by a training loop that runs backward itself and calls flush_sinks() before it reads the gradients:
+        # gradients of a position embedding shared by many attention sites are then summed once (GradSink)
+        self.defer_pos_grads = False
+        self.sinks = []
+
+    def flush_sinks(self):
+        for sink in self.sinks:
+            sink.flush()
 
     def set_step(self, step):
         """Host side, between steps / graph replays: an asynchronous 8-byte copy on the current stream."""
@@ -43,6 +51,7 @@ def activate(ctx):
     prev, _ACTIVE = _ACTIVE, ctx
     if ctx is not None:
         ctx.site = 0
+        ctx.sinks = []
     try:
         yield ctx
     finally:
@@ -51,6 +60,43 @@ def activate(ctx):
 
 def current():
     return _ACTIVE
+
+
+class GradSink:
+    """The decoder adds the SAME query position embedding at 2 sites per layer (transformer.py:330-346): 14 gradients of
+    shape (B, L, E) that the autograd engine would add pairwise (13 launches) before the expand-backward sum.  With a
+    sink the sites see a detached copy of the embedding, push their gradient here, and ``flush`` adds them in one
+    stack + sum and back-propagates the total into the embedding's own graph.  Only used when a FusedContext with
+    ``defer_pos_grads`` is active, i.e. by a loop that promises to flush before reading gradients; any consumer that
+    cannot push (a non-fused fallback) raises instead of dropping the gradient (transformer._add_pos)."""
+
+    def __init__(self, source):
+        self.source = source
+        self.grads = []
+
+    def add(self, g):
+        self.grads.append(g)
+
+    def flush(self):
+        if not self.grads:
+            return
+        gs, self.grads = self.grads, []
+        total = gs[0] if len(gs) == 1 else torch.stack(gs).sum(dim=0)
+        torch.autograd.backward([self.source], [total.view_as(self.source)])
+
+
+def defer_grads(pos):
+    """pos (requires grad) -> a detached alias carrying a GradSink, or pos itself when deferral is off."""
+    ctx = _ACTIVE
+    if ctx is None or not ctx.defer_pos_grads or not pos.requires_grad or not torch.is_grad_enabled():
+        return pos
+    if not (pos.is_cuda and pos.dtype == torch.float32 and torch.is_autocast_enabled("cuda")
+            and torch.get_autocast_dtype("cuda") == torch.bfloat16):
+        return pos  # the consumers that can push (_SelfAttnInProj, _AddPosLinear) are the bf16-autocast nodes
+    alias = pos.detach()
+    alias._pcm_sink = GradSink(pos)
+    ctx.sinks.append(alias._pcm_sink)
+    return alias
 
 
 class _DRLN(Function):
@@ -297,13 +343,17 @@ class _SelfAttnInProj(Function):
             qk = torch.nn.functional.linear(qk_in, wc[: 2 * E], bc[: 2 * E]).view(*shape[:-1], 2, E)
             v = torch.nn.functional.linear(v_in, wc[2 * E:], bc[2 * E:]).view(shape)
         ctx.save_for_backward(qk_in, v_in, wc)
-        ctx.meta = (shape, pos.shape, w.dtype, b.dtype, pos.requires_grad)
+        ctx.sink = getattr(pos, "_pcm_sink", None)
+        ctx.meta = (shape, pos.shape, w.dtype, b.dtype, pos.requires_grad or ctx.sink is not None)
         ctx.side_ok = _goes_to_optimizer(w)
         q, k = qk.unbind(-2)
-        return q, k, v
+        # x is handed back as a fourth output for the caller's residual branch: x then has ONE consumer in the autograd
+        # graph and this node receives the residual's gradient, which it folds into its closing add kernel (otherwise the
+        # engine adds the two gradients of x with a launch of its own)
+        return q, k, v, x.view_as(x)
 
     @staticmethod
-    def backward(ctx, dq, dk, dv):
+    def backward(ctx, dq, dk, dv, dres=None):
         from .rows_linear import weight_grad
 
         L = _lib.load()
@@ -332,9 +382,13 @@ class _SelfAttnInProj(Function):
             dx = torch.empty(rows, E, dtype=torch.float32, device=dev)
             # the position gradient is d_qk_in alone: widened by the same launch when it has the shape of x (query_pos)
             dpos32 = torch.empty(rows, E, dtype=torch.float32, device=dev) if (pos_grad and tuple(pos_shape) == tuple(shape)) else None
-            rc = L.pcm_add2_cast2_hip(dx.numel(), d_qk_in.data_ptr(), d_v_in.data_ptr(), dx.data_ptr(),
-                                      dpos32.data_ptr() if dpos32 is not None else 0, st)
-            _lib.check(rc, "pcm_add2_cast2_hip")
+            if dres is not None:
+                dres = dres.reshape(rows, E)
+                if dres.dtype != torch.float32 or not dres.is_contiguous():
+                    dres = dres.float().contiguous()
+            rc = L.pcm_add3_cast2_hip(dx.numel(), d_qk_in.data_ptr(), d_v_in.data_ptr(), dres.data_ptr() if dres is not None else 0,
+                                      dx.data_ptr(), dpos32.data_ptr() if dpos32 is not None else 0, st)
+            _lib.check(rc, "pcm_add3_cast2_hip")
             dw = torch.empty(3 * E, E, dtype=wdt, device=dev)
             weight_grad(dqk, qk_in, wdt, out=dw[: 2 * E], side=ctx.side_ok)
             weight_grad(dv2, v_in, wdt, out=dw[2 * E:], side=ctx.side_ok)
@@ -349,6 +403,9 @@ class _SelfAttnInProj(Function):
                 dpos = dpos32.view(shape)
             elif pos_grad:
                 dpos = d_qk_in.float().view(shape).sum_to_size(pos_shape)
+            if ctx.sink is not None and dpos is not None:
+                ctx.sink.add(dpos)
+                dpos = None
         return dx.view(shape), dpos, dw, db
 
 
@@ -382,6 +439,7 @@ class _AddPosLinear(Function):
         ctx.save_for_backward(s_in, wc)
         ctx.meta = (shape, pos.shape, w.dtype, b.dtype)
         ctx.side_ok = _goes_to_optimizer(w)
+        ctx.sink = getattr(pos, "_pcm_sink", None)
         return y
 
     @staticmethod
@@ -396,10 +454,13 @@ class _AddPosLinear(Function):
             dy2 = dy2.to(bf).contiguous()
         dx = dpos = dw = db = None
         with torch.cuda.device(dy.device), torch.autocast("cuda", enabled=False):
-            if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.sink is not None:
                 d_in = torch.mm(dy2, wc, out_dtype=torch.float32).view(shape)  # fp32 out of the bf16 GEMM: no cast kernel
                 dx = d_in if ctx.needs_input_grad[0] else None
-                dpos = d_in.sum_to_size(pos_shape) if ctx.needs_input_grad[1] else None
+                if ctx.sink is not None:
+                    ctx.sink.add(d_in.sum_to_size(pos_shape))
+                else:
+                    dpos = d_in.sum_to_size(pos_shape) if ctx.needs_input_grad[1] else None
             if ctx.needs_input_grad[2]:
                 dw = weight_grad(dy2, s_in, wdt, side=ctx.side_ok)
             if ctx.needs_input_grad[3]:
@@ -428,5 +489,6 @@ def self_attn_in_proj_supported(x, pos, mha):
 
 
 def self_attn_in_proj(x, pos, mha):
-    """q, k, v (each (B, S, E) bf16) for self-attention with position-augmented queries / keys."""
+    """q, k, v (each (B, S, E) bf16) for self-attention with position-augmented queries / keys, and x again (an alias
+    for the residual branch, see _SelfAttnInProj.forward)."""
     return _SelfAttnInProj.apply(x, pos, mha.in_proj_weight, mha.in_proj_bias)

@@ -52,7 +52,9 @@ def _attn_add_norm(norm: nn.Module, dropout: nn.Module, x: Tensor, mha: nn.Multi
 
     ctx_on = fused_ops.current() is not None and x.is_cuda and x.dtype == torch.float32
     if ctx_on:
-        a = attention(mha, *args, project=False, **kwargs)
+        aux = {}
+        a = attention(mha, *args, project=False, aux=aux, **kwargs)
+        x = aux.get("residual", x)  # the in-projection node's alias of x (fused_ops._SelfAttnInProj): one consumer of x
         ydt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else a.dtype
         if fused_ops.drln_supported(x, None, norm, y_dtype=ydt) and mha.out_proj.bias is not None:
             return fused_ops.proj_drln(a, mha.out_proj, x, norm, dropout)
@@ -81,6 +83,7 @@ def attention(
     project: bool = True,
     qk_parts: Optional[tuple] = None,
     q_parts: Optional[tuple] = None,
+    aux: Optional[dict] = None,
 ) -> Tensor:
     """Multi-head attention with the parameters of ``mha``; inputs (B, L, E) / (B, S, E).
     ``key_padding_mask`` (B, S) bool, True = ignore (nn.MultiheadAttention convention).
@@ -97,7 +100,9 @@ def attention(
 
         x_in, pos_in = qk_parts
         if fused_ops.self_attn_in_proj_supported(x_in, pos_in, mha):
-            q, k, v = fused_ops.self_attn_in_proj(x_in, pos_in, mha)  # one autograd node (csrc/tokens.hip)
+            q, k, v, x_res = fused_ops.self_attn_in_proj(x_in, pos_in, mha)  # one autograd node (csrc/tokens.hip)
+            if aux is not None:
+                aux["residual"] = x_res  # the caller's residual branch reads x through this alias
             query, projected = x_in, True
         else:
             query = key = _add_pos(x_in, pos_in)
@@ -158,6 +163,9 @@ def _activation(name):
 
 
 def _add_pos(x, pos):
+    if pos is not None and getattr(pos, "_pcm_sink", None) is not None:
+        raise RuntimeError("a position embedding with deferred gradients (fused_ops.defer_grads) reached a consumer that "
+                           "cannot push into its sink: its gradient would be lost")
     return x if pos is None else x + pos
 
 
@@ -357,5 +365,9 @@ class Transformer(nn.Module):
         memory = self.encoder(tokens, src_key_padding_mask=mask, pos=pos)
         memory, pos_dec = staging.cut("transformer.decoder", memory, pos)
         query_pos = query_embed.unsqueeze(0).expand(bs, -1, -1)
+        if self.training and not self.decoder.layers[0].normalize_before:
+            from . import fused_ops
+
+            query_pos = fused_ops.defer_grads(query_pos)  # 14 gradient sites -> one sum (no-op unless a training loop opted in)
         tgt = torch.zeros_like(query_pos)
         return self.decoder(tgt, memory, memory_key_padding_mask=mask, pos=pos_dec, query_pos=query_pos)

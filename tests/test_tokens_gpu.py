@@ -64,23 +64,77 @@ def test_self_attn_in_proj_node_matches_framework_chain(pos_batch, pos_grad):
     x = torch.randn(b, s, e, device=DEV, requires_grad=True)
     pos = torch.randn(pos_batch, s, e, device=DEV, requires_grad=pos_grad)
     gq, gk, gv = (torch.randn(b, s, e, device=DEV).bfloat16() for _ in range(3))
+    gres = torch.randn(b, s, e, device=DEV)  # gradient of the residual branch that reads x through the node's alias
 
     def ref():
         qk_in = (x + pos).bfloat16()
         q, k = F.linear(qk_in, w16[: 2 * e], b16[: 2 * e]).unflatten(-1, (2, e)).unbind(-2)
         v = F.linear(x.bfloat16(), w16[2 * e:], b16[2 * e:])
-        return q, k, v
+        return q, k, v, x * 1.0
 
     with fused_ops.activate(fused_ops.FusedContext(DEV)), torch.autocast("cuda", dtype=torch.bfloat16):
         assert fused_ops.self_attn_in_proj_supported(x, pos, mha)
         got = fused_ops._SelfAttnInProj.apply(x, pos, w16, b16)
     want = ref()
+    assert len(got) == 4 and got[3].data_ptr() == x.data_ptr()  # q, k, v and x again (alias for the residual branch)
     for a, r in zip(got, want):
         torch.testing.assert_close(a.float(), r.float(), rtol=1e-2, atol=1e-2)
     ins = [x, w16, b16] + ([pos] if pos_grad else [])
-    g_got = torch.autograd.grad(got, ins, (gq, gk, gv))
-    g_ref = torch.autograd.grad(want, ins, (gq, gk, gv))
+    g_got = torch.autograd.grad(got, ins, (gq, gk, gv, gres))
+    g_ref = torch.autograd.grad(want, ins, (gq, gk, gv, gres))
     for a, r, name in zip(g_got, g_ref, ("dx", "dw", "db", "dpos")):
         assert a.dtype == r.dtype and a.shape == r.shape, name
         scale = r.float().abs().max().item()
         assert (a.float() - r.float()).abs().max().item() <= 2e-2 * scale + 1e-3, name
+
+
+@pytest.mark.parametrize("broadcast", [False, True])
+def test_add_pos_linear_node_and_gradient_sink(broadcast):
+    """fused_ops._AddPosLinear (the decoder's cross-attention query projection) against the framework chain, with the
+    position gradient returned directly and pushed into a GradSink (fused_ops.defer_grads)."""
+    from pointcloudmatters_amd.policy import fused_ops
+
+    torch.manual_seed(1)
+    b, s, e = 4, 100, 256
+    lin = nn.Linear(e, e).to(DEV)
+    w16 = lin.weight.detach().bfloat16().requires_grad_(True)
+    b16 = lin.bias.detach().bfloat16().requires_grad_(True)
+    x = torch.randn(b, s, e, device=DEV, requires_grad=True)
+    emb = torch.randn(s, e, device=DEV, requires_grad=True)
+    g = torch.randn(b, s, e, device=DEV).bfloat16()
+
+    def pos_of():
+        return emb.unsqueeze(0).expand(b, -1, -1) if broadcast else emb.unsqueeze(0).expand(b, -1, -1) * 1.0
+
+    want = F.linear((x + pos_of()).bfloat16(), w16, b16)
+    g_ref = torch.autograd.grad(want, [x, emb, w16, b16], g)
+    for deferred in (False, True):
+        ctx = fused_ops.FusedContext(DEV)
+        ctx.defer_pos_grads = deferred
+        with fused_ops.activate(ctx), torch.autocast("cuda", dtype=torch.bfloat16):
+            pos = fused_ops.defer_grads(pos_of())
+            assert (getattr(pos, "_pcm_sink", None) is not None) == deferred
+            assert fused_ops.add_pos_linear_supported(x, pos, w16, b16)
+            got = fused_ops.add_pos_linear(x, pos, w16, b16)
+            got2 = fused_ops.add_pos_linear(x, pos, w16, b16)  # a second site sharing the embedding
+        torch.testing.assert_close(got.float(), want.float(), rtol=1e-2, atol=1e-2)
+        for t in (x, emb, w16, b16):
+            t.grad = None
+        torch.autograd.backward([got, got2], [g, g])
+        if deferred:
+            assert emb.grad is None  # nothing arrived yet: the sites pushed into the sink
+            ctx.flush_sinks()
+        for t, r, name in zip((x, emb, w16, b16), g_ref, ("dx", "demb", "dw", "db")):
+            scale = r.float().abs().max().item()
+            assert (t.grad.float() - 2 * r.float()).abs().max().item() <= 4e-2 * scale + 2e-3, (name, deferred)
+    # a consumer that cannot push must refuse the detached alias instead of dropping the gradient
+    from pointcloudmatters_amd.policy.transformer import _add_pos
+
+    ctx = fused_ops.FusedContext(DEV)
+    ctx.defer_pos_grads = True
+    with fused_ops.activate(ctx), torch.autocast("cuda", dtype=torch.bfloat16):
+        pos = fused_ops.defer_grads(pos_of())
+        with pytest.raises(RuntimeError):
+            _add_pos(x, pos)
+    with fused_ops.activate(ctx):  # no bf16 autocast: the pushing nodes would not run, so nothing is deferred
+        assert getattr(fused_ops.defer_grads(pos_of()), "_pcm_sink", None) is None
