@@ -84,8 +84,9 @@ def timed_events(fn, iters, warmup=3):
 
 
 class KernelTable:
-    def __init__(self):
+    def __init__(self, shape_name=None):
         self.rows = {}
+        self.shape_name = shape_name  # key into profiles/pmc_traffic.json ("shapes"), None = the workload (C2)
 
     def add(self, name, ms, nbytes, bound, note, flops=None, extra=None):
         rec = {"ms": round(ms, 5), "bound": bound, "note": note}
@@ -97,6 +98,12 @@ class KernelTable:
                        frac_of_mfma_peak=round(flops / ms / 1e9 / MFMA_BF16_PEAK_TF, 6))
         if extra:
             rec.update(extra)
+        if "pcm_" in name and "(" not in name and "+" not in name:  # a single kernel: its PMC-measured HBM bytes per launch
+            pmc = pmc_traffic(name, self.shape_name)
+            if pmc is not None:
+                rec["pmc_hbm_bytes"] = int(pmc)
+                if nbytes:
+                    rec["pmc_over_algorithmic"] = round(pmc / nbytes, 2)
         self.rows[name] = rec
 
 
@@ -423,7 +430,7 @@ def kernel_rooflines_hbm(device, names=None):
     for name, shape in HBM_SHAPES.items():
         if names and name not in names:
             continue
-        t = KernelTable()
+        t = KernelTable(shape_name=name)
         pointops_and_sa_kernels(t, shape, device)
         out[name] = {"shape": dict(shape), "kernels": t.rows}
         torch.cuda.empty_cache()
@@ -524,7 +531,7 @@ def pick_roofline(trace, kernels):
                "avg_us_in_trace": rec["avg_us"], "launches_per_step": rec["launches_per_step"], "ms_alone": kr["ms"], "note": kr["note"]}
         if kr["bound"] == "mfma":
             out.update(bound="mfma", achieved=kr["achieved_TFLOPs"], peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s", frac=kr["frac_of_mfma_peak"],
-                       traffic=None)
+                       traffic=pmc_traffic(key))
         else:
             out.update(bound="hbm", limited_by=kr["bound"], achieved=kr["achieved_GBs"], peak=HBM_PEAK_GBS, unit="GB/s",
                        frac=kr["frac_of_hbm_peak"], traffic=pmc_traffic(key))

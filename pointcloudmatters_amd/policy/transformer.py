@@ -365,7 +365,9 @@ class Transformer(nn.Module):
         memory = self.encoder(tokens, src_key_padding_mask=mask, pos=pos)
         memory, pos_dec = staging.cut("transformer.decoder", memory, pos)
         query_pos = query_embed.unsqueeze(0).expand(bs, -1, -1)
-        if self.training and not self.decoder.layers[0].normalize_before:
+        dec = self.decoder
+        batched_kv = dec.batch_memory_kv and not (dec.return_intermediate and dec.first_only == "skip")
+        if self.training and batched_kv and not dec.layers[0].normalize_before:  # both sites of every layer can push
             from . import fused_ops
 
             query_pos = fused_ops.defer_grads(query_pos)  # 14 gradient sites -> one sum (no-op unless a training loop opted in)
