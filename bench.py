@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--dead-decoder-layers", default="keep", choices=["keep", "prune_backward", "skip"],
                     help="ACT reads only decoder output [0] (act.py:270): keep = the reference's autograd graph (default, what "
                          "`value` is quoted on); prune_backward / skip = dead-code elimination variants, reported separately")
+    ap.add_argument("--sampling-in-graph", action="store_true",
+                    help="graph mode: capture FPS / kNN inside the graph (round-1 behaviour) instead of running them one batch ahead")
     ap.add_argument("--no-prefetch", action="store_true", help="do not hand the next batch to the trainer early (hybrid / flat / eager modes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel legs (kernels, kernels_hbm, step_trace, roofline)")
@@ -622,14 +624,14 @@ def run_workload(name, args, device, world, rank, steps, warmup, precision=None,
         # captured stages are exchanged between graph replays, overlapping the rest of backward.
         mode = "hybrid" if (wl["ragged"] or world > 1) else "graph"
     trainer = BCTrainer(policy, total_steps=max(steps + warmup + trace_steps, 100), precision=wl["dtype"], device=device,
-                        distributed=world > 1, mode=mode,
+                        distributed=world > 1, mode=mode, external_sampling=not getattr(args, "sampling_in_graph", False),
                         optim=dict(DP_OPTIM) if is_dp else (dict(RLBENCH_ACT_OPTIM) if is_rlb else dict(accumulate_grad_batches=1)))
     batches = [make_batch(wl["batch"], wl["n_points"], seed=1000 + rank + 97 * i, ragged=wl["ragged"], device=device)
                for i in range(4)]
 
     def step(i):
-        # the next batch is handed over early, as a prefetching data loader would: outside graph mode its FPS + kNN run one
-        # step ahead on the side stream (graph mode ignores it: the sampling is inside the captured graph)
+        # the next batch is handed over early, as a prefetching data loader would: its FPS + kNN + SA index pass run one step
+        # ahead on the side stream (in graph mode through static index buffers; every batch is sampled exactly once)
         nxt = None if args.no_prefetch else batches[(i + 1) % len(batches)]
         trainer.training_step(clone_batch(batches[i % len(batches)]), prefetch=nxt)
 

@@ -103,9 +103,11 @@ class BCTrainer:
 
     def __init__(self, policy, total_steps, optim=None, precision="fp32", device=None, distributed=False,
                  sync_batchnorm=True, bucket_cap_mb=32, log_every_n_steps=50, mode="eager", flat_optimizer_cls=None, staged=None,
-                 side_weight_grads=False):
+                 side_weight_grads=False, external_sampling=True):
         o = dict(ACT_OPTIM)
         self.side_weight_grads = bool(side_weight_grads)
+        self.external_sampling = bool(external_sampling)  # graph mode: FPS / kNN outside the captured graph (prefetchable)
+        self._static_sampling = False
         if optim:
             o.update(optim)
         self.cfg = o
@@ -465,6 +467,15 @@ class BCTrainer:
         self._static_sig = self._signature(batch)
         self._static_batch = self._clone_static(batch)
         stages = self._stages
+        # sampling outside the graph: FPS / kNN / index statistics depend on the coordinates only, so they are computed
+        # eagerly on the side stream -- one batch ahead when the caller hands the next batch over (training_step(...,
+        # prefetch=)) -- and reach the replayed graphs through static index buffers
+        self._static_sampling = False
+        target, pcds = self._sampling_target(), self._pcds_of(self._static_batch)
+        if self.external_sampling and target is not None and hasattr(target, "install_static_sampling") and pcds is not None \
+                and getattr(target, "sa_impl", None) == "fused":
+            target.install_static_sampling(pcds, target.sampling_for(pcds, overlap=False))
+            self._static_sampling = True
 
         def gen(first):
             def make_out():
@@ -566,18 +577,28 @@ class BCTrainer:
 
     def prefetch_sampling(self, next_batch):
         """Hand the NEXT micro-batch over early (what a data loader's prefetch does): its FPS + kNN indices -- functions of
-        the input coordinates only -- are computed on the side stream while the current step runs.  Pays off in hybrid
-        mode, where the sampling otherwise sits in front of the captured graph; a no-op in graph mode (the sampling is
-        part of the captured graph there) and on the host."""
-        if self.mode == "graph" or next_batch is None:
+        the input coordinates only -- are computed on the side stream while the current step runs.  In hybrid mode the
+        sampling otherwise sits in front of the captured graph; in graph mode it is kept OUT of the captured graph
+        (static index buffers, `_static_sampling`) precisely so that it can run one batch ahead."""
+        if next_batch is None or (self.mode == "graph" and not self._static_sampling):
             return
-        pcds = next_batch["pcds"] if "pcds" in next_batch else next_batch.get("obs", {}).get("pcds")
+        pcds = self._pcds_of(next_batch)
         if pcds is None or not pcds["coord"].is_cuda:
             return
+        target = self._sampling_target()
+        if target is not None:
+            target.prefetch_sampling(pcds)
+
+    @staticmethod
+    def _pcds_of(batch):
+        return batch["pcds"] if "pcds" in batch else batch.get("obs", {}).get("pcds")
+
+    def _sampling_target(self):
         pol = self.policy
         target = pol if hasattr(pol, "prefetch_sampling") else getattr(pol, "obs_encoder", None)
         if target is not None and getattr(target, "overlap_sampling", False) and hasattr(target, "prefetch_sampling"):
-            target.prefetch_sampling(pcds)
+            return target
+        return None
 
     def training_step(self, batch, prefetch=None):
         """One micro-batch: forward, loss, backward and -- on accumulation boundaries -- the
@@ -628,6 +649,9 @@ class BCTrainer:
                                      "use mode='flat' for ragged batches")
                 if first:
                     self.optimizer.zero_grad()
+                if self._static_sampling:  # this batch's indices: prefetched during the previous step, or computed now
+                    target = self._sampling_target()
+                    target.load_static_sampling(target.sampling_for(self._pcds_of(batch), overlap=True))
                 self._copy_into(self._static_batch, batch)
                 use_acc = not (first or self._graph_acc is None)
                 for si, g in enumerate(self._graph_acc if use_acc else self._graph):

@@ -211,6 +211,18 @@ class ACTPCD(nn.Module):
         coord, offset = pcd_dict["coord"], pcd_dict["offset"]
         set_abstraction.prefetch_sampling(self, self.pointops, coord, offset, self._new_offsets(offset))
 
+    def sampling_for(self, pcd_dict, overlap=True):
+        """FPS / kNN / index statistics of these clouds: the prefetched result if `prefetch_sampling` saw them, else
+        computed now (on the side stream with `overlap`)."""
+        coord, offset = pcd_dict["coord"], pcd_dict["offset"]
+        return set_abstraction.sample_and_query(self, self.pointops, coord, offset, self._new_offsets(offset), overlap=overlap)
+
+    def install_static_sampling(self, pcd_dict, pre):
+        set_abstraction.install_static(self, pcd_dict["coord"], pcd_dict["offset"], pre)
+
+    def load_static_sampling(self, pre):
+        set_abstraction.load_static(self, pre)
+
     def forward_pcd_embed(self, pcd_dict):
         coord, offset = pcd_dict["coord"], pcd_dict["offset"]
         n_o = self._new_offsets(offset)
