@@ -505,7 +505,17 @@ class PCDObsEncoder(_AttrMixin):
         x = pcd_dict["sa_tokens"] if "sa_tokens" in pcd_dict else self.sa_tokens(pcd_model, pcd_dict)
         x = x.view(-1, self.pcd_npoints, x.shape[-1]).transpose(1, 2)  # "(b n) c -> b c n"
         for layer in self.projector:  # 1x1 convolutions as GEMMs (MIOpen falls back to naive bf16 kernels here)
-            x = conv1d_gemm(x, layer) if isinstance(layer, nn.Conv1d) else layer(x.contiguous() if isinstance(layer, nn.BatchNorm1d) else x)
+            if isinstance(layer, nn.Conv1d):
+                x = conv1d_gemm(x, layer)
+            elif isinstance(layer, nn.MaxPool1d) and x.is_cuda and layer.kernel_size == x.shape[-1] and layer.stride == layer.kernel_size \
+                    and layer.padding == 0 and layer.dilation == 1 and not layer.ceil_mode:
+                # MaxPool1d over the whole token axis == a row maximum: the framework's max_pool_forward_nchw walks the
+                # 2048-wide window with one thread per output (282 us at C5 against 9 us for the reduction kernel)
+                # (.max(dim), not amax: like the pooling kernel it routes the gradient to ONE position -- the first maximum --
+                # where amax would split it among bf16 ties)
+                x = x.max(dim=-1, keepdim=True).values
+            else:
+                x = layer(x.contiguous() if isinstance(layer, nn.BatchNorm1d) else x)
         return x.squeeze(-1)
 
     def pcd_features(self, pcd_dict):
