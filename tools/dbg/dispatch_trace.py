@@ -33,11 +33,19 @@ class Tracer(TorchDispatchMode):
         return func(*args, **(kwargs or {}))
 
 dev = torch.device("cuda:0")
-wl = WORKLOADS["C2"]
+WL = os.environ.get("PCM_TRACE_WORKLOAD", "C2")
+wl = WORKLOADS[WL]
 torch.manual_seed(1000)
-pol = build_act_policy(pcd_npoints=wl["pcd_npoints"], sa_impl="fused").to(dev)
-tr = BCTrainer(pol, total_steps=100, precision="bf16", device=dev, mode="flat", optim=dict(accumulate_grad_batches=1))
-batches = [make_act_batch(wl["batch"], wl["n_points"], seed=1000 + 97 * i, device=dev) for i in range(4)]
+if wl.get("policy") == "dp" or WL in ("C3", "C5"):
+    from pointcloudmatters_amd.bc import build_dp_policy, make_dp_batch
+    from pointcloudmatters_amd.bc.configs import DP_OPTIM
+    pol = build_dp_policy(pcd_npoints=wl["pcd_npoints"], sa_impl="fused").to(dev)
+    tr = BCTrainer(pol, total_steps=100, precision="bf16", device=dev, mode="flat", optim=dict(DP_OPTIM))
+    batches = [make_dp_batch(wl["batch"], wl["n_points"], seed=1000 + 97 * i, device=dev) for i in range(4)]
+else:
+    pol = build_act_policy(pcd_npoints=wl["pcd_npoints"], sa_impl="fused").to(dev)
+    tr = BCTrainer(pol, total_steps=100, precision="bf16", device=dev, mode="flat", optim=dict(accumulate_grad_batches=1))
+    batches = [make_act_batch(wl["batch"], wl["n_points"], seed=1000 + 97 * i, device=dev) for i in range(4)]
 for i in range(3):
     tr.training_step(clone_batch(batches[i % 4]))
 torch.cuda.synchronize()
