@@ -470,6 +470,7 @@ def _family(name):
 def step_trace(step_fn, steps):
     """Kernel-level composition of the timed step: torch.profiler (roctracer) over `steps` extra steps -- graph replays
     report every replayed kernel.  Returns {"error": ...} when the profiler is unavailable."""
+    done = 0
     try:
         from torch.profiler import ProfilerActivity, profile
 
@@ -477,6 +478,7 @@ def step_trace(step_fn, steps):
         with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
             for i in range(steps):
                 step_fn(i)
+                done += 1
             torch.cuda.synchronize()
         rows = []
         for e in prof.key_averages():
@@ -486,6 +488,9 @@ def step_trace(step_fn, steps):
             if dt and dt > 0 and "CUDA" in str(getattr(e, "device_type", "DeviceType.CUDA")):
                 rows.append((float(dt), int(e.count), e.key))
     except Exception as e:  # depends on the box
+        for i in range(done, steps):  # the other ranks take exactly `steps` steps (collectives inside): stay in lockstep
+            step_fn(i)
+        torch.cuda.synchronize()
         return {"error": "%s: %s" % (type(e).__name__, e)}
     if not rows:
         return {"error": "the profiler returned no device events"}
@@ -680,6 +685,18 @@ def main():
                                                   trace_steps=8)
     metrics = trainer.metrics()
     is_dp = wl["policy"] == "dp"
+    # the step trace runs extra training steps: with several ranks EVERY rank must take them (they contain the gradient
+    # exchange and the SyncBN collectives); only rank 0 records the profile
+    trace = None
+    if not args.no_roofline:
+        if rank == 0:
+            trace = step_trace(step, 6)
+        elif world > 1:
+            for i in range(6):
+                step(i)
+            torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
 
     if rank == 0:
         samples = wl["batch"] * world * args.steps
@@ -702,7 +719,6 @@ def main():
             "final_loss": round(metrics.get("train/loss", float("nan")), 4),
         }
         if not args.no_roofline:
-            trace = step_trace(step, 6)
             kr = kernel_rooflines(wl, device, c_feat=96 if is_dp else 512, hidden=96 if is_dp else 512)
             out["step_trace"] = trace
             rl = pick_roofline(trace, kr)
