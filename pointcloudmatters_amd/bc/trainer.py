@@ -279,18 +279,39 @@ class BCTrainer:
             return torch.autocast(device_type=self.device.type, dtype=torch.bfloat16)
         return contextlib.nullcontext()
 
-    def _shadow_repl(self, only=None):
+    def _shadow_items(self, only=None):
+        """(module, attribute name, master parameter, flat index) of every bf16-mirrored parameter (restricted to the flat
+        indices in `only`), resolved once: the per-step substitution is then two dict operations per parameter instead
+        of torch.func.functional_call's walk over the module tree (1 ms per call for this policy)."""
         shadows = getattr(self, "_shadow_names", None)
         if not shadows:
-            return None
-        opt = self.optimizer
-        return {n: _ShadowParam.apply(p, opt.shadow[k], opt, k) for n, p, k in shadows if only is None or k in only}
+            return ()
+        cache = self.__dict__.setdefault("_shadow_item_cache", {})
+        key = None if only is None else id(only)
+        if key not in cache:
+            items = []
+            for n, p, k in shadows:
+                if only is not None and k not in only:
+                    continue
+                path, _, attr = n.rpartition(".")
+                items.append((self.policy.get_submodule(path) if path else self.policy, attr, p, k))
+            cache[key] = (tuple(items), only)  # `only` kept alive: its id is the cache key
+        return cache[key][0]
 
     def _call_policy(self, batch, only=None, **kwargs):
-        repl = self._shadow_repl(only)
-        if repl is not None:
-            return torch.func.functional_call(self.policy, repl, (batch,), kwargs)
-        return self.module(batch, **kwargs)
+        items = self._shadow_items(only)
+        if not items:
+            return self.module(batch, **kwargs)
+        opt = self.optimizer
+        try:
+            # an instance attribute shadows the registered nn.Parameter for every `module.weight` read in forward();
+            # named_parameters() / state_dict() keep seeing the fp32 masters
+            for mod, attr, p, k in items:
+                mod.__dict__[attr] = _ShadowParam.apply(p, opt.shadow[k], opt, k)
+            return self.policy(batch, **kwargs)
+        finally:
+            for mod, attr, _, _ in items:
+                mod.__dict__.pop(attr, None)
 
     @staticmethod
     def _stats_of(out):
