@@ -625,7 +625,8 @@ class BCTrainer:
         """One micro-batch: forward, loss, backward and -- on accumulation boundaries -- the
         optimizer step.  Returns the (detached, on-device) loss dict of this micro-batch.
         `prefetch`: the next micro-batch, if it is already on the device (see prefetch_sampling)."""
-        self.module.train()
+        if not self.module.training:  # .train() walks ~230 modules (1 ms of host time): only when something switched to eval
+            self.module.train()
         if prefetch is not None:
             self.prefetch_sampling(prefetch)
         if self._fused_ctx is not None:

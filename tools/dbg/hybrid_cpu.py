@@ -26,4 +26,4 @@ pr = cProfile.Profile(); pr.enable()
 for i in range(20):
     tr.training_step(clone_batch(batches[i % 4]), prefetch=batches[(i + 1) % 4])
 pr.disable(); torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+pstats.Stats(pr).sort_stats("tottime").print_stats(45)
