@@ -667,11 +667,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py measures the MI355X path; no HIP device found"
+    # test hook (tests/test_bench_multirank_gpu.py): PCM_BENCH_SHARE_GPU=1 puts every rank on device 0 and carries the
+    # collectives over gloo, so that the complete multi-rank flow of this file runs on a one-GPU box.  Never set by the driver.
+    share_gpu = os.environ.get("PCM_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl")  # "nccl" is RCCL on ROCm; communicators are created lazily
+        dist.init_process_group(backend="gloo" if share_gpu else "nccl")  # "nccl" is RCCL on ROCm; communicators are created lazily
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     if args.kernels_only:
