@@ -321,7 +321,7 @@ class ACTPCD(nn.Module):
         # The CVAE encoder (102 tokens) and the point-cloud tokenizer are independent until the decoder:
         # on the GPU the former runs on a forked HIP stream (its backward follows on the same stream), so
         # its ~200 small kernels fill the gaps of the PointNet / set-abstraction branch.
-        fork = self.overlap_sampling and data_dict["qpos"].is_cuda
+        fork = self.overlap_sampling and getattr(self, "fork_cvae", True) and data_dict["qpos"].is_cuda
         if fork:
             main = torch.cuda.current_stream(data_dict["qpos"].device)
             side = self.__dict__.get("_cvae_stream")
