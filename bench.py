@@ -13,12 +13,14 @@ Data parallel: one process per GPU, batch sharded (weak scaling: B per GPU fixed
 all-reduced over RCCL in backward-ordered slabs that overlap the rest of backward (bc/trainer.py).
 Prints ONE JSON line on rank 0.
 
-What the JSON line carries besides the contract fields:
+The stdout line (< 4 KB, asserted) carries the contract fields plus
+  roofline     the hand-written kernel with the LARGEST total time in a kernel trace of the timed step, priced against its bound
+  cpu_baseline the reference path restated on the host cores;  extra: an fp32 GPU line and the shipped REF shape
+  step         launches per step and device-time share by kernel family
+and `tables` names the side file (gpurun_out/bench_tables.json) with the bulky evidence:
   step_trace   composition of the timed step from a torch.profiler (roctracer) kernel trace of a few extra steps
-  roofline     the hand-written kernel with the LARGEST total time in that trace, priced against its bound
   kernels      every hand-written kernel timed alone with HIP events at the workload's shapes
   kernels_hbm  the gather / scatter / sampling kernels at shapes whose operands exceed the caches (C3, C5, REF)
-  cpu_baseline the reference path restated on the host cores;  extra: an fp32 GPU line and the shipped REF shape
 """
 import argparse
 import json
@@ -64,6 +66,9 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip the extra lines (fp32 GPU run, REF shape)")
     ap.add_argument("--kernels-only", action="store_true", help="only run the per-kernel timing leg (for rocprofv3 --pmc passes)")
     ap.add_argument("--kernel-shape", default=None, help="with --kernels-only: C2 (default = the workload) | C3 | C5 | REF")
+    ap.add_argument("--no-hbm-tables", action="store_true", help="skip the per-kernel tables at the HBM-sized shapes (C3 / C5 / REF)")
+    ap.add_argument("--tables-out", default=os.path.join(ROOT, "gpurun_out", "bench_tables.json"),
+                    help="where the per-kernel tables and the step trace are written (they are NOT part of the stdout line)")
     ap.add_argument("--cpu-steps", type=int, default=6)
     ap.add_argument("--cpu-threads", type=int, default=16)
     return ap.parse_args()
@@ -90,7 +95,9 @@ class KernelTable:
         self.rows = {}
         self.shape_name = shape_name  # key into profiles/pmc_traffic.json ("shapes"), None = the workload (C2)
 
-    def add(self, name, ms, nbytes, bound, note, flops=None, extra=None):
+    def add(self, name, ms, nbytes, bound, note, flops=None, extra=None, pmc_key=None):
+        """pmc_key: the exact rocprofv3 kernel name (template arguments included) whose PMC row belongs to this entry, for
+        entries whose label is not a kernel name (API ops made of several launches)."""
         rec = {"ms": round(ms, 5), "bound": bound, "note": note}
         if nbytes is not None:
             rec.update(algorithmic_bytes=int(nbytes), achieved_GBs=round(nbytes / ms / 1e6, 3),
@@ -100,9 +107,11 @@ class KernelTable:
                        frac_of_mfma_peak=round(flops / ms / 1e9 / MFMA_BF16_PEAK_TF, 6))
         if extra:
             rec.update(extra)
-        if "pcm_" in name and "(" not in name and "+" not in name:  # a single kernel: its PMC-measured HBM bytes per launch
-            pmc = pmc_traffic(name, self.shape_name)
+        if pmc_key or ("pcm_" in name and "(" not in name and "+" not in name):  # a single kernel: its PMC-measured HBM bytes per launch
+            pmc = pmc_traffic(pmc_key or name, self.shape_name)
             if pmc is not None:
+                if pmc_key:
+                    rec["pmc_kernel"] = pmc_key
                 rec["pmc_hbm_bytes"] = int(pmc)
                 if nbytes:
                     rec["pmc_over_algorithmic"] = round(pmc / nbytes, 2)
@@ -221,7 +230,8 @@ def pointops_and_sa_kernels(t, shape, device):
 
     t.add("pcm_group_xyz_feat backward (plan + pcm_segment_sum_kernel)", timed_events(gbwd, 20),
           rows * (c_feat + 3) * 4 + 12 * rows + n_tot * c_feat * 4, "hbm",
-          "API op backward: idx inverted to a CSR (5 small launches), then every feature row summed once, no atomics")
+          "API op backward: idx inverted to a CSR (5 small launches), then every feature row summed once, no atomics",
+          pmc_key="pcm_segment_sum_kernel<%d, 0>" % (4 if (c_feat + 3) % 4 == 0 else 1))
     del grouped, gout
     # ---- interpolation (kNN k=3 weights + gather) and ball query, API ops ----------------------------------
     try:
@@ -241,7 +251,8 @@ def pointops_and_sa_kernels(t, shape, device):
               timed_events(lambda: L.pcm_interpolation_forward_hip(n_tot, c_feat, 3, fm.data_ptr(), idx3.data_ptr(), w3.data_ptr(),
                                                                    o3.data_ptr(), st), 20),
               n_tot * 3 * 8 + m * c_feat * 4 + n_tot * c_feat * 4, "hbm",
-              "the gather alone: one lane group per output row, 16-byte loads, (idx, weight) fetched once per group")
+              "the gather alone: one lane group per output row, 16-byte loads, (idx, weight) fetched once per group",
+              pmc_key="pcm_segment_sum_kernel<%d, 1>" % (4 if c_feat % 4 == 0 else 1))
         go = torch.randn_like(out)
 
         def ibwd():
@@ -549,23 +560,30 @@ def pick_roofline(trace, kernels):
     return None
 
 
-def pmc_traffic(kernel, shape=None):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json,
-    produced by tools/collect_profiles.sh with the FETCH_SIZE / WRITE_SIZE corrections of the guide), or None."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if not os.path.exists(path):
-        return None
-    with open(path) as f:
-        table = json.load(f)
+def _norm_kernel_name(name):
+    return name.replace("(anonymous namespace)::", "").replace("void ", "").replace(" ", "")
+
+
+def pmc_traffic(kernel, shape=None, table=None):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, produced by
+    tools/collect_profiles.sh with the FETCH_SIZE / WRITE_SIZE corrections of the guide), or None.  Rows are keyed by the FULL
+    kernel name: `pcm_segment_sum_kernel<4, 1>` and `<1, 0>` are different kernels with different traffic.  A name without
+    template arguments matches only when exactly one instantiation of that kernel was profiled."""
+    if table is None:
+        path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if not os.path.exists(path):
+            return None
+        with open(path) as f:
+            table = json.load(f)
     kernels = table.get("shapes", {}).get(shape or "C2", None)
     if kernels is None:
         kernels = table.get("kernels", {}) if shape is None else {}
-    best = None
-    for name, rec in kernels.items():
-        base = name.split("<")[0]
-        if base and base in kernel and (best is None or len(base) > len(best[0])):
-            best = (base, rec.get("hbm_bytes_per_launch"))
-    return best[1] if best else None
+    want = _norm_kernel_name(kernel.split("(")[0])
+    exact = [rec for name, rec in kernels.items() if _norm_kernel_name(name) == want]
+    if exact:
+        return exact[0].get("hbm_bytes_per_launch")
+    variants = [rec for name, rec in kernels.items() if _norm_kernel_name(name).split("<")[0] == want.split("<")[0]]
+    return variants[0].get("hbm_bytes_per_launch") if len(variants) == 1 else None
 
 
 def cpu_baseline(wl, steps, threads=16):
@@ -659,6 +677,59 @@ def run_workload(name, args, device, world, rank, steps, warmup, precision=None,
     return dt, trainer, step, wl, sa_impl
 
 
+def summarize_trace(trace):
+    """The few numbers of the step trace that belong in the headline line (the full trace goes to the tables file)."""
+    if not trace or "error" in trace:
+        return {"error": (trace or {}).get("error", "no trace")}
+    return {"launches_per_step": trace["launches_per_step"], "device_ms_per_step": trace["device_ms_per_step"],
+            "share_by_family": {k: v["share"] for k, v in trace["by_family"].items()}}
+
+
+MAX_LINE_BYTES = 4096  # the driver keeps only a tail of stdout: the ONE JSON line must fit with a wide margin
+
+
+def compact_line(out):
+    """json.dumps(out) guaranteed to stay under MAX_LINE_BYTES: optional blocks are dropped (never the contract fields,
+    `roofline` or `cpu_baseline`), long strings inside them are clipped first."""
+    def clip(o, n):
+        if isinstance(o, dict):
+            return {k: clip(v, n) for k, v in o.items()}
+        if isinstance(o, list):
+            return [clip(v, n) for v in o]
+        if isinstance(o, str) and len(o) > n:
+            return o[:n - 1] + "~"
+        return o
+
+    line = json.dumps(out)
+    for n in (240, 160, 100, 60):
+        if len(line) < MAX_LINE_BYTES:
+            return line
+        out = clip(out, n)
+        line = json.dumps(out)
+    for key in ("step", "extra", "roofline_hbm_resident", "tables", "final_loss"):
+        if len(line) < MAX_LINE_BYTES:
+            break
+        out = {k: v for k, v in out.items() if k != key}
+        line = json.dumps(out)
+    assert len(line) < MAX_LINE_BYTES, len(line)
+    return line
+
+
+def emit(out, tables, tables_path):
+    """Per-kernel tables and the step trace go to a side file (gpurun_out/bench_tables.json by default); stdout carries
+    exactly ONE short JSON line, last."""
+    if tables:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(tables_path)), exist_ok=True)
+            with open(tables_path, "w") as f:
+                json.dump(dict(tables, headline={k: v for k, v in out.items()}), f, indent=1)
+            out["tables"] = os.path.relpath(tables_path, ROOT)
+        except OSError as e:  # read-only tree: the headline must still print
+            out["tables"] = "not written: %s" % e
+    sys.stdout.flush()
+    print(compact_line(out), flush=True)
+
+
 def main():
     args = parse()
     from pointcloudmatters_amd.bc import WORKLOADS
@@ -739,9 +810,11 @@ def main():
                        "dead_decoder_layers": "n/a" if is_dp else args.dead_decoder_layers},
             "final_loss": round(metrics.get("train/loss", float("nan")), 4),
         }
+        tables = {}
         if not args.no_roofline:
             kr = kernel_rooflines(wl, device, c_feat=96 if is_dp else 512, hidden=96 if is_dp else 512)
-            out["step_trace"] = trace
+            tables["step_trace"] = trace
+            out["step"] = summarize_trace(trace)
             rl = pick_roofline(trace, kr)
             if rl is None:  # no trace on this box: fall back to the longest isolated hand-written kernel
                 dom = max((k for k in kr if "ms" in kr[k] and not any(s in k for s in ("group_xyz", "interpolation", "ball_query"))),
@@ -757,24 +830,22 @@ def main():
                 k = max(big, key=lambda k: kr[k]["ms"])
                 out["roofline_hbm_resident"] = {"kernel": k, "bound": "hbm", "achieved": kr[k]["achieved_GBs"], "peak": HBM_PEAK_GBS,
                                                 "unit": "GB/s", "frac": kr[k]["frac_of_hbm_peak"], "traffic": pmc_traffic(k),
-                                                "algorithmic_bytes": kr[k]["algorithmic_bytes"], "ms_alone": kr[k]["ms"],
-                                                "note": "largest HBM-bound kernel of the step whose bytes per launch exceed the Infinity Cache"}
-            out["kernels"] = kr
+                                                "algorithmic_bytes": kr[k]["algorithmic_bytes"], "ms_alone": kr[k]["ms"]}
+            tables["kernels"] = kr
             del trainer, step
             torch.cuda.empty_cache()
-            hb = kernel_rooflines_hbm(device)
-            for shape_name, rec in hb.items():
-                for kname, krec in rec["kernels"].items():
-                    tr = pmc_traffic(kname, shape_name)
-                    if tr is not None and krec.get("algorithmic_bytes"):
-                        krec["pmc_hbm_bytes"] = tr
-                        krec["traffic_over_algorithmic"] = round(tr / krec["algorithmic_bytes"], 3)
-            out["kernels_hbm"] = hb
+            if not args.no_hbm_tables:
+                hb = kernel_rooflines_hbm(device)
+                for shape_name, rec in hb.items():
+                    for kname, krec in rec["kernels"].items():
+                        if krec.get("pmc_hbm_bytes") and krec.get("algorithmic_bytes"):
+                            krec["traffic_over_algorithmic"] = round(krec["pmc_hbm_bytes"] / krec["algorithmic_bytes"], 3)
+                tables["kernels_hbm"] = hb
         if extra is not None:
             out["extra"] = extra
         if not args.no_cpu_baseline and world == 1 and not is_dp:
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_steps, args.cpu_threads)
-        print(json.dumps(out), flush=True)
+        emit(out, tables, args.tables_out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

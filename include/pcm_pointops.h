@@ -140,9 +140,16 @@ int pcm_aggregation_backward_hip(int n, int nsample, int c, int w_c, const float
  *     dst[j, col] = sign * sum_{t in segment j} src[s(e_t) * src_stride + src_off + col] * scale(e_t, col)
  * with segment j = [start[j], start[j+1]) (start == NULL: [j*seglen, (j+1)*seglen)), e_t = list ? list[t] : t,
  * s(e) = map ? map[e] : e / rowdiv (negative: skipped), scale_mode 0 none | 1 scale[e] | 2 scale[e*w_c + col % w_c]. */
-int pcm_scatter_plan_ws_ints(long rows, int n_dst);
+long pcm_scatter_plan_ws_ints(long rows, int n_dst);
 int pcm_scatter_plan_hip(long rows, int n_dst, const int *idx, int *ws, const int **start_out,
                          const int **list_out, void *stream);
+/* The same CSR with every segment sorted ascending -- a function of idx alone, so a sum taken in list order is
+ * reproducible from run to run (the unsorted plan fills in the order its atomics retire, like the reference's scatter).
+ * start (n_dst + 1) and list (rows) are caller-owned; scratch: pcm_scatter_plan_sorted_scratch_ints(n_dst) ints.
+ * rows + 3 * n_dst must stay below 2^31 (PCM_ERR_UNSUPPORTED otherwise; the same limit applies to pcm_scatter_plan_hip). */
+long pcm_scatter_plan_sorted_scratch_ints(int n_dst);
+int pcm_scatter_plan_sorted_hip(long rows, int n_dst, const int *idx, int *scratch, int *start, int *list,
+                                void *stream);
 int pcm_segment_sum_hip(long n_dst, int c, const int *start, int seglen, const int *list, const int *map,
                         int rowdiv, const float *scale, int scale_mode, int w_c, float sign,
                         const float *src, int src_stride, int src_off, float *dst, void *stream);
@@ -237,6 +244,28 @@ int pcm_sa_fused_backward_hip(int m, int n, int K, int H, int gf_is_bf16, const 
                               float *dWp, float *dgamma, float *dbeta, const int *offset,
                               const int *new_offset, int b, int n_max, const float *red_global, double count,
                               int stage_mask, void *stream);
+
+/* Reproducible (atomic-free) forms of the index pass and of backward pass 1 (csrc/sa_scatter.hip; SURVEY.md section 5
+ * "deterministic-mode option (sorted segmented reduce)").  The neighbour lists are inverted once per batch into a CSR with
+ * sorted segments; cnt / S are segment sums in list order, RM a fixed-order two-level sum; the m*H deltas are bucketed per
+ * query by arg-extremum slot ("pack": runs of (channel, delta)) and every D row is summed run by run in list order
+ * ("gather").  Same results as the atomic kernels up to fp32 re-association, bit-identical from run to run.
+ *   pcm_sa_index_det_hip : writes ent (m,K,4), csr = start (n+1) | list (m*K) ints, cnt (n), S (n,3), RM (12); nothing is
+ *                          zeroed by the caller; scratch: pcm_sa_index_det_scratch_ints(n) ints.
+ *   pcm_sa_bwd1_det_hip  : replaces stages 2|4 of pcm_sa_fused_backward_hip (run that with stage_mask 8|16|32 afterwards):
+ *                          D (n,H) written entirely, red1 (5,H); partial: pcm_sa_bwd1_det_slots(m) * 5 * H floats;
+ *                          ws: pcm_sa_bwd1_det_ws_bytes(m,K,H) bytes.  stage_mask 1 pack | 2 gather | 4 reduce (<= 0 all).
+ *   pcm_sa_det_supported : K <= 63, H <= 1024. */
+int pcm_sa_det_supported(int K, int H);
+long pcm_sa_index_det_scratch_ints(int n);
+int pcm_sa_index_entries_hip(int m, int K, const float *p, const float *q, const int *idx, void *ent, void *stream);
+int pcm_sa_index_det_hip(int m, int K, int n, const float *p, const float *q, const int *idx, void *ent, int *csr,
+                         int *scratch, float *cnt, float *S, float *RM, void *stream);
+int pcm_sa_bwd1_det_slots(int m);
+long pcm_sa_bwd1_det_ws_bytes(int m, int K, int H);
+int pcm_sa_bwd1_det_hip(int m, int n, int K, int H, const float *dz, const float *sel, const unsigned char *asel,
+                        const float *stat, const void *ent, const int *csr, void *ws, float *D, float *partial,
+                        float *red1, int stage_mask, void *stream);
 
 /* ---- hipGraph surgery -----------------------------------------------------------------------------------
  * Replace every MEMSET node of a captured, not yet instantiated hipGraph_t by a fill-kernel node with the same

@@ -34,6 +34,15 @@ SIGNATURES = {
     "pcm_aggregation_backward_hip": [_i, _i, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "pcm_scatter_plan_ws_ints": [ctypes.c_long, _i],
     "pcm_scatter_plan_hip": [ctypes.c_long, _i, _P, _P, _P, _P, _P],
+    "pcm_scatter_plan_sorted_scratch_ints": [_i],
+    "pcm_scatter_plan_sorted_hip": [ctypes.c_long, _i, _P, _P, _P, _P, _P],
+    "pcm_sa_det_supported": [_i, _i],
+    "pcm_sa_index_det_scratch_ints": [_i],
+    "pcm_sa_index_entries_hip": [_i, _i, _P, _P, _P, _P, _P],
+    "pcm_sa_index_det_hip": [_i, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "pcm_sa_bwd1_det_slots": [_i],
+    "pcm_sa_bwd1_det_ws_bytes": [_i, _i, _i],
+    "pcm_sa_bwd1_det_hip": [_i, _i, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _i, _P],
     "pcm_segment_sum_hip": [ctypes.c_long, _i, _P, _i, _P, _P, _i, _P, _i, _i, _f, _P, _i, _i, _P, _P],
     "pcm_attention_relation_step_forward_hip": [_i, _i, _i, _P, _P, _P, _P, _P, _P, _P],
     "pcm_attention_relation_step_backward_hip": [_i, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
@@ -84,6 +93,10 @@ SIGNATURES = {
     "pcm_adamw_flat_hip": [ctypes.c_long, _P, _P, _P, _P, _P, _P, _i, _P, _P, _P],
 }
 
+# functions that return a size (long); everything else returns an int status
+LONG_RESULTS = ("pcm_scatter_plan_ws_ints", "pcm_scatter_plan_sorted_scratch_ints", "pcm_sa_index_det_scratch_ints",
+                "pcm_sa_bwd1_det_ws_bytes")
+
 _LIB = None
 
 
@@ -116,7 +129,7 @@ def load():
         except AttributeError as e:
             raise PointopsLibraryError(f"{LIB_PATH} does not export {name}") from e
         fn.argtypes = args
-        fn.restype = ctypes.c_int
+        fn.restype = ctypes.c_long if name in LONG_RESULTS else ctypes.c_int
     lib.pcm_version.restype = ctypes.c_char_p
     lib.pcm_version.argtypes = []
     _LIB = lib

@@ -904,6 +904,17 @@ extern "C" int pcm_sa_fused_forward_hip(int m, int K, int H, int gf_is_bf16, con
 // index-only products of the neighbour lists: ent (m,K) 16-byte records (j, p_j - q_i), cnt (n), S (n,3), RM (12).
 // cnt / S / RM must be zero on entry.  With the cloud layout (offset, new_offset, b, n_max) and many clouds the
 // statistics use one LDS tile per cloud, otherwise global atomics.
+// the 16-byte neighbour records alone (the reproducible index pass of csrc/sa_scatter.hip builds the rest from a sorted CSR)
+extern "C" int pcm_sa_index_entries_hip(int m, int K, const float *p, const float *q, const int *idx, void *ent, void *stream)
+{
+    if (m <= 0 || K <= 0 || K > kMaxK) return PCM_ERR_BAD_ARG;
+    const long rows = (long)m * K;
+    long blocks = (rows + kBlock - 1) / kBlock;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(pcm_sa_entries_kernel, dim3((int)blocks), dim3(kBlock), 0, PCM_SA_ST, rows, K, p, q, idx, (float4 *)ent);
+    return PCM_LAUNCH_STATUS();
+}
+
 extern "C" int pcm_sa_index_hip(int m, int K, const float *p, const float *q, const int *idx, const int *offset,
                                 const int *new_offset, int b, int n_max, void *ent, float *cnt, float *S, float *RM,
                                 void *stream)

@@ -11,7 +11,8 @@
 // loads and written exactly once: no read-modify-write traffic, no contention on hub rows, and the destination
 // needs no zero-fill.  The per-term arithmetic is the reference's (`acc = acc + g * w`, un-contracted fp32);
 // only the order of the terms of one destination row differs from run to run (the fill order), exactly as the
-// order of the reference's atomics does.
+// order of the reference's atomics does -- unless the plan is built by pcm_scatter_plan_sorted_hip, whose segments are
+// sorted and therefore reproducible.
 //
 //   segment j  = entries t in [start[j], start[j+1])            (start == nullptr: [j*seglen, (j+1)*seglen))
 //   entry id   e = list ? list[t] : t
@@ -111,6 +112,87 @@ __global__ __launch_bounds__(kBlock) void pcm_plan_fill_kernel(long rows, int n_
     for (long r = (long)blockIdx.x * kBlock + threadIdx.x; r < rows; r += (long)gridDim.x * kBlock) {
         const int j = idx[r];
         if (j >= 0 && j < n_dst) list[atomicAdd(cursor + j, 1)] = (int)r;
+    }
+}
+
+// ---- deterministic order: sort the entries of every segment ascending ------------------------------------------
+// pcm_plan_fill_kernel places the entries of one destination row in the order its atomics happen to retire.  After
+// these two passes list[start[j] .. start[j+1]) is ascending, i.e. the CSR -- and every sum taken over it in list
+// order -- is a function of idx alone.  Segments of <= 64 entries (every kNN / ball-query neighbourhood in practice)
+// are rank-sorted in the registers of one wave; longer ones by a bitonic network in LDS (one workgroup each, up to
+// kSortCap entries); anything longer by one thread's in-place heap sort (correct, slow, never seen outside fuzzing).
+constexpr int kSortCap = 16384;  // ints of LDS for one long segment (64 KiB)
+
+__global__ __launch_bounds__(kBlock) void pcm_plan_sort_small_kernel(int n_dst, const int *__restrict__ start, int *__restrict__ list)
+{
+    const int lane = threadIdx.x & 63;
+    const long wave = ((long)blockIdx.x * kBlock + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * kBlock) >> 6;
+    for (long j = wave; j < n_dst; j += nwaves) {
+        const int t0 = start[j], len = start[j + 1] - t0;  // wave-uniform
+        if (len < 2 || len > 64) continue;
+        const int v = lane < len ? list[t0 + lane] : 0x7FFFFFFF;
+        int rank = 0;
+        for (int u = 0; u < len; ++u) rank += __shfl(v, u) < v ? 1 : 0;  // entries are distinct row ids
+        if (lane < len) list[t0 + rank] = v;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void pcm_plan_sort_large_kernel(int n_dst, int per_block, const int *__restrict__ start,
+                                                                      int *__restrict__ list)
+{
+    extern __shared__ int sbuf[];  // kSortCap ints, then a queue of up to kBlock long segments
+    __shared__ int queue[kBlock];
+    __shared__ int nqueue;
+    const int j_begin = blockIdx.x * per_block, j_end = min(n_dst, j_begin + per_block);
+    for (int base = j_begin; base < j_end; base += kBlock) {
+        if (threadIdx.x == 0) nqueue = 0;
+        __syncthreads();
+        const int j = base + threadIdx.x;
+        if (j < j_end && start[j + 1] - start[j] > 64) queue[atomicAdd(&nqueue, 1)] = j;
+        __syncthreads();
+        const int nq = nqueue;
+        for (int qi = 0; qi < nq; ++qi) {
+            const int jj = queue[qi];
+            const int t0 = start[jj], len = start[jj + 1] - t0;
+            if (len <= kSortCap) {
+                int P = 128;
+                while (P < len) P <<= 1;
+                for (int e = threadIdx.x; e < P; e += kBlock) sbuf[e] = e < len ? list[t0 + e] : 0x7FFFFFFF;
+                __syncthreads();
+                for (int k = 2; k <= P; k <<= 1)
+                    for (int s = k >> 1; s > 0; s >>= 1) {
+                        for (int e = threadIdx.x; e < P; e += kBlock) {
+                            const int o = e ^ s;
+                            if (o > e) {
+                                const int a = sbuf[e], b = sbuf[o];
+                                if ((a > b) == ((e & k) == 0)) sbuf[e] = b, sbuf[o] = a;
+                            }
+                        }
+                        __syncthreads();
+                    }
+                for (int e = threadIdx.x; e < len; e += kBlock) list[t0 + e] = sbuf[e];
+                __syncthreads();
+            } else if (threadIdx.x == 0) {  // heap sort in place
+                int *a = list + t0;
+                auto sift = [&](int root, int end) {
+                    for (;;) {
+                        int child = 2 * root + 1;
+                        if (child >= end) break;
+                        if (child + 1 < end && a[child + 1] > a[child]) ++child;
+                        if (a[root] >= a[child]) break;
+                        const int t = a[root];
+                        a[root] = a[child], a[child] = t, root = child;
+                    }
+                };
+                for (int r = len / 2 - 1; r >= 0; --r) sift(r, len);
+                for (int e = len - 1; e > 0; --e) {
+                    const int t = a[0];
+                    a[0] = a[e], a[e] = t;
+                    sift(0, e);
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -247,10 +329,40 @@ inline int blocks_for(long items, long per_block, long cap)
 
 }  // namespace
 
-extern "C" int pcm_scatter_plan_ws_ints(long rows, int n_dst)
+static int plan_build(long rows, int n_dst, const int *idx, int *cnt, int *start, int *cursor, int *tsum, int *list, int sorted,
+                      hipStream_t st)
+{
+    const int tiles = (n_dst + kScanTile - 1) / kScanTile;
+    if (n_dst == 0) {  // start = { 0 }
+        hipLaunchKernelGGL(pcm_plan_zero_kernel, dim3(1), dim3(kBlock), 0, st, 1, start);
+        return PCM_LAUNCH_STATUS();
+    }
+    hipLaunchKernelGGL(pcm_plan_zero_kernel, dim3(blocks_for(n_dst, kBlock, 2048)), dim3(kBlock), 0, st, n_dst, cnt);
+    if (rows > 0)
+        hipLaunchKernelGGL(pcm_plan_count_kernel, dim3(blocks_for(rows, kBlock, 4096)), dim3(kBlock), 0, st, rows, n_dst, idx, cnt);
+    hipLaunchKernelGGL(pcm_plan_tilesum_kernel, dim3(tiles), dim3(kBlock), 0, st, n_dst, cnt, tsum);
+    hipLaunchKernelGGL(pcm_plan_scan_kernel, dim3(tiles), dim3(kBlock), 0, st, n_dst, cnt, tsum, start, cursor);
+    if (rows > 0)
+        hipLaunchKernelGGL(pcm_plan_fill_kernel, dim3(blocks_for(rows, kBlock, 4096)), dim3(kBlock), 0, st, rows, n_dst, idx, cursor, list);
+    if (sorted && rows > 1) {
+        hipLaunchKernelGGL(pcm_plan_sort_small_kernel, dim3(blocks_for(n_dst, kBlock / 64, 2048)), dim3(kBlock), 0, st, n_dst, start, list);
+        const int grid = blocks_for(n_dst, kBlock, 1024);
+        const int per_block = (n_dst + grid - 1) / grid;
+        const size_t lds = (size_t)kSortCap * sizeof(int);
+        const int rc = pcm_status(hipFuncSetAttribute(reinterpret_cast<const void *>(pcm_plan_sort_large_kernel),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (rc) return rc;
+        hipLaunchKernelGGL(pcm_plan_sort_large_kernel, dim3(grid), dim3(kBlock), lds, st, n_dst, per_block, start, list);
+    }
+    return PCM_LAUNCH_STATUS();
+}
+
+static bool plan_fits(long rows, int n_dst) { return rows >= 0 && n_dst >= 0 && rows + 3L * n_dst + 4096 < 2147483647L; }
+
+extern "C" long pcm_scatter_plan_ws_ints(long rows, int n_dst)
 {
     const long tiles = ((long)n_dst + kScanTile - 1) / kScanTile;
-    return (int)(3L * n_dst + 2 + tiles + rows);  // cnt | start (n_dst+1) | cursor | tile sums | list (rows)
+    return 3L * n_dst + 2 + tiles + rows;  // cnt | start (n_dst+1) | cursor | tile sums | list (rows)
 }
 
 // ws: pcm_scatter_plan_ws_ints(rows, n_dst) ints.  On return *start_out / *list_out point into ws.
@@ -258,20 +370,29 @@ extern "C" int pcm_scatter_plan_hip(long rows, int n_dst, const int *idx, int *w
                                     const int **list_out, void *stream)
 {
     if (rows < 0 || n_dst < 0 || (rows > 0 && idx == nullptr) || ws == nullptr) return PCM_ERR_BAD_ARG;
-    hipStream_t st = (hipStream_t)stream;
+    if (!plan_fits(rows, n_dst)) return PCM_ERR_UNSUPPORTED;  // the scan and the list use 32-bit offsets
     const int tiles = (n_dst + kScanTile - 1) / kScanTile;
     int *cnt = ws, *start = cnt + n_dst, *cursor = start + n_dst + 1, *tsum = cursor + n_dst, *list = tsum + (tiles > 0 ? tiles : 0);
     if (start_out) *start_out = start;
     if (list_out) *list_out = list;
-    hipLaunchKernelGGL(pcm_plan_zero_kernel, dim3(blocks_for(n_dst + 1, kBlock, 2048)), dim3(kBlock), 0, st, n_dst + 1, ws);  // cnt, and start[0] for n_dst == 0
-    if (n_dst == 0) return PCM_LAUNCH_STATUS();
-    if (rows > 0)
-        hipLaunchKernelGGL(pcm_plan_count_kernel, dim3(blocks_for(rows, kBlock, 4096)), dim3(kBlock), 0, st, rows, n_dst, idx, cnt);
-    hipLaunchKernelGGL(pcm_plan_tilesum_kernel, dim3(tiles), dim3(kBlock), 0, st, n_dst, cnt, tsum);
-    hipLaunchKernelGGL(pcm_plan_scan_kernel, dim3(tiles), dim3(kBlock), 0, st, n_dst, cnt, tsum, start, cursor);
-    if (rows > 0)
-        hipLaunchKernelGGL(pcm_plan_fill_kernel, dim3(blocks_for(rows, kBlock, 4096)), dim3(kBlock), 0, st, rows, n_dst, idx, cursor, list);
-    return PCM_LAUNCH_STATUS();
+    return plan_build(rows, n_dst, idx, cnt, start, cursor, tsum, list, 0, (hipStream_t)stream);
+}
+
+// The same CSR with every segment sorted ascending (a function of idx alone: sums taken in list order are reproducible
+// from run to run), written to caller-owned arrays: start (n_dst + 1), list (rows); scratch:
+// pcm_scatter_plan_sorted_scratch_ints(n_dst) ints.
+extern "C" long pcm_scatter_plan_sorted_scratch_ints(int n_dst)
+{
+    return 2L * n_dst + ((long)n_dst + kScanTile - 1) / kScanTile + 1;  // cnt | cursor | tile sums
+}
+
+extern "C" int pcm_scatter_plan_sorted_hip(long rows, int n_dst, const int *idx, int *scratch, int *start, int *list, void *stream)
+{
+    if (rows < 0 || n_dst < 0 || (rows > 0 && (idx == nullptr || list == nullptr)) || scratch == nullptr || start == nullptr)
+        return PCM_ERR_BAD_ARG;
+    if (!plan_fits(rows, n_dst)) return PCM_ERR_UNSUPPORTED;
+    int *cnt = scratch, *cursor = cnt + n_dst, *tsum = cursor + n_dst;
+    return plan_build(rows, n_dst, idx, cnt, start, cursor, tsum, list, 1, (hipStream_t)stream);
 }
 
 extern "C" int pcm_segment_sum_hip(long n_dst, int c, const int *start, int seglen, const int *list, const int *map,

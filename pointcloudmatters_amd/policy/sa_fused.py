@@ -8,11 +8,27 @@ statistics and keeps per-(query, channel) max / min / arg -- see the kernel file
 Same result as ``sa_impl="reference"`` up to fp32 re-association (tests: 1e-4 relative), ~K times
 less HBM traffic and no (m, K, 3+C) / (m, H, K) intermediates.
 """
+import os
+
 import torch
 from torch.autograd import Function
 
 from .. import _lib
 from .rows_linear import linear_rows
+
+# How the index statistics and the m*H backward deltas are accumulated:
+#   "sorted"  (default) csrc/sa_scatter.hip: a CSR of the neighbour lists with sorted segments, sums taken in list order --
+#             no float atomics anywhere, two runs of the same step give bit-identical gradients (SURVEY.md section 5);
+#   "atomic"  csrc/sa_fused.hip's LDS / global float atomics (the reference's own backward is atomic too,
+#             libs/pointops/src/grouping/grouping_cuda_kernel.cu:24): a little less traffic, last bits vary from run to run.
+SCATTER_MODE = os.environ.get("PCM_SA_SCATTER", "sorted")
+
+
+def set_scatter_mode(mode):
+    global SCATTER_MODE
+    assert mode in ("sorted", "atomic"), mode
+    old, SCATTER_MODE = SCATTER_MODE, mode
+    return old
 
 
 def _ptr(t):
@@ -22,11 +38,24 @@ def _ptr(t):
 def index_stats(p, q, knn_idx, o32=None, no32=None, n_max=0):
     """cnt (n), S (n,3), RM (12) of the neighbour lists -- the index-only part of the backward (occurrence count and summed
     relative coordinates of every point, global moments).  A function of the coordinates alone: sample_and_query runs it
-    right behind the kNN query on the side stream, off the critical path."""
+    right behind the kNN query on the side stream, off the critical path.  Returns (ent, stats) in "atomic" mode and
+    (ent, stats, csr) in "sorted" mode, csr = start (n+1) | list (m*K) of the sorted inverse neighbour lists."""
     L = _lib.load()
     n = p.shape[0]
     m, K = knn_idx.shape
     b = int(o32.shape[0]) if o32 is not None else 0
+    if SCATTER_MODE == "sorted" and L.pcm_sa_det_supported(K, 4):
+        with torch.cuda.device(p.device):
+            buf = torch.empty(4 * n + 12, dtype=torch.float32, device=p.device)
+            ent = torch.empty(m, K, 4, dtype=torch.float32, device=p.device)
+            csr = torch.empty(n + 1 + m * K, dtype=torch.int32, device=p.device)
+            scratch = torch.empty(L.pcm_sa_index_det_scratch_ints(n), dtype=torch.int32, device=p.device)
+            cnt, S, RM = buf[:n], buf[n: 4 * n], buf[4 * n:]
+            rc = L.pcm_sa_index_det_hip(m, K, n, p.data_ptr(), q.data_ptr(), knn_idx.data_ptr(), ent.data_ptr(), csr.data_ptr(),
+                                        scratch.data_ptr(), cnt.data_ptr(), S.data_ptr(), RM.data_ptr(),
+                                        torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "pcm_sa_index_det_hip")
+        return ent, buf, csr
     with torch.cuda.device(p.device):
         buf = torch.zeros(4 * n + 12, dtype=torch.float32, device=p.device)
         ent = torch.empty(m, K, 4, dtype=torch.float32, device=p.device)  # (j bits, rel x, rel y, rel z) per neighbour slot
@@ -38,12 +67,13 @@ def index_stats(p, q, knn_idx, o32=None, no32=None, n_max=0):
 
 
 def _slots(L, m, n, H, bf, K, b):
-    return max(L.pcm_sa_fused_slots(m, H, bf, K), L.pcm_sa_fused_slots(m, H, 0, 1), L.pcm_sa_fused_slots(n, H, bf, 1), b, 1)
+    return max(L.pcm_sa_fused_slots(m, H, bf, K), L.pcm_sa_fused_slots(m, H, 0, 1), L.pcm_sa_fused_slots(n, H, bf, 1),
+               L.pcm_sa_bwd1_det_slots(m), b, 1)
 
 
 class _SAFused(Function):
     @staticmethod
-    def forward(ctx, gf, ent, wp, gamma, beta, running_mean, running_var, eps, momentum, o32, no32, n_max, istats, sync_bn):
+    def forward(ctx, gf, ent, wp, gamma, beta, running_mean, running_var, eps, momentum, o32, no32, n_max, istats, sync_bn, csr=None):
         L = _lib.load()
         assert gf.is_cuda and gf.is_contiguous() and gf.dtype in (torch.float32, torch.bfloat16)
         n, H = gf.shape
@@ -84,6 +114,7 @@ class _SAFused(Function):
                 stat, count = S.combine_forward(sync_bn, shift + d, sums[1] - sums[0] * d, rows)
                 launch(8, stat)
         ctx.save_for_backward(gf, ent, wp, stat, sel, asel, istats)
+        ctx.csr = csr if (csr is not None and L.pcm_sa_det_supported(K, H)) else None
         ctx.partial = partial
         ctx.layout = (o32, no32, int(n_max))
         ctx.sync = (sync_bn, count)
@@ -103,9 +134,10 @@ class _SAFused(Function):
             f32 = dict(dtype=torch.float32, device=dev)
             o32, no32, n_max = ctx.layout
             b = int(o32.shape[0]) if o32 is not None else 0
-            lds_path = b > 0 and L.pcm_sa_fused_bwd1_lds_channels(H, n_max) > 0
-            # the LDS-staged scatter writes every element of D itself; the global-atomic fallback adds into zeros
-            D = torch.empty(n * H, **f32) if lds_path else torch.zeros(n * H, **f32)
+            csr = ctx.csr
+            lds_path = csr is None and b > 0 and L.pcm_sa_fused_bwd1_lds_channels(H, n_max) > 0
+            # the sorted and the LDS-staged scatter write every element of D themselves; the global-atomic fallback adds into zeros
+            D = torch.empty(n * H, **f32) if (lds_path or csr is not None) else torch.zeros(n * H, **f32)
             cnt, S, RM = istats[:n], istats[n: 4 * n], istats[4 * n:]
             red1, red2 = torch.empty(5, H, **f32), torch.empty(3, H, **f32)
             dgf = torch.empty_like(gf)
@@ -113,6 +145,15 @@ class _SAFused(Function):
             sync_bn, count = ctx.sync
 
             def launch(mask, red_g=None):
+                if csr is not None and (mask <= 0 or mask & 6):  # stages 2|4 (delta scatter + its sums) without atomics
+                    ws = torch.empty(L.pcm_sa_bwd1_det_ws_bytes(m, K, H), dtype=torch.uint8, device=dev)
+                    rc_ = L.pcm_sa_bwd1_det_hip(m, n, K, H, dz.data_ptr(), sel.data_ptr(), asel.data_ptr(), stat.data_ptr(),
+                                                ent.data_ptr(), csr.data_ptr(), ws.data_ptr(), D.data_ptr(), ctx.partial.data_ptr(),
+                                                red1.data_ptr(), 0, st)
+                    _lib.check(rc_, "pcm_sa_bwd1_det_hip")
+                    mask = (0x3E if mask <= 0 else mask) & ~6
+                    if not mask:
+                        return
                 rc_ = L.pcm_sa_fused_backward_hip(
                     m, n, K, H, 1 if gf.dtype == torch.bfloat16 else 0, gf.data_ptr(), ent.data_ptr(),
                     wp.data_ptr(), stat.data_ptr(), dz.data_ptr(), sel.data_ptr(), asel.data_ptr(), D.data_ptr(), cnt.data_ptr(),
@@ -129,7 +170,7 @@ class _SAFused(Function):
                 launch(2 | 4)
                 red_g = SB.reduce_backward(sync_bn, red1[:2], count)  # count = rows_loc / N_global (device scalar)
                 launch(8 | 16 | 32, red_g)
-        return dgf, None, dwp, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+        return dgf, None, dwp, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
 
 
 def supports(owner, x):
@@ -194,14 +235,15 @@ def sa_fused_forward(owner, p, x, n_p, fps_idx, knn_idx, o=None, n_o=None, istat
     if istats is None:
         with torch.no_grad():
             istats = index_stats(p, n_p, knn_idx, o32, no32, n_max)
-    ent, stats = istats
+    ent, stats = istats[0], istats[1]
+    csr = istats[2] if len(istats) > 2 else None
     if not owner.training:
         with torch.no_grad():
             return _sa_fused_eval(owner, gf.contiguous(), ent, w[:, :3])
     from .sync_bn import wants_sync
 
     z, _ = _SAFused.apply(gf.contiguous(), ent, w[:, :3], bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                          bn.eps, bn.momentum, o32, no32, n_max, stats, bn if wants_sync(bn) else None)
+                          bn.eps, bn.momentum, o32, no32, n_max, stats, bn if wants_sync(bn) else None, csr)
     with torch.no_grad():
         bn.num_batches_tracked.add_(1)
     return z

@@ -34,3 +34,78 @@ def test_gradient_sink_adds_once_and_backpropagates_into_the_source_graph():
     torch.testing.assert_close(emb.grad, sum(gs).sum(0))
     sink.flush()  # emptied by the first flush
     torch.testing.assert_close(emb.grad, sum(gs).sum(0))
+
+
+def _fat_bench_record():
+    """A bench record as bulky as round 2's (which overflowed the driver's stdout tail): long notes everywhere."""
+    note = "x" * 400
+    return {
+        "metric": "BC train samples/sec (obs->action), PointNet + SA tokenizer + ACT", "value": 1118.1, "unit": "samples/s", "n_gpus": 1,
+        "steps": 30, "warmup": 8, "ms_per_step": 7.155, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "C2: " + note, "global_batch": 8, "parallelism": "dp1", "gradient_exchange": note, "step_mode": "graph"},
+        "final_loss": 1.0,
+        "step": {"launches_per_step": 700.0, "device_ms_per_step": 8.0, "share_by_family": {("family%d" % i): 0.1 for i in range(8)}},
+        "roofline": {"kernel": "pcm_fps_reg_kernel", "bound": "hbm", "achieved": 0.44, "peak": 8000.0, "unit": "GB/s", "frac": 5.5e-5,
+                     "traffic": 169035, "limited_by": "latency", "note": note, "selected_by": note, "clocks_per_pick_at_2400MHz": 1232.0},
+        "roofline_hbm_resident": {"kernel": "pcm_adamw_flat_kernel", "bound": "hbm", "achieved": 6400.0, "peak": 8000.0, "frac": 0.8,
+                                  "traffic": 723102569, "note": note},
+        "extra": {("tag%d" % i): {"workload": "REF", "value": 1.0, "ms_per_step": 2.0, "error": note} for i in range(6)},
+        "cpu_baseline": {"value": 4.54, "unit": "samples/s", "cores": 16, "kind": "port", "sample": note * 3},
+    }
+
+
+def test_bench_line_stays_under_4_kib_and_keeps_the_contract_fields():
+    """bench.py prints ONE JSON line; the driver only keeps a tail of stdout (round 2's 30 KB line lost `value`).  The line is
+    clipped to < 4096 bytes without ever dropping the contract fields, `roofline` or `cpu_baseline`."""
+    import json
+
+    import bench
+
+    line = bench.compact_line(_fat_bench_record())
+    assert len(line) < bench.MAX_LINE_BYTES <= 4096 and "\n" not in line
+    rec = json.loads(line)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in rec, key
+    assert rec["value"] == 1118.1 and rec["config"]["workload"].startswith("C2")
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in rec["roofline"], key
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in rec["cpu_baseline"], key
+    small = {"metric": "m", "value": 1.0, "roofline": {"frac": 0.5}, "cpu_baseline": {"value": 1.0}}
+    assert json.loads(bench.compact_line(small)) == small  # nothing is touched when the line already fits
+
+
+def test_bench_emit_writes_the_tables_to_a_side_file_and_prints_one_line(tmp_path, capsys):
+    import json
+
+    import bench
+
+    tables = {"kernels": {("pcm_kernel_%d" % i): {"ms": 0.1, "note": "y" * 300} for i in range(60)}}
+    path = str(tmp_path / "sub" / "bench_tables.json")
+    bench.emit(_fat_bench_record(), tables, path)
+    lines = [ln for ln in capsys.readouterr().out.splitlines() if ln.strip()]
+    assert len(lines) == 1 and len(lines[0]) < 4096
+    rec = json.loads(lines[0])
+    assert "kernels" not in rec and "roofline" in rec and "cpu_baseline" in rec
+    with open(path) as f:
+        side = json.load(f)
+    assert len(side["kernels"]) == 60 and side["headline"]["value"] == 1118.1
+
+
+def test_pmc_rows_are_keyed_by_the_full_template_name():
+    """Round 2 attributed the <1,0> (grouping backward) variant's HBM bytes to the interpolation forward, a different
+    instantiation of pcm_segment_sum_kernel.  A row is matched by its full name, or by its base name only when unique."""
+    import bench
+
+    table = {"shapes": {"REF": {
+        "pcm_segment_sum_kernel<1, 0>": {"hbm_bytes_per_launch": 700}, "pcm_segment_sum_kernel<4, 1>": {"hbm_bytes_per_launch": 200},
+        "pcm_sa_fwd_kernel<__hip_bfloat16, 8>": {"hbm_bytes_per_launch": 139}, "pcm_sa_index_kernel": {"hbm_bytes_per_launch": 36},
+        "pcm_sa_index_lds_kernel": {"hbm_bytes_per_launch": 18}}}}
+    f = lambda k: bench.pmc_traffic(k, "REF", table)  # noqa: E731
+    assert f("pcm_segment_sum_kernel<4, 1>") == 200 and f("pcm_segment_sum_kernel<1,0>") == 700
+    assert f("pcm_segment_sum_kernel") is None          # ambiguous: two instantiations
+    assert f("pcm_sa_fwd_kernel<bf16>") == 139           # unique base name
+    assert f("pcm_sa_index_kernel") == 36 and f("pcm_sa_index_lds_kernel") == 18  # a prefix of another name is not a match
+    assert f("pcm_interpolation forward (pcm_segment_sum_kernel)") is None

@@ -248,6 +248,27 @@ def test_dead_decoder_layer_options_leave_every_parameter_update_unchanged(how, 
             torch.testing.assert_close(pb[k], pa[k], rtol=0, atol=0, msg=k)
 
 
+def _compare_mode_runs(run_a, run_b, precision="fp32", accumulate=1):
+    """Two execution modes of the same maths, compared where the comparison is well-posed.
+
+    Up to the first optimizer step both runs hold the SAME parameters, so losses and gradients may differ only by the
+    modes' own arithmetic (fp32: 1e-5 relative -- the kernels are the same and the fused tokenizer is reproducible,
+    policy/sa_fused.SCATTER_MODE).  After an update the comparison is no longer one of modes alone: AdamW normalises by
+    sqrt(v), so a last-bit difference in a gradient element that is noise (exact-zero-in-theory entries such as softmax key
+    biases) becomes a full +-lr parameter change, which feeds the next step.  Later steps are therefore held to a looser
+    bound (2e-3: with lr = 1e-5 on weights of magnitude 1e-2 .. 1e-1 the perturbation is at most a few 1e-4 relative per step)."""
+    la, ga = run_a[0], run_a[1]
+    lb, gb = run_b[0], run_b[1]
+    first = accumulate  # micro-batches before the first optimizer step
+    tight_l, loose_l = (1e-6, 1e-3) if precision == "fp32" else (2e-2, 2e-2)
+    tight_g, loose_g = (1e-5, 2e-3) if precision == "fp32" else (5e-2, 5e-2)
+    assert la[:first] == pytest.approx(lb[:first], rel=tight_l), (la, lb)
+    assert la[first:] == pytest.approx(lb[first:], rel=loose_l), (la, lb)
+    for i, (a, b) in enumerate(zip(ga, gb)):
+        tol = tight_g if i < first else loose_g
+        assert (a - b).norm().item() <= tol * a.norm().item() + 1e-8, (i, (a - b).norm().item(), a.norm().item())
+
+
 @pytest.mark.parametrize("precision,accumulate", [("fp32", 1), ("bf16", 1), ("fp32", 2)])
 def test_hybrid_mode_matches_flat_mode_on_ragged_batches(precision, accumulate, hip_device):
     """mode="hybrid": eager tokenizer (cloud sizes change every step) + one captured graph for the rest; same maths as
@@ -273,10 +294,7 @@ def test_hybrid_mode_matches_flat_mode_on_ragged_batches(precision, accumulate, 
             grads.append(tr.optimizer.flat_g.detach().clone())
         assert tr.mode == mode
         runs[mode] = (losses, grads, pol.bn.running_mean.detach().clone())
-    tol = 1e-5 if precision == "fp32" else 2e-2
-    assert runs["flat"][0] == pytest.approx(runs["hybrid"][0], rel=tol)
-    for ga, gb in zip(runs["flat"][1], runs["hybrid"][1]):
-        assert (ga - gb).norm().item() <= (1e-4 if precision == "fp32" else 5e-2) * ga.norm().item() + 1e-8
+    _compare_mode_runs(runs["flat"], runs["hybrid"], precision, accumulate)
     torch.testing.assert_close(runs["flat"][2], runs["hybrid"][2], rtol=1e-4, atol=1e-6)
 
 
@@ -294,16 +312,17 @@ def test_prefetched_sampling_gives_identical_steps(mode, hip_device):
     for use_prefetch in (False, True):
         torch.manual_seed(0)
         pol = build_act_policy(pcd_npoints=64, sa_impl="fused", **small).to(hip_device)
-        tr = BCTrainer(pol, total_steps=20, precision="fp32", device=hip_device, mode=mode, optim=dict(accumulate_grad_batches=1, lr=1e-3))
-        losses = []
+        tr = BCTrainer(pol, total_steps=20, precision="fp32", device=hip_device, mode=mode, optim=dict(accumulate_grad_batches=1, lr=1e-5))
+        losses, grads = [], []
         for i in range(6):
             b = clone_batch(batches[i % 3])
             b["vae_eps"] = eps
             losses.append(tr.training_step(b, prefetch=batches[(i + 1) % 3] if use_prefetch else None)["loss"].item())
-        runs.append(losses)
+            grads.append(tr.optimizer.flat_g.detach().clone())
+        runs.append((losses, grads))
         assert len(pol.__dict__.get("_prefetched", {})) == (1 if use_prefetch else 0)  # only the batch after the last step is pending
-    # float atomics (scatter of the deltas, neighbour statistics) land in a different order from run to run
-    assert runs[0] == pytest.approx(runs[1], rel=2e-5)
+    # a wrong or stale index set would change the loss by percents; see _compare_mode_runs for the two bounds
+    _compare_mode_runs(runs[0], runs[1])
 
 
 def test_hybrid_mode_matches_flat_mode_for_the_diffusion_policy(hip_device):
@@ -328,9 +347,7 @@ def test_hybrid_mode_matches_flat_mode_for_the_diffusion_policy(hip_device):
             grads.append(tr.optimizer.flat_g.detach().clone())
         assert tr.mode == mode
         runs[mode] = (losses, grads)
-    assert runs["flat"][0] == pytest.approx(runs["hybrid"][0], rel=1e-5)
-    for ga, gb in zip(runs["flat"][1], runs["hybrid"][1]):
-        assert (ga - gb).norm().item() <= 1e-4 * ga.norm().item() + 1e-8
+    _compare_mode_runs(runs["flat"], runs["hybrid"])
 
 
 @pytest.mark.parametrize("mode,precision", [("flat", "fp32"), ("graph", "bf16"), ("hybrid", "bf16")])
@@ -633,7 +650,7 @@ def test_graph_mode_with_sampling_outside_the_graph_matches_sampling_inside(kind
         eps = torch.randn(2, 8, generator=torch.Generator().manual_seed(1)).to(hip_device)
         extra = {"vae_eps": eps}
         build = lambda: build_act_policy(pcd_npoints=64, sa_impl="fused", **small)
-        optim = dict(accumulate_grad_batches=1, lr=1e-3)
+        optim = dict(accumulate_grad_batches=1, lr=1e-5)
     else:
         batches = [make_dp_batch(3, 128, seed=40 + i, device=hip_device) for i in range(3)]
         g = torch.Generator().manual_seed(3)
@@ -656,5 +673,6 @@ def test_graph_mode_with_sampling_outside_the_graph_matches_sampling_inside(kind
         runs[(external, use_prefetch)] = losses
     base = runs[(False, False)]
     assert all(l == l for l in base)
-    assert runs[(True, False)] == pytest.approx(base, rel=2e-5)  # float atomics order differs from run to run
-    assert runs[(True, True)] == pytest.approx(base, rel=2e-5)
+    for key in ((True, False), (True, True)):  # same parameters up to the first update: tight; later steps: _compare_mode_runs
+        assert runs[key][:1] == pytest.approx(base[:1], rel=1e-6), key
+        assert runs[key][1:] == pytest.approx(base[1:], rel=1e-3), key

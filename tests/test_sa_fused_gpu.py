@@ -155,3 +155,103 @@ def test_fused_statistics_survive_a_large_feature_offset(hip_device):
     t_f, gx_f, gp_f, rm_f, rv_f, _ = _run("fused", fused_owner, p, x, o, n_o, gout)
     assert (rv_f - rv_r).abs().max().item() <= 1e-3 * rv_r.abs().max().item()
     assert (t_f - t_r).abs().max().item() <= 2e-3 * t_r.abs().max().item() + 1e-4
+
+
+SCATTER_CASES = [
+    ([1024] * 4, [512] * 4, 64, 128, 16),
+    ([700, 300, 20, 5], [64] * 4, 96, 96, 16),             # -1 slots, DP width
+    ([300], [100], 10, 30, 8),                            # H % 4 != 0
+    ([3100, 4096, 5000, 3600], [2048] * 4, 512, 512, 16),  # REF (ragged)
+    ([4096] * 4, [2048] * 4, 96, 96, 16),                  # C5
+    ([9000], [512], 96, 96, 16),
+    ([600, 424], [256, 256], 40, 1024, 32),               # widest supported layer, 32 neighbours
+]
+
+
+@pytest.mark.parametrize("sizes,ms,c,h,k", SCATTER_CASES)
+def test_sorted_scatter_matches_the_atomic_kernels_and_is_reproducible(hip_device, sizes, ms, c, h, k):
+    """policy/sa_fused.SCATTER_MODE: "sorted" (csrc/sa_scatter.hip, the default) gives the same index statistics and the same
+    gradients as the float-atomic kernels up to fp32 re-association, and -- unlike them -- the SAME BITS on every run."""
+    import pointcloudmatters_amd.pointops as po
+    from pointcloudmatters_amd.policy import sa_fused
+    from pointcloudmatters_amd.policy.sa_layer import sample_and_query
+
+    torch.manual_seed(0)
+    xyz, off = make_clouds(sizes, seed=11)
+    noff = new_offsets(ms)
+    p, o, n_o = xyz.to(hip_device), off.to(hip_device), noff.to(hip_device)
+    x = torch.randn(xyz.shape[0], c, device=hip_device)
+    owner = Owner(c, h, k).to(hip_device).train()
+    owner.sa_impl = "fused"
+    with torch.no_grad():
+        owner.bn.weight.uniform_(-1.0, 1.0)
+        owner.bn.bias.uniform_(-0.5, 0.5)
+    state = {kk: v.clone() for kk, v in owner.state_dict().items()}
+    gout = torch.randn(sum(ms), h, device=hip_device)
+    runs = {}
+    old = sa_fused.SCATTER_MODE
+    try:
+        for tag, mode in (("atomic", "atomic"), ("sorted_a", "sorted"), ("sorted_b", "sorted")):
+            sa_fused.set_scatter_mode(mode)
+            owner.load_state_dict(state)
+            pre = sample_and_query(owner, po, p, o, n_o)
+            assert len(pre["istats"]) == (3 if mode == "sorted" else 2)
+            t, gx, gp, *_ = _run("fused", owner, p, x, o, n_o, gout, pre=pre)
+            runs[tag] = (pre["istats"][1].clone(), t, gx, gp)
+    finally:
+        sa_fused.set_scatter_mode(old)
+    n = xyz.shape[0]
+    st_a, st_s = runs["atomic"][0], runs["sorted_a"][0]
+    assert torch.equal(st_a[:n], st_s[:n])  # occurrence counts are integers: exact either way
+    torch.testing.assert_close(st_s[n:], st_a[n:], rtol=1e-4, atol=1e-5)
+
+    def close(a, b, name, tol=2e-5):
+        scale = b.abs().max().item() + 1e-12
+        assert (a - b).abs().max().item() <= tol * scale + 1e-7, (name, (a - b).abs().max().item(), scale)
+
+    assert torch.equal(runs["atomic"][1], runs["sorted_a"][1])  # the forward does not depend on the mode
+    close(runs["sorted_a"][2], runs["atomic"][2], "grad_x")
+    for name in runs["atomic"][3]:
+        close(runs["sorted_a"][3][name], runs["atomic"][3][name], name)
+    # run-to-run: bit-identical statistics and gradients
+    assert torch.equal(runs["sorted_a"][0], runs["sorted_b"][0])
+    assert torch.equal(runs["sorted_a"][2], runs["sorted_b"][2])
+    for name in runs["sorted_a"][3]:
+        assert torch.equal(runs["sorted_a"][3][name], runs["sorted_b"][3][name]), name
+
+
+def test_sorted_scatter_with_a_hub_point(hip_device):
+    """Every query's neighbour list names the same few points (all coordinates equal): segments of m entries -- the LDS
+    bitonic path of the plan and long run lists in the gather -- still match the atomic kernels."""
+    import pointcloudmatters_amd.pointops as po
+    from pointcloudmatters_amd.policy import sa_fused
+    from pointcloudmatters_amd.policy.sa_layer import sample_and_query
+
+    torch.manual_seed(0)
+    n, m, c, h, k = 3000, 1500, 16, 64, 16
+    p = torch.zeros(n, 3, device=hip_device)
+    p[2000:] = torch.rand(1000, 3, device=hip_device)
+    o = torch.tensor([n], dtype=torch.int32, device=hip_device)
+    n_o = torch.tensor([m], dtype=torch.int32, device=hip_device)
+    x = torch.randn(n, c, device=hip_device)
+    owner = Owner(c, h, k).to(hip_device).train()
+    owner.sa_impl = "fused"
+    state = {kk: v.clone() for kk, v in owner.state_dict().items()}
+    gout = torch.randn(m, h, device=hip_device)
+    out = {}
+    old = sa_fused.SCATTER_MODE
+    try:
+        for mode in ("atomic", "sorted"):
+            sa_fused.set_scatter_mode(mode)
+            owner.load_state_dict(state)
+            pre = sample_and_query(owner, po, p, o, n_o)
+            out[mode] = _run("fused", owner, p, x, o, n_o, gout, pre=pre)
+            if mode == "sorted":
+                assert pre["istats"][1][:n].max().item() >= 400  # a hub: one point named by hundreds of queries
+    finally:
+        sa_fused.set_scatter_mode(old)
+    gx_a, gx_s = out["atomic"][1], out["sorted"][1]
+    assert (gx_a - gx_s).abs().max().item() <= 1e-4 * gx_a.abs().max().item() + 1e-7
+    for name in out["atomic"][2]:
+        a, s = out["atomic"][2][name], out["sorted"][2][name]
+        assert (a - s).abs().max().item() <= 1e-4 * a.abs().max().item() + 1e-7, name

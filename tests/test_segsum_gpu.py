@@ -177,3 +177,30 @@ def test_ball_queries_with_and_without_the_cloud_count(hip_device):
     for x, y in zip(*outs):
         assert torch.equal(x, y)
     assert (outs[0][0] >= 0).any()
+
+
+@pytest.mark.parametrize("rows,n_dst,hub", [(0, 5, False), (7, 1, False), (1000, 37, False), (5000, 4096, False), (70000, 9001, True),
+                                            (300000, 131072, True), (40000, 3, True), (120000, 2000, True)])
+def test_sorted_scatter_plan_is_the_sorted_csr_inverse(hip_device, rows, n_dst, hub):
+    """pcm_scatter_plan_sorted_hip: start = exclusive prefix of the counts, list = the entries of every destination row in
+    ASCENDING order -- for short segments (register rank sort), long ones (LDS bitonic: the hub row of rows/3 entries) and
+    segments beyond the LDS capacity (40000 entries on 3 rows: in-place heap sort).  Equal to numpy's stable argsort."""
+    from pointcloudmatters_amd import _lib
+
+    L = _lib.load()
+    idx = _idx(rows, n_dst, seed=rows + 3 * n_dst, hub=hub)
+    d_idx = idx.to(hip_device)
+    start = torch.full((n_dst + 1,), -7, dtype=torch.int32, device=hip_device)
+    lst = torch.full((max(rows, 1),), -7, dtype=torch.int32, device=hip_device)
+    scratch = torch.empty(L.pcm_scatter_plan_sorted_scratch_ints(n_dst), dtype=torch.int32, device=hip_device)
+    for _ in range(2):  # the second build must not depend on what the first left in the scratch
+        rc = L.pcm_scatter_plan_sorted_hip(rows, n_dst, d_idx.data_ptr(), scratch.data_ptr(), start.data_ptr(), lst.data_ptr(),
+                                           torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+    torch.cuda.synchronize()
+    h = idx.numpy()
+    valid = np.nonzero(h >= 0)[0]
+    order = valid[np.argsort(h[valid], kind="stable")]
+    counts = np.bincount(h[valid], minlength=n_dst)
+    assert np.array_equal(start.cpu().numpy(), np.concatenate([[0], np.cumsum(counts)]).astype(np.int32))
+    assert np.array_equal(lst.cpu().numpy()[: len(order)], order.astype(np.int32))
