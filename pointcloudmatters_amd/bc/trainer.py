@@ -88,6 +88,37 @@ class _Stage:
         self.index_set = set(indices)
 
 
+def plan_slabs(stage_params, lead_end, numel):
+    """Gradient slabs [start, end) of the flat buffer, one per backward stage, exchanged when that stage's backward is done.
+
+    stage_params[si] = [(offset, numel), ...] of the stage's parameters.  The flat buffer holds the LEADING parameter group
+    (the decayed weights, laid out in backward order) in [0, lead_end) and, with `filter_bias_and_bn`, a small undecayed
+    group (biases, norm weights) of ALL stages behind it.  Slabs are cut from the leading group only: stage si ends where
+    the first leading-group parameter of any later stage begins; the undecayed tail rides with the last slab.  A stage with
+    no leading-group parameter (only biases / norm weights) gets an empty slab -- its gradients sit in the tail, which is
+    exchanged after the last stage, i.e. never before they are complete.  Checked: slabs are monotone, disjoint, cover
+    [0, numel), and every parameter of stage si lies in a slab with index >= si."""
+    n_stage = len(stage_params)
+    lead_starts = [min((o for o, _ in ps if o < lead_end), default=None) for ps in stage_params]
+    slabs, cursor = [], 0
+    for si in range(n_stage):
+        if si == n_stage - 1:
+            end = numel
+        else:
+            later = [s for s in lead_starts[si + 1:] if s is not None]
+            end = min(later) if later else lead_end
+            assert end >= cursor, "backward stages must be laid out in backward order inside the leading parameter group"
+        slabs.append((cursor, end))
+        cursor = end
+    assert slabs[0][0] == 0 and slabs[-1][1] == numel and all(a[1] == b[0] and a[0] <= a[1] for a, b in zip(slabs, slabs[1:]))
+    for si, ps in enumerate(stage_params):
+        for o, cnt in ps:
+            owner = next(k for k, (a, b) in enumerate(slabs) if a <= o < b or (k == n_stage - 1 and o >= a))
+            assert owner >= si and o + cnt <= slabs[owner][1], (
+                "gradient of a stage-%d parameter at offset %d would be exchanged with stage %d, before it is complete" % (si, o, owner))
+    return slabs
+
+
 class BCTrainer:
     """mode:
       "eager"  torch.optim.AdamW + OneCycleLR, DistributedDataParallel (+ SyncBatchNorm) when
@@ -247,17 +278,10 @@ class BCTrainer:
                 o += p.numel()
         numel = getattr(opt, "numel", None) or int(opt.flat_g.numel())
         idxs = [sorted(index[id(p)] for p in ps) for _, ps in stage_defs]
-        # a stage's slab starts at its first parameter (stages are contiguous and ascending inside the leading group)
-        starts = [offsets[ix[0]] if ix else None for ix in idxs]
-        stages, cursor = [], 0
-        for si, (lower, _) in enumerate(stage_defs):
-            start = cursor
-            nxt = next((s for s in starts[si + 1:] if s is not None and s >= start), None)
-            end = numel if (si == len(stage_defs) - 1 or nxt is None) else nxt
-            stages.append(_Stage(lower, idxs[si], (start, end)))
-            cursor = end
-        stages[-1].slab = (stages[-1].slab[0], numel)
-        return stages
+        segments = getattr(opt, "segments", None)
+        lead_end = segments[0][0] + segments[0][1] if segments else numel  # end of the leading (decayed) parameter group
+        slabs = plan_slabs([[(offsets[k], opt.params[k].numel()) for k in ix] for ix in idxs], lead_end, numel)
+        return [_Stage(lower, idxs[si], slabs[si]) for si, (lower, _) in enumerate(stage_defs)]
 
     def _exchange(self, si):
         """Stage `si` of the stepping micro-batch is done: start the all-reduce of its gradient slab (asynchronous: it runs

@@ -109,3 +109,21 @@ def test_pmc_rows_are_keyed_by_the_full_template_name():
     assert f("pcm_sa_fwd_kernel<bf16>") == 139           # unique base name
     assert f("pcm_sa_index_kernel") == 36 and f("pcm_sa_index_lds_kernel") == 18  # a prefix of another name is not a match
     assert f("pcm_interpolation forward (pcm_segment_sum_kernel)") is None
+
+
+def test_gradient_slabs_are_cut_from_the_decayed_group_only():
+    """bc/trainer.plan_slabs: with a no-decay group at the tail of the flat buffer a stage that owns only biases / norm
+    weights must NOT pull an earlier slab's end into the tail (round-2 advisor finding: starts = [0, 1000, 100] gave stage 0
+    the slab [0, 1000), covering stage 2's gradients before they exist)."""
+    from pointcloudmatters_amd.bc.trainer import plan_slabs
+
+    # leading (decayed) group [0, 900): stage 0 -> [0, 400), stage 1 has no decayed parameter, stage 2 -> [400, 900);
+    # tail [900, 1000): biases of stage 0 (900..939), stage 1 (940..969), stage 2 (970..999)
+    stages = [[(0, 400), (900, 40)], [(940, 30)], [(400, 500), (970, 30)]]
+    assert plan_slabs(stages, 900, 1000) == [(0, 400), (400, 400), (400, 1000)]
+    # one group, three contiguous stages
+    assert plan_slabs([[(0, 10), (10, 5)], [(15, 20)], [(35, 65)]], 100, 100) == [(0, 15), (15, 35), (35, 100)]
+    # only the last stage holds decayed weights
+    assert plan_slabs([[(50, 10)], [(0, 50), (60, 4)]], 50, 64) == [(0, 0), (0, 64)]
+    # a layout that is NOT in backward order loses the overlap, never the correctness: everything goes with the last stage
+    assert plan_slabs([[(500, 100)], [(0, 500)]], 600, 600) == [(0, 0), (0, 600)]
