@@ -1,0 +1,70 @@
+"""Run-to-run reproducibility of the training step ("deterministic-mode option"): with the sorted
+scatter of csrc/sa_scatter.hip (the default, policy/sa_fused.SCATTER_MODE) no float atomic is left on the hot path, so two
+executions of the same steps from the same state give bit-identical gradients -- in every execution mode, for both
+policies.  The reference cannot offer this: its grouping backward is atomicAdd
+(/root/reference/libs/pointops/src/grouping/grouping_cuda_kernel.cu:24)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _act_run(mode, precision, device, ragged):
+    from pointcloudmatters_amd.bc import BCTrainer, build_act_policy, clone_batch, make_act_batch
+
+    small = dict(hidden_dim=512, nhead=8, dim_feedforward=32, num_encoder_layers=2, num_decoder_layers=2, dropout=0.1, latent_dim=8,
+                 num_queries=10)
+    batches = [make_act_batch(3, 400, seed=50 + i, ragged=ragged, device=device, num_queries=10) for i in range(2)]
+    eps = torch.randn(3, 8, generator=torch.Generator().manual_seed(1)).to(device)
+    torch.manual_seed(0)
+    pol = build_act_policy(pcd_npoints=128, sa_impl="fused", **small).to(device)
+    tr = BCTrainer(pol, total_steps=20, precision=precision, device=device, mode=mode, optim=dict(accumulate_grad_batches=1, lr=1e-4))
+    out = []
+    for i in range(3):
+        b = clone_batch(batches[i % 2])
+        b["vae_eps"] = eps
+        loss = tr.training_step(b)["loss"]
+        out.append((loss.detach().clone(), tr.optimizer.flat_g.detach().clone()))
+    assert tr.mode == mode
+    return out, tr.optimizer.flat_p.detach().clone()
+
+
+@pytest.mark.parametrize("mode,precision,ragged", [("flat", "fp32", True), ("hybrid", "bf16", True), ("graph", "bf16", False),
+                                                   ("flat", "bf16", False)])
+def test_act_training_steps_are_bit_reproducible(mode, precision, ragged, hip_device):
+    """Dropout on (seeded counter hash), three optimizer steps: losses, every flat gradient and the final parameters of two
+    independent runs are torch.equal."""
+    a, pa = _act_run(mode, precision, hip_device, ragged)
+    b, pb = _act_run(mode, precision, hip_device, ragged)
+    for i, ((la, ga), (lb, gb)) in enumerate(zip(a, b)):
+        assert torch.equal(la, lb), (i, la.item(), lb.item())
+        assert torch.equal(ga, gb), (i, (ga - gb).abs().max().item())
+    assert torch.equal(pa, pb)
+
+
+@pytest.mark.parametrize("mode", ["flat", "hybrid"])
+def test_diffusion_policy_training_steps_are_bit_reproducible(mode, hip_device):
+    from pointcloudmatters_amd.bc import BCTrainer, build_dp_policy, clone_batch, make_dp_batch
+    from pointcloudmatters_amd.bc.configs import DP_OPTIM
+    from tests.golden.make_golden import DP_SMALL
+
+    batches = [make_dp_batch(3, 150, seed=40 + i, ragged=True, device=hip_device) for i in range(2)]
+    noise = torch.randn(3, 16, 7, generator=torch.Generator().manual_seed(3)).to(hip_device)
+    tsteps = torch.tensor([3, 57, 99], device=hip_device)
+
+    def run():
+        torch.manual_seed(0)
+        pol = build_dp_policy(pcd_npoints=32, sa_impl="fused", **DP_SMALL).to(hip_device)
+        tr = BCTrainer(pol, total_steps=20, precision="fp32", device=hip_device, mode=mode, optim=dict(DP_OPTIM, lr=1e-4))
+        out = []
+        for i in range(3):
+            b = clone_batch(batches[i % 2])
+            b["noise"], b["timesteps"] = noise, tsteps
+            loss = tr.training_step(b)["loss"]
+            out.append((loss.detach().clone(), tr.optimizer.flat_g.detach().clone()))
+        return out
+
+    a, b = run(), run()
+    for i, ((la, ga), (lb, gb)) in enumerate(zip(a, b)):
+        assert torch.equal(la, lb), (i, la.item(), lb.item())
+        assert torch.equal(ga, gb), (i, (ga - gb).abs().max().item())
