@@ -267,6 +267,24 @@ int pcm_sa_bwd1_det_hip(int m, int n, int K, int H, const float *dz, const float
                         const float *stat, const void *ent, const int *csr, void *ws, float *D, float *partial,
                         float *red1, int stage_mask, void *stream);
 
+/* ---- attention for long query sets (csrc/attn_flash.hip) ----------------------------------------------------
+ * Same contract as pcm_attn_small_*_hip (head_dim 64, bf16, key_padding_mask (B,S) bytes, counter-hash dropout keyed by
+ * (seed, site, b, h, q, key), out / dout (B, L, H*64) contiguous, lse (B, H, L) fp32), organised for hundreds to
+ * thousands of queries: a workgroup keeps 128 rows resident and streams 64-row tiles of the other side through
+ * swizzled LDS (ds_read_b64_tr_b16 for the transposed operands).  Replaces the framework's flash kernels on the encoder
+ * self-attention (reference: src/models/components/act/transformer.py:221,244-262 nn.MultiheadAttention).  Backward is
+ * three launches (delta, dK/dV, dQ), atomic-free; `delta` is a (B, H, L) fp32 workspace. */
+int pcm_attn_flash_supported(int L, int S, int head_dim);
+int pcm_attn_flash_forward_hip(int B, int H, int L, int S, const void *q, long q_bs, long q_ls, const void *k, long k_bs,
+                               long k_ls, const void *v, long v_bs, long v_ls, const unsigned char *key_padding_mask,
+                               float scale, float p_drop, const long *seed, unsigned site, void *out, float *lse,
+                               void *stream);
+int pcm_attn_flash_backward_hip(int B, int H, int L, int S, const void *q, long q_bs, long q_ls, const void *k, long k_bs,
+                                long k_ls, const void *v, long v_bs, long v_ls, const unsigned char *key_padding_mask,
+                                float scale, float p_drop, const long *seed, unsigned site, const void *out,
+                                const void *dout, const float *lse, float *delta, void *dq, long dq_bs, long dq_ls, void *dk,
+                                long dk_bs, long dk_ls, void *dv, long dv_bs, long dv_ls, void *stream);
+
 /* ---- hipGraph surgery -----------------------------------------------------------------------------------
  * Replace every MEMSET node of a captured, not yet instantiated hipGraph_t by a fill-kernel node with the same
  * destination, value, extent and dependencies (csrc/graph_fix.hip: memset nodes created by stream capture replay

@@ -1,0 +1,102 @@
+// pcm_attn.hpp -- types, MFMA operand helpers and the dropout hash shared by the attention kernels
+// (csrc/attn_small.hip: short query sets; csrc/attn_flash.hip: long sequences).
+#pragma once
+#include "pcm_elem.hpp"
+
+#include <math.h>
+
+namespace {
+
+typedef short s4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef unsigned short u16;
+
+#define PCM_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a, b, c, 0, 0, 0)
+
+struct AttnParams {
+    const u16 *q, *k, *v;
+    long q_bs, q_ls, k_bs, k_ls, v_bs, v_ls;  // element strides: batch, row
+    const unsigned char *kpm;                 // (B, S) or NULL
+    int B, H, L, S;
+    float scale, p_drop;
+    const long *seed;
+    unsigned site;
+};
+
+__device__ __forceinline__ float bf2f(u16 v)
+{
+    return __uint_as_float((uint32_t)v << 16);
+}
+__device__ __forceinline__ s4 pack4(float a, float b, float c, float d)  // 2 x v_cvt_pk_bf16_f32
+{
+    const __hip_bfloat162 lo = __float22bfloat162_rn(make_float2(a, b)), hi = __float22bfloat162_rn(make_float2(c, d));
+    uint2 r = make_uint2(*reinterpret_cast<const uint32_t *>(&lo), *reinterpret_cast<const uint32_t *>(&hi));
+    return *reinterpret_cast<s4 *>(&r);
+}
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+#define PCM_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+__device__ __forceinline__ bf8 as_bf8(const uint4 &v)
+{
+    return __builtin_bit_cast(bf8, v);
+}
+__device__ __forceinline__ bf8 cat8(const s4 &a, const s4 &b)  // (k 0..3 | k 4..7) of one lane's 32x32x16 operand
+{
+    const uint2 x = __builtin_bit_cast(uint2, a), y = __builtin_bit_cast(uint2, b);
+    return as_bf8(make_uint4(x.x, x.y, y.x, y.y));
+}
+__device__ __forceinline__ bf8 lds_bf8(const u16 *p)
+{
+    return as_bf8(*reinterpret_cast<const uint4 *>(p));
+}
+__device__ __forceinline__ s4 lds_s4(const u16 *p)
+{
+    return *reinterpret_cast<const s4 *>(p);
+}
+__device__ __forceinline__ s4 zero_s4()
+{
+    s4 z = {0, 0, 0, 0};
+    return z;
+}
+__device__ __forceinline__ int crow(int r, int lane)  // accumulator register r of `lane` -> tile row
+{
+    return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+}
+
+// dropout on the attention weights.  One 32-bit hash serves the PAIR of adjacent keys (2j, 2j+1) of a query:
+//   h = mixp(rowbase(b, h, q) + j * C);  keep(2j) = (h & 0xFFFF) >= thr16,  keep(2j+1) = (h >> 16) >= thr16,
+// thr16 = round(p * 65536) (|p_eff - p| < 8e-6).  mixp uses 24-bit multiplies (full-rate v_mul_u32_u24; the 32-bit
+// integer multiply is quarter rate) -- the mask generator used to cost as much VALU time as the softmax itself.
+__device__ __forceinline__ uint32_t attn_rowbase(uint64_t seed, uint32_t site, uint32_t rowid)
+{
+    const uint32_t k = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9E3779B9u) ^ (site * 0x85EBCA6Bu);
+    return mix32(k ^ rowid);
+}
+__device__ __forceinline__ uint32_t mixp(uint32_t x)
+{
+    x ^= x >> 15;
+    x = __umul24(x, 0xD35A2Du) ^ (x >> 9);   // 24-bit multiplicands: low 24 bits of x, 24-bit odd constant
+    x ^= x >> 13;
+    x = __umul24(x, 0x6B4F29u) + (x >> 11);
+    x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t attn_pair_bits(uint32_t rowbase, uint32_t key_pair)
+{
+    return mixp(rowbase + key_pair * 0x9E3779B1u);
+}
+
+struct DropCfg {
+    bool on;
+    uint64_t seed;
+    uint32_t thr;
+    float inv_keep;
+    __device__ DropCfg(const AttnParams &P)
+    {
+        on = P.p_drop > 0.f;
+        seed = on ? (uint64_t)P.seed[0] : 0ull;
+        thr = on ? (uint32_t)((double)P.p_drop * 65536.0 + 0.5) : 0u;  // 16-bit threshold, see attn_pair_bits
+        inv_keep = on ? 1.f / (1.f - P.p_drop) : 1.f;
+    }
+};
+
+}  // namespace

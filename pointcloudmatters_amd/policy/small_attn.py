@@ -1,11 +1,14 @@
-"""Attention core for short query sequences on the matrix cores (csrc/attn_small.hip) as an autograd function.
+"""Attention cores on the matrix cores as autograd functions: csrc/attn_small.hip for short query sets, csrc/attn_flash.hip
+for long ones (the encoder's self-attention over the point tokens).
 
 ``small_attention(q, k, v, key_padding_mask, heads, dropout_p)`` == softmax(q k^T / sqrt(d) + mask) (dropout) v per head
 for q (B, L, E), k / v (B, S, E) in bf16 with E = heads * 64 (the policy uses it for L <= 128, S <= 4096); returns (B, L, E) -- already in the layout
 the output projection wants (the SDPA path needs a transpose copy).  Used by policy/transformer.attention for the CVAE
-encoder and the decoder; the long encoder self-attention (S = M + 3 tokens) stays on the framework's flash kernel.
+encoder and the decoder; query sets longer than MAX_QUERIES (the encoder self-attention over S = M + 3 tokens) go to the
+same interface backed by csrc/attn_flash.hip (PCM_ATTN_LONG=sdpa keeps them on the framework's kernel, for A/B runs).
 """
 import math
+import os
 
 import torch
 from torch.autograd import Function
@@ -18,6 +21,9 @@ from .. import _lib
 # the policy routes only <= 128 queries here (CVAE encoder, decoder self- and cross-attention).
 MAX_QUERIES = 128
 MAX_KEYS = 4096  # cross-attention over the REF memory (2051 tokens): forward 28 us vs 61 us for the flash kernel, backward on par
+
+
+LONG_IMPL = os.environ.get("PCM_ATTN_LONG", "flash")  # "flash" (csrc/attn_flash.hip) | "sdpa" (framework kernel)
 
 
 def _st(t):
@@ -35,11 +41,12 @@ class _SmallAttn(Function):
         with torch.cuda.device(dev):
             out = torch.empty(B, L, E, dtype=torch.bfloat16, device=dev)
             lse = torch.empty(B, heads, L, dtype=torch.float32, device=dev)
-            rc = L_.pcm_attn_small_forward_hip(B, heads, L, S, q.data_ptr(), *_st(q), k.data_ptr(), *_st(k), v.data_ptr(), *_st(v),
-                                               kpm.data_ptr() if kpm is not None else 0, 1.0 / math.sqrt(E // heads), float(p_drop),
-                                               seed.data_ptr() if seed is not None else 0, int(site), out.data_ptr(),
-                                               lse.data_ptr(), torch.cuda.current_stream().cuda_stream)
-        _lib.check(rc, "pcm_attn_small_forward_hip")
+            fwd = L_.pcm_attn_flash_forward_hip if L > MAX_QUERIES else L_.pcm_attn_small_forward_hip
+            rc = fwd(B, heads, L, S, q.data_ptr(), *_st(q), k.data_ptr(), *_st(k), v.data_ptr(), *_st(v),
+                     kpm.data_ptr() if kpm is not None else 0, 1.0 / math.sqrt(E // heads), float(p_drop),
+                     seed.data_ptr() if seed is not None else 0, int(site), out.data_ptr(),
+                     lse.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "pcm_attn_flash_forward_hip" if L > MAX_QUERIES else "pcm_attn_small_forward_hip")
         ctx.save_for_backward(q, k, v, out, lse, kpm)
         ctx.meta = (heads, float(p_drop), seed, int(site))
         return out
@@ -61,22 +68,32 @@ class _SmallAttn(Function):
                 dq = torch.empty(B, L, E, dtype=torch.bfloat16, device=dev)
                 dk = torch.empty(B, S, E, dtype=torch.bfloat16, device=dev)
             dv = torch.empty(B, S, E, dtype=torch.bfloat16, device=dev)
-            rc = L_.pcm_attn_small_backward_hip(B, heads, L, S, q.data_ptr(), *_st(q), k.data_ptr(), *_st(k), v.data_ptr(), *_st(v),
-                                                kpm.data_ptr() if kpm is not None else 0, 1.0 / math.sqrt(E // heads), p_drop,
-                                                seed.data_ptr() if seed is not None else 0, site, out.data_ptr(), dout.data_ptr(),
-                                                lse.data_ptr(), dq.data_ptr(), *_st(dq), dk.data_ptr(), *_st(dk), dv.data_ptr(),
-                                                *_st(dv), torch.cuda.current_stream().cuda_stream)
-        _lib.check(rc, "pcm_attn_small_backward_hip")
+            head = (B, heads, L, S, q.data_ptr(), *_st(q), k.data_ptr(), *_st(k), v.data_ptr(), *_st(v),
+                    kpm.data_ptr() if kpm is not None else 0, 1.0 / math.sqrt(E // heads), p_drop,
+                    seed.data_ptr() if seed is not None else 0, site, out.data_ptr(), dout.data_ptr(), lse.data_ptr())
+            tail = (dq.data_ptr(), *_st(dq), dk.data_ptr(), *_st(dk), dv.data_ptr(), *_st(dv), torch.cuda.current_stream().cuda_stream)
+            if L > MAX_QUERIES:
+                delta = torch.empty(B, heads, L, dtype=torch.float32, device=dev)
+                rc = L_.pcm_attn_flash_backward_hip(*head, delta.data_ptr(), *tail)
+            else:
+                rc = L_.pcm_attn_small_backward_hip(*head, *tail)
+        _lib.check(rc, "pcm_attn_flash_backward_hip" if L > MAX_QUERIES else "pcm_attn_small_backward_hip")
         return dq, dk, dv, None, None, None, None, None
 
 
 def supported(q, k, v, heads, dropout_p=0.0):
+    """True when this call goes to the hand-written kernels: <= MAX_QUERIES queries -> attn_small, more -> attn_flash."""
     from . import fused_ops
 
     if not (q.is_cuda and q.dtype == k.dtype == v.dtype == torch.bfloat16 and q.dim() == 3):
         return False
     e = q.shape[-1]
-    if e % heads or e // heads != 64 or q.shape[1] > MAX_QUERIES or q.shape[1] < 1 or k.shape[1] < 1 or k.shape[1] > MAX_KEYS:
+    if e % heads or e // heads != 64 or q.shape[1] < 1 or k.shape[1] < 1:
+        return False
+    if q.shape[1] > MAX_QUERIES:
+        if LONG_IMPL != "flash":
+            return False
+    elif k.shape[1] > MAX_KEYS:
         return False
     if dropout_p > 0 and fused_ops.current() is None:
         return False  # the dropout seed lives in the training loop's FusedContext
