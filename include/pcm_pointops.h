@@ -185,6 +185,10 @@ int pcm_attention_fusion_step_backward_hip(int m, int g, int c, const float *wei
 int pcm_knn_query_b_hip(int b, int m, int nsample, const float *xyz, const float *new_xyz,
                         const int *offset, const int *new_offset, int *idx, float *dist2,
                         void *stream);
+/* ... and with the size of the largest cloud, n_max (0 = unknown), when the caller knows it on the host (reserved for
+ * size-specialised variants; the results never depend on it). */
+int pcm_knn_query_n_hip(int b, int n_max, int m, int nsample, const float *xyz, const float *new_xyz,
+                        const int *offset, const int *new_offset, int *idx, float *dist2, void *stream);
 
 /* grouping(idx, feat, xyz, new_xyz, with_xyz)   functions/grouping.py:35-59
  * with_xyz (xyz and new_xyz non-null): output (m, nsample, 3+c) =

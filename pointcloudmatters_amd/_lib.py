@@ -20,6 +20,7 @@ SIGNATURES = {
     "pcm_farthest_point_sampling_hip": [_i, _i, _P, _P, _P, _P, _P, _P],
     "pcm_knn_query_hip": [_i, _i, _P, _P, _P, _P, _P, _P, _P],
     "pcm_knn_query_b_hip": [_i, _i, _i, _P, _P, _P, _P, _P, _P, _P],
+    "pcm_knn_query_n_hip": [_i, _i, _i, _i, _P, _P, _P, _P, _P, _P, _P],
     "pcm_ball_query_hip": [_i, _i, _f, _f, _P, _P, _P, _P, _P, _P, _P],
     "pcm_random_ball_query_hip": [_i, _i, _f, _f, _P, _P, _P, _P, _P, _P, _P, _P],
     "pcm_ball_query_b_hip": [_i, _i, _i, _f, _f, _P, _P, _P, _P, _P, _P, _P],

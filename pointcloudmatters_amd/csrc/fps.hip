@@ -23,6 +23,7 @@
 #include "pcm_common.hpp"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -368,7 +369,19 @@ extern "C" int pcm_farthest_point_sampling_hip(int b, int n, const float *xyz, c
         if (need <= 8) return launch_reg<256, 8, 2, true>(b, xyz, offset, new_offset, idx, L, st);
         return launch_reg<256, 16, 2, true>(b, xyz, offset, new_offset, idx, L, st);
     }
-    if (n <= 1024 * 8) return launch_reg<1024, 8, 0, true>(b, xyz, offset, new_offset, idx, L, st);
+    if (n <= 1024 * 8) {
+        // 4096 < n_max <= 8192 (BS = 1024).  The 1024-thread kernel pays 16 waves' worth of slots per pick (1.24 us / pick on
+        // a ragged 8 x ~4096 batch); fewer, fatter threads keep the pick latency of the 4096-point variant:
+        // 256 threads x 24 / 32 points (four reference threads folded into one) or 512 x 12 / 16 (two).
+        static const int t512 = getenv("PCM_FPS_T512") ? atoi(getenv("PCM_FPS_T512")) : 0;  // A/B switch for tools/mb
+        if (t512 == 2) return launch_reg<1024, 8, 0, true>(b, xyz, offset, new_offset, idx, L, st);
+        if (n <= 256 * 24) {
+            if (t512) return launch_reg<512, 12, 1, true>(b, xyz, offset, new_offset, idx, L, st);
+            return launch_reg<256, 24, 2, true>(b, xyz, offset, new_offset, idx, L, st);
+        }
+        if (t512) return launch_reg<512, 16, 1, true>(b, xyz, offset, new_offset, idx, L, st);
+        return launch_reg<256, 32, 2, true>(b, xyz, offset, new_offset, idx, L, st);
+    }
     if (n <= kMaxRegPoints) return launch_reg<1024, 16, 0, false>(b, xyz, offset, new_offset, idx, L, st);
     if (tmp == nullptr) return PCM_ERR_BAD_ARG;
     hipLaunchKernelGGL(pcm_fps_big_kernel, dim3(b), dim3(1024), 0, st, xyz, offset, new_offset, tmp, idx, L);

@@ -5,9 +5,11 @@
 //
 // The reference runs one thread per query with a 128-entry max-heap in scratch memory.  Here:
 //
-//  fast kernel   one wave64 per query.  Lane l looks at point (chunk*64 + l): coalesced xyz reads,
-//                one distance per lane, then `ballot(d2 < tau)` picks the few lanes that can enter
-//                the result.  The running result is a sorted list of nsample+1 (d2, idx) pairs held
+//  fast kernel   one wave64 per Q queries, four waves per workgroup sharing the cloud through LDS
+//                (the "LDS-staged per-query neighbourhoods" of the task statement: a cloud chunk is
+//                fetched from L2 once per 4 Q queries instead of once per query).  Lane l looks at point
+//                (slab*64 + l): one distance per lane and query, then `ballot(d2 < tau)` picks the few
+//                lanes that can enter the result.  The running result is a sorted list of nsample+1 (d2, idx) pairs held
 //                ACROSS LANES (lane s = s-th smallest); an insertion is a ballot/popcount for the
 //                position plus one wave_shr DPP shift -- no LDS, no scratch, no divergence.
 //                Candidates are consumed in ascending point index with a strict '<' against the
@@ -26,68 +28,123 @@
 //                Also serves nsample in 64..128, which does not fit the cross-lane list.
 #include "pcm_common.hpp"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int kFastMaxNsample = 63;  // list capacity nsample+1 <= 64 lanes
+constexpr int kWaves = 4;             // waves per workgroup
+constexpr int kChunk = 512;           // points staged in LDS at a time (SoA x | y | z), double-buffered
 
-__global__ __launch_bounds__(256) void pcm_knn_fast_kernel(int b, int m, int nsample,
-                                                           const float *__restrict__ xyz,
-                                                           const float *__restrict__ new_xyz,
-                                                           const int *__restrict__ offset,
-                                                           const int *__restrict__ new_offset,
-                                                           int *__restrict__ idx,
-                                                           float *__restrict__ dist2)
+// One workgroup = 4 waves x Q consecutive queries; the cloud those queries live in is streamed ONCE per workgroup through
+// LDS (coalesced global reads, structure-of-arrays in LDS so that lane l reads point l of a 64-point slab without bank
+// conflicts) and every lane evaluates ITS point against the wave's Q queries, whose coordinates and current thresholds are
+// wave-uniform (scalar registers).  Each query keeps the sorted cross-lane list described above.  A block of queries that
+// straddles a cloud boundary scans both clouds, each query taking part only in its own.
+template <int Q>
+__global__ __launch_bounds__(64 * kWaves) void pcm_knn_fast_kernel(int b, int m, int nsample, const float *__restrict__ xyz,
+                                                                    const float *__restrict__ new_xyz, const int *__restrict__ offset,
+                                                                    const int *__restrict__ new_offset, int *__restrict__ idx,
+                                                                    float *__restrict__ dist2)
 {
-    const int lane = threadIdx.x & 63;
-    const int wave_in_block = threadIdx.x >> 6;
-    const int waves_per_block = blockDim.x >> 6;
+    __shared__ float pts[2][3][kChunk];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int K1 = nsample + 1;
     const uint32_t PAD = __float_as_uint(1e10f);
-
-    for (int q = blockIdx.x * waves_per_block + wave_in_block; q < m; q += gridDim.x * waves_per_block) {
-        const int bt = pcm_cloud_of(q, new_offset, b);
-        const int start = bt == 0 ? 0 : offset[bt - 1];
-        const int end = offset[bt];
-        const float qx = new_xyz[(size_t)q * 3 + 0];
-        const float qy = new_xyz[(size_t)q * 3 + 1];
-        const float qz = new_xyz[(size_t)q * 3 + 2];
-
-        // sorted list across lanes; lanes >= K1 hold a sentinel that never moves
-        uint32_t ld = lane < K1 ? PAD : 0xFFFFFFFFu;
-        int li = -1;
-        uint32_t tau = PAD;  // d2 bits of list entry K1-1 (wave-uniform)
-
-        for (int base = start; base < end; base += 64) {
-            const int p = base + lane;
-            uint32_t db = 0xFFFFFFFFu;
-            if (p < end) {
-                const float d = pcm_sqdist(qx, qy, qz, xyz[(size_t)p * 3 + 0], xyz[(size_t)p * 3 + 1], xyz[(size_t)p * 3 + 2]);
-                db = __float_as_uint(d);  // d >= +0: unsigned order == float order
-            }
-            unsigned long long cand = __ballot(db < tau);
-            while (cand) {
-                const int l = __builtin_ctzll(cand);  // ascending lane == ascending point index
-                cand &= cand - 1;
-                const uint32_t d = __builtin_amdgcn_readlane(db, l);
-                if (d < tau) {  // tau may have dropped since the ballot
-                    const int pos = __builtin_popcountll(__ballot(ld <= d));  // sentinel lanes never count
-                    const uint32_t up_d = pcm_dpp<0x138>(ld);                 // wave_shr:1
-                    const uint32_t up_i = pcm_dpp<0x138>((uint32_t)li);
-                    const bool shift = lane > pos && lane < K1;
-                    ld = shift ? up_d : (lane == pos ? d : ld);
-                    li = shift ? (int)up_i : (lane == pos ? base + l : li);
-                    tau = __builtin_amdgcn_readlane(ld, K1 - 1);
+    constexpr int QB = Q * kWaves;  // queries per workgroup
+    for (int qb = blockIdx.x * QB; qb < m; qb += gridDim.x * QB) {
+        const int q0 = qb + wave * Q;  // this wave's first query (may lie beyond m: then it only helps with the staging)
+        const int q_last_wg = min(qb + QB, m) - 1;
+        const int c_first = pcm_cloud_of(qb, new_offset, b), c_last = pcm_cloud_of(q_last_wg, new_offset, b);
+        uint32_t ld[Q], tau[Q];
+        int li[Q];
+        float qx[Q], qy[Q], qz[Q];
+#pragma unroll
+        for (int i = 0; i < Q; ++i) {
+            ld[i] = lane < K1 ? PAD : 0xFFFFFFFFu;  // lanes >= K1 hold a sentinel that never moves
+            li[i] = -1;
+            tau[i] = PAD;                           // d2 bits of list entry K1-1 (wave-uniform)
+            const int q = q0 + i < m ? q0 + i : m - 1;
+            qx[i] = new_xyz[(size_t)q * 3 + 0], qy[i] = new_xyz[(size_t)q * 3 + 1], qz[i] = new_xyz[(size_t)q * 3 + 2];
+        }
+        for (int c = c_first; c <= c_last; ++c) {
+            const int start = c == 0 ? 0 : offset[c - 1], end = offset[c];
+            const int qs = c == 0 ? 0 : new_offset[c - 1], qe = new_offset[c];  // queries of this cloud
+            bool act[Q];
+#pragma unroll
+            for (int i = 0; i < Q; ++i) act[i] = q0 + i >= qs && q0 + i < qe && q0 + i < m;
+            const int npts = end - start;
+            const int nchunks = (npts + kChunk - 1) / kChunk;
+            float rx[2], ry[2], rz[2];
+            auto fetch = [&](int ch) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int p = ch * kChunk + u * 256 + (int)threadIdx.x;
+                    const bool ok = p < npts;
+                    const float *src = xyz + (size_t)(start + (ok ? p : 0)) * 3;
+                    rx[u] = ok ? src[0] : 0.f, ry[u] = ok ? src[1] : 0.f, rz[u] = ok ? src[2] : 0.f;
+                }
+            };
+            if (nchunks > 0) fetch(0);
+            for (int ch = 0; ch < nchunks; ++ch) {
+                float(*buf)[kChunk] = pts[ch & 1];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) buf[0][u * 256 + threadIdx.x] = rx[u], buf[1][u * 256 + threadIdx.x] = ry[u], buf[2][u * 256 + threadIdx.x] = rz[u];
+                __syncthreads();  // one barrier per chunk: the other buffer was last read before the previous barrier
+                if (ch + 1 < nchunks) fetch(ch + 1);
+                const int left = npts - ch * kChunk;  // points in this chunk (may exceed kChunk)
+                // the next slab's coordinates are requested before this slab's candidates are worked through, and the Q distances
+                // of a slab are computed back to back (independent chains) before the first ballot
+                const int nslab = left < kChunk ? (left + 63) / 64 : kChunk / 64;
+                float px = buf[0][lane], py = buf[1][lane], pz = buf[2][lane];
+                for (int sub = 0; sub < nslab; ++sub) {
+                    const bool valid = sub * 64 + lane < left;
+                    const int nx = sub + 1 < nslab ? (sub + 1) * 64 + lane : lane;
+                    const float fx = buf[0][nx], fy = buf[1][nx], fz = buf[2][nx];
+                    const int pbase = start + ch * kChunk + sub * 64;
+                    uint32_t db[Q];
+#pragma unroll
+                    for (int i = 0; i < Q; ++i) {
+                        const float d = pcm_sqdist(qx[i], qy[i], qz[i], px, py, pz);
+                        db[i] = valid ? __float_as_uint(d) : 0xFFFFFFFFu;  // d >= +0: unsigned order == float order
+                    }
+#pragma unroll
+                    for (int i = 0; i < Q; ++i) {
+                        if (!act[i]) continue;  // wave-uniform
+                        unsigned long long cand = __ballot(db[i] < tau[i]);
+                        while (cand) {
+                            const int l = __builtin_ctzll(cand);  // ascending lane == ascending point index
+                            cand &= cand - 1;
+                            const uint32_t dd = __builtin_amdgcn_readlane(db[i], l);
+                            if (dd < tau[i]) {  // tau may have dropped since the ballot
+                                const int pos = __builtin_popcountll(__ballot(ld[i] <= dd));  // sentinel lanes never count
+                                const uint32_t up_d = pcm_dpp<0x138>(ld[i]);                  // wave_shr:1
+                                const uint32_t up_i = pcm_dpp<0x138>((uint32_t)li[i]);
+                                const bool shift = lane > pos && lane < K1;
+                                ld[i] = shift ? up_d : (lane == pos ? dd : ld[i]);
+                                li[i] = shift ? (int)up_i : (lane == pos ? pbase + l : li[i]);
+                                tau[i] = __builtin_amdgcn_readlane(ld[i], K1 - 1);
+                            }
+                        }
+                    }
+                    px = fx, py = fy, pz = fz;
                 }
             }
+            __syncthreads();  // the next cloud (or query block) restarts with buffer 0
         }
-        // exact-tie detection over the nsample+1 smallest (pads, li == -1, are not ties)
-        const uint32_t nd = pcm_dpp<0x130>(ld);                // wave_shl:1 -> lane l sees l+1
-        const int ni = (int)pcm_dpp<0x130>((uint32_t)li);
-        const bool tie = lane < K1 - 1 && ld == nd && li >= 0 && ni >= 0;
-        const bool any_tie = __ballot(tie) != 0ull;
-        if (lane < nsample) {
-            idx[(size_t)q * nsample + lane] = li;
-            dist2[(size_t)q * nsample + lane] = (lane == 0 && any_tie) ? -1.f : __uint_as_float(ld);
+#pragma unroll
+        for (int i = 0; i < Q; ++i) {
+            const int q = q0 + i;
+            if (q >= m) continue;  // wave-uniform
+            // exact-tie detection over the nsample+1 smallest (pads, li == -1, are not ties)
+            const uint32_t nd = pcm_dpp<0x130>(ld[i]);  // wave_shl:1 -> lane l sees l+1
+            const int ni = (int)pcm_dpp<0x130>((uint32_t)li[i]);
+            const bool tie = lane < K1 - 1 && ld[i] == nd && li[i] >= 0 && ni >= 0;
+            const bool any_tie = __ballot(tie) != 0ull;
+            if (lane < nsample) {
+                idx[(size_t)q * nsample + lane] = li[i];
+                dist2[(size_t)q * nsample + lane] = (lane == 0 && any_tie) ? -1.f : __uint_as_float(ld[i]);
+            }
         }
     }
 }
@@ -156,20 +213,29 @@ __global__ __launch_bounds__(64) void pcm_knn_exact_kernel(int b, int m, int nsa
 
 }  // namespace
 
-extern "C" int pcm_knn_query_b_hip(int b, int m, int nsample, const float *xyz, const float *new_xyz,
-                                   const int *offset, const int *new_offset, int *idx, float *dist2,
-                                   void *stream)
+// n_max: size of the largest cloud when the caller knows it on the host (0: unknown); reserved for size-specialised
+// variants, the streaming kernel serves every size.
+extern "C" int pcm_knn_query_n_hip(int b, int n_max, int m, int nsample, const float *xyz, const float *new_xyz,
+                                   const int *offset, const int *new_offset, int *idx, float *dist2, void *stream)
 {
-    if (m < 0 || nsample < 1 || nsample > PCM_KNN_MAX_NSAMPLE) return PCM_ERR_BAD_ARG;
+    if (m < 0 || nsample < 1 || nsample > PCM_KNN_MAX_NSAMPLE || n_max < 0) return PCM_ERR_BAD_ARG;
     if (m == 0) return PCM_OK;
     hipStream_t st = (hipStream_t)stream;
     const int exact_blocks = (m + 63) / 64 < 4096 ? (m + 63) / 64 : 4096;
     if (nsample <= kFastMaxNsample) {
-        const int waves_per_block = 4;
-        int blocks = (m + waves_per_block - 1) / waves_per_block;
-        if (blocks > 256 * 8) blocks = 256 * 8;  // 8 workgroups per CU, grid-stride beyond
-        hipLaunchKernelGGL(pcm_knn_fast_kernel, dim3(blocks), dim3(64 * waves_per_block), 0, st, b, m, nsample, xyz, new_xyz,
-                           offset, new_offset, idx, dist2);
+        {
+            // queries per wave.  Measured on MI355X (us; Q = 1 / 2 / 4): 128 x 1024 pts, m = 65536: 255 / 236 / 229;
+            // 32 x 4096, m = 65536: 394 / 351 / 342; 8 ragged x ~4096, m = 16384: 107 / 106 / 127.  The kernel is bound by the
+            // serial insertion chain (vector -> scalar -> vector dependencies, ~K ln(N/K) insertions per query), not by the
+            // cloud reads: more queries per wave save L2 traffic but leave fewer independent waves to hide that latency.
+            static const int forced = getenv("PCM_KNN_Q") ? atoi(getenv("PCM_KNN_Q")) : 0;  // A/B switch for tools/mb
+            const int Q = forced ? forced : (m >= 16 * kWaves * 1024 ? 4 : (m >= 2 * kWaves * 1024 ? 2 : 1));
+            int blocks = (m + Q * kWaves - 1) / (Q * kWaves);
+            if (blocks > 256 * 16) blocks = 256 * 16;
+#define PCM_KNN(QQ) hipLaunchKernelGGL(pcm_knn_fast_kernel<QQ>, dim3(blocks), dim3(64 * kWaves), 0, st, b, m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2)
+            if (Q == 4) PCM_KNN(4); else if (Q == 2) PCM_KNN(2); else PCM_KNN(1);
+#undef PCM_KNN
+        }
         int rc = PCM_LAUNCH_STATUS();
         if (rc) return rc;
         hipLaunchKernelGGL(pcm_knn_exact_kernel, dim3(exact_blocks), dim3(64), 0, st, b, m, nsample, 0, xyz, new_xyz, offset,
@@ -181,9 +247,16 @@ extern "C" int pcm_knn_query_b_hip(int b, int m, int nsample, const float *xyz, 
     return PCM_LAUNCH_STATUS();
 }
 
+extern "C" int pcm_knn_query_b_hip(int b, int m, int nsample, const float *xyz, const float *new_xyz,
+                                   const int *offset, const int *new_offset, int *idx, float *dist2,
+                                   void *stream)
+{
+    return pcm_knn_query_n_hip(b, 0, m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2, stream);
+}
+
 extern "C" int pcm_knn_query_hip(int m, int nsample, const float *xyz, const float *new_xyz,
                                  const int *offset, const int *new_offset, int *idx, float *dist2,
                                  void *stream)
 {
-    return pcm_knn_query_b_hip(0, m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2, stream);
+    return pcm_knn_query_n_hip(0, 0, m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2, stream);
 }

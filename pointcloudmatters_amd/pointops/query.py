@@ -25,8 +25,9 @@ def knn_query_raw(nsample, xyz, offset, new_xyz=None, new_offset=None):
         idx = torch.empty(m, nsample, dtype=torch.int32, device=xyz.device)
         dist2 = torch.empty(m, nsample, dtype=torch.float32, device=xyz.device)
         o32, no32 = C.i32c(offset), C.i32c(new_offset)
-        rc = L.pcm_knn_query_b_hip(
-            int(offset.shape[0]), m, nsample, C.ptr(xyz), C.ptr(new_xyz), C.ptr(o32), C.ptr(no32), C.ptr(idx),
+        n_max = max(C.counts_from_offsets(C.host_offsets(offset)), default=0)  # host copy rides on the tensor: no sync
+        rc = L.pcm_knn_query_n_hip(
+            int(offset.shape[0]), int(n_max), m, nsample, C.ptr(xyz), C.ptr(new_xyz), C.ptr(o32), C.ptr(no32), C.ptr(idx),
             C.ptr(dist2), C.stream(),
         )
     C._lib.check(rc, "pcm_knn_query_hip")

@@ -24,6 +24,7 @@ MAX_KEYS = 4096  # cross-attention over the REF memory (2051 tokens): forward 28
 
 
 LONG_IMPL = os.environ.get("PCM_ATTN_LONG", "flash")  # "flash" (csrc/attn_flash.hip) | "sdpa" (framework kernel)
+FLASH_FROM = int(os.environ.get("PCM_ATTN_FLASH_FROM", "129"))  # query count from which attn_flash.hip takes over from attn_small.hip
 
 
 def _st(t):
@@ -41,21 +42,22 @@ class _SmallAttn(Function):
         with torch.cuda.device(dev):
             out = torch.empty(B, L, E, dtype=torch.bfloat16, device=dev)
             lse = torch.empty(B, heads, L, dtype=torch.float32, device=dev)
-            fwd = L_.pcm_attn_flash_forward_hip if L > MAX_QUERIES else L_.pcm_attn_small_forward_hip
+            use_flash = L >= FLASH_FROM
+            fwd = L_.pcm_attn_flash_forward_hip if use_flash else L_.pcm_attn_small_forward_hip
             rc = fwd(B, heads, L, S, q.data_ptr(), *_st(q), k.data_ptr(), *_st(k), v.data_ptr(), *_st(v),
                      kpm.data_ptr() if kpm is not None else 0, 1.0 / math.sqrt(E // heads), float(p_drop),
                      seed.data_ptr() if seed is not None else 0, int(site), out.data_ptr(),
                      lse.data_ptr(), torch.cuda.current_stream().cuda_stream)
-        _lib.check(rc, "pcm_attn_flash_forward_hip" if L > MAX_QUERIES else "pcm_attn_small_forward_hip")
+        _lib.check(rc, "pcm_attn_flash_forward_hip" if use_flash else "pcm_attn_small_forward_hip")
         ctx.save_for_backward(q, k, v, out, lse, kpm)
-        ctx.meta = (heads, float(p_drop), seed, int(site))
+        ctx.meta = (heads, float(p_drop), seed, int(site), use_flash)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         L_ = _lib.load()
         q, k, v, out, lse, kpm = ctx.saved_tensors
-        heads, p_drop, seed, site = ctx.meta
+        heads, p_drop, seed, site, use_flash = ctx.meta
         B, L, E = q.shape
         S = k.shape[1]
         dout = dout.to(torch.bfloat16).contiguous()
@@ -72,12 +74,12 @@ class _SmallAttn(Function):
                     kpm.data_ptr() if kpm is not None else 0, 1.0 / math.sqrt(E // heads), p_drop,
                     seed.data_ptr() if seed is not None else 0, site, out.data_ptr(), dout.data_ptr(), lse.data_ptr())
             tail = (dq.data_ptr(), *_st(dq), dk.data_ptr(), *_st(dk), dv.data_ptr(), *_st(dv), torch.cuda.current_stream().cuda_stream)
-            if L > MAX_QUERIES:
+            if use_flash:
                 delta = torch.empty(B, heads, L, dtype=torch.float32, device=dev)
                 rc = L_.pcm_attn_flash_backward_hip(*head, delta.data_ptr(), *tail)
             else:
                 rc = L_.pcm_attn_small_backward_hip(*head, *tail)
-        _lib.check(rc, "pcm_attn_flash_backward_hip" if L > MAX_QUERIES else "pcm_attn_small_backward_hip")
+        _lib.check(rc, "pcm_attn_flash_backward_hip" if use_flash else "pcm_attn_small_backward_hip")
         return dq, dk, dv, None, None, None, None, None
 
 

@@ -16,7 +16,10 @@ FPS_CASES = [
     ([1024] * 8, [512] * 8, "uniform"),
     ([2048] * 4, [1024] * 4, "uniform"),
     ([4096] * 8, [2048] * 8, "uniform"),
-    ([3100, 4096, 5000, 3600], [2048] * 4, "uniform"),       # ragged, PPT 32 path (T=1024)
+    ([3100, 4096, 5000, 3600], [2048] * 4, "uniform"),       # ragged REF batch: 4096 < n_max <= 6144 -> 256 threads x 24 points
+    ([6144, 4097], [2048, 700], "lattice"),                   # ... at its capacity, with forced ties
+    ([8192, 7000, 6145], [1024, 512, 300], "uniform"),       # 6144 < n_max <= 8192 -> 256 threads x 32 points
+    ([8000, 5000], [400, 400], "dup"),
     ([1000, 37, 260, 1023], [64, 50, 64, 600], "uniform"),    # ragged incl. N < M and N < BS
     ([5, 3, 1], [8, 2, 4], "uniform"),                        # tiny, M > N
     ([100], [100], "uniform"),                                # BS = 64 < T
@@ -57,6 +60,10 @@ KNN_CASES = [
     ([2000], [300], 64, "uniform"),                           # exact kernel only
     ([500], [100], 128, "lattice"),
     ([300], [300], 1, "dup"),
+    ([700, 300, 20, 5, 1030], [64, 64, 64, 64, 130], 16, "uniform"),   # query blocks of one workgroup straddling up to 4 clouds
+    ([5000, 1], [2500, 3], 16, "lattice"),                    # > 8 chunks of 512 points; a one-point cloud behind it
+    ([4096] * 8, [2048] * 8, 16, "uniform"),                  # m = 16384: four queries per wave
+    ([1024] * 16, [600] * 16, 8, "dup"),                      # m = 9600: two queries per wave, duplicates
 ]
 
 
