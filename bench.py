@@ -161,7 +161,8 @@ def pointops_and_sa_kernels(t, shape, device):
     rm, rv = torch.zeros(H, **f32), torch.ones(H, **f32)
     sel = torch.empty(m, H, **f32)
     asel = torch.empty(m, H, dtype=torch.uint8, device=device)
-    slots = max(L.pcm_sa_fused_slots(m, H, 1, k), L.pcm_sa_fused_slots(m, H, 0, 1), L.pcm_sa_fused_slots(n_tot, H, 1, 1), b)
+    slots = max(L.pcm_sa_fused_slots(m, H, 1, k), L.pcm_sa_fused_slots(m, H, 0, 1), L.pcm_sa_fused_slots(n_tot, H, 1, 1), b,
+                L.pcm_sa_bwd1_det_slots(m)) + L.pcm_sa_fused_reduce_scratch_rows()
     partial = torch.empty(slots * 5 * H, **f32)
     sums, stat, z = torch.empty(2, H, **f32), torch.empty(4, H, **f32), torch.empty(m, H, **f32)
     dz = torch.randn(m, H, **f32)
@@ -213,6 +214,31 @@ def pointops_and_sa_kernels(t, shape, device):
     t.add("pcm_sa_bwd1_lds_kernel<CH=%d>" % lds_ch if lds_ch else "pcm_sa_bwd1_kernel(global atomics)", timed_events(lambda: bwd(2), 30),
           m * H * 9 + 16 * rows + n_tot * H * 4, "hbm",
           "m*H deltas (dz 4 B + sel 4 B + slot 1 B read) scattered with ds_add_f32 into an LDS tile per (cloud, channel chunk); D written once")
+    # the reproducible (sorted-CSR) forms of the index pass and of backward pass 1 -- what the training step runs by default
+    if L.pcm_sa_det_supported(k, H):
+        csr = torch.empty(n_tot + 1 + rows, dtype=torch.int32, device=device)
+        scratch = torch.empty(L.pcm_sa_index_det_scratch_ints(n_tot), dtype=torch.int32, device=device)
+        ws = torch.empty(L.pcm_sa_bwd1_det_ws_bytes(m, k, H), dtype=torch.uint8, device=device)
+
+        def index_det():
+            assert L.pcm_sa_index_det_hip(m, k, n_tot, coord.data_ptr(), n_p.data_ptr(), knn_idx.data_ptr(), ent.data_ptr(), csr.data_ptr(),
+                                          scratch.data_ptr(), cnt.data_ptr(), S.data_ptr(), RM.data_ptr(), st) == 0
+
+        def bwd1_det(mask):
+            assert L.pcm_sa_bwd1_det_hip(m, n_tot, k, H, dz.data_ptr(), sel.data_ptr(), asel.data_ptr(), stat.data_ptr(), ent.data_ptr(),
+                                         csr.data_ptr(), ws.data_ptr(), D.data_ptr(), partial.data_ptr(), red1.data_ptr(), mask, st) == 0
+
+        index_det()
+        bwd1_det(0)
+        t.add("pcm_sa_index (sorted CSR: entries + plan + sort + segment sums)", timed_events(index_det, 30),
+              4 * rows + 12 * n_tot + 12 * m + 2 * 16 * rows + 16 * n_tot + 8 * rows, "hbm",
+              "reproducible index pass (10 launches, sampling side stream): neighbour records, sorted inverse lists, cnt / S / RM")
+        t.add("pcm_sa_bwd1_pack_kernel", timed_events(lambda: bwd1_det(1), 30), m * H * 9 + m * H * 3, "hbm",
+              "per query: delta = dz * [relu'] bucketed by arg-extremum slot; ~half of the (channel, delta) pairs survive the ReLU")
+        t.add("pcm_sa_bwd1_gather_kernel", timed_events(lambda: bwd1_det(2), 30), m * H * 3 + n_tot * H * 4 + 4 * rows, "hbm",
+              "per point: runs of (channel, delta) added in list order into an LDS row; D written once")
+        index()  # back to the atomic kernels' statistics for the rows below
+        bwd(0)
     t.add("pcm_sa_bwd2_kernel<bf16>", timed_events(lambda: bwd(8), 30), n_tot * H * (2 + 4 + 2) + 16 * n_tot, "hbm", "dense n*H pass")
     t.add("pcm_sa_reduce_kernel", timed_events(lambda: bwd(4), 30), slots * 5 * H * 4, "hbm", "fp64 reduction of per-block partial rows")
 
@@ -350,6 +376,36 @@ def policy_kernels(t, wl, device, hidden=512):
         t.add("pcm_attn_small_bwd_kernel", timed_events(attn_b, 30), None, "mfma", "same shape, dQ and dK/dV roles in one launch",
               flops=flops_f * 5 // 2)
 
+    # ---- MFMA attention for long query sets: the encoder self-attention ((M+3)^2 tokens, 8 heads x 64, dropout 0.1) ----------
+    S_enc = m_per + 3
+    qkv = torch.randn(b, S_enc, 3, hidden, **f32).to(torch.bfloat16)
+    qe, ke, ve = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    oe = torch.empty(b, S_enc, hidden, dtype=torch.bfloat16, device=device)
+    lse_e, delta_e = torch.empty(b, nh, S_enc, **f32), torch.empty(b, nh, S_enc, **f32)
+    goe = torch.randn(b, S_enc, hidden, **f32).to(torch.bfloat16)
+    dqkv = torch.empty_like(qkv)
+    seed_e = torch.full((1,), 1234, dtype=torch.int64, device=device)
+    sc = 1.0 / 8.0
+    head = (b, nh, S_enc, S_enc, qe.data_ptr(), qe.stride(0), qe.stride(1), ke.data_ptr(), ke.stride(0), ke.stride(1), ve.data_ptr(),
+            ve.stride(0), ve.stride(1), 0, sc, 0.1, seed_e.data_ptr(), 7)
+
+    def fl_f():
+        assert L.pcm_attn_flash_forward_hip(*head, oe.data_ptr(), lse_e.data_ptr(), st) == 0
+
+    def fl_b(mask):
+        assert L.pcm_attn_flash_backward_stages_hip(*head, oe.data_ptr(), goe.data_ptr(), lse_e.data_ptr(), delta_e.data_ptr(),
+                                                    dqkv[:, :, 0].data_ptr(), dqkv.stride(0), dqkv.stride(1),
+                                                    dqkv[:, :, 1].data_ptr(), dqkv.stride(0), dqkv.stride(1),
+                                                    dqkv[:, :, 2].data_ptr(), dqkv.stride(0), dqkv.stride(1), mask, st) == 0
+
+    fl_f()
+    fl_b(0)
+    unit = 2 * b * nh * S_enc * S_enc * 64  # one S x S x 64 GEMM per (batch, head)
+    note = "encoder self-attention, %d x %d tokens x %d (batch, head) pairs, dropout 0.1 (counter hash recomputed in backward)" % (S_enc, S_enc, b * nh)
+    t.add("pcm_attn_flash_fwd_kernel", timed_events(fl_f, 20), None, "mfma", note + "; QK^T + PV", flops=2 * unit)
+    t.add("pcm_attn_flash_bwd_dkv_kernel", timed_events(lambda: fl_b(2), 20), None, "mfma", note + "; S, dP, dV, dK: 4 GEMMs", flops=4 * unit)
+    t.add("pcm_attn_flash_bwd_dq_kernel", timed_events(lambda: fl_b(4), 20), None, "mfma", note + "; S, dP, dQ: 3 GEMMs", flops=3 * unit)
+
     # ---- PointNet layer tail: BatchNorm1d + ReLU over the packed point features (widest layer: n x 512, bf16) ----
     Cb = 512
     yb = torch.randn(n_tot, Cb, **f32).to(torch.bfloat16)
@@ -452,6 +508,9 @@ def kernel_rooflines_hbm(device, names=None):
 
 # trace kernel name (substring) -> key prefix in the `kernels` table
 TRACE_TO_TABLE = [
+    ("pcm_sa_bwd1_pack", "pcm_sa_bwd1_pack_kernel"), ("pcm_sa_bwd1_gather", "pcm_sa_bwd1_gather_kernel"),
+    ("pcm_attn_flash_fwd", "pcm_attn_flash_fwd_kernel"), ("pcm_attn_flash_bwd_dkv", "pcm_attn_flash_bwd_dkv_kernel"),
+    ("pcm_attn_flash_bwd_dq", "pcm_attn_flash_bwd_dq_kernel"),
     ("pcm_fps", "pcm_fps_reg_kernel"), ("pcm_knn", "pcm_knn_fast_kernel"), ("pcm_sa_fwd", "pcm_sa_fwd_kernel"),
     ("pcm_sa_apply", "pcm_sa_apply_kernel"), ("pcm_sa_entries", "pcm_sa_entries+index"), ("pcm_sa_index", "pcm_sa_entries+index"),
     ("pcm_sa_bwd1", "pcm_sa_bwd1"), ("pcm_sa_bwd2", "pcm_sa_bwd2_kernel"), ("pcm_sa_reduce", "pcm_sa_reduce_kernel"),

@@ -231,6 +231,9 @@ int pcm_group_xyz_feat_backward_hip(int m, int nsample, int c, int with_xyz,
  * `count` = m*K of the global batch (red_global NULL / count <= 0: single rank).
  * pcm_sa_fused_slots(rows, H, bf16, K): partial-row slots a row-streaming kernel over `rows` rows writes. */
 int pcm_sa_fused_slots(int units, int H, int bf16, int K);
+/* the partial-row buffer must hold pcm_sa_fused_reduce_scratch_rows() rows beyond the slots (second level of the reductions) */
+int pcm_sa_fused_reduce_scratch_rows(void);
+int pcm_sa_reduce_rows_hip(int nslots, int VH, const float *partial, float *scratch, float *out, void *stream);
 int pcm_sa_fused_bwd1_lds_channels(int H, int n_max);
 int pcm_sa_fused_forward_hip(int m, int K, int H, int gf_is_bf16, const void *Gf, const void *ent,
                              const float *Wp, const float *gamma, const float *beta, float eps,
@@ -288,6 +291,13 @@ int pcm_attn_flash_backward_hip(int B, int H, int L, int S, const void *q, long 
                                 float scale, float p_drop, const long *seed, unsigned site, const void *out,
                                 const void *dout, const float *lse, float *delta, void *dq, long dq_bs, long dq_ls, void *dk,
                                 long dk_bs, long dk_ls, void *dv, long dv_bs, long dv_ls, void *stream);
+/* the same with a stage mask (1 delta | 2 dK, dV | 4 dQ; <= 0 all): lets bench.py time one kernel at a time */
+int pcm_attn_flash_backward_stages_hip(int B, int H, int L, int S, const void *q, long q_bs, long q_ls, const void *k,
+                                       long k_bs, long k_ls, const void *v, long v_bs, long v_ls,
+                                       const unsigned char *key_padding_mask, float scale, float p_drop, const long *seed,
+                                       unsigned site, const void *out, const void *dout, const float *lse, float *delta,
+                                       void *dq, long dq_bs, long dq_ls, void *dk, long dk_bs, long dk_ls, void *dv, long dv_bs,
+                                       long dv_ls, int stage_mask, void *stream);
 
 /* ---- hipGraph surgery -----------------------------------------------------------------------------------
  * Replace every MEMSET node of a captured, not yet instantiated hipGraph_t by a fill-kernel node with the same

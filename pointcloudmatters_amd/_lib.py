@@ -52,6 +52,8 @@ SIGNATURES = {
     "pcm_group_xyz_feat_forward_hip": [_i, _i, _i, _P, _P, _P, _P, _P, _P],
     "pcm_group_xyz_feat_backward_hip": [_i, _i, _i, _i, _P, _P, _P, _P],
     "pcm_sa_fused_slots": [_i, _i, _i, _i],
+    "pcm_sa_fused_reduce_scratch_rows": [],
+    "pcm_sa_reduce_rows_hip": [_i, _i, _P, _P, _P, _P],
     "pcm_sa_fused_bwd1_lds_channels": [_i, _i],
     "pcm_sa_fused_forward_hip": [_i, _i, _i, _i, _P, _P, _P, _P, _P, _f, _f, _P, _P, _P, _P, _P, _P, _P, _P, _i, _P],
     "pcm_sa_index_hip": [_i, _i, _P, _P, _P, _P, _P, _i, _i, _P, _P, _P, _P, _P],
@@ -92,6 +94,8 @@ SIGNATURES = {
     "pcm_attn_flash_forward_hip": [_i, _i, _i, _i, _P, ctypes.c_long, ctypes.c_long, _P, ctypes.c_long, ctypes.c_long, _P, ctypes.c_long, ctypes.c_long, _P, _f, _f, _P, ctypes.c_uint, _P, _P, _P],
     "pcm_attn_flash_backward_hip": [_i, _i, _i, _i, _P, ctypes.c_long, ctypes.c_long, _P, ctypes.c_long, ctypes.c_long, _P, ctypes.c_long, ctypes.c_long, _P, _f, _f, _P, ctypes.c_uint,
                                     _P, _P, _P, _P, _P, ctypes.c_long, ctypes.c_long, _P, ctypes.c_long, ctypes.c_long, _P, ctypes.c_long, ctypes.c_long, _P],
+    "pcm_attn_flash_backward_stages_hip": [_i, _i, _i, _i, _P, ctypes.c_long, ctypes.c_long, _P, ctypes.c_long, ctypes.c_long, _P, ctypes.c_long, ctypes.c_long, _P, _f, _f, _P, ctypes.c_uint,
+                                           _P, _P, _P, _P, _P, ctypes.c_long, ctypes.c_long, _P, ctypes.c_long, ctypes.c_long, _P, ctypes.c_long, ctypes.c_long, _i, _P],
     "pcm_graph_replace_memsets": [_P, _P],
     "pcm_optim_partials_capacity": [],
     "pcm_grad_sumsq_hip": [ctypes.c_long, _P, _P, _P, _P],

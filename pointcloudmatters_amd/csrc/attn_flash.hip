@@ -504,6 +504,36 @@ extern "C" int pcm_attn_flash_forward_hip(int B, int H, int L, int S, const void
 }
 
 // delta: (B, H, L) fp32 workspace (written here).  dq / dk / dv: bf16 with the given batch / row strides.
+// stage_mask: 1 delta | 2 dK, dV | 4 dQ (bench.py times the kernels one at a time; <= 0: all)
+extern "C" int pcm_attn_flash_backward_stages_hip(int B, int H, int L, int S, const void *q, long q_bs, long q_ls, const void *k,
+                                                  long k_bs, long k_ls, const void *v, long v_bs, long v_ls,
+                                                  const unsigned char *key_padding_mask, float scale, float p_drop, const long *seed,
+                                                  unsigned site, const void *out, const void *dout, const float *lse, float *delta,
+                                                  void *dq, long dq_bs, long dq_ls, void *dk, long dk_bs, long dk_ls, void *dv,
+                                                  long dv_bs, long dv_ls, int stage_mask, void *stream)
+{
+    if (B <= 0 || H <= 0) return B == 0 ? PCM_OK : PCM_ERR_BAD_ARG;
+    if (!pcm_attn_flash_supported(L, S, HD)) return PCM_ERR_UNSUPPORTED;
+    if (!strides_ok(q_bs, q_ls) || !strides_ok(k_bs, k_ls) || !strides_ok(v_bs, v_ls)) return PCM_ERR_BAD_ARG;
+    if (dq_ls % 8 || dk_ls % 8 || dv_ls % 8 || dq_bs % 8 || dk_bs % 8 || dv_bs % 8) return PCM_ERR_BAD_ARG;
+    if (stage_mask <= 0) stage_mask = 7;
+    AttnParams P{(const u16 *)q, (const u16 *)k, (const u16 *)v, q_bs, q_ls, k_bs, k_ls, v_bs, v_ls, key_padding_mask,
+                 B, H, L, S, scale, p_drop, seed, site};
+    hipStream_t st = (hipStream_t)stream;
+    const long groups = (long)B * L * H * 8;
+    long pblocks = (groups + WG - 1) / WG;
+    if (pblocks > 4096) pblocks = 4096;
+    if (stage_mask & 1)
+        hipLaunchKernelGGL(pcm_attn_flash_prep_kernel, dim3((int)pblocks), dim3(WG), 0, st, B, H, L, (const u16 *)out, (const u16 *)dout, delta);
+    if (stage_mask & 2)
+        hipLaunchKernelGGL(pcm_attn_flash_bwd_dkv_kernel, dim3(B * H, (S + RWG - 1) / RWG), dim3(WG), 0, st, P, (const u16 *)dout, lse, delta,
+                           (u16 *)dk, dk_bs, dk_ls, (u16 *)dv, dv_bs, dv_ls);
+    if (stage_mask & 4)
+        hipLaunchKernelGGL(pcm_attn_flash_bwd_dq_kernel, dim3(B * H, (L + RWG - 1) / RWG), dim3(WG), 0, st, P, (const u16 *)dout, lse, delta,
+                           (u16 *)dq, dq_bs, dq_ls);
+    return PCM_LAUNCH_STATUS();
+}
+
 extern "C" int pcm_attn_flash_backward_hip(int B, int H, int L, int S, const void *q, long q_bs, long q_ls, const void *k,
                                            long k_bs, long k_ls, const void *v, long v_bs, long v_ls,
                                            const unsigned char *key_padding_mask, float scale, float p_drop, const long *seed,
@@ -511,20 +541,6 @@ extern "C" int pcm_attn_flash_backward_hip(int B, int H, int L, int S, const voi
                                            void *dq, long dq_bs, long dq_ls, void *dk, long dk_bs, long dk_ls, void *dv,
                                            long dv_bs, long dv_ls, void *stream)
 {
-    if (B <= 0 || H <= 0) return B == 0 ? PCM_OK : PCM_ERR_BAD_ARG;
-    if (!pcm_attn_flash_supported(L, S, HD)) return PCM_ERR_UNSUPPORTED;
-    if (!strides_ok(q_bs, q_ls) || !strides_ok(k_bs, k_ls) || !strides_ok(v_bs, v_ls)) return PCM_ERR_BAD_ARG;
-    if (dq_ls % 8 || dk_ls % 8 || dv_ls % 8 || dq_bs % 8 || dk_bs % 8 || dv_bs % 8) return PCM_ERR_BAD_ARG;
-    AttnParams P{(const u16 *)q, (const u16 *)k, (const u16 *)v, q_bs, q_ls, k_bs, k_ls, v_bs, v_ls, key_padding_mask,
-                 B, H, L, S, scale, p_drop, seed, site};
-    hipStream_t st = (hipStream_t)stream;
-    const long groups = (long)B * L * H * 8;
-    long pblocks = (groups + WG - 1) / WG;
-    if (pblocks > 4096) pblocks = 4096;
-    hipLaunchKernelGGL(pcm_attn_flash_prep_kernel, dim3((int)pblocks), dim3(WG), 0, st, B, H, L, (const u16 *)out, (const u16 *)dout, delta);
-    hipLaunchKernelGGL(pcm_attn_flash_bwd_dkv_kernel, dim3(B * H, (S + RWG - 1) / RWG), dim3(WG), 0, st, P, (const u16 *)dout, lse, delta,
-                       (u16 *)dk, dk_bs, dk_ls, (u16 *)dv, dv_bs, dv_ls);
-    hipLaunchKernelGGL(pcm_attn_flash_bwd_dq_kernel, dim3(B * H, (L + RWG - 1) / RWG), dim3(WG), 0, st, P, (const u16 *)dout, lse, delta,
-                       (u16 *)dq, dq_bs, dq_ls);
-    return PCM_LAUNCH_STATUS();
+    return pcm_attn_flash_backward_stages_hip(B, H, L, S, q, q_bs, q_ls, k, k_bs, k_ls, v, v_bs, v_ls, key_padding_mask, scale, p_drop, seed,
+                                              site, out, dout, lse, delta, dq, dq_bs, dq_ls, dk, dk_bs, dk_ls, dv, dv_bs, dv_ls, 0, stream);
 }

@@ -355,19 +355,23 @@ __global__ __launch_bounds__(kBlock) void pcm_sa_fwd_kernel(int m, int K, int H,
     group_reduce_store<2, VEC>(vals, partial, slot, H, chunk, lpq, qpw, qi, gl, lane_on, smem);
 }
 
-// out[e] = sum over slots of partial[slot][e], e in [0, V*H), accumulated in fp64.
-// One block per 64 consecutive elements; its 8 waves stride over the slots with coalesced 256-byte
-// reads and meet in LDS.
+// out[e] = sum over slots of partial[slot][e], e in [0, V*H), accumulated in fp64, in a fixed order.
+// One block per (64 consecutive elements, slot group): its 8 waves stride over the group's slots with coalesced 256-byte
+// reads and meet in LDS.  With many slots a single level leaves the chip idle (V*H / 64 = 16 .. 40 workgroups streaming
+// megabytes: 57 us at the shipped ACT shape), so the slots are first folded into kRedGroups partial rows by
+// V*H / 64 x kRedGroups workgroups and those rows are summed by a second, tiny launch.
 constexpr int kRedWaves = 8;
+constexpr int kRedGroups = 16;
 __global__ __launch_bounds__(64 * kRedWaves) void pcm_sa_reduce_kernel(int nslots, int VH, const float *__restrict__ partial,
                                                                          float *__restrict__ out)
 {
     __shared__ double red[kRedWaves][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + lane;
+    const int g = blockIdx.y, ng = gridDim.y;  // slot group: slots g, g + ng, ...
     double acc = 0.0;
     if (e < VH) {
-        for (int s = wave; s < nslots; s += kRedWaves) acc += (double)partial[(size_t)s * VH + e];
+        for (int s = g + wave * ng; s < nslots; s += kRedWaves * ng) acc += (double)partial[(size_t)s * VH + e];
     }
     red[wave][lane] = acc;
     __syncthreads();
@@ -375,7 +379,7 @@ __global__ __launch_bounds__(64 * kRedWaves) void pcm_sa_reduce_kernel(int nslot
         double t = 0.0;
 #pragma unroll
         for (int w = 0; w < kRedWaves; ++w) t += red[w][lane];
-        out[e] = (float)t;
+        out[(size_t)g * VH + e] = (float)t;
     }
 }
 
@@ -849,6 +853,23 @@ extern "C" int pcm_sa_fused_bwd1_lds_channels(int H, int n_max)
 
 #define PCM_SA_ST ((hipStream_t)stream)
 
+// partial (nslots, VH) -> out (VH).  Above 256 slots: two levels through `scratch` (kRedGroups * VH floats; callers pass the
+// tail of the partial-row buffer, which they allocate pcm_sa_fused_reduce_scratch_rows() rows longer than the slots need).
+extern "C" int pcm_sa_fused_reduce_scratch_rows(void) { return kRedGroups; }
+
+extern "C" int pcm_sa_reduce_rows_hip(int nslots, int VH, const float *partial, float *scratch, float *out, void *stream)
+{
+    if (nslots <= 0 || VH <= 0) return PCM_ERR_BAD_ARG;
+    const int bx = (VH + 63) / 64;
+    if (nslots <= 256 || scratch == nullptr) {
+        hipLaunchKernelGGL(pcm_sa_reduce_kernel, dim3(bx, 1), dim3(64 * kRedWaves), 0, PCM_SA_ST, nslots, VH, partial, out);
+    } else {
+        hipLaunchKernelGGL(pcm_sa_reduce_kernel, dim3(bx, kRedGroups), dim3(64 * kRedWaves), 0, PCM_SA_ST, nslots, VH, partial, scratch);
+        hipLaunchKernelGGL(pcm_sa_reduce_kernel, dim3(bx, 1), dim3(64 * kRedWaves), 0, PCM_SA_ST, kRedGroups, VH, scratch, out);
+    }
+    return PCM_LAUNCH_STATUS();
+}
+
 extern "C" int pcm_sa_fused_forward_hip(int m, int K, int H, int gf_is_bf16, const void *Gf, const void *ent,
                                         const float *Wp, const float *gamma, const float *beta, float eps,
                                         float momentum, float *running_mean, float *running_var, float *sel,
@@ -877,8 +898,7 @@ extern "C" int pcm_sa_fused_forward_hip(int m, int K, int H, int gf_is_bf16, con
 #undef PCM_FWD
     int rc = PCM_LAUNCH_STATUS();
     if (rc) return rc;
-    if (stage_mask & 2)
-        hipLaunchKernelGGL(pcm_sa_reduce_kernel, dim3((2 * H + 63) / 64), dim3(64 * kRedWaves), 0, PCM_SA_ST, nslots, 2 * H, partial, sums);
+    if (stage_mask & 2) pcm_sa_reduce_rows_hip(nslots, 2 * H, partial, partial + (size_t)nslots * 2 * H, sums, stream);
     if (stage_mask & 4) {
         if (gf_is_bf16)
             hipLaunchKernelGGL(pcm_sa_stats_kernel<__hip_bfloat16>, dim3((H + kBlock - 1) / kBlock), dim3(kBlock), 0, PCM_SA_ST, H,
@@ -987,7 +1007,7 @@ extern "C" int pcm_sa_fused_backward_hip(int m, int n, int K, int H, int gf_is_b
                 hipLaunchKernelGGL((pcm_sa_bwd1_kernel<1>), dim3(grid), dim3(kBlock), smem, PCM_SA_ST, m, K, H, mp.lpq, mp.qpw, mp.nchunk,
                                    dz, sel, asel, stat, (const float4 *)ent, D, partial);
         }
-        if (stage_mask & 4) hipLaunchKernelGGL(pcm_sa_reduce_kernel, dim3((5 * H + 63) / 64), dim3(64 * kRedWaves), 0, PCM_SA_ST, nslots, 5 * H, partial, red1);
+        if (stage_mask & 4) pcm_sa_reduce_rows_hip(nslots, 5 * H, partial, partial + (size_t)nslots * 5 * H, red1, stream);
     }
     {
         const RowMap mp = row_map(H, gf_is_bf16, 1);
@@ -1006,7 +1026,7 @@ extern "C" int pcm_sa_fused_backward_hip(int m, int n, int K, int H, int gf_is_b
             if (mp.vec == 4) PCM_B2(float, 4); else PCM_B2(float, 1);
         }
 #undef PCM_B2
-        if (stage_mask & 16) hipLaunchKernelGGL(pcm_sa_reduce_kernel, dim3((3 * H + 63) / 64), dim3(64 * kRedWaves), 0, PCM_SA_ST, nslots, 3 * H, partial, red2);
+        if (stage_mask & 16) pcm_sa_reduce_rows_hip(nslots, 3 * H, partial, partial + (size_t)nslots * 3 * H, red2, stream);
     }
     if (stage_mask & 32) hipLaunchKernelGGL(pcm_sa_bwd3_kernel, dim3((H + kBlock - 1) / kBlock), dim3(kBlock), 0, PCM_SA_ST, H, count, stat, red1, redn,
                        red2, RM, Wp, dWp, dgamma, dbeta);

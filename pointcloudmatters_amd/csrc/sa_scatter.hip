@@ -121,26 +121,33 @@ __global__ __launch_bounds__(kBlock) void pcm_sa_bwd1_pack_kernel(int m, int K, 
     for (int i = blockIdx.x * kWaves + wave; i < m; i += gridDim.x * kWaves) {
         tab[lane] = 0;
         wave_lds_sync();
-        float delta[TMAX];
+        // three phases so that the memory round trips overlap: every row load first, then every record gather, then the
+        // sums and the run positions (a per-channel chain of load -> gather -> atomic cost ~12 us per query)
+        float delta[TMAX], ssv[TMAX];
         int slot[TMAX], pos[TMAX];
         const size_t row = (size_t)i * H;
 #pragma unroll
         for (int t = 0; t < TMAX; ++t) {
             const int c = lane + 64 * t;
-            delta[t] = 0.f, slot[t] = 0, pos[t] = -1;
-            if (c < H) {
-                const float ss = sel[row + c], dd = dz[row + c];
-                slot[t] = asel[row + c];
-                const float d = (a[t] * ss + bb[t]) > 0.f ? dd : 0.f;
-                if (d != 0.f) {
-                    const float4 e = ent[(size_t)i * K + slot[t]];
-                    acc[0][t] += d;
-                    acc[1][t] += d * ((ss - mean[t]) * invstd[t]);
-                    if (__float_as_int(e.x) >= 0) {
-                        acc[2][t] += d * e.y, acc[3][t] += d * e.z, acc[4][t] += d * e.w;
-                        delta[t] = d;
-                        pos[t] = atomicAdd(&tab[slot[t]], 1);  // integer LDS atomic: position inside the run (any order: channels of a run are distinct)
-                    }
+            const bool on = c < H;
+            ssv[t] = on ? sel[row + c] : 0.f;
+            const float dd = on ? dz[row + c] : 0.f;
+            slot[t] = on ? (int)asel[row + c] : 0;
+            delta[t] = (on && (a[t] * ssv[t] + bb[t]) > 0.f) ? dd : 0.f;
+        }
+        float4 rec[TMAX];
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) rec[t] = ent[(size_t)i * K + slot[t]];  // the K records of a query are 256 contiguous bytes: cache hits
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) {
+            pos[t] = -1;
+            const float d = delta[t];
+            if (d != 0.f) {
+                acc[0][t] += d;
+                acc[1][t] += d * ((ssv[t] - mean[t]) * invstd[t]);
+                if (__float_as_int(rec[t].x) >= 0) {
+                    acc[2][t] += d * rec[t].y, acc[3][t] += d * rec[t].z, acc[4][t] += d * rec[t].w;
+                    pos[t] = atomicAdd(&tab[slot[t]], 1);  // integer LDS atomic: position inside the run (any order: channels of a run are distinct)
                 }
             }
         }
@@ -254,25 +261,6 @@ __global__ __launch_bounds__(kBlock) void pcm_sa_bwd1_gather_kernel(int n, int K
     }
 }
 
-__global__ __launch_bounds__(512) void pcm_sa_reduce5_kernel(int nslots, int VH, const float *__restrict__ partial, float *__restrict__ out)
-{
-    // out[e] = sum over slots of partial[slot][e] in fp64, slots strided over the 8 waves in a fixed order
-    __shared__ double red[8][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int e = blockIdx.x * 64 + lane;
-    double acc = 0.0;
-    if (e < VH)
-        for (int s = wave; s < nslots; s += 8) acc += (double)partial[(size_t)s * VH + e];
-    red[wave][lane] = acc;
-    __syncthreads();
-    if (wave == 0 && e < VH) {
-        double t = 0.0;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) t += red[w][lane];
-        out[e] = (float)t;
-    }
-}
-
 inline size_t pack_wave_bytes(int H) { return 64 * sizeof(int) + (size_t)H * 4 + (((size_t)H * 2 + 15) & ~(size_t)15); }
 
 inline int pack_grid(int m)
@@ -302,6 +290,7 @@ extern "C" long pcm_sa_index_det_scratch_ints(int n)
 }
 
 extern "C" int pcm_sa_index_entries_hip(int m, int K, const float *p, const float *q, const int *idx, void *ent, void *stream);
+extern "C" int pcm_sa_reduce_rows_hip(int nslots, int VH, const float *partial, float *scratch, float *out, void *stream);
 
 extern "C" int pcm_sa_index_det_hip(int m, int K, int n, const float *p, const float *q, const int *idx, void *ent, int *csr,
                                     int *scratch, float *cnt, float *S, float *RM, void *stream)
@@ -375,7 +364,6 @@ extern "C" int pcm_sa_bwd1_det_hip(int m, int n, int K, int H, const float *dz, 
         if (G == 64) PCM_GATHER(64); else if (G == 32) PCM_GATHER(32); else PCM_GATHER(16);
 #undef PCM_GATHER
     }
-    if (stage_mask & 4)
-        hipLaunchKernelGGL(pcm_sa_reduce5_kernel, dim3((5 * H + 63) / 64), dim3(512), 0, st, grid, 5 * H, partial, red1);
+    if (stage_mask & 4) return pcm_sa_reduce_rows_hip(grid, 5 * H, partial, partial + (size_t)grid * 5 * H, red1, stream);
     return PCM_LAUNCH_STATUS();
 }

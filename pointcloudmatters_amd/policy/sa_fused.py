@@ -68,7 +68,7 @@ def index_stats(p, q, knn_idx, o32=None, no32=None, n_max=0):
 
 def _slots(L, m, n, H, bf, K, b):
     return max(L.pcm_sa_fused_slots(m, H, bf, K), L.pcm_sa_fused_slots(m, H, 0, 1), L.pcm_sa_fused_slots(n, H, bf, 1),
-               L.pcm_sa_bwd1_det_slots(m), b, 1)
+               L.pcm_sa_bwd1_det_slots(m), b, 1) + L.pcm_sa_fused_reduce_scratch_rows()  # + second-level rows of the reductions
 
 
 class _SAFused(Function):
@@ -192,7 +192,7 @@ def _sa_fused_eval(owner, gf, ent, wp):
     m, K = ent.shape[:2]
     dev = gf.device
     bf = 1 if gf.dtype == torch.bfloat16 else 0
-    slots = L.pcm_sa_fused_slots(m, H, bf, K)
+    slots = L.pcm_sa_fused_slots(m, H, bf, K) + L.pcm_sa_fused_reduce_scratch_rows()
     with torch.cuda.device(dev):
         f32 = dict(dtype=torch.float32, device=dev)
         invstd = torch.rsqrt(bn.running_var.float() + bn.eps)
