@@ -127,7 +127,7 @@ __device__ __forceinline__ bf8 p_frag(const float (&p)[16], int j8)  // register
 
 // ------------------------------------------------------------------------------------------------ forward
 // grid (B*H, ceil(L / 128))
-__global__ __launch_bounds__(WG) void pcm_attn_flash_fwd_kernel(AttnParams P, u16 *__restrict__ out, float *__restrict__ lse)
+__global__ __launch_bounds__(WG, 2) void pcm_attn_flash_fwd_kernel(AttnParams P, u16 *__restrict__ out, float *__restrict__ lse)
 {
     __shared__ __attribute__((aligned(16))) u16 smem[4 * TILE];  // K[2] | V[2]; the epilogue stages O in it
     const int bh = blockIdx.x, b = bh / P.H, h = bh % P.H;
@@ -174,10 +174,11 @@ __global__ __launch_bounds__(WG) void pcm_attn_flash_fwd_kernel(AttnParams P, u1
             s1 = PCM_MFMA16(lds_bf8(Kt + lo.row[sl] + 32 * HD), qf[sl], s1);
         }
         const bool edge = (kt + 1) * TR > P.S || mask != nullptr;
+        // the running maximum is kept on the RAW scores (scale > 0 commutes with max): the scale is folded into the
+        // exponent's FMA, exp2(s * scale2 - m * scale2), instead of costing one multiply per score
         float tmax = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s0[r] *= scale2, s1[r] *= scale2;
             if (edge) {
                 const int key = kt * TR + crow(r, lane);
                 const bool v0 = key < P.S && !(mask != nullptr && mask[key] != 0);
@@ -190,16 +191,17 @@ __global__ __launch_bounds__(WG) void pcm_attn_flash_fwd_kernel(AttnParams P, u1
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
         const float m_new = fmaxf(m, tmax);
         const bool dead = m_new == -INFINITY;  // nothing visible yet for this query
+        const float mneg = dead ? 0.f : -m_new * scale2;
         float p0[16], p1[16], psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            p0[r] = dead ? 0.f : __builtin_amdgcn_exp2f(s0[r] - m_new);
-            p1[r] = dead ? 0.f : __builtin_amdgcn_exp2f(s1[r] - m_new);
+            p0[r] = dead ? 0.f : __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], scale2, mneg));
+            p1[r] = dead ? 0.f : __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], scale2, mneg));
             psum += p0[r] + p1[r];
         }
         psum += __shfl_xor(psum, 32);
         if (__any(m_new != m)) {  // the running maximum moves in the first tiles only
-            const float alpha = (dead || m == -INFINITY) ? (dead ? 1.f : 0.f) : __builtin_amdgcn_exp2f(m - m_new);
+            const float alpha = (dead || m == -INFINITY) ? (dead ? 1.f : 0.f) : __builtin_amdgcn_exp2f((m - m_new) * scale2);
             lsum *= alpha;
 #pragma unroll
             for (int r = 0; r < 16; ++r) o0[r] *= alpha, o1[r] *= alpha;
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(WG) void pcm_attn_flash_fwd_kernel(AttnParams P, u1
     }
     const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
     store_acc_rows(smem + w * RW * OS, o0, o1, inv, out + (long)b * P.L * (P.H * HD) + h * HD, (long)P.H * HD, q0, P.L, lane);
-    if (lane < 32 && qok) lse[(long)bh * P.L + qi] = lsum > 0.f ? m * 0.693147180559945f + logf(lsum) : INFINITY;
+    if (lane < 32 && qok) lse[(long)bh * P.L + qi] = lsum > 0.f ? m * P.scale + logf(lsum) : INFINITY;  // m: raw-score maximum
 }
 
 // ------------------------------------------------------------------------------------------------ backward
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(WG) void pcm_attn_flash_prep_kernel(int B, int H, i
 }
 
 // dQ: grid (B*H, ceil(L / 128)); streams K / V tiles
-__global__ __launch_bounds__(WG) void pcm_attn_flash_bwd_dq_kernel(AttnParams P, const u16 *__restrict__ dout, const float *__restrict__ lse,
+__global__ __launch_bounds__(WG, 2) void pcm_attn_flash_bwd_dq_kernel(AttnParams P, const u16 *__restrict__ dout, const float *__restrict__ lse,
                                                                    const float *__restrict__ delta, u16 *__restrict__ dq, long dq_bs,
                                                                    long dq_ls)
 {
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(WG) void pcm_attn_flash_bwd_dq_kernel(AttnParams P,
             float ds[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float pr = __builtin_amdgcn_exp2f(s[r] * scale2 - lq2);
+                float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], scale2, -lq2));
                 if (edge) {
                     const int key = kt * TR + 32 * kh + crow(r, lane);
                     const bool vis = key < P.S && !(mask != nullptr && mask[key] != 0);
@@ -438,7 +440,7 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_flash_bwd_dkv_kernel(AttnParam
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int r = 4 * g + i;
-                    const float pr = kok ? __builtin_amdgcn_exp2f(s[r] * scale2 - lv[i]) : 0.f;
+                    const float pr = kok ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], scale2, -lv[i])) : 0.f;
                     float dpv = dp[r];
                     pd[r] = pr;
                     if (dc.on) {

@@ -64,7 +64,7 @@ __device__ __forceinline__ int crow(int r, int lane)  // accumulator register r 
 
 // dropout on the attention weights.  One 32-bit hash serves the PAIR of adjacent keys (2j, 2j+1) of a query:
 //   h = mixp(rowbase(b, h, q) + j * C);  keep(2j) = (h & 0xFFFF) >= thr16,  keep(2j+1) = (h >> 16) >= thr16,
-// thr16 = round(p * 65536) (|p_eff - p| < 8e-6).  mixp uses 24-bit multiplies (full-rate v_mul_u32_u24; the 32-bit
+// thr16 = round(p * 65536) (|p_eff - p| < 8e-6).  mixp uses a 24-bit multiply (full-rate v_mul_u32_u24; the 32-bit
 // integer multiply is quarter rate) -- the mask generator used to cost as much VALU time as the softmax itself.
 __device__ __forceinline__ uint32_t attn_rowbase(uint64_t seed, uint32_t site, uint32_t rowid)
 {
@@ -73,11 +73,12 @@ __device__ __forceinline__ uint32_t attn_rowbase(uint64_t seed, uint32_t site, u
 }
 __device__ __forceinline__ uint32_t mixp(uint32_t x)
 {
-    x ^= x >> 15;
-    x = __umul24(x, 0xD35A2Du) ^ (x >> 9);   // 24-bit multiplicands: low 24 bits of x, 24-bit odd constant
-    x ^= x >> 13;
-    x = __umul24(x, 0x6B4F29u) + (x >> 11);
+    // one xorshift-multiply-xorshift round on top of the Weyl sequence of attn_pair_bits (5 VALU operations; the mask
+    // generator used to cost more VALU time than the softmax).  Keep rate, row / column means and the correlations between
+    // adjacent keys, adjacent pairs and adjacent rows are at the noise level of i.i.d. bits (tests/test_small_attn_gpu.py).
     x ^= x >> 16;
+    x = __umul24(x, 0xD35A2Du);  // 24-bit multiplicands: low 24 bits of x, 24-bit odd constant
+    x ^= x >> 12;
     return x;
 }
 __device__ __forceinline__ uint32_t attn_pair_bits(uint32_t rowbase, uint32_t key_pair)

@@ -127,3 +127,43 @@ def test_gradient_slabs_are_cut_from_the_decayed_group_only():
     assert plan_slabs([[(50, 10)], [(0, 50), (60, 4)]], 50, 64) == [(0, 0), (0, 64)]
     # a layout that is NOT in backward order loses the overlap, never the correctness: everything goes with the last stage
     assert plan_slabs([[(500, 100)], [(0, 500)]], 600, 600) == [(0, 0), (0, 600)]
+
+
+def test_attention_dropout_hash_statistics():
+    """The attention-dropout mask generator (csrc/pcm_attn.hpp: Weyl sequence over key pairs + one xorshift-multiply-xorshift
+    round, 16-bit thresholds) restated in numpy: keep rate, row / column means and the correlations between adjacent keys,
+    adjacent pairs and adjacent rows stay at the noise level of independent bits."""
+    import numpy as np
+
+    M32 = 0xFFFFFFFF
+
+    def mix32(h):
+        h = h ^ (h >> 16)
+        h = (h * 0x7FEB352D) & M32
+        h = h ^ (h >> 15)
+        h = (h * 0x846CA68B) & M32
+        return h ^ (h >> 16)
+
+    def mixp(x):
+        x = x ^ (x >> 16)
+        x = ((x & 0xFFFFFF) * 0xD35A2D) & M32
+        return x ^ (x >> 12)
+
+    rows, S = 2048, 2048
+    for seed, p in ((1, 0.1), (12345678901234, 0.1), (2 ** 40 + 77, 0.5)):
+        rowid = np.arange(rows, dtype=np.int64)
+        k = (seed & M32) ^ (((seed >> 32) * 0x9E3779B9) & M32) ^ ((3 * 0x85EBCA6B) & M32)
+        rb = mix32((k ^ rowid) & M32)
+        key = np.arange(S, dtype=np.int64)
+        bits = mixp((rb[:, None] + (key >> 1)[None, :] * 0x9E3779B1) & M32)
+        half = np.where((key & 1)[None, :] == 1, bits >> 16, bits & 0xFFFF)
+        m = (half >= int(p * 65536 + 0.5)).astype(np.float64)
+        x = m - m.mean()
+        v = x.var()
+        assert abs(m.mean() - (1 - p)) < 1.5e-3
+        for lag_keys, lag_rows in ((1, 0), (2, 0), (0, 1), (0, 2), (1, 1)):
+            a = x[lag_rows:, lag_keys:]
+            b = x[: rows - lag_rows, : S - lag_keys]
+            assert abs((a * b).mean() / v) < 3e-3, (seed, p, lag_keys, lag_rows)
+        sd = (p * (1 - p) / S) ** 0.5
+        assert np.abs(m.mean(1) - (1 - p)).max() < 5.5 * sd and np.abs(m.mean(0) - (1 - p)).max() < 5.5 * (p * (1 - p) / rows) ** 0.5

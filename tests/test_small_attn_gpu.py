@@ -19,12 +19,10 @@ def mix32(h):
 
 
 def mixp(x):
-    """mixp of csrc/attn_small.hip: 24-bit multiplies (v_mul_u32_u24 keeps the low 32 bits of the 48-bit product)."""
-    x = x ^ (x >> 15)
-    x = ((((x & 0xFFFFFF) * 0xD35A2D) & M32) ^ (x >> 9)) & M32
-    x = x ^ (x >> 13)
-    x = ((((x & 0xFFFFFF) * 0x6B4F29) & M32) + (x >> 11)) & M32
-    return x ^ (x >> 16)
+    """mixp of csrc/pcm_attn.hpp: xorshift, one 24-bit multiply (v_mul_u32_u24 keeps the low 32 bits of the product), xorshift."""
+    x = x ^ (x >> 16)
+    x = ((x & 0xFFFFFF) * 0xD35A2D) & M32
+    return x ^ (x >> 12)
 
 
 def keep_mask(seed, site, B, H, L, S, p):
