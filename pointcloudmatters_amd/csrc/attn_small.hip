@@ -34,10 +34,15 @@ constexpr int NW = 4;     // waves per workgroup; they split the streamed dimens
 constexpr int WG = 64 * NW;
 constexpr int TILE_U16 = KT * RS;
 
-__device__ __forceinline__ s4 lds_col4(const u16 *p)  // 4 elements of one column, consecutive rows of a row-major tile
+// 4 elements of one column (rows r .. r+3 of a row-major tile), `p` = &tile[r][lane & 31 (+32)]: ONE ds_read_b64_tr_b16.
+// Inside each 16-lane group lane i (= lane & 15) supplies the address of 4 contiguous elements of row r + i/4 at columns
+// 4 (i % 4) .. +3 of the group's 16 columns; the hardware hands lane i the column i of that 4 x 16 block (semantics pinned
+// by tools/mb/tr_probe.hip).  It replaces four 2-byte reads and their packing.
+typedef s4 __attribute__((address_space(3))) * lds_s4_ptr;
+__device__ __forceinline__ s4 lds_col4(const u16 *p)
 {
-    s4 r = {(short)p[0], (short)p[RS], (short)p[2 * RS], (short)p[3 * RS]};
-    return r;
+    const int i = threadIdx.x & 15;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(p - i + (i >> 2) * RS + 4 * (i & 3)));
 }
 // one (32 x 64) bf16 tile = 256 chunks of 16 B, 4 per lane of ONE wave: chunk c = lane + 64*i -> row c>>3, cols (c&7)*8..
 struct TileRegs {
