@@ -21,7 +21,61 @@ def _close(a, b, tol=2e-4):
     assert (a - b).abs().max().item() <= tol * (b.abs().max().item() + 1e-12) + 1e-6
 
 
-def test_pointnet2_encoder_and_fp_match_cpu_oracle_composition():
+class TieMask:
+    """The max over the K neighbours of a set-abstraction stage is a SELECTION: where the two best candidates of a (query,
+    channel) pair are closer than fp32 re-association noise, the reference op order and the fused algebra may legitimately
+    pick different neighbours (same token value, the gradient lands on another row).  In a multi-stage network a handful of
+    such flips moves every upstream gradient by ~1e-3 relative, which would hide real errors behind a loose tolerance.  This
+    helper finds those pairs in fp64 during the reference (CPU) run -- for EVERY set-abstraction call of the composition --
+    and zeroes the upstream gradient exactly there in both runs, as tests/test_sa_fused_gpu.py does for one layer; everything
+    else (including exact ties, which both sides break towards the first neighbour) is then compared at 1e-4."""
+
+    def __init__(self):
+        self.masks, self.cursor, self.recording = [], 0, True
+
+    def install(self, monkeypatch):
+        from pointcloudmatters_amd.policy import pointnet2, sa_layer
+
+        real = sa_layer.set_abstraction
+        outer = self
+
+        def wrapped(owner, pointops, p, x, o, n_o, impl="reference", pre=None):
+            if pre is None:
+                pre = sa_layer.sample_and_query(owner, pointops, p, o, n_o)
+            n_p, tokens, idx = real(owner, pointops, p, x, o, n_o, impl=impl, pre=pre)
+            if outer.recording:
+                with torch.no_grad():
+                    k = pre["knn_idx"].shape[1]
+                    grouped, _ = pointops.knn_query_and_group(x.detach().float(), p, offset=o, new_xyz=pre["n_p"], new_offset=n_o,
+                                                              idx=pre["knn_idx"], nsample=k, with_xyz=True)
+                    y = grouped.double() @ owner.linear.weight.detach().double().t()  # (m, K, H)
+                    scale = y.abs().amax(dim=1)
+                    if k > 1:
+                        hi, lo = y.topk(2, dim=1).values, (-y).topk(2, dim=1).values
+                        gap = torch.where(owner.bn.weight.detach() >= 0, hi[:, 0] - hi[:, 1], lo[:, 0] - lo[:, 1])
+                        amb = (gap > 0) & (gap < 2e-5 * scale + 1e-7)
+                    else:
+                        amb = torch.zeros_like(scale, dtype=torch.bool)
+                    assert amb.float().mean().item() < 2e-3
+                outer.masks.append(amb.cpu())
+            else:
+                amb = outer.masks[outer.cursor]
+                outer.cursor += 1
+            if tokens.requires_grad:
+                keep = (~amb).to(tokens.device)
+                tokens.register_hook(lambda g, keep=keep: g * keep)
+            return n_p, tokens, idx
+
+        for name in ("sample_and_query", "prefetch_sampling", "install_static", "load_static"):
+            setattr(wrapped, name, getattr(real, name))
+        monkeypatch.setattr(pointnet2, "set_abstraction", wrapped)
+        return self
+
+    def replay(self):
+        self.recording, self.cursor = False, 0
+
+
+def test_pointnet2_encoder_and_fp_match_cpu_oracle_composition(monkeypatch):
     from oracle import pointops_cpu
     from pointcloudmatters_amd import pointops
     from pointcloudmatters_amd.policy.pointnet2 import FeaturePropagation, PointNet2Encoder
@@ -34,23 +88,27 @@ def test_pointnet2_encoder_and_fp_match_cpu_oracle_composition():
     gpu_fp = FeaturePropagation(64, 32, 24, pointops=pointops)
     gpu.load_state_dict(cpu.state_dict()), gpu_fp.load_state_dict(cpu_fp.state_dict())
     gpu, gpu_fp = gpu.to(DEV), gpu_fp.to(DEV)
+    ties = TieMask().install(monkeypatch)
     outs = []
     for enc, fp, dev in ((cpu, cpu_fp, "cpu"), (gpu, gpu_fp, DEV)):
         levels = enc(_batch(dev), return_all=True)
         dense = fp(levels[1], levels[2])  # propagate the coarsest features back onto stage-1 points
         (levels[2][1].square().mean() + dense.square().mean()).backward()
         outs.append((levels, dense))
+        if dev == "cpu":
+            ties.replay()
+    assert ties.cursor == len(ties.masks) == 2
     (lc, dc), (lg, dg) = outs
     for (pc, xc, oc), (pg, xg, og) in zip(lc, lg):
         assert torch.equal(pc, pg.cpu()) and oc.tolist() == og.tolist()  # FPS picks are bit-exact
-        _close(xg.detach().float().cpu(), xc.detach())
-    _close(dg.detach().cpu(), dc.detach())
+        _close(xg.detach().float().cpu(), xc.detach(), 1e-4)
+    _close(dg.detach().cpu(), dc.detach(), 1e-4)
     gc, gg = _grads(cpu), _grads(gpu)
     assert gc.keys() == gg.keys()
     for k in gc:
-        _close(gg[k], gc[k], 5e-4)
+        _close(gg[k], gc[k], 1e-4)
     for k, v in _grads(cpu_fp).items():
-        _close(_grads(gpu_fp)[k], v, 5e-4)
+        _close(_grads(gpu_fp)[k], v, 1e-4)
 
 
 def test_patch_tokenizer_shapes_and_parity():
@@ -66,19 +124,21 @@ def test_patch_tokenizer_shapes_and_parity():
     tc, pc = cpu(_batch("cpu"))
     tg, pg = gpu(_batch(DEV))
     assert tg.shape == (3, 16, 48) and pg.shape == (3, 16, 48)
-    _close(tg.detach().cpu(), tc.detach())
+    _close(tg.detach().cpu(), tc.detach(), 1e-4)
     _close(pg.cpu(), pc, 1e-5)
 
 
 @pytest.mark.parametrize("n_points", [2048, 4096])
-def test_msg_and_pointnext_match_cpu_oracle_composition_at_config_sizes(n_points):
+def test_msg_and_pointnext_match_cpu_oracle_composition_at_config_sizes(n_points, monkeypatch):
     """PointNet++ MSG stage and the PointNeXt backbone (InvResMLP blocks) at the cloud sizes of BASELINE configs[3] / [4]:
-    fused HIP composition == the same modules on the CPU with the oracle's pointops, forward and backward."""
+    fused HIP composition == the same modules on the CPU with the oracle's pointops, forward and backward, at 1e-4 with the
+    fp64-identified near-tie selections masked out of the gradient (TieMask)."""
     from oracle import pointops_cpu
     from pointcloudmatters_amd import pointops
     from pointcloudmatters_amd.bc import make_act_batch
     from pointcloudmatters_amd.policy.pointnet2 import PointNeXtBackbone, SAStageMSG
 
+    ties = TieMask().install(monkeypatch)
     torch.manual_seed(2)
     scales = ((16, 0.06, 32), (32, None, 64))
     cpu_msg = SAStageMSG(32, n_points // 4, scales, pointops=pointops_cpu, sa_impl="reference")
@@ -94,18 +154,21 @@ def test_msg_and_pointnext_match_cpu_oracle_composition_at_config_sizes(n_points
         n_p, tok, n_o = msg(pcd["coord"], x, pcd["offset"])
         tok.square().mean().backward()
         outs.append((x.detach().float().cpu(), n_p.cpu(), tok.detach().float().cpu()))
+        if dev == "cpu":
+            ties.replay()  # the GPU run applies the masks the reference run recorded
+    assert ties.cursor == len(ties.masks) > 2  # every set-abstraction call of the composition was masked in both runs
     (xc, pc, tc), (xg, pg, tg) = outs
     assert torch.equal(pc, pg)  # FPS picks bit-exact
-    _close(xg, xc, 5e-4)
-    _close(tg, tc, 1e-3)
+    _close(xg, xc, 1e-4)
+    _close(tg, tc, 1e-4)
     for cm, gm in ((cpu_nx, gpu_nx), (cpu_msg, gpu_msg)):
         gc, gg = _grads(cm), _grads(gm)
         assert gc.keys() == gg.keys()
         for k in gc:
-            assert (gg[k] - gc[k]).norm() <= 5e-3 * gc[k].norm() + 1e-7, k
+            assert (gg[k] - gc[k]).norm() <= 1e-4 * gc[k].norm() + 1e-7, (k, ((gg[k] - gc[k]).norm() / gc[k].norm()).item())
 
 
-def test_patchbert_obs_encoder_matches_cpu_oracle_composition():
+def test_patchbert_obs_encoder_matches_cpu_oracle_composition(monkeypatch):
     from oracle import pointops_cpu
     from pointcloudmatters_amd import pointops
     from pointcloudmatters_amd.bc import make_act_batch
@@ -119,14 +182,16 @@ def test_patchbert_obs_encoder_matches_cpu_oracle_composition():
     gpu.load_state_dict(cpu.state_dict())
     gpu = gpu.to(DEV)
     q = torch.randn(2, 9)
+    ties = TieMask().install(monkeypatch)
     oc = cpu({"pcds": make_act_batch(2, 4096, seed=34, ragged=True)["pcds"], "qpos": q})
+    ties.replay()
     og = gpu({"pcds": make_act_batch(2, 4096, seed=34, ragged=True, device=DEV)["pcds"], "qpos": q.to(DEV)})
-    assert og.shape == (2, 48 + 9)
-    _close(og.detach().cpu(), oc.detach(), 1e-3)
+    assert og.shape == (2, 48 + 9) and ties.cursor == len(ties.masks) >= 1
+    _close(og.detach().cpu(), oc.detach(), 1e-4)
     oc.square().mean().backward(), og.square().mean().backward()
     gc, gg = _grads(cpu), _grads(gpu)
     for k in gc:
-        assert (gg[k] - gc[k]).norm() <= 5e-3 * gc[k].norm() + 1e-7, k
+        assert (gg[k] - gc[k]).norm() <= 1e-4 * gc[k].norm() + 1e-7, (k, ((gg[k] - gc[k]).norm() / gc[k].norm()).item())
 
 
 @pytest.mark.parametrize("workload", ["C4N", "C5B"])
@@ -139,13 +204,16 @@ def test_hierarchical_workloads_train(workload):
     wl = WORKLOADS[workload]
     torch.manual_seed(0)
     if wl["policy"] == "dp":
+        # the workload's own shapes (16 samples x 2 clouds x 4096 points -> 128 patches); only the U-Net is narrowed
         pol = build_dp_policy(pcd_npoints=wl["pcd_npoints"], sa_impl="fused", obs_encoder=wl["obs_encoder"], down_dims=(64, 128, 256)).to(DEV)
         tr = BCTrainer(pol, total_steps=100, precision="bf16", device=DEV, mode="graph", optim=dict(DP_OPTIM, lr=1e-3))
-        batch = make_dp_batch(4, 1024, seed=2, device=DEV)
+        batch = make_dp_batch(wl["batch"], wl["n_points"], seed=2, device=DEV)
     else:
-        pol = build_act_policy(pcd_npoints=256, sa_impl="fused", backbone=wl["backbone"], num_encoder_layers=1, num_decoder_layers=2).to(DEV)
+        # the workload's own shapes (8 clouds x 2048 points -> 1024 tokens); the transformer depth is cut to keep the test short
+        pol = build_act_policy(pcd_npoints=wl["pcd_npoints"], sa_impl="fused", backbone=wl["backbone"], num_encoder_layers=1,
+                               num_decoder_layers=2).to(DEV)
         tr = BCTrainer(pol, total_steps=100, precision="bf16", device=DEV, mode="graph", optim=dict(accumulate_grad_batches=1, lr=2e-4))
-        batch = make_act_batch(2, 512, seed=2, device=DEV)
+        batch = make_act_batch(wl["batch"], wl["n_points"], seed=2, device=DEV)
     first = None
     for i in range(20):
         tr.training_step(clone_batch(batch))
