@@ -675,18 +675,25 @@ def cpu_baseline(wl, steps, threads=16):
 
 def run_workload(name, args, device, world, rank, steps, warmup, precision=None, mode="auto", trace_steps=0):
     """Build the policy + trainer of workload `name`, run warm-up + `steps` timed steps."""
-    from pointcloudmatters_amd.bc import (DP_OPTIM, RLBENCH_ACT_MODEL, RLBENCH_ACT_OPTIM, BCTrainer, WORKLOADS, build_act_policy,
-                                          build_dp_policy, build_rlbench_act_policy, clone_batch, make_act_batch, make_dp_batch)
+    from pointcloudmatters_amd.bc import (DP_OPTIM, RLBENCH_ACT_MODEL, RLBENCH_ACT_OPTIM, RLBENCH_DP_MODEL, RLBENCH_DP_OPTIM, BCTrainer,
+                                          WORKLOADS, build_act_policy, build_dp_policy, build_rlbench_act_policy, clone_batch,
+                                          make_act_batch, make_dp_batch)
 
     wl = dict(WORKLOADS[name])
     if precision is not None:
         wl["dtype"] = precision
     sa_impl = "fused" if args.sa_impl == "auto" else args.sa_impl
     torch.manual_seed(1000 + rank)
-    is_dp = wl["policy"] == "dp"
+    is_rlbdp = wl["policy"] == "dp_rlbench"
+    is_dp = wl["policy"] == "dp" or is_rlbdp
     is_rlb = wl["policy"] == "act_rlbench"
     build = build_dp_policy if is_dp else (build_rlbench_act_policy if is_rlb else build_act_policy)
     make_batch = make_dp_batch if is_dp else make_act_batch
+    if is_rlbdp:  # RLBench Diffusion Policy: 11-d action / proprioception, 512-d task embedding as goal, 2 micro-batches per step
+        r = RLBENCH_DP_MODEL
+
+        def make_batch(b, n, **kw):  # noqa: F811
+            return make_dp_batch(b, n, action_dim=r["action_dim"], qpos_dim=r["qpos_dim"], goal_dim=r["goal_dim"], **kw)
     if is_rlb:  # RLBench ACT: 11-d action / proprioception, 512-d task embedding (configs/model/rlbench_act_pcd_model.yaml)
         m = RLBENCH_ACT_MODEL
 
@@ -695,6 +702,8 @@ def run_workload(name, args, device, world, rank, steps, warmup, precision=None,
             out["actions"][..., -2:] = (out["actions"][..., -2:] > 0).float()
             return out
     extra = {} if is_dp else {"dead_decoder_layers": args.dead_decoder_layers}
+    if is_rlbdp:
+        extra.update(action_dim=RLBENCH_DP_MODEL["action_dim"], qpos_dim=RLBENCH_DP_MODEL["qpos_dim"], goal_dim=RLBENCH_DP_MODEL["goal_dim"])
     for opt_key in ("backbone", "obs_encoder"):  # the hierarchical encoders of policy/pointnet2.py (C4N, C5B)
         if opt_key in wl:
             extra[opt_key] = wl[opt_key]
@@ -707,7 +716,8 @@ def run_workload(name, args, device, world, rank, steps, warmup, precision=None,
         mode = "hybrid" if (wl["ragged"] or world > 1) else "graph"
     trainer = BCTrainer(policy, total_steps=max(steps + warmup + trace_steps, 100), precision=wl["dtype"], device=device,
                         distributed=world > 1, mode=mode, external_sampling=not getattr(args, "sampling_in_graph", False),
-                        optim=dict(DP_OPTIM) if is_dp else (dict(RLBENCH_ACT_OPTIM) if is_rlb else dict(accumulate_grad_batches=1)))
+                        optim=dict(RLBENCH_DP_OPTIM) if is_rlbdp else (dict(DP_OPTIM) if is_dp else (
+                            dict(RLBENCH_ACT_OPTIM) if is_rlb else dict(accumulate_grad_batches=1))))
     batches = [make_batch(wl["batch"], wl["n_points"], seed=1000 + rank + 97 * i, ragged=wl["ragged"], device=device)
                for i in range(4)]
 
@@ -819,7 +829,7 @@ def main():
     dt, trainer, step, wl, sa_impl = run_workload(args.workload, args, device, world, rank, args.steps, args.warmup, mode=args.mode,
                                                   trace_steps=8)
     metrics = trainer.metrics()
-    is_dp = wl["policy"] == "dp"
+    is_dp = wl["policy"] in ("dp", "dp_rlbench")
     # extra lines (fp32 run of the same workload, the reference's shipped shape) BEFORE the profiler is attached for the
     # step trace: roctracer keeps slowing host-side launches afterwards, which the host-paced hybrid mode would feel
     extra = None
@@ -865,7 +875,7 @@ def main():
                        "tokens_per_cloud": wl["pcd_npoints"], "parallelism": "dp%d" % world, "sa_impl": sa_impl, "step_mode": trainer.mode,
                        "batchnorm": "sync" if trainer.sync_batchnorm else "per-rank",
                        "gradient_exchange": getattr(trainer, "exchange_description", "one all-reduce after backward") if world > 1 else "single GPU",
-                       "accumulate_grad_batches": 1, "optimizer_step_every_step": True,
+                       "accumulate_grad_batches": trainer.accumulate, "optimizer_step_every_step": trainer.accumulate == 1,
                        "dead_decoder_layers": "n/a" if is_dp else args.dead_decoder_layers},
             "final_loss": round(metrics.get("train/loss", float("nan")), 4),
         }

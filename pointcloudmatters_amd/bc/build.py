@@ -60,6 +60,8 @@ def build_dp_policy(pcd_npoints, pointops=None, sa_impl="reference", overlap_sam
     shape_meta = {"obs": {"pcds": {"shape": [c["in_channels"]], "type": "pcd"},
                           "qpos": {"shape": [c["qpos_dim"]], "type": "low_dim"}},
                   "action": {"shape": [c["action_dim"]]}}
+    if c.get("goal_dim"):  # language goal: rlbench_diffusion_policy_model.yaml:26-28
+        shape_meta["goal"] = {"task_emb": {"shape": [int(c["goal_dim"])]}}
     if obs_encoder == "patchbert":
         from ..policy.pointnet2 import PatchBertObsEncoder
 

@@ -36,6 +36,14 @@ DP_MODEL = dict(
 DP_OPTIM = dict(lr=1e-4, weight_decay=1e-4, betas=(0.9, 0.95), pct_start=0.15, div_factor=100.0, final_div_factor=1000.0,
                 gradient_clip_val=0.5, accumulate_grad_batches=1, filter_bias_and_bn=True)
 
+# RLBench Diffusion Policy: /root/reference/configs/model/rlbench_diffusion_policy_model.yaml:3-28 (AdamW lr 1e-4, wd 0.05, default
+# betas, build_optimizer_v2 -> no decay on biases / norm weights; goal = 512-d task embedding appended to the global
+# condition, diffusion_unet_image_policy.py:58-62,262-266), configs/data/rlbench_diffusion_policy_pcd_dataset.yaml:12-18
+# (chunk_size 16, action_dim 11 = position 3 + 6-D rotation + gripper + collision; qpos has the same width),
+# exp_rlbench_diffusion_policy/rlbench_model/scratch_pointnet_pcd.yaml:9-13 (batch 16, accumulate_grad_batches 2).
+RLBENCH_DP_MODEL = dict(DP_MODEL, action_dim=11, qpos_dim=11, goal_dim=512)
+RLBENCH_DP_OPTIM = dict(DP_OPTIM, weight_decay=0.05, betas=(0.9, 0.999), accumulate_grad_batches=2)
+
 # name -> per-GPU batch, points per cloud, tokens per cloud (pcd_npoints), compute dtype
 WORKLOADS = {
     # BASELINE.json configs[0]: CPU plumbing case
@@ -56,6 +64,9 @@ WORKLOADS = {
     "C5B": dict(policy="dp", batch=16, n_points=4096, pcd_npoints=128, dtype="bf16", ragged=False, obs_encoder="patchbert"),
     # configs[4]-shaped ACT: RLBench multi-view fused cloud (ragged ~4096 points) -> 2048 tokens, ACTRLBenchPCD head
     "RLB": dict(policy="act_rlbench", batch=8, n_points=4096, pcd_npoints=2048, dtype="bf16", ragged=True),
+    # configs[4] as the reference's RLBench Diffusion-Policy experiment really runs it: 512-d task embedding as goal, 11-d
+    # action / proprioception, two micro-batches of 16 per optimizer step, ragged fused clouds (mode="hybrid")
+    "RLBDP": dict(policy="dp_rlbench", batch=16, n_points=4096, pcd_npoints=2048, dtype="bf16", ragged=True),
     # C2 with ragged clouds: the headline shape as real data delivers it (mode="hybrid")
     "C2R": dict(policy="act", batch=8, n_points=1024, pcd_npoints=512, dtype="bf16", ragged=True),
     # C3 with ragged clouds (what GridSamplePCD really delivers): exercises mode="hybrid" for the Diffusion-Policy trainer

@@ -52,18 +52,21 @@ def make_act_batch(batch, n_points, seed=1000, ragged=False, num_queries=100, ac
 
 
 def make_dp_batch(batch, n_points, seed=1000, ragged=False, horizon=16, n_obs_steps=2, action_dim=7, qpos_dim=9,
-                  device="cpu"):
+                  device="cpu", goal_dim=0):
     """Diffusion-Policy batch: B samples, each with n_obs_steps clouds flattened sample-major
     (sparse_tensor_utils.py:74-75 -> b = B*To clouds), qpos window (B, horizon, qpos_dim), action (B, horizon, Da)."""
     clouds = make_act_batch(batch * n_obs_steps, n_points, seed=seed, ragged=ragged, num_queries=1, action_dim=1,
                             qpos_dim=1, goal_cond_dim=0, device=device)["pcds"]
     rng = np.random.default_rng(seed + 1)
     dev = torch.device(device)
-    return {
+    out = {
         "obs": {"pcds": clouds,
                 "qpos": torch.from_numpy(rng.uniform(-1, 1, (batch, horizon, qpos_dim)).astype(np.float32)).to(dev)},
         "action": torch.from_numpy(rng.uniform(-1, 1, (batch, horizon, action_dim)).astype(np.float32)).to(dev),
     }
+    if goal_dim:  # RLBench: a language embedding of the task (rlbench_diffusion_policy_model.yaml:26-28)
+        out["goal"] = {"task_emb": torch.from_numpy(rng.standard_normal((batch, goal_dim)).astype(np.float32)).to(dev)}
+    return out
 
 
 def clone_batch(batch):

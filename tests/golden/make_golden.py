@@ -380,6 +380,64 @@ def golden_dp(ref):
     print("dp_pcd_small.npz: loss", float(loss))
 
 
+def golden_dp_rlbench(ref):
+    """The RLBench Diffusion-Policy composition: as golden_dp, with the 512-d language goal appended to the global condition
+    (diffusion_unet_image_policy.py:58-62,262-266; configs/model/rlbench_diffusion_policy_model.yaml:26-28) and the 11-d
+    action / proprioception of configs/data/rlbench_diffusion_policy_pcd_dataset.yaml:17."""
+    from oracle import pointops_cpu
+    from pointcloudmatters_amd.bc import build_dp_policy, make_dp_batch
+    from pointcloudmatters_amd.policy import PointNet
+
+    pcd_npoints, ad, gd = 32, 11, 512
+    torch.manual_seed(987)
+    ours = build_dp_policy(pcd_npoints=pcd_npoints, pointops=pointops_cpu, sa_impl="reference", action_dim=ad, qpos_dim=ad, goal_dim=gd,
+                           **DP_SMALL)
+    sd = ours.state_dict()
+    shape_meta = {"obs": {"pcds": {"shape": [6], "type": "pcd"}, "qpos": {"shape": [ad], "type": "low_dim"}},
+                  "action": {"shape": [ad]}, "goal": {"task_emb": {"shape": [gd]}}}
+    enc = ref.pcd_enc.PCDObsEncoder(shape_meta=shape_meta, pcd_model=PointNet(in_channels=6, num_classes=24),
+                                    share_pcd_model=True, n_obs_step=2, pcd_nsample=16, pcd_npoints=pcd_npoints,
+                                    pcd_hidden_dim=24, projector_layers=1, projector_channels=[24, 40, 40])
+    enc.load_state_dict({k[len("obs_encoder."):]: v for k, v in sd.items() if k.startswith("obs_encoder.")}, strict=True)
+    unet = ref.unet.ConditionalUnet1D(input_dim=ad, local_cond_dim=None, global_cond_dim=(40 + ad) * 2 + gd,
+                                      diffusion_step_embed_dim=16, down_dims=[16, 32, 64], kernel_size=5, n_groups=8,
+                                      cond_predict_scale=True)
+    unet.load_state_dict({k[len("model."):]: v for k, v in sd.items() if k.startswith("model.")}, strict=True)
+    mg = ref.maskgen.LowdimMaskGenerator(action_dim=ad, obs_dim=0, max_n_obs_steps=2, fix_obs_steps=True, action_visible=False)
+    enc.train(), unet.train()
+    batch = make_dp_batch(3, 150, seed=13, ragged=True, action_dim=ad, qpos_dim=ad, goal_dim=gd)
+    g = torch.Generator().manual_seed(18)
+    noise = torch.randn(3, 16, ad, generator=g)
+    timesteps = torch.tensor([0, 41, 99])
+    qpos, action, task_emb = batch["obs"]["qpos"], batch["action"], batch["goal"]["task_emb"]
+    this_nobs = {"qpos": qpos[:, :2].reshape(-1, ad), "pcds": {k: v.clone() for k, v in batch["obs"]["pcds"].items()}}
+    global_cond = torch.cat([enc(this_nobs).reshape(3, -1), task_emb], dim=-1)  # :262-266
+    mask = mg((3, 16, ad))
+    acp = ours.noise_scheduler.alphas_cumprod[timesteps]  # diffusers absent: our restated schedule (parity unpinned)
+    noisy = acp.sqrt()[:, None, None] * action + (1 - acp).sqrt()[:, None, None] * noise
+    noisy[mask] = action[mask]
+    pred = unet(noisy, timesteps, local_cond=None, global_cond=global_cond)
+    loss = torch.nn.functional.mse_loss(pred, noise, reduction="none") * (~mask).float()
+    loss = loss.reshape(3, -1).mean(1).mean()
+    loss.backward()
+    fx = {"noise": noise.numpy(), "timesteps": timesteps.numpy(), "out.loss": loss.detach().numpy(), "out.pred": pred.detach().numpy(),
+          "out.global_cond": global_cond.detach().numpy(), "in.qpos": qpos.numpy(), "in.action": action.numpy(),
+          "in.task_emb": task_emb.numpy()}
+    for k, v in batch["obs"]["pcds"].items():
+        fx[f"in.pcds.{k}"] = v.numpy()
+    for k, v in sd.items():
+        fx[f"w.{k}"] = v.numpy()
+    g_enc, g_unet = dict(enc.named_parameters()), dict(unet.named_parameters())
+    for k in ("linear.weight", "projector.4.weight", "key_model_map.pcd.conv5.0.weight"):
+        fx[f"grad.obs_encoder.{k}"] = g_enc[k].grad.numpy()
+    for k in ("down_modules.0.0.cond_encoder.1.weight", "mid_modules.0.cond_encoder.1.weight", "final_conv.1.weight",
+              "up_modules.0.0.blocks.0.block.0.weight"):
+        fx[f"grad.model.{k}"] = g_unet[k].grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "dp_rlbench_small.npz"), **fx)
+    print("dp_rlbench_small.npz: loss", float(loss), "global_cond", tuple(global_cond.shape))
+
+
+
 def golden_rollout(ref):
     """The policy side of a rollout step, from the reference's own Python:
       * TemporalAgg (src/utils/misc.py:88-141) fed a seeded sequence of action chunks;
@@ -495,6 +553,7 @@ if __name__ == "__main__":
     ref = install_reference()
     only = set(sys.argv[1:])  # e.g. `make_golden.py rollout` regenerates one fixture
     for name, fn in (("act", golden_act), ("grouping", golden_grouping), ("misc", golden_misc), ("dp", golden_dp),
-                     ("rollout", golden_rollout), ("gridsample", golden_gridsample), ("rlbench", golden_rlbench)):
+                     ("rollout", golden_rollout), ("gridsample", golden_gridsample), ("rlbench", golden_rlbench),
+                     ("dp_rlbench", golden_dp_rlbench)):
         if not only or name in only:
             fn(ref)

@@ -167,3 +167,43 @@ def test_attention_dropout_hash_statistics():
             assert abs((a * b).mean() / v) < 3e-3, (seed, p, lag_keys, lag_rows)
         sd = (p * (1 - p) / S) ** 0.5
         assert np.abs(m.mean(1) - (1 - p)).max() < 5.5 * sd and np.abs(m.mean(0) - (1 - p)).max() < 5.5 * (p * (1 - p) / rows) ** 0.5
+
+
+def test_pointnet_accepts_both_spconv_checkpoint_layouts():
+    """policy/pointnet.PointNet.load_reference_state_dict: the reference's PointNet stores its k = 1 SubMConv3d weights in
+    spconv's layouts (/root/reference/src/models/components/pcd_encoder/pointnet.py:31-55): (1,1,1,Cin,Cout) (spconv 2.x
+    default) or (Cout,1,1,1,Cin) (KRSC builds).  A 1x1x1 submanifold convolution is out[n, co] = sum_ci feat[n, ci] *
+    W[ci -> co]; the loaded module must compute exactly that from either layout, BatchNorm buffers and the biased `final`
+    head included."""
+    import torch
+
+    from pointcloudmatters_amd.policy.pointnet import PointNet
+
+    torch.manual_seed(0)
+    src = PointNet(6, num_classes=96).eval()
+    with torch.no_grad():
+        for blk in (src.conv1, src.conv2, src.conv3, src.conv4, src.conv5):
+            blk[1].running_mean.normal_(0, 0.1), blk[1].running_var.uniform_(0.5, 1.5)
+            blk[1].weight.uniform_(0.5, 1.5), blk[1].bias.normal_(0, 0.1)
+    feat = torch.randn(50, 6)
+    want = src({"feat": feat})
+
+    def conv_by_definition(x, w5, layout):  # the convolution as spconv defines it, straight from the checkpoint tensor
+        return torch.einsum("ni,io->no", x, w5[0, 0, 0]) if layout == "rsck" else torch.einsum("ni,oi->no", x, w5[:, 0, 0, 0])
+
+    for layout in ("rsck", "krsc"):
+        ckpt = {}
+        for k, v in src.state_dict().items():
+            if k.endswith(".0.weight") and k.startswith("conv"):
+                v = v.t()[None, None, None].contiguous() if layout == "rsck" else v[:, None, None, None, :].contiguous()
+                assert v.dim() == 5
+            ckpt[k] = v.clone()
+        dst = PointNet(6, num_classes=96).eval()
+        res = dst.load_reference_state_dict(ckpt, strict=True)
+        assert not res.missing_keys and not res.unexpected_keys
+        torch.testing.assert_close(dst({"feat": feat}), want, rtol=1e-6, atol=1e-6)
+        # first layer against the definition of the convolution on the raw checkpoint tensor
+        y = conv_by_definition(feat, ckpt["conv1.0.weight"], layout)
+        torch.testing.assert_close(dst.conv1[0](feat), y, rtol=1e-6, atol=1e-6)
+        for k, v in src.state_dict().items():
+            assert torch.equal(dst.state_dict()[k], v), k

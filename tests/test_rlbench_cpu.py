@@ -78,3 +78,55 @@ def test_rotation_helpers_roundtrip():
                       2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
                       2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], dim=-1).view(64, 3, 3)
     assert torch.allclose(R2, R, atol=1e-5)
+
+
+# ---- RLBench Diffusion Policy: language goal appended to the global condition ------------------------------------------
+def load_dp_rlbench_fixture(device="cpu"):
+    """dp_rlbench_small.npz (tests/golden/make_golden.py::golden_dp_rlbench): the reference PCDObsEncoder +
+    ConditionalUnet1D + LowdimMaskGenerator composed as DiffusionUnetImagePolicy.compute_loss does WITH a task embedding
+    (diffusion_unet_image_policy.py:262-266), 11-d action / proprioception."""
+    import os
+
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "dp_rlbench_small.npz"))
+    dev = torch.device(device)
+    pcds = {k[len("in.pcds."):]: torch.from_numpy(fx[k]).to(dev) for k in fx.files if k.startswith("in.pcds.")}
+    batch = {"obs": {"pcds": pcds, "qpos": torch.from_numpy(fx["in.qpos"]).to(dev)}, "action": torch.from_numpy(fx["in.action"]).to(dev),
+             "goal": {"task_emb": torch.from_numpy(fx["in.task_emb"]).to(dev)}, "noise": torch.from_numpy(fx["noise"]).to(dev),
+             "timesteps": torch.from_numpy(fx["timesteps"]).to(dev)}
+    weights = {k[2:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("w.")}
+    return fx, batch, weights
+
+
+def build_small_dp_rlbench(pointops, sa_impl, weights, device="cpu"):
+    from pointcloudmatters_amd.bc import RLBENCH_DP_MODEL, build_dp_policy
+    from tests.golden.make_golden import DP_SMALL
+
+    r = RLBENCH_DP_MODEL
+    pol = build_dp_policy(pcd_npoints=32, pointops=pointops, sa_impl=sa_impl, overlap_sampling=device != "cpu", action_dim=r["action_dim"],
+                          qpos_dim=r["qpos_dim"], goal_dim=r["goal_dim"], **DP_SMALL)
+    pol.load_state_dict(weights, strict=True)
+    return pol.to(device).train()
+
+
+def check_dp_rlbench(fx, pol, out):
+    np.testing.assert_allclose(out["loss"].detach().float().cpu().numpy(), fx["out.loss"], rtol=1e-4, atol=1e-6)
+    grads = dict(pol.named_parameters())
+    for k in fx.files:
+        if k.startswith("grad."):
+            g, ref = grads[k[5:]].grad.detach().cpu().numpy(), fx[k]
+            assert np.abs(g - ref).max() <= 1e-4 * (np.abs(ref).max() + 1e-12) + 1e-7, k
+
+
+@pytest.mark.parametrize("sa_impl", ["reference", "torch"])
+def test_dp_rlbench_policy_matches_reference_modules_cpu(sa_impl):
+    from oracle import pointops_cpu
+
+    fx, batch, weights = load_dp_rlbench_fixture()
+    pol = build_small_dp_rlbench(pointops_cpu, sa_impl, weights)
+    assert pol.goal_dim == 512
+    out = pol(batch)
+    out["loss"].backward()
+    check_dp_rlbench(fx, pol, out)
+    no_goal = {k: v for k, v in batch.items() if k != "goal"}
+    with pytest.raises(ValueError):  # a goal-conditioned model refuses a batch without its task embedding
+        pol(no_goal)

@@ -37,3 +37,41 @@ def test_rlbench_training_step_hybrid_bf16(hip_device):
             first = tr.metrics()["train/loss"]
     last = tr.metrics()["train/loss"]
     assert tr._graph is not None and last == last and last < first, (first, last)
+
+
+@pytest.mark.parametrize("sa_impl", ["reference", "fused"])
+def test_dp_rlbench_policy_matches_reference_modules_gpu(hip_device, sa_impl):
+    """The goal-conditioned Diffusion Policy of the RLBench experiments through the HIP kernels against the fixture generated
+    from the reference's own modules (loss and seven gradients within 1e-4)."""
+    import pointcloudmatters_amd.pointops as po
+    from tests.test_rlbench_cpu import build_small_dp_rlbench, check_dp_rlbench, load_dp_rlbench_fixture
+
+    fx, batch, weights = load_dp_rlbench_fixture(device=hip_device)
+    pol = build_small_dp_rlbench(po, sa_impl, weights, device=hip_device)
+    out = pol(batch)
+    out["loss"].backward()
+    check_dp_rlbench(fx, pol, out)
+
+
+def test_dp_rlbench_workload_trains_with_two_micro_batches_per_step(hip_device):
+    """bench.py --workload RLBDP in miniature: ragged clouds -> hybrid mode, bf16, 512-d task embedding, accumulate_grad_batches 2
+    (configs/exp_rlbench_diffusion_policy/rlbench_model/scratch_pointnet_pcd.yaml:9-13): the optimizer steps every second
+    micro-batch and the loss falls on a fixed pair of batches."""
+    from pointcloudmatters_amd.bc import RLBENCH_DP_MODEL, RLBENCH_DP_OPTIM, BCTrainer, build_dp_policy, clone_batch, make_dp_batch
+
+    r = RLBENCH_DP_MODEL
+    torch.manual_seed(0)
+    pol = build_dp_policy(pcd_npoints=256, sa_impl="fused", action_dim=r["action_dim"], qpos_dim=r["qpos_dim"], goal_dim=r["goal_dim"],
+                          down_dims=(64, 128, 256)).to(hip_device)
+    tr = BCTrainer(pol, total_steps=100, precision="bf16", device=hip_device, mode="hybrid", optim=dict(RLBENCH_DP_OPTIM, lr=1e-3))
+    assert tr.accumulate == 2
+    batches = [make_dp_batch(4, 1024, seed=5 + i, ragged=True, device=hip_device, action_dim=r["action_dim"], qpos_dim=r["qpos_dim"],
+                             goal_dim=r["goal_dim"]) for i in range(2)]
+    first = None
+    for i in range(24):
+        tr.training_step(clone_batch(batches[i % 2]))
+        if i == 3:
+            first = tr.metrics()["train/loss"]
+    last = tr.metrics()["train/loss"]
+    assert tr.optimizer_steps == 12 and tr.mode == "hybrid" and tr._graph is not None
+    assert last == last and last < first, (first, last)
