@@ -829,6 +829,7 @@ def main():
     dt, trainer, step, wl, sa_impl = run_workload(args.workload, args, device, world, rank, args.steps, args.warmup, mode=args.mode,
                                                   trace_steps=8)
     metrics = trainer.metrics()
+    exch = trainer.exchange_stats() if world > 1 and hasattr(trainer, "exchange_stats") else None
     is_dp = wl["policy"] in ("dp", "dp_rlbench")
     # extra lines (fp32 run of the same workload, the reference's shipped shape) BEFORE the profiler is attached for the
     # step trace: roctracer keeps slowing host-side launches afterwards, which the host-paced hybrid mode would feel
@@ -879,6 +880,8 @@ def main():
                        "dead_decoder_layers": "n/a" if is_dp else args.dead_decoder_layers},
             "final_loss": round(metrics.get("train/loss", float("nan")), 4),
         }
+        if exch is not None:  # how much of the gradient exchange backward did not hide (rank 0, events on the compute stream)
+            out["config"]["gradient_exchange_exposed_ms"] = exch
         tables = {}
         if not args.no_roofline:
             kr = kernel_rooflines(wl, device, c_feat=96 if is_dp else 512, hidden=96 if is_dp else 512)

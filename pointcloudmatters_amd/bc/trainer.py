@@ -293,9 +293,31 @@ class BCTrainer:
             self._works.append(dist.all_reduce(self.optimizer.flat_g[a:b], async_op=True))  # SUM; 1/world is applied by Adam
 
     def _finish_exchange(self):
+        """Join the slab all-reduces before the optimizer reads the gradients.  Two events bracket the join on the compute
+        stream: their distance is the part of the gradient exchange that backward did NOT hide (exchange_stats())."""
+        timed = bool(self._works) and self.device.type == "cuda"
+        if timed:
+            ring = self.__dict__.setdefault("_exchange_events", [])
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
         for w in self._works:
             w.wait()
+        if timed:
+            b.record()
+            ring.append((a, b))
+            del ring[:-32]
         self._works = []
+
+    def exchange_stats(self):
+        """Data-parallel runs: exposed gradient-exchange time per optimizer step (mean / max over the last <= 32 steps, ms) and
+        the slab sizes.  Synchronises with the device: call it outside timed regions."""
+        ring = self.__dict__.get("_exchange_events") or []
+        if not ring:
+            return None
+        torch.cuda.synchronize(self.device)
+        ms = [a.elapsed_time(b) for a, b in ring]
+        return {"exposed_ms_mean": round(sum(ms) / len(ms), 4), "exposed_ms_max": round(max(ms), 4), "steps": len(ms),
+                "slabs_mb": [round((s.slab[1] - s.slab[0]) * 4 / 1e6, 2) for s in self._stages]}
 
     # ------------------------------------------------------------------------------------------
     def _autocast(self):

@@ -35,6 +35,8 @@ def test_bench_two_ranks_prints_one_line_and_exits(hip_device):
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["warmup"] == 3 and out["scaling"] == "weak" and out["higher_is_better"]
     assert out["config"]["global_batch"] == 16 and out["config"]["parallelism"] == "dp2" and out["config"]["step_mode"] == "hybrid"
     assert out["config"]["batchnorm"] == "sync"
+    ex = out["config"]["gradient_exchange_exposed_ms"]  # per-step exposed exchange time + the four slabs of the flat gradient
+    assert ex["steps"] >= 4 and ex["exposed_ms_mean"] >= 0 and len(ex["slabs_mb"]) == 4 and abs(sum(ex["slabs_mb"]) - 96.4) < 1.0
     assert out["value"] > 0 and abs(out["value"] - 16 * 4 / (out["ms_per_step"] * 4 / 1e3)) < 1e-2 * out["value"]
     assert "roofline" in out and "step" in out and "cpu_baseline" not in out  # cpu_baseline: rank 0 at N = 1 only
     assert out["final_loss"] == out["final_loss"]  # finite
