@@ -23,6 +23,17 @@ class _BNReLU(Function):
         dev = y.device
         st = torch.cuda.current_stream().cuda_stream
         count = None
+        if n == 0:
+            # a rank without rows (ragged data-parallel batches): nothing to launch, but with synchronised statistics the rank
+            # must still take part in the collectives -- with count 0, like torch's SyncBatchNorm -- or its peers block forever
+            assert sync_bn is not None, "bn_relu on an empty batch is only meaningful with synchronised statistics"
+            from . import sync_bn as S
+
+            zero = torch.zeros(c, dtype=torch.float32, device=dev)
+            stat, count = S.combine_forward(sync_bn, zero, zero, 0)
+            ctx.save_for_backward(y, stat)
+            ctx.partial, ctx.sync = None, (sync_bn, count)
+            return torch.empty_like(y)
         with torch.cuda.device(dev):
             f32 = dict(dtype=torch.float32, device=dev)
             partial = torch.empty(L.pcm_bn_relu_slots(n, c) * 2 * c, **f32)
@@ -52,6 +63,13 @@ class _BNReLU(Function):
         L = _lib.load()
         y, stat = ctx.saved_tensors
         n, c = y.shape
+        if n == 0:  # see forward: contribute zero sums to the exchange, no local gradient
+            from . import sync_bn as S
+
+            sync_bn, count = ctx.sync
+            sums = torch.zeros(2, c, dtype=torch.float32, device=y.device)
+            S.reduce_backward(sync_bn, sums, count)
+            return torch.empty_like(y), sums[1], sums[0], None, None, None, None, None
         dz = dz.contiguous()
         if dz.dtype != y.dtype:
             dz = dz.to(y.dtype)
@@ -76,6 +94,10 @@ class _BNReLU(Function):
 
 
 def supported(y, bn):
+    if y.is_cuda and y.dim() == 2 and y.shape[0] == 0 and type(bn) is torch.nn.BatchNorm1d and bn.training:
+        from .sync_bn import wants_sync
+
+        return wants_sync(bn)  # an empty rank of a synchronised BatchNorm still joins the collectives (bn_relu handles it)
     return (y.is_cuda and y.dim() == 2 and y.dtype in (torch.float32, torch.bfloat16) and type(bn) is torch.nn.BatchNorm1d
             and bn.affine and bn.track_running_stats and bn.weight.dtype == torch.float32
             and (not bn.training or bn.momentum is not None)

@@ -124,3 +124,62 @@ def test_fused_batchnorm_statistics_are_exchanged(hip_device):
     for k, v in grads.items():
         ref = v.cpu()
         assert (torch.from_numpy(got["grads"][k]) - ref).norm() <= 2e-3 * ref.norm() + 1e-5, k
+
+
+def _empty_rank_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pointcloudmatters_amd.policy import bn_relu
+        from pointcloudmatters_amd.policy.sync_bn import enable_sync_batchnorm
+
+        dev = torch.device("cuda:0")
+        torch.manual_seed(0)
+        bn = torch.nn.BatchNorm1d(64).to(dev).train()
+        holder = torch.nn.ModuleDict({"bn": bn})
+        holder.fused_batchnorms = lambda: [bn]
+        enable_sync_batchnorm(holder)
+        y = torch.randn(500, 64, generator=torch.Generator().manual_seed(3)).to(dev)
+        mine = (y if rank == 0 else y[:0]).clone().requires_grad_(True)  # rank 1 holds NO rows
+        assert bn_relu.supported(mine, bn)
+        z = bn_relu.bn_relu(mine, bn)
+        (z * 2.0).sum().backward()
+        q.put({"z%d" % rank: z.detach().cpu().numpy(), "g%d" % rank: mine.grad.cpu().numpy(), "rm%d" % rank: bn.running_mean.cpu().numpy(),
+               "gw%d" % rank: bn.weight.grad.cpu().numpy()})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_rank_without_rows_still_joins_the_statistics_exchange(hip_device):
+    """Ragged data-parallel batches can leave a rank without a single row in front of a synchronised BatchNorm.  It must take
+    part in the all_gather / all_reduce with count 0 (like torch's SyncBatchNorm) instead of failing locally while its peers
+    block: the rank WITH rows then gets exactly the single-process result."""
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_empty_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(1200):
+        while not q.empty():
+            got.update(q.get())
+        if len(got) >= 8 or any(p.exitcode not in (None, 0) for p in procs):
+            break
+        time.sleep(0.1)
+    for p in procs:
+        p.join(60)
+        if p.is_alive():
+            p.kill()
+        assert p.exitcode == 0
+    assert got["z1"].shape == (0, 64) and got["g1"].shape == (0, 64) and not got["gw1"].any()
+    torch.manual_seed(0)
+    bn = torch.nn.BatchNorm1d(64).to(hip_device).train()
+    y = torch.randn(500, 64, generator=torch.Generator().manual_seed(3)).to(hip_device).requires_grad_(True)
+    z = torch.relu(bn(y))
+    (z * 2.0).sum().backward()
+    torch.testing.assert_close(torch.from_numpy(got["z0"]), z.detach().cpu(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(torch.from_numpy(got["g0"]), y.grad.cpu(), rtol=1e-3, atol=1e-5)
+    for r in (0, 1):
+        torch.testing.assert_close(torch.from_numpy(got["rm%d" % r]), bn.running_mean.cpu(), rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(torch.from_numpy(got["gw0"]), bn.weight.grad.cpu(), rtol=1e-3, atol=1e-4)
