@@ -671,8 +671,19 @@ class BCTrainer:
         """One micro-batch: forward, loss, backward and -- on accumulation boundaries -- the
         optimizer step.  Returns the (detached, on-device) loss dict of this micro-batch.
         `prefetch`: the next micro-batch, if it is already on the device (see prefetch_sampling)."""
-        if not self.module.training:  # .train() walks ~230 modules (1 ms of host time): only when something switched to eval
+        # Mode contract.  .train() walks ~230 modules (1 ms of host time), so it runs only when the ROOT module is in eval
+        # mode (what policy.eval() / a rollout helper leaves behind).  A submodule the caller put into eval() on its own
+        # (a frozen backbone's BatchNorm) therefore STAYS in eval -- Lightning's loop would have forced it back to train
+        # every step.  Every 64th micro-batch the whole tree is checked, so a child that was flipped by evaluation code
+        # without touching the root cannot silently train without BatchNorm updates / dropout for long; captured graphs
+        # bake the mode in at capture time either way.
+        if not self.module.training:
             self.module.train()
+        elif self.micro % 64 == 0 and not getattr(self, "allow_eval_submodules", False):
+            stale = [n for n, m in self.module.named_modules() if not m.training]
+            if stale:
+                raise RuntimeError("training_step: submodules in eval mode under a training root: %s ... -- call policy.train(), or set "
+                                   "trainer.allow_eval_submodules = True if they are frozen on purpose" % ", ".join(stale[:4]))
         if prefetch is not None:
             self.prefetch_sampling(prefetch)
         if self._fused_ctx is not None:
