@@ -14,6 +14,8 @@
 //  * random ball query: first nsample hits in `order`; no LDS at all.
 #include "pcm_common.hpp"
 
+#include <stdlib.h>
+
 namespace {
 
 __device__ __forceinline__ bool in_ball(float d2, float min_r2, float max_r2)
@@ -26,7 +28,7 @@ __global__ __launch_bounds__(64) void pcm_ball_query_kernel(int m, int nsample, 
                                                            const float *__restrict__ new_xyz,
                                                            const int *__restrict__ offset,
                                                            const int *__restrict__ new_offset, int b,
-                                                           int *__restrict__ idx, float *__restrict__ dist2)
+                                                           int *__restrict__ idx, float *__restrict__ dist2, int only_flagged)
 {
     __shared__ float cd[PCM_BALL_MAX_CAND];
     __shared__ int ci[PCM_BALL_MAX_CAND];
@@ -36,6 +38,7 @@ __global__ __launch_bounds__(64) void pcm_ball_query_kernel(int m, int nsample, 
     const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
 
     for (int q = blockIdx.x; q < m; q += gridDim.x) {
+        if (only_flagged && idx[(size_t)q * nsample] != -2) continue;  // block-uniform: answered by the lane-per-query kernel
         const int bt = pcm_cloud_of(q, new_offset, b);
         const int start = bt == 0 ? 0 : offset[bt - 1];
         const int end = offset[bt];
@@ -161,6 +164,109 @@ __global__ __launch_bounds__(64) void pcm_ball_query_kernel(int m, int nsample, 
     }
 }
 
+// ---- lane-per-query variant ------------------------------------------------------------------------------------
+// The wave-per-query kernel above spends its time in the literal heap_sort replay: O(cnt log cnt) DEPENDENT steps for one
+// query at a time (1.45 ms for 65 536 queries with ~67 candidates each).  The replay cannot be parallelised inside a
+// query, so it is run for 64 queries at once instead, the way the reference's one-thread-per-query kernel does
+// (ball_query_cuda_kernel.cu:58-123), but out of LDS rather than scratch memory:
+//   * one wave = 64 consecutive queries, lane = query; the candidates of lane l live in the LDS columns cd[k][l], ci[k][l]
+//     (bank = lane: conflict-free whatever k each lane touches);
+//   * the cloud is staged through LDS in chunks of 512 points and every lane walks the chunk in scan order (same address
+//     in all lanes = LDS broadcast), appending to its own column -- the scan order of the reference by construction;
+//   * the heap_sort replay and the output rows are plain per-lane code.
+// A block of queries that straddles clouds walks each cloud it touches; a query with more than kLaneCap candidates is
+// flagged (idx[q][0] = -2) and redone by the wave-per-query kernel, which handles up to PCM_BALL_MAX_CAND.
+constexpr int kLaneCap = 96;    // candidates per query held in LDS: 96 x 64 x 8 B = 48 KiB per wave
+constexpr int kBallChunk = 512;
+
+__global__ __launch_bounds__(64) void pcm_ball_query_lanes_kernel(int m, int nsample, float min_radius, float max_radius,
+                                                                   const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                                                                   const int *__restrict__ offset, const int *__restrict__ new_offset,
+                                                                   int b, int *__restrict__ idx, float *__restrict__ dist2)
+{
+    __shared__ float cd[kLaneCap][64];
+    __shared__ int ci[kLaneCap][64];
+    __shared__ float4 pts[kBallChunk];
+    const int lane = threadIdx.x;
+    const float max_r2 = max_radius * max_radius;
+    const float min_r2 = min_radius * min_radius;
+    for (int qb = blockIdx.x * 64; qb < m; qb += gridDim.x * 64) {
+        const int q = qb + lane;
+        const bool live = q < m;
+        const int qq = live ? q : m - 1;
+        const float qx = new_xyz[(size_t)qq * 3 + 0], qy = new_xyz[(size_t)qq * 3 + 1], qz = new_xyz[(size_t)qq * 3 + 2];
+        const int c_first = pcm_cloud_of(qb, new_offset, b), c_last = pcm_cloud_of(min(qb + 64, m) - 1, new_offset, b);
+        int cnt = 0;
+        for (int c = c_first; c <= c_last; ++c) {
+            const int start = c == 0 ? 0 : offset[c - 1], end = offset[c];
+            const int qs = c == 0 ? 0 : new_offset[c - 1], qe = new_offset[c];
+            const bool mine = live && q >= qs && q < qe;
+            for (int base = start; base < end; base += kBallChunk) {
+                const int nch = min(kBallChunk, end - base);
+                __syncthreads();  // the previous chunk has been read by every lane
+                for (int t = lane; t < nch; t += 64) {
+                    const float *p = xyz + (size_t)(base + t) * 3;
+                    pts[t] = make_float4(p[0], p[1], p[2], 0.f);
+                }
+                __syncthreads();
+                if (mine) {
+                    for (int t = 0; t < nch; ++t) {
+                        const float4 p = pts[t];  // same address in every lane: broadcast
+                        const float d2 = pcm_sqdist(qx, qy, qz, p.x, p.y, p.z);
+                        if (in_ball(d2, min_r2, max_r2)) {
+                            if (cnt < kLaneCap) cd[cnt][lane] = d2, ci[cnt][lane] = base + t;
+                            ++cnt;
+                        }
+                    }
+                }
+            }
+        }
+        if (live) {
+            int *oi = idx + (size_t)q * nsample;
+            float *od = dist2 + (size_t)q * nsample;
+            if (cnt > kLaneCap) {
+                oi[0] = -2;  // redone by the wave-per-query kernel
+            } else {
+                // heap_sort (:33-42) on the un-heapified candidate array, literally
+                for (int i = cnt - 1; i > 0; --i) {
+                    float td = cd[0][lane];
+                    int ti = ci[0][lane];
+                    cd[0][lane] = cd[i][lane], ci[0][lane] = ci[i][lane];
+                    cd[i][lane] = td, ci[i][lane] = ti;
+                    int root = 0, child = 1;
+                    float dr = cd[0][lane];
+                    while (child < i) {
+                        float dc = cd[child][lane];
+                        if (child + 1 < i) {
+                            const float dc1 = cd[child + 1][lane];
+                            if (dc1 > dc) child++, dc = dc1;
+                        }
+                        if (dr > dc) break;
+                        const int xr = ci[root][lane], xc = ci[child][lane];
+                        cd[root][lane] = dc, ci[root][lane] = xc;
+                        cd[child][lane] = dr, ci[child][lane] = xr;
+                        root = child;  // dr travels down with the root
+                        child = root * 2 + 1;
+                    }
+                }
+                if (cnt <= nsample) {
+                    for (int i = 0; i < nsample; ++i) {
+                        oi[i] = i < cnt ? ci[i][lane] : -1;
+                        od[i] = i < cnt ? cd[i][lane] : 1e10f;
+                    }
+                } else {
+                    const float sep = (float)cnt / nsample;  // :115
+                    for (int i = 0; i < nsample; ++i) {
+                        const int index = (int)(sep * i);  // :118
+                        oi[i] = ci[index][lane];
+                        od[i] = (float)ci[index][lane];  // :120 (sic): the reference stores the index as dist2
+                    }
+                }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void pcm_random_ball_query_kernel(int m, int nsample, float min_radius, float max_radius,
                                                                     const int *__restrict__ order,
                                                                     const float *__restrict__ xyz,
@@ -222,8 +328,19 @@ extern "C" int pcm_ball_query_b_hip(int b, int m, int nsample, float min_radius,
     if (m < 0 || nsample < 1 || b < 0) return PCM_ERR_BAD_ARG;
     if (m == 0) return PCM_OK;
     int blocks = m < 256 * 16 ? m : 256 * 16;
+    static const int force_wave = getenv("PCM_BALL_WAVE") ? atoi(getenv("PCM_BALL_WAVE")) : 0;  // A/B switch for tools/mb
+    if (b > 0 && m >= 4096 && !force_wave) {
+        // enough queries to fill the chip with 64-query waves: lane-per-query kernel, then the flagged leftovers
+        int lblocks = (m + 63) / 64;
+        if (lblocks > 256 * 8) lblocks = 256 * 8;
+        hipLaunchKernelGGL(pcm_ball_query_lanes_kernel, dim3(lblocks), dim3(64), 0, (hipStream_t)stream, m, nsample, min_radius,
+                           max_radius, xyz, new_xyz, offset, new_offset, b, idx, dist2);
+        hipLaunchKernelGGL(pcm_ball_query_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, m, nsample, min_radius,
+                           max_radius, xyz, new_xyz, offset, new_offset, b, idx, dist2, 1);
+        return PCM_LAUNCH_STATUS();
+    }
     hipLaunchKernelGGL(pcm_ball_query_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, m, nsample, min_radius,
-                       max_radius, xyz, new_xyz, offset, new_offset, b, idx, dist2);
+                       max_radius, xyz, new_xyz, offset, new_offset, b, idx, dist2, 0);
     return PCM_LAUNCH_STATUS();
 }
 
