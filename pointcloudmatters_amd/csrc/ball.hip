@@ -176,8 +176,15 @@ __global__ __launch_bounds__(64) void pcm_ball_query_kernel(int m, int nsample, 
 //   * the heap_sort replay and the output rows are plain per-lane code.
 // A block of queries that straddles clouds walks each cloud it touches; a query with more than kLaneCap candidates is
 // flagged (idx[q][0] = -2) and redone by the wave-per-query kernel, which handles up to PCM_BALL_MAX_CAND.
-constexpr int kLaneCap = 96;    // candidates per query held in LDS: 96 x 64 x 8 B = 48 KiB per wave
+constexpr int kLaneCap = 96;    // candidates per query held in LDS: 96 x 64 x (4 + 2) B = 36 KiB per wave (indices cloud-local, 16 bit)
 constexpr int kBallChunk = 512;
+
+// (double)d2 <= 1e-5 for a float d2  <=>  d2 <= 1e-5f: 1e-5f = 9.99999974737875e-06 lies below 1e-5 and the next float above it
+// lies above 1e-5, so the comparison can stay in single precision (same truth value for every float)
+__device__ __forceinline__ bool in_ball_f(float d2, float min_r2, float max_r2)
+{
+    return d2 <= 1e-5f || (d2 >= min_r2 && d2 < max_r2);
+}
 
 __global__ __launch_bounds__(64) void pcm_ball_query_lanes_kernel(int m, int nsample, float min_radius, float max_radius,
                                                                    const float *__restrict__ xyz, const float *__restrict__ new_xyz,
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(64) void pcm_ball_query_lanes_kernel(int m, int nsa
                                                                    int b, int *__restrict__ idx, float *__restrict__ dist2)
 {
     __shared__ float cd[kLaneCap][64];
-    __shared__ int ci[kLaneCap][64];
+    __shared__ unsigned short ci[kLaneCap][64];
     __shared__ float4 pts[kBallChunk];
     const int lane = threadIdx.x;
     const float max_r2 = max_radius * max_radius;
@@ -196,26 +203,38 @@ __global__ __launch_bounds__(64) void pcm_ball_query_lanes_kernel(int m, int nsa
         const int qq = live ? q : m - 1;
         const float qx = new_xyz[(size_t)qq * 3 + 0], qy = new_xyz[(size_t)qq * 3 + 1], qz = new_xyz[(size_t)qq * 3 + 2];
         const int c_first = pcm_cloud_of(qb, new_offset, b), c_last = pcm_cloud_of(min(qb + 64, m) - 1, new_offset, b);
-        int cnt = 0;
+        int cnt = 0, my_start = 0;
         for (int c = c_first; c <= c_last; ++c) {
             const int start = c == 0 ? 0 : offset[c - 1], end = offset[c];
             const int qs = c == 0 ? 0 : new_offset[c - 1], qe = new_offset[c];
             const bool mine = live && q >= qs && q < qe;
+            if (mine) {
+                my_start = start;
+                if (end - start > 65535) cnt = kLaneCap + 1;  // cloud-local indices would not fit 16 bits: leave it to the other kernel
+            }
             for (int base = start; base < end; base += kBallChunk) {
                 const int nch = min(kBallChunk, end - base);
                 __syncthreads();  // the previous chunk has been read by every lane
-                for (int t = lane; t < nch; t += 64) {
-                    const float *p = xyz + (size_t)(base + t) * 3;
-                    pts[t] = make_float4(p[0], p[1], p[2], 0.f);
+                for (int t = lane; t < kBallChunk; t += 64) {
+                    const float *p = xyz + (size_t)(base + (t < nch ? t : 0)) * 3;
+                    pts[t] = t < nch ? make_float4(p[0], p[1], p[2], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
                 __syncthreads();
                 if (mine) {
-                    for (int t = 0; t < nch; ++t) {
-                        const float4 p = pts[t];  // same address in every lane: broadcast
-                        const float d2 = pcm_sqdist(qx, qy, qz, p.x, p.y, p.z);
-                        if (in_ball(d2, min_r2, max_r2)) {
-                            if (cnt < kLaneCap) cd[cnt][lane] = d2, ci[cnt][lane] = base + t;
-                            ++cnt;
+                    constexpr int UN = 8;  // distances of 8 points in flight before the first (divergent) append
+                    for (int t0 = 0; t0 < nch; t0 += UN) {
+                        float d2[UN];
+#pragma unroll
+                        for (int u = 0; u < UN; ++u) {
+                            const float4 p = pts[t0 + u];  // same address in every lane: broadcast
+                            d2[u] = pcm_sqdist(qx, qy, qz, p.x, p.y, p.z);
+                        }
+#pragma unroll
+                        for (int u = 0; u < UN; ++u) {
+                            if (t0 + u < nch && in_ball_f(d2[u], min_r2, max_r2)) {
+                                if (cnt < kLaneCap) cd[cnt][lane] = d2[u], ci[cnt][lane] = (unsigned short)(base + t0 + u - start);
+                                ++cnt;
+                            }
                         }
                     }
                 }
@@ -230,7 +249,7 @@ __global__ __launch_bounds__(64) void pcm_ball_query_lanes_kernel(int m, int nsa
                 // heap_sort (:33-42) on the un-heapified candidate array, literally
                 for (int i = cnt - 1; i > 0; --i) {
                     float td = cd[0][lane];
-                    int ti = ci[0][lane];
+                    unsigned short ti = ci[0][lane];
                     cd[0][lane] = cd[i][lane], ci[0][lane] = ci[i][lane];
                     cd[i][lane] = td, ci[i][lane] = ti;
                     int root = 0, child = 1;
@@ -242,7 +261,7 @@ __global__ __launch_bounds__(64) void pcm_ball_query_lanes_kernel(int m, int nsa
                             if (dc1 > dc) child++, dc = dc1;
                         }
                         if (dr > dc) break;
-                        const int xr = ci[root][lane], xc = ci[child][lane];
+                        const unsigned short xr = ci[root][lane], xc = ci[child][lane];
                         cd[root][lane] = dc, ci[root][lane] = xc;
                         cd[child][lane] = dr, ci[child][lane] = xr;
                         root = child;  // dr travels down with the root
@@ -251,15 +270,15 @@ __global__ __launch_bounds__(64) void pcm_ball_query_lanes_kernel(int m, int nsa
                 }
                 if (cnt <= nsample) {
                     for (int i = 0; i < nsample; ++i) {
-                        oi[i] = i < cnt ? ci[i][lane] : -1;
+                        oi[i] = i < cnt ? my_start + (int)ci[i][lane] : -1;
                         od[i] = i < cnt ? cd[i][lane] : 1e10f;
                     }
                 } else {
                     const float sep = (float)cnt / nsample;  // :115
                     for (int i = 0; i < nsample; ++i) {
                         const int index = (int)(sep * i);  // :118
-                        oi[i] = ci[index][lane];
-                        od[i] = (float)ci[index][lane];  // :120 (sic): the reference stores the index as dist2
+                        oi[i] = my_start + (int)ci[index][lane];
+                        od[i] = (float)(my_start + (int)ci[index][lane]);  // :120 (sic): the reference stores the index as dist2
                     }
                 }
             }
@@ -329,8 +348,10 @@ extern "C" int pcm_ball_query_b_hip(int b, int m, int nsample, float min_radius,
     if (m == 0) return PCM_OK;
     int blocks = m < 256 * 16 ? m : 256 * 16;
     static const int force_wave = getenv("PCM_BALL_WAVE") ? atoi(getenv("PCM_BALL_WAVE")) : 0;  // A/B switch for tools/mb
-    if (b > 0 && m >= 4096 && !force_wave) {
-        // enough queries to fill the chip with 64-query waves: lane-per-query kernel, then the flagged leftovers
+    if (b > 0 && m >= 32768 && !force_wave) {
+        // enough queries to fill the chip with 64-query waves (48 KiB of LDS each: three per CU): lane-per-query kernel, then
+        // the flagged leftovers.  Measured, radius 0.1, nsample 16 (wave-per-query -> lanes): 128 x 1024 points / 65 536 queries
+        // 0.32 -> 0.25 ms; 32 x 4096 / 65 536: 1.45 -> 1.00 ms; 8 x ~4096 / 16 384: 0.40 -> 0.60 ms (too few waves), hence the bound
         int lblocks = (m + 63) / 64;
         if (lblocks > 256 * 8) lblocks = 256 * 8;
         hipLaunchKernelGGL(pcm_ball_query_lanes_kernel, dim3(lblocks), dim3(64), 0, (hipStream_t)stream, m, nsample, min_radius,

@@ -129,6 +129,38 @@ def test_ball_query_bit_exact(hip_device, sizes, ms, nsample, rmax, rmin, mode):
     assert torch.equal(gd.cpu(), wd)
 
 
+BALL_MANY = [
+    ([1024] * 64, [512] * 64, 16, 0.1, 0.0, "uniform"),                      # 32 768 queries: lane-per-query kernel, ~16 candidates each
+    ([700, 1300, 2048, 333, 4096] * 5, [650, 1200, 2000, 300, 2500] * 5, 16, 0.12, 0.01, "lattice"),  # ragged, exact ties, 64-query blocks straddle clouds
+    ([2048] * 20, [1700] * 20, 32, 0.25, 0.0, "uniform"),                    # > 96 candidates for most queries: flagged and redone wave-per-query
+    ([70000, 500], [32500, 400], 8, 0.03, 0.0, "uniform"),                   # a cloud too large for 16-bit local indices
+]
+
+
+@pytest.mark.parametrize("sizes,ms,nsample,rmax,rmin,mode", BALL_MANY)
+def test_ball_query_bit_exact_with_many_queries(hip_device, sizes, ms, nsample, rmax, rmin, mode):
+    """>= 32 768 queries take the lane-per-query kernel (64 queries per wave, candidates in LDS columns, the heap_sort replay run
+    for 64 queries at once); its flagged leftovers go through the wave-per-query kernel.  Same bits as the oracle either way."""
+    from pointcloudmatters_amd.pointops.query import ball_query_raw
+    from oracle import lib as olib
+
+    xyz, off = make_clouds(sizes, seed=9, mode=mode)
+    noff = new_offsets(ms)
+    assert sum(ms) >= 32768
+    starts = [0] + off.tolist()[:-1]
+    sel = torch.cat([st + (torch.arange(mq) * 7919) % n for st, n, mq in zip(starts, sizes, ms)])  # queries: a strided subset of each cloud
+    new_xyz = xyz[sel].contiguous()
+    L = olib.load()
+    wi = torch.zeros(new_xyz.shape[0], nsample, dtype=torch.int32)
+    wd = torch.zeros(new_xyz.shape[0], nsample, dtype=torch.float32)
+    rc = L.pcm_ball_query_cpu(new_xyz.shape[0], nsample, rmin, rmax, xyz.data_ptr(), new_xyz.data_ptr(),
+                              off.data_ptr(), noff.data_ptr(), wi.data_ptr(), wd.data_ptr())
+    assert rc in (0, 2)
+    gi, gd = ball_query_raw(nsample, rmax, rmin, xyz.to(hip_device), off.to(hip_device), new_xyz.to(hip_device), noff.to(hip_device))
+    assert torch.equal(gi.cpu(), wi)
+    assert torch.equal(gd.cpu(), wd)
+
+
 @pytest.mark.parametrize("sizes,ms,nsample,rmax,rmin", [([1024] * 4, [256] * 4, 16, 0.1, 0.0), ([300, 20], [50, 20], 8, 0.3, 0.05)])
 def test_random_ball_query_bit_exact(hip_device, sizes, ms, nsample, rmax, rmin):
     from pointcloudmatters_amd.pointops.query import random_ball_query_raw
