@@ -94,7 +94,7 @@ __global__ __launch_bounds__(64) void pcm_sa_rm_reduce_kernel(int nblocks, const
 // goff (m, K+1) u16: run (i,s) = positions [goff[i][s], goff[i][s+1]) of row i of cperm / dperm
 // ---------------------------------------------------------------------------------------------
 template <int TMAX>
-__global__ __launch_bounds__(kBlock) void pcm_sa_bwd1_pack_kernel(int m, int K, int H, const float *__restrict__ dz,
+__global__ __launch_bounds__(kBlock, 3) void pcm_sa_bwd1_pack_kernel(int m, int K, int H, const float *__restrict__ dz,
                                                                   const float *__restrict__ sel, const uint8_t *__restrict__ asel,
                                                                   const float *__restrict__ stat, const float4 *__restrict__ ent,
                                                                   uint16_t *__restrict__ goff, uint16_t *__restrict__ cperm,
