@@ -173,30 +173,40 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_flash_fwd_kernel(AttnParams P,
             s0 = PCM_MFMA16(lds_bf8(Kt + lo.row[sl]), qf[sl], s0);
             s1 = PCM_MFMA16(lds_bf8(Kt + lo.row[sl] + 32 * HD), qf[sl], s1);
         }
+        // the transposed V fragments of the whole tile are requested NOW: the LDS reads drain under the softmax below instead
+        // of stalling each P V MFMA on its own operand
+        bf8 va0[4], va1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const u16 *vs = Vt + j * 16 * HD;
+            va0[j] = cat8(lds_tr(vs + lo.tr[0][0]), lds_tr(vs + lo.tr[1][0]));
+            va1[j] = cat8(lds_tr(vs + lo.tr[0][1]), lds_tr(vs + lo.tr[1][1]));
+        }
         const bool edge = (kt + 1) * TR > P.S || mask != nullptr;
         // the running maximum is kept on the RAW scores (scale > 0 commutes with max): the scale is folded into the
         // exponent's FMA, exp2(s * scale2 - m * scale2), instead of costing one multiply per score
-        float tmax = -INFINITY;
+        if (edge) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if (edge) {
+            for (int r = 0; r < 16; ++r) {
                 const int key = kt * TR + crow(r, lane);
                 const bool v0 = key < P.S && !(mask != nullptr && mask[key] != 0);
                 const bool v1 = key + 32 < P.S && !(mask != nullptr && mask[key + 32] != 0);
                 s0[r] = v0 ? s0[r] : -INFINITY;
                 s1[r] = v1 ? s1[r] : -INFINITY;
             }
-            tmax = fmaxf(tmax, fmaxf(s0[r], s1[r]));
         }
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tmax = max3f(tmax, s0[r], s1[r]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
         const float m_new = fmaxf(m, tmax);
-        const bool dead = m_new == -INFINITY;  // nothing visible yet for this query
+        const bool dead = m_new == -INFINITY;  // nothing visible yet for this query: every score is -inf
         const float mneg = dead ? 0.f : -m_new * scale2;
         float p0[16], p1[16], psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            p0[r] = dead ? 0.f : __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], scale2, mneg));
-            p1[r] = dead ? 0.f : __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], scale2, mneg));
+            p0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], scale2, mneg));  // dead: exp2(-inf * scale2 + 0) = 0, no select needed
+            p1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], scale2, mneg));
             psum += p0[r] + p1[r];
         }
         psum += __shfl_xor(psum, 32);
@@ -213,19 +223,19 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_flash_fwd_kernel(AttnParams P,
             for (int gh = 0; gh < 8; ++gh) {  // registers 2gh, 2gh+1 hold adjacent keys: one hash for the pair
                 const uint32_t pair = (uint32_t)(kt * (TR / 2) + 4 * (gh >> 1) + 2 * hl + (gh & 1));
                 const uint32_t b0 = attn_pair_bits(rb, pair), b1 = attn_pair_bits(rb, pair + 16);
-                p0[2 * gh] = (b0 & 0xFFFFu) >= dc.thr ? p0[2 * gh] * dc.inv_keep : 0.f;
-                p0[2 * gh + 1] = (b0 >> 16) >= dc.thr ? p0[2 * gh + 1] * dc.inv_keep : 0.f;
-                p1[2 * gh] = (b1 & 0xFFFFu) >= dc.thr ? p1[2 * gh] * dc.inv_keep : 0.f;
-                p1[2 * gh + 1] = (b1 >> 16) >= dc.thr ? p1[2 * gh + 1] * dc.inv_keep : 0.f;
+                // the 1 / (1 - p) rescale of the kept weights is a constant: it is folded into the final normalisation of O
+                p0[2 * gh] = (b0 & 0xFFFFu) >= dc.thr ? p0[2 * gh] : 0.f;
+                p0[2 * gh + 1] = (b0 >> 16) >= dc.thr ? p0[2 * gh + 1] : 0.f;
+                p1[2 * gh] = (b1 & 0xFFFFu) >= dc.thr ? p1[2 * gh] : 0.f;
+                p1[2 * gh + 1] = (b1 >> 16) >= dc.thr ? p1[2 * gh + 1] : 0.f;
             }
         }
         // O^T += V^T P^T, 16 keys per MFMA: slab j = keys 16j .. 16j+15 of the tile
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bf8 pf = j < 2 ? p_frag(p0, 8 * (j & 1)) : p_frag(p1, 8 * (j & 1));
-            const u16 *vs = Vt + j * 16 * HD;
-            o0 = PCM_MFMA16(cat8(lds_tr(vs + lo.tr[0][0]), lds_tr(vs + lo.tr[1][0])), pf, o0);
-            o1 = PCM_MFMA16(cat8(lds_tr(vs + lo.tr[0][1]), lds_tr(vs + lo.tr[1][1])), pf, o1);
+            o0 = PCM_MFMA16(va0[j], pf, o0);
+            o1 = PCM_MFMA16(va1[j], pf, o1);
         }
         if (kt + 1 < ntiles) {
             stage_store(kr, smem + ((kt + 1) & 1) * TILE, tid);
@@ -233,7 +243,7 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_flash_fwd_kernel(AttnParams P,
         }
         __syncthreads();
     }
-    const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
+    const float inv = lsum > 0.f ? dc.inv_keep / lsum : 0.f;
     store_acc_rows(smem + w * RW * OS, o0, o1, inv, out + (long)b * P.L * (P.H * HD) + h * HD, (long)P.H * HD, q0, P.L, lane);
     if (lane < 32 && qok) lse[(long)bh * P.L + qi] = lsum > 0.f ? m * P.scale + logf(lsum) : INFINITY;  // m: raw-score maximum
 }
@@ -289,7 +299,9 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_flash_bwd_dq_kernel(AttnParams
     const uint32_t rb = dc.on ? attn_rowbase(dc.seed, P.site, (uint32_t)(bh * P.L + qi)) : 0u;
     const float scale2 = P.scale * 1.44269504088896f;
     const float lq2 = qok ? lse[(long)bh * P.L + qi] * 1.44269504088896f : INFINITY;  // +inf silences padded queries
-    const float Dq = qok ? delta[(long)bh * P.L + qi] : 0.f;
+    // dS = p * (keep * dP / (1 - p_drop) - D) * scale  =  p * (keep * dP - D * (1 - p_drop)) * (scale / (1 - p_drop))
+    const float Dq = (qok ? delta[(long)bh * P.L + qi] : 0.f) / dc.inv_keep;
+    const float sk = P.scale * dc.inv_keep;
     f16v a0, a1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) a0[r] = 0.f, a1[r] = 0.f;
@@ -320,12 +332,20 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_flash_bwd_dq_kernel(AttnParams
                 s = PCM_MFMA16(lds_bf8(Kt + lo.row[sl] + kh * 32 * HD), qf[sl], s);
                 dp = PCM_MFMA16(lds_bf8(Vt + lo.row[sl] + kh * 32 * HD), gf[sl], dp);
             }
+            // the transposed K fragments of this 32-key half are requested before the softmax arithmetic below
+            bf8 kt0[2], kt1[2];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const u16 *ks = Kt + (2 * kh + jj) * 16 * HD;
+                kt0[jj] = cat8(lds_tr(ks + lo.tr[0][0]), lds_tr(ks + lo.tr[1][0]));
+                kt1[jj] = cat8(lds_tr(ks + lo.tr[0][1]), lds_tr(ks + lo.tr[1][1]));
+            }
             if (dc.on) {
 #pragma unroll
                 for (int gh = 0; gh < 8; ++gh) {
                     const uint32_t bits = attn_pair_bits(rb, (uint32_t)(kt * (TR / 2) + 16 * kh + 4 * (gh >> 1) + 2 * hl + (gh & 1)));
-                    dp[2 * gh] = (bits & 0xFFFFu) >= dc.thr ? dp[2 * gh] * dc.inv_keep : 0.f;
-                    dp[2 * gh + 1] = (bits >> 16) >= dc.thr ? dp[2 * gh + 1] * dc.inv_keep : 0.f;
+                    dp[2 * gh] = (bits & 0xFFFFu) >= dc.thr ? dp[2 * gh] : 0.f;  // 1 / (1 - p) is folded into Dk / sk below
+                    dp[2 * gh + 1] = (bits >> 16) >= dc.thr ? dp[2 * gh + 1] : 0.f;
                 }
             }
             float ds[16];
@@ -337,15 +357,14 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_flash_bwd_dq_kernel(AttnParams
                     const bool vis = key < P.S && !(mask != nullptr && mask[key] != 0);
                     pr = vis ? pr : 0.f;
                 }
-                ds[r] = pr * (dp[r] - Dq) * P.scale;
+                ds[r] = pr * (dp[r] - Dq);  // the constant factor scale / (1 - p_drop) is applied once, to the finished dQ
             }
             // dQ^T += K^T dS^T: slab jj = keys 16 jj .. of this 32-key half
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 const bf8 df = p_frag(ds, 8 * jj);
-                const u16 *ks = Kt + (2 * kh + jj) * 16 * HD;
-                a0 = PCM_MFMA16(cat8(lds_tr(ks + lo.tr[0][0]), lds_tr(ks + lo.tr[1][0])), df, a0);
-                a1 = PCM_MFMA16(cat8(lds_tr(ks + lo.tr[0][1]), lds_tr(ks + lo.tr[1][1])), df, a1);
+                a0 = PCM_MFMA16(kt0[jj], df, a0);
+                a1 = PCM_MFMA16(kt1[jj], df, a1);
             }
         }
         if (kt + 1 < ntiles) {
@@ -354,7 +373,7 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_flash_bwd_dq_kernel(AttnParams
         }
         __syncthreads();
     }
-    store_acc_rows(smem + w * RW * OS, a0, a1, 1.f, dq + (long)b * dq_bs + h * HD, dq_ls, q0, P.L, lane);
+    store_acc_rows(smem + w * RW * OS, a0, a1, sk, dq + (long)b * dq_bs + h * HD, dq_ls, q0, P.L, lane);
 }
 
 // dK, dV: grid (B*H, ceil(S / 128)); streams Q / dO tiles (+ lse, delta, dropout row keys of the tile's queries)
@@ -372,6 +391,7 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_flash_bwd_dkv_kernel(AttnParam
     const unsigned char *mask = P.kpm ? P.kpm + (long)b * P.S : nullptr;
     const bool kin = key < P.S;
     const bool kok = kin && !(mask != nullptr && mask[key] != 0);
+    const bool all_ok = __all(kok);  // wave-uniform: interior key blocks without padding skip the per-element select
     const LaneOffsets lo = lane_offsets(lane);
     bf8 kf[4], vf[4];
     {
@@ -385,6 +405,7 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_flash_bwd_dkv_kernel(AttnParam
     }
     const DropCfg dc(P);
     const float scale2 = P.scale * 1.44269504088896f;
+    const float sk = P.scale * dc.inv_keep;
     f16v dk0, dk1, dv0, dv1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dk0[r] = 0.f, dk1[r] = 0.f, dv0[r] = 0.f, dv1[r] = 0.f;
@@ -398,7 +419,7 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_flash_bwd_dkv_kernel(AttnParam
         if (tid < TR) {
             const int row = t * TR + tid;
             rl = row < P.L ? lse[(long)bh * P.L + row] * 1.44269504088896f : INFINITY;
-            rd = row < P.L ? delta[(long)bh * P.L + row] : 0.f;
+            rd = row < P.L ? delta[(long)bh * P.L + row] / dc.inv_keep : 0.f;  // D * (1 - p_drop), see the dQ kernel
             rrb = dc.on ? attn_rowbase(dc.seed, P.site, (uint32_t)(bh * P.L + row)) : 0u;
         }
     };
@@ -440,16 +461,17 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_flash_bwd_dkv_kernel(AttnParam
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int r = 4 * g + i;
-                    const float pr = kok ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], scale2, -lv[i])) : 0.f;
+                    float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], scale2, -lv[i]));
+                    if (!all_ok) pr = kok ? pr : 0.f;
                     float dpv = dp[r];
                     pd[r] = pr;
                     if (dc.on) {
                         const uint32_t bits = attn_pair_bits(rows_rb[cur][qr0 + i], (uint32_t)key >> 1);
                         const bool keep = ((key & 1) ? (bits >> 16) : (bits & 0xFFFFu)) >= dc.thr;
-                        pd[r] = keep ? pr * dc.inv_keep : 0.f;
-                        dpv = keep ? dpv * dc.inv_keep : 0.f;
+                        pd[r] = keep ? pr : 0.f;  // dV is rescaled by 1 / (1 - p_drop) once, when it is stored
+                        dpv = keep ? dpv : 0.f;
                     }
-                    ds[r] = pr * (dpv - dv4[i]) * P.scale;
+                    ds[r] = pr * (dpv - dv4[i]);  // scale / (1 - p_drop): applied once, to the finished dK
                 }
             }
             // dV^T += dO^T P, dK^T += Q^T dS: slab jq = queries 16 jq .. of this 32-query half
@@ -471,11 +493,11 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_flash_bwd_dkv_kernel(AttnParam
         __syncthreads();
     }
     u16 *stage = smem + w * RW * OS;
-    store_acc_rows(stage, dk0, dk1, 1.f, dk + (long)b * dk_bs + h * HD, dk_ls, k0, P.S, lane);
+    store_acc_rows(stage, dk0, dk1, sk, dk + (long)b * dk_bs + h * HD, dk_ls, k0, P.S, lane);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    store_acc_rows(stage, dv0, dv1, 1.f, dv + (long)b * dv_bs + h * HD, dv_ls, k0, P.S, lane);
+    store_acc_rows(stage, dv0, dv1, dc.inv_keep, dv + (long)b * dv_bs + h * HD, dv_ls, k0, P.S, lane);
 }
 
 inline bool strides_ok(long bs, long ls)

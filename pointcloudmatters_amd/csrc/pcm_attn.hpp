@@ -27,11 +27,26 @@ __device__ __forceinline__ float bf2f(u16 v)
 {
     return __uint_as_float((uint32_t)v << 16);
 }
-__device__ __forceinline__ s4 pack4(float a, float b, float c, float d)  // 2 x v_cvt_pk_bf16_f32
+// two fp32 -> one dword of two bf16 (round to nearest even): ONE v_cvt_pk_bf16_f32.  The library form
+// (__float22bfloat162_rn + reinterpretation) compiled to a conversion per element plus shifts and ors: 4 VALU operations
+// per pair, a quarter of the softmax's instruction count in the attention kernels.
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi)
 {
-    const __hip_bfloat162 lo = __float22bfloat162_rn(make_float2(a, b)), hi = __float22bfloat162_rn(make_float2(c, d));
-    uint2 r = make_uint2(*reinterpret_cast<const uint32_t *>(&lo), *reinterpret_cast<const uint32_t *>(&hi));
-    return *reinterpret_cast<s4 *>(&r);
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ s4 pack4(float a, float b, float c, float d)
+{
+    const uint2 r = make_uint2(cvt_pk_bf16(a, b), cvt_pk_bf16(c, d));
+    return __builtin_bit_cast(s4, r);
+}
+// max of three in one instruction (fmaxf chains also pick up a canonicalising v_max per MFMA output)
+__device__ __forceinline__ float max3f(float a, float b, float c)
+{
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
 }
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 #define PCM_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
