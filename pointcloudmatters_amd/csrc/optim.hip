@@ -132,8 +132,7 @@ __global__ __launch_bounds__(kBlock) void pcm_adamw_flat_kernel(long n4, long n,
         if (MODE & 2) nt_store(mm, m4 + i); else m4[i] = mm;
         if (MODE & 2) nt_store(vv, v4 + i); else v4[i] = vv;
         if (p_bf16) {  // bf16 mirror of the weights for the next step's GEMMs (no per-weight cast kernels)
-            __hip_bfloat16 o[4] = {__float2bfloat16(pp.x), __float2bfloat16(pp.y), __float2bfloat16(pp.z), __float2bfloat16(pp.w)};
-            *reinterpret_cast<uint2 *>(p_bf16 + i * 4) = *reinterpret_cast<const uint2 *>(o);
+            *reinterpret_cast<uint2 *>(p_bf16 + i * 4) = make_uint2(pcm_cvt_pk_bf16(pp.x, pp.y), pcm_cvt_pk_bf16(pp.z, pp.w));
         }
         if (two) {
             adam_elem(pq.x, gq.x, mq.x, vq.x, lr, b1, b2, eps, wd, bc1, bc2s, gscale);
@@ -144,8 +143,7 @@ __global__ __launch_bounds__(kBlock) void pcm_adamw_flat_kernel(long n4, long n,
             if (MODE & 2) nt_store(mq, m4 + j); else m4[j] = mq;
             if (MODE & 2) nt_store(vq, v4 + j); else v4[j] = vq;
             if (p_bf16) {
-                __hip_bfloat16 o[4] = {__float2bfloat16(pq.x), __float2bfloat16(pq.y), __float2bfloat16(pq.z), __float2bfloat16(pq.w)};
-                *reinterpret_cast<uint2 *>(p_bf16 + j * 4) = *reinterpret_cast<const uint2 *>(o);
+                *reinterpret_cast<uint2 *>(p_bf16 + j * 4) = make_uint2(pcm_cvt_pk_bf16(pq.x, pq.y), pcm_cvt_pk_bf16(pq.z, pq.w));
             }
         }
     }

@@ -44,6 +44,15 @@ __device__ __forceinline__ uint32_t pcm_wave_min_u32(uint32_t v)
     return min(min(a, b), min(c, d));
 }
 
+// two fp32 -> one dword holding two bf16 (round to nearest even), ONE v_cvt_pk_bf16_f32 (gfx950).  The library route
+// (__float2bfloat16 per element + reinterpretation) costs a conversion per element plus a shift and an or per pair.
+__device__ __forceinline__ uint32_t pcm_cvt_pk_bf16(float lo, float hi)
+{
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
 __device__ __forceinline__ int pcm_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 // Squared distance in the reference's order: (a-b)*(a-b) for x, y, z summed left to right.

@@ -57,8 +57,7 @@ __device__ __forceinline__ void store4<float>(float *p, const float (&o)[4])
 template <>
 __device__ __forceinline__ void store4<__hip_bfloat16>(__hip_bfloat16 *p, const float (&o)[4])
 {
-    __hip_bfloat16 t[4] = {__float2bfloat16(o[0]), __float2bfloat16(o[1]), __float2bfloat16(o[2]), __float2bfloat16(o[3])};
-    *reinterpret_cast<uint2 *>(p) = *reinterpret_cast<const uint2 *>(t);
+    *reinterpret_cast<uint2 *>(p) = make_uint2(pcm_cvt_pk_bf16(o[0], o[1]), pcm_cvt_pk_bf16(o[2], o[3]));
 }
 
 

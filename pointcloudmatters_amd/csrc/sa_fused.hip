@@ -155,8 +155,7 @@ __device__ __forceinline__ void store_vec(T *dst, const float (&in)[VEC])
         uint32_t w[VEC / 2];
 #pragma unroll
         for (int v = 0; v < VEC; v += 2) {
-            const __hip_bfloat16 lo = __float2bfloat16(in[v]), hi = __float2bfloat16(in[v + 1]);
-            w[v / 2] = (uint32_t)(*reinterpret_cast<const uint16_t *>(&lo)) | ((uint32_t)(*reinterpret_cast<const uint16_t *>(&hi)) << 16);
+            w[v / 2] = pcm_cvt_pk_bf16(in[v], in[v + 1]);
         }
         if constexpr (VEC == 8)
             *reinterpret_cast<uint4 *>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
