@@ -45,7 +45,8 @@ def build_act_policy(pcd_npoints, pointops=None, sa_impl="reference", overlap_sa
         env_state_dim=0, latent_dim=c["latent_dim"], action_loss=nn.MSELoss(reduction="none"),
         klloss=KLDivergence(), kl_weight=c["kl_weight"], goal_cond_dim=c["goal_cond_dim"],
         pcd_nsample=c["pcd_nsample"], pcd_npoints=pcd_npoints, pointops=pointops, sa_impl=sa_impl,
-        overlap_sampling=overlap_sampling, dead_decoder_layers=dead_decoder_layers, **extra,
+        overlap_sampling=overlap_sampling, dead_decoder_layers=dead_decoder_layers,
+        use_mask=c.get("use_mask", False), bg_ratio=c.get("bg_ratio", 0.0), **extra,
     )
 
 
@@ -74,7 +75,8 @@ def build_dp_policy(pcd_npoints, pointops=None, sa_impl="reference", overlap_sam
         enc = PCDObsEncoder(shape_meta=shape_meta, pcd_model=pcd_model, share_pcd_model=True, n_obs_step=c["n_obs_steps"],
                             pcd_nsample=c["pcd_nsample"], pcd_npoints=pcd_npoints, pcd_hidden_dim=c["pcd_hidden_dim"],
                             projector_layers=c["projector_layers"], projector_channels=c["projector_channels"],
-                            pointops=pointops, sa_impl=sa_impl, overlap_sampling=overlap_sampling)
+                            pointops=pointops, sa_impl=sa_impl, overlap_sampling=overlap_sampling,
+                            use_mask=c.get("use_mask", False), bg_ratio=c.get("bg_ratio", 0.0))
     sched = DDPMSchedule(num_train_timesteps=c["num_train_timesteps"], beta_schedule="squaredcos_cap_v2",
                          prediction_type="epsilon")
     pol = DiffusionUnetPcdPolicy(shape_meta=shape_meta, noise_scheduler=sched, obs_encoder=enc, horizon=c["horizon"],

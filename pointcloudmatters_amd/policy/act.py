@@ -78,10 +78,8 @@ class ACTPCD(nn.Module):
         super().__init__()
         if backbone is None:
             raise ValueError("ACTPCD needs a point-cloud backbone")
-        if use_mask:
-            # act.py:396-442 indexes the unmasked cloud with indices local to the masked subset and
-            # concatenates fg/bg batch-major, breaking the (b n) token layout -- unsupported here.
-            raise NotImplementedError("use_mask=True (foreground/background split FPS) is not supported")
+        if not 0.0 <= bg_ratio < 1.0:
+            raise ValueError("bg_ratio must be in [0, 1)")
         if pre_sample:
             raise NotImplementedError("pre_sample=True is not used by any shipped config")
         if "fps" not in sampling:
@@ -197,7 +195,8 @@ class ACTPCD(nn.Module):
         """(p (n,3), x (n,c), o (b)) -> [n_p (m,3), x (m,H), n_o (b)] -- the set-abstraction layer."""
         p, x, o = pxo
         n_o = self._new_offsets(o)
-        out = set_abstraction(self, self.pointops, p, x, o, n_o, impl=self.sa_impl)
+        pre = set_abstraction.sample_and_query(self, self.pointops, p, o, n_o, mask=mask)
+        out = set_abstraction(self, self.pointops, p, x, o, n_o, impl=self.sa_impl, pre=pre)
         n_p, feat, idx = out
         if return_index:
             return [n_p, feat, n_o, idx]
@@ -209,13 +208,19 @@ class ACTPCD(nn.Module):
     def prefetch_sampling(self, pcd_dict):
         """Start FPS + kNN for a future batch's clouds on the side stream (see sa_layer.prefetch_sampling)."""
         coord, offset = pcd_dict["coord"], pcd_dict["offset"]
-        set_abstraction.prefetch_sampling(self, self.pointops, coord, offset, self._new_offsets(offset))
+        set_abstraction.prefetch_sampling(self, self.pointops, coord, offset, self._new_offsets(offset),
+                                          mask=self._mask_of(pcd_dict))
 
     def sampling_for(self, pcd_dict, overlap=True):
         """FPS / kNN / index statistics of these clouds: the prefetched result if `prefetch_sampling` saw them, else
         computed now (on the side stream with `overlap`)."""
         coord, offset = pcd_dict["coord"], pcd_dict["offset"]
-        return set_abstraction.sample_and_query(self, self.pointops, coord, offset, self._new_offsets(offset), overlap=overlap)
+        return set_abstraction.sample_and_query(self, self.pointops, coord, offset, self._new_offsets(offset), overlap=overlap,
+                                                mask=self._mask_of(pcd_dict))
+
+    def _mask_of(self, pcd_dict):
+        """act.py:511-515: with ``use_mask`` the batch must carry the per-point foreground mask (KeyError otherwise)."""
+        return pcd_dict["mask"] if self.use_mask else None
 
     def install_static_sampling(self, pcd_dict, pre):
         set_abstraction.install_static(self, pcd_dict["coord"], pcd_dict["offset"], pre)
@@ -228,7 +233,7 @@ class ACTPCD(nn.Module):
         n_o = self._new_offsets(offset)
         # indices first (coordinates only), overlapped with the backbone when on the GPU
         pre = set_abstraction.sample_and_query(self, self.pointops, coord, offset, n_o,
-                                               overlap=self.overlap_sampling and coord.is_cuda)
+                                               overlap=self.overlap_sampling and coord.is_cuda, mask=self._mask_of(pcd_dict))
         features = self.backbone(pcd_dict)
         n_p, tokens, _ = set_abstraction(self, self.pointops, coord, features, offset, n_o, impl=self.sa_impl, pre=pre)
         b = offset.shape[0]

@@ -429,8 +429,11 @@ class PCDObsEncoder(_AttrMixin):
                  use_mask=False, bg_ratio=0.0, pcd_hidden_dim=128, projector_layers=2, projector_channels=(128, 128, 128),
                  pre_sample=False, in_channel=6, pointops=None, sa_impl="reference", overlap_sampling=True, **kwargs):
         super().__init__()
-        if use_mask or pre_sample or not share_pcd_model:
-            raise NotImplementedError("use_mask / pre_sample / per-key pcd models are not used by any shipped config")
+        if pre_sample or not share_pcd_model:
+            raise NotImplementedError("pre_sample / per-key pcd models are not used by any shipped config")
+        if not 0.0 <= bg_ratio < 1.0:
+            raise ValueError("bg_ratio must be in [0, 1)")
+        self.use_mask, self.bg_ratio = use_mask, bg_ratio
         if pointops is None:
             from .. import pointops as _hip_pointops
 
@@ -475,13 +478,19 @@ class PCDObsEncoder(_AttrMixin):
 
     def prefetch_sampling(self, pcd_dict):
         coord, offset = pcd_dict["coord"], pcd_dict["offset"]
-        set_abstraction.prefetch_sampling(self, self.pointops, coord, offset, self._new_offsets(offset))
+        set_abstraction.prefetch_sampling(self, self.pointops, coord, offset, self._new_offsets(offset),
+                                          mask=self._mask_of(pcd_dict))
 
     def sampling_for(self, pcd_dict, overlap=True):
         """FPS / kNN / index statistics of these clouds: the prefetched result if `prefetch_sampling` saw them, else
         computed now (on the side stream with `overlap`)."""
         coord, offset = pcd_dict["coord"], pcd_dict["offset"]
-        return set_abstraction.sample_and_query(self, self.pointops, coord, offset, self._new_offsets(offset), overlap=overlap)
+        return set_abstraction.sample_and_query(self, self.pointops, coord, offset, self._new_offsets(offset), overlap=overlap,
+                                                mask=self._mask_of(pcd_dict))
+
+    def _mask_of(self, pcd_dict):
+        """pcd_obs_encoder.py:203-207: with ``use_mask`` the clouds must carry the per-point foreground mask."""
+        return pcd_dict["mask"] if self.use_mask else None
 
     def install_static_sampling(self, pcd_dict, pre):
         set_abstraction.install_static(self, pcd_dict["coord"], pcd_dict["offset"], pre)
@@ -497,7 +506,7 @@ class PCDObsEncoder(_AttrMixin):
         coord, offset = pcd_dict["coord"], pcd_dict["offset"]
         n_o = self._new_offsets(offset)
         pre = set_abstraction.sample_and_query(self, self.pointops, coord, offset, n_o,
-                                               overlap=self.overlap_sampling and coord.is_cuda)
+                                               overlap=self.overlap_sampling and coord.is_cuda, mask=self._mask_of(pcd_dict))
         features = pcd_model(pcd_dict)
         return set_abstraction(self, self.pointops, coord, features, offset, n_o, impl=self.sa_impl, pre=pre)[1]
 

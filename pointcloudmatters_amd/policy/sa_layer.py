@@ -44,13 +44,37 @@ def coord_embedding_sine(coord, hidden_dim, temperature=10000, normalize=False, 
     return pos
 
 
-def sample_and_query(owner, pointops, p, o, n_o, overlap=False):
+def masked_fps(owner, pointops, p, o, n_o, mask):
+    """The ``use_mask`` branch of ``pcd_sampling`` (reference act.py:394-442, pcd_obs_encoder.py:131-180), literally:
+    FPS runs over the foreground subset ``p[mask]`` (and, with ``bg_ratio`` > 0, over the background subset for the
+    last ``int(npoints * bg_ratio)`` samples of every cloud), and the returned indices are LOCAL TO THOSE SUBSETS,
+    foreground block first -- exactly what the reference then uses to index the unmasked cloud.  The per-cloud subset
+    sizes come from one cumulative sum instead of the reference's per-cloud ``.item()`` loop; the boolean gather still
+    needs its size on the host, so this branch cannot be captured into a graph."""
+    if p.is_cuda and torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("use_mask sampling has data-dependent sizes and cannot run under graph capture")
+    mask = mask.bool()
+    b = o.shape[0]
+    last = o.long() - 1
+    n_bg = int(owner.pcd_npoints * owner.bg_ratio) if owner.bg_ratio > 0.0 else 0
+    steps = torch.arange(1, b + 1, device=o.device, dtype=torch.int32)
+    fg_n_o = steps * (owner.pcd_npoints - n_bg) if n_bg else n_o
+    fg_o = torch.cumsum(mask, 0, dtype=torch.int32)[last]
+    idx = pointops.farthest_point_sampling(p[mask], fg_o, fg_n_o)
+    if n_bg:
+        bg_o = torch.cumsum(~mask, 0, dtype=torch.int32)[last]
+        idx = torch.cat([idx, pointops.farthest_point_sampling(p[~mask], bg_o, steps * n_bg)], dim=0)
+    return idx
+
+
+def sample_and_query(owner, pointops, p, o, n_o, overlap=False, mask=None):
     """Coordinate-only part of the layer: FPS indices, sampled centres, kNN lists.
 
     With ``overlap`` the three launches go to a side HIP stream so they run concurrently with
     whatever the caller enqueues next on the current stream (the PointNet MLP); ``wait()`` joins.
     """
     nsample = owner.pcd_nsample
+    masked = bool(getattr(owner, "use_mask", False)) and mask is not None
     static = owner.__dict__.get("_static_pre")
     if static is not None and static["key"] == _key(p, o):
         return static["pre"]  # graph mode: the indices live in static buffers that the trainer fills before each replay
@@ -64,7 +88,10 @@ def sample_and_query(owner, pointops, p, o, n_o, overlap=False):
 
     def run():
         with torch.no_grad():
-            idx = pointops.farthest_point_sampling(p, o, n_o)  # (m) int32
+            if masked:
+                idx = masked_fps(owner, pointops, p, o, n_o, mask)
+            else:
+                idx = pointops.farthest_point_sampling(p, o, n_o)  # (m) int32
             n_p = p[idx.long(), :]  # (m, 3)
             knn_idx, _ = pointops.knn_query(nsample, p, o, n_p, n_o)
             istats = None
@@ -117,7 +144,7 @@ def load_static(owner, pre):
     torch._foreach_copy_(_pre_tensors(static), _pre_tensors(pre))
 
 
-def prefetch_sampling(owner, pointops, p, o, n_o):
+def prefetch_sampling(owner, pointops, p, o, n_o, mask=None):
     """FPS + kNN depend on the coordinates only, i.e. on the INPUT batch, not on any weight: like a data-loader worker they
     can run one batch ahead.  Launches them now on the side stream for the coordinates of a FUTURE batch; the next
     ``sample_and_query`` called with the same tensors picks the result up instead of computing it on the critical path.
@@ -127,7 +154,7 @@ def prefetch_sampling(owner, pointops, p, o, n_o):
     key = (p.data_ptr(), tuple(p.shape), o.data_ptr())
     ready = owner.__dict__.setdefault("_prefetched", {})
     if key not in ready:
-        ready[key] = (sample_and_query(owner, pointops, p, o, n_o, overlap=True), p, o)  # p, o kept alive with the result
+        ready[key] = (sample_and_query(owner, pointops, p, o, n_o, overlap=True, mask=mask), p, o)  # p, o kept alive with the result
 
 
 def set_abstraction(owner, pointops, p, x, o, n_o, impl="reference", pre=None):

@@ -438,6 +438,83 @@ def golden_dp_rlbench(ref):
 
 
 
+def fg_mask(coord, offset, seed, frac=0.6):
+    """A seeded per-point foreground mask (~`frac` of every cloud), like the datasets' `pcd["mask"]`
+    (maniskill2_single_task_pcd_act.py:229, rlbench_single_task_act.py:307)."""
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(coord.shape[0], generator=g) < frac
+
+
+def golden_mask(ref):
+    """The `use_mask` / `bg_ratio` branch of pcd_sampling (act.py:394-442, pcd_obs_encoder.py:131-180): reference ACTPCD and
+    PCDObsEncoder with foreground/background split FPS.  Weights and inputs are those of act_pcd_small.npz / dp_pcd_small.npz
+    (same seeds); only the mask, the sampled indices and the outputs are stored."""
+    from oracle import pointops_cpu
+    from pointcloudmatters_amd.bc import build_dp_policy, make_act_batch, make_dp_batch
+    from pointcloudmatters_amd.policy import PointNet
+
+    fx = {}
+    pcd_npoints = 32
+    ours = build_ours(pcd_npoints, seed=1234)
+    old = np.load(os.path.join(OUT, "act_pcd_small.npz"))
+    assert all(np.array_equal(old[f"w.{k}"], v.numpy()) for k, v in ours.state_dict().items())
+    batch = make_act_batch(3, 180, seed=77, ragged=True, num_queries=SMALL["num_queries"])
+    assert np.array_equal(old["in.pcds.coord"], batch["pcds"]["coord"].numpy())
+    eps = torch.from_numpy(old["eps"])
+    mask = fg_mask(batch["pcds"]["coord"], batch["pcds"]["offset"], seed=int(os.environ.get("PCM_MASK_SEED", 21)))
+    fx["act.mask"] = mask.numpy()
+    for tag, bg in (("bg25", 0.25), ("bg0", 0.0)):
+        model = build_reference_actpcd(ref, ours, pcd_npoints)
+        model.use_mask, model.bg_ratio = True, bg
+        model.train()
+        orig = ref.act.reparametrize
+        ref.act.reparametrize = lambda mu, logvar: mu + logvar.div(2).exp() * eps
+        try:
+            dd = {k: (dict(v) if isinstance(v, dict) else v) for k, v in batch.items()}
+            dd["pcds"]["offset"] = dd["pcds"]["offset"].clone()
+            dd["pcds"]["mask"] = mask
+            with torch.no_grad():
+                p, o = dd["pcds"]["coord"], dd["pcds"]["offset"]
+                idx = model.pcd_sampling((p, torch.zeros(p.shape[0], model.backbone.num_channels), o), mask, return_index=True)[3]
+            model.bn.running_mean.zero_(), model.bn.running_var.fill_(1.0), model.bn.num_batches_tracked.zero_()
+            out = model(dd)
+            out["loss"].backward()
+        finally:
+            ref.act.reparametrize = orig
+        fx[f"act.{tag}.idx"] = idx.numpy()
+        for k in ("a_hat", "loss", "src", "pos"):
+            fx[f"act.{tag}.out.{k}"] = out[k].detach().numpy()
+        grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+        for k in ("linear.weight", "backbone.conv1.0.weight", "transformer.encoder.layers.0.self_attn.in_proj_weight"):
+            fx[f"act.{tag}.grad.{k}"] = grads[k].numpy()
+        print(f"mask_ref.npz act {tag}: loss", float(out["loss"]), "idx[:6]", idx[:6].tolist())
+    # ---- Diffusion-Policy observation encoder
+    torch.manual_seed(4321)
+    dp = build_dp_policy(pcd_npoints=pcd_npoints, pointops=pointops_cpu, sa_impl="reference", **DP_SMALL)
+    sd = dp.state_dict()
+    oldd = np.load(os.path.join(OUT, "dp_pcd_small.npz"))
+    assert all(np.array_equal(oldd[f"w.{k}"], v.numpy()) for k, v in sd.items())
+    shape_meta = {"obs": {"pcds": {"shape": [6], "type": "pcd"}, "qpos": {"shape": [9], "type": "low_dim"}},
+                  "action": {"shape": [7]}}
+    enc = ref.pcd_enc.PCDObsEncoder(shape_meta=shape_meta, pcd_model=PointNet(in_channels=6, num_classes=24),
+                                    share_pcd_model=True, n_obs_step=2, pcd_nsample=16, pcd_npoints=pcd_npoints,
+                                    pcd_hidden_dim=24, projector_layers=1, projector_channels=[24, 40, 40],
+                                    use_mask=True, bg_ratio=0.25)
+    enc.load_state_dict({k[len("obs_encoder."):]: v for k, v in sd.items() if k.startswith("obs_encoder.")}, strict=True)
+    enc.train()
+    dbatch = make_dp_batch(3, 150, seed=11, ragged=True)
+    pc = {k: v.clone() for k, v in dbatch["obs"]["pcds"].items()}
+    dmask = fg_mask(pc["coord"], pc["offset"], seed=22)
+    pc["mask"] = dmask
+    feat = enc({"qpos": dbatch["obs"]["qpos"][:, :2].reshape(-1, 9), "pcds": pc})
+    (feat * torch.sin(torch.arange(feat.numel(), device=feat.device).float()).view_as(feat)).sum().backward()
+    fx["dp.mask"] = dmask.numpy()
+    fx["dp.bg25.feat"] = feat.detach().numpy()
+    fx["dp.bg25.grad.linear.weight"] = enc.linear.weight.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "mask_ref.npz"), **fx)
+    print("mask_ref.npz: dp feat", tuple(feat.shape))
+
+
 def golden_rollout(ref):
     """The policy side of a rollout step, from the reference's own Python:
       * TemporalAgg (src/utils/misc.py:88-141) fed a seeded sequence of action chunks;
@@ -554,6 +631,6 @@ if __name__ == "__main__":
     only = set(sys.argv[1:])  # e.g. `make_golden.py rollout` regenerates one fixture
     for name, fn in (("act", golden_act), ("grouping", golden_grouping), ("misc", golden_misc), ("dp", golden_dp),
                      ("rollout", golden_rollout), ("gridsample", golden_gridsample), ("rlbench", golden_rlbench),
-                     ("dp_rlbench", golden_dp_rlbench)):
+                     ("dp_rlbench", golden_dp_rlbench), ("mask", golden_mask)):
         if not only or name in only:
             fn(ref)

@@ -1,0 +1,140 @@
+"""The ``use_mask`` / ``bg_ratio`` branch of ``pcd_sampling`` (reference act.py:394-442, pcd_obs_encoder.py:131-180):
+foreground / background split FPS whose subset-local indices then index the unmasked cloud -- reproduced literally.
+
+Fixture: tests/golden/mask_ref.npz (reference ACTPCD / PCDObsEncoder run by tests/golden/make_golden.py ``mask``; weights
+and inputs are those of act_pcd_small.npz / dp_pcd_small.npz).  Indices exact, features / loss / gradients 1e-4.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.test_golden_cpu import ATOL, RTOL, _load, load_act_fixture, load_dp_fixture
+
+
+def _act_policy(pointops, sa_impl, weights, bg, device="cpu"):
+    from pointcloudmatters_amd.bc import build_act_policy
+    from tests.golden.make_golden import SMALL
+
+    pol = build_act_policy(pcd_npoints=32, pointops=pointops, sa_impl=sa_impl, overlap_sampling=device != "cpu",
+                           use_mask=True, bg_ratio=bg, **SMALL)
+    pol.load_state_dict(weights, strict=True)
+    return pol.to(device).train()
+
+
+def _check_act(pointops, sa_impl, tag, bg, device="cpu"):
+    mx = _load("mask_ref.npz")
+    _, batch, weights = load_act_fixture(device)
+    batch["pcds"]["mask"] = torch.from_numpy(mx["act.mask"]).to(device)
+    pol = _act_policy(pointops, sa_impl, weights, bg, device)
+    pre = pol.sampling_for(batch["pcds"], overlap=False)
+    assert np.array_equal(pre["idx"].cpu().numpy(), mx[f"act.{tag}.idx"])
+    out = pol(batch)
+    out["loss"].backward()
+    for k in ("a_hat", "loss", "src", "pos"):
+        np.testing.assert_allclose(out[k].detach().float().cpu().numpy(), mx[f"act.{tag}.out.{k}"], rtol=RTOL, atol=ATOL, err_msg=k)
+    grads = dict(pol.named_parameters())
+    pre_ = f"act.{tag}.grad."
+    for k in mx.files:
+        if k.startswith(pre_):
+            ref = mx[k]
+            g = grads[k[len(pre_):]].grad.detach().cpu().numpy()
+            # the first PointNet layer sits behind five training-mode BatchNorms: its weight gradient is a sum that cancels
+            # to ~1e-3 of its terms, and the SAME code on 1 vs N CPU threads already differs by up to 2e-3 there
+            tol = 5e-3 if "backbone" in k else 1e-4
+            assert np.abs(g - ref).max() <= tol * (np.abs(ref).max() + 1e-12) + 1e-6, k
+
+
+def _check_dp(pointops, sa_impl, device="cpu"):
+    from pointcloudmatters_amd.bc import build_dp_policy
+    from tests.golden.make_golden import DP_SMALL
+
+    mx = _load("mask_ref.npz")
+    _, batch, weights = load_dp_fixture(device)
+    pol = build_dp_policy(pcd_npoints=32, pointops=pointops, sa_impl=sa_impl, overlap_sampling=device != "cpu",
+                          use_mask=True, bg_ratio=0.25, **DP_SMALL)
+    pol.load_state_dict(weights, strict=True)
+    enc = pol.obs_encoder.to(device).train()
+    pcds = dict(batch["obs"]["pcds"], mask=torch.from_numpy(mx["dp.mask"]).to(device))
+    feat = enc({"qpos": batch["obs"]["qpos"][:, :2].reshape(-1, 9), "pcds": pcds})
+    np.testing.assert_allclose(feat.detach().float().cpu().numpy(), mx["dp.bg25.feat"], rtol=RTOL, atol=ATOL)
+    (feat * torch.sin(torch.arange(feat.numel(), device=feat.device).float()).view_as(feat)).sum().backward()
+    ref = mx["dp.bg25.grad.linear.weight"]
+    g = enc.linear.weight.grad.cpu().numpy()
+    assert np.abs(g - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-6
+
+
+@pytest.mark.parametrize("tag,bg", [("bg25", 0.25), ("bg0", 0.0)])
+@pytest.mark.parametrize("sa_impl", ["reference", "torch"])
+def test_act_mask_sampling_matches_reference_cpu(sa_impl, tag, bg):
+    from oracle import pointops_cpu
+
+    _check_act(pointops_cpu, sa_impl, tag, bg)
+
+
+def test_dp_mask_sampling_matches_reference_cpu():
+    from oracle import pointops_cpu
+
+    _check_dp(pointops_cpu, "reference")
+
+
+def test_mask_is_required_and_ratio_checked():
+    from oracle import pointops_cpu
+
+    _, batch, weights = load_act_fixture()
+    pol = _act_policy(pointops_cpu, "reference", weights, 0.25)
+    with pytest.raises(KeyError):  # act.py:514 reads pcd_dict["mask"] unconditionally when use_mask is set
+        pol(batch)
+    with pytest.raises(ValueError):
+        _act_policy(pointops_cpu, "reference", weights, 1.0)
+    # use_mask off: a mask in the batch is ignored (act.py:394)
+    from tests.test_golden_cpu import build_small_policy, check_against_fixture
+
+    fx, batch, weights = load_act_fixture()
+    batch["pcds"]["mask"] = torch.from_numpy(_load("mask_ref.npz")["act.mask"])
+    pol = build_small_policy(pointops_cpu, "reference", weights)
+    out = pol(batch)
+    out["loss"].backward()
+    check_against_fixture(fx, pol, out)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,bg", [("bg25", 0.25), ("bg0", 0.0)])
+@pytest.mark.parametrize("sa_impl", ["reference", "torch", "fused"])
+def test_act_mask_sampling_matches_reference_gpu(hip_device, sa_impl, tag, bg):
+    import pointcloudmatters_amd.pointops as po
+
+    _check_act(po, sa_impl, tag, bg, device=hip_device)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sa_impl", ["torch", "fused"])
+def test_dp_mask_sampling_matches_reference_gpu(hip_device, sa_impl):
+    import pointcloudmatters_amd.pointops as po
+
+    _check_dp(po, sa_impl, device=hip_device)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["eager", "flat", "hybrid", "graph"])
+def test_mask_sampling_in_every_trainer_mode(hip_device, mode):
+    """The masked branch computes data-dependent subset sizes on the host, so it must stay outside any captured graph:
+    every trainer mode gives the eager losses."""
+    from pointcloudmatters_amd.bc import BCTrainer, build_act_policy, clone_batch, make_act_batch
+
+    def run(m):
+        torch.manual_seed(0)
+        pol = build_act_policy(pcd_npoints=64, sa_impl="fused", dropout=0.0, hidden_dim=96, nhead=4, num_encoder_layers=1,
+                               num_decoder_layers=1, use_mask=True, bg_ratio=0.25).to(hip_device)
+        tr = BCTrainer(pol, total_steps=50, precision="fp32", device=hip_device, mode=m, optim=dict(accumulate_grad_batches=1))
+        losses = []
+        for i in range(4):
+            b = make_act_batch(3, 400, seed=10 + i, device=hip_device)  # graph mode: equal cloud sizes
+            b["pcds"]["mask"] = torch.rand(b["pcds"]["coord"].shape[0], device=hip_device,
+                                           generator=torch.Generator(hip_device).manual_seed(i)) < 0.6
+            b["vae_eps"] = torch.randn(3, 32, generator=torch.Generator().manual_seed(i)).to(hip_device)
+            losses.append(float(tr.training_step(clone_batch(b))["loss"]))
+        return losses
+
+    ref = run("eager")
+    got = run(mode)
+    np.testing.assert_allclose(got, ref, rtol=2e-3)
