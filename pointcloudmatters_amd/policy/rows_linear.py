@@ -16,19 +16,20 @@ from torch.autograd import Function
 MIN_ROWS = 2048        # below this the plain GEMM is as fast
 TARGET_CHUNK = 768     # rows per partial product
 MAX_SPLITS = 64
+MAX_PARTIAL_BYTES = 64 << 20  # fp32 partial products of one weight gradient (S x m x k)
 
 
-def _splits(rows):
-    """Number of row blocks.  Powers of two first: measured on MI355X (bf16, device time), hipBLASLt's batched kernels for
+def _splits(rows, s_max=MAX_SPLITS):
+    """Number of row blocks (at most `s_max`).  Powers of two first: measured on MI355X (bf16, device time), hipBLASLt's batched kernels for
     S = 4 / 8 / 16 are up to 2x faster than for S = 5 at the same total work (4120 x 1024 x 512: 24 us vs 51 us), so the
     largest power of two that divides the rows and leaves >= TARGET_CHUNK rows per block wins; any other divisor close to
     the target is the fallback."""
     s = MAX_SPLITS
     while s >= 2:
-        if rows % s == 0 and rows // s >= TARGET_CHUNK:
+        if s <= s_max and rows % s == 0 and rows // s >= TARGET_CHUNK:
             return s
         s //= 2
-    s = max(1, min(MAX_SPLITS, rows // TARGET_CHUNK))
+    s = max(1, min(s_max, rows // TARGET_CHUNK))
     for cand in range(s, max(1, s // 2), -1):  # an exact divisor close to the target
         if rows % cand == 0:
             return cand
@@ -101,14 +102,17 @@ def weight_grad(go, x, out_dtype, out=None, side=False):
 def _weight_grad(go, x, out_dtype, out=None):
     rows, m = go.shape
     k = x.shape[1]
-    if rows < MIN_ROWS or m * k > 1024 * 1024:
+    # wide outputs (the decoder's 7-layer key / value projection: 3584 x 512) are split too, as long as the fp32
+    # partials stay small: unsplit, hipBLASLt runs that product on 65 workgroups (216 us at 16408 rows)
+    s_max = min(MAX_SPLITS, MAX_PARTIAL_BYTES // (m * k * 4))
+    if rows < MIN_ROWS or s_max < 2:
         if out is not None and out.dtype == go.dtype and out.is_contiguous():
             return torch.mm(go.t(), x, out=out)  # straight into the (slice of the) packed gradient: no copy kernel
         dw = go.t() @ x
         if out is not None:
             return out.copy_(dw)
         return dw.to(out_dtype)
-    s = _splits(rows)
+    s = _splits(rows, s_max)
     chunk = rows // s
     main = s * chunk
     a, b = go[:main].view(s, chunk, m).transpose(1, 2), x[:main].view(s, chunk, k)

@@ -33,7 +33,7 @@ def _st(t):
 
 class _SmallAttn(Function):
     @staticmethod
-    def forward(ctx, q, k, v, kpm, heads, p_drop, seed, site):
+    def forward(ctx, q, k, v, kpm, heads, p_drop, seed, site, slots=(None, None)):
         L_ = _lib.load()
         B, L, E = q.shape
         S = k.shape[1]
@@ -51,6 +51,7 @@ class _SmallAttn(Function):
         _lib.check(rc, "pcm_attn_flash_forward_hip" if use_flash else "pcm_attn_small_forward_hip")
         ctx.save_for_backward(q, k, v, out, lse, kpm)
         ctx.meta = (heads, float(p_drop), seed, int(site), use_flash)
+        ctx.slots = slots
         return out
 
     @staticmethod
@@ -68,8 +69,8 @@ class _SmallAttn(Function):
                 dq, dk = dqk[:, :, 0], dqk[:, :, 1]
             else:
                 dq = torch.empty(B, L, E, dtype=torch.bfloat16, device=dev)
-                dk = torch.empty(B, S, E, dtype=torch.bfloat16, device=dev)
-            dv = torch.empty(B, S, E, dtype=torch.bfloat16, device=dev)
+                dk = _grad_buffer(ctx.slots[0], B, S, E, dev)
+            dv = _grad_buffer(ctx.slots[1], B, S, E, dev)
             head = (B, heads, L, S, q.data_ptr(), *_st(q), k.data_ptr(), *_st(k), v.data_ptr(), *_st(v),
                     kpm.data_ptr() if kpm is not None else 0, 1.0 / math.sqrt(E // heads), p_drop,
                     seed.data_ptr() if seed is not None else 0, site, out.data_ptr(), dout.data_ptr(), lse.data_ptr())
@@ -80,7 +81,17 @@ class _SmallAttn(Function):
             else:
                 rc = L_.pcm_attn_small_backward_hip(*head, *tail)
         _lib.check(rc, "pcm_attn_flash_backward_hip" if use_flash else "pcm_attn_small_backward_hip")
-        return dq, dk, dv, None, None, None, None, None
+        return dq, dk, dv, None, None, None, None, None, None
+
+
+def _grad_buffer(slot, B, S, E, dev):
+    """Where dK / dV go: the caller's shared gradient buffer (transformer.GradArena, written through its strides) when
+    the tensor came out of a `shared_unbind`, else a fresh (B, S, E) tensor."""
+    if slot is not None:
+        arena, l = slot
+        if arena.shape == (B, S, E) and arena.dtype == torch.bfloat16:
+            return arena.slot(l)
+    return torch.empty(B, S, E, dtype=torch.bfloat16, device=dev)
 
 
 def supported(q, k, v, heads, dropout_p=0.0):
@@ -114,4 +125,5 @@ def small_attention(q, k, v, key_padding_mask, heads, dropout_p=0.0):
         kpm = kpm.view(torch.uint8) if kpm.dtype == torch.bool else kpm.to(torch.uint8)
     ctx = fused_ops.current()
     seed, site = (ctx.seed, ctx.next_site()) if dropout_p > 0 else (None, 0)
-    return _SmallAttn.apply(q, k, v, kpm, heads, dropout_p, seed, site)
+    slots = (getattr(k, "_pcm_grad_slot", None), getattr(v, "_pcm_grad_slot", None))
+    return _SmallAttn.apply(q, k, v, kpm, heads, dropout_p, seed, site, slots)

@@ -152,6 +152,66 @@ def attention(
     return linear_rows(out, mha.out_proj.weight, mha.out_proj.bias)
 
 
+class GradArena:
+    """One (B, S, n, E) buffer for the gradients of the n tensors a `shared_unbind` hands out.  A consumer whose backward
+    can write through strides (policy/small_attn.py) asks for `slot(l)` and writes its gradient there; when every
+    gradient that comes back to the unbind IS its slot, the stacked gradient is the buffer itself and the n-way copy
+    (235 MB of traffic per projection at the 2051-token shape) never happens."""
+
+    hits = 0  # backward passes that returned the shared buffer without a copy (tests read it)
+
+    def __init__(self, n, shape, dtype, device):
+        self.n, self.shape, self.dtype, self.device = n, tuple(shape), dtype, device
+        self.buf = None
+
+    def slot(self, l):
+        if self.buf is None:
+            b, s, e = self.shape
+            self.buf = torch.empty(b, s, self.n, e, dtype=self.dtype, device=self.device)
+        return self.buf[:, :, l]
+
+    def is_slot(self, g, l):
+        if self.buf is None or g is None or g.dtype != self.buf.dtype:
+            return False
+        ref = self.buf[:, :, l]
+        return g.data_ptr() == ref.data_ptr() and g.shape == ref.shape and g.stride() == ref.stride()
+
+
+class _SharedUnbind(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, n, arena):
+        ctx.arena, ctx.n = arena, n
+        ctx.set_materialize_grads(False)
+        return y.unflatten(-1, (n, y.shape[-1] // n)).unbind(-2)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        arena, n = ctx.arena, ctx.n
+        hits = [arena.is_slot(g, l) for l, g in enumerate(grads)]
+        if any(hits) and all(h or g is None for h, g in zip(hits, grads)):
+            for l, g in enumerate(grads):
+                if g is None:  # a layer autograd never visited ("prune_backward")
+                    arena.slot(l).zero_()
+            buf, arena.buf = arena.buf, None
+            GradArena.hits += 1
+            return buf.flatten(-2), None, None
+        arena.buf = None
+        ref = next(g for g in grads if g is not None)
+        return torch.stack([g if g is not None else torch.zeros_like(ref) for g in grads], dim=-2).flatten(-2), None, None
+
+
+def shared_unbind(y, n):
+    """``y.unflatten(-1, (n, E)).unbind(-2)`` for (B, S, n*E) activations whose n consumers may write their gradients straight
+    into one shared buffer (GradArena): each returned tensor carries ``_pcm_grad_slot = (arena, l)``."""
+    if not (y.is_cuda and y.dim() == 3 and y.requires_grad and torch.is_grad_enabled()):
+        return y.unflatten(-1, (n, y.shape[-1] // n)).unbind(-2)
+    arena = GradArena(n, (y.shape[0], y.shape[1], y.shape[2] // n), y.dtype, y.device)
+    outs = _SharedUnbind.apply(y, n, arena)
+    for l, o in enumerate(outs):
+        o._pcm_grad_slot = (arena, l)
+    return outs
+
+
 def _activation(name):
     if name == "relu":
         return F.relu
@@ -289,8 +349,8 @@ class TransformerDecoder(nn.Module):
             b_q, b_k, b_v = torch.split(mha.in_proj_bias, [e, e, e], dim=0)    # backward is a single cat
             wq.append(w_q), wk.append(w_k), wv.append(w_v), bq.append(b_q), bk.append(b_k), bv.append(b_v)
         n = len(self.layers)
-        k_all = linear_rows(memory_pos, torch.cat(wk, dim=0), torch.cat(bk, dim=0)).unflatten(-1, (n, e)).unbind(-2)
-        v_all = linear_rows(memory, torch.cat(wv, dim=0), torch.cat(bv, dim=0)).unflatten(-1, (n, e)).unbind(-2)
+        k_all = shared_unbind(linear_rows(memory_pos, torch.cat(wk, dim=0), torch.cat(bk, dim=0)), n)
+        v_all = shared_unbind(linear_rows(memory, torch.cat(wv, dim=0), torch.cat(bv, dim=0)), n)
         return list(zip(k_all, v_all, wq, bq))
 
     # What a caller that reads only output [0] (ACT, act.py:270) may ask for:

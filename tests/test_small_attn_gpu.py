@@ -137,3 +137,48 @@ def test_zero_upstream_gradient_takes_the_fast_path_and_returns_exact_zeros():
     dq, dk, dv = torch.autograd.grad(out, (q, k, v), g)
     assert torch.count_nonzero(dq[1]) > 0 and torch.count_nonzero(dk[1]) > 0 and torch.count_nonzero(dv[1]) > 0
     assert torch.count_nonzero(dq[0]) == 0 and torch.count_nonzero(dv[0]) == 0
+
+
+@pytest.mark.parametrize("first_only", ["keep", "prune_backward"])
+def test_decoder_memory_gradients_through_the_shared_buffer(first_only):
+    """TransformerDecoder._project_memory hands every layer a (B, S, E) slice of ONE key / value projection; the layers'
+    cross-attention backward writes dK / dV straight into the shared (B, S, n, E) gradient buffer (transformer.GradArena)
+    instead of autograd stacking n tensors.  Same kernels either way: the gradients must be bit-identical to the stacked
+    path, and the no-copy path must actually have been taken."""
+    from pointcloudmatters_amd.policy import fused_ops, transformer as tr
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    dec = tr.TransformerDecoder(tr.TransformerDecoderLayer(128, 2, dim_feedforward=64, dropout=0.0), 3, norm=torch.nn.LayerNorm(128),
+                                return_intermediate=True).to(dev)
+    dec.first_only = first_only
+    B, S, L = 3, 333, 20
+    mem = torch.randn(B, S, 128, device=dev)
+    pos = torch.randn(B, S, 128, device=dev)
+    tgt = torch.zeros(B, L, 128, device=dev)
+    qpos = torch.randn(B, L, 128, device=dev)
+
+    def run(shared):
+        orig = tr.shared_unbind
+        if not shared:
+            tr.shared_unbind = lambda y, n: y.unflatten(-1, (n, y.shape[-1] // n)).unbind(-2)
+        try:
+            m = mem.clone().requires_grad_(True)
+            for p in dec.parameters():
+                p.grad = None
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                hs = dec(tgt, m, pos=pos, query_pos=qpos)
+            hs[0].float().square().sum().backward()
+            return m.grad.clone(), {n: p.grad.clone() for n, p in dec.named_parameters() if p.grad is not None}
+        finally:
+            tr.shared_unbind = orig
+
+    before = tr.GradArena.hits
+    g_mem, g_par = run(True)
+    assert tr.GradArena.hits == before + 2  # keys and values
+    r_mem, r_par = run(False)
+    assert tr.GradArena.hits == before + 2
+    assert torch.equal(g_mem, r_mem)
+    assert g_par.keys() == r_par.keys()
+    for n in g_par:
+        assert torch.equal(g_par[n], r_par[n]), n
