@@ -24,6 +24,13 @@
 //   prep   delta[b,h,q] = sum_d dO . O
 //   dq     one workgroup per 128 queries, streams K / V:   S^T, dP^T = V dO^T, dQ^T += K^T dS^T
 //   dkv    one workgroup per 128 keys,    streams Q / dO:  S, dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS
+// Remainder rows.  The token sets of this path are M + 3 long (515, 1027, 2051): after the full 128-row blocks, 3 rows are
+// left per (batch, head), and a workgroup for them costs as much as a full one -- at 2051 tokens that is 64 x 17 = 1088
+// workgroups on 512 resident slots, i.e. a THIRD pass over the chip for 0.15 % of the rows (measured: SQ_WAVE_CYCLES says
+// every wave lives 1/3 of the kernel).  When the remainder is <= 32 rows its workgroup therefore runs in "rem" mode: all
+// four waves stage the streamed tiles as usual, but waves 0 and 1 each take one 32-row HALF of every streamed tile for the
+// same resident rows and their partial results are merged through LDS at the end (online-softmax merge in the forward,
+// plain sums in the backward kernels): half the time of a full workgroup instead of all of it.
 // Dropout on the attention weights: the counter hash of attn_small.hip (same bits for the same (seed, site, b, h, q, key),
 // recomputed in both backward kernels).  P and dS are rounded to bf16 for the second GEMMs like every flash kernel.
 // q, k, v: bf16, arbitrary batch / row strides (multiples of 8), unit stride over the 64 head channels (head h at column
@@ -132,7 +139,9 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_flash_fwd_kernel(AttnParams P,
     __shared__ __attribute__((aligned(16))) u16 smem[4 * TILE];  // K[2] | V[2]; the epilogue stages O in it
     const int bh = blockIdx.x, b = bh / P.H, h = bh % P.H;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int q0 = blockIdx.y * RWG + w * RW, qi = q0 + (lane & 31);
+    const int nfull = P.L / RWG, remr = P.L - nfull * RWG;
+    const bool rem = remr > 0 && remr <= RW && (int)blockIdx.y == nfull;  // "rem" mode, see the header
+    const int q0 = rem ? nfull * RWG : blockIdx.y * RWG + w * RW, qi = q0 + (lane & 31);
     const bool qok = qi < P.L;
     const LaneOffsets lo = lane_offsets(lane);
     bf8 qf[4];
@@ -159,6 +168,99 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_flash_fwd_kernel(AttnParams P,
     stage_store(kr, smem, tid);
     stage_store(vr, smem + 2 * TILE, tid);
     __syncthreads();
+    if (rem) {
+        // waves 0 / 1: keys 0..31 / 32..63 of every tile against the same (remainder) queries
+        for (int kt = 0; kt < ntiles; ++kt) {
+            const u16 *Kt = smem + (kt & 1) * TILE, *Vt = smem + (2 + (kt & 1)) * TILE;
+            if (kt + 1 < ntiles) {
+                stage_fetch(kr, kb, P.k_ls, (kt + 1) * TR, P.S, tid);
+                stage_fetch(vr, vb, P.v_ls, (kt + 1) * TR, P.S, tid);
+            }
+            const int key0 = kt * TR + 32 * w;
+            if (w < 2 && key0 < P.S) {  // wave-uniform
+                f16v s;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl) s = PCM_MFMA16(lds_bf8(Kt + lo.row[sl] + w * 32 * HD), qf[sl], s);
+                bf8 va0[2], va1[2];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const u16 *vs = Vt + (2 * w + jj) * 16 * HD;
+                    va0[jj] = cat8(lds_tr(vs + lo.tr[0][0]), lds_tr(vs + lo.tr[1][0]));
+                    va1[jj] = cat8(lds_tr(vs + lo.tr[0][1]), lds_tr(vs + lo.tr[1][1]));
+                }
+                if (key0 + 32 > P.S || mask != nullptr) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = key0 + crow(r, lane);
+                        s[r] = (key < P.S && !(mask != nullptr && mask[key] != 0)) ? s[r] : -INFINITY;
+                    }
+                }
+                float tmax = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) tmax = max3f(tmax, s[r], s[r + 1]);
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+                const float m_new = fmaxf(m, tmax);
+                const bool dead = m_new == -INFINITY;
+                const float mneg = dead ? 0.f : -m_new * scale2;
+                float p[16], psum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    p[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], scale2, mneg));
+                    psum += p[r];
+                }
+                psum += __shfl_xor(psum, 32);
+                if (__any(m_new != m)) {
+                    const float alpha = (dead || m == -INFINITY) ? (dead ? 1.f : 0.f) : __builtin_amdgcn_exp2f((m - m_new) * scale2);
+                    lsum *= alpha;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o0[r] *= alpha, o1[r] *= alpha;
+                }
+                lsum += psum;
+                m = m_new;
+                if (dc.on) {
+#pragma unroll
+                    for (int gh = 0; gh < 8; ++gh) {
+                        const uint32_t bits = attn_pair_bits(rb, (uint32_t)(kt * (TR / 2) + 16 * w + 4 * (gh >> 1) + 2 * hl + (gh & 1)));
+                        p[2 * gh] = (bits & 0xFFFFu) >= dc.thr ? p[2 * gh] : 0.f;
+                        p[2 * gh + 1] = (bits >> 16) >= dc.thr ? p[2 * gh + 1] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const bf8 pf = p_frag(p, 8 * jj);
+                    o0 = PCM_MFMA16(va0[jj], pf, o0);
+                    o1 = PCM_MFMA16(va1[jj], pf, o1);
+                }
+            }
+            if (kt + 1 < ntiles) {
+                stage_store(kr, smem + ((kt + 1) & 1) * TILE, tid);
+                stage_store(vr, smem + (2 + ((kt + 1) & 1)) * TILE, tid);
+            }
+            __syncthreads();
+        }
+        // wave 1's partial (m, sum, O^T) joins wave 0's: the usual online-softmax merge
+        float *part = reinterpret_cast<float *>(smem) + 2048;  // 8 KiB in: clear of wave 0's epilogue staging rows
+        if (w == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[r * 64 + lane] = o0[r], part[(16 + r) * 64 + lane] = o1[r];
+            part[32 * 64 + lane] = m, part[33 * 64 + lane] = lsum;
+        }
+        __syncthreads();
+        if (w != 0) return;
+        const float m1 = part[32 * 64 + lane], l1 = part[33 * 64 + lane];
+        const float mm = fmaxf(m, m1);
+        const float f0 = m == -INFINITY ? 0.f : __builtin_amdgcn_exp2f((m - mm) * scale2);
+        const float f1 = m1 == -INFINITY ? 0.f : __builtin_amdgcn_exp2f((m1 - mm) * scale2);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            o0[r] = o0[r] * f0 + part[r * 64 + lane] * f1;
+            o1[r] = o1[r] * f0 + part[(16 + r) * 64 + lane] * f1;
+        }
+        lsum = lsum * f0 + l1 * f1;
+        m = mm;
+    } else
     for (int kt = 0; kt < ntiles; ++kt) {
         const u16 *Kt = smem + (kt & 1) * TILE, *Vt = smem + (2 + (kt & 1)) * TILE;
         if (kt + 1 < ntiles) {
@@ -282,7 +384,9 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_flash_bwd_dq_kernel(AttnParams
     const int bh = blockIdx.x, b = bh / P.H, h = bh % P.H;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hl = lane >> 5;
     const int E = P.H * HD;
-    const int q0 = blockIdx.y * RWG + w * RW, qi = q0 + (lane & 31);
+    const int nfull = P.L / RWG, remr = P.L - nfull * RWG;
+    const bool rem = remr > 0 && remr <= RW && (int)blockIdx.y == nfull;  // "rem" mode, see the header
+    const int q0 = rem ? nfull * RWG : blockIdx.y * RWG + w * RW, qi = q0 + (lane & 31);
     const bool qok = qi < P.L;
     const LaneOffsets lo = lane_offsets(lane);
     bf8 qf[4], gf[4];
@@ -324,6 +428,7 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_flash_bwd_dq_kernel(AttnParams
         const bool edge = (kt + 1) * TR > P.S || mask != nullptr;
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {  // 32 keys at a time
+            if (rem && kh != w) continue;  // rem mode: wave 0 / 1 owns key half 0 / 1, waves 2 and 3 only stage
             f16v s, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = 0.f, dp[r] = 0.f;
@@ -373,6 +478,17 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_flash_bwd_dq_kernel(AttnParams
         }
         __syncthreads();
     }
+    if (rem) {  // wave 1's half of the key sum joins wave 0's
+        float *part = reinterpret_cast<float *>(smem) + 2048;  // 8 KiB in: clear of wave 0's epilogue staging rows
+        if (w == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[r * 64 + lane] = a0[r], part[(16 + r) * 64 + lane] = a1[r];
+        }
+        __syncthreads();
+        if (w != 0) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a0[r] += part[r * 64 + lane], a1[r] += part[(16 + r) * 64 + lane];
+    }
     store_acc_rows(smem + w * RW * OS, a0, a1, sk, dq + (long)b * dq_bs + h * HD, dq_ls, q0, P.L, lane);
 }
 
@@ -387,7 +503,9 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_flash_bwd_dkv_kernel(AttnParam
     const int bh = blockIdx.x, b = bh / P.H, h = bh % P.H;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hl = lane >> 5;
     const int E = P.H * HD;
-    const int k0 = blockIdx.y * RWG + w * RW, key = k0 + (lane & 31);
+    const int nfull = P.S / RWG, remr = P.S - nfull * RWG;
+    const bool rem = remr > 0 && remr <= RW && (int)blockIdx.y == nfull;  // "rem" mode, see the header
+    const int k0 = rem ? nfull * RWG : blockIdx.y * RWG + w * RW, key = k0 + (lane & 31);
     const unsigned char *mask = P.kpm ? P.kpm + (long)b * P.S : nullptr;
     const bool kin = key < P.S;
     const bool kok = kin && !(mask != nullptr && mask[key] != 0);
@@ -443,6 +561,7 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_flash_bwd_dkv_kernel(AttnParam
         }
 #pragma unroll
         for (int qh = 0; qh < 2; ++qh) {  // 32 queries at a time
+            if (rem && qh != w) continue;  // rem mode: wave 0 / 1 owns query half 0 / 1, waves 2 and 3 only stage
             f16v s, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = 0.f, dp[r] = 0.f;
@@ -491,6 +610,23 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_flash_bwd_dkv_kernel(AttnParam
             store_rows(cur ^ 1);
         }
         __syncthreads();
+    }
+    if (rem) {  // wave 1's half of the query sums joins wave 0's
+        float *part = reinterpret_cast<float *>(smem) + 2048;  // 8 KiB in: clear of wave 0's epilogue staging rows
+        if (w == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                part[r * 64 + lane] = dk0[r], part[(16 + r) * 64 + lane] = dk1[r];
+                part[(32 + r) * 64 + lane] = dv0[r], part[(48 + r) * 64 + lane] = dv1[r];
+            }
+        }
+        __syncthreads();
+        if (w != 0) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            dk0[r] += part[r * 64 + lane], dk1[r] += part[(16 + r) * 64 + lane];
+            dv0[r] += part[(32 + r) * 64 + lane], dv1[r] += part[(48 + r) * 64 + lane];
+        }
     }
     u16 *stage = smem + w * RW * OS;
     store_acc_rows(stage, dk0, dk1, sk, dk + (long)b * dk_bs + h * HD, dk_ls, k0, P.S, lane);

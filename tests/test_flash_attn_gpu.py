@@ -23,7 +23,9 @@ def test_encoder_self_attention_shapes_match_fp32(S, masked):
 
 
 @pytest.mark.parametrize("B,H,L,S", [(1, 2, 129, 40), (1, 1, 300, 257), (2, 3, 130, 64), (1, 2, 192, 63), (1, 1, 257, 129),
-                                     (2, 2, 640, 100), (1, 8, 1027, 130), (1, 1, 131, 1)])
+                                     (2, 2, 640, 100), (1, 8, 1027, 130), (1, 1, 131, 1),
+                                     # remainders of exactly 32 / 33 rows (rem mode on / off), a whole problem inside one remainder block
+                                     (1, 2, 160, 160), (1, 1, 161, 288), (2, 2, 32, 20), (1, 2, 2051, 2051)])
 @pytest.mark.parametrize("masked", [False, True])
 def test_ragged_lengths_around_the_tile_edges(B, H, L, S, masked):
     run_case(B, H, L, S, masked, packed=False)
