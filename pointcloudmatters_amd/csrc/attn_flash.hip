@@ -134,6 +134,7 @@ __device__ __forceinline__ bf8 p_frag(const float (&p)[16], int j8)  // register
 
 // ------------------------------------------------------------------------------------------------ forward
 // grid (B*H, ceil(L / 128))
+template <bool DROP>  // dropout on / off is compiled in: as a run-time flag it left a branch around every masked element
 __global__ __launch_bounds__(WG, 2) void pcm_attn_flash_fwd_kernel(AttnParams P, u16 *__restrict__ out, float *__restrict__ lse)
 {
     __shared__ __attribute__((aligned(16))) u16 smem[4 * TILE];  // K[2] | V[2]; the epilogue stages O in it
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_flash_fwd_kernel(AttnParams P,
         for (int sl = 0; sl < 4; ++sl) qf[sl] = as_bf8(qok ? *reinterpret_cast<const uint4 *>(qp + sl * 16) : make_uint4(0, 0, 0, 0));
     }
     const DropCfg dc(P);
-    const uint32_t rb = dc.on ? attn_rowbase(dc.seed, P.site, (uint32_t)(bh * P.L + qi)) : 0u;
+    const uint32_t rb = DROP ? attn_rowbase(dc.seed, P.site, (uint32_t)(bh * P.L + qi)) : 0u;
     const int hl = lane >> 5;
     f16v o0, o1;
 #pragma unroll
@@ -219,12 +220,13 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_flash_fwd_kernel(AttnParams P,
                 }
                 lsum += psum;
                 m = m_new;
-                if (dc.on) {
+                if (DROP) {
 #pragma unroll
                     for (int gh = 0; gh < 8; ++gh) {
                         const uint32_t bits = attn_pair_bits(rb, (uint32_t)(kt * (TR / 2) + 16 * w + 4 * (gh >> 1) + 2 * hl + (gh & 1)));
-                        p[2 * gh] = (bits & 0xFFFFu) >= dc.thr ? p[2 * gh] : 0.f;
-                        p[2 * gh + 1] = (bits >> 16) >= dc.thr ? p[2 * gh + 1] : 0.f;
+                        lanemask k0, k1;
+                        keep_masks(bits, dc.thr, k0, k1);
+                        p[2 * gh] = keep_if(k0, p[2 * gh]), p[2 * gh + 1] = keep_if(k1, p[2 * gh + 1]);
                     }
                 }
 #pragma unroll
@@ -320,16 +322,17 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_flash_fwd_kernel(AttnParams P,
         }
         lsum += psum;
         m = m_new;
-        if (dc.on) {
+        if (DROP) {
 #pragma unroll
             for (int gh = 0; gh < 8; ++gh) {  // registers 2gh, 2gh+1 hold adjacent keys: one hash for the pair
                 const uint32_t pair = (uint32_t)(kt * (TR / 2) + 4 * (gh >> 1) + 2 * hl + (gh & 1));
                 const uint32_t b0 = attn_pair_bits(rb, pair), b1 = attn_pair_bits(rb, pair + 16);
                 // the 1 / (1 - p) rescale of the kept weights is a constant: it is folded into the final normalisation of O
-                p0[2 * gh] = (b0 & 0xFFFFu) >= dc.thr ? p0[2 * gh] : 0.f;
-                p0[2 * gh + 1] = (b0 >> 16) >= dc.thr ? p0[2 * gh + 1] : 0.f;
-                p1[2 * gh] = (b1 & 0xFFFFu) >= dc.thr ? p1[2 * gh] : 0.f;
-                p1[2 * gh + 1] = (b1 >> 16) >= dc.thr ? p1[2 * gh + 1] : 0.f;
+                lanemask k0, k1, k2, k3;
+                keep_masks(b0, dc.thr, k0, k1);
+                keep_masks(b1, dc.thr, k2, k3);
+                p0[2 * gh] = keep_if(k0, p0[2 * gh]), p0[2 * gh + 1] = keep_if(k1, p0[2 * gh + 1]);
+                p1[2 * gh] = keep_if(k2, p1[2 * gh]), p1[2 * gh + 1] = keep_if(k3, p1[2 * gh + 1]);
             }
         }
         // O^T += V^T P^T, 16 keys per MFMA: slab j = keys 16j .. 16j+15 of the tile
@@ -376,6 +379,7 @@ __global__ __launch_bounds__(WG) void pcm_attn_flash_prep_kernel(int B, int H, i
 }
 
 // dQ: grid (B*H, ceil(L / 128)); streams K / V tiles
+template <bool DROP>  // dropout on / off is compiled in: as a run-time flag it left a branch around every masked element
 __global__ __launch_bounds__(WG, 2) void pcm_attn_flash_bwd_dq_kernel(AttnParams P, const u16 *__restrict__ dout, const float *__restrict__ lse,
                                                                    const float *__restrict__ delta, u16 *__restrict__ dq, long dq_bs,
                                                                    long dq_ls)
@@ -400,7 +404,7 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_flash_bwd_dq_kernel(AttnParams
         }
     }
     const DropCfg dc(P);
-    const uint32_t rb = dc.on ? attn_rowbase(dc.seed, P.site, (uint32_t)(bh * P.L + qi)) : 0u;
+    const uint32_t rb = DROP ? attn_rowbase(dc.seed, P.site, (uint32_t)(bh * P.L + qi)) : 0u;
     const float scale2 = P.scale * 1.44269504088896f;
     const float lq2 = qok ? lse[(long)bh * P.L + qi] * 1.44269504088896f : INFINITY;  // +inf silences padded queries
     // dS = p * (keep * dP / (1 - p_drop) - D) * scale  =  p * (keep * dP - D * (1 - p_drop)) * (scale / (1 - p_drop))
@@ -445,12 +449,13 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_flash_bwd_dq_kernel(AttnParams
                 kt0[jj] = cat8(lds_tr(ks + lo.tr[0][0]), lds_tr(ks + lo.tr[1][0]));
                 kt1[jj] = cat8(lds_tr(ks + lo.tr[0][1]), lds_tr(ks + lo.tr[1][1]));
             }
-            if (dc.on) {
+            if (DROP) {
 #pragma unroll
                 for (int gh = 0; gh < 8; ++gh) {
                     const uint32_t bits = attn_pair_bits(rb, (uint32_t)(kt * (TR / 2) + 16 * kh + 4 * (gh >> 1) + 2 * hl + (gh & 1)));
-                    dp[2 * gh] = (bits & 0xFFFFu) >= dc.thr ? dp[2 * gh] : 0.f;  // 1 / (1 - p) is folded into Dk / sk below
-                    dp[2 * gh + 1] = (bits >> 16) >= dc.thr ? dp[2 * gh + 1] : 0.f;
+                    lanemask k0, k1;
+                    keep_masks(bits, dc.thr, k0, k1);
+                    dp[2 * gh] = keep_if(k0, dp[2 * gh]), dp[2 * gh + 1] = keep_if(k1, dp[2 * gh + 1]);  // 1 / (1 - p): in Dq / sk
                 }
             }
             float ds[16];
@@ -493,6 +498,7 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_flash_bwd_dq_kernel(AttnParams
 }
 
 // dK, dV: grid (B*H, ceil(S / 128)); streams Q / dO tiles (+ lse, delta, dropout row keys of the tile's queries)
+template <bool DROP>  // dropout on / off is compiled in: as a run-time flag it left a branch around every masked element
 __global__ __launch_bounds__(WG, 2) void pcm_attn_flash_bwd_dkv_kernel(AttnParams P, const u16 *__restrict__ dout, const float *__restrict__ lse,
                                                                     const float *__restrict__ delta, u16 *__restrict__ dk, long dk_bs,
                                                                     long dk_ls, u16 *__restrict__ dv, long dv_bs, long dv_ls)
@@ -538,7 +544,7 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_flash_bwd_dkv_kernel(AttnParam
             const int row = t * TR + tid;
             rl = row < P.L ? lse[(long)bh * P.L + row] * 1.44269504088896f : INFINITY;
             rd = row < P.L ? delta[(long)bh * P.L + row] / dc.inv_keep : 0.f;  // D * (1 - p_drop), see the dQ kernel
-            rrb = dc.on ? attn_rowbase(dc.seed, P.site, (uint32_t)(bh * P.L + row)) : 0u;
+            rrb = DROP ? attn_rowbase(dc.seed, P.site, (uint32_t)(bh * P.L + row)) : 0u;
         }
     };
     auto store_rows = [&](int buf) {
@@ -577,6 +583,21 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_flash_bwd_dkv_kernel(AttnParam
                 const float4 l4 = *reinterpret_cast<const float4 *>(&rows_f[cur][0][qr0]);
                 const float4 d4 = *reinterpret_cast<const float4 *>(&rows_f[cur][1][qr0]);
                 const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv4[4] = {d4.x, d4.y, d4.z, d4.w};
+                // Dropout bits.  Here a lane is a KEY and a register a query, so the two keys that share a hash word sit in
+                // adjacent lanes: the even lane hashes query 2jj, the odd lane query 2jj+1 (half the hashes of one per element),
+                // and the four keep bits of the 2 x 2 block are routed to their (register, lane) as wave masks on the scalar unit.
+                lanemask km[4] = {0, 0, 0, 0};
+                if (DROP) {
+                    constexpr lanemask EV = 0x5555555555555555ull, OD = 0xAAAAAAAAAAAAAAAAull;
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const uint32_t bits = attn_pair_bits(rows_rb[cur][qr0 + 2 * jj + (lane & 1)], (uint32_t)key >> 1);
+                        lanemask clo, chi;  // even lanes: (query 2jj, own key | next key); odd lanes: (query 2jj+1, previous key | own key)
+                        keep_masks(bits, dc.thr, clo, chi);
+                        km[2 * jj] = (clo & EV) | ((chi & EV) << 1);
+                        km[2 * jj + 1] = (chi & OD) | ((clo & OD) >> 1);
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int r = 4 * g + i;
@@ -584,11 +605,9 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_flash_bwd_dkv_kernel(AttnParam
                     if (!all_ok) pr = kok ? pr : 0.f;
                     float dpv = dp[r];
                     pd[r] = pr;
-                    if (dc.on) {
-                        const uint32_t bits = attn_pair_bits(rows_rb[cur][qr0 + i], (uint32_t)key >> 1);
-                        const bool keep = ((key & 1) ? (bits >> 16) : (bits & 0xFFFFu)) >= dc.thr;
-                        pd[r] = keep ? pr : 0.f;  // dV is rescaled by 1 / (1 - p_drop) once, when it is stored
-                        dpv = keep ? dpv : 0.f;
+                    if (DROP) {
+                        pd[r] = keep_if(km[i], pr);  // dV is rescaled by 1 / (1 - p_drop) once, when it is stored
+                        dpv = keep_if(km[i], dpv);
                     }
                     ds[r] = pr * (dpv - dv4[i]);  // scale / (1 - p_drop): applied once, to the finished dK
                 }
@@ -659,7 +678,10 @@ extern "C" int pcm_attn_flash_forward_hip(int B, int H, int L, int S, const void
     if (p_drop < 0.f || p_drop >= 1.f || (p_drop > 0.f && seed == nullptr)) return PCM_ERR_BAD_ARG;
     AttnParams P{(const u16 *)q, (const u16 *)k, (const u16 *)v, q_bs, q_ls, k_bs, k_ls, v_bs, v_ls, key_padding_mask,
                  B, H, L, S, scale, p_drop, seed, site};
-    hipLaunchKernelGGL(pcm_attn_flash_fwd_kernel, dim3(B * H, (L + RWG - 1) / RWG), dim3(WG), 0, (hipStream_t)stream, P, (u16 *)out, lse);
+    if (p_drop > 0.f)
+        hipLaunchKernelGGL(pcm_attn_flash_fwd_kernel<true>, dim3(B * H, (L + RWG - 1) / RWG), dim3(WG), 0, (hipStream_t)stream, P, (u16 *)out, lse);
+    else
+        hipLaunchKernelGGL(pcm_attn_flash_fwd_kernel<false>, dim3(B * H, (L + RWG - 1) / RWG), dim3(WG), 0, (hipStream_t)stream, P, (u16 *)out, lse);
     return PCM_LAUNCH_STATUS();
 }
 
@@ -686,11 +708,11 @@ extern "C" int pcm_attn_flash_backward_stages_hip(int B, int H, int L, int S, co
     if (stage_mask & 1)
         hipLaunchKernelGGL(pcm_attn_flash_prep_kernel, dim3((int)pblocks), dim3(WG), 0, st, B, H, L, (const u16 *)out, (const u16 *)dout, delta);
     if (stage_mask & 2)
-        hipLaunchKernelGGL(pcm_attn_flash_bwd_dkv_kernel, dim3(B * H, (S + RWG - 1) / RWG), dim3(WG), 0, st, P, (const u16 *)dout, lse, delta,
-                           (u16 *)dk, dk_bs, dk_ls, (u16 *)dv, dv_bs, dv_ls);
+        hipLaunchKernelGGL(p_drop > 0.f ? pcm_attn_flash_bwd_dkv_kernel<true> : pcm_attn_flash_bwd_dkv_kernel<false>, dim3(B * H, (S + RWG - 1) / RWG),
+                           dim3(WG), 0, st, P, (const u16 *)dout, lse, delta, (u16 *)dk, dk_bs, dk_ls, (u16 *)dv, dv_bs, dv_ls);
     if (stage_mask & 4)
-        hipLaunchKernelGGL(pcm_attn_flash_bwd_dq_kernel, dim3(B * H, (L + RWG - 1) / RWG), dim3(WG), 0, st, P, (const u16 *)dout, lse, delta,
-                           (u16 *)dq, dq_bs, dq_ls);
+        hipLaunchKernelGGL(p_drop > 0.f ? pcm_attn_flash_bwd_dq_kernel<true> : pcm_attn_flash_bwd_dq_kernel<false>, dim3(B * H, (L + RWG - 1) / RWG),
+                           dim3(WG), 0, st, P, (const u16 *)dout, lse, delta, (u16 *)dq, dq_bs, dq_ls);
     return PCM_LAUNCH_STATUS();
 }
 

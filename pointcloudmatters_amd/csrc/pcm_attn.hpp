@@ -101,6 +101,22 @@ __device__ __forceinline__ uint32_t attn_pair_bits(uint32_t rowbase, uint32_t ke
     return mixp(rowbase + key_pair * 0x9E3779B1u);
 }
 
+// keep masks of one hash word as WAVE masks (one bit per lane, in scalar registers): two SDWA compares on the 16-bit halves,
+// no extraction arithmetic.  `__builtin_amdgcn_inverse_ballot_w64(mask)` turns such a mask back into a per-lane condition
+// (a v_cndmask on that scalar pair), and masks can be combined / shifted between lanes on the SCALAR unit for free.
+typedef unsigned long long lanemask;
+__device__ __forceinline__ void keep_masks(uint32_t bits, uint32_t thr, lanemask &lo, lanemask &hi)
+{
+    asm("v_cmp_ge_u32_sdwa %0, %2, %3 src0_sel:WORD_0 src1_sel:DWORD\n\t"
+        "v_cmp_ge_u32_sdwa %1, %2, %3 src0_sel:WORD_1 src1_sel:DWORD"
+        : "=&s"(lo), "=&s"(hi)
+        : "v"(bits), "s"(thr));
+}
+__device__ __forceinline__ float keep_if(lanemask m, float x)
+{
+    return __builtin_amdgcn_inverse_ballot_w64(m) ? x : 0.f;
+}
+
 struct DropCfg {
     bool on;
     uint64_t seed;
