@@ -81,6 +81,7 @@ __device__ __forceinline__ void spill_acc(float *part, const f16v &a0, const f16
 // v_mfma_f32_32x32x16_bf16: a lane holds 8 consecutive k per operand.  For S^T = K Q^T both operands are natural 16-byte
 // reads.  For O^T += V^T P^T the B operand comes straight from the S^T accumulator: registers 8j..8j+7 of lane-half h are
 // keys {16j+4h+i} and {16j+8+4h+i}; the A operand (V^T) is gathered with the SAME key order, so the k-sum is unchanged.
+template <bool DROP>
 __device__ __forceinline__ void fwd_tile(const u16 *Ks, const u16 *Vs, const bf8 (&qf)[4], f16v &o0, f16v &o1, float &m, float &lsum,
                                          int kt, int lane, const AttnParams &P, const unsigned char *mask, const DropCfg &dc, uint32_t rb)
 {
@@ -131,12 +132,13 @@ __device__ __forceinline__ void fwd_tile(const u16 *Ks, const u16 *Vs, const bf8
     }
     lsum += psum;
     m = m_new;
-    if (dc.on) {
+    if (DROP) {
 #pragma unroll
         for (int gh = 0; gh < 8; ++gh) {  // registers 2gh, 2gh+1 hold adjacent keys: one hash for the pair
             const uint32_t bits = attn_pair_bits(rb, (uint32_t)(kt * (KT / 2) + 4 * (gh >> 1) + 2 * (lane >> 5) + (gh & 1)));
-            p[2 * gh] = (bits & 0xFFFFu) >= dc.thr ? p[2 * gh] * dc.inv_keep : 0.f;
-            p[2 * gh + 1] = (bits >> 16) >= dc.thr ? p[2 * gh + 1] * dc.inv_keep : 0.f;
+            lanemask k0, k1;
+            keep_masks(bits, dc.thr, k0, k1);
+            p[2 * gh] = keep_if(k0, p[2 * gh] * dc.inv_keep), p[2 * gh + 1] = keep_if(k1, p[2 * gh + 1] * dc.inv_keep);
         }
     }
 #pragma unroll
@@ -151,6 +153,7 @@ __device__ __forceinline__ void fwd_tile(const u16 *Ks, const u16 *Vs, const bf8
 // ------------------------------------------------------------------------------------------------ forward
 // grid (B*H, ceil(L/32)), 4 waves: all own the SAME 32 query columns; wave j takes key tiles j, j+4, ... with its own
 // online-softmax state and LDS tiles (no barrier in the loop); the four partial (m, l, O) meet once at the end.
+template <bool DROP>  // dropout on / off is compiled in (a run-time flag leaves branches around the masked elements)
 __global__ __launch_bounds__(WG) void pcm_attn_small_fwd_kernel(AttnParams P, u16 *__restrict__ out, float *__restrict__ lse)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[NW * 2 * TILE_U16 * 2 > NW * (64 * 32 + 64) * 4 ? NW * 2 * TILE_U16 * 2
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(WG) void pcm_attn_small_fwd_kernel(AttnParams P, u1
         for (int sl = 0; sl < 4; ++sl) qf[sl] = as_bf8(qok ? *reinterpret_cast<const uint4 *>(qp + sl * 16) : make_uint4(0, 0, 0, 0));
     }
     const DropCfg dc(P);
-    const uint32_t rb = dc.on ? attn_rowbase(dc.seed, P.site, (uint32_t)(bh * P.L + qi)) : 0u;
+    const uint32_t rb = DROP ? attn_rowbase(dc.seed, P.site, (uint32_t)(bh * P.L + qi)) : 0u;
     f16v o0, o1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) o0[r] = 0.f, o1[r] = 0.f;
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(WG) void pcm_attn_small_fwd_kernel(AttnParams P, u1
             tile_fetch(kr, kb, P.k_ls, (kt + NW) * KT, P.S, lane);
             tile_fetch(vr, vb, P.v_ls, (kt + NW) * KT, P.S, lane);
         }
-        fwd_tile(Ks, Vs, qf, o0, o1, m, lsum, kt, lane, P, mask, dc, rb);
+        fwd_tile<DROP>(Ks, Vs, qf, o0, o1, m, lsum, kt, lane, P, mask, dc, rb);
     }
     // ---- the four partial results meet: part[w] = O_w (64 x 32), ml[w] = (m_w, l_w) per query
     __syncthreads();
@@ -252,7 +255,8 @@ __device__ __forceinline__ void store_rows_bf16(u16 *dst, const float *part, int
     reinterpret_cast<uint2 *>(dst + dg * 8)[1] = c;
 }
 
-__global__ __launch_bounds__(WG) void pcm_attn_small_bwd_kernel(AttnParams P, const u16 *__restrict__ out,
+template <bool DROP>
+__global__ __launch_bounds__(WG, 2) void pcm_attn_small_bwd_kernel(AttnParams P, const u16 *__restrict__ out,
                                                                 const u16 *__restrict__ dout, const float *__restrict__ lse,
                                                                 u16 *__restrict__ dq, long dq_bs, long dq_ls, u16 *__restrict__ dk,
                                                                 long dk_bs, long dk_ls, u16 *__restrict__ dv, long dv_bs, long dv_ls)
@@ -308,7 +312,7 @@ __global__ __launch_bounds__(WG) void pcm_attn_small_bwd_kernel(AttnParams P, co
         }
         const float scale2 = P.scale * 1.44269504088896f;
         const float lq2 = qok ? lse[(long)bh * P.L + qi] * 1.44269504088896f : INFINITY;  // log2 domain
-        const uint32_t rb = dc.on ? attn_rowbase(dc.seed, P.site, (uint32_t)(bh * P.L + qi)) : 0u;
+        const uint32_t rb = DROP ? attn_rowbase(dc.seed, P.site, (uint32_t)(bh * P.L + qi)) : 0u;
         f16v a0, a1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) a0[r] = 0.f, a1[r] = 0.f;
@@ -335,12 +339,13 @@ __global__ __launch_bounds__(WG) void pcm_attn_small_bwd_kernel(AttnParams P, co
             }
             const bool edge = (kt + 1) * KT > P.S || mask != nullptr;
             float ds[16];
-            if (dc.on) {
+            if (DROP) {
 #pragma unroll
                 for (int gh = 0; gh < 8; ++gh) {
                     const uint32_t bits = attn_pair_bits(rb, (uint32_t)(kt * (KT / 2) + 4 * (gh >> 1) + 2 * (lane >> 5) + (gh & 1)));
-                    dp[2 * gh] = (bits & 0xFFFFu) >= dc.thr ? dp[2 * gh] * dc.inv_keep : 0.f;
-                    dp[2 * gh + 1] = (bits >> 16) >= dc.thr ? dp[2 * gh + 1] * dc.inv_keep : 0.f;
+                    lanemask k0, k1;
+                    keep_masks(bits, dc.thr, k0, k1);
+                    dp[2 * gh] = keep_if(k0, dp[2 * gh] * dc.inv_keep), dp[2 * gh + 1] = keep_if(k1, dp[2 * gh + 1] * dc.inv_keep);
                 }
             }
 #pragma unroll
@@ -435,7 +440,7 @@ __global__ __launch_bounds__(WG) void pcm_attn_small_bwd_kernel(AttnParams P, co
             if ((idx & 7) == 0) {
                 D_s[lrow] = dsum;
                 lse_s[lrow] = row < P.L ? lse[(long)bh * P.L + row] * 1.44269504088896f : INFINITY;  // log2 domain; +inf silences padded queries
-                rb_s[lrow] = dc.on ? attn_rowbase(dc.seed, P.site, (uint32_t)(bh * P.L + row)) : 0u;
+                rb_s[lrow] = DROP ? attn_rowbase(dc.seed, P.site, (uint32_t)(bh * P.L + row)) : 0u;
             }
         }
         __syncthreads();
@@ -450,19 +455,35 @@ __global__ __launch_bounds__(WG) void pcm_attn_small_bwd_kernel(AttnParams P, co
                 dp = PCM_MFMA(lds_s4(dOs + off), vf[sl], dp);
             }
             float pd[16], ds[16];
+            // dropout bits: a lane is a key here, so the two keys of a hash word sit in adjacent lanes -- the even lane hashes
+            // query 2j, the odd lane query 2j+1, and the 2 x 2 keep bits are routed as wave masks (see attn_flash.hip, dK/dV)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int qr = qt * 32 + crow(r, lane);  // row within the staged chunk
-                const float pr = kok ? __builtin_amdgcn_exp2f(s[r] * scale2 - lse_s[qr]) : 0.f;  // lse_s holds lse * log2(e)
-                float dpv = dp[r];
-                pd[r] = pr;
-                if (dc.on) {
-                    const uint32_t bits = attn_pair_bits(rb_s[qr], (uint32_t)key >> 1);
-                    const bool keep = ((key & 1) ? (bits >> 16) : (bits & 0xFFFFu)) >= dc.thr;
-                    pd[r] = keep ? pr * dc.inv_keep : 0.f;
-                    dpv = keep ? dpv * dc.inv_keep : 0.f;
+            for (int g = 0; g < 4; ++g) {  // registers 4g .. 4g+3 = four consecutive queries
+                lanemask km[4] = {0, 0, 0, 0};
+                if (DROP) {
+                    constexpr lanemask EV = 0x5555555555555555ull, OD = 0xAAAAAAAAAAAAAAAAull;
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const uint32_t bits = attn_pair_bits(rb_s[qt * 32 + crow(4 * g + 2 * jj, lane) + (lane & 1)], (uint32_t)key >> 1);
+                        lanemask clo, chi;
+                        keep_masks(bits, dc.thr, clo, chi);
+                        km[2 * jj] = (clo & EV) | ((chi & EV) << 1);
+                        km[2 * jj + 1] = (chi & OD) | ((clo & OD) >> 1);
+                    }
                 }
-                ds[r] = pr * (dpv - D_s[qr]) * P.scale;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 4 * g + i;
+                    const int qr = qt * 32 + crow(r, lane);  // row within the staged chunk
+                    const float pr = kok ? __builtin_amdgcn_exp2f(s[r] * scale2 - lse_s[qr]) : 0.f;  // lse_s holds lse * log2(e)
+                    float dpv = dp[r];
+                    pd[r] = pr;
+                    if (DROP) {
+                        pd[r] = keep_if(km[i], pr * dc.inv_keep);
+                        dpv = keep_if(km[i], dpv * dc.inv_keep);
+                    }
+                    ds[r] = pr * (dpv - D_s[qr]) * P.scale;
+                }
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -512,7 +533,8 @@ extern "C" int pcm_attn_small_forward_hip(int B, int H, int L, int S, const void
     if (p_drop < 0.f || p_drop >= 1.f || (p_drop > 0.f && seed == nullptr)) return PCM_ERR_BAD_ARG;
     AttnParams P{(const u16 *)q, (const u16 *)k, (const u16 *)v, q_bs, q_ls, k_bs, k_ls, v_bs, v_ls, key_padding_mask,
                  B, H, L, S, scale, p_drop, seed, site};
-    hipLaunchKernelGGL(pcm_attn_small_fwd_kernel, dim3(B * H, (L + 31) / 32), dim3(WG), 0, (hipStream_t)stream, P, (u16 *)out, lse);
+    hipLaunchKernelGGL(p_drop > 0.f ? pcm_attn_small_fwd_kernel<true> : pcm_attn_small_fwd_kernel<false>, dim3(B * H, (L + 31) / 32), dim3(WG), 0,
+                       (hipStream_t)stream, P, (u16 *)out, lse);
     return PCM_LAUNCH_STATUS();
 }
 
@@ -529,7 +551,8 @@ extern "C" int pcm_attn_small_backward_hip(int B, int H, int L, int S, const voi
     if (dq_ls % 8 || dk_ls % 8 || dv_ls % 8 || dq_bs % 8 || dk_bs % 8 || dv_bs % 8) return PCM_ERR_BAD_ARG;
     AttnParams P{(const u16 *)q, (const u16 *)k, (const u16 *)v, q_bs, q_ls, k_bs, k_ls, v_bs, v_ls, key_padding_mask,
                  B, H, L, S, scale, p_drop, seed, site};
-    hipLaunchKernelGGL(pcm_attn_small_bwd_kernel, dim3(B * H, (L + 31) / 32 + (S + KT - 1) / KT), dim3(WG), 0, (hipStream_t)stream, P, (const u16 *)out,
+    hipLaunchKernelGGL(p_drop > 0.f ? pcm_attn_small_bwd_kernel<true> : pcm_attn_small_bwd_kernel<false>, dim3(B * H, (L + 31) / 32 + (S + KT - 1) / KT),
+                       dim3(WG), 0, (hipStream_t)stream, P, (const u16 *)out,
                        (const u16 *)dout, lse, (u16 *)dq, dq_bs, dq_ls, (u16 *)dk, dk_bs, dk_ls, (u16 *)dv, dv_bs, dv_ls);
     return PCM_LAUNCH_STATUS();
 }

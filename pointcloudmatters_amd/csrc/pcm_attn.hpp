@@ -32,21 +32,18 @@ __device__ __forceinline__ float bf2f(u16 v)
 // per pair, a quarter of the softmax's instruction count in the attention kernels.
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi)
 {
-    uint32_t r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
+    return pcm_cvt_pk_bf16(lo, hi);  // compiler-visible (hazards between v_exp_f32 and its reader are the compiler's job)
 }
 __device__ __forceinline__ s4 pack4(float a, float b, float c, float d)
 {
     const uint2 r = make_uint2(cvt_pk_bf16(a, b), cvt_pk_bf16(c, d));
     return __builtin_bit_cast(s4, r);
 }
-// max of three in one instruction (fmaxf chains also pick up a canonicalising v_max per MFMA output)
+// max of three: the builtin chain compiles to ONE v_max3_f32 (no canonicalising v_max), and -- unlike an asm statement --
+// lets the compiler insert the wait states an MFMA result needs before a VALU instruction may read it
 __device__ __forceinline__ float max3f(float a, float b, float c)
 {
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
+    return __builtin_fmaxf(__builtin_fmaxf(a, b), c);
 }
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 #define PCM_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
@@ -101,16 +98,16 @@ __device__ __forceinline__ uint32_t attn_pair_bits(uint32_t rowbase, uint32_t ke
     return mixp(rowbase + key_pair * 0x9E3779B1u);
 }
 
-// keep masks of one hash word as WAVE masks (one bit per lane, in scalar registers): two SDWA compares on the 16-bit halves,
-// no extraction arithmetic.  `__builtin_amdgcn_inverse_ballot_w64(mask)` turns such a mask back into a per-lane condition
-// (a v_cndmask on that scalar pair), and masks can be combined / shifted between lanes on the SCALAR unit for free.
+// keep masks of one hash word as WAVE masks (one bit per lane, in scalar registers): the ballots compile to two SDWA
+// compares on the 16-bit halves, no extraction arithmetic.  `__builtin_amdgcn_inverse_ballot_w64(mask)` turns such a mask back
+// into a per-lane condition (a v_cndmask on that scalar pair), and masks can be combined / shifted between lanes on the SCALAR
+// unit for free.  (Builtins, not inline assembly: gfx950 needs two wait states between a VALU write of a scalar register and
+// a VALU read of it, which only the compiler's hazard recognizer inserts.)
 typedef unsigned long long lanemask;
 __device__ __forceinline__ void keep_masks(uint32_t bits, uint32_t thr, lanemask &lo, lanemask &hi)
 {
-    asm("v_cmp_ge_u32_sdwa %0, %2, %3 src0_sel:WORD_0 src1_sel:DWORD\n\t"
-        "v_cmp_ge_u32_sdwa %1, %2, %3 src0_sel:WORD_1 src1_sel:DWORD"
-        : "=&s"(lo), "=&s"(hi)
-        : "v"(bits), "s"(thr));
+    lo = __builtin_amdgcn_ballot_w64((bits & 0xFFFFu) >= thr);
+    hi = __builtin_amdgcn_ballot_w64((bits >> 16) >= thr);
 }
 __device__ __forceinline__ float keep_if(lanemask m, float x)
 {

@@ -46,11 +46,15 @@ __device__ __forceinline__ uint32_t pcm_wave_min_u32(uint32_t v)
 
 // two fp32 -> one dword holding two bf16 (round to nearest even), ONE v_cvt_pk_bf16_f32 (gfx950).  The library route
 // (__float2bfloat16 per element + reinterpretation) costs a conversion per element plus a shift and an or per pair.
+// Written as a vector conversion, NOT as inline assembly: the hazard recognizer does not look inside an asm statement, and
+// gfx950 needs a wait state between a transcendental (v_exp_f32, v_rcp_f32 ...) and a VALU instruction that reads its result
+// -- an asm v_cvt_pk placed right behind a v_exp read a stale register (found when a loop was restructured).
+typedef float pcm_f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 pcm_bf2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pcm_cvt_pk_bf16(float lo, float hi)
 {
-    uint32_t r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
+    const pcm_f2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, pcm_bf2));
 }
 
 __device__ __forceinline__ int pcm_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
