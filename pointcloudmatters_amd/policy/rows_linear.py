@@ -17,6 +17,8 @@ MIN_ROWS = 2048        # below this the plain GEMM is as fast
 TARGET_CHUNK = 768     # rows per partial product
 MAX_SPLITS = 64
 MAX_PARTIAL_BYTES = 64 << 20  # fp32 partial products of one weight gradient (S x m x k)
+WIDE_OUTPUT = 1024 * 1024      # m * k above which the fixed cost of summing the partials (20 us at 3584 x 512) ...
+WIDE_MIN_ROWS = 8192           # ... only pays for this many rows (4120 rows: 44 us unsplit vs 48 + 20 split; 16408: 216 vs 95)
 
 
 def _splits(rows, s_max=MAX_SPLITS):
@@ -105,7 +107,7 @@ def _weight_grad(go, x, out_dtype, out=None):
     # wide outputs (the decoder's 7-layer key / value projection: 3584 x 512) are split too, as long as the fp32
     # partials stay small: unsplit, hipBLASLt runs that product on 65 workgroups (216 us at 16408 rows)
     s_max = min(MAX_SPLITS, MAX_PARTIAL_BYTES // (m * k * 4))
-    if rows < MIN_ROWS or s_max < 2:
+    if rows < MIN_ROWS or s_max < 2 or (m * k > WIDE_OUTPUT and rows < WIDE_MIN_ROWS):
         if out is not None and out.dtype == go.dtype and out.is_contiguous():
             return torch.mm(go.t(), x, out=out)  # straight into the (slice of the) packed gradient: no copy kernel
         dw = go.t() @ x
