@@ -149,6 +149,206 @@ __global__ __launch_bounds__(64 * kWaves) void pcm_knn_fast_kernel(int b, int m,
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Two-pass variant.  The insertion kernel above spends two thirds of its instructions on ~K ln(N/K)
+// serial list insertions per query.  Here a wave first computes ALL distances of a 4096-point stretch of the cloud into
+// registers (64 slabs x one register) while every lane tracks the minimum it has seen.  The 64 lane minima belong to 64
+// different points, so the (nsample+1)-th smallest of them bounds the (nsample+1)-th smallest distance of the query from
+// above: a 14-step bisection over the float bit patterns (one compare + scalar popcount per step) turns that into a
+// threshold tau, and a second sweep over the REGISTERS (no distance is recomputed) appends the few points below tau --
+// typically ~1.5 (nsample+1) of them -- to a per-wave LDS buffer.  One cross-lane bitonic sort at the end (and between
+// 4096-point stretches of larger clouds) produces the sorted list.  Exactness: the candidate set is a superset of the
+// nsample+1 smallest (d2), the sort orders by d2, ties among the nsample+1 smallest mark the query for the exact kernel
+// exactly as above, and so does the (never observed outside adversarial inputs) overflow of the 128-entry buffer.
+constexpr int kSuper = 64;    // slabs (of 64 points) whose distances a lane keeps in registers: 4096 points
+constexpr int kBufCap = 128;  // candidate buffer entries per wave
+
+struct XorAddr {
+    int a[6];  // byte addresses of lane ^ (1 << k) for ds_bpermute
+};
+
+// one compare-exchange step of the cross-lane bitonic network: partner = lane ^ (1 << KBIT); `take_min` lanes keep the smaller
+template <int KBIT>
+__device__ __forceinline__ void knn_cx(uint32_t &d, int &i, const XorAddr &xa, bool take_min)
+{
+    const uint32_t pd = (uint32_t)__builtin_amdgcn_ds_bpermute(xa.a[KBIT], (int)d);
+    const int pi = __builtin_amdgcn_ds_bpermute(xa.a[KBIT], i);
+    const bool take = take_min ? pd < d : pd > d;  // equal keys: both lanes keep their own entry
+    d = take ? pd : d;
+    i = take ? pi : i;
+}
+
+// ascending bitonic sort of 64 (d, i) pairs held one per lane
+__device__ __forceinline__ void knn_sort64(uint32_t &d, int &i, const XorAddr &xa, int lane)
+{
+#define PCM_CX(KB, JB) knn_cx<JB>(d, i, xa, (((lane >> (JB)) & 1) == 0) == ((KB) == 6 || ((lane >> (KB)) & 1) == 0))
+    PCM_CX(1, 0);
+    PCM_CX(2, 1); PCM_CX(2, 0);
+    PCM_CX(3, 2); PCM_CX(3, 1); PCM_CX(3, 0);
+    PCM_CX(4, 3); PCM_CX(4, 2); PCM_CX(4, 1); PCM_CX(4, 0);
+    PCM_CX(5, 4); PCM_CX(5, 3); PCM_CX(5, 2); PCM_CX(5, 1); PCM_CX(5, 0);
+    PCM_CX(6, 5); PCM_CX(6, 4); PCM_CX(6, 3); PCM_CX(6, 2); PCM_CX(6, 1); PCM_CX(6, 0);
+#undef PCM_CX
+}
+
+// buffer (cnt <= 128 unsorted entries in LDS) -> its 64 smallest, sorted ascending, one per lane (missing entries: key ~0u)
+__device__ __forceinline__ void knn_compact(const uint32_t *bd, const int *bi, int cnt, uint32_t &d, int &i, const XorAddr &xa, int lane)
+{
+    d = lane < cnt ? bd[lane] : 0xFFFFFFFFu;
+    i = lane < cnt ? bi[lane] : -1;
+    knn_sort64(d, i, xa, lane);
+    if (cnt > 64) {  // wave-uniform
+        uint32_t e = 64 + lane < cnt ? bd[64 + lane] : 0xFFFFFFFFu;
+        int ei = 64 + lane < cnt ? bi[64 + lane] : -1;
+        knn_sort64(e, ei, xa, lane);
+        // min(d[l], e[63 - l]) over l is a bitonic sequence holding the 64 smallest of the 128
+        const int rev = (63 - lane) << 2;
+        const uint32_t re = (uint32_t)__builtin_amdgcn_ds_bpermute(rev, (int)e);
+        const int rei = __builtin_amdgcn_ds_bpermute(rev, ei);
+        const bool take = re < d;
+        d = take ? re : d;
+        i = take ? rei : i;
+#define PCM_CX(JB) knn_cx<JB>(d, i, xa, ((lane >> (JB)) & 1) == 0)
+        PCM_CX(5); PCM_CX(4); PCM_CX(3); PCM_CX(2); PCM_CX(1); PCM_CX(0);
+#undef PCM_CX
+    }
+}
+
+__global__ __launch_bounds__(64 * kWaves) void pcm_knn_twopass_kernel(int b, int m, int nsample, const float *__restrict__ xyz,
+                                                                       const float *__restrict__ new_xyz, const int *__restrict__ offset,
+                                                                       const int *__restrict__ new_offset, int *__restrict__ idx,
+                                                                       float *__restrict__ dist2)
+{
+    __shared__ float pts[2][3][kChunk];
+    __shared__ uint32_t cand_d[kWaves][kBufCap];
+    __shared__ int cand_i[kWaves][kBufCap];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // SCALAR: everything derived from it branches on the scalar unit
+    const int K1 = nsample + 1;
+    const uint32_t PAD = __float_as_uint(1e10f);
+    XorAddr xa;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) xa.a[k] = (lane ^ (1 << k)) << 2;
+    uint32_t *bd = cand_d[wave];
+    int *bi = cand_i[wave];
+    for (int qb = blockIdx.x * kWaves; qb < m; qb += gridDim.x * kWaves) {
+        const int q = qb + wave;  // may lie beyond m: then the wave only helps with the staging
+        const int q_last_wg = min(qb + kWaves, m) - 1;
+        const int c_first = pcm_cloud_of(qb, new_offset, b), c_last = pcm_cloud_of(q_last_wg, new_offset, b);
+        const int qq = q < m ? q : m - 1;
+        const float qx = new_xyz[(size_t)qq * 3 + 0], qy = new_xyz[(size_t)qq * 3 + 1], qz = new_xyz[(size_t)qq * 3 + 2];
+        int cnt = 0;          // entries in the candidate buffer (wave-uniform)
+        uint32_t tau = PAD;   // candidates need d2 < tau (bit patterns: d2 >= +0, unsigned order == float order)
+        bool overflow = false;
+        for (int c = c_first; c <= c_last; ++c) {
+            const int start = c == 0 ? 0 : offset[c - 1], end = offset[c];
+            const int qs = c == 0 ? 0 : new_offset[c - 1], qe = new_offset[c];
+            const bool act = q >= qs && q < qe && q < m;  // wave-uniform
+            const int npts = end - start;
+            const int nchunks = (npts + kChunk - 1) / kChunk;
+            constexpr int CPS = kSuper * 64 / kChunk;  // LDS chunks per register stretch (8)
+            const int nsuper = (nchunks + CPS - 1) / CPS;
+            float rx[2], ry[2], rz[2];
+            auto fetch = [&](int ch) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int p = ch * kChunk + u * 256 + (int)threadIdx.x;
+                    const bool ok = p < npts;
+                    const float *src = xyz + (size_t)(start + (ok ? p : 0)) * 3;
+                    rx[u] = ok ? src[0] : 0.f, ry[u] = ok ? src[1] : 0.f, rz[u] = ok ? src[2] : 0.f;
+                }
+            };
+            if (nchunks > 0) fetch(0);
+            for (int sc = 0; sc < nsuper; ++sc) {
+                uint32_t dreg[kSuper];
+                uint32_t lmin = 0xFFFFFFFFu;
+                // ---- pass 1: distances of up to 4096 points into registers, per-lane minimum
+#pragma unroll
+                for (int cc = 0; cc < CPS; ++cc) {
+                    const int ch = sc * CPS + cc;
+                    if (ch < nchunks) {  // block-uniform
+                        float(*buf)[kChunk] = pts[cc & 1];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) buf[0][u * 256 + threadIdx.x] = rx[u], buf[1][u * 256 + threadIdx.x] = ry[u], buf[2][u * 256 + threadIdx.x] = rz[u];
+                        __syncthreads();  // one barrier per chunk (CPS is even: the buffer parity carries across stretches)
+                        if (ch + 1 < nchunks) fetch(ch + 1);
+                        const int left = npts - ch * kChunk;
+                        if (act) {  // wave-uniform.  All eight slabs form ONE basic block: their LDS reads are issued together
+#pragma unroll
+                            for (int sub = 0; sub < kChunk / 64; ++sub) {
+                                const float px = buf[0][sub * 64 + lane], py = buf[1][sub * 64 + lane], pz = buf[2][sub * 64 + lane];
+                                const float dist = pcm_sqdist(qx, qy, qz, px, py, pz);
+                                const uint32_t dd = sub * 64 + lane < left ? __float_as_uint(dist) : 0xFFFFFFFFu;
+                                lmin = min(lmin, dd);
+                                dreg[cc * (kChunk / 64) + sub] = dd;
+                            }
+                        } else {
+#pragma unroll
+                            for (int sub = 0; sub < kChunk / 64; ++sub) dreg[cc * (kChunk / 64) + sub] = 0xFFFFFFFFu;
+                        }
+                    } else {
+#pragma unroll
+                        for (int sub = 0; sub < kChunk / 64; ++sub) dreg[cc * (kChunk / 64) + sub] = 0xFFFFFFFFu;
+                    }
+                }
+                if (!act) continue;  // wave-uniform; barriers above were all passed
+                // ---- threshold: an upper bound of the K1-th smallest lane minimum (each belongs to a different point)
+                if (tau > 0u) {
+                    uint32_t lo = 0u, hi = tau - 1u;
+                    if (__builtin_popcountll(__ballot(lmin <= hi)) >= K1) {
+#pragma unroll 1
+                        for (int it = 0; it < 14; ++it) {
+                            const uint32_t mid = lo + ((hi - lo) >> 1);
+                            if (__builtin_popcountll(__ballot(lmin <= mid)) >= K1) hi = mid; else lo = mid + 1u;
+                        }
+                        tau = hi + 1u;
+                    }
+                }
+                // ---- pass 2: the registers below tau go to the candidate buffer
+                const int pbase0 = start + sc * kSuper * 64;
+#pragma unroll
+                for (int s = 0; s < kSuper; ++s) {
+                    const bool hit = dreg[s] < tau;
+                    const unsigned long long mk = __ballot(hit);
+                    if (mk) {  // wave-uniform
+                        const int n = __builtin_popcountll(mk);
+                        if (cnt + n <= kBufCap) {
+                            const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+                            if (hit) bd[pos] = dreg[s], bi[pos] = pbase0 + s * 64 + lane;
+                            cnt += n;
+                        } else {
+                            overflow = true;
+                        }
+                    }
+                }
+                // ---- between stretches of a large cloud: keep the K1 smallest, tighten tau
+                if (sc + 1 < nsuper && cnt > K1) {
+                    uint32_t d;
+                    int i;
+                    knn_compact(bd, bi, cnt, d, i, xa, lane);
+                    bd[lane] = d, bi[lane] = i;
+                    cnt = K1;
+                    tau = min(tau, (uint32_t)__builtin_amdgcn_readlane((int)d, K1 - 1));
+                }
+            }
+            __syncthreads();  // the next cloud (or query block) restarts with buffer 0
+        }
+        if (q >= m) continue;  // wave-uniform
+        uint32_t d;
+        int i;
+        knn_compact(bd, bi, cnt, d, i, xa, lane);
+        if (lane >= cnt || lane >= K1) d = lane < K1 ? PAD : 0xFFFFFFFFu, i = -1;  // fewer points than nsample+1: the reference's pads
+        const uint32_t nd = pcm_dpp<0x130>(d);  // wave_shl:1 -> lane l sees l+1
+        const int ni = (int)pcm_dpp<0x130>((uint32_t)i);
+        const bool tie = lane < K1 - 1 && d == nd && i >= 0 && ni >= 0;
+        const bool redo = __ballot(tie) != 0ull || overflow;
+        if (lane < nsample) {
+            idx[(size_t)q * nsample + lane] = i;
+            dist2[(size_t)q * nsample + lane] = (lane == 0 && redo) ? -1.f : __uint_as_float(d);
+        }
+    }
+}
+
 // Literal reference algorithm for the queries the fast kernel marked (or for all, if all_queries).
 __global__ __launch_bounds__(64) void pcm_knn_exact_kernel(int b, int m, int nsample, int all_queries,
                                                           const float *__restrict__ xyz,
@@ -229,12 +429,19 @@ extern "C" int pcm_knn_query_n_hip(int b, int n_max, int m, int nsample, const f
             // serial insertion chain (vector -> scalar -> vector dependencies, ~K ln(N/K) insertions per query), not by the
             // cloud reads: more queries per wave save L2 traffic but leave fewer independent waves to hide that latency.
             static const int forced = getenv("PCM_KNN_Q") ? atoi(getenv("PCM_KNN_Q")) : 0;  // A/B switch for tools/mb
+            static const int twopass = getenv("PCM_KNN_TWOPASS") ? atoi(getenv("PCM_KNN_TWOPASS")) : 1;
+            if (twopass) {
+                int blocks2 = (m + kWaves - 1) / kWaves;
+                if (blocks2 > 256 * 32) blocks2 = 256 * 32;
+                hipLaunchKernelGGL(pcm_knn_twopass_kernel, dim3(blocks2), dim3(64 * kWaves), 0, st, b, m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2);
+            } else {
             const int Q = forced ? forced : (m >= 16 * kWaves * 1024 ? 4 : (m >= 2 * kWaves * 1024 ? 2 : 1));
             int blocks = (m + Q * kWaves - 1) / (Q * kWaves);
             if (blocks > 256 * 16) blocks = 256 * 16;
 #define PCM_KNN(QQ) hipLaunchKernelGGL(pcm_knn_fast_kernel<QQ>, dim3(blocks), dim3(64 * kWaves), 0, st, b, m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2)
             if (Q == 4) PCM_KNN(4); else if (Q == 2) PCM_KNN(2); else PCM_KNN(1);
 #undef PCM_KNN
+            }
         }
         int rc = PCM_LAUNCH_STATUS();
         if (rc) return rc;
