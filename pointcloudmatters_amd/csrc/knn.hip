@@ -164,31 +164,67 @@ constexpr int kSuper = 64;    // slabs (of 64 points) whose distances a lane kee
 constexpr int kBufCap = 128;  // candidate buffer entries per wave
 
 struct XorAddr {
-    int a[6];  // byte addresses of lane ^ (1 << k) for ds_bpermute
+    int a[6];  // byte addresses for ds_bpermute: [0] lane ^ 4, [1] ^ 8, [2] ^ 16, [3] ^ 31, [4] ^ 63, [5] ^ 32
 };
 
-// one compare-exchange step of the cross-lane bitonic network: partner = lane ^ (1 << KBIT); `take_min` lanes keep the smaller
-template <int KBIT>
-__device__ __forceinline__ void knn_cx(uint32_t &d, int &i, const XorAddr &xa, bool take_min)
+// lanes whose bit JB is clear: they hold the LOWER element of a (lane, lane ^ partner) pair and keep the smaller key
+constexpr unsigned long long knn_low_mask(int jb)
 {
-    const uint32_t pd = (uint32_t)__builtin_amdgcn_ds_bpermute(xa.a[KBIT], (int)d);
-    const int pi = __builtin_amdgcn_ds_bpermute(xa.a[KBIT], i);
-    const bool take = take_min ? pd < d : pd > d;  // equal keys: both lanes keep their own entry
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l)
+        if (((l >> jb) & 1) == 0) m |= 1ull << l;
+    return m;
+}
+
+// one compare-exchange step: the lower lane of each pair keeps the smaller key, the upper lane the larger (equal keys: both
+// keep their own entry).  The decision is formed on the scalar unit from two compare masks and a constant lane pattern.
+template <int JB>
+__device__ __forceinline__ void knn_cx_apply(uint32_t &d, int &i, uint32_t pd, int pi)
+{
+    constexpr unsigned long long LOW = knn_low_mask(JB);
+    const unsigned long long lt = __builtin_amdgcn_ballot_w64(pd < d), gt = __builtin_amdgcn_ballot_w64(pd > d);
+    const bool take = __builtin_amdgcn_inverse_ballot_w64((lt & LOW) | (gt & ~LOW));
     d = take ? pd : d;
     i = take ? pi : i;
 }
+template <int JB, int CTRL>  // partner through a DPP lane pattern (no LDS round trip)
+__device__ __forceinline__ void knn_cx_dpp(uint32_t &d, int &i)
+{
+    knn_cx_apply<JB>(d, i, pcm_dpp<CTRL>(d), (int)pcm_dpp<CTRL>((uint32_t)i));
+}
+template <int JB>  // partner through ds_bpermute
+__device__ __forceinline__ void knn_cx_perm(uint32_t &d, int &i, int addr)
+{
+    knn_cx_apply<JB>(d, i, (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)d), __builtin_amdgcn_ds_bpermute(addr, i));
+}
 
-// ascending bitonic sort of 64 (d, i) pairs held one per lane
+// the last log2(W) steps of a bitonic merge of width W (partners lane ^ W/2 ... lane ^ 1), ascending
+template <int W>
+__device__ __forceinline__ void knn_merge_tail(uint32_t &d, int &i, const XorAddr &xa)
+{
+    if (W >= 64) knn_cx_perm<4>(d, i, xa.a[2]);  // ^16
+    if (W >= 32) knn_cx_perm<3>(d, i, xa.a[1]);  // ^8
+    if (W >= 16) knn_cx_perm<2>(d, i, xa.a[0]);  // ^4
+    if (W >= 8) knn_cx_dpp<1, 0x4E>(d, i);       // ^2: quad_perm [2,3,0,1]
+    if (W >= 4) knn_cx_dpp<0, 0xB1>(d, i);       // ^1: quad_perm [1,0,3,2]
+}
+
+// ascending bitonic sort of 64 (d, i) pairs held one per lane.  "Mirror" form: each merge stage starts by comparing lane l
+// with lane l ^ (W - 1), after which every step keeps the smaller key in the lower lane -- no alternating directions, and
+// the mirrors of width 2 .. 16 as well as the ^1 / ^2 exchanges are DPP patterns: 13 of the 21 steps never touch the LDS.
 __device__ __forceinline__ void knn_sort64(uint32_t &d, int &i, const XorAddr &xa, int lane)
 {
-#define PCM_CX(KB, JB) knn_cx<JB>(d, i, xa, (((lane >> (JB)) & 1) == 0) == ((KB) == 6 || ((lane >> (KB)) & 1) == 0))
-    PCM_CX(1, 0);
-    PCM_CX(2, 1); PCM_CX(2, 0);
-    PCM_CX(3, 2); PCM_CX(3, 1); PCM_CX(3, 0);
-    PCM_CX(4, 3); PCM_CX(4, 2); PCM_CX(4, 1); PCM_CX(4, 0);
-    PCM_CX(5, 4); PCM_CX(5, 3); PCM_CX(5, 2); PCM_CX(5, 1); PCM_CX(5, 0);
-    PCM_CX(6, 5); PCM_CX(6, 4); PCM_CX(6, 3); PCM_CX(6, 2); PCM_CX(6, 1); PCM_CX(6, 0);
-#undef PCM_CX
+    knn_cx_dpp<0, 0xB1>(d, i);   // W = 2: ^1
+    knn_cx_dpp<1, 0x1B>(d, i);   // W = 4: ^3 (quad_perm [3,2,1,0]); the lower lane of the pair is the one with bit 1 clear
+    knn_merge_tail<4>(d, i, xa);
+    knn_cx_dpp<2, 0x141>(d, i);  // W = 8: ^7 (row_half_mirror)
+    knn_merge_tail<8>(d, i, xa);
+    knn_cx_dpp<3, 0x140>(d, i);  // W = 16: ^15 (row_mirror)
+    knn_merge_tail<16>(d, i, xa);
+    knn_cx_perm<4>(d, i, xa.a[3]);  // W = 32: ^31
+    knn_merge_tail<32>(d, i, xa);
+    knn_cx_perm<5>(d, i, xa.a[4]);  // W = 64: ^63
+    knn_merge_tail<64>(d, i, xa);
 }
 
 // buffer (cnt <= 128 unsorted entries in LDS) -> its 64 smallest, sorted ascending, one per lane (missing entries: key ~0u)
@@ -202,15 +238,13 @@ __device__ __forceinline__ void knn_compact(const uint32_t *bd, const int *bi, i
         int ei = 64 + lane < cnt ? bi[64 + lane] : -1;
         knn_sort64(e, ei, xa, lane);
         // min(d[l], e[63 - l]) over l is a bitonic sequence holding the 64 smallest of the 128
-        const int rev = (63 - lane) << 2;
-        const uint32_t re = (uint32_t)__builtin_amdgcn_ds_bpermute(rev, (int)e);
-        const int rei = __builtin_amdgcn_ds_bpermute(rev, ei);
+        const uint32_t re = (uint32_t)__builtin_amdgcn_ds_bpermute(xa.a[4], (int)e);  // lane 63 - l
+        const int rei = __builtin_amdgcn_ds_bpermute(xa.a[4], ei);
         const bool take = re < d;
         d = take ? re : d;
         i = take ? rei : i;
-#define PCM_CX(JB) knn_cx<JB>(d, i, xa, ((lane >> (JB)) & 1) == 0)
-        PCM_CX(5); PCM_CX(4); PCM_CX(3); PCM_CX(2); PCM_CX(1); PCM_CX(0);
-#undef PCM_CX
+        knn_cx_perm<5>(d, i, xa.a[5]);  // ^32
+        knn_merge_tail<64>(d, i, xa);
     }
 }
 
@@ -227,8 +261,8 @@ __global__ __launch_bounds__(64 * kWaves) void pcm_knn_twopass_kernel(int b, int
     const int K1 = nsample + 1;
     const uint32_t PAD = __float_as_uint(1e10f);
     XorAddr xa;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) xa.a[k] = (lane ^ (1 << k)) << 2;
+    xa.a[0] = (lane ^ 4) << 2, xa.a[1] = (lane ^ 8) << 2, xa.a[2] = (lane ^ 16) << 2;
+    xa.a[3] = (lane ^ 31) << 2, xa.a[4] = (lane ^ 63) << 2, xa.a[5] = (lane ^ 32) << 2;
     uint32_t *bd = cand_d[wave];
     int *bi = cand_i[wave];
     for (int qb = blockIdx.x * kWaves; qb < m; qb += gridDim.x * kWaves) {
@@ -301,7 +335,7 @@ __global__ __launch_bounds__(64 * kWaves) void pcm_knn_twopass_kernel(int b, int
                             const uint32_t mid = lo + ((hi - lo) >> 1);
                             if (__builtin_popcountll(__ballot(lmin <= mid)) >= K1) hi = mid; else lo = mid + 1u;
                         }
-                        tau = hi + 1u;
+                        tau = (uint32_t)__builtin_amdgcn_readfirstlane((int)(hi + 1u));  // keep the threshold on the scalar unit
                     }
                 }
                 // ---- pass 2: the registers below tau go to the candidate buffer
@@ -315,7 +349,7 @@ __global__ __launch_bounds__(64 * kWaves) void pcm_knn_twopass_kernel(int b, int
                         if (cnt + n <= kBufCap) {
                             const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
                             if (hit) bd[pos] = dreg[s], bi[pos] = pbase0 + s * 64 + lane;
-                            cnt += n;
+                            cnt = __builtin_amdgcn_readfirstlane(cnt + n);
                         } else {
                             overflow = true;
                         }
@@ -328,7 +362,7 @@ __global__ __launch_bounds__(64 * kWaves) void pcm_knn_twopass_kernel(int b, int
                     knn_compact(bd, bi, cnt, d, i, xa, lane);
                     bd[lane] = d, bi[lane] = i;
                     cnt = K1;
-                    tau = min(tau, (uint32_t)__builtin_amdgcn_readlane((int)d, K1 - 1));
+                    tau = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(tau, (uint32_t)__builtin_amdgcn_readlane((int)d, K1 - 1)));
                 }
             }
             __syncthreads();  // the next cloud (or query block) restarts with buffer 0
