@@ -81,12 +81,16 @@ __global__ __launch_bounds__(kBlock) void pcm_sa_index_csr_kernel(int n, const i
     }
 }
 
+// RM[t] = sum over blocks of rm_partial[block][t], t < 12: one wave per output (grid 12), lanes stride over the blocks, fp64,
+// fixed-order tree -- the single-thread-per-output loop this replaces took 86 us at n = 131072 (512 dependent loads)
 __global__ __launch_bounds__(64) void pcm_sa_rm_reduce_kernel(int nblocks, const float *__restrict__ rm_partial, float *__restrict__ RM)
 {
-    if (threadIdx.x >= 12) return;
+    const int t = blockIdx.x, lane = threadIdx.x;
     double v = 0.0;
-    for (int b = 0; b < nblocks; ++b) v += (double)rm_partial[(size_t)b * 12 + threadIdx.x];
-    RM[threadIdx.x] = (float)v;
+    for (int b = lane; b < nblocks; b += 64) v += (double)rm_partial[(size_t)b * 12 + t];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (lane == 0) RM[t] = (float)v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -306,7 +310,7 @@ extern "C" int pcm_sa_index_det_hip(int m, int K, int n, const float *p, const f
     float *rm_partial = reinterpret_cast<float *>(scratch + pcm_scatter_plan_sorted_scratch_ints(n));
     const int blocks = (n + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(pcm_sa_index_csr_kernel, dim3(blocks), dim3(kBlock), 0, st, n, start, list, (const float4 *)ent, cnt, S, rm_partial);
-    hipLaunchKernelGGL(pcm_sa_rm_reduce_kernel, dim3(1), dim3(64), 0, st, blocks, rm_partial, RM);
+    hipLaunchKernelGGL(pcm_sa_rm_reduce_kernel, dim3(12), dim3(64), 0, st, blocks, rm_partial, RM);
     return PCM_LAUNCH_STATUS();
 }
 
