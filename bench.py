@@ -149,7 +149,7 @@ def pointops_and_sa_kernels(t, shape, device):
                  "dist_evals_per_s": round(sum(sizes) * picks / ms * 1e3, 1)})
     ms = timed_events(lambda: knn_query_raw(k, coord, off, n_p, noff), 20)
     evals = sum(sz * m_per for sz in sizes)
-    t.add("pcm_knn_fast_kernel(+exact)", ms, 12 * n_tot + 12 * m + 8 * m * k, "alu",
+    t.add("pcm_knn_twopass_kernel(+exact)", ms, 12 * n_tot + 12 * m + 8 * m * k, "alu",
           "%.1f M distance evaluations; sampling side stream" % (evals / 1e6), extra={"dist_evals_per_s": round(evals / ms * 1e3, 1)})
 
     # ---- fused set-abstraction layer, one kernel at a time (bf16 Gf as under autocast) ----------------
@@ -511,7 +511,7 @@ TRACE_TO_TABLE = [
     ("pcm_sa_bwd1_pack", "pcm_sa_bwd1_pack_kernel"), ("pcm_sa_bwd1_gather", "pcm_sa_bwd1_gather_kernel"),
     ("pcm_attn_flash_fwd", "pcm_attn_flash_fwd_kernel"), ("pcm_attn_flash_bwd_dkv", "pcm_attn_flash_bwd_dkv_kernel"),
     ("pcm_attn_flash_bwd_dq", "pcm_attn_flash_bwd_dq_kernel"),
-    ("pcm_fps", "pcm_fps_reg_kernel"), ("pcm_knn", "pcm_knn_fast_kernel"), ("pcm_sa_fwd", "pcm_sa_fwd_kernel"),
+    ("pcm_fps", "pcm_fps_reg_kernel"), ("pcm_knn", "pcm_knn_twopass_kernel"), ("pcm_sa_fwd", "pcm_sa_fwd_kernel"),
     ("pcm_sa_apply", "pcm_sa_apply_kernel"), ("pcm_sa_entries", "pcm_sa_entries+index"), ("pcm_sa_index", "pcm_sa_entries+index"),
     ("pcm_sa_bwd1", "pcm_sa_bwd1"), ("pcm_sa_bwd2", "pcm_sa_bwd2_kernel"), ("pcm_sa_reduce", "pcm_sa_reduce_kernel"),
     ("pcm_drln_fwd", "pcm_drln_fwd_kernel"), ("pcm_drln_bwd", "pcm_drln_bwd_kernel"), ("pcm_drln_reduce", "pcm_drln_bwd_kernel"),

@@ -383,62 +383,79 @@ __global__ __launch_bounds__(64 * kWaves) void pcm_knn_twopass_kernel(int b, int
     }
 }
 
-// Literal reference algorithm for the queries the fast kernel marked (or for all, if all_queries).
-__global__ __launch_bounds__(64) void pcm_knn_exact_kernel(int b, int m, int nsample, int all_queries,
-                                                          const float *__restrict__ xyz,
-                                                          const float *__restrict__ new_xyz,
-                                                          const int *__restrict__ offset,
-                                                          const int *__restrict__ new_offset,
-                                                          int *__restrict__ idx,
-                                                          float *__restrict__ dist2)
+// Literal reference algorithm for the queries the fast kernel marked (or for all, if all_queries): the reference's heap
+// (knn_query_cuda_kernel.cu:15-42, :86-103), kept in LDS and driven by lane 0 -- its order of operations decides which of
+// several equal distances survives, so it is replayed literally.  One WAVE per query: the 64 lanes compute the distances
+// of a slab, a ballot against the current heap root finds the points that can enter at all, and only those go through the
+// serial heap code in ascending index order (re-checked against the root, which the previous one may have lowered) --
+// exactly the sequence of `if (d2 < best_dist[0])` hits of the reference's loop.  (One thread per query, as before, took
+// 455 us for a single marked query of a 5000-point cloud; this takes ~25 us.)
+__global__ __launch_bounds__(64 * kWaves) void pcm_knn_exact_kernel(int b, int m, int nsample, int all_queries,
+                                                                   const float *__restrict__ xyz,
+                                                                   const float *__restrict__ new_xyz,
+                                                                   const int *__restrict__ offset,
+                                                                   const int *__restrict__ new_offset,
+                                                                   int *__restrict__ idx,
+                                                                   float *__restrict__ dist2)
 {
-    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < m; q += gridDim.x * blockDim.x) {
-        if (!all_queries && !(dist2[(size_t)q * nsample] < 0.f)) continue;
+    __shared__ float hd[kWaves][PCM_KNN_MAX_NSAMPLE];
+    __shared__ int hi[kWaves][PCM_KNN_MAX_NSAMPLE];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    volatile float *bd = hd[wave];
+    volatile int *bi = hi[wave];
+    auto reheap = [&](int k) {  // lane 0 only
+        int root = 0, child = 1;
+        while (child < k) {
+            if (child + 1 < k && bd[child + 1] > bd[child]) child++;
+            if (bd[root] > bd[child]) return;
+            const float td = bd[root];
+            const int ti = bi[root];
+            bd[root] = bd[child];
+            bi[root] = bi[child];
+            bd[child] = td;
+            bi[child] = ti;
+            root = child;
+            child = root * 2 + 1;
+        }
+    };
+    for (int q = blockIdx.x * kWaves + wave; q < m; q += gridDim.x * kWaves) {
+        if (!all_queries && !(dist2[(size_t)q * nsample] < 0.f)) continue;  // wave-uniform
         const int bt = pcm_cloud_of(q, new_offset, b);
         const int start = bt == 0 ? 0 : offset[bt - 1];
         const int end = offset[bt];
         const float qx = new_xyz[(size_t)q * 3 + 0];
         const float qy = new_xyz[(size_t)q * 3 + 1];
         const float qz = new_xyz[(size_t)q * 3 + 2];
-        float bd[PCM_KNN_MAX_NSAMPLE];
-        int bi[PCM_KNN_MAX_NSAMPLE];
-        for (int i = 0; i < nsample; ++i) {
-            bd[i] = 1e10f;
-            bi[i] = -1;
-        }
-        auto reheap = [&](int k) {
-            int root = 0, child = 1;
-            while (child < k) {
-                if (child + 1 < k && bd[child + 1] > bd[child]) child++;
-                if (bd[root] > bd[child]) return;
-                const float td = bd[root];
-                const int ti = bi[root];
-                bd[root] = bd[child];
-                bi[root] = bi[child];
-                bd[child] = td;
-                bi[child] = ti;
-                root = child;
-                child = root * 2 + 1;
-            }
-        };
-        for (int i = start; i < end; ++i) {
-            const float d2 = pcm_sqdist(qx, qy, qz, xyz[(size_t)i * 3 + 0], xyz[(size_t)i * 3 + 1], xyz[(size_t)i * 3 + 2]);
-            if (d2 < bd[0]) {
-                bd[0] = d2;
-                bi[0] = i;
-                reheap(nsample);
+        for (int i = lane; i < nsample; i += 64) bd[i] = 1e10f, bi[i] = -1;
+        for (int base = start; base < end; base += 64) {
+            const int p = base + lane;
+            float d2 = INFINITY;
+            if (p < end) d2 = pcm_sqdist(qx, qy, qz, xyz[(size_t)p * 3 + 0], xyz[(size_t)p * 3 + 1], xyz[(size_t)p * 3 + 2]);
+            unsigned long long cand = __ballot(d2 < bd[0]);  // the root only ever decreases: a superset of the hits
+            while (cand) {
+                const int l = __builtin_ctzll(cand);  // ascending lane == ascending point index
+                cand &= cand - 1;
+                const float dd = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(d2), l));
+                if (lane == 0 && dd < bd[0]) {
+                    bd[0] = dd;
+                    bi[0] = base + l;
+                    reheap(nsample);
+                }
             }
         }
-        for (int i = nsample - 1; i > 0; --i) {
-            const float td = bd[0];
-            const int ti = bi[0];
-            bd[0] = bd[i];
-            bi[0] = bi[i];
-            bd[i] = td;
-            bi[i] = ti;
-            reheap(i);
+        if (lane == 0) {
+            for (int i = nsample - 1; i > 0; --i) {
+                const float td = bd[0];
+                const int ti = bi[0];
+                bd[0] = bd[i];
+                bi[0] = bi[i];
+                bd[i] = td;
+                bi[i] = ti;
+                reheap(i);
+            }
         }
-        for (int i = 0; i < nsample; ++i) {
+        for (int i = lane; i < nsample; i += 64) {
             idx[(size_t)q * nsample + i] = bi[i];
             dist2[(size_t)q * nsample + i] = bd[i];
         }
@@ -455,7 +472,7 @@ extern "C" int pcm_knn_query_n_hip(int b, int n_max, int m, int nsample, const f
     if (m < 0 || nsample < 1 || nsample > PCM_KNN_MAX_NSAMPLE || n_max < 0) return PCM_ERR_BAD_ARG;
     if (m == 0) return PCM_OK;
     hipStream_t st = (hipStream_t)stream;
-    const int exact_blocks = (m + 63) / 64 < 4096 ? (m + 63) / 64 : 4096;
+    const int exact_blocks = (m + kWaves - 1) / kWaves < 2048 ? (m + kWaves - 1) / kWaves : 2048;  // one wave per query, grid-strided
     if (nsample <= kFastMaxNsample) {
         {
             // queries per wave.  Measured on MI355X (us; Q = 1 / 2 / 4): 128 x 1024 pts, m = 65536: 255 / 236 / 229;
@@ -479,11 +496,13 @@ extern "C" int pcm_knn_query_n_hip(int b, int n_max, int m, int nsample, const f
         }
         int rc = PCM_LAUNCH_STATUS();
         if (rc) return rc;
-        hipLaunchKernelGGL(pcm_knn_exact_kernel, dim3(exact_blocks), dim3(64), 0, st, b, m, nsample, 0, xyz, new_xyz, offset,
+        static const int skip_exact = getenv("PCM_KNN_SKIP_EXACT") ? atoi(getenv("PCM_KNN_SKIP_EXACT")) : 0;  // tools/mb: count the marked queries
+        if (skip_exact) return PCM_OK;
+        hipLaunchKernelGGL(pcm_knn_exact_kernel, dim3(exact_blocks), dim3(64 * kWaves), 0, st, b, m, nsample, 0, xyz, new_xyz, offset,
                            new_offset, idx, dist2);
         return PCM_LAUNCH_STATUS();
     }
-    hipLaunchKernelGGL(pcm_knn_exact_kernel, dim3(exact_blocks), dim3(64), 0, st, b, m, nsample, 1, xyz, new_xyz, offset,
+    hipLaunchKernelGGL(pcm_knn_exact_kernel, dim3(exact_blocks), dim3(64 * kWaves), 0, st, b, m, nsample, 1, xyz, new_xyz, offset,
                        new_offset, idx, dist2);
     return PCM_LAUNCH_STATUS();
 }
