@@ -365,6 +365,11 @@ extern "C" int pcm_farthest_point_sampling_hip(int b, int n, const float *xyz, c
             return launch_reg<256, 4, 1, true>(b, xyz, offset, new_offset, idx, L, st);
         }
         // BS == 1024: four reference threads per thread
+        // n <= 1024: 128 threads x 8 points (two waves to synchronise per pick instead of four) measured 476 vs 498 ns / pick
+        // at 8 x 1024 and 482 vs 562 at 128 x 1024; ONE wave x 16 points is slower again (599: the in-thread chain dominates)
+        static const int small_t = getenv("PCM_FPS_SMALL_T") ? atoi(getenv("PCM_FPS_SMALL_T")) : 128;  // A/B switch for tools/mb
+        if (need <= 4 && small_t == 64) return launch_reg<64, 16, 4, true>(b, xyz, offset, new_offset, idx, L, st);
+        if (need <= 4 && small_t == 128) return launch_reg<128, 8, 3, true>(b, xyz, offset, new_offset, idx, L, st);
         if (need <= 4) return launch_reg<256, 4, 2, true>(b, xyz, offset, new_offset, idx, L, st);
         if (need <= 8) return launch_reg<256, 8, 2, true>(b, xyz, offset, new_offset, idx, L, st);
         return launch_reg<256, 16, 2, true>(b, xyz, offset, new_offset, idx, L, st);
