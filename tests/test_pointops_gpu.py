@@ -64,6 +64,10 @@ KNN_CASES = [
     ([5000, 1], [2500, 3], 16, "lattice"),                    # > 8 chunks of 512 points; a one-point cloud behind it
     ([4096] * 8, [2048] * 8, 16, "uniform"),                  # m = 16384: four queries per wave
     ([1024] * 16, [600] * 16, 8, "dup"),                      # m = 9600: two queries per wave, duplicates
+    # two-pass kernel: clouds of several 4096-point register stretches (buffer compacted in between), ragged stretch tails
+    ([9000, 4097, 12289], [300, 200, 400], 16, "uniform"),
+    ([8192 + 5], [500], 32, "lattice"),                       # ties across stretch boundaries -> exact kernel
+    ([4500], [200], 62, "uniform"),                           # nsample + 1 = 63 list entries, candidates close to the buffer size
 ]
 
 
@@ -86,6 +90,25 @@ def test_knn_bit_exact(hip_device, sizes, ms, nsample, mode):
     assert torch.equal(pi.cpu(), wi)
     # torch.sqrt on the GPU is not correctly rounded (1 ulp off the CPU's): fp32 feature tolerance
     torch.testing.assert_close(pd.cpu(), torch.sqrt(wd), rtol=1e-6, atol=0)
+
+
+def test_knn_candidate_buffer_overflow_goes_to_the_exact_kernel(hip_device):
+    """More than 128 points below the two-pass kernel's threshold: 400 copies of each of 8 locations.  Every lane minimum is
+    one of 8 values, so the threshold admits hundreds of equal distances, the candidate buffer overflows and the query must
+    come back from the exact kernel -- bit-exact like everything else (the reference's heap decides among the copies)."""
+    from pointcloudmatters_amd.pointops.query import knn_query_raw
+    from oracle import pointops_cpu as ref
+
+    g = torch.Generator().manual_seed(3)
+    base = torch.rand(8, 3, generator=g)
+    xyz = base.repeat_interleave(400, dim=0)[torch.randperm(3200, generator=g)].contiguous()
+    xyz = torch.cat([xyz, torch.rand(900, 3, generator=g)]).contiguous()  # a second, ordinary cloud behind it
+    off = torch.tensor([3200, 4100], dtype=torch.int32)
+    new_xyz = torch.cat([base, torch.rand(24, 3, generator=g), xyz[3200:3232]]).contiguous()
+    noff = torch.tensor([32, 64], dtype=torch.int32)
+    wi, wd = ref.knn_query_raw(16, xyz, off, new_xyz, noff)
+    gi, gd = knn_query_raw(16, xyz.to(hip_device), off.to(hip_device), new_xyz.to(hip_device), noff.to(hip_device))
+    assert torch.equal(gi.cpu(), wi) and torch.equal(gd.cpu(), wd)
 
 
 def test_knn_self_query_defaults(hip_device):
