@@ -145,8 +145,20 @@ class FlatAdamW:
         for dsts, srcs in by_dtype.values():
             if first:
                 torch._foreach_copy_(dsts, srcs)
+            elif srcs[0].dtype == torch.float32:
+                torch._foreach_add_(dsts, srcs)
             else:
-                torch._foreach_add_(dsts, [s_.to(torch.float32) for s_ in srcs] if srcs[0].dtype != torch.float32 else srcs)
+                # bf16 gradients into the fp32 buffer.  Large tensors: one mixed-dtype add each (reads 2 B + 4 B, writes 4 B
+                # per element -- the cast-then-add route moved 18 B and ran a cast kernel per tensor); the many small ones
+                # stay on the multi-tensor path.  Same sums either way (the bf16 value is widened exactly).
+                small_d, small_s = [], []
+                for d, s_ in zip(dsts, srcs):
+                    if s_.numel() >= (1 << 18):
+                        d.add_(s_)
+                    else:
+                        small_d.append(d), small_s.append(s_.to(torch.float32))
+                if small_d:
+                    torch._foreach_add_(small_d, small_s)
 
     # ---- device side (capturable) -----------------------------------------------------------------
     def zero_grad(self):
