@@ -23,3 +23,22 @@ for k, v in sorted(agg.items(), key=lambda x: -x[1][1])[:top if not odd else 100
     if odd and not (("Cijk" not in k and "pcm_" not in k and avg > 14) or (small and avg > 12) or ("pcm_" in k and avg > 60)):
         continue
     print(f"{v[0]:4d} {avg:8.1f}us tot {v[1]:8.1f}  {k}")
+
+if "--gaps" in sys.argv:  # idle time of the device inside the step (union over streams)
+    ev = sorted((r[1], r[2]) for r in step)
+    cs, ce = ev[0]
+    busy, gaps = 0, []
+    for s_, e_ in ev[1:]:
+        if s_ > ce:
+            gaps.append((s_ - ce, ce - step[0][1]))
+            busy += ce - cs
+            cs, ce = s_, e_
+        else:
+            ce = max(ce, e_)
+    busy += ce - cs
+    print("union busy us", round(busy / 1e3), "idle us", round(sum(g for g, _ in gaps) / 1e3), "gaps > 15 us (us, at us):",
+          [(round(g / 1e3), round(t / 1e3)) for g, t in gaps if g > 15e3][:40])
+    per = collections.Counter(r[6] for r in step)
+    for sid, n in per.items():
+        ks = [r for r in step if r[6] == sid]
+        print(" stream", sid, "kernels", n, "busy us", round(sum(r[2] - r[1] for r in ks) / 1e3), "from", round((ks[0][1] - step[0][1]) / 1e3), "to", round((ks[-1][2] - step[0][1]) / 1e3))

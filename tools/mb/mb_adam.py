@@ -16,3 +16,10 @@ for n_par in (24_100_000//64*64, 255_600_000//64*64):
         e0.record(); run(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
     ts.sort(); t=ts[len(ts)//2]
     print(f"n={n_par/1e6:.1f}M adamw {t*1e3:.1f} us  {30*n_par/t/1e6:.0f} GB/s  frac {30*n_par/t/1e6/8000:.3f}")
+    def run2(): assert L.pcm_grad_sumsq_hip(n_par,g.data_ptr(),parts.data_ptr(),ctypes.addressof(npart),st)==0
+    for _ in range(3): run2()
+    ts=[]
+    for _ in range(20):
+        e0.record(); run2(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
+    ts.sort(); t=ts[len(ts)//2]
+    print(f"n={n_par/1e6:.1f}M sumsq {t*1e3:.1f} us  {4*n_par/t/1e6:.0f} GB/s  frac {4*n_par/t/1e6/8000:.3f}")
