@@ -123,9 +123,12 @@ def build(verbose=False):
 def load():
     """Load the library and bind every declared symbol.  Raises PointopsLibraryError if anything
     is missing -- the product never degrades to a non-HIP path."""
-    global _LIB
+    global _LIB, LIB_PATH
     if _LIB is not None:
         return _LIB
+    # PCM_POINTOPS_LIB: another BUILD of the same library (the address-sanitizer build of `make -C csrc asan`, tools/run_asan.sh).
+    # Still the HIP library with every symbol checked below -- not a fallback path.
+    LIB_PATH = os.environ.get("PCM_POINTOPS_LIB", LIB_PATH)
     if not os.path.exists(LIB_PATH):
         raise PointopsLibraryError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
