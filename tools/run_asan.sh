@@ -12,6 +12,8 @@ LOG=gpurun_out/asan_$TAG.log
   export HSA_XNACK=1 PCM_POINTOPS_LIB=$PWD/pointcloudmatters_amd/lib_asan/libpcm_pointops.so
   export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:halt_on_error=1
   echo "# pytest (LD_PRELOAD=$RT)"
-  LD_PRELOAD=$RT timeout 900 python -m pytest tests/test_pointops_gpu.py tests/test_segsum_gpu.py -q -m gpu -x -k "not 4096 and not 16384 and not 9000" 2>&1 | grep -v "NCCL\|RCCL" | tail -15
+  LD_PRELOAD=$RT timeout 900 python -m pytest tests/test_pointops_gpu.py tests/test_segsum_gpu.py -q -m gpu -x -k "not 4096 and not 16384 and not 9000" > gpurun_out/asan_pytest_$TAG.txt 2>&1
+  echo "# pytest exit status $?"
+  grep -v "NCCL\|RCCL" gpurun_out/asan_pytest_$TAG.txt | tail -25
 } > $LOG 2>&1
 tail -20 $LOG
