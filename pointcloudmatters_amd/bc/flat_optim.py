@@ -14,6 +14,7 @@ import torch
 
 from .. import _lib
 from .._host import PinnedRing
+from .._lib import raw_stream as _raw_stream
 
 _ALIGN = 64  # floats: every parameter view starts on a 256-byte boundary
 
@@ -167,7 +168,7 @@ class FlatAdamW:
 
     def launch_step(self):
         """Enqueue norm + AdamW on the current stream.  No host reads: safe inside graph capture."""
-        st = torch.cuda.current_stream().cuda_stream
+        st = _raw_stream()
         lib = self.lib
         import ctypes
 

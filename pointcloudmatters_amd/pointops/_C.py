@@ -10,10 +10,11 @@ Like the reference: caller-owned, pre-allocated / pre-filled buffers, no validat
 import torch
 
 from .. import _lib
+from .._lib import raw_stream as _raw_stream
 
 
 def _st():
-    return torch.cuda.current_stream().cuda_stream
+    return _raw_stream()
 
 
 def _f(t):

@@ -2,6 +2,7 @@
 import torch
 
 from .. import _lib
+from .._lib import raw_stream as _raw_stream
 
 
 def lib():
@@ -38,7 +39,7 @@ def ptr(t):
 
 
 def stream():
-    return torch.cuda.current_stream().cuda_stream
+    return _raw_stream()
 
 
 def host_offsets(offset):

@@ -8,6 +8,7 @@ import torch
 from torch.autograd import Function
 
 from .. import _lib
+from .._lib import raw_stream as _raw_stream
 
 
 def _ptr(t):
@@ -21,7 +22,7 @@ class _BNReLU(Function):
         n, c = y.shape
         y = y.contiguous()
         dev = y.device
-        st = torch.cuda.current_stream().cuda_stream
+        st = _raw_stream()
         count = None
         if n == 0:
             # a rank without rows (ragged data-parallel batches): nothing to launch, but with synchronised statistics the rank
@@ -77,7 +78,7 @@ class _BNReLU(Function):
         with torch.cuda.device(dev):
             sums = torch.empty(2, c, dtype=torch.float32, device=dev)
             dy = torch.empty_like(y)
-            st = torch.cuda.current_stream().cuda_stream
+            st = _raw_stream()
             args = (n, c, int(y.dtype == torch.bfloat16), y.data_ptr(), dz.data_ptr(), stat.data_ptr(), ctx.partial.data_ptr())
             sync_bn, count = ctx.sync
             if sync_bn is None:
@@ -126,6 +127,6 @@ def bn_relu(y, bn):
         z = torch.empty_like(y)
         rc = L.pcm_bn_relu_forward_hip(n, c, int(y.dtype == torch.bfloat16), y.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(),
                                        float(bn.eps), 0.0, 0, 0, 1, 0, 0, stat.data_ptr(), z.data_ptr(),
-                                       torch.cuda.current_stream().cuda_stream)
+                                       _raw_stream())
     _lib.check(rc, "pcm_bn_relu_forward_hip")
     return z

@@ -24,6 +24,7 @@ import torch.nn.functional as F
 from .rows_linear import linear_rows
 from .sa_layer import set_abstraction
 from .unet_ops import conv1d_cl, conv_transpose1d_cl, gn_mish_cl
+from .._lib import raw_stream as _raw_stream
 
 
 # ----------------------------------------------------------------------------- U-Net pieces
@@ -301,7 +302,7 @@ class DDPMSchedule(nn.Module):
                                          nz.data_ptr() if nz is not None else 0,
                                          mask8.data_ptr() if mask8 is not None else 0,
                                          cnd.data_ptr() if cnd is not None else 0, sa, sb, c0, ct, sigma, clip,
-                                         prev.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                                         prev.data_ptr(), _raw_stream())
             _lib.check(rc, "pcm_ddpm_step_hip")
             return prev
         x0 = (sample - sb * model_output.float()) / sa

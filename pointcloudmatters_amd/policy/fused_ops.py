@@ -13,6 +13,7 @@ from torch.autograd import Function
 
 from .. import _lib
 from .rows_linear import goes_to_optimizer as _goes_to_optimizer
+from .._lib import raw_stream as _raw_stream
 
 _ACTIVE = None
 
@@ -135,7 +136,7 @@ def _drln_forward(x2, y2, gamma, beta, eps, p_drop, seed, site):
         rc = L.pcm_drln_forward_hip(R, E, 1 if y2.dtype == torch.bfloat16 else 0, x2.data_ptr(), y2.data_ptr(), gamma.data_ptr(),
                                     beta.data_ptr(), float(eps), float(p_drop), seed.data_ptr() if seed is not None else 0,
                                     int(site), s.data_ptr(), out.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                    torch.cuda.current_stream().cuda_stream)
+                                    _raw_stream())
     _lib.check(rc, "pcm_drln_forward_hip")
     return out, s, mean, rstd
 
@@ -157,7 +158,7 @@ def _drln_backward(dout, s, mean, rstd, gamma, ydtype, p_drop, seed, site, dysum
         rc = L.pcm_drln_backward_hip(R, E, 1 if ydtype == torch.bfloat16 else 0, d2.data_ptr(), s.data_ptr(), mean.data_ptr(),
                                      rstd.data_ptr(), gamma.data_ptr(), p_drop, seed.data_ptr() if seed is not None else 0, site,
                                      dx.data_ptr(), dy.data_ptr(), partial.data_ptr(), sums.data_ptr(),
-                                     db16.data_ptr() if db16 is not None else 0, torch.cuda.current_stream().cuda_stream)
+                                     db16.data_ptr() if db16 is not None else 0, _raw_stream())
     _lib.check(rc, "pcm_drln_backward_hip")
     if dysum_bf16:
         return dx, dy, sums, db16
@@ -254,7 +255,7 @@ class _FFNLN(Function):
             rc = L.pcm_ffn_ln_forward_hip(R, E, Fh, x2.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
                                           gamma.data_ptr(), beta.data_ptr(), float(eps), float(p_hidden), float(p_out), sp,
                                           int(site_a), int(site_b), hd.data_ptr(), s.data_ptr(), out.data_ptr(), mean.data_ptr(),
-                                          rstd.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                                          rstd.data_ptr(), _raw_stream())
         _lib.check(rc, "pcm_ffn_ln_forward_hip")
         ctx.save_for_backward(x2, w1, w2, gamma, hd, s, mean, rstd)
         ctx.meta = (shape, float(p_hidden), float(p_out), seed, int(site_b))
@@ -282,7 +283,7 @@ class _FFNLN(Function):
                                            hd.data_ptr(), w1.data_ptr(), w2.data_ptr(), gamma.data_ptr(), p_hidden, p_out,
                                            seed.data_ptr() if seed is not None else 0, site_b, dx.data_ptr(), dy.data_ptr(),
                                            dh.data_ptr(), partial.data_ptr(), sums.data_ptr(),
-                                           torch.cuda.current_stream().cuda_stream)
+                                           _raw_stream())
             _lib.check(rc, "pcm_ffn_ln_backward_hip")
             from .rows_linear import weight_grad
 
@@ -337,7 +338,7 @@ class _SelfAttnInProj(Function):
             qk_in = torch.empty(rows, E, dtype=bf, device=dev)
             v_in = torch.empty(rows, E, dtype=bf, device=dev)
             rc = L.pcm_add_cast2_hip(x2.numel(), posc.numel(), x2.data_ptr(), posc.data_ptr(), qk_in.data_ptr(), v_in.data_ptr(),
-                                     torch.cuda.current_stream().cuda_stream)
+                                     _raw_stream())
         _lib.check(rc, "pcm_add_cast2_hip")
         with torch.autocast("cuda", enabled=False):
             qk = torch.nn.functional.linear(qk_in, wc[: 2 * E], bc[: 2 * E]).view(*shape[:-1], 2, E)
@@ -363,7 +364,7 @@ class _SelfAttnInProj(Function):
         rows = qk_in.shape[0]
         dev = qk_in.device
         bf = torch.bfloat16
-        st = torch.cuda.current_stream().cuda_stream
+        st = _raw_stream()
         with torch.cuda.device(dev), torch.autocast("cuda", enabled=False):
             if (dq.dtype == bf and dk.dtype == bf and dq.stride() == dk.stride() and dq.stride()[-2:] == (2 * E, 1)
                     and dk.data_ptr() - dq.data_ptr() == 2 * E and dq.is_contiguous() is False
@@ -432,7 +433,7 @@ class _AddPosLinear(Function):
         with torch.cuda.device(x.device):
             s_in = torch.empty(x2.shape, dtype=bf, device=x.device)
             rc = L.pcm_add_cast2_hip(x2.numel(), posc.numel(), x2.data_ptr(), posc.data_ptr(), s_in.data_ptr(), 0,
-                                     torch.cuda.current_stream().cuda_stream)
+                                     _raw_stream())
         _lib.check(rc, "pcm_add_cast2_hip")
         with torch.autocast("cuda", enabled=False):
             y = torch.nn.functional.linear(s_in, wc, bc).view(*shape[:-1], wc.shape[0])

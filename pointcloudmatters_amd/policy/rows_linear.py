@@ -12,6 +12,7 @@ order by pcm_slab_sum_hip with a single rounding to the gradient dtype.
 import torch
 import torch.nn.functional as F
 from torch.autograd import Function
+from .._lib import raw_stream as _raw_stream
 
 MIN_ROWS = 2048        # below this the plain GEMM is as fast
 TARGET_CHUNK = 768     # rows per partial product
@@ -127,7 +128,7 @@ def _weight_grad(go, x, out_dtype, out=None):
         dw = out if out is not None else torch.empty(m, k, dtype=out_dtype, device=go.device)
         with torch.cuda.device(go.device):
             rc = _lib.load().pcm_slab_sum_hip(s, m * k, part.data_ptr(), int(dw.dtype == torch.bfloat16), dw.data_ptr(),
-                                              torch.cuda.current_stream().cuda_stream)
+                                              _raw_stream())
         _lib.check(rc, "pcm_slab_sum_hip")
         return dw
     dw = part.sum(dim=0)

@@ -15,6 +15,7 @@ from torch.autograd import Function
 
 from .. import _lib
 from .rows_linear import linear_rows
+from .._lib import raw_stream as _raw_stream
 
 # How the index statistics and the m*H backward deltas are accumulated:
 #   "sorted"  (default) csrc/sa_scatter.hip: a CSR of the neighbour lists with sorted segments, sums taken in list order --
@@ -53,7 +54,7 @@ def index_stats(p, q, knn_idx, o32=None, no32=None, n_max=0):
             cnt, S, RM = buf[:n], buf[n: 4 * n], buf[4 * n:]
             rc = L.pcm_sa_index_det_hip(m, K, n, p.data_ptr(), q.data_ptr(), knn_idx.data_ptr(), ent.data_ptr(), csr.data_ptr(),
                                         scratch.data_ptr(), cnt.data_ptr(), S.data_ptr(), RM.data_ptr(),
-                                        torch.cuda.current_stream().cuda_stream)
+                                        _raw_stream())
         _lib.check(rc, "pcm_sa_index_det_hip")
         return ent, buf, csr
     with torch.cuda.device(p.device):
@@ -61,7 +62,7 @@ def index_stats(p, q, knn_idx, o32=None, no32=None, n_max=0):
         ent = torch.empty(m, K, 4, dtype=torch.float32, device=p.device)  # (j bits, rel x, rel y, rel z) per neighbour slot
         cnt, S, RM = buf[:n], buf[n: 4 * n], buf[4 * n:]
         rc = L.pcm_sa_index_hip(m, K, p.data_ptr(), q.data_ptr(), knn_idx.data_ptr(), _ptr(o32), _ptr(no32), b, int(n_max),
-                                ent.data_ptr(), cnt.data_ptr(), S.data_ptr(), RM.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                                ent.data_ptr(), cnt.data_ptr(), S.data_ptr(), RM.data_ptr(), _raw_stream())
     _lib.check(rc, "pcm_sa_index_hip")
     return ent, buf
 
@@ -81,7 +82,7 @@ class _SAFused(Function):
         dev = gf.device
         bf = 1 if gf.dtype == torch.bfloat16 else 0
         slots = _slots(L, m, n, H, bf, K, int(o32.shape[0]) if o32 is not None else 0)
-        st = torch.cuda.current_stream().cuda_stream
+        st = _raw_stream()
         with torch.cuda.device(dev):
             f32 = dict(dtype=torch.float32, device=dev)
             sel = torch.empty(m, H, **f32)
@@ -128,7 +129,7 @@ class _SAFused(Function):
         n, H = gf.shape
         m, K = ent.shape[:2]
         dev = gf.device
-        st = torch.cuda.current_stream().cuda_stream
+        st = _raw_stream()
         dz = dz.contiguous().float()
         with torch.cuda.device(dev):
             f32 = dict(dtype=torch.float32, device=dev)
@@ -208,7 +209,7 @@ def _sa_fused_eval(owner, gf, ent, wp):
             m, K, H, bf, gf.data_ptr(), ent.data_ptr(),
             wp.data_ptr(), gamma.data_ptr(), bn.bias.data_ptr(), float(bn.eps), 0.0, 0, 0, sel.data_ptr(),
             asel.data_ptr(), partial.data_ptr(), 0, stat.data_ptr(), z.data_ptr(), 1 | 8,
-            torch.cuda.current_stream().cuda_stream)
+            _raw_stream())
     _lib.check(rc, "pcm_sa_fused_forward_hip")
     return z
 

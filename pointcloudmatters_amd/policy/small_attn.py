@@ -14,6 +14,7 @@ import torch
 from torch.autograd import Function
 
 from .. import _lib
+from .._lib import raw_stream as _raw_stream
 
 
 # The kernels handle any length (tests go to 515 x 515), but they win only for short query sets: measured on MI355X at
@@ -47,7 +48,7 @@ class _SmallAttn(Function):
             rc = fwd(B, heads, L, S, q.data_ptr(), *_st(q), k.data_ptr(), *_st(k), v.data_ptr(), *_st(v),
                      kpm.data_ptr() if kpm is not None else 0, 1.0 / math.sqrt(E // heads), float(p_drop),
                      seed.data_ptr() if seed is not None else 0, int(site), out.data_ptr(),
-                     lse.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                     lse.data_ptr(), _raw_stream())
         _lib.check(rc, "pcm_attn_flash_forward_hip" if use_flash else "pcm_attn_small_forward_hip")
         ctx.save_for_backward(q, k, v, out, lse, kpm)
         ctx.meta = (heads, float(p_drop), seed, int(site), use_flash)
@@ -74,7 +75,7 @@ class _SmallAttn(Function):
             head = (B, heads, L, S, q.data_ptr(), *_st(q), k.data_ptr(), *_st(k), v.data_ptr(), *_st(v),
                     kpm.data_ptr() if kpm is not None else 0, 1.0 / math.sqrt(E // heads), p_drop,
                     seed.data_ptr() if seed is not None else 0, site, out.data_ptr(), dout.data_ptr(), lse.data_ptr())
-            tail = (dq.data_ptr(), *_st(dq), dk.data_ptr(), *_st(dk), dv.data_ptr(), *_st(dv), torch.cuda.current_stream().cuda_stream)
+            tail = (dq.data_ptr(), *_st(dq), dk.data_ptr(), *_st(dk), dv.data_ptr(), *_st(dv), _raw_stream())
             if use_flash:
                 delta = torch.empty(B, heads, L, dtype=torch.float32, device=dev)
                 rc = L_.pcm_attn_flash_backward_hip(*head, delta.data_ptr(), *tail)

@@ -14,10 +14,11 @@ from torch.autograd import Function
 
 from .. import _lib
 from .rows_linear import linear_rows
+from .._lib import raw_stream as _raw_stream
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return _raw_stream()
 
 
 def _bf(t):

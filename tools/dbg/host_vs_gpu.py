@@ -16,7 +16,12 @@ dev = torch.device("cuda:0")
 torch.manual_seed(0)
 pol = build_act_policy(pcd_npoints=wl["pcd_npoints"], sa_impl="fused").to(dev)
 mode = mode or ("hybrid" if wl.get("ragged") else "graph")
-tr = BCTrainer(pol, total_steps=10000, precision="bf16", device=dev, mode=mode, optim=dict(accumulate_grad_batches=1))
+kw = {}
+if "PCM_DBG_STAGED" in os.environ:
+    kw["staged"] = bool(int(os.environ["PCM_DBG_STAGED"]))
+if "PCM_DBG_SPLIT" in os.environ:
+    kw["overlap_rest_backward"] = bool(int(os.environ["PCM_DBG_SPLIT"]))
+tr = BCTrainer(pol, total_steps=10000, precision="bf16", device=dev, mode=mode, optim=dict(accumulate_grad_batches=1), **kw)
 batches = [make_act_batch(wl["batch"], wl["n_points"], seed=s, ragged=wl.get("ragged", False), device=dev) for s in range(4)]
 for i in range(8):
     tr.training_step(clone_batch(batches[i % 4]), prefetch=batches[(i + 1) % 4])
@@ -53,5 +58,17 @@ for s_, e_ in ev[1:]:
 busy += ce - cs
 span = ev[-1][1] - ev[0][0]
 big = sorted(gaps, reverse=True)[:12]
+if "--around" in sys.argv:  # what runs before / after the largest gap
+    evn = sorted((e.time_range.start, e.time_range.end, e.name) for e in prof.events()
+                 if e.device_type == torch.autograd.DeviceType.CUDA and e.time_range.end > e.time_range.start)
+    ends, best, cur_end = [], None, evn[0][1]
+    for i in range(1, len(evn)):
+        if evn[i][0] > cur_end and (best is None or evn[i][0] - cur_end > best[0]) and i > len(evn) // 2:
+            best = (evn[i][0] - cur_end, i)
+        cur_end = max(cur_end, evn[i][1])
+    g, i = best
+    print("largest gap in the second half: %.1f us; kernels around it:" % g)
+    for a, b, n in evn[i - 6:i + 8]:
+        print("   %10.1f  %7.1f us  %s" % (a - evn[i][0], b - a, n[:90]))
 print(f"profiled 6 steps: span {span / 6e3:.3f} ms/step, device busy (union over streams) {busy / 6e3:.3f} ms/step, idle {(span - busy) / 6e3:.3f} ms/step; "
       f"largest gaps (us): {[round(g, 1) for g in big]}")
