@@ -431,6 +431,15 @@ int pcm_slab_sum_hip(int nslabs, long n, const float *partial, int out_is_bf16, 
 int pcm_colsum_hip(long rows, int C, int ntensors, int in_is_bf16, const void *g0, long ld0, const void *g1, long ld1,
                    const void *g2, long ld2, float *partial, int out_is_bf16, void *out, void *stream);
 
+/* ---- sine position embedding of the sampled centres (src/models/components/act/act.py:467-506, default arguments) ------
+ * out (m, H) fp32: for axis a = x, y, z and npf = H / 3 (even), k = npf / 2:
+ *     out[r][a*npf + j]     = sin(coord[r][a] / dim_t[2j]),      j < k
+ *     out[r][a*npf + k + j] = cos(coord[r][a] / dim_t[2j + 1]),  j < k
+ * (the reference's x_embed is (m, 1), so its stack(..., dim=2).flatten(1) yields the sine BLOCK followed by the cosine
+ * block per axis, not DETR's interleaving), columns 3*npf .. H-1 = 0.  dim_t (npf) = temperature ** (2 * (i // 2) / npf) is
+ * passed in (computed once by the caller with the reference's own expression).  One launch instead of ~18 framework kernels. */
+int pcm_coord_embed_sine_hip(long m, int H, int npf, const float *coord, const float *dim_t, float *out, void *stream);
+
 /* ---- multi-head attention for short query sequences (L <= 128 queries, head_dim 64), MFMA -----------------------
  * replaces nn.MultiheadAttention's scaled-dot-product core for the CVAE encoder and the decoder of
  * src/models/components/act/transformer.py:225-262, 296-346 (100-102 queries; 18 of 22 attention calls per step).

@@ -161,6 +161,35 @@ extern "C" int pcm_add2_cast_hip(long n, const void *a_bf16, const void *b_bf16,
     return pcm_add2_cast2_hip(n, a_bf16, b_bf16, out, nullptr, stream);
 }
 
+// sine position embedding, act.py:467-506 with its default arguments (layout: see include/pcm_pointops.h)
+__global__ __launch_bounds__(256) void pcm_coord_embed_sine_kernel(long total, int H, int npf, const float *__restrict__ coord,
+                                                                    const float *__restrict__ dim_t, float *__restrict__ out)
+{
+    const int k = npf / 2;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long r = e / H;
+        const int c = (int)(e - r * H);
+        float v = 0.f;
+        if (c < 3 * npf) {
+            const int a = c / npf, i = c - a * npf;
+            const float x = coord[r * 3 + a];
+            v = i < k ? sinf(x / dim_t[2 * i]) : cosf(x / dim_t[2 * (i - k) + 1]);
+        }
+        out[e] = v;
+    }
+}
+
+extern "C" int pcm_coord_embed_sine_hip(long m, int H, int npf, const float *coord, const float *dim_t, float *out, void *stream)
+{
+    if (m < 0 || H <= 0 || npf <= 0 || (npf & 1) || 3 * npf > H) return PCM_ERR_BAD_ARG;
+    if (m == 0) return PCM_OK;
+    const long total = m * (long)H;
+    long blocks = (total + 255) / 256;
+    if (blocks > 65535) blocks = 65535;
+    hipLaunchKernelGGL(pcm_coord_embed_sine_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, total, H, npf, coord, dim_t, out);
+    return PCM_LAUNCH_STATUS();
+}
+
 extern "C" int pcm_slab_sum_hip(int nslabs, long n, const float *partial, int out_is_bf16, void *out, void *stream)
 {
     // out[e] = sum_s partial[s][e]: the closing reduction of a split-K product (policy/rows_linear.py), fp64 accumulation in a

@@ -21,13 +21,19 @@ import torch
 
 
 def coord_embedding_sine(coord, hidden_dim, temperature=10000, normalize=False, scale=None):
-    """act.py:467-506: per-axis interleaved sin/cos with H//3 features per axis, zero-padded to H."""
+    """act.py:467-506: per axis H//3 features -- with the default arguments the sine BLOCK followed by the cosine block (the
+    reference's x_embed is (m, 1) there; with `normalize` it is (m,) and the two interleave) --, zero-padded to H.
+    On the HIP device the default-argument form is one kernel (csrc/tokens.hip) instead of ~18 framework launches."""
     npf = hidden_dim // 3
     pad = hidden_dim - npf * 3
     if scale is not None and normalize is False:
         raise ValueError("normalize should be True if scale is passed")
     if scale is None:
         scale = 2 * torch.pi
+    if coord.is_cuda and not normalize and npf > 0 and npf % 2 == 0 and coord.dtype == torch.float32 and coord.dim() == 2 \
+            and coord.shape[1] == 3 and not (torch.is_grad_enabled() and coord.requires_grad) \
+            and ((npf, float(temperature), coord.device) in _DIM_T or not torch.cuda.is_current_stream_capturing()):
+        return _coord_embedding_sine_hip(coord, hidden_dim, npf, temperature)
     axes = [coord[:, 0:1], coord[:, 1:2], coord[:, 2:3]]
     if normalize:
         eps = 1e-6
@@ -42,6 +48,26 @@ def coord_embedding_sine(coord, hidden_dim, temperature=10000, normalize=False, 
     if pad:
         pos = torch.cat((pos, pos.new_zeros(pos.shape[0], pad)), dim=1)
     return pos
+
+
+_DIM_T = {}
+
+
+def _coord_embedding_sine_hip(coord, hidden_dim, npf, temperature):
+    from .. import _lib
+
+    key = (npf, float(temperature), coord.device)
+    dim_t = _DIM_T.get(key)
+    if dim_t is None:  # the reference's own expression, evaluated once per (npf, temperature, device)
+        dim_t = torch.arange(npf, dtype=torch.float32, device=coord.device)
+        dim_t = _DIM_T[key] = (temperature ** (2 * (dim_t // 2) / npf)).contiguous()
+    coord = coord.contiguous()
+    out = torch.empty(coord.shape[0], hidden_dim, dtype=torch.float32, device=coord.device)
+    with torch.cuda.device(coord.device):
+        rc = _lib.load().pcm_coord_embed_sine_hip(coord.shape[0], hidden_dim, npf, coord.data_ptr(), dim_t.data_ptr(), out.data_ptr(),
+                                                  _lib.raw_stream())
+    _lib.check(rc, "pcm_coord_embed_sine_hip")
+    return out
 
 
 def masked_fps(owner, pointops, p, o, n_o, mask):

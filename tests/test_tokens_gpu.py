@@ -138,3 +138,25 @@ def test_add_pos_linear_node_and_gradient_sink(broadcast):
             _add_pos(x, pos)
     with fused_ops.activate(ctx):  # no bf16 autocast: the pushing nodes would not run, so nothing is deferred
         assert getattr(fused_ops.defer_grads(pos_of()), "_pcm_sink", None) is None
+
+
+@pytest.mark.parametrize("hidden", [512, 96, 50])
+def test_sine_position_embedding_kernel_matches_the_framework_composition(hidden):
+    """csrc/tokens.hip pcm_coord_embed_sine_kernel against the literal act.py:467-506 composition (the framework path of the
+    same function, taken when the coordinates require a gradient) on the device, and against the CPU: same layout -- per
+    axis the sine block, then the cosine block --, zero padding, values to the last bits of sinf / cosf."""
+    from pointcloudmatters_amd.policy.sa_layer import coord_embedding_sine
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    coord = (torch.rand(777, 3, generator=g) * 4 - 2).to(dev)
+    got = coord_embedding_sine(coord, hidden)
+    with torch.enable_grad():
+        want = coord_embedding_sine(coord.clone().requires_grad_(True), hidden).detach()  # framework ops on the device
+    assert got.shape == want.shape == (777, hidden) and got.dtype == torch.float32
+    torch.testing.assert_close(got, want, rtol=0, atol=2e-7)
+    torch.testing.assert_close(got.cpu(), coord_embedding_sine(coord.cpu(), hidden), rtol=0, atol=1e-6)
+    npf = hidden // 3
+    if hidden - 3 * npf:
+        assert torch.count_nonzero(got[:, 3 * npf:]) == 0
+    assert coord_embedding_sine(coord[:0], hidden).shape == (0, hidden)
