@@ -431,6 +431,19 @@ int pcm_slab_sum_hip(int nslabs, long n, const float *partial, int out_is_bf16, 
 int pcm_colsum_hip(long rows, int C, int ntensors, int in_is_bf16, const void *g0, long ld0, const void *g1, long ld1,
                    const void *g2, long ld2, float *partial, int out_is_bf16, void *out, void *stream);
 
+/* ---- the ACT training loss (src/models/components/act/act.py:281-291, loss/misc.py:10-26) in one launch each way -----------
+ * a_hat (B, Q, A) fp32 or bf16, actions (B, Q, A) fp32, is_pad (B, Q) bytes (non-zero = padded), mu / logvar (B, D) fp32 or
+ * bf16; n = B*Q*A, bd = B*D.  action = mean over ALL n elements of (a_hat - actions)^2 * !is_pad (MSELoss(reduction="none")
+ * then .mean()), kl = mean_b sum_d -0.5 (1 + logvar - mu^2 - exp(logvar)), loss = action + kl_weight * kl.
+ * forward : stats[3] = {loss, action, kl}; ga (n), gmu (bd), glv (bd) fp32 = gradients per unit of upstream gradient.
+ * backward: upstream gradients of (loss, action, kl) as device scalars (NULL = 0); da / dmu / dlv in the inputs' dtypes. */
+int pcm_act_loss_forward_hip(int n, int A, int bd, int B, int a_is_bf16, const void *a_hat, const float *actions,
+                             const unsigned char *is_pad, int l_is_bf16, const void *mu, const void *logvar, float kl_weight,
+                             float *stats, float *ga, float *gmu, float *glv, void *stream);
+int pcm_act_loss_backward_hip(int n, int bd, const float *g_loss, const float *g_action, const float *g_kl, float kl_weight,
+                              const float *ga, const float *gmu, const float *glv, int a_is_bf16, void *da, int l_is_bf16,
+                              void *dmu, void *dlv, void *stream);
+
 /* ---- sine position embedding of the sampled centres (src/models/components/act/act.py:467-506, default arguments) ------
  * out (m, H) fp32: for axis a = x, y, z and npf = H / 3 (even), k = npf / 2:
  *     out[r][a*npf + j]     = sin(coord[r][a] / dim_t[2j]),      j < k

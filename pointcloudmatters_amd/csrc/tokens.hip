@@ -161,6 +161,72 @@ extern "C" int pcm_add2_cast_hip(long n, const void *a_bf16, const void *b_bf16,
     return pcm_add2_cast2_hip(n, a_bf16, b_bf16, out, nullptr, stream);
 }
 
+__device__ __forceinline__ float pcm_to_float(float v) { return v; }
+__device__ __forceinline__ float pcm_to_float(__hip_bfloat16 v) { return __bfloat162float(v); }
+__device__ __forceinline__ void pcm_store(float *p, float v) { *p = v; }
+__device__ __forceinline__ void pcm_store(__hip_bfloat16 *p, float v) { *p = __float2bfloat16(v); }
+
+// ---- ACT training loss (act.py:281-291 + loss/misc.py:10-26) as ONE workgroup: the values, and the gradients per unit of upstream
+// gradient, in a fixed summation order (same bits on every run).  ~27 framework launches of 1-element tensors otherwise.
+//   action = mean_{b,q,a}( (a_hat - actions)^2 * !is_pad[b,q] )           (MSELoss(reduction="none"), mean over ALL elements)
+//   kl     = mean_b sum_d -0.5 (1 + logvar - mu^2 - exp(logvar))
+//   loss   = action + kl_weight * kl
+// stats[3] = {loss, action, kl};  ga (n) = d action / d a_hat,  gmu / glv (bd) = d kl / d mu, d kl / d logvar  (all fp32)
+template <typename TA, typename TL>
+__global__ __launch_bounds__(256) void pcm_act_loss_kernel(int n, int A, int bd, int B, const TA *__restrict__ a_hat,
+                                                            const float *__restrict__ actions, const unsigned char *__restrict__ is_pad,
+                                                            const TL *__restrict__ mu, const TL *__restrict__ logvar, float kl_weight,
+                                                            float *__restrict__ stats, float *__restrict__ ga, float *__restrict__ gmu,
+                                                            float *__restrict__ glv)
+{
+    __shared__ double red[2][256];
+    const int t = threadIdx.x;
+    double sa = 0.0, sk = 0.0;
+    const float inv_n = 1.f / (float)n, inv_b = 1.f / (float)B;
+    for (int i = t; i < n; i += 256) {
+        const float e = pcm_to_float(a_hat[i]) - actions[i];
+        const float w = is_pad[i / A] ? 0.f : 1.f;
+        sa += (double)(e * e * w);
+        ga[i] = 2.f * e * w * inv_n;
+    }
+    for (int i = t; i < bd; i += 256) {
+        const float m = pcm_to_float(mu[i]), lv = pcm_to_float(logvar[i]);
+        const float ex = expf(lv);
+        sk += (double)(-0.5f * (1.f + lv - m * m - ex));
+        gmu[i] = m * inv_b;
+        glv[i] = -0.5f * (1.f - ex) * inv_b;
+    }
+    red[0][t] = sa, red[1][t] = sk;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (t < off) red[0][t] += red[0][t + off], red[1][t] += red[1][t + off];
+        __syncthreads();
+    }
+    if (t == 0) {
+        const float action = (float)(red[0][0] / (double)n), kl = (float)(red[1][0] / (double)B);
+        stats[0] = action + kl * kl_weight, stats[1] = action, stats[2] = kl;
+    }
+}
+
+// gradients for the upstream gradients g[0..2] of (loss, action, kl) -- device scalars, NULL = 0:
+//   d a_hat = (g0 + g1) ga,   d mu = (g0 kl_weight + g2) gmu,   d logvar = (g0 kl_weight + g2) glv,  rounded to the input dtypes
+template <typename TA, typename TL>
+__global__ __launch_bounds__(256) void pcm_act_loss_bwd_kernel(int n, int bd, const float *__restrict__ g0, const float *__restrict__ g1,
+                                                                const float *__restrict__ g2, float kl_weight, const float *__restrict__ ga,
+                                                                const float *__restrict__ gmu, const float *__restrict__ glv,
+                                                                TA *__restrict__ da, TL *__restrict__ dmu, TL *__restrict__ dlv)
+{
+    const float a = (g0 ? g0[0] : 0.f) + (g1 ? g1[0] : 0.f), k = (g0 ? g0[0] : 0.f) * kl_weight + (g2 ? g2[0] : 0.f);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n + bd; i += gridDim.x * 256) {
+        if (i < n) {
+            pcm_store(da + i, a * ga[i]);
+        } else {
+            pcm_store(dmu + (i - n), k * gmu[i - n]);
+            pcm_store(dlv + (i - n), k * glv[i - n]);
+        }
+    }
+}
+
 // sine position embedding, act.py:467-506 with its default arguments (layout: see include/pcm_pointops.h)
 __global__ __launch_bounds__(256) void pcm_coord_embed_sine_kernel(long total, int H, int npf, const float *__restrict__ coord,
                                                                     const float *__restrict__ dim_t, float *__restrict__ out)
@@ -177,6 +243,43 @@ __global__ __launch_bounds__(256) void pcm_coord_embed_sine_kernel(long total, i
         }
         out[e] = v;
     }
+}
+
+extern "C" int pcm_act_loss_forward_hip(int n, int A, int bd, int B, int a_is_bf16, const void *a_hat, const float *actions,
+                                        const unsigned char *is_pad, int l_is_bf16, const void *mu, const void *logvar, float kl_weight,
+                                        float *stats, float *ga, float *gmu, float *glv, void *stream)
+{
+    if (n <= 0 || A <= 0 || n % A || bd <= 0 || B <= 0 || bd % B) return PCM_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+#define PCM_L(TA, TL)                                                                                                       \
+    hipLaunchKernelGGL((pcm_act_loss_kernel<TA, TL>), dim3(1), dim3(256), 0, st, n, A, bd, B, (const TA *)a_hat, actions, is_pad, \
+                       (const TL *)mu, (const TL *)logvar, kl_weight, stats, ga, gmu, glv)
+    if (a_is_bf16) {
+        if (l_is_bf16) PCM_L(__hip_bfloat16, __hip_bfloat16); else PCM_L(__hip_bfloat16, float);
+    } else {
+        if (l_is_bf16) PCM_L(float, __hip_bfloat16); else PCM_L(float, float);
+    }
+#undef PCM_L
+    return PCM_LAUNCH_STATUS();
+}
+
+extern "C" int pcm_act_loss_backward_hip(int n, int bd, const float *g_loss, const float *g_action, const float *g_kl, float kl_weight,
+                                         const float *ga, const float *gmu, const float *glv, int a_is_bf16, void *da, int l_is_bf16,
+                                         void *dmu, void *dlv, void *stream)
+{
+    if (n <= 0 || bd <= 0) return PCM_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = (n + bd + 255) / 256;
+#define PCM_L(TA, TL)                                                                                                          \
+    hipLaunchKernelGGL((pcm_act_loss_bwd_kernel<TA, TL>), dim3(blocks), dim3(256), 0, st, n, bd, g_loss, g_action, g_kl, kl_weight, ga, gmu, \
+                       glv, (TA *)da, (TL *)dmu, (TL *)dlv)
+    if (a_is_bf16) {
+        if (l_is_bf16) PCM_L(__hip_bfloat16, __hip_bfloat16); else PCM_L(__hip_bfloat16, float);
+    } else {
+        if (l_is_bf16) PCM_L(float, __hip_bfloat16); else PCM_L(float, float);
+    }
+#undef PCM_L
+    return PCM_LAUNCH_STATUS();
 }
 
 extern "C" int pcm_coord_embed_sine_hip(long m, int H, int npf, const float *coord, const float *dim_t, float *out, void *stream)

@@ -283,6 +283,14 @@ class ACTPCD(nn.Module):
 
         # produced by the CVAE encoder (the stage under the "transformer.encoder" boundary), consumed here at the top
         mu, logvar = staging.cut("transformer.encoder", data_dict["mu"], data_dict["logvar"], consumed_above="transformer.decoder")
+        from . import fused_ops
+
+        if type(self) is ACTPCD and fused_ops.act_loss_supported(data_dict["a_hat"], data_dict["actions"], data_dict["is_pad"], mu, logvar,
+                                                                   self.action_loss, self.klloss):
+            # one launch each way instead of ~27 (csrc/tokens.hip); same formula, fixed summation order
+            data_dict["loss"], data_dict["action_loss"], data_dict["kl_loss"] = fused_ops.act_loss(
+                data_dict["a_hat"], data_dict["actions"], data_dict["is_pad"], mu, logvar, self.kl_weight)
+            return data_dict
         total_kld = self.klloss(mu, logvar)
         action_loss = self.action_loss(data_dict["a_hat"].float(), data_dict["actions"])
         action_loss = (action_loss * ~data_dict["is_pad"].unsqueeze(-1)).mean()

@@ -493,3 +493,58 @@ def self_attn_in_proj(x, pos, mha):
     """q, k, v (each (B, S, E) bf16) for self-attention with position-augmented queries / keys, and x again (an alias
     for the residual branch, see _SelfAttnInProj.forward)."""
     return _SelfAttnInProj.apply(x, pos, mha.in_proj_weight, mha.in_proj_bias)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# ACT training loss in one launch each way (csrc/tokens.hip pcm_act_loss_*): replaces ~27 framework launches on tensors of
+# a few hundred elements on the critical path between forward and backward.
+class _ActLoss(Function):
+    @staticmethod
+    def forward(ctx, a_hat, actions, is_pad, mu, logvar, kl_weight):
+        L = _lib.load()
+        dev = a_hat.device
+        B, D = mu.shape
+        n, A = a_hat.numel(), a_hat.shape[-1]
+        with torch.cuda.device(dev):
+            ws = torch.empty(3 + n + 2 * B * D, dtype=torch.float32, device=dev)
+            stats, ga, gmu, glv = ws[:3], ws[3:3 + n], ws[3 + n:3 + n + B * D], ws[3 + n + B * D:]
+            rc = L.pcm_act_loss_forward_hip(n, A, B * D, B, int(a_hat.dtype == torch.bfloat16), a_hat.data_ptr(), actions.data_ptr(),
+                                            is_pad.data_ptr(), int(mu.dtype == torch.bfloat16), mu.data_ptr(), logvar.data_ptr(),
+                                            float(kl_weight), stats.data_ptr(), ga.data_ptr(), gmu.data_ptr(), glv.data_ptr(), _raw_stream())
+        _lib.check(rc, "pcm_act_loss_forward_hip")
+        ctx.set_materialize_grads(False)  # action_loss / kl_loss are logged, not differentiated: no zero gradients for them
+        ctx.save_for_backward(ws)
+        ctx.meta = (n, B * D, float(kl_weight), a_hat.shape, a_hat.dtype, mu.shape, mu.dtype)
+        return stats[0], stats[1], stats[2]
+
+    @staticmethod
+    def backward(ctx, g_loss, g_action, g_kl):
+        L = _lib.load()
+        (ws,) = ctx.saved_tensors
+        n, bd, kl_weight, a_shape, a_dtype, mu_shape, mu_dtype = ctx.meta
+        dev = ws.device
+        with torch.cuda.device(dev):
+            da = torch.empty(a_shape, dtype=a_dtype, device=dev)
+            dml = torch.empty((2,) + tuple(mu_shape), dtype=mu_dtype, device=dev)
+            gs = [None if g is None else g.to(torch.float32).contiguous() for g in (g_loss, g_action, g_kl)]
+            rc = L.pcm_act_loss_backward_hip(n, bd, *(0 if g is None else g.data_ptr() for g in gs), kl_weight, ws[3:].data_ptr(),
+                                             ws[3 + n:].data_ptr(), ws[3 + n + bd:].data_ptr(), int(a_dtype == torch.bfloat16), da.data_ptr(),
+                                             int(mu_dtype == torch.bfloat16), dml[0].data_ptr(), dml[1].data_ptr(), _raw_stream())
+        _lib.check(rc, "pcm_act_loss_backward_hip")
+        return da, None, None, dml[0], dml[1], None
+
+
+def act_loss_supported(a_hat, actions, is_pad, mu, logvar, action_loss, klloss):
+    from .losses import KLDivergence
+
+    return (current() is not None and a_hat.is_cuda and type(action_loss) is torch.nn.MSELoss and action_loss.reduction == "none"
+            and type(klloss) is KLDivergence and mu is not None and mu.dim() == 2 and a_hat.dim() == 3
+            and a_hat.dtype in (torch.float32, torch.bfloat16) and mu.dtype in (torch.float32, torch.bfloat16) and mu.dtype == logvar.dtype
+            and actions.dtype == torch.float32 and actions.shape == a_hat.shape and is_pad.dtype == torch.bool
+            and is_pad.shape == a_hat.shape[:2] and torch.is_grad_enabled())
+
+
+def act_loss(a_hat, actions, is_pad, mu, logvar, kl_weight):
+    """-> (loss, action_loss, kl_loss), the three scalars of ACT.forward_loss."""
+    return _ActLoss.apply(a_hat.contiguous(), actions.contiguous(), is_pad.contiguous().view(torch.uint8), mu.contiguous(),
+                          logvar.contiguous(), kl_weight)

@@ -160,3 +160,42 @@ def test_sine_position_embedding_kernel_matches_the_framework_composition(hidden
     if hidden - 3 * npf:
         assert torch.count_nonzero(got[:, 3 * npf:]) == 0
     assert coord_embedding_sine(coord[:0], hidden).shape == (0, hidden)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_fused_act_loss_matches_the_framework_chain(dt):
+    """policy/fused_ops.act_loss (one launch each way) against ACT.forward_loss's framework composition: MSELoss(reduction=
+    "none") masked by ~is_pad and averaged over ALL elements, the KL term of loss/misc.py, their weighted sum -- values and
+    the gradients w.r.t. a_hat / mu / logvar, also when action_loss and kl_loss are differentiated on their own."""
+    from pointcloudmatters_amd.policy import fused_ops
+    from pointcloudmatters_amd.policy.losses import KLDivergence
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    B, Q, A, D, klw = 8, 100, 7, 32, 10.0
+    a0 = torch.randn(B, Q, A, generator=g).to(dev).to(dt)
+    actions = torch.randn(B, Q, A, generator=g).to(dev)
+    is_pad = (torch.rand(B, Q, generator=g) < 0.3).to(dev)
+    mu0, lv0 = (torch.randn(B, D, generator=g) * 0.5).to(dev).to(dt), (torch.randn(B, D, generator=g) * 0.3).to(dev).to(dt)
+
+    def run(fused, weights):
+        a, mu, lv = (t.clone().requires_grad_(True) for t in (a0, mu0, lv0))
+        if fused:
+            with fused_ops.activate(fused_ops.FusedContext(dev)):
+                assert fused_ops.act_loss_supported(a, actions, is_pad, mu, lv, torch.nn.MSELoss(reduction="none"), KLDivergence())
+                loss, act, kl = fused_ops.act_loss(a, actions, is_pad, mu, lv, klw)
+        else:
+            kl = KLDivergence()(mu, lv)
+            act = (torch.nn.functional.mse_loss(a.float(), actions, reduction="none") * ~is_pad.unsqueeze(-1)).mean()
+            loss = act + kl * klw
+        (weights[0] * loss + weights[1] * act + weights[2] * kl).backward()
+        return [x.detach().float() for x in (loss, act, kl, a.grad, mu.grad, lv.grad)]
+
+    tol = 1e-6 if dt == torch.float32 else 1e-2
+    for weights in ((0.5, 0.0, 0.0), (1.0, 0.25, 2.0)):
+        got, want = run(True, weights), run(False, weights)
+        for x, y in zip(got[:3], want[:3]):
+            torch.testing.assert_close(x, y, rtol=1e-6, atol=1e-7)
+        for x, y in zip(got[3:], want[3:]):
+            assert (x - y).abs().max().item() <= tol * y.abs().max().item() + 1e-9
+    assert torch.count_nonzero(run(True, (1.0, 0.0, 0.0))[3][is_pad]) == 0  # padded steps carry no gradient
