@@ -359,6 +359,17 @@ class BCTrainer:
             for mod, attr, _, _ in items:
                 mod.__dict__.pop(attr, None)
 
+    def _loss_seed(self, loss):
+        """d(loss / accumulate) / d loss as a cached device scalar: seeding backward with it replaces the division kernel, the
+        ones_like fill of .backward() and the division's backward multiply (three one-element launches per micro-batch)."""
+        key = (loss.device, loss.dtype)
+        seeds = self.__dict__.setdefault("_loss_seeds", {})
+        if key not in seeds:
+            if loss.is_cuda and torch.cuda.is_current_stream_capturing():
+                return torch.full_like(loss, 1.0 / self.accumulate)  # first use inside a capture: not cached (graph-pool memory)
+            seeds[key] = torch.full((), 1.0 / self.accumulate, device=loss.device, dtype=loss.dtype)
+        return seeds[key]
+
     @staticmethod
     def _stats_of(out):
         loss = out["loss"]
@@ -394,7 +405,7 @@ class BCTrainer:
         opt = self.optimizer
         if len(stages) == 1:
             out = make_out()
-            (out["loss"] / self.accumulate).backward()
+            out["loss"].backward(self._loss_seed(out["loss"]))
             if self._fused_ctx is not None:
                 self._fused_ctx.flush_sinks()
             rows_linear.join_side()
@@ -405,7 +416,7 @@ class BCTrainer:
         with staging.record() as rec:
             out = make_out()
         stats = self._stats_of(out)
-        roots, grads = [out["loss"] / self.accumulate], [None]
+        roots, grads = [out["loss"]], [self._loss_seed(out["loss"])]
         for si, st in enumerate(stages):
             inputs = rec.requested(st.lower) + [opt.params[k] for k in st.indices]
             last = si == len(stages) - 1

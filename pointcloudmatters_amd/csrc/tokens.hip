@@ -173,23 +173,23 @@ __device__ __forceinline__ void pcm_store(__hip_bfloat16 *p, float v) { *p = __f
 //   loss   = action + kl_weight * kl
 // stats[3] = {loss, action, kl};  ga (n) = d action / d a_hat,  gmu / glv (bd) = d kl / d mu, d kl / d logvar  (all fp32)
 template <typename TA, typename TL>
-__global__ __launch_bounds__(256) void pcm_act_loss_kernel(int n, int A, int bd, int B, const TA *__restrict__ a_hat,
+__global__ __launch_bounds__(1024) void pcm_act_loss_kernel(int n, int A, int bd, int B, const TA *__restrict__ a_hat,
                                                             const float *__restrict__ actions, const unsigned char *__restrict__ is_pad,
                                                             const TL *__restrict__ mu, const TL *__restrict__ logvar, float kl_weight,
                                                             float *__restrict__ stats, float *__restrict__ ga, float *__restrict__ gmu,
                                                             float *__restrict__ glv)
 {
-    __shared__ double red[2][256];
+    __shared__ double red[2][1024];
     const int t = threadIdx.x;
     double sa = 0.0, sk = 0.0;
     const float inv_n = 1.f / (float)n, inv_b = 1.f / (float)B;
-    for (int i = t; i < n; i += 256) {
+    for (int i = t; i < n; i += 1024) {
         const float e = pcm_to_float(a_hat[i]) - actions[i];
         const float w = is_pad[i / A] ? 0.f : 1.f;
         sa += (double)(e * e * w);
         ga[i] = 2.f * e * w * inv_n;
     }
-    for (int i = t; i < bd; i += 256) {
+    for (int i = t; i < bd; i += 1024) {
         const float m = pcm_to_float(mu[i]), lv = pcm_to_float(logvar[i]);
         const float ex = expf(lv);
         sk += (double)(-0.5f * (1.f + lv - m * m - ex));
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void pcm_act_loss_kernel(int n, int A, int bd,
     }
     red[0][t] = sa, red[1][t] = sk;
     __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
+    for (int off = 512; off > 0; off >>= 1) {
         if (t < off) red[0][t] += red[0][t + off], red[1][t] += red[1][t + off];
         __syncthreads();
     }
@@ -252,7 +252,7 @@ extern "C" int pcm_act_loss_forward_hip(int n, int A, int bd, int B, int a_is_bf
     if (n <= 0 || A <= 0 || n % A || bd <= 0 || B <= 0 || bd % B) return PCM_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
 #define PCM_L(TA, TL)                                                                                                       \
-    hipLaunchKernelGGL((pcm_act_loss_kernel<TA, TL>), dim3(1), dim3(256), 0, st, n, A, bd, B, (const TA *)a_hat, actions, is_pad, \
+    hipLaunchKernelGGL((pcm_act_loss_kernel<TA, TL>), dim3(1), dim3(1024), 0, st, n, A, bd, B, (const TA *)a_hat, actions, is_pad, \
                        (const TL *)mu, (const TL *)logvar, kl_weight, stats, ga, gmu, glv)
     if (a_is_bf16) {
         if (l_is_bf16) PCM_L(__hip_bfloat16, __hip_bfloat16); else PCM_L(__hip_bfloat16, float);
