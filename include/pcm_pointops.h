@@ -430,6 +430,16 @@ int pcm_colsum_slots(long rows, int C);
 int pcm_slab_sum_hip(int nslabs, long n, const float *partial, int out_is_bf16, void *out, void *stream);
 int pcm_colsum_hip(long rows, int C, int ntensors, int in_is_bf16, const void *g0, long ld0, const void *g1, long ld1,
                    const void *g2, long ld2, float *partial, int out_is_bf16, void *out, void *stream);
+/* n closing reductions in ONE launch per 24: out[e] = sum_{s < nslots[i]} partial[i][s * width[i] + e], fp64 in the fixed
+ * order of pcm_slab_sum_hip (bit-identical results).  out_f32[i] (nullable) takes all columns, out_bf16[i] (nullable) the
+ * columns bf16_from[i]..width[i]-1 stored from index 0; at least one of the two per reduction.  Host arrays of length n.
+ * The first stages leave their partial rows for it when called with a NULL result pointer: pcm_drln_backward_hip
+ * (dgamma_dbeta = NULL: pcm_drln_blocks(R) rows of 3E), pcm_ffn_ln_backward_hip (sums = NULL: pcm_ffn_ln_blocks(R) rows of
+ * 3E + F), pcm_colsum_hip (out = NULL: pcm_colsum_slots(rows, C) rows of ntensors*C).  The backward pass of the reference
+ * runs one reduction kernel per bias / norm gradient (torch autograd, transformer.py:296-346); here a whole backward
+ * stage closes all of them together (policy/deferred.py). */
+int pcm_reduce_batch_hip(int n, const void *const *partial, const int *nslots, const int *width, void *const *out_f32,
+                         void *const *out_bf16, const int *bf16_from, void *stream);
 
 /* ---- the ACT training loss (src/models/components/act/act.py:281-291, loss/misc.py:10-26) in one launch each way -----------
  * a_hat (B, Q, A) fp32 or bf16, actions (B, Q, A) fp32, is_pad (B, Q) bytes (non-zero = padded), mu / logvar (B, D) fp32 or

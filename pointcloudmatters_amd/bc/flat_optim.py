@@ -111,9 +111,10 @@ class FlatAdamW:
         if self._stash[k] is None:
             self._stash[k] = g
             return
-        from ..policy import rows_linear
+        from ..policy import deferred, rows_linear
 
         rows_linear.join_side()  # a second gradient for the same weight: the sum reads both, possibly side-stream products
+        deferred.flush()         # ... or pending closing reductions
         self._stash[k] = self._stash[k] + g
 
     def collect(self, first, subset=None):

@@ -17,6 +17,7 @@ Metrics stay on the device and are only read every ``log_every_n_steps`` (ddp.ya
 per-step ``.item()`` would serialise host and GPU.
 """
 import contextlib
+import os
 
 import torch
 import torch.distributed as dist
@@ -134,9 +135,11 @@ class BCTrainer:
 
     def __init__(self, policy, total_steps, optim=None, precision="fp32", device=None, distributed=False,
                  sync_batchnorm=True, bucket_cap_mb=32, log_every_n_steps=50, mode="eager", flat_optimizer_cls=None, staged=None,
-                 side_weight_grads=False, external_sampling=True):
+                 side_weight_grads=False, external_sampling=True, defer_reductions=None):
         o = dict(ACT_OPTIM)
         self.side_weight_grads = bool(side_weight_grads)
+        # closing reductions batched per backward stage (policy/deferred.py); PCM_DEFER_REDUCTIONS=0 is the A/B switch
+        self.defer_reductions = (os.environ.get("PCM_DEFER_REDUCTIONS", "1") != "0") if defer_reductions is None else bool(defer_reductions)
         self.external_sampling = bool(external_sampling)  # graph mode: FPS / kNN outside the captured graph (prefetchable)
         self._static_sampling = False
         if optim:
@@ -386,21 +389,26 @@ class BCTrainer:
         # hybrid mode always hands gradients over explicitly (its two halves write disjoint parts of the flat buffer at
         # different times); the other modes do so only for the bf16 mirror, fp32 accumulates through the .grad views
         collect = getattr(opt, "collect_mode", False) or self.mode == "hybrid"
-        from ..policy import rows_linear
+        from ..policy import deferred, rows_linear
 
         # weight-gradient products on a second stream (rows_linear._SideQueue): only where gradients are handed over
         # explicitly (nothing reads a dW before `collect`) and the step is replayed as a hipGraph (parallel branches).
         # OFF by default: measured on MI355X / ROCm 7.2 at C2 the replayed step gets SLOWER with the extra branches
         # (7.55 -> 7.93 ms with every dW on the side stream, 8.1 ms with only the 8192-row ones): DESIGN.md section 9
         rows_linear.SIDE.active = bool(collect and self.side_weight_grads and self.mode in ("graph", "hybrid"))
+        # closing reductions of the fused backward kernels batched per backward stage (policy/deferred.py): only where the
+        # gradients are handed over explicitly, i.e. nothing reads one before `collect`
+        window = bool(collect and self.defer_reductions and not rows_linear.SIDE.active) and deferred.begin()
         try:
             yield from self._segments_inner(make_out, first, stages, leaf, collect)
         finally:
             rows_linear.join_side()
             rows_linear.SIDE.active = False
+            if window:
+                deferred.end()
 
     def _segments_inner(self, make_out, first, stages, leaf, collect):
-        from ..policy import rows_linear, staging
+        from ..policy import deferred, rows_linear, staging
 
         opt = self.optimizer
         if len(stages) == 1:
@@ -408,6 +416,7 @@ class BCTrainer:
             out["loss"].backward(self._loss_seed(out["loss"]))
             if self._fused_ctx is not None:
                 self._fused_ctx.flush_sinks()
+            deferred.flush()
             rows_linear.join_side()
             if collect:
                 opt.collect(first=first, subset=None if len(stages[0].indices) == len(opt.params) else stages[0].indices)
@@ -426,6 +435,7 @@ class BCTrainer:
                 torch.autograd.backward(roots, grads, inputs=inputs)
             if self._fused_ctx is not None:
                 self._fused_ctx.flush_sinks()  # deferred position-embedding gradients of this stage (fused_ops.GradSink)
+            deferred.flush()  # this stage's closing reductions, one launch per 24
             rows_linear.join_side()
             if collect:
                 opt.collect(first=first, subset=st.indices)

@@ -233,6 +233,7 @@ extern "C" int pcm_drln_backward_hip(long R, int E, int y_is_bf16, const float *
         if (n == 1) PCM_B(float, 1); else if (n == 2) PCM_B(float, 2); else if (n == 3) PCM_B(float, 3); else PCM_B(float, 4);
     }
 #undef PCM_B
+    if (dgamma_dbeta == nullptr) return PCM_LAUNCH_STATUS();  // partial rows only: closed later by pcm_reduce_batch_hip
     hipLaunchKernelGGL(pcm_drln_reduce_kernel, dim3((3 * E + 63) / 64), dim3(512), 0, st, grid, 3 * E, partial, dgamma_dbeta,
                        (__hip_bfloat16 *)dysum_bf16, 2 * E);
     return PCM_LAUNCH_STATUS();

@@ -380,6 +380,7 @@ extern "C" int pcm_ffn_ln_backward_hip(long R, int E, int F, const float *dout, 
     if (E == 512) PCM_FB(512); else PCM_FB(256);
 #undef PCM_FB
     const int PW = 3 * E + F;
+    if (sums == nullptr) return PCM_LAUNCH_STATUS();  // partial rows only: closed later by pcm_reduce_batch_hip
     hipLaunchKernelGGL(pcm_ffn_reduce_kernel, dim3((PW + 63) / 64), dim3(512), 0, st, grid, PW, partial, sums);
     return PCM_LAUNCH_STATUS();
 }

@@ -122,6 +122,45 @@ __global__ __launch_bounds__(512) void pcm_colsum_reduce_kernel(int nslots, int 
     }
 }
 
+// Several closing reductions in ONE launch (policy/deferred.py): every workgroup finds its reduction in a table passed by
+// value (so a captured graph keeps it) and sums 64 columns exactly as pcm_colsum_reduce_kernel / pcm_drln_reduce_kernel /
+// pcm_ffn_reduce_kernel do -- same wave striding, same fp64 order -- so deferring a reduction never changes a bit.
+constexpr int kReduceBatch = 24;
+struct ReduceDesc {
+    const float *partial;
+    float *out;              // fp32 result (may be NULL)
+    __hip_bfloat16 *out16;   // bf16 copy of the columns [from16, VH) (may be NULL)
+    int nslots, VH, from16, blk0;  // blk0: first workgroup of this reduction
+};
+struct ReduceBatch {
+    ReduceDesc d[kReduceBatch];
+    int n;
+};
+__global__ __launch_bounds__(512) void pcm_reduce_batch_kernel(ReduceBatch b)
+{
+    __shared__ double red[8][64];
+    int i = 0;
+    for (int j = 1; j < b.n; ++j)
+        if ((int)blockIdx.x >= b.d[j].blk0) i = j;
+    const ReduceDesc &D = b.d[i];
+    const float *__restrict__ partial = D.partial;
+    const int VH = D.VH, nslots = D.nslots;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = ((int)blockIdx.x - D.blk0) * 64 + lane;
+    double acc = 0.0;
+    if (e < VH)
+        for (int s = wave; s < nslots; s += 8) acc += (double)partial[(size_t)s * VH + e];
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && e < VH) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) t += red[w][lane];
+        if (D.out) D.out[e] = (float)t;
+        if (D.out16 && e >= D.from16) D.out16[e - D.from16] = __float2bfloat16((float)t);
+    }
+}
+
 inline int colsum_slots_for(long rows, int C)
 {
     const int rpp = kBlock / (C / 4);
@@ -309,6 +348,32 @@ extern "C" int pcm_slab_sum_hip(int nslabs, long n, const float *partial, int ou
     return PCM_LAUNCH_STATUS();
 }
 
+extern "C" int pcm_reduce_batch_hip(int n, const void *const *partial, const int *nslots, const int *width, void *const *out_f32,
+                                    void *const *out_bf16, const int *bf16_from, void *stream)
+{
+    // n closing reductions out[e] = sum_s partial[s * width + e] (s < nslots), kReduceBatch per launch.  out_f32[i] and / or
+    // out_bf16[i] receive the sums (bf16: columns bf16_from[i]..width-1, stored from index 0).  Host arrays.
+    if (n < 0 || (n > 0 && (!partial || !nslots || !width || !out_f32 || !out_bf16 || !bf16_from))) return PCM_ERR_BAD_ARG;
+    for (int i = 0; i < n; ++i)
+        if (!partial[i] || nslots[i] <= 0 || width[i] < 0 || (!out_f32[i] && !out_bf16[i]) || bf16_from[i] < 0) return PCM_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    for (int base = 0; base < n; base += kReduceBatch) {
+        ReduceBatch b;
+        b.n = 0;
+        long blocks = 0;
+        for (int i = base; i < n && b.n < kReduceBatch; ++i) {
+            if (width[i] == 0) continue;
+            ReduceDesc &d = b.d[b.n++];
+            d.partial = (const float *)partial[i], d.out = (float *)out_f32[i], d.out16 = (__hip_bfloat16 *)out_bf16[i];
+            d.nslots = nslots[i], d.VH = width[i], d.from16 = bf16_from[i], d.blk0 = (int)blocks;
+            blocks += (width[i] + 63) / 64;
+        }
+        if (blocks > 0x7FFFFFFF) return PCM_ERR_BAD_ARG;
+        if (b.n) hipLaunchKernelGGL(pcm_reduce_batch_kernel, dim3((unsigned)blocks), dim3(512), 0, s, b);
+    }
+    return PCM_LAUNCH_STATUS();
+}
+
 extern "C" int pcm_colsum_slots(long rows, int C)
 {
     if (rows <= 0 || C <= 0 || C % 4 || C > 1024) return 0;
@@ -331,6 +396,7 @@ extern "C" int pcm_colsum_hip(long rows, int C, int ntensors, int in_is_bf16, co
     else
         hipLaunchKernelGGL(pcm_colsum_kernel<float>, dim3(slots, ntensors), dim3(kBlock), 0, s, rows, C, rps, a, partial);
     const int VH = ntensors * C;
+    if (out == nullptr) return PCM_LAUNCH_STATUS();  // partial sums only: the caller closes them with pcm_reduce_batch_hip
     if (out_is_bf16)
         hipLaunchKernelGGL(pcm_colsum_reduce_kernel<__hip_bfloat16>, dim3((VH + 63) / 64), dim3(512), 0, s, slots, VH, partial,
                            (__hip_bfloat16 *)out);

@@ -12,6 +12,7 @@ import torch
 from torch.autograd import Function
 
 from .. import _lib
+from . import deferred
 from .rows_linear import goes_to_optimizer as _goes_to_optimizer
 from .._lib import raw_stream as _raw_stream
 
@@ -114,13 +115,14 @@ class _DRLN(Function):
         out, s, mean, rstd = _drln_forward(x2, y2, gamma, beta, eps, p_drop, seed, site)
         ctx.save_for_backward(s, mean, rstd, gamma)
         ctx.meta = (shape, y.dtype, float(p_drop), seed, int(site))
+        ctx.defer = deferred.targets(gamma, beta)
         return out.view(shape)
 
     @staticmethod
     def backward(ctx, dout):
         s, mean, rstd, gamma = ctx.saved_tensors
         shape, ydtype, p_drop, seed, site = ctx.meta
-        dx, dy, sums = _drln_backward(dout, s, mean, rstd, gamma, ydtype, p_drop, seed, site)
+        dx, dy, sums = _drln_backward(dout, s, mean, rstd, gamma, ydtype, p_drop, seed, site, defer=deferred.clear(*ctx.defer))
         return dx.view(shape), dy.view(shape), sums[0], sums[1], None, None, None, None
 
 
@@ -141,8 +143,9 @@ def _drln_forward(x2, y2, gamma, beta, eps, p_drop, seed, site):
     return out, s, mean, rstd
 
 
-def _drln_backward(dout, s, mean, rstd, gamma, ydtype, p_drop, seed, site, dysum_bf16=False):
-    """-> dx (R,E) fp32, dy (R,E) in ydtype, sums (3,E) fp32 = dgamma | dbeta | column sums of dy (+ those sums in bf16)."""
+def _drln_backward(dout, s, mean, rstd, gamma, ydtype, p_drop, seed, site, dysum_bf16=False, defer=False):
+    """-> dx (R,E) fp32, dy (R,E) in ydtype, sums (3,E) fp32 = dgamma | dbeta | column sums of dy (+ those sums in bf16).
+    defer: leave the closing reduction of `sums` to policy/deferred.flush (the caller checked deferred.clear)."""
     L = _lib.load()
     R, E = s.shape
     dev = s.device
@@ -152,12 +155,14 @@ def _drln_backward(dout, s, mean, rstd, gamma, ydtype, p_drop, seed, site, dysum
     with torch.cuda.device(dev):
         dx = torch.empty_like(s)
         dy = torch.empty(R, E, dtype=ydtype, device=dev)
-        partial = torch.empty(L.pcm_drln_blocks(R) * 3 * E, dtype=torch.float32, device=dev)
+        blocks = L.pcm_drln_blocks(R)
+        partial = torch.empty(blocks * 3 * E, dtype=torch.float32, device=dev)
         sums = torch.empty(3, E, dtype=torch.float32, device=dev)
         db16 = torch.empty(E, dtype=torch.bfloat16, device=dev) if dysum_bf16 else None
+        defer = defer and R > 0 and deferred.push(partial, blocks, 3 * E, out_f32=sums, out_bf16=db16, bf16_from=2 * E)
         rc = L.pcm_drln_backward_hip(R, E, 1 if ydtype == torch.bfloat16 else 0, d2.data_ptr(), s.data_ptr(), mean.data_ptr(),
                                      rstd.data_ptr(), gamma.data_ptr(), p_drop, seed.data_ptr() if seed is not None else 0, site,
-                                     dx.data_ptr(), dy.data_ptr(), partial.data_ptr(), sums.data_ptr(),
+                                     dx.data_ptr(), dy.data_ptr(), partial.data_ptr(), 0 if defer else sums.data_ptr(),
                                      db16.data_ptr() if db16 is not None else 0, _raw_stream())
     _lib.check(rc, "pcm_drln_backward_hip")
     if dysum_bf16:
@@ -190,6 +195,8 @@ class _ProjDRLN(Function):
         ctx.save_for_backward(a2, wc, s, mean, rstd, gamma)
         ctx.meta = (shape, a.shape, a.dtype, weight.dtype, bias.dtype, y2.dtype, float(p_drop), seed, int(site))
         ctx.side_ok = _goes_to_optimizer(weight)
+        ok, leaves = deferred.targets(weight, bias, gamma, beta)
+        ctx.defer = (ok and bias.dtype in (torch.bfloat16, torch.float32), leaves)
         return out.view(shape)
 
     @staticmethod
@@ -199,13 +206,14 @@ class _ProjDRLN(Function):
         a2, wc, s, mean, rstd, gamma = ctx.saved_tensors
         shape, ashape, adt, wdt, bdt, ydt, p_drop, seed, site = ctx.meta
         want16 = bdt == torch.bfloat16
-        res = _drln_backward(dout, s, mean, rstd, gamma, ydt, p_drop, seed, site, dysum_bf16=want16)
+        defer = deferred.clear(*ctx.defer)
+        res = _drln_backward(dout, s, mean, rstd, gamma, ydt, p_drop, seed, site, dysum_bf16=want16, defer=defer)
         dx, dy, sums = res[:3]
         with torch.autocast("cuda", enabled=False):
             da = (dy @ wc).view(ashape)
             if da.dtype != adt:
                 da = da.to(adt)
-            dw = weight_grad(dy, a2, wdt, side=ctx.side_ok)
+            dw = weight_grad(dy, a2, wdt, side=ctx.side_ok, defer=defer)
             db = res[3] if want16 else sums[2].to(bdt)
         return da, dw, db, dx.view(shape), sums[0], sums[1], None, None, None, None
 
@@ -260,6 +268,7 @@ class _FFNLN(Function):
         ctx.save_for_backward(x2, w1, w2, gamma, hd, s, mean, rstd)
         ctx.meta = (shape, float(p_hidden), float(p_out), seed, int(site_b))
         ctx.side_ok = _goes_to_optimizer(w1) and _goes_to_optimizer(w2)
+        ctx.defer = deferred.targets(w1, b1, w2, b2, gamma, beta)
         return out.view(shape)
 
     @staticmethod
@@ -277,19 +286,22 @@ class _FFNLN(Function):
         with torch.cuda.device(dev):
             dx, dy, dh = torch.empty(R, E, **f32), torch.empty(R, E, **f32), torch.empty(R, Fh, **f32)
             pw = 3 * E + Fh
-            partial = torch.empty(L.pcm_ffn_ln_blocks(R) * pw, **f32)
+            blocks = L.pcm_ffn_ln_blocks(R)
+            partial = torch.empty(blocks * pw, **f32)
             sums = torch.empty(pw, **f32)
+            defer = deferred.clear(*ctx.defer)
+            defer_sums = defer and R > 0 and deferred.push(partial, blocks, pw, out_f32=sums)
             rc = L.pcm_ffn_ln_backward_hip(R, E, Fh, d2.data_ptr(), x2.data_ptr(), s.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                            hd.data_ptr(), w1.data_ptr(), w2.data_ptr(), gamma.data_ptr(), p_hidden, p_out,
                                            seed.data_ptr() if seed is not None else 0, site_b, dx.data_ptr(), dy.data_ptr(),
-                                           dh.data_ptr(), partial.data_ptr(), sums.data_ptr(),
+                                           dh.data_ptr(), partial.data_ptr(), 0 if defer_sums else sums.data_ptr(),
                                            _raw_stream())
             _lib.check(rc, "pcm_ffn_ln_backward_hip")
             from .rows_linear import weight_grad
 
             with torch.autocast(device_type="cuda", enabled=False):
-                dw2 = weight_grad(dy, hd, torch.float32, side=ctx.side_ok)  # (E, F)   split-K over the rows when there are thousands
-                dw1 = weight_grad(dh, x2, torch.float32, side=ctx.side_ok)  # (F, E)
+                dw2 = weight_grad(dy, hd, torch.float32, side=ctx.side_ok, defer=defer)  # (E, F)   split-K over the rows when there are thousands
+                dw1 = weight_grad(dh, x2, torch.float32, side=ctx.side_ok, defer=defer)  # (F, E)
         dgamma, dbeta, db2, db1 = sums[:E], sums[E : 2 * E], sums[2 * E : 3 * E], sums[3 * E :]
         return dx.view(shape), dw1, db1, dw2, db2, dgamma, dbeta, None, None, None, None, None, None
 
@@ -347,6 +359,7 @@ class _SelfAttnInProj(Function):
         ctx.sink = getattr(pos, "_pcm_sink", None)
         ctx.meta = (shape, pos.shape, w.dtype, b.dtype, pos.requires_grad or ctx.sink is not None)
         ctx.side_ok = _goes_to_optimizer(w)
+        ctx.defer = deferred.targets(w, b)
         q, k = qk.unbind(-2)
         # x is handed back as a fourth output for the caller's residual branch: x then has ONE consumer in the autograd
         # graph and this node receives the residual's gradient, which it folds into its closing add kernel (otherwise the
@@ -391,13 +404,16 @@ class _SelfAttnInProj(Function):
                                       dx.data_ptr(), dpos32.data_ptr() if dpos32 is not None else 0, st)
             _lib.check(rc, "pcm_add3_cast2_hip")
             dw = torch.empty(3 * E, E, dtype=wdt, device=dev)
-            weight_grad(dqk, qk_in, wdt, out=dw[: 2 * E], side=ctx.side_ok)
-            weight_grad(dv2, v_in, wdt, out=dw[2 * E:], side=ctx.side_ok)
+            defer = deferred.clear(*ctx.defer)
+            weight_grad(dqk, qk_in, wdt, out=dw[: 2 * E], side=ctx.side_ok, defer=defer)
+            weight_grad(dv2, v_in, wdt, out=dw[2 * E:], side=ctx.side_ok, defer=defer)
             db = torch.empty(3 * E, dtype=bdt, device=dev)
-            partial = torch.empty(L.pcm_colsum_slots(rows, E) * 3 * E, dtype=torch.float32, device=dev)
+            slots = L.pcm_colsum_slots(rows, E)
+            partial = torch.empty(slots * 3 * E, dtype=torch.float32, device=dev)
             es = dqk.element_size()
+            defer = defer and deferred.push(partial, slots, 3 * E, **({"out_bf16": db} if bdt == bf else {"out_f32": db}))
             rc = L.pcm_colsum_hip(rows, E, 3, 1, dqk.data_ptr(), 2 * E, dqk.data_ptr() + E * es, 2 * E, dv2.data_ptr(), E,
-                                  partial.data_ptr(), int(bdt == bf), db.data_ptr(), st)
+                                  partial.data_ptr(), int(bdt == bf), 0 if defer else db.data_ptr(), st)
             _lib.check(rc, "pcm_colsum_hip")
             dpos = None
             if dpos32 is not None:
@@ -440,6 +456,7 @@ class _AddPosLinear(Function):
         ctx.save_for_backward(s_in, wc)
         ctx.meta = (shape, pos.shape, w.dtype, b.dtype)
         ctx.side_ok = _goes_to_optimizer(w)
+        ctx.defer = deferred.targets(w)
         ctx.sink = getattr(pos, "_pcm_sink", None)
         return y
 
@@ -463,7 +480,7 @@ class _AddPosLinear(Function):
                 else:
                     dpos = d_in.sum_to_size(pos_shape) if ctx.needs_input_grad[1] else None
             if ctx.needs_input_grad[2]:
-                dw = weight_grad(dy2, s_in, wdt, side=ctx.side_ok)
+                dw = weight_grad(dy2, s_in, wdt, side=ctx.side_ok, defer=deferred.clear(*ctx.defer))
             if ctx.needs_input_grad[3]:
                 db = dy2.sum(dim=0).to(bdt)
         return dx, dpos, dw, db

@@ -85,9 +85,11 @@ def goes_to_optimizer(weight):
     return fn is None or type(fn).__name__ == "_ShadowParamBackward"
 
 
-def weight_grad(go, x, out_dtype, out=None, side=False):
+def weight_grad(go, x, out_dtype, out=None, side=False, defer=False):
     """dW = go^T @ x for go (rows, m), x (rows, k) -> (m, k) in `out_dtype` (written into `out`, a contiguous (m, k)
-    tensor or row-slice of a packed gradient, when given).  ``side``: may run on the side stream (see _SideQueue)."""
+    tensor or row-slice of a packed gradient, when given).  ``side``: may run on the side stream (see _SideQueue).
+    ``defer``: the closing sum of a split product may stay pending until policy/deferred.flush (the caller checked
+    deferred.clear: nothing reads dW before the gradient hand-off)."""
     if side and SIDE.active and go.is_cuda and go.shape[0] >= SIDE.min_rows:
         main = torch.cuda.current_stream(go.device)
         st = SIDE.stream_for(go.device)
@@ -99,10 +101,10 @@ def weight_grad(go, x, out_dtype, out=None, side=False):
         SIDE.held.append((go, x))
         SIDE.pending = True
         return out
-    return _weight_grad(go, x, out_dtype, out)
+    return _weight_grad(go, x, out_dtype, out, defer)
 
 
-def _weight_grad(go, x, out_dtype, out=None):
+def _weight_grad(go, x, out_dtype, out=None, defer=False):
     rows, m = go.shape
     k = x.shape[1]
     # wide outputs (the decoder's 7-layer key / value projection: 3584 x 512) are split too, as long as the fp32
@@ -126,6 +128,11 @@ def _weight_grad(go, x, out_dtype, out=None):
         from .. import _lib
 
         dw = out if out is not None else torch.empty(m, k, dtype=out_dtype, device=go.device)
+        if defer:
+            from . import deferred
+
+            if deferred.push(part, s, m * k, **({"out_bf16": dw} if dw.dtype == torch.bfloat16 else {"out_f32": dw})):
+                return dw
         with torch.cuda.device(go.device):
             rc = _lib.load().pcm_slab_sum_hip(s, m * k, part.data_ptr(), int(dw.dtype == torch.bfloat16), dw.data_ptr(),
                                               _raw_stream())
@@ -153,6 +160,9 @@ class _LinearRows(Function):
         ctx.save_for_backward(xc, wc)
         ctx.meta = (x.dtype, weight.dtype, bias.dtype if bias is not None else None, x.shape)
         ctx.side_ok = goes_to_optimizer(weight)
+        from . import deferred
+
+        ctx.defer = deferred.targets(weight)
         return y
 
     @staticmethod
@@ -172,7 +182,10 @@ class _LinearRows(Function):
                 if dx.dtype != xdt:
                     dx = dx.to(xdt)
             if ctx.needs_input_grad[1]:
-                dw = weight_grad(go2, x2 if x2.is_contiguous() else x2.contiguous(), wdt, side=ctx.side_ok)
+                from . import deferred
+
+                dw = weight_grad(go2, x2 if x2.is_contiguous() else x2.contiguous(), wdt, side=ctx.side_ok,
+                                 defer=deferred.clear(*ctx.defer))
             if bdt is not None and ctx.needs_input_grad[2]:
                 db = go2.sum(dim=0).to(bdt)
         return dx, dw, db

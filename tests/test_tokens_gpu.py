@@ -51,6 +51,69 @@ def test_colsum_matches_fp64_sum(rows, c, dt):
         assert torch.equal(out, again)  # fixed reduction order
 
 
+def test_batched_closing_reductions_equal_the_single_ones():
+    """pcm_reduce_batch_hip (one launch per 24 reductions, table by value) against pcm_slab_sum_hip, one launch each: 53
+    reductions of mixed widths / slot counts / output kinds, bit for bit; and through policy/deferred's window."""
+    import ctypes
+
+    from pointcloudmatters_amd import _lib
+    from pointcloudmatters_amd.policy import deferred
+
+    L = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(0)
+    jobs = []
+    for i in range(53):
+        width = int(torch.randint(1, 5000, (1,), generator=g)) if i % 7 else 262144
+        nslots = int(torch.randint(1, 300, (1,), generator=g)) if i % 7 else 5
+        part = torch.randn(nslots, width, device=DEV) * (1 + i)
+        kind = i % 3  # fp32 | bf16 | fp32 + bf16 tail
+        from16 = 0 if kind == 1 else width // 3
+        o32 = torch.full((width,), float("nan"), device=DEV) if kind != 1 else None
+        o16 = torch.full((width - from16,), float("nan"), dtype=torch.bfloat16, device=DEV) if kind != 0 else None
+        want32 = torch.empty(width, device=DEV)
+        assert L.pcm_slab_sum_hip(nslots, width, part.data_ptr(), 0, want32.data_ptr(), st) == 0
+        want16 = torch.empty(width, dtype=torch.bfloat16, device=DEV)
+        assert L.pcm_slab_sum_hip(nslots, width, part.data_ptr(), 1, want16.data_ptr(), st) == 0
+        torch.testing.assert_close(want32.double(), part.double().sum(0), rtol=1e-6, atol=1e-4 * (1 + i))
+        jobs.append((part, nslots, width, o32, o16, from16, want32, want16))
+    n = len(jobs)
+    P, I = ctypes.c_void_p * n, ctypes.c_int * n
+    rc = L.pcm_reduce_batch_hip(n, P(*[j[0].data_ptr() for j in jobs]), I(*[j[1] for j in jobs]), I(*[j[2] for j in jobs]),
+                                P(*[j[3].data_ptr() if j[3] is not None else None for j in jobs]),
+                                P(*[j[4].data_ptr() if j[4] is not None else None for j in jobs]), I(*[j[5] for j in jobs]), st)
+    assert rc == 0
+
+    def check():
+        for part, nslots, width, o32, o16, from16, want32, want16 in jobs:
+            if o32 is not None:
+                assert torch.equal(o32, want32)
+            if o16 is not None:
+                assert torch.equal(o16, want16[from16:])
+
+    check()
+    # the same through the window: nothing is written before flush(), everything after
+    for j in jobs:
+        for o in (j[3], j[4]):
+            if o is not None:
+                o.fill_(float("nan"))
+    assert not deferred.push(jobs[0][0], jobs[0][1], jobs[0][2], out_f32=jobs[0][6])  # no window: the producer reduces itself
+    assert deferred.begin()
+    try:
+        for part, nslots, width, o32, o16, from16, _, _ in jobs:
+            assert deferred.push(part, nslots, width, out_f32=o32, out_bf16=o16, bf16_from=from16)
+        torch.cuda.synchronize()
+        assert all(bool(torch.isnan(o.float()).all()) for j in jobs for o in (j[3], j[4]) if o is not None)
+        assert deferred.flush() == n and deferred.flush() == 0
+    finally:
+        deferred.end()
+    check()
+    assert not deferred.active()
+    # bad arguments are refused, not launched
+    assert L.pcm_reduce_batch_hip(1, P(*([None] * n)), I(*([1] * n)), I(*([4] * n)), P(*([None] * n)), P(*([None] * n)), I(*([0] * n)), st) != 0
+    assert L.pcm_reduce_batch_hip(0, None, None, None, None, None, None, st) == 0
+
+
 @pytest.mark.parametrize("pos_batch", [1, 3])
 @pytest.mark.parametrize("pos_grad", [False, True])
 def test_self_attn_in_proj_node_matches_framework_chain(pos_batch, pos_grad):
