@@ -9,6 +9,8 @@ into S row blocks -- one batched GEMM producing S partial products, then one fp3
 (19 us and 18 us for the two shapes above) and is at least as accurate: the partials stay fp32 and are summed in a fixed
 order by pcm_slab_sum_hip with a single rounding to the gradient dtype.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 from torch.autograd import Function
@@ -18,6 +20,7 @@ MIN_ROWS = 2048        # below this the plain GEMM is as fast
 TARGET_CHUNK = 768     # rows per partial product
 MAX_SPLITS = 64
 MAX_PARTIAL_BYTES = 64 << 20  # fp32 partial products of one weight gradient (S x m x k)
+DEFER_MAX_BYTES = int(os.environ.get("PCM_DEFER_SLAB_BYTES", 0))  # split-K sums up to this size may join policy/deferred.py's batch
 WIDE_OUTPUT = 1024 * 1024      # m * k above which the fixed cost of summing the partials (20 us at 3584 x 512) ...
 WIDE_MIN_ROWS = 8192           # ... only pays for this many rows (4120 rows: 44 us unsplit vs 48 + 20 split; 16408: 216 vs 95)
 
@@ -111,6 +114,12 @@ def _weight_grad(go, x, out_dtype, out=None, defer=False):
     # partials stay small: unsplit, hipBLASLt runs that product on 65 workgroups (216 us at 16408 rows)
     s_max = min(MAX_SPLITS, MAX_PARTIAL_BYTES // (m * k * 4))
     if rows < MIN_ROWS or s_max < 2 or (m * k > WIDE_OUTPUT and rows < WIDE_MIN_ROWS):
+        if defer:
+            from . import deferred
+
+            dw = deferred.push_wgrad(go, x, out_dtype, out)  # one batched product per shape at the end of the backward stage
+            if dw is not None:
+                return dw
         if out is not None and out.dtype == go.dtype and out.is_contiguous():
             return torch.mm(go.t(), x, out=out)  # straight into the (slice of the) packed gradient: no copy kernel
         dw = go.t() @ x
@@ -128,7 +137,9 @@ def _weight_grad(go, x, out_dtype, out=None, defer=False):
         from .. import _lib
 
         dw = out if out is not None else torch.empty(m, k, dtype=out_dtype, device=go.device)
-        if defer:
+        # small sums only: a large one reads its partials out of the caches when it runs right behind the product that wrote
+        # them (32 MiB in 7 us); at the end of the stage the same sum comes from HBM (measured at C2: 107 -> 250 us in total)
+        if defer and part.numel() * 4 <= DEFER_MAX_BYTES:
             from . import deferred
 
             if deferred.push(part, s, m * k, **({"out_bf16": dw} if dw.dtype == torch.bfloat16 else {"out_f32": dw})):

@@ -9,11 +9,11 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _act_run(mode, precision, device, ragged, trainer_kw=None, dim_feedforward=32, points=400):
+def _act_run(mode, precision, device, ragged, trainer_kw=None, dim_feedforward=32, points=400, decoder_layers=2):
     from pointcloudmatters_amd.bc import BCTrainer, build_act_policy, clone_batch, make_act_batch
 
-    small = dict(hidden_dim=512, nhead=8, dim_feedforward=dim_feedforward, num_encoder_layers=2, num_decoder_layers=2, dropout=0.1,
-                 latent_dim=8, num_queries=10)
+    small = dict(hidden_dim=512, nhead=8, dim_feedforward=dim_feedforward, num_encoder_layers=2, num_decoder_layers=decoder_layers,
+                 dropout=0.1, latent_dim=8, num_queries=10)
     batches = [make_act_batch(3, points, seed=50 + i, ragged=ragged, device=device, num_queries=10) for i in range(2)]
     eps = torch.randn(3, 8, generator=torch.Generator().manual_seed(1)).to(device)
     torch.manual_seed(0)
@@ -45,13 +45,14 @@ def test_act_training_steps_are_bit_reproducible(mode, precision, ragged, hip_de
 
 @pytest.mark.parametrize("mode,precision,ragged,ff", [("hybrid", "bf16", True, 3200), ("graph", "bf16", False, 3200), ("flat", "bf16", False, 32),
                                                       ("hybrid", "fp32", True, 3200)])
-def test_batched_closing_reductions_change_no_bit(mode, precision, ragged, ff, hip_device):
+def test_batched_closing_reductions_change_no_bit(mode, precision, ragged, ff, hip_device, monkeypatch):
     """policy/deferred.py: the second-level reductions of the fused backward kernels (norm / bias gradients, split-K weight
     gradients) launched together at the end of each backward stage instead of one by one.  Same arithmetic in the same
     order -> losses, every flat gradient and the parameters after three steps are torch.equal with the window on and off;
     a result read before its reduction ran (the failure this guards against) would show up as stale values."""
     from pointcloudmatters_amd.policy import deferred
 
+    monkeypatch.setattr(deferred, "BATCH_WGRADS", False)  # the batched weight gradients agree to rounding only (next test)
     n0 = dict(deferred.STATS)
     a, pa = _act_run(mode, precision, hip_device, ragged, dict(defer_reductions=True), dim_feedforward=ff, points=1200)
     n1 = dict(deferred.STATS)
@@ -63,6 +64,34 @@ def test_batched_closing_reductions_change_no_bit(mode, precision, ragged, ff, h
         assert torch.equal(la, lb), (i, la.item(), lb.item())
         assert torch.equal(ga, gb), (i, (ga - gb).abs().max().item())
     assert torch.equal(pa, pb)
+
+
+@pytest.mark.parametrize("mode,precision", [("graph", "bf16"), ("hybrid", "bf16"), ("hybrid", "fp32")])
+def test_batched_weight_gradients_agree_and_reproduce(mode, precision, hip_device, monkeypatch):
+    """policy/deferred.push_wgrad: the seven decoder layers' weight gradients of one shape as ONE batched product per backward
+    stage.  Another GEMM kernel sums in another order, so: against the single products the losses of three steps and every
+    gradient agree to rounding (bf16 results: one unit in the last place of some elements); two runs WITH batching are
+    bit-identical (the batched kernels are deterministic); and the batching did run."""
+    from pointcloudmatters_amd.policy import deferred
+
+    monkeypatch.setattr(deferred, "_EXPECT", {})
+    monkeypatch.setattr(deferred, "BATCH_WGRADS", True)
+    n0 = dict(deferred.STATS)
+    a, pa = _act_run(mode, precision, hip_device, mode != "graph", decoder_layers=7)
+    n1 = dict(deferred.STATS)
+    assert n1["wgrad_batches"] > n0["wgrad_batches"] and n1["wgrads"] - n0["wgrads"] >= 5 * (n1["wgrad_batches"] - n0["wgrad_batches"])
+    a2, pa2 = _act_run(mode, precision, hip_device, mode != "graph", decoder_layers=7)
+    for (la, ga), (lb, gb) in zip(a, a2):
+        assert torch.equal(la, lb) and torch.equal(ga, gb)
+    assert torch.equal(pa, pa2)
+    monkeypatch.setattr(deferred, "BATCH_WGRADS", False)
+    n2 = dict(deferred.STATS)
+    b, pb = _act_run(mode, precision, hip_device, mode != "graph", decoder_layers=7)
+    assert deferred.STATS["wgrad_batches"] == n2["wgrad_batches"] and deferred.STATS["wgrads"] == n2["wgrads"]
+    tol = 2e-2 if precision == "bf16" else 1e-4
+    for i, ((la, ga), (lb, gb)) in enumerate(zip(a, b)):
+        torch.testing.assert_close(la, lb, rtol=2e-3 if precision == "bf16" else 1e-5, atol=0)
+        assert (ga - gb).abs().max() <= tol * gb.abs().max(), (i, (ga - gb).abs().max().item(), gb.abs().max().item())
 
 
 @pytest.mark.parametrize("mode", ["flat", "hybrid"])
