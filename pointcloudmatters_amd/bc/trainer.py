@@ -515,12 +515,28 @@ class BCTrainer:
         return out
 
     @staticmethod
-    def _copy_into(static, batch):
+    def _copy_into(static, batch, _pairs=None):
+        """The batch into the captured step's input tensors: one multi-tensor copy per dtype instead of a copy per tensor
+        (15 tensors in an ACT batch)."""
+        pairs = [] if _pairs is None else _pairs
         for k, v in batch.items():
             if isinstance(v, dict):
-                BCTrainer._copy_into(static[k], v)
+                BCTrainer._copy_into(static[k], v, pairs)
             elif torch.is_tensor(v) and static[k] is not v:
-                static[k].copy_(v, non_blocking=True)
+                pairs.append((static[k], v))
+        if _pairs is None and pairs:
+            same = [(d, s_) for d, s_ in pairs if d.device == s_.device and d.dtype == s_.dtype and d.shape == s_.shape and d.is_cuda]
+            by_dtype = {}
+            for d, s_ in same:
+                by_dtype.setdefault(d.dtype, []).append((d, s_))
+            done = set()
+            for grp in by_dtype.values():
+                if len(grp) > 1:
+                    torch._foreach_copy_([d for d, _ in grp], [s_ for _, s_ in grp], non_blocking=True)
+                    done.update(id(d) for d, _ in grp)
+            for d, s_ in pairs:
+                if id(d) not in done:
+                    d.copy_(s_, non_blocking=True)
 
     def _reset_grads(self):
         opt = self.optimizer

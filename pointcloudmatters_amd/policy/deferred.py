@@ -30,7 +30,7 @@ _W = {}    # pending weight gradients of this stage by shape key
 _SEEN = {}    # shape key -> products computed singly since the last flush
 _EXPECT = {}  # shape key -> products seen at the last flush (sizes the shared result buffer of the next stage with that key)
 BATCH_WGRADS = os.environ.get("PCM_BATCH_WGRADS", "1") != "0"
-WGRAD_MIN_GROUP = 5  # fewer products of a shape than this: not worth two stacking copies (measured: 4 x 11 us vs 35 us)
+WGRAD_MIN_GROUP = int(os.environ.get("PCM_WGRAD_MIN_GROUP", 4))  # fewer products of a shape than this are computed singly (C2: 5.63 ms with 5, 5.55 with 4)
 STATS = {"pushed": 0, "launches": 0, "wgrads": 0, "wgrad_batches": 0}  # tests / tools read these
 
 

@@ -457,6 +457,7 @@ class _AddPosLinear(Function):
         ctx.meta = (shape, pos.shape, w.dtype, b.dtype)
         ctx.side_ok = _goes_to_optimizer(w)
         ctx.defer = deferred.targets(w)
+        ctx.defer_b = deferred.targets(b)
         ctx.sink = getattr(pos, "_pcm_sink", None)
         return y
 
@@ -482,7 +483,9 @@ class _AddPosLinear(Function):
             if ctx.needs_input_grad[2]:
                 dw = weight_grad(dy2, s_in, wdt, side=ctx.side_ok, defer=deferred.clear(*ctx.defer))
             if ctx.needs_input_grad[3]:
-                db = dy2.sum(dim=0).to(bdt)
+                from .rows_linear import bias_grad
+
+                db = bias_grad(dy2, bdt, defer=deferred.clear(*ctx.defer_b))
         return dx, dpos, dw, db
 
 

@@ -83,3 +83,29 @@ def test_proj_drln_matches_the_plain_chain(p):
     ins = [a, x, proj.weight, proj.bias, norm.weight, norm.bias]
     for got, ref, name in zip(torch.autograd.grad(out, ins, g), torch.autograd.grad(want, ins, g), "a x W b gamma beta".split()):
         assert (got - ref).norm().item() <= 1e-4 * ref.norm().item() + 1e-5, name
+
+
+@pytest.mark.parametrize("rows,c,dt,odt", [(800, 512, torch.bfloat16, torch.bfloat16), (4120, 3584, torch.bfloat16, torch.bfloat16),
+                                           (4120, 3584, torch.bfloat16, torch.float32), (37, 12, torch.float32, torch.float32),
+                                           (2000, 2500, torch.float32, torch.float32), (5, 6, torch.float32, torch.float32)])
+def test_bias_grad_column_sums(rows, c, dt, odt):
+    """rows_linear.bias_grad (two-stage column sums in <= 1024-column pieces, up to three per launch) against the fp64 sum,
+    immediately and with its closing stage left to policy/deferred.py's batch; odd widths fall back to the framework."""
+    from pointcloudmatters_amd.policy import deferred
+    from pointcloudmatters_amd.policy.rows_linear import bias_grad
+
+    torch.manual_seed(0)
+    go = (torch.randn(rows, c, device="cuda") + 0.3).to(dt)
+    want = go.double().sum(0)
+    tol = 1e-5 if odt == torch.float32 else 8e-3
+    got = bias_grad(go, odt)
+    assert got.dtype == odt and got.shape == (c,)
+    torch.testing.assert_close(got.double(), want, rtol=tol, atol=tol * rows ** 0.5)
+    assert deferred.begin()
+    try:
+        pending = bias_grad(go, odt, defer=True)
+        n = deferred.flush()
+        assert n >= (1 if c % 4 == 0 else 0)
+    finally:
+        deferred.end()
+    assert torch.equal(pending, got)
