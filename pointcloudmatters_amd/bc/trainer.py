@@ -413,7 +413,8 @@ class BCTrainer:
         opt = self.optimizer
         if len(stages) == 1:
             out = make_out()
-            out["loss"].backward(self._loss_seed(out["loss"]))
+            with deferred.backward_phase():
+                out["loss"].backward(self._loss_seed(out["loss"]))
             if self._fused_ctx is not None:
                 self._fused_ctx.flush_sinks()
             deferred.flush()
@@ -432,7 +433,8 @@ class BCTrainer:
             if last and st.lower is None and leaf is not None:
                 inputs = inputs + [leaf]
             if roots:
-                torch.autograd.backward(roots, grads, inputs=inputs)
+                with deferred.backward_phase():
+                    torch.autograd.backward(roots, grads, inputs=inputs)
             if self._fused_ctx is not None:
                 self._fused_ctx.flush_sinks()  # deferred position-embedding gradients of this stage (fused_ops.GradSink)
             deferred.flush()  # this stage's closing reductions, one launch per 24
@@ -445,7 +447,8 @@ class BCTrainer:
                 for t in roots:
                     t.grad = None
                 if last and leaf is not None and roots:  # the short way from the last cut down to the leaf, same segment
-                    torch.autograd.backward(roots, grads, inputs=[leaf])
+                    with deferred.backward_phase():
+                        torch.autograd.backward(roots, grads, inputs=[leaf])
             yield si, stats
 
     def _forward_backward(self, batch, first=None):

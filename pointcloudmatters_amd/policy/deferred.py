@@ -29,9 +29,10 @@ _Q = None  # None: no window.  Else the pending reductions of this backward stag
 _W = {}    # pending weight gradients of this stage by shape key
 _SEEN = {}    # shape key -> products computed singly since the last flush
 _EXPECT = {}  # shape key -> products seen at the last flush (sizes the shared result buffer of the next stage with that key)
+_DEBUG = os.environ.get("PCM_DEFER_DEBUG", "0") != "0"
 BATCH_WGRADS = os.environ.get("PCM_BATCH_WGRADS", "1") != "0"
 WGRAD_MIN_GROUP = int(os.environ.get("PCM_WGRAD_MIN_GROUP", 4))  # fewer products of a shape than this are computed singly (C2: 5.63 ms with 5, 5.55 with 4)
-STATS = {"pushed": 0, "launches": 0, "wgrads": 0, "wgrad_batches": 0}  # tests / tools read these
+STATS = {"pushed": 0, "launches": 0, "wgrads": 0, "wgrad_batches": 0, "stacked": 0}  # tests / tools read these
 
 
 def active():
@@ -54,6 +55,10 @@ def end():
         _Q = None
         _W = {}
         _SEEN.clear()
+        _ARENAS.clear()
+        _TAKE_EXPECT.clear()
+        _TAKE_EXPECT.update(_TAKEN)
+        _TAKEN.clear()
 
 
 def targets(*params):
@@ -90,6 +95,81 @@ def push(partial, nslots, width, out_f32=None, out_bf16=None, bf16_from=0):
     return True
 
 
+# ---- operand arenas ------------------------------------------------------------------------------------------------
+# A batched product wants its operands as ONE strided tensor.  The fused nodes allocate the activations that later become
+# weight-gradient operands (attention outputs, dy of the norms, the bf16 inputs of the projections) through ``take``:
+# inside a window, tensors of one (shape, dtype) are consecutive slots of one buffer, sized from the count of the previous
+# window.  Identical layers allocate in an identical order, so the l-th layer's operand sits at a fixed slot stride and the
+# flush can describe all of them with as_strided -- no stacking copy.  Anything else (first step, other allocation order,
+# tensors from framework ops) falls back to torch.stack.
+_ARENAS = {}       # (shape, dtype, device) -> [buffer, next slot]
+_TAKEN = {}        # takes per key in this window
+_TAKE_EXPECT = {}  # ... in the previous window
+ARENA_MAX_BYTES = 8 << 20  # per slot: only the short activations whose weight gradients are batched
+
+
+_BACKWARD = False  # set by the training loop around its autograd calls (``backward_phase``)
+
+
+class backward_phase:
+    """with deferred.backward_phase(): torch.autograd.backward(...) -- tells ``take`` which way to fill its arenas."""
+
+    def __enter__(self):
+        global _BACKWARD
+        self.prev, _BACKWARD = _BACKWARD, True
+
+    def __exit__(self, *exc):
+        global _BACKWARD
+        _BACKWARD = self.prev
+
+
+def take(shape, dtype, device):
+    """torch.empty(shape) -- as a slot of this window's arena for that shape when weight gradients are being batched.
+    Forward allocations fill their arena upwards, backward allocations fill theirs DOWNWARDS: backward visits the layers in
+    reverse, so in the order the weight gradients are pushed both kinds of operand then sit at descending addresses, and
+    the flush (which batches in reverse push order) sees two ascending, uniformly strided sets."""
+    shape = tuple(int(v) for v in shape)
+    if _Q is None or not BATCH_WGRADS:
+        return torch.empty(shape, dtype=dtype, device=device)
+    key = (shape, dtype, torch.device(device), _BACKWARD)
+    _TAKEN[key] = _TAKEN.get(key, 0) + 1
+    ar = _ARENAS.get(key)
+    if ar is None:
+        n = _TAKE_EXPECT.get(key, 0)
+        numel = 1
+        for v in shape:
+            numel *= v
+        if n < WGRAD_MIN_GROUP or numel * torch.empty((), dtype=dtype).element_size() > ARENA_MAX_BYTES or numel == 0:
+            return torch.empty(shape, dtype=dtype, device=device)
+        # a quarter more slots than needed, free at the top: the padded batch (7 -> 8) of a strided operand set reads one
+        # stride past its last member and stays inside the buffer
+        ar = _ARENAS[key] = [torch.empty((n + (n + 3) // 4,) + shape, dtype=dtype, device=device), 0, n]
+    if ar[1] >= ar[2]:
+        return torch.empty(shape, dtype=dtype, device=device)
+    t = ar[0][ar[2] - 1 - ar[1] if _BACKWARD else ar[1]]
+    ar[1] += 1
+    return t
+
+
+def _as_batch(ts, nb):
+    """The tensors of `ts` (same shape, contiguous) as one (n', ...) strided view when they sit at a uniform stride in one
+    storage: n' = nb if that many slots fit in the storage, else len(ts).  None when they do not line up."""
+    t0 = ts[0]
+    es, p0 = t0.element_size(), t0.data_ptr()
+    if len(ts) < 2:
+        return None
+    d = ts[1].data_ptr() - p0
+    if d <= 0 or d % es or d < t0.numel() * es:
+        return None
+    st = t0.untyped_storage()
+    base = st.data_ptr()
+    for i, t in enumerate(ts):
+        if t.data_ptr() - p0 != i * d or t.untyped_storage().data_ptr() != base:
+            return None
+    n = nb if p0 + (nb - 1) * d + t0.numel() * es <= base + st.nbytes() else len(ts)
+    return torch.as_strided(t0, (n,) + tuple(t0.shape), (d // es,) + tuple(t0.stride()))
+
+
 def _padded(n):
     # hipBLASLt's batched kernels are markedly faster at 4 / 8 / 16 batches than at 5 or 7 (tools/mb/mb_wgrad_batch.py)
     for p in (4, 8, 16):
@@ -118,7 +198,7 @@ def push_wgrad(go, x, out_dtype, out=None):
         grp = _W[key] = {"buf": buf, "gos": [], "xs": [], "extra": []}
     i = len(grp["gos"])
     if out is None and i < want:
-        dw = grp["buf"][i]
+        dw = grp["buf"][want - 1 - i]  # the flush batches in REVERSE push order (see take)
     else:  # a caller's slice, or more products than last time: filled by the scatter copy
         dw = out if out is not None else torch.empty(go.shape[1], x.shape[1], dtype=out_dtype, device=go.device)
         grp["extra"].append((i, dw.view(-1)))
@@ -137,22 +217,35 @@ def _flush_wgrads():
         return
     groups, _W = _W, {}
     for key, grp in groups.items():
-        gos, xs, buf = grp["gos"], grp["xs"], grp["buf"]
+        gos, xs, buf = grp["gos"][::-1], grp["xs"][::-1], grp["buf"]  # batch j = push n-1-j
         n = len(gos)
+        want = _EXPECT.get(key, 0)
         _EXPECT[key] = n
         out_dtype = key[3]
         nb = _padded(n)
-        a = torch.stack(gos + gos[: nb - n])
-        b = torch.stack(xs + xs[: nb - n])
+        a, b = _as_batch(gos, nb), _as_batch(xs, nb)
+        if a is not None and b is not None and a.shape[0] != b.shape[0]:
+            nb = n
+            a, b = a[:n], b[:n]
+        elif a is not None or b is not None:
+            nb = (a if a is not None else b).shape[0]
+        STATS["stacked"] += (a is None) + (b is None)
+        if _DEBUG and (a is None or b is None):
+            print("deferred: stacked", "go" if a is None else "", "x" if b is None else "", key[:4],
+                  [t.data_ptr() - gos[0].data_ptr() for t in gos], [t.data_ptr() - xs[0].data_ptr() for t in xs], flush=True)
+        if a is None:
+            a = torch.stack(gos + gos[: nb - n])
+        if b is None:
+            b = torch.stack(xs + xs[: nb - n])
         kw = {"out_dtype": out_dtype} if (a.dtype == torch.bfloat16 and out_dtype == torch.float32) else {}
-        if not grp["extra"] and buf.shape[0] == nb and not kw:
-            torch.bmm(a.transpose(1, 2), b, out=buf)
+        if not grp["extra"] and n == want and buf.shape[0] == nb and not kw:
+            torch.bmm(a.transpose(1, 2), b, out=buf)  # push i was handed buf[want-1-i] = batch n-1-i
         else:
             r = torch.bmm(a.transpose(1, 2), b, **kw)
             taken = {i for i, _ in grp["extra"]}
-            own = [i for i in range(min(n, buf.shape[0])) if i not in taken]
-            dsts = [buf[i].view(-1) for i in own] + [d for _, d in grp["extra"]]
-            srcs = [r[i].reshape(-1) for i in own] + [r[i].reshape(-1) for i, _ in grp["extra"]]
+            own = [i for i in range(min(n, want)) if i not in taken]  # push indices that were handed a slot of buf
+            dsts = [buf[want - 1 - i].view(-1) for i in own] + [d for _, d in grp["extra"]]
+            srcs = [r[n - 1 - i].reshape(-1) for i in own] + [r[n - 1 - i].reshape(-1) for i, _ in grp["extra"]]
             torch._foreach_copy_(dsts, srcs)
         STATS["wgrad_batches"] += 1
 

@@ -132,7 +132,7 @@ def _drln_forward(x2, y2, gamma, beta, eps, p_drop, seed, site):
     dev = x2.device
     with torch.cuda.device(dev):
         s = torch.empty_like(x2)
-        out = torch.empty_like(x2)
+        out = deferred.take(x2.shape, x2.dtype, dev)
         mean = torch.empty(R, dtype=torch.float32, device=dev)
         rstd = torch.empty(R, dtype=torch.float32, device=dev)
         rc = L.pcm_drln_forward_hip(R, E, 1 if y2.dtype == torch.bfloat16 else 0, x2.data_ptr(), y2.data_ptr(), gamma.data_ptr(),
@@ -154,7 +154,7 @@ def _drln_backward(dout, s, mean, rstd, gamma, ydtype, p_drop, seed, site, dysum
         d2 = d2.float().contiguous()
     with torch.cuda.device(dev):
         dx = torch.empty_like(s)
-        dy = torch.empty(R, E, dtype=ydtype, device=dev)
+        dy = deferred.take((R, E), ydtype, dev)
         blocks = L.pcm_drln_blocks(R)
         partial = torch.empty(blocks * 3 * E, dtype=torch.float32, device=dev)
         sums = torch.empty(3, E, dtype=torch.float32, device=dev)
@@ -257,7 +257,7 @@ class _FFNLN(Function):
         dev = x.device
         f32 = dict(dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            hd, s, out = torch.empty(R, Fh, **f32), torch.empty(R, E, **f32), torch.empty(R, E, **f32)
+            hd, s, out = deferred.take((R, Fh), torch.float32, dev), torch.empty(R, E, **f32), deferred.take((R, E), torch.float32, dev)
             mean, rstd = torch.empty(R, **f32), torch.empty(R, **f32)
             sp = seed.data_ptr() if seed is not None else 0
             rc = L.pcm_ffn_ln_forward_hip(R, E, Fh, x2.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
@@ -284,7 +284,7 @@ class _FFNLN(Function):
         if d2.dtype != torch.float32 or not d2.is_contiguous():
             d2 = d2.float().contiguous()
         with torch.cuda.device(dev):
-            dx, dy, dh = torch.empty(R, E, **f32), torch.empty(R, E, **f32), torch.empty(R, Fh, **f32)
+            dx, dy, dh = torch.empty(R, E, **f32), deferred.take((R, E), torch.float32, dev), deferred.take((R, Fh), torch.float32, dev)
             pw = 3 * E + Fh
             blocks = L.pcm_ffn_ln_blocks(R)
             partial = torch.empty(blocks * pw, **f32)
@@ -347,8 +347,8 @@ class _SelfAttnInProj(Function):
         wc = w if w.dtype == bf else w.to(bf)
         bc = b if b.dtype == bf else b.to(bf)
         with torch.cuda.device(dev):
-            qk_in = torch.empty(rows, E, dtype=bf, device=dev)
-            v_in = torch.empty(rows, E, dtype=bf, device=dev)
+            qk_in = deferred.take((rows, E), bf, dev)
+            v_in = deferred.take((rows, E), bf, dev)
             rc = L.pcm_add_cast2_hip(x2.numel(), posc.numel(), x2.data_ptr(), posc.data_ptr(), qk_in.data_ptr(), v_in.data_ptr(),
                                      _raw_stream())
         _lib.check(rc, "pcm_add_cast2_hip")
@@ -447,7 +447,7 @@ class _AddPosLinear(Function):
         wc = w if w.dtype == bf else w.to(bf)
         bc = b if b.dtype == bf else b.to(bf)
         with torch.cuda.device(x.device):
-            s_in = torch.empty(x2.shape, dtype=bf, device=x.device)
+            s_in = deferred.take(x2.shape, bf, x.device)
             rc = L.pcm_add_cast2_hip(x2.numel(), posc.numel(), x2.data_ptr(), posc.data_ptr(), s_in.data_ptr(), 0,
                                      _raw_stream())
         _lib.check(rc, "pcm_add_cast2_hip")

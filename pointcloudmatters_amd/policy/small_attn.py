@@ -14,6 +14,7 @@ import torch
 from torch.autograd import Function
 
 from .. import _lib
+from . import deferred
 from .._lib import raw_stream as _raw_stream
 
 
@@ -41,7 +42,7 @@ class _SmallAttn(Function):
         q, k, v = (t if t.stride(-1) == 1 else t.contiguous() for t in (q, k, v))
         dev = q.device
         with torch.cuda.device(dev):
-            out = torch.empty(B, L, E, dtype=torch.bfloat16, device=dev)
+            out = deferred.take((B, L, E), torch.bfloat16, dev)
             lse = torch.empty(B, heads, L, dtype=torch.float32, device=dev)
             use_flash = L >= FLASH_FROM
             fwd = L_.pcm_attn_flash_forward_hip if use_flash else L_.pcm_attn_small_forward_hip
@@ -66,10 +67,10 @@ class _SmallAttn(Function):
         dev = q.device
         with torch.cuda.device(dev):
             if L == S:  # self-attention: dq | dk side by side, the layout the packed in-projection consumes without a copy
-                dqk = torch.empty(B, L, 2, E, dtype=torch.bfloat16, device=dev)
+                dqk = deferred.take((B, L, 2, E), torch.bfloat16, dev)
                 dq, dk = dqk[:, :, 0], dqk[:, :, 1]
             else:
-                dq = torch.empty(B, L, E, dtype=torch.bfloat16, device=dev)
+                dq = deferred.take((B, L, E), torch.bfloat16, dev)
                 dk = _grad_buffer(ctx.slots[0], B, S, E, dev)
             dv = _grad_buffer(ctx.slots[1], B, S, E, dev)
             head = (B, heads, L, S, q.data_ptr(), *_st(q), k.data_ptr(), *_st(k), v.data_ptr(), *_st(v),
@@ -92,7 +93,7 @@ def _grad_buffer(slot, B, S, E, dev):
         arena, l = slot
         if arena.shape == (B, S, E) and arena.dtype == torch.bfloat16:
             return arena.slot(l)
-    return torch.empty(B, S, E, dtype=torch.bfloat16, device=dev)
+    return deferred.take((B, S, E), torch.bfloat16, dev)
 
 
 def supported(q, k, v, heads, dropout_p=0.0):
