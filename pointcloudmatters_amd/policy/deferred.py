@@ -105,7 +105,7 @@ def push(partial, nslots, width, out_f32=None, out_bf16=None, bf16_from=0):
 _ARENAS = {}       # (shape, dtype, device) -> [buffer, next slot]
 _TAKEN = {}        # takes per key in this window
 _TAKE_EXPECT = {}  # ... in the previous window
-ARENA_MAX_BYTES = 8 << 20  # per slot: only the short activations whose weight gradients are batched
+ARENA_MAX_BYTES = 16 << 20  # per slot (and per operand of a batched product): larger activations keep the split-K route
 
 
 _BACKWARD = False  # set by the training loop around its autograd calls (``backward_phase``)
@@ -123,15 +123,16 @@ class backward_phase:
         _BACKWARD = self.prev
 
 
-def take(shape, dtype, device):
-    """torch.empty(shape) -- as a slot of this window's arena for that shape when weight gradients are being batched.
+def take(shape, dtype, device, tag=None):
+    """torch.empty(shape) -- as a slot of this window's arena for that (call site `tag`, shape) when weight gradients are
+    being batched: one site's tensors are consecutive slots whatever else is allocated in between.
     Forward allocations fill their arena upwards, backward allocations fill theirs DOWNWARDS: backward visits the layers in
     reverse, so in the order the weight gradients are pushed both kinds of operand then sit at descending addresses, and
     the flush (which batches in reverse push order) sees two ascending, uniformly strided sets."""
     shape = tuple(int(v) for v in shape)
     if _Q is None or not BATCH_WGRADS:
         return torch.empty(shape, dtype=dtype, device=device)
-    key = (shape, dtype, torch.device(device), _BACKWARD)
+    key = (tag, shape, dtype, torch.device(device), _BACKWARD)
     _TAKEN[key] = _TAKEN.get(key, 0) + 1
     ar = _ARENAS.get(key)
     if ar is None:
@@ -171,14 +172,15 @@ def _as_batch(ts, nb):
 
 
 def _padded(n):
-    # hipBLASLt's batched kernels are markedly faster at 4 / 8 / 16 batches than at 5 or 7 (tools/mb/mb_wgrad_batch.py)
-    for p in (4, 8, 16):
-        if n <= p and p - n <= 1:
+    # hipBLASLt's batched kernels are markedly faster at 4 / 8 / 16 batches than at 5, 7 or 14 (800 x 512 x 512 bf16: 14
+    # batches 24.7 us, 16 batches 16.9 us; tools/mb/mb_wgrad_batch.py, mb_wgrad_enc.py)
+    for p, slack in ((4, 1), (8, 1), (16, 2)):
+        if n <= p and p - n <= slack:
             return p
     return n
 
 
-def push_wgrad(go, x, out_dtype, out=None):
+def push_wgrad(go, x, out_dtype, out=None, tag=None):
     """Queue dW = go^T @ x (go (rows, m), x (rows, k), contiguous, same dtype) and return the tensor that WILL hold it (`out`,
     a contiguous (m, k) tensor or slice, when given), or None when the caller should compute it now (no window, batching
     off, or a shape that came fewer than WGRAD_MIN_GROUP times in the last stage that had it)."""
@@ -187,7 +189,9 @@ def push_wgrad(go, x, out_dtype, out=None):
         return None
     if go.dtype == torch.float32 and out_dtype != torch.float32:
         return None
-    key = (tuple(go.shape), tuple(x.shape), go.dtype, out_dtype, go.device)
+    if max(go.numel(), x.numel()) * go.element_size() > ARENA_MAX_BYTES:
+        return None
+    key = (tuple(go.shape), tuple(x.shape), go.dtype, out_dtype, go.device, tag)
     want = _EXPECT.get(key, 0)
     grp = _W.get(key)
     if grp is None:

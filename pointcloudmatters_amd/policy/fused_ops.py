@@ -132,7 +132,7 @@ def _drln_forward(x2, y2, gamma, beta, eps, p_drop, seed, site):
     dev = x2.device
     with torch.cuda.device(dev):
         s = torch.empty_like(x2)
-        out = deferred.take(x2.shape, x2.dtype, dev)
+        out = deferred.take(x2.shape, x2.dtype, dev, "drln.out")
         mean = torch.empty(R, dtype=torch.float32, device=dev)
         rstd = torch.empty(R, dtype=torch.float32, device=dev)
         rc = L.pcm_drln_forward_hip(R, E, 1 if y2.dtype == torch.bfloat16 else 0, x2.data_ptr(), y2.data_ptr(), gamma.data_ptr(),
@@ -154,7 +154,7 @@ def _drln_backward(dout, s, mean, rstd, gamma, ydtype, p_drop, seed, site, dysum
         d2 = d2.float().contiguous()
     with torch.cuda.device(dev):
         dx = torch.empty_like(s)
-        dy = deferred.take((R, E), ydtype, dev)
+        dy = deferred.take((R, E), ydtype, dev, "drln.dy")
         blocks = L.pcm_drln_blocks(R)
         partial = torch.empty(blocks * 3 * E, dtype=torch.float32, device=dev)
         sums = torch.empty(3, E, dtype=torch.float32, device=dev)
@@ -213,7 +213,7 @@ class _ProjDRLN(Function):
             da = (dy @ wc).view(ashape)
             if da.dtype != adt:
                 da = da.to(adt)
-            dw = weight_grad(dy, a2, wdt, side=ctx.side_ok, defer=defer)
+            dw = weight_grad(dy, a2, wdt, side=ctx.side_ok, defer=defer, tag="proj_drln")
             db = res[3] if want16 else sums[2].to(bdt)
         return da, dw, db, dx.view(shape), sums[0], sums[1], None, None, None, None
 
@@ -257,7 +257,7 @@ class _FFNLN(Function):
         dev = x.device
         f32 = dict(dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            hd, s, out = deferred.take((R, Fh), torch.float32, dev), torch.empty(R, E, **f32), deferred.take((R, E), torch.float32, dev)
+            hd, s, out = deferred.take((R, Fh), torch.float32, dev, "ffn.hd"), torch.empty(R, E, **f32), deferred.take((R, E), torch.float32, dev, "drln.out")
             mean, rstd = torch.empty(R, **f32), torch.empty(R, **f32)
             sp = seed.data_ptr() if seed is not None else 0
             rc = L.pcm_ffn_ln_forward_hip(R, E, Fh, x2.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
@@ -284,7 +284,7 @@ class _FFNLN(Function):
         if d2.dtype != torch.float32 or not d2.is_contiguous():
             d2 = d2.float().contiguous()
         with torch.cuda.device(dev):
-            dx, dy, dh = torch.empty(R, E, **f32), deferred.take((R, E), torch.float32, dev), deferred.take((R, Fh), torch.float32, dev)
+            dx, dy, dh = torch.empty(R, E, **f32), deferred.take((R, E), torch.float32, dev, "ffn.dy"), deferred.take((R, Fh), torch.float32, dev, "ffn.dh")
             pw = 3 * E + Fh
             blocks = L.pcm_ffn_ln_blocks(R)
             partial = torch.empty(blocks * pw, **f32)
@@ -300,8 +300,8 @@ class _FFNLN(Function):
             from .rows_linear import weight_grad
 
             with torch.autocast(device_type="cuda", enabled=False):
-                dw2 = weight_grad(dy, hd, torch.float32, side=ctx.side_ok, defer=defer)  # (E, F)   split-K over the rows when there are thousands
-                dw1 = weight_grad(dh, x2, torch.float32, side=ctx.side_ok, defer=defer)  # (F, E)
+                dw2 = weight_grad(dy, hd, torch.float32, side=ctx.side_ok, defer=defer, tag="ffn.w2")  # (E, F)   split-K over the rows when there are thousands
+                dw1 = weight_grad(dh, x2, torch.float32, side=ctx.side_ok, defer=defer, tag="ffn.w1")  # (F, E)
         dgamma, dbeta, db2, db1 = sums[:E], sums[E : 2 * E], sums[2 * E : 3 * E], sums[3 * E :]
         return dx.view(shape), dw1, db1, dw2, db2, dgamma, dbeta, None, None, None, None, None, None
 
@@ -347,8 +347,8 @@ class _SelfAttnInProj(Function):
         wc = w if w.dtype == bf else w.to(bf)
         bc = b if b.dtype == bf else b.to(bf)
         with torch.cuda.device(dev):
-            qk_in = deferred.take((rows, E), bf, dev)
-            v_in = deferred.take((rows, E), bf, dev)
+            qk_in = deferred.take((rows, E), bf, dev, "in_proj.qk")
+            v_in = deferred.take((rows, E), bf, dev, "in_proj.v")
             rc = L.pcm_add_cast2_hip(x2.numel(), posc.numel(), x2.data_ptr(), posc.data_ptr(), qk_in.data_ptr(), v_in.data_ptr(),
                                      _raw_stream())
         _lib.check(rc, "pcm_add_cast2_hip")
@@ -405,8 +405,8 @@ class _SelfAttnInProj(Function):
             _lib.check(rc, "pcm_add3_cast2_hip")
             dw = torch.empty(3 * E, E, dtype=wdt, device=dev)
             defer = deferred.clear(*ctx.defer)
-            weight_grad(dqk, qk_in, wdt, out=dw[: 2 * E], side=ctx.side_ok, defer=defer)
-            weight_grad(dv2, v_in, wdt, out=dw[2 * E:], side=ctx.side_ok, defer=defer)
+            weight_grad(dqk, qk_in, wdt, out=dw[: 2 * E], side=ctx.side_ok, defer=defer, tag="in_proj.qk")
+            weight_grad(dv2, v_in, wdt, out=dw[2 * E:], side=ctx.side_ok, defer=defer, tag="in_proj.v")
             db = torch.empty(3 * E, dtype=bdt, device=dev)
             slots = L.pcm_colsum_slots(rows, E)
             partial = torch.empty(slots * 3 * E, dtype=torch.float32, device=dev)
@@ -447,7 +447,7 @@ class _AddPosLinear(Function):
         wc = w if w.dtype == bf else w.to(bf)
         bc = b if b.dtype == bf else b.to(bf)
         with torch.cuda.device(x.device):
-            s_in = deferred.take(x2.shape, bf, x.device)
+            s_in = deferred.take(x2.shape, bf, x.device, "add_pos.s")
             rc = L.pcm_add_cast2_hip(x2.numel(), posc.numel(), x2.data_ptr(), posc.data_ptr(), s_in.data_ptr(), 0,
                                      _raw_stream())
         _lib.check(rc, "pcm_add_cast2_hip")
@@ -481,7 +481,7 @@ class _AddPosLinear(Function):
                 else:
                     dpos = d_in.sum_to_size(pos_shape) if ctx.needs_input_grad[1] else None
             if ctx.needs_input_grad[2]:
-                dw = weight_grad(dy2, s_in, wdt, side=ctx.side_ok, defer=deferred.clear(*ctx.defer))
+                dw = weight_grad(dy2, s_in, wdt, side=ctx.side_ok, defer=deferred.clear(*ctx.defer), tag="add_pos")
             if ctx.needs_input_grad[3]:
                 from .rows_linear import bias_grad
 

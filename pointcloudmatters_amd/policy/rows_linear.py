@@ -88,7 +88,7 @@ def goes_to_optimizer(weight):
     return fn is None or type(fn).__name__ == "_ShadowParamBackward"
 
 
-def weight_grad(go, x, out_dtype, out=None, side=False, defer=False):
+def weight_grad(go, x, out_dtype, out=None, side=False, defer=False, tag=None):
     """dW = go^T @ x for go (rows, m), x (rows, k) -> (m, k) in `out_dtype` (written into `out`, a contiguous (m, k)
     tensor or row-slice of a packed gradient, when given).  ``side``: may run on the side stream (see _SideQueue).
     ``defer``: the closing sum of a split product may stay pending until policy/deferred.flush (the caller checked
@@ -104,22 +104,24 @@ def weight_grad(go, x, out_dtype, out=None, side=False, defer=False):
         SIDE.held.append((go, x))
         SIDE.pending = True
         return out
-    return _weight_grad(go, x, out_dtype, out, defer)
+    return _weight_grad(go, x, out_dtype, out, defer, tag)
 
 
-def _weight_grad(go, x, out_dtype, out=None, defer=False):
+def _weight_grad(go, x, out_dtype, out=None, defer=False, tag=None):
     rows, m = go.shape
     k = x.shape[1]
     # wide outputs (the decoder's 7-layer key / value projection: 3584 x 512) are split too, as long as the fp32
     # partials stay small: unsplit, hipBLASLt runs that product on 65 workgroups (216 us at 16408 rows)
     s_max = min(MAX_SPLITS, MAX_PARTIAL_BYTES // (m * k * 4))
-    if rows < MIN_ROWS or s_max < 2 or (m * k > WIDE_OUTPUT and rows < WIDE_MIN_ROWS):
-        if defer:
-            from . import deferred
+    if defer:
+        # one batched product per (site, shape) at the end of the backward stage -- also for the encoder's 4120 rows: four
+        # layers' unsplit products in one launch fill the chip (31 us) where four split products + closing sums take 76
+        from . import deferred
 
-            dw = deferred.push_wgrad(go, x, out_dtype, out)  # one batched product per shape at the end of the backward stage
-            if dw is not None:
-                return dw
+        dw = deferred.push_wgrad(go, x, out_dtype, out, tag)
+        if dw is not None:
+            return dw
+    if rows < MIN_ROWS or s_max < 2 or (m * k > WIDE_OUTPUT and rows < WIDE_MIN_ROWS):
         if out is not None and out.dtype == go.dtype and out.is_contiguous():
             return torch.mm(go.t(), x, out=out)  # straight into the (slice of the) packed gradient: no copy kernel
         dw = go.t() @ x
@@ -237,7 +239,7 @@ class _LinearRows(Function):
                 from . import deferred
 
                 dw = weight_grad(go2, x2 if x2.is_contiguous() else x2.contiguous(), wdt, side=ctx.side_ok,
-                                 defer=deferred.clear(*ctx.defer))
+                                 defer=deferred.clear(*ctx.defer), tag="linear_rows")
             if bdt is not None and ctx.needs_input_grad[2]:
                 db = bias_grad(go2, bdt, defer=deferred.clear(*ctx.defer_b))
         return dx, dw, db

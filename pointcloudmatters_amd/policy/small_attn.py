@@ -42,7 +42,7 @@ class _SmallAttn(Function):
         q, k, v = (t if t.stride(-1) == 1 else t.contiguous() for t in (q, k, v))
         dev = q.device
         with torch.cuda.device(dev):
-            out = deferred.take((B, L, E), torch.bfloat16, dev)
+            out = deferred.take((B, L, E), torch.bfloat16, dev, "attn.out")
             lse = torch.empty(B, heads, L, dtype=torch.float32, device=dev)
             use_flash = L >= FLASH_FROM
             fwd = L_.pcm_attn_flash_forward_hip if use_flash else L_.pcm_attn_small_forward_hip
@@ -67,10 +67,10 @@ class _SmallAttn(Function):
         dev = q.device
         with torch.cuda.device(dev):
             if L == S:  # self-attention: dq | dk side by side, the layout the packed in-projection consumes without a copy
-                dqk = deferred.take((B, L, 2, E), torch.bfloat16, dev)
+                dqk = deferred.take((B, L, 2, E), torch.bfloat16, dev, "attn.dqk")
                 dq, dk = dqk[:, :, 0], dqk[:, :, 1]
             else:
-                dq = deferred.take((B, L, E), torch.bfloat16, dev)
+                dq = deferred.take((B, L, E), torch.bfloat16, dev, "attn.dq")
                 dk = _grad_buffer(ctx.slots[0], B, S, E, dev)
             dv = _grad_buffer(ctx.slots[1], B, S, E, dev)
             head = (B, heads, L, S, q.data_ptr(), *_st(q), k.data_ptr(), *_st(k), v.data_ptr(), *_st(v),
@@ -93,7 +93,7 @@ def _grad_buffer(slot, B, S, E, dev):
         arena, l = slot
         if arena.shape == (B, S, E) and arena.dtype == torch.bfloat16:
             return arena.slot(l)
-    return deferred.take((B, S, E), torch.bfloat16, dev)
+    return deferred.take((B, S, E), torch.bfloat16, dev, "attn.dkv")
 
 
 def supported(q, k, v, heads, dropout_p=0.0):
