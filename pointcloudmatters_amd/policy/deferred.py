@@ -32,7 +32,7 @@ _EXPECT = {}  # shape key -> products seen at the last flush (sizes the shared r
 _DEBUG = os.environ.get("PCM_DEFER_DEBUG", "0") != "0"
 BATCH_WGRADS = os.environ.get("PCM_BATCH_WGRADS", "1") != "0"
 WGRAD_MIN_GROUP = int(os.environ.get("PCM_WGRAD_MIN_GROUP", 4))  # fewer products of a shape than this are computed singly (C2: 5.63 ms with 5, 5.55 with 4)
-STATS = {"pushed": 0, "launches": 0, "wgrads": 0, "wgrad_batches": 0, "stacked": 0}  # tests / tools read these
+STATS = {"pushed": 0, "launches": 0, "wgrads": 0, "wgrad_batches": 0, "stacked": 0, "scattered": 0}  # tests / tools read these
 
 
 def active():
@@ -160,7 +160,7 @@ def _as_batch(ts, nb):
     if len(ts) < 2:
         return None
     d = ts[1].data_ptr() - p0
-    if d <= 0 or d % es or d < t0.numel() * es:
+    if d <= 0 or d % es or d < t0.numel() * es or not t0.is_contiguous():
         return None
     st = t0.untyped_storage()
     base = st.data_ptr()
@@ -198,14 +198,15 @@ def push_wgrad(go, x, out_dtype, out=None, tag=None):
         if want < WGRAD_MIN_GROUP:
             _SEEN[key] = _SEEN.get(key, 0) + 1  # computed singly, counted: the next stage with this many of them batches
             return None
-        buf = torch.empty(_padded(want), go.shape[1], x.shape[1], dtype=out_dtype, device=go.device)
-        grp = _W[key] = {"buf": buf, "gos": [], "xs": [], "extra": []}
+        grp = _W[key] = {"buf": None, "gos": [], "xs": [], "extra": []}
     i = len(grp["gos"])
     if out is None and i < want:
+        if grp["buf"] is None:
+            grp["buf"] = torch.empty(_padded(want), go.shape[1], x.shape[1], dtype=out_dtype, device=go.device)
         dw = grp["buf"][want - 1 - i]  # the flush batches in REVERSE push order (see take)
     else:  # a caller's slice, or more products than last time: filled by the scatter copy
         dw = out if out is not None else torch.empty(go.shape[1], x.shape[1], dtype=out_dtype, device=go.device)
-        grp["extra"].append((i, dw.view(-1)))
+        grp["extra"].append((i, dw.view(go.shape[1], x.shape[1])))
     grp["gos"].append(go)
     grp["xs"].append(x)
     STATS["wgrads"] += 1
@@ -242,13 +243,21 @@ def _flush_wgrads():
         if b is None:
             b = torch.stack(xs + xs[: nb - n])
         kw = {"out_dtype": out_dtype} if (a.dtype == torch.bfloat16 and out_dtype == torch.float32) else {}
-        if not grp["extra"] and n == want and buf.shape[0] == nb and not kw:
+        ov = None
+        if len(grp["extra"]) == n and not kw:  # every product has its own destination (slices of packed gradients taken
+            ov = _as_batch([d for _, d in grp["extra"]][::-1], nb)  # from an arena): one strided output if they line up
+            if ov is not None and ov.shape[0] != nb:
+                ov = None
+        if ov is not None:
+            torch.bmm(a.transpose(1, 2), b, out=ov)
+        elif not grp["extra"] and n == want and buf is not None and buf.shape[0] == nb and not kw:
             torch.bmm(a.transpose(1, 2), b, out=buf)  # push i was handed buf[want-1-i] = batch n-1-i
         else:
+            STATS["scattered"] += 1
             r = torch.bmm(a.transpose(1, 2), b, **kw)
             taken = {i for i, _ in grp["extra"]}
             own = [i for i in range(min(n, want)) if i not in taken]  # push indices that were handed a slot of buf
-            dsts = [buf[want - 1 - i].view(-1) for i in own] + [d for _, d in grp["extra"]]
+            dsts = [buf[want - 1 - i].view(-1) for i in own] + [d.view(-1) for _, d in grp["extra"]]
             srcs = [r[n - 1 - i].reshape(-1) for i in own] + [r[n - 1 - i].reshape(-1) for i, _ in grp["extra"]]
             torch._foreach_copy_(dsts, srcs)
         STATS["wgrad_batches"] += 1

@@ -403,7 +403,7 @@ class _SelfAttnInProj(Function):
             rc = L.pcm_add3_cast2_hip(dx.numel(), d_qk_in.data_ptr(), d_v_in.data_ptr(), dres.data_ptr() if dres is not None else 0,
                                       dx.data_ptr(), dpos32.data_ptr() if dpos32 is not None else 0, st)
             _lib.check(rc, "pcm_add3_cast2_hip")
-            dw = torch.empty(3 * E, E, dtype=wdt, device=dev)
+            dw = deferred.take((3 * E, E), wdt, dev, "in_proj.dw")
             defer = deferred.clear(*ctx.defer)
             weight_grad(dqk, qk_in, wdt, out=dw[: 2 * E], side=ctx.side_ok, defer=defer, tag="in_proj.qk")
             weight_grad(dv2, v_in, wdt, out=dw[2 * E:], side=ctx.side_ok, defer=defer, tag="in_proj.v")
