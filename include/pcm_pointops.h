@@ -440,6 +440,11 @@ int pcm_colsum_hip(long rows, int C, int ntensors, int in_is_bf16, const void *g
  * stage closes all of them together (policy/deferred.py). */
 int pcm_reduce_batch_hip(int n, const void *const *partial, const int *nslots, const int *width, void *const *out_f32,
                          void *const *out_bf16, const int *bf16_from, void *stream);
+/* first stages of n column sums in one launch per 16: per job the arguments of pcm_colsum_hip as host arrays (g and ld
+ * hold 3 entries per job); partial[i] receives pcm_colsum_slots(rows[i], C[i]) rows of ntensors[i]*C[i] sums, closed by
+ * pcm_reduce_batch_hip.  Same arithmetic as pcm_colsum_hip. */
+int pcm_colsum_batch_hip(int n, const long *rows, const int *C, const int *ntensors, const int *in_is_bf16, const void *const *g,
+                         const long *ld, void *const *partial, void *stream);
 
 /* ---- the ACT training loss (src/models/components/act/act.py:281-291, loss/misc.py:10-26) in one launch each way -----------
  * a_hat (B, Q, A) fp32 or bf16, actions (B, Q, A) fp32, is_pad (B, Q) bytes (non-zero = padded), mu / logvar (B, D) fp32 or

@@ -66,19 +66,15 @@ struct ColsumArgs {
     long ld[3];  // row stride in elements
 };
 
-// grid (slots, ntensors); a thread owns 4 channels of one tensor; rows_per_pass = 256 / (C/4) rows in flight
+// a thread owns 4 channels of one tensor; rows_per_pass = 256 / (C/4) rows in flight
 template <typename T>
-__global__ __launch_bounds__(kBlock) void pcm_colsum_kernel(long rows, int C, long rows_per_slot, ColsumArgs args,
-                                                            float *__restrict__ partial)
+__device__ __forceinline__ void colsum_body(long rows, int C, long rows_per_slot, const T *__restrict__ g, long ld, int slot, int t,
+                                            int ntensors, float *__restrict__ partial, float *lds)
 {
-    __shared__ float lds[4 * kBlock];
-    const int t = blockIdx.y;
-    const T *__restrict__ g = (const T *)args.g[t];
-    const long ld = args.ld[t];
     const int lpr = C / 4, rpp = kBlock / lpr;
     const int col4 = threadIdx.x % lpr, rsub = threadIdx.x / lpr;
     const bool act = rsub < rpp;
-    const long r0 = (long)blockIdx.x * rows_per_slot;
+    const long r0 = (long)slot * rows_per_slot;
     const long r1 = r0 + rows_per_slot < rows ? r0 + rows_per_slot : rows;
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     if (act)
@@ -96,9 +92,49 @@ __global__ __launch_bounds__(kBlock) void pcm_colsum_kernel(long rows, int C, lo
         for (int u = 0; u < 4; ++u) {
             float acc = 0.f;
             for (int rr = 0; rr < rpp; ++rr) acc += lds[u * kBlock + rr * lpr + col4];
-            partial[((size_t)blockIdx.x * gridDim.y + t) * C + col4 * 4 + u] = acc;
+            partial[((size_t)slot * ntensors + t) * C + col4 * 4 + u] = acc;
         }
     }
+}
+
+// grid (slots, ntensors)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void pcm_colsum_kernel(long rows, int C, long rows_per_slot, ColsumArgs args,
+                                                            float *__restrict__ partial)
+{
+    __shared__ float lds[4 * kBlock];
+    const int t = blockIdx.y;
+    colsum_body<T>(rows, C, rows_per_slot, (const T *)args.g[t], args.ld[t], blockIdx.x, t, gridDim.y, partial, lds);
+}
+
+// the first stages of several column sums in one launch (policy/deferred.py): job table by value, one workgroup = one
+// (job, slot, tensor); same arithmetic as pcm_colsum_kernel
+constexpr int kColsumBatch = 16;
+struct ColsumJob {
+    ColsumArgs a;
+    long rows, rps;
+    float *partial;
+    int C, ntensors, is_bf16, blk0;
+};
+struct ColsumBatch {
+    ColsumJob j[kColsumBatch];
+    int n;
+};
+__global__ __launch_bounds__(kBlock) void pcm_colsum_batch_kernel(ColsumBatch b)
+{
+    __shared__ float lds[4 * kBlock];
+    int i = 0;
+    for (int q = 1; q < b.n; ++q)
+        if ((int)blockIdx.x >= b.j[q].blk0) i = q;
+    const ColsumJob &J = b.j[i];
+    const int local = (int)blockIdx.x - J.blk0;
+    const int slot = local / J.ntensors, t = local - slot * J.ntensors;
+    const void *g = t == 0 ? J.a.g[0] : (t == 1 ? J.a.g[1] : J.a.g[2]);
+    const long ld = t == 0 ? J.a.ld[0] : (t == 1 ? J.a.ld[1] : J.a.ld[2]);
+    if (J.is_bf16)
+        colsum_body<__hip_bfloat16>(J.rows, J.C, J.rps, (const __hip_bfloat16 *)g, ld, slot, t, J.ntensors, J.partial, lds);
+    else
+        colsum_body<float>(J.rows, J.C, J.rps, (const float *)g, ld, slot, t, J.ntensors, J.partial, lds);
 }
 
 template <typename TO>
@@ -345,6 +381,37 @@ extern "C" int pcm_slab_sum_hip(int nslabs, long n, const float *partial, int ou
                            (__hip_bfloat16 *)out);
     else
         hipLaunchKernelGGL(pcm_colsum_reduce_kernel<float>, dim3((VH + 63) / 64), dim3(512), 0, s, nslabs, VH, partial, (float *)out);
+    return PCM_LAUNCH_STATUS();
+}
+
+extern "C" int pcm_colsum_batch_hip(int n, const long *rows, const int *C, const int *ntensors, const int *in_is_bf16,
+                                    const void *const *g, const long *ld, void *const *partial, void *stream)
+{
+    // first stages of n column sums (the arguments of pcm_colsum_hip, as host arrays; g / ld hold 3 entries per job), 16 per
+    // launch; partial[i] receives pcm_colsum_slots(rows[i], C[i]) rows of ntensors[i] * C[i] sums for pcm_reduce_batch_hip
+    if (n < 0 || (n > 0 && (!rows || !C || !ntensors || !in_is_bf16 || !g || !ld || !partial))) return PCM_ERR_BAD_ARG;
+    for (int i = 0; i < n; ++i) {
+        if (rows[i] <= 0 || ntensors[i] < 1 || ntensors[i] > 3 || !partial[i]) return PCM_ERR_BAD_ARG;
+        if (C[i] <= 0 || C[i] % 4 || C[i] > 1024) return PCM_ERR_UNSUPPORTED;
+        for (int t = 0; t < ntensors[i]; ++t)
+            if (!g[3 * i + t]) return PCM_ERR_BAD_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    for (int base = 0; base < n; base += kColsumBatch) {
+        ColsumBatch b;
+        b.n = 0;
+        long blocks = 0;
+        for (int i = base; i < n && b.n < kColsumBatch; ++i) {
+            ColsumJob &J = b.j[b.n++];
+            for (int t = 0; t < 3; ++t) J.a.g[t] = g[3 * i + t], J.a.ld[t] = ld[3 * i + t];
+            const int slots = colsum_slots_for(rows[i], C[i]);
+            J.rows = rows[i], J.rps = (rows[i] + slots - 1) / slots, J.partial = (float *)partial[i];
+            J.C = C[i], J.ntensors = ntensors[i], J.is_bf16 = in_is_bf16[i], J.blk0 = (int)blocks;
+            blocks += (long)slots * ntensors[i];
+        }
+        if (blocks > 0x7FFFFFFF) return PCM_ERR_BAD_ARG;
+        hipLaunchKernelGGL(pcm_colsum_batch_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, b);
+    }
     return PCM_LAUNCH_STATUS();
 }
 

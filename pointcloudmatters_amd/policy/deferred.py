@@ -54,6 +54,7 @@ def end():
     finally:
         _Q = None
         _W = {}
+        _C.clear()
         _SEEN.clear()
         _ARENAS.clear()
         _TAKE_EXPECT.clear()
@@ -263,11 +264,42 @@ def _flush_wgrads():
         STATS["wgrad_batches"] += 1
 
 
+_C = []  # pending first stages of column sums (their closing stages are already in _Q)
+
+
+def push_colsum(rows, C, tensors, lds, in_dtype, partial, keep):
+    """Queue the FIRST stage of a column sum (pcm_colsum_hip's arguments: up to three (pointer, row stride) pairs of one
+    dtype); the caller has pushed its closing stage.  `keep`: tensors that must outlive the flush."""
+    if _Q is None:
+        return False
+    g = [int(p) for p in tensors] + [0] * (3 - len(tensors))
+    ld = [int(v) for v in lds] + [0] * (3 - len(lds))
+    _C.append((int(rows), int(C), len(tensors), int(in_dtype == torch.bfloat16), g, ld, partial.data_ptr(), partial.device, (partial, keep)))
+    return True
+
+
+def _flush_colsums():
+    global _C
+    if not _C:
+        return
+    q, _C = _C, []
+    n = len(q)
+    Lg, I, P = ctypes.c_long * n, ctypes.c_int * n, ctypes.c_void_p * n
+    g = (ctypes.c_void_p * (3 * n))(*[p or None for e in q for p in e[4]])
+    ld = (ctypes.c_long * (3 * n))(*[v for e in q for v in e[5]])
+    with torch.cuda.device(q[0][7]):
+        rc = _lib.load().pcm_colsum_batch_hip(n, Lg(*[e[0] for e in q]), I(*[e[1] for e in q]), I(*[e[2] for e in q]),
+                                              I(*[e[3] for e in q]), g, ld, P(*[e[6] for e in q]), _raw_stream())
+    _lib.check(rc, "pcm_colsum_batch_hip")
+    STATS["launches"] += (n + 15) // 16
+
+
 @torch.no_grad()
 def flush():
     """Launch the pending reductions on the current stream (capturable: the table travels as a kernel argument)."""
     global _Q
     _flush_wgrads()
+    _flush_colsums()
     if not _Q:
         return 0
     q, _Q = _Q, []

@@ -412,9 +412,11 @@ class _SelfAttnInProj(Function):
             partial = torch.empty(slots * 3 * E, dtype=torch.float32, device=dev)
             es = dqk.element_size()
             defer = defer and deferred.push(partial, slots, 3 * E, **({"out_bf16": db} if bdt == bf else {"out_f32": db}))
-            rc = L.pcm_colsum_hip(rows, E, 3, 1, dqk.data_ptr(), 2 * E, dqk.data_ptr() + E * es, 2 * E, dv2.data_ptr(), E,
-                                  partial.data_ptr(), int(bdt == bf), 0 if defer else db.data_ptr(), st)
-            _lib.check(rc, "pcm_colsum_hip")
+            if not (defer and deferred.push_colsum(rows, E, [dqk.data_ptr(), dqk.data_ptr() + E * es, dv2.data_ptr()], [2 * E, 2 * E, E],
+                                                  bf, partial, (dqk, dv2))):
+                rc = L.pcm_colsum_hip(rows, E, 3, 1, dqk.data_ptr(), 2 * E, dqk.data_ptr() + E * es, 2 * E, dv2.data_ptr(), E,
+                                      partial.data_ptr(), int(bdt == bf), 0 if defer else db.data_ptr(), st)
+                _lib.check(rc, "pcm_colsum_hip")
             dpos = None
             if dpos32 is not None:
                 dpos = dpos32.view(shape)

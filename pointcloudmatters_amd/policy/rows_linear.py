@@ -190,6 +190,9 @@ def bias_grad(go, out_dtype, defer=False):
             ptr = [go.data_ptr() + (c0 + j * w) * es if j < nt else 0 for j in range(3)]
             out = db[c0: c0 + nt * w]
             pending = defer and deferred.push(partial, slots, nt * w, **({"out_bf16": out} if out_dtype == torch.bfloat16 else {"out_f32": out}))
+            if pending and deferred.push_colsum(rows, w, ptr[:nt], [C] * nt, go.dtype, partial, go):
+                i += nt  # both stages ride the batch
+                continue
             rc = L.pcm_colsum_hip(rows, w, nt, int(go.dtype == torch.bfloat16), ptr[0], C, ptr[1], C, ptr[2], C, partial.data_ptr(),
                                   int(out_dtype == torch.bfloat16), 0 if pending else db.data_ptr() + c0 * os_, st)
             _lib.check(rc, "pcm_colsum_hip")
