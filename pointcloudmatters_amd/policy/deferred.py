@@ -55,11 +55,20 @@ def end():
         _Q = None
         _W = {}
         _C.clear()
+        _P.clear()
         _SEEN.clear()
         _ARENAS.clear()
         _TAKE_EXPECT.clear()
         _TAKE_EXPECT.update(_TAKEN)
         _TAKEN.clear()
+
+
+def handout(t):
+    """The tensor a producer returns to autograd for a PENDING result `t` that the queues still reference: a fresh alias.
+    AccumulateGrad takes a gradient without copying only when nothing else references that tensor object -- and a view
+    kept in a queue references its base -- otherwise it CLONES it on the spot, i.e. reads the result before it is written.
+    So the queues keep `t` (and views of it), autograd gets this separate alias."""
+    return t.view(t.shape)
 
 
 def targets(*params):
@@ -208,6 +217,8 @@ def push_wgrad(go, x, out_dtype, out=None, tag=None):
     else:  # a caller's slice, or more products than last time: filled by the scatter copy
         dw = out if out is not None else torch.empty(go.shape[1], x.shape[1], dtype=out_dtype, device=go.device)
         grp["extra"].append((i, dw.view(go.shape[1], x.shape[1])))
+        if out is None:
+            dw = handout(dw)
     grp["gos"].append(go)
     grp["xs"].append(x)
     STATS["wgrads"] += 1
@@ -294,6 +305,31 @@ def _flush_colsums():
     STATS["launches"] += (n + 15) // 16
 
 
+_P = []  # pending copies (dst, src): run LAST in a flush, after everything that produces a src
+
+
+def push_copies(pairs):
+    """Queue dst.copy_(src) for every pair (same shape and dtype per pair); all pending copies of a stage are one multi-tensor
+    launch per dtype.  The sources may themselves be pending results of this window."""
+    if _Q is None:
+        return False
+    _P.extend(pairs)
+    return True
+
+
+def _flush_copies():
+    global _P
+    if not _P:
+        return
+    q, _P = _P, []
+    by = {}
+    for d, s_ in q:
+        by.setdefault((d.dtype, s_.dtype, d.device), []).append((d, s_))
+    for grp in by.values():
+        torch._foreach_copy_([d for d, _ in grp], [s_ for _, s_ in grp])
+        STATS["launches"] += 1
+
+
 @torch.no_grad()
 def flush():
     """Launch the pending reductions on the current stream (capturable: the table travels as a kernel argument)."""
@@ -301,6 +337,7 @@ def flush():
     _flush_wgrads()
     _flush_colsums()
     if not _Q:
+        _flush_copies()
         return 0
     q, _Q = _Q, []
     n = len(q)
@@ -312,4 +349,5 @@ def flush():
                                               _raw_stream())
     _lib.check(rc, "pcm_reduce_batch_hip")
     STATS["launches"] += (n + 23) // 24
+    _flush_copies()
     return n

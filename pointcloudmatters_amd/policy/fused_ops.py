@@ -166,7 +166,7 @@ def _drln_backward(dout, s, mean, rstd, gamma, ydtype, p_drop, seed, site, dysum
                                      db16.data_ptr() if db16 is not None else 0, _raw_stream())
     _lib.check(rc, "pcm_drln_backward_hip")
     if dysum_bf16:
-        return dx, dy, sums, db16
+        return dx, dy, sums, (deferred.handout(db16) if defer else db16)
     return dx, dy, sums
 
 
@@ -425,7 +425,8 @@ class _SelfAttnInProj(Function):
             if ctx.sink is not None and dpos is not None:
                 ctx.sink.add(dpos)
                 dpos = None
-        return dx.view(shape), dpos, dw, db
+        # pending results go to autograd as fresh aliases (deferred.handout): the queues hold views of dw / db
+        return dx.view(shape), dpos, deferred.handout(dw), deferred.handout(db)
 
 
 class _AddPosLinear(Function):

@@ -145,7 +145,7 @@ def _weight_grad(go, x, out_dtype, out=None, defer=False, tag=None):
             from . import deferred
 
             if deferred.push(part, s, m * k, **({"out_bf16": dw} if dw.dtype == torch.bfloat16 else {"out_f32": dw})):
-                return dw
+                return dw if out is not None else deferred.handout(dw)
         with torch.cuda.device(go.device):
             rc = _lib.load().pcm_slab_sum_hip(s, m * k, part.data_ptr(), int(dw.dtype == torch.bfloat16), dw.data_ptr(),
                                               _raw_stream())
@@ -176,6 +176,7 @@ def bias_grad(go, out_dtype, defer=False):
     if C % chunk:
         pieces.append((C - C % chunk, C % chunk))
     db = torch.empty(C, dtype=out_dtype, device=go.device)
+    any_pending = False
     es, os_ = go.element_size(), db.element_size()
     st = _raw_stream()
     with torch.cuda.device(go.device):
@@ -190,6 +191,7 @@ def bias_grad(go, out_dtype, defer=False):
             ptr = [go.data_ptr() + (c0 + j * w) * es if j < nt else 0 for j in range(3)]
             out = db[c0: c0 + nt * w]
             pending = defer and deferred.push(partial, slots, nt * w, **({"out_bf16": out} if out_dtype == torch.bfloat16 else {"out_f32": out}))
+            any_pending = any_pending or bool(pending)
             if pending and deferred.push_colsum(rows, w, ptr[:nt], [C] * nt, go.dtype, partial, go):
                 i += nt  # both stages ride the batch
                 continue
@@ -197,7 +199,7 @@ def bias_grad(go, out_dtype, defer=False):
                                   int(out_dtype == torch.bfloat16), 0 if pending else db.data_ptr() + c0 * os_, st)
             _lib.check(rc, "pcm_colsum_hip")
             i += nt
-    return db
+    return deferred.handout(db) if any_pending else db
 
 
 class _LinearRows(Function):

@@ -200,6 +200,76 @@ class _SharedUnbind(torch.autograd.Function):
         return torch.stack([g if g is not None else torch.zeros_like(ref) for g in grads], dim=-2).flatten(-2), None, None
 
 
+class _SplitPacked(torch.autograd.Function):
+    """w (3E, ...) -> its three row blocks, like torch.split(w, [E, E, E]): views forward; backward assembles the packed
+    gradient.  Inside a deferral window (policy/deferred.py) the three block copies of every layer's weight and bias join ONE
+    multi-tensor copy at the end of the backward stage instead of a cat launch per tensor (14 in ACT's decoder)."""
+
+    @staticmethod
+    def forward(ctx, w):
+        from . import deferred
+
+        e = w.shape[0] // 3
+        ctx.defer = deferred.targets(w)
+        ctx.meta = (w.shape, w.dtype, w.device, e)
+        return w[:e], w[e: 2 * e], w[2 * e:]
+
+    @staticmethod
+    def backward(ctx, *gs):
+        from . import deferred
+
+        shape, dtype, dev, e = ctx.meta
+        if all(g is None for g in gs):
+            return None
+        gs = [g if g is not None else torch.zeros((e,) + tuple(shape[1:]), dtype=dtype, device=dev) for g in gs]
+        if all(g.dtype == dtype for g in gs) and deferred.clear(*ctx.defer):
+            out = torch.empty(shape, dtype=dtype, device=dev)
+            if deferred.push_copies([(out[i * e: (i + 1) * e], g) for i, g in enumerate(gs)]):
+                return deferred.handout(out)
+        return torch.cat([g.to(dtype) for g in gs], dim=0)
+
+
+class _PackRows(torch.autograd.Function):
+    """cat(group, dim=0) for several groups of equally shaped tensors at once: ONE multi-tensor copy forward (the decoder's 7
+    key weights, 7 value weights and their biases: four cat launches otherwise); backward hands out views."""
+
+    @staticmethod
+    def forward(ctx, sizes, *ts):
+        outs, pairs, k = [], [], 0
+        for n in sizes:
+            grp = ts[k: k + n]
+            k += n
+            rows = grp[0].shape[0]
+            out = torch.empty((rows * n,) + tuple(grp[0].shape[1:]), dtype=grp[0].dtype, device=grp[0].device)
+            pairs += [(out[i * rows: (i + 1) * rows], t) for i, t in enumerate(grp)]
+            outs.append(out)
+        by = {}
+        for d, s_ in pairs:
+            by.setdefault(d.dtype, []).append((d, s_))
+        for grp in by.values():
+            torch._foreach_copy_([d for d, _ in grp], [s_ for _, s_ in grp])
+        ctx.sizes = sizes
+        ctx.rows = [t.shape[0] for t in ts]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        res, k = [None], 0
+        for n, g in zip(ctx.sizes, gs):
+            for i in range(n):
+                r = ctx.rows[k]
+                res.append(None if g is None else g[i * r: (i + 1) * r])
+                k += 1
+        return tuple(res)
+
+
+def pack_rows(*groups):
+    """[cat(g, dim=0) for g in groups] with one copy launch per dtype (every group: tensors of one shape and dtype)."""
+    if not groups[0][0].is_cuda or any(t.shape != g[0].shape or t.dtype != g[0].dtype for g in groups for t in g):
+        return [torch.cat(list(g), dim=0) for g in groups]
+    return list(_PackRows.apply(tuple(len(g) for g in groups), *[t for g in groups for t in g]))
+
+
 def shared_unbind(y, n):
     """``y.unflatten(-1, (n, E)).unbind(-2)`` for (B, S, n*E) activations whose n consumers may write their gradients straight
     into one shared buffer (GradArena): each returned tensor carries ``_pcm_grad_slot = (arena, l)``."""
@@ -345,12 +415,17 @@ class TransformerDecoder(nn.Module):
         wq, wk, wv, bq, bk, bv = [], [], [], [], [], []
         for layer in self.layers:
             mha = layer.multihead_attn
-            w_q, w_k, w_v = torch.split(mha.in_proj_weight, [e, e, e], dim=0)  # ONE split per weight: its
-            b_q, b_k, b_v = torch.split(mha.in_proj_bias, [e, e, e], dim=0)    # backward is a single cat
+            if mha.in_proj_weight.is_cuda and torch.is_grad_enabled():
+                w_q, w_k, w_v = _SplitPacked.apply(mha.in_proj_weight)  # ONE split per weight; the packed gradients of all
+                b_q, b_k, b_v = _SplitPacked.apply(mha.in_proj_bias)    # layers are assembled by one copy launch
+            else:
+                w_q, w_k, w_v = torch.split(mha.in_proj_weight, [e, e, e], dim=0)  # backward: a single cat
+                b_q, b_k, b_v = torch.split(mha.in_proj_bias, [e, e, e], dim=0)
             wq.append(w_q), wk.append(w_k), wv.append(w_v), bq.append(b_q), bk.append(b_k), bv.append(b_v)
         n = len(self.layers)
-        k_all = shared_unbind(linear_rows(memory_pos, torch.cat(wk, dim=0), torch.cat(bk, dim=0)), n)
-        v_all = shared_unbind(linear_rows(memory, torch.cat(wv, dim=0), torch.cat(bv, dim=0)), n)
+        wk_all, bk_all, wv_all, bv_all = pack_rows(wk, bk, wv, bv)
+        k_all = shared_unbind(linear_rows(memory_pos, wk_all, bk_all), n)
+        v_all = shared_unbind(linear_rows(memory, wv_all, bv_all), n)
         return list(zip(k_all, v_all, wq, bq))
 
     # What a caller that reads only output [0] (ACT, act.py:270) may ask for:

@@ -109,3 +109,33 @@ def test_bias_grad_column_sums(rows, c, dt, odt):
     finally:
         deferred.end()
     assert torch.equal(pending, got)
+
+
+def test_pending_results_reach_leaf_parameters_intact():
+    """A result that is still pending in policy/deferred.py's window must not be COPIED by AccumulateGrad before it is
+    written (it clones a gradient that anything else references -- e.g. a queue's view of it): fp32 leaf parameters,
+    4120 rows (split-K weight gradient + two-stage bias sum, both with deferred closing stages)."""
+    from pointcloudmatters_amd.policy import deferred
+    from pointcloudmatters_amd.policy import rows_linear
+    from pointcloudmatters_amd.policy.rows_linear import linear_rows
+
+    torch.manual_seed(0)
+    lin = nn.Linear(512, 256).to(DEV)
+    x = torch.randn(4120, 512, device=DEV)
+    go = torch.randn(4120, 256, device=DEV)
+    old = rows_linear.DEFER_MAX_BYTES
+    rows_linear.DEFER_MAX_BYTES = 1 << 30  # also leave the split-K closing sum pending
+    try:
+        assert deferred.begin()
+        try:
+            y = linear_rows(x, lin.weight, lin.bias)
+            with deferred.backward_phase():
+                y.backward(go)
+            assert deferred.flush() >= 2
+        finally:
+            deferred.end()
+    finally:
+        rows_linear.DEFER_MAX_BYTES = old
+    gw, gb = lin.weight.grad.clone(), lin.bias.grad.clone()
+    torch.testing.assert_close(gb.double(), go.double().sum(0), rtol=1e-5, atol=1e-3)
+    torch.testing.assert_close(gw.double(), go.double().t() @ x.double(), rtol=1e-4, atol=1e-2)
