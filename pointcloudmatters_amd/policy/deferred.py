@@ -77,7 +77,7 @@ def targets(*params):
     from .rows_linear import goes_to_optimizer
 
     ps = [p for p in params if p is not None]
-    return all(goes_to_optimizer(p) for p in ps), [p for p in ps if p.grad_fn is None and p.requires_grad]
+    return all(goes_to_optimizer(p) for p in ps), [p for p in ps if p.is_leaf and p.requires_grad]
 
 
 def clear(ok, leaves):

@@ -85,7 +85,9 @@ def goes_to_optimizer(weight):
     """True when the gradient of `weight` is handed to the optimizer without passing through another kernel: a leaf
     parameter, or the bf16 mirror of one (bc/trainer.py _ShadowParam)."""
     fn = weight.grad_fn
-    return fn is None or type(fn).__name__ == "_ShadowParamBackward"
+    # _pcm_defer_ok: set by nodes that only pass the gradient on (views) or copy it inside the deferral window themselves
+    # (transformer.split_packed / pack_rows)
+    return fn is None or type(fn).__name__ == "_ShadowParamBackward" or bool(getattr(weight, "_pcm_defer_ok", False))
 
 
 def weight_grad(go, x, out_dtype, out=None, side=False, defer=False, tag=None):

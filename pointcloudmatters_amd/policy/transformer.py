@@ -263,11 +263,29 @@ class _PackRows(torch.autograd.Function):
         return tuple(res)
 
 
+def split_packed(w):
+    """The three row blocks of a packed (3E, ...) parameter; their gradients may stay pending inside a deferral window (the
+    node copies them into the packed gradient at the end of the stage, after everything that produces them)."""
+    from .rows_linear import goes_to_optimizer
+
+    parts = _SplitPacked.apply(w)
+    if goes_to_optimizer(w):
+        for p in parts:
+            p._pcm_defer_ok = True
+    return parts
+
+
 def pack_rows(*groups):
     """[cat(g, dim=0) for g in groups] with one copy launch per dtype (every group: tensors of one shape and dtype)."""
+    from .rows_linear import goes_to_optimizer
+
     if not groups[0][0].is_cuda or any(t.shape != g[0].shape or t.dtype != g[0].dtype for g in groups for t in g):
         return [torch.cat(list(g), dim=0) for g in groups]
-    return list(_PackRows.apply(tuple(len(g) for g in groups), *[t for g in groups for t in g]))
+    outs = list(_PackRows.apply(tuple(len(g) for g in groups), *[t for g in groups for t in g]))
+    for o, g in zip(outs, groups):
+        if all(goes_to_optimizer(t) for t in g):
+            o._pcm_defer_ok = True  # backward hands out views of the gradient: nothing reads it here
+    return outs
 
 
 def shared_unbind(y, n):
@@ -416,8 +434,8 @@ class TransformerDecoder(nn.Module):
         for layer in self.layers:
             mha = layer.multihead_attn
             if mha.in_proj_weight.is_cuda and torch.is_grad_enabled():
-                w_q, w_k, w_v = _SplitPacked.apply(mha.in_proj_weight)  # ONE split per weight; the packed gradients of all
-                b_q, b_k, b_v = _SplitPacked.apply(mha.in_proj_bias)    # layers are assembled by one copy launch
+                w_q, w_k, w_v = split_packed(mha.in_proj_weight)  # ONE split per weight; the packed gradients of all
+                b_q, b_k, b_v = split_packed(mha.in_proj_bias)    # layers are assembled by one copy launch
             else:
                 w_q, w_k, w_v = torch.split(mha.in_proj_weight, [e, e, e], dim=0)  # backward: a single cat
                 b_q, b_k, b_v = torch.split(mha.in_proj_bias, [e, e, e], dim=0)
