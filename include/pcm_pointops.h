@@ -323,6 +323,13 @@ int pcm_drln_backward_hip(long R, int E, int y_is_bf16, const float *dout, const
                           const float *mean, const float *rstd, const float *gamma, float p_drop,
                           const long *seed, unsigned site, float *dx, void *dy, float *partial,
                           float *dgamma_dbeta, void *dysum_bf16, void *stream);
+/* same with the output gradient given as TWO addends (dout2 nullable): the layer output had two consumers in the graph (the
+ * decoder's norm1 output feeds the cross-attention query AND the residual, transformer.py:330-338) and their gradients
+ * are summed while loading instead of by the autograd engine's add launch */
+int pcm_drln_backward2_hip(long R, int E, int y_is_bf16, const float *dout, const float *dout2, const float *s,
+                           const float *mean, const float *rstd, const float *gamma, float p_drop, const long *seed,
+                           unsigned site, float *dx, void *dy, float *partial, float *dgamma_dbeta, void *dysum_bf16,
+                           void *stream);
 
 /* ---- fused feed-forward sub-layer  out = LayerNorm(x + dropout(W2 dropout(relu(W1 x + b1)) + b2)) ------------
  * replaces linear1 -> relu -> dropout -> linear2 -> dropout -> add -> norm of every transformer layer
@@ -343,6 +350,12 @@ int pcm_ffn_ln_backward_hip(long R, int E, int F, const float *dout, const float
                             const float *W2, const float *gamma, float p_hidden, float p_out,
                             const long *seed, unsigned site_b, float *dx, float *dy, float *dh,
                             float *partial, float *sums, void *stream);
+/* same, output gradient as two addends (dout2 nullable), see pcm_drln_backward2_hip (here: a decoder layer's output feeds
+ * the next layer AND the stack of intermediate outputs, transformer.py:185-199) */
+int pcm_ffn_ln_backward2_hip(long R, int E, int F, const float *dout, const float *dout2, const float *x, const float *s,
+                             const float *mean, const float *rstd, const float *hd, const float *W1, const float *W2,
+                             const float *gamma, float p_hidden, float p_out, const long *seed, unsigned site_b,
+                             float *dx, float *dy, float *dh, float *partial, float *sums, void *stream);
 
 /* ---- Diffusion-Policy sampler: one fused DDPM reverse step x_t -> x_{t-1} ------------------------------
  * replaces diffusers' DDPMScheduler.step + the conditioning re-imposition inside `conditional_sample`

@@ -85,7 +85,8 @@ __global__ __launch_bounds__(kBlock) void pcm_drln_fwd_kernel(long R, const floa
 
 // partial layout [block][2][E] = { dgamma, dbeta }
 template <typename T, int NCH>
-__global__ __launch_bounds__(kBlock) void pcm_drln_bwd_kernel(long R, const float *__restrict__ dout, const float *__restrict__ s,
+__global__ __launch_bounds__(kBlock) void pcm_drln_bwd_kernel(long R, const float *__restrict__ dout, const float *__restrict__ dout2,
+                                                              const float *__restrict__ s,
                                                               const float *__restrict__ mean, const float *__restrict__ rstd,
                                                               const float *__restrict__ gamma, float p_drop,
                                                               const long *__restrict__ seed_ptr, unsigned site,
@@ -115,6 +116,12 @@ __global__ __launch_bounds__(kBlock) void pcm_drln_bwd_kernel(long R, const floa
             const long e0 = r * E + c * 256 + lane * 4;
             float dv[4], sv[4];
             load4<float>(dout + e0, dv);
+            if (dout2 != nullptr) {  // the output had two consumers: their gradients are summed here, not by an add launch
+                float d2[4];
+                load4<float>(dout2 + e0, d2);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) dv[v] += d2[v];
+            }
             load4<float>(s + e0, sv);
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
@@ -215,16 +222,30 @@ extern "C" int pcm_drln_forward_hip(long R, int E, int y_is_bf16, const float *x
     return PCM_LAUNCH_STATUS();
 }
 
+extern "C" int pcm_drln_backward2_hip(long R, int E, int y_is_bf16, const float *dout, const float *dout2, const float *s,
+                                      const float *mean, const float *rstd, const float *gamma, float p_drop, const long *seed,
+                                      unsigned site, float *dx, void *dy, float *partial, float *dgamma_dbeta, void *dysum_bf16,
+                                      void *stream);
+
 extern "C" int pcm_drln_backward_hip(long R, int E, int y_is_bf16, const float *dout, const float *s, const float *mean,
                                      const float *rstd, const float *gamma, float p_drop, const long *seed, unsigned site,
                                      float *dx, void *dy, float *partial, float *dgamma_dbeta, void *dysum_bf16, void *stream)
+{
+    return pcm_drln_backward2_hip(R, E, y_is_bf16, dout, nullptr, s, mean, rstd, gamma, p_drop, seed, site, dx, dy, partial,
+                                  dgamma_dbeta, dysum_bf16, stream);
+}
+
+extern "C" int pcm_drln_backward2_hip(long R, int E, int y_is_bf16, const float *dout, const float *dout2, const float *s,
+                                      const float *mean, const float *rstd, const float *gamma, float p_drop, const long *seed,
+                                      unsigned site, float *dx, void *dy, float *partial, float *dgamma_dbeta, void *dysum_bf16,
+                                      void *stream)
 {
     if (R <= 0) return R == 0 ? PCM_OK : PCM_ERR_BAD_ARG;
     if (E % 256 != 0 || E > 1024 || E <= 0) return PCM_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const int grid = drln_grid(R);
 #define PCM_B(T, N)                                                                                                         \
-    hipLaunchKernelGGL((pcm_drln_bwd_kernel<T, N>), dim3(grid), dim3(kBlock), 0, st, R, dout, s, mean, rstd, gamma, p_drop,  \
+    hipLaunchKernelGGL((pcm_drln_bwd_kernel<T, N>), dim3(grid), dim3(kBlock), 0, st, R, dout, dout2, s, mean, rstd, gamma, p_drop,  \
                        seed, site, dx, (T *)dy, partial)
     const int n = E / 256;
     if (y_is_bf16) {

@@ -185,7 +185,8 @@ __global__ __launch_bounds__(kThreads) void pcm_ffn_ln_fwd_kernel(long R, const 
 
 // partial layout per block: [ dgamma(E) | dbeta(E) | db2(E) | db1(F) ]
 template <int E, int F>
-__global__ __launch_bounds__(kThreads) void pcm_ffn_ln_bwd_kernel(long R, const float *__restrict__ dout, const float *__restrict__ x,
+__global__ __launch_bounds__(kThreads) void pcm_ffn_ln_bwd_kernel(long R, const float *__restrict__ dout, const float *__restrict__ dout2,
+                                                                  const float *__restrict__ x,
                                                                   const float *__restrict__ s, const float *__restrict__ mean,
                                                                   const float *__restrict__ rstd, const float *__restrict__ hd,
                                                                   const float *__restrict__ W1, const float *__restrict__ W2,
@@ -220,6 +221,12 @@ __global__ __launch_bounds__(kThreads) void pcm_ffn_ln_bwd_kernel(long R, const 
         for (int t = 0; t < PER; t += 4) {
             float dv[4], sv[4];
             load4<float>(dout + r * E + col_of(lane, t), dv);
+            if (dout2 != nullptr) {  // second consumer's gradient, summed here instead of by an add launch
+                float d2[4];
+                load4<float>(dout2 + r * E + col_of(lane, t), d2);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) dv[u] += d2[u];
+            }
             load4<float>(s + r * E + col_of(lane, t), sv);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -359,10 +366,24 @@ extern "C" int pcm_ffn_ln_forward_hip(long R, int E, int F, const float *x, cons
     return PCM_LAUNCH_STATUS();
 }
 
+extern "C" int pcm_ffn_ln_backward2_hip(long R, int E, int F, const float *dout, const float *dout2, const float *x, const float *s,
+                                        const float *mean, const float *rstd, const float *hd, const float *W1, const float *W2,
+                                        const float *gamma, float p_hidden, float p_out, const long *seed, unsigned site_b,
+                                        float *dx, float *dy, float *dh, float *partial, float *sums, void *stream);
+
 extern "C" int pcm_ffn_ln_backward_hip(long R, int E, int F, const float *dout, const float *x, const float *s, const float *mean,
                                        const float *rstd, const float *hd, const float *W1, const float *W2, const float *gamma,
                                        float p_hidden, float p_out, const long *seed, unsigned site_b, float *dx, float *dy,
                                        float *dh, float *partial, float *sums, void *stream)
+{
+    return pcm_ffn_ln_backward2_hip(R, E, F, dout, nullptr, x, s, mean, rstd, hd, W1, W2, gamma, p_hidden, p_out, seed, site_b, dx,
+                                    dy, dh, partial, sums, stream);
+}
+
+extern "C" int pcm_ffn_ln_backward2_hip(long R, int E, int F, const float *dout, const float *dout2, const float *x, const float *s,
+                                        const float *mean, const float *rstd, const float *hd, const float *W1, const float *W2,
+                                        const float *gamma, float p_hidden, float p_out, const long *seed, unsigned site_b,
+                                        float *dx, float *dy, float *dh, float *partial, float *sums, void *stream)
 {
     if (R <= 0) return R == 0 ? PCM_OK : PCM_ERR_BAD_ARG;
     if (!pcm_ffn_ln_supported(E, F)) return PCM_ERR_UNSUPPORTED;
@@ -374,7 +395,7 @@ extern "C" int pcm_ffn_ln_backward_hip(long R, int E, int F, const float *dout, 
         auto k = pcm_ffn_ln_bwd_kernel<EE, 32>;                                                                              \
         int rc = set_lds(k, lds);                                                                                            \
         if (rc) return rc;                                                                                                   \
-        hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), lds, st, R, dout, x, s, mean, rstd, hd, W1, W2, gamma, p_hidden,   \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), lds, st, R, dout, dout2, x, s, mean, rstd, hd, W1, W2, gamma, p_hidden,   \
                            p_out, seed, site_b, dx, dy, dh, partial);                                                        \
     } while (0)
     if (E == 512) PCM_FB(512); else PCM_FB(256);

@@ -143,7 +143,22 @@ def _drln_forward(x2, y2, gamma, beta, eps, p_drop, seed, site):
     return out, s, mean, rstd
 
 
-def _drln_backward(dout, s, mean, rstd, gamma, ydtype, p_drop, seed, site, dysum_bf16=False, defer=False):
+def _f32_rows(g, R, E):
+    g = g.reshape(R, E)
+    return g if g.dtype == torch.float32 and g.is_contiguous() else g.float().contiguous()
+
+
+def _two_addends(douts, R, E):
+    """The gradients of a node's aliased outputs -> (dout, dout2 or None): two are summed inside the backward kernel."""
+    gs = [_f32_rows(g, R, E) for g in douts if g is not None]
+    if not gs:
+        return None, None
+    while len(gs) > 2:
+        gs = [gs[0] + gs[1]] + gs[2:]
+    return gs[0], (gs[1] if len(gs) > 1 else None)
+
+
+def _drln_backward(dout, s, mean, rstd, gamma, ydtype, p_drop, seed, site, dysum_bf16=False, defer=False, dout2=None):
     """-> dx (R,E) fp32, dy (R,E) in ydtype, sums (3,E) fp32 = dgamma | dbeta | column sums of dy (+ those sums in bf16).
     defer: leave the closing reduction of `sums` to policy/deferred.flush (the caller checked deferred.clear)."""
     L = _lib.load()
@@ -160,11 +175,12 @@ def _drln_backward(dout, s, mean, rstd, gamma, ydtype, p_drop, seed, site, dysum
         sums = torch.empty(3, E, dtype=torch.float32, device=dev)
         db16 = torch.empty(E, dtype=torch.bfloat16, device=dev) if dysum_bf16 else None
         defer = defer and R > 0 and deferred.push(partial, blocks, 3 * E, out_f32=sums, out_bf16=db16, bf16_from=2 * E)
-        rc = L.pcm_drln_backward_hip(R, E, 1 if ydtype == torch.bfloat16 else 0, d2.data_ptr(), s.data_ptr(), mean.data_ptr(),
-                                     rstd.data_ptr(), gamma.data_ptr(), p_drop, seed.data_ptr() if seed is not None else 0, site,
-                                     dx.data_ptr(), dy.data_ptr(), partial.data_ptr(), 0 if defer else sums.data_ptr(),
-                                     db16.data_ptr() if db16 is not None else 0, _raw_stream())
-    _lib.check(rc, "pcm_drln_backward_hip")
+        rc = L.pcm_drln_backward2_hip(R, E, 1 if ydtype == torch.bfloat16 else 0, d2.data_ptr(),
+                                      dout2.data_ptr() if dout2 is not None else 0, s.data_ptr(), mean.data_ptr(),
+                                      rstd.data_ptr(), gamma.data_ptr(), p_drop, seed.data_ptr() if seed is not None else 0, site,
+                                      dx.data_ptr(), dy.data_ptr(), partial.data_ptr(), 0 if defer else sums.data_ptr(),
+                                      db16.data_ptr() if db16 is not None else 0, _raw_stream())
+    _lib.check(rc, "pcm_drln_backward2_hip")
     if dysum_bf16:
         return dx, dy, sums, (deferred.handout(db16) if defer else db16)
     return dx, dy, sums
@@ -177,7 +193,7 @@ class _ProjDRLN(Function):
     split-K product for dW (rows_linear.weight_grad)."""
 
     @staticmethod
-    def forward(ctx, a, weight, bias, x, gamma, beta, eps, p_drop, seed, site):
+    def forward(ctx, a, weight, bias, x, gamma, beta, eps, p_drop, seed, site, n_out=1):
         shape = x.shape
         E = shape[-1]
         if torch.is_autocast_enabled("cuda"):
@@ -197,17 +213,25 @@ class _ProjDRLN(Function):
         ctx.side_ok = _goes_to_optimizer(weight)
         ok, leaves = deferred.targets(weight, bias, gamma, beta)
         ctx.defer = (ok and bias.dtype in (torch.bfloat16, torch.float32), leaves)
-        return out.view(shape)
+        if n_out == 1:
+            return out.view(shape)
+        # one alias per consumer: the engine hands their gradients over separately and the backward kernel sums them while
+        # loading, instead of an add launch in between
+        ctx.set_materialize_grads(False)
+        return tuple(out.view(shape) for _ in range(n_out))
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, *douts):
         from .rows_linear import weight_grad
 
         a2, wc, s, mean, rstd, gamma = ctx.saved_tensors
         shape, ashape, adt, wdt, bdt, ydt, p_drop, seed, site = ctx.meta
         want16 = bdt == torch.bfloat16
+        dout, dout2 = _two_addends(douts, *s.shape)
+        if dout is None:
+            return (None,) * 11
         defer = deferred.clear(*ctx.defer)
-        res = _drln_backward(dout, s, mean, rstd, gamma, ydt, p_drop, seed, site, dysum_bf16=want16, defer=defer)
+        res = _drln_backward(dout, s, mean, rstd, gamma, ydt, p_drop, seed, site, dysum_bf16=want16, defer=defer, dout2=dout2)
         dx, dy, sums = res[:3]
         with torch.autocast("cuda", enabled=False):
             da = (dy @ wc).view(ashape)
@@ -215,15 +239,16 @@ class _ProjDRLN(Function):
                 da = da.to(adt)
             dw = weight_grad(dy, a2, wdt, side=ctx.side_ok, defer=defer, tag="proj_drln")
             db = res[3] if want16 else sums[2].to(bdt)
-        return da, dw, db, dx.view(shape), sums[0], sums[1], None, None, None, None
+        return da, dw, db, dx.view(shape), sums[0], sums[1], None, None, None, None, None
 
 
-def proj_drln(a, linear, x, norm, dropout):
-    """norm(x + dropout(linear(a))); the caller checked ``drln_supported(x, <linear output>, norm)``."""
+def proj_drln(a, linear, x, norm, dropout, n_out=1):
+    """norm(x + dropout(linear(a))); the caller checked ``drln_supported(x, <linear output>, norm)``.  n_out > 1: that many
+    aliases of the result, one per consumer (their gradients are summed inside the backward kernel)."""
     p = dropout.p if (dropout is not None and dropout.training) else 0.0
     ctx = _ACTIVE
     return _ProjDRLN.apply(a, linear.weight, linear.bias, x, norm.weight, norm.bias, norm.eps, p,
-                           ctx.seed if p > 0 else None, ctx.next_site())
+                           ctx.seed if p > 0 else None, ctx.next_site(), n_out)
 
 
 def drln_supported(x, y, norm, y_dtype=None):
@@ -246,7 +271,7 @@ class _FFNLN(Function):
     """out = norm(x + dropout_out(linear2(dropout_hidden(relu(linear1(x)))))) -- csrc/ffn.hip."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, eps, p_hidden, p_out, seed, site_a, site_b):
+    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, eps, p_hidden, p_out, seed, site_a, site_b, n_out=1):
         L = _lib.load()
         shape = x.shape
         E, Fh = shape[-1], w1.shape[0]
@@ -269,10 +294,13 @@ class _FFNLN(Function):
         ctx.meta = (shape, float(p_hidden), float(p_out), seed, int(site_b))
         ctx.side_ok = _goes_to_optimizer(w1) and _goes_to_optimizer(w2)
         ctx.defer = deferred.targets(w1, b1, w2, b2, gamma, beta)
-        return out.view(shape)
+        if n_out == 1:
+            return out.view(shape)
+        ctx.set_materialize_grads(False)  # one alias per consumer, see _ProjDRLN.forward
+        return tuple(out.view(shape) for _ in range(n_out))
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, *douts):
         L = _lib.load()
         x2, w1, w2, gamma, hd, s, mean, rstd = ctx.saved_tensors
         shape, p_hidden, p_out, seed, site_b = ctx.meta
@@ -280,9 +308,9 @@ class _FFNLN(Function):
         Fh = w1.shape[0]
         dev = x2.device
         f32 = dict(dtype=torch.float32, device=dev)
-        d2 = dout.reshape(R, E)
-        if d2.dtype != torch.float32 or not d2.is_contiguous():
-            d2 = d2.float().contiguous()
+        d2, d2b = _two_addends(douts, R, E)
+        if d2 is None:
+            return (None,) * 14
         with torch.cuda.device(dev):
             dx, dy, dh = torch.empty(R, E, **f32), deferred.take((R, E), torch.float32, dev, "ffn.dy"), deferred.take((R, Fh), torch.float32, dev, "ffn.dh")
             pw = 3 * E + Fh
@@ -291,19 +319,20 @@ class _FFNLN(Function):
             sums = torch.empty(pw, **f32)
             defer = deferred.clear(*ctx.defer)
             defer_sums = defer and R > 0 and deferred.push(partial, blocks, pw, out_f32=sums)
-            rc = L.pcm_ffn_ln_backward_hip(R, E, Fh, d2.data_ptr(), x2.data_ptr(), s.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                           hd.data_ptr(), w1.data_ptr(), w2.data_ptr(), gamma.data_ptr(), p_hidden, p_out,
-                                           seed.data_ptr() if seed is not None else 0, site_b, dx.data_ptr(), dy.data_ptr(),
-                                           dh.data_ptr(), partial.data_ptr(), 0 if defer_sums else sums.data_ptr(),
-                                           _raw_stream())
-            _lib.check(rc, "pcm_ffn_ln_backward_hip")
+            rc = L.pcm_ffn_ln_backward2_hip(R, E, Fh, d2.data_ptr(), d2b.data_ptr() if d2b is not None else 0, x2.data_ptr(),
+                                            s.data_ptr(), mean.data_ptr(), rstd.data_ptr(), hd.data_ptr(), w1.data_ptr(),
+                                            w2.data_ptr(), gamma.data_ptr(), p_hidden, p_out,
+                                            seed.data_ptr() if seed is not None else 0, site_b, dx.data_ptr(), dy.data_ptr(),
+                                            dh.data_ptr(), partial.data_ptr(), 0 if defer_sums else sums.data_ptr(),
+                                            _raw_stream())
+            _lib.check(rc, "pcm_ffn_ln_backward2_hip")
             from .rows_linear import weight_grad
 
             with torch.autocast(device_type="cuda", enabled=False):
                 dw2 = weight_grad(dy, hd, torch.float32, side=ctx.side_ok, defer=defer, tag="ffn.w2")  # (E, F)   split-K over the rows when there are thousands
                 dw1 = weight_grad(dh, x2, torch.float32, side=ctx.side_ok, defer=defer, tag="ffn.w1")  # (F, E)
         dgamma, dbeta, db2, db1 = sums[:E], sums[E : 2 * E], sums[2 * E : 3 * E], sums[3 * E :]
-        return dx.view(shape), dw1, db1, dw2, db2, dgamma, dbeta, None, None, None, None, None, None
+        return dx.view(shape), dw1, db1, dw2, db2, dgamma, dbeta, None, None, None, None, None, None, None
 
 
 def ffn_ln_supported(x, linear1, linear2, norm):
@@ -315,12 +344,12 @@ def ffn_ln_supported(x, linear1, linear2, norm):
     return bool(_lib.load().pcm_ffn_ln_supported(int(x.shape[-1]), int(linear1.weight.shape[0])))
 
 
-def ffn_ln(x, linear1, linear2, norm, dropout_hidden, dropout_out):
+def ffn_ln(x, linear1, linear2, norm, dropout_hidden, dropout_out, n_out=1):
     pa = dropout_hidden.p if dropout_hidden.training else 0.0
     pb = dropout_out.p if dropout_out.training else 0.0
     ctx = _ACTIVE
     return _FFNLN.apply(x, linear1.weight, linear1.bias, linear2.weight, linear2.bias, norm.weight, norm.bias, norm.eps, pa, pb,
-                        ctx.seed if (pa > 0 or pb > 0) else None, ctx.next_site(), ctx.next_site())
+                        ctx.seed if (pa > 0 or pb > 0) else None, ctx.next_site(), ctx.next_site(), n_out)
 
 
 class _SelfAttnInProj(Function):

@@ -45,11 +45,25 @@ def _add_norm(norm: nn.Module, dropout: nn.Module, x: Tensor, y: Tensor) -> Tens
     return norm(_residual(x, dropout(y)))
 
 
-def _attn_add_norm(norm: nn.Module, dropout: nn.Module, x: Tensor, mha: nn.MultiheadAttention, *args, **kwargs) -> Tensor:
+def _attn_add_norm(norm: nn.Module, dropout: nn.Module, x: Tensor, mha: nn.MultiheadAttention, *args, n_out: int = 1, **kwargs):
     """norm(x + dropout(mha(...))): with a FusedContext active the output projection, the residual add and the norm
-    are one autograd node (fused_ops.proj_drln); otherwise the plain chain."""
+    are one autograd node (fused_ops.proj_drln); otherwise the plain chain.  n_out = 2: the result twice, for two consumers --
+    the fused node hands out two aliases and sums their gradients inside its backward kernel (no add launch)."""
     from . import fused_ops
 
+    if n_out > 1:
+        ctx_on = fused_ops.current() is not None and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
+        if ctx_on:
+            aux = {}
+            a = attention(mha, *args, project=False, aux=aux, **kwargs)
+            x = aux.get("residual", x)
+            ydt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else a.dtype
+            if fused_ops.drln_supported(x, None, norm, y_dtype=ydt) and mha.out_proj.bias is not None:
+                return fused_ops.proj_drln(a, mha.out_proj, x, norm, dropout, n_out=n_out)
+            out = _add_norm(norm, dropout, x, linear_rows(a, mha.out_proj.weight, mha.out_proj.bias))
+        else:
+            out = _add_norm(norm, dropout, x, attention(mha, *args, **kwargs))
+        return (out,) * n_out
     ctx_on = fused_ops.current() is not None and x.is_cuda and x.dtype == torch.float32
     if ctx_on:
         aux = {}
@@ -62,14 +76,17 @@ def _attn_add_norm(norm: nn.Module, dropout: nn.Module, x: Tensor, mha: nn.Multi
     return _add_norm(norm, dropout, x, attention(mha, *args, **kwargs))
 
 
-def _ffn_norm(layer, norm: nn.Module, dropout_out: nn.Module, x: Tensor) -> Tensor:
+def _ffn_norm(layer, norm: nn.Module, dropout_out: nn.Module, x: Tensor, n_out: int = 1):
     """norm(x + dropout_out(linear2(dropout(act(linear1(x)))))): one fused HIP kernel each way for the shipped
-    relu / dim_feedforward = 32 layers when a FusedContext is active, framework ops otherwise."""
+    relu / dim_feedforward = 32 layers when a FusedContext is active, framework ops otherwise.  n_out: see _attn_add_norm."""
     from . import fused_ops
 
     if layer.activation is F.relu and fused_ops.ffn_ln_supported(x, layer.linear1, layer.linear2, norm):
-        return fused_ops.ffn_ln(x, layer.linear1, layer.linear2, norm, layer.dropout, dropout_out)
-    return _add_norm(norm, dropout_out, x, layer._ffn(x))
+        if n_out > 1 and not torch.is_grad_enabled():
+            return (fused_ops.ffn_ln(x, layer.linear1, layer.linear2, norm, layer.dropout, dropout_out),) * n_out
+        return fused_ops.ffn_ln(x, layer.linear1, layer.linear2, norm, layer.dropout, dropout_out, n_out=n_out)
+    out = _add_norm(norm, dropout_out, x, layer._ffn(x))
+    return out if n_out == 1 else (out,) * n_out
 
 
 def attention(
@@ -369,7 +386,7 @@ class TransformerDecoderLayer(nn.Module):
     def _ffn(self, x):
         return self.linear2(self.dropout(self.activation(self.linear1(x))))
 
-    def forward(self, tgt, memory, memory_pos, memory_key_padding_mask=None, query_pos=None, kv=None):
+    def forward(self, tgt, memory, memory_pos, memory_key_padding_mask=None, query_pos=None, kv=None, n_out=1):
         """memory_pos = memory + pos (the cross-attention key input), shared by all layers; ``kv`` = this
         layer's already-projected memory keys / values (or None: project here)."""
         ca = self.multihead_attn
@@ -381,15 +398,16 @@ class TransformerDecoderLayer(nn.Module):
             tgt = _residual(tgt, self.dropout2(
                 attention(ca, _add_pos(y, query_pos), memory_pos, memory, memory_key_padding_mask, self.training, kv=kv)))
             return _residual(tgt, self.dropout3(self._ffn(self.norm3(tgt))))
-        tgt = _attn_add_norm(self.norm1, self.dropout1, tgt, self.self_attn, None, None, None, None, self.training,
-                             qk_parts=(tgt, query_pos))
+        # norm1's output has two consumers (the cross-attention query and the residual): two aliases, see _attn_add_norm
+        tgt, tgt_q = _attn_add_norm(self.norm1, self.dropout1, tgt, self.self_attn, None, None, None, None, self.training,
+                                    qk_parts=(tgt, query_pos), n_out=2)
         if kv is not None and query_pos is not None:  # query = tgt + query_pos is formed inside the projection's node
-            tgt = _attn_add_norm(self.norm2, self.dropout2, tgt, ca, tgt, memory_pos, memory, memory_key_padding_mask,
-                                 self.training, kv=kv, q_parts=(tgt, query_pos))
+            tgt = _attn_add_norm(self.norm2, self.dropout2, tgt, ca, tgt_q, memory_pos, memory, memory_key_padding_mask,
+                                 self.training, kv=kv, q_parts=(tgt_q, query_pos))
         else:
-            tgt = _attn_add_norm(self.norm2, self.dropout2, tgt, ca, _add_pos(tgt, query_pos), memory_pos, memory,
+            tgt = _attn_add_norm(self.norm2, self.dropout2, tgt, ca, _add_pos(tgt_q, query_pos), memory_pos, memory,
                                  memory_key_padding_mask, self.training, kv=kv)
-        return _ffn_norm(self, self.norm3, self.dropout3, tgt)
+        return _ffn_norm(self, self.norm3, self.dropout3, tgt, n_out=n_out)
 
 
 def _clones(module, n):
@@ -463,7 +481,13 @@ class TransformerDecoder(nn.Module):
         else:
             kvs = [None] * len(layers)
         inter = []
-        for layer, kv in zip(layers, kvs):
+        for li, (layer, kv) in enumerate(zip(layers, kvs)):
+            if self.return_intermediate and li + 1 < len(layers):
+                # the layer's output feeds the next layer AND the stack of intermediate outputs: two aliases
+                out, out_i = layer(out, memory, memory_pos, memory_key_padding_mask=memory_key_padding_mask, query_pos=query_pos,
+                                   kv=kv, n_out=2)
+                inter.append(out_i)
+                continue
             out = layer(out, memory, memory_pos, memory_key_padding_mask=memory_key_padding_mask, query_pos=query_pos, kv=kv)
             if self.return_intermediate:
                 inter.append(out)
