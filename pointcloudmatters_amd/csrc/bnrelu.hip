@@ -131,19 +131,17 @@ __global__ __launch_bounds__(64 * kRedWaves) void pcm_bn_reduce_kernel(int nslot
 
 // sums[2][C] -> stat[4][C] = { mean, invstd, a = gamma*invstd, b = beta - a*mean } and the running-stat update
 template <typename T>
-__global__ __launch_bounds__(kBlock) void pcm_bn_stats_kernel(int C, double count, float eps, float momentum, const T *__restrict__ y,
-                                                              const float *__restrict__ sums, const float *__restrict__ gamma,
-                                                              const float *__restrict__ beta, float *__restrict__ stat,
-                                                              float *__restrict__ running_mean, float *__restrict__ running_var)
+__device__ __forceinline__ void bn_stats_of(int c, int C, double count, float eps, float momentum, const T *__restrict__ y, float s1,
+                                            float s2, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                            float *__restrict__ stat, float *__restrict__ running_mean,
+                                            float *__restrict__ running_var)
 {
-    const int c = blockIdx.x * kBlock + threadIdx.x;
-    if (c >= C) return;
     float shv;
     if constexpr (sizeof(T) == 2) shv = __uint_as_float((uint32_t)reinterpret_cast<const uint16_t *>(y)[c] << 16);
     else shv = (float)y[c];
-    const double dm = (double)sums[c] / count;  // mean of (y - shift), shift = row 0 of y (see pcm_bn_colsum_kernel)
+    const double dm = (double)s1 / count;  // mean of (y - shift), shift = row 0 of y (see pcm_bn_colsum_kernel)
     const double mean = (double)shv + dm;
-    double var = (double)sums[C + c] / count - dm * dm;  // biased: what the normalisation uses
+    double var = (double)s2 / count - dm * dm;  // biased: what the normalisation uses
     if (var < 0.0) var = 0.0;
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
     const float a = gamma[c] * invstd;
@@ -156,6 +154,60 @@ __global__ __launch_bounds__(kBlock) void pcm_bn_stats_kernel(int C, double coun
         running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
         running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
     }
+}
+
+// pcm_bn_reduce_kernel + pcm_bn_stats_kernel in one launch (single-rank training): a workgroup reduces both moments of 64
+// channels -- the same chains and order as pcm_bn_reduce_kernel, so the same bits -- and its first wave finishes the
+// statistics.  One launch less per BatchNorm layer (6 per ACT step, each on the critical path of the tokenizer).
+template <typename T>
+__global__ __launch_bounds__(64 * kRedWaves) void pcm_bn_reduce_stats_kernel(int nslots, int C, const float *__restrict__ partial,
+                                                                               float *__restrict__ sums, double count, float eps,
+                                                                               float momentum, const T *__restrict__ y,
+                                                                               const float *__restrict__ gamma,
+                                                                               const float *__restrict__ beta, float *__restrict__ stat,
+                                                                               float *__restrict__ running_mean,
+                                                                               float *__restrict__ running_var)
+{
+    __shared__ double red[2][kRedWaves][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int VH = 2 * C;
+#pragma unroll
+    for (int mom = 0; mom < 2; ++mom) {
+        const int e = mom * C + c;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        if (c < C) {
+            int s = wave;
+            for (; s + 3 * kRedWaves < nslots; s += 4 * kRedWaves) {
+                a0 += (double)partial[(size_t)s * VH + e];
+                a1 += (double)partial[(size_t)(s + kRedWaves) * VH + e];
+                a2 += (double)partial[(size_t)(s + 2 * kRedWaves) * VH + e];
+                a3 += (double)partial[(size_t)(s + 3 * kRedWaves) * VH + e];
+            }
+            for (; s < nslots; s += kRedWaves) a0 += (double)partial[(size_t)s * VH + e];
+        }
+        red[mom][wave][lane] = (a0 + a1) + (a2 + a3);
+    }
+    __syncthreads();
+    if (wave == 0 && c < C) {
+        double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < kRedWaves; ++w) t1 += red[0][w][lane], t2 += red[1][w][lane];
+        const float s1 = (float)t1, s2 = (float)t2;
+        sums[c] = s1, sums[C + c] = s2;
+        bn_stats_of<T>(c, C, count, eps, momentum, y, s1, s2, gamma, beta, stat, running_mean, running_var);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void pcm_bn_stats_kernel(int C, double count, float eps, float momentum, const T *__restrict__ y,
+                                                              const float *__restrict__ sums, const float *__restrict__ gamma,
+                                                              const float *__restrict__ beta, float *__restrict__ stat,
+                                                              float *__restrict__ running_mean, float *__restrict__ running_var)
+{
+    const int c = blockIdx.x * kBlock + threadIdx.x;
+    if (c >= C) return;
+    bn_stats_of<T>(c, C, count, eps, momentum, y, sums[c], sums[C + c], gamma, beta, stat, running_mean, running_var);
 }
 
 template <typename T>
@@ -264,6 +316,15 @@ extern "C" int pcm_bn_relu_forward_hip(long n, int C, int is_bf16, const void *y
         else
             hipLaunchKernelGGL((pcm_bn_colsum_kernel<float, 0>), grid, dim3(kBlock), 0, s, n, C, p.chunkW, p.rows_per_slot,
                                (const float *)y, (const float *)nullptr, (const float *)nullptr, partial);
+        if (use_given_stat == 0) {  // reduce + statistics in one launch
+            if (is_bf16)
+                hipLaunchKernelGGL(pcm_bn_reduce_stats_kernel<bf>, dim3((C + 63) / 64), dim3(64 * kRedWaves), 0, s, p.nslots, C, partial,
+                                   sums, (double)n, eps, momentum, (const bf *)y, gamma, beta, stat, running_mean, running_var);
+            else
+                hipLaunchKernelGGL(pcm_bn_reduce_stats_kernel<float>, dim3((C + 63) / 64), dim3(64 * kRedWaves), 0, s, p.nslots, C,
+                                   partial, sums, (double)n, eps, momentum, (const float *)y, gamma, beta, stat, running_mean,
+                                   running_var);
+        } else {
         hipLaunchKernelGGL(pcm_bn_reduce_kernel, dim3((2 * C + 63) / 64), dim3(64 * kRedWaves), 0, s, p.nslots, 2 * C, partial, sums);
         if (use_given_stat == 2) return PCM_LAUNCH_STATUS();
         if (is_bf16)
@@ -272,6 +333,7 @@ extern "C" int pcm_bn_relu_forward_hip(long n, int C, int is_bf16, const void *y
         else
             hipLaunchKernelGGL(pcm_bn_stats_kernel<float>, dim3((C + kBlock - 1) / kBlock), dim3(kBlock), 0, s, C, (double)n, eps,
                                momentum, (const float *)y, sums, gamma, beta, stat, running_mean, running_var);
+        }
     }
     const long total4 = n * C / 4;
     if (is_bf16)
