@@ -43,9 +43,10 @@ def test_act_training_steps_are_bit_reproducible(mode, precision, ragged, hip_de
     assert torch.equal(pa, pb)
 
 
-@pytest.mark.parametrize("mode,precision,ragged,ff", [("hybrid", "bf16", True, 3200), ("graph", "bf16", False, 3200), ("flat", "bf16", False, 32),
-                                                      ("hybrid", "fp32", True, 3200)])
-def test_batched_closing_reductions_change_no_bit(mode, precision, ragged, ff, hip_device, monkeypatch):
+@pytest.mark.parametrize("mode,precision,ragged,ff,staged", [("hybrid", "bf16", True, 3200, None), ("graph", "bf16", False, 3200, None),
+                                                             ("flat", "bf16", False, 32, None), ("hybrid", "fp32", True, 3200, None),
+                                                             ("hybrid", "bf16", True, 32, True), ("graph", "bf16", False, 32, True)])
+def test_batched_closing_reductions_change_no_bit(mode, precision, ragged, ff, staged, hip_device, monkeypatch):
     """policy/deferred.py: the second-level reductions of the fused backward kernels (norm / bias gradients, split-K weight
     gradients) launched together at the end of each backward stage instead of one by one.  Same arithmetic in the same
     order -> losses, every flat gradient and the parameters after three steps are torch.equal with the window on and off;
@@ -54,20 +55,23 @@ def test_batched_closing_reductions_change_no_bit(mode, precision, ragged, ff, h
 
     monkeypatch.setattr(deferred, "BATCH_WGRADS", False)  # the batched weight gradients agree to rounding only (next test)
     n0 = dict(deferred.STATS)
-    a, pa = _act_run(mode, precision, hip_device, ragged, dict(defer_reductions=True), dim_feedforward=ff, points=1200)
+    # staged=True: the backward stages of the data-parallel runs (one flush per stage, gradients handed over per stage)
+    a, pa = _act_run(mode, precision, hip_device, ragged, dict(defer_reductions=True, staged=staged), dim_feedforward=ff, points=1200)
     n1 = dict(deferred.STATS)
-    b, pb = _act_run(mode, precision, hip_device, ragged, dict(defer_reductions=False), dim_feedforward=ff, points=1200)
+    b, pb = _act_run(mode, precision, hip_device, ragged, dict(defer_reductions=False, staged=staged), dim_feedforward=ff, points=1200)
     assert dict(deferred.STATS) == n1 and not deferred.active()
     pushed, launches = n1["pushed"] - n0["pushed"], n1["launches"] - n0["launches"]
-    assert pushed >= 10 and launches * 4 <= pushed, (pushed, launches)  # the window was used, and it batches
+    # the window was used, and it batches (four backward stages flush four times: fewer reductions per launch)
+    assert pushed >= 10 and launches * (2 if staged else 4) <= pushed, (pushed, launches)
     for i, ((la, ga), (lb, gb)) in enumerate(zip(a, b)):
         assert torch.equal(la, lb), (i, la.item(), lb.item())
         assert torch.equal(ga, gb), (i, (ga - gb).abs().max().item())
     assert torch.equal(pa, pb)
 
 
-@pytest.mark.parametrize("mode,precision", [("graph", "bf16"), ("hybrid", "bf16"), ("hybrid", "fp32")])
-def test_batched_weight_gradients_agree_and_reproduce(mode, precision, hip_device, monkeypatch):
+@pytest.mark.parametrize("mode,precision,staged", [("graph", "bf16", None), ("hybrid", "bf16", None), ("hybrid", "fp32", None),
+                                                   ("hybrid", "bf16", True)])
+def test_batched_weight_gradients_agree_and_reproduce(mode, precision, staged, hip_device, monkeypatch):
     """policy/deferred.push_wgrad: the seven decoder layers' weight gradients of one shape as ONE batched product per backward
     stage.  Another GEMM kernel sums in another order, so: against the single products the losses of three steps and every
     gradient agree to rounding (bf16 results: one unit in the last place of some elements); two runs WITH batching are
@@ -77,16 +81,17 @@ def test_batched_weight_gradients_agree_and_reproduce(mode, precision, hip_devic
     monkeypatch.setattr(deferred, "_EXPECT", {})
     monkeypatch.setattr(deferred, "BATCH_WGRADS", True)
     n0 = dict(deferred.STATS)
-    a, pa = _act_run(mode, precision, hip_device, mode != "graph", decoder_layers=7)
+    kw = dict(staged=staged)
+    a, pa = _act_run(mode, precision, hip_device, mode != "graph", kw, decoder_layers=7)
     n1 = dict(deferred.STATS)
     assert n1["wgrad_batches"] > n0["wgrad_batches"] and n1["wgrads"] - n0["wgrads"] >= 5 * (n1["wgrad_batches"] - n0["wgrad_batches"])
-    a2, pa2 = _act_run(mode, precision, hip_device, mode != "graph", decoder_layers=7)
+    a2, pa2 = _act_run(mode, precision, hip_device, mode != "graph", kw, decoder_layers=7)
     for (la, ga), (lb, gb) in zip(a, a2):
         assert torch.equal(la, lb) and torch.equal(ga, gb)
     assert torch.equal(pa, pa2)
     monkeypatch.setattr(deferred, "BATCH_WGRADS", False)
     n2 = dict(deferred.STATS)
-    b, pb = _act_run(mode, precision, hip_device, mode != "graph", decoder_layers=7)
+    b, pb = _act_run(mode, precision, hip_device, mode != "graph", kw, decoder_layers=7)
     assert deferred.STATS["wgrad_batches"] == n2["wgrad_batches"] and deferred.STATS["wgrads"] == n2["wgrads"]
     tol = 2e-2 if precision == "bf16" else 1e-4
     for i, ((la, ga), (lb, gb)) in enumerate(zip(a, b)):
