@@ -319,6 +319,13 @@ int pcm_drln_blocks(long R);
 int pcm_drln_forward_hip(long R, int E, int y_is_bf16, const float *x, const void *y, const float *gamma,
                          const float *beta, float eps, float p_drop, const long *seed, unsigned site,
                          float *s, float *out, float *mean, float *rstd, void *stream);
+/* same, and the consumer's bf16 operands emitted by the same launch (replaces its pcm_add_cast2_hip): sum_bf16 (nullable) =
+ * bf16(out + pos) with pos (pos_n elements, a multiple of E that divides R*E) broadcast over the leading rows -- the
+ * decoder's cross-attention query input tgt + query_pos, transformer.py:332 -- and out_bf16 (nullable) = bf16(out) */
+int pcm_drln_forward2_hip(long R, int E, int y_is_bf16, const float *x, const void *y, const float *gamma,
+                          const float *beta, float eps, float p_drop, const long *seed, unsigned site, float *s,
+                          float *out, float *mean, float *rstd, const float *pos, long pos_n, void *sum_bf16,
+                          void *out_bf16, void *stream);
 int pcm_drln_backward_hip(long R, int E, int y_is_bf16, const float *dout, const float *s,
                           const float *mean, const float *rstd, const float *gamma, float p_drop,
                           const long *seed, unsigned site, float *dx, void *dy, float *partial,
@@ -345,6 +352,13 @@ int pcm_ffn_ln_forward_hip(long R, int E, int F, const float *x, const float *W1
                            float eps, float p_hidden, float p_out, const long *seed, unsigned site_a,
                            unsigned site_b, float *hd, float *s, float *out, float *mean, float *rstd,
                            void *stream);
+/* same, emitting the NEXT layer's in-projection operands bf16(out + pos) / bf16(out) (see pcm_drln_forward2_hip;
+ * q = k = src + pos, v = src of the next layer, transformer.py:244-249) */
+int pcm_ffn_ln_forward2_hip(long R, int E, int F, const float *x, const float *W1, const float *b1, const float *W2,
+                            const float *b2, const float *gamma, const float *beta, float eps, float p_hidden,
+                            float p_out, const long *seed, unsigned site_a, unsigned site_b, float *hd, float *s,
+                            float *out, float *mean, float *rstd, const float *pos, long pos_n, void *sum_bf16,
+                            void *out_bf16, void *stream);
 int pcm_ffn_ln_backward_hip(long R, int E, int F, const float *dout, const float *x, const float *s,
                             const float *mean, const float *rstd, const float *hd, const float *W1,
                             const float *W2, const float *gamma, float p_hidden, float p_out,

@@ -64,6 +64,8 @@ SIGNATURES = {
     "pcm_drln_blocks": [ctypes.c_long],
     "pcm_drln_forward_hip": [ctypes.c_long, _i, _i, _P, _P, _P, _P, _f, _f, _P, ctypes.c_uint, _P, _P, _P, _P, _P],
     "pcm_drln_backward_hip": [ctypes.c_long, _i, _i, _P, _P, _P, _P, _P, _f, _P, ctypes.c_uint, _P, _P, _P, _P, _P, _P],
+    "pcm_drln_forward2_hip": [ctypes.c_long, _i, _i, _P, _P, _P, _P, _f, _f, _P, ctypes.c_uint, _P, _P, _P, _P, _P, ctypes.c_long, _P, _P,
+                              _P],
     "pcm_drln_backward2_hip": [ctypes.c_long, _i, _i, _P, _P, _P, _P, _P, _P, _f, _P, ctypes.c_uint, _P, _P, _P, _P, _P, _P],
     "pcm_ffn_ln_supported": [_i, _i],
     "pcm_ffn_ln_blocks": [ctypes.c_long],
@@ -71,6 +73,8 @@ SIGNATURES = {
                                _P, _P, _P, _P, _P, _P],
     "pcm_ffn_ln_backward_hip": [ctypes.c_long, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P, _P, _f, _f, _P, ctypes.c_uint,
                                 _P, _P, _P, _P, _P, _P],
+    "pcm_ffn_ln_forward2_hip": [ctypes.c_long, _i, _i, _P, _P, _P, _P, _P, _P, _P, _f, _f, _f, _P, ctypes.c_uint, ctypes.c_uint,
+                                _P, _P, _P, _P, _P, _P, ctypes.c_long, _P, _P, _P],
     "pcm_ffn_ln_backward2_hip": [ctypes.c_long, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _f, _f, _P, ctypes.c_uint,
                                  _P, _P, _P, _P, _P, _P],
     "pcm_ddpm_step_hip": [ctypes.c_long, _i, _P, _P, _P, _P, _P, _f, _f, _f, _f, _f, _f, _P, _P],

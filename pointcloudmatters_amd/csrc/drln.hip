@@ -29,7 +29,9 @@ __global__ __launch_bounds__(kBlock) void pcm_drln_fwd_kernel(long R, const floa
                                                               const float *__restrict__ gamma, const float *__restrict__ beta,
                                                               float eps, float p_drop, const long *__restrict__ seed_ptr,
                                                               unsigned site, float *__restrict__ s_out, float *__restrict__ out,
-                                                              float *__restrict__ mean_out, float *__restrict__ rstd_out)
+                                                              float *__restrict__ mean_out, float *__restrict__ rstd_out,
+                                                              const float *__restrict__ pos, long pos_n,
+                                                              __hip_bfloat16 *__restrict__ sum16, __hip_bfloat16 *__restrict__ x16)
 {
     constexpr int E = NCH * 256;
     const int lane = threadIdx.x & 63;
@@ -78,6 +80,16 @@ __global__ __launch_bounds__(kBlock) void pcm_drln_fwd_kernel(long R, const floa
             for (int v = 0; v < 4; ++v) o[v] = (s[c][v] - mu) * rstd * g[c][v] + b[c][v];
             store4<float>(s_out + e0, s[c]);
             store4<float>(out + e0, o);
+            // the consumer's bf16 operands, emitted here instead of by its own add + cast launch (pcm_add_cast2_hip):
+            // sum16 = bf16(out + pos) (pos broadcast over the leading rows), x16 = bf16(out)
+            if (sum16 != nullptr) {
+                float p[4], q[4];
+                load4<float>(pos + (r * E) % pos_n + c * 256 + lane * 4, p);  // E divides pos_n: a row never wraps
+#pragma unroll
+                for (int v = 0; v < 4; ++v) q[v] = o[v] + p[v];
+                store4<__hip_bfloat16>(sum16 + e0, q);
+            }
+            if (x16 != nullptr) store4<__hip_bfloat16>(x16 + e0, o);
         }
         if (lane == 0) mean_out[r] = mu, rstd_out[r] = rstd;
     }
@@ -200,10 +212,25 @@ inline int drln_grid(long R)
 
 extern "C" int pcm_drln_blocks(long R) { return drln_grid(R); }
 
+extern "C" int pcm_drln_forward2_hip(long R, int E, int y_is_bf16, const float *x, const void *y, const float *gamma,
+                                     const float *beta, float eps, float p_drop, const long *seed, unsigned site, float *s,
+                                     float *out, float *mean, float *rstd, const float *pos, long pos_n, void *sum_bf16,
+                                     void *out_bf16, void *stream);
+
 extern "C" int pcm_drln_forward_hip(long R, int E, int y_is_bf16, const float *x, const void *y, const float *gamma,
                                     const float *beta, float eps, float p_drop, const long *seed, unsigned site, float *s,
                                     float *out, float *mean, float *rstd, void *stream)
 {
+    return pcm_drln_forward2_hip(R, E, y_is_bf16, x, y, gamma, beta, eps, p_drop, seed, site, s, out, mean, rstd, nullptr, 0, nullptr,
+                                 nullptr, stream);
+}
+
+extern "C" int pcm_drln_forward2_hip(long R, int E, int y_is_bf16, const float *x, const void *y, const float *gamma,
+                                     const float *beta, float eps, float p_drop, const long *seed, unsigned site, float *s,
+                                     float *out, float *mean, float *rstd, const float *pos, long pos_n, void *sum_bf16,
+                                     void *out_bf16, void *stream)
+{
+    if (sum_bf16 != nullptr && (pos == nullptr || pos_n <= 0 || pos_n % E || (R * E) % pos_n)) return PCM_ERR_BAD_ARG;
     if (R <= 0) return R == 0 ? PCM_OK : PCM_ERR_BAD_ARG;
     if (E % 256 != 0 || E > 1024 || E <= 0) return PCM_ERR_UNSUPPORTED;
     if (p_drop < 0.f || p_drop >= 1.f || (p_drop > 0.f && seed == nullptr)) return PCM_ERR_BAD_ARG;
@@ -211,7 +238,7 @@ extern "C" int pcm_drln_forward_hip(long R, int E, int y_is_bf16, const float *x
     const int grid = drln_grid(R);
 #define PCM_F(T, N)                                                                                                         \
     hipLaunchKernelGGL((pcm_drln_fwd_kernel<T, N>), dim3(grid), dim3(kBlock), 0, st, R, x, (const T *)y, gamma, beta, eps,   \
-                       p_drop, seed, site, s, out, mean, rstd)
+                       p_drop, seed, site, s, out, mean, rstd, pos, pos_n, (__hip_bfloat16 *)sum_bf16, (__hip_bfloat16 *)out_bf16)
     const int n = E / 256;
     if (y_is_bf16) {
         if (n == 1) PCM_F(__hip_bfloat16, 1); else if (n == 2) PCM_F(__hip_bfloat16, 2); else if (n == 3) PCM_F(__hip_bfloat16, 3); else PCM_F(__hip_bfloat16, 4);

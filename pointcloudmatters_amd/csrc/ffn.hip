@@ -101,7 +101,9 @@ __global__ __launch_bounds__(kThreads) void pcm_ffn_ln_fwd_kernel(long R, const 
                                                                   const long *__restrict__ seed_ptr, unsigned site_a, unsigned site_b,
                                                                   float *__restrict__ hd_out, float *__restrict__ s_out,
                                                                   float *__restrict__ out, float *__restrict__ mean_out,
-                                                                  float *__restrict__ rstd_out)
+                                                                  float *__restrict__ rstd_out, const float *__restrict__ pos,
+                                                                  long pos_n, __hip_bfloat16 *__restrict__ sum16,
+                                                                  __hip_bfloat16 *__restrict__ x16)
 {
     static_assert(F == 32 && E % 256 == 0, "specialised for dim_feedforward = 32");
     constexpr int PER = E / 64;
@@ -178,6 +180,16 @@ __global__ __launch_bounds__(kThreads) void pcm_ffn_ln_fwd_kernel(long R, const 
             for (int u = 0; u < 4; ++u) sv[u] = s[t + u], o[u] = (s[t + u] - mu) * rstd * g[t + u] + bt[t + u];
             store4<float>(s_out + r * E + col_of(lane, t), sv);
             store4<float>(out + r * E + col_of(lane, t), o);
+            // the next layer's in-projection operands, emitted here (see pcm_drln_forward2_hip)
+            if (sum16 != nullptr) {
+                const long e0 = r * E + col_of(lane, t);
+                float p[4], q[4];
+                load4<float>(pos + (r * E) % pos_n + col_of(lane, t), p);  // E divides pos_n: a row never wraps
+#pragma unroll
+                for (int u = 0; u < 4; ++u) q[u] = o[u] + p[u];
+                store4<__hip_bfloat16>(sum16 + e0, q);
+            }
+            if (x16 != nullptr) store4<__hip_bfloat16>(x16 + r * E + col_of(lane, t), o);
         }
         if (lane == 0) mean_out[r] = mu, rstd_out[r] = rstd;
     }
@@ -342,11 +354,28 @@ int set_lds(K kernel, size_t bytes)
 extern "C" int pcm_ffn_ln_supported(int E, int F) { return (F == 32 && (E == 256 || E == 512)) ? 1 : 0; }
 extern "C" int pcm_ffn_ln_blocks(long R) { return ffn_grid(R); }
 
+extern "C" int pcm_ffn_ln_forward2_hip(long R, int E, int F, const float *x, const float *W1, const float *b1, const float *W2,
+                                       const float *b2, const float *gamma, const float *beta, float eps, float p_hidden,
+                                       float p_out, const long *seed, unsigned site_a, unsigned site_b, float *hd, float *s,
+                                       float *out, float *mean, float *rstd, const float *pos, long pos_n, void *sum_bf16,
+                                       void *out_bf16, void *stream);
+
 extern "C" int pcm_ffn_ln_forward_hip(long R, int E, int F, const float *x, const float *W1, const float *b1, const float *W2,
                                       const float *b2, const float *gamma, const float *beta, float eps, float p_hidden,
                                       float p_out, const long *seed, unsigned site_a, unsigned site_b, float *hd, float *s,
                                       float *out, float *mean, float *rstd, void *stream)
 {
+    return pcm_ffn_ln_forward2_hip(R, E, F, x, W1, b1, W2, b2, gamma, beta, eps, p_hidden, p_out, seed, site_a, site_b, hd, s, out,
+                                   mean, rstd, nullptr, 0, nullptr, nullptr, stream);
+}
+
+extern "C" int pcm_ffn_ln_forward2_hip(long R, int E, int F, const float *x, const float *W1, const float *b1, const float *W2,
+                                       const float *b2, const float *gamma, const float *beta, float eps, float p_hidden,
+                                       float p_out, const long *seed, unsigned site_a, unsigned site_b, float *hd, float *s,
+                                       float *out, float *mean, float *rstd, const float *pos, long pos_n, void *sum_bf16,
+                                       void *out_bf16, void *stream)
+{
+    if (sum_bf16 != nullptr && (pos == nullptr || pos_n <= 0 || pos_n % E || (R * E) % pos_n)) return PCM_ERR_BAD_ARG;
     if (R <= 0) return R == 0 ? PCM_OK : PCM_ERR_BAD_ARG;
     if (!pcm_ffn_ln_supported(E, F)) return PCM_ERR_UNSUPPORTED;
     if ((p_hidden > 0.f || p_out > 0.f) && seed == nullptr) return PCM_ERR_BAD_ARG;
@@ -359,7 +388,8 @@ extern "C" int pcm_ffn_ln_forward_hip(long R, int E, int F, const float *x, cons
         int rc = set_lds(k, lds);                                                                                            \
         if (rc) return rc;                                                                                                   \
         hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), lds, st, R, x, W1, b1, W2, b2, gamma, beta, eps, p_hidden, p_out,  \
-                           seed, site_a, site_b, hd, s, out, mean, rstd);                                                    \
+                           seed, site_a, site_b, hd, s, out, mean, rstd, pos, pos_n, (__hip_bfloat16 *)sum_bf16,             \
+                           (__hip_bfloat16 *)out_bf16);                                                                      \
     } while (0)
     if (E == 512) PCM_FF(512); else PCM_FF(256);
 #undef PCM_FF

@@ -8,6 +8,8 @@ context (CPU runs, reference-order tests, eager mode) callers fall back to the f
 """
 import contextlib
 
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -126,10 +128,24 @@ class _DRLN(Function):
         return dx.view(shape), dy.view(shape), sums[0], sums[1], None, None, None, None
 
 
-def _drln_forward(x2, y2, gamma, beta, eps, p_drop, seed, site):
+def _drln_forward(x2, y2, gamma, beta, eps, p_drop, seed, site, emit=None):
     L = _lib.load()
     R, E = x2.shape
     dev = x2.device
+    if emit is not None:
+        with torch.cuda.device(dev):
+            s = torch.empty_like(x2)
+            out = deferred.take(x2.shape, x2.dtype, dev, "drln.out")
+            mean = torch.empty(R, dtype=torch.float32, device=dev)
+            rstd = torch.empty(R, dtype=torch.float32, device=dev)
+            extra, rec = _emit_args(emit, R, E, dev)
+            rc = L.pcm_drln_forward2_hip(R, E, 1 if y2.dtype == torch.bfloat16 else 0, x2.data_ptr(), y2.data_ptr(), gamma.data_ptr(),
+                                         beta.data_ptr(), float(eps), float(p_drop), seed.data_ptr() if seed is not None else 0,
+                                         int(site), s.data_ptr(), out.data_ptr(), mean.data_ptr(), rstd.data_ptr(), *extra,
+                                         _raw_stream())
+        _lib.check(rc, "pcm_drln_forward2_hip")
+        emit["record"] = rec
+        return out, s, mean, rstd
     with torch.cuda.device(dev):
         s = torch.empty_like(x2)
         out = deferred.take(x2.shape, x2.dtype, dev, "drln.out")
@@ -141,6 +157,58 @@ def _drln_forward(x2, y2, gamma, beta, eps, p_drop, seed, site):
                                     _raw_stream())
     _lib.check(rc, "pcm_drln_forward_hip")
     return out, s, mean, rstd
+
+
+def _pos_rows(pos, x_shape):
+    """`pos` as the contiguous fp32 block that the add + cast kernels broadcast over the leading rows of x (shape x_shape):
+    trailing dimensions expanded to x's, a batch-broadcast view reduced to its single row block."""
+    nd = len(x_shape)
+    posc = pos.expand(pos.shape[0], *x_shape[1:]) if pos.dim() == nd and tuple(pos.shape[1:]) != tuple(x_shape[1:]) else pos
+    if posc.dim() == nd and posc.shape[0] > 1 and posc.stride(0) == 0:
+        posc = posc[:1]  # a batch-broadcast view (query_pos): the kernel broadcasts by index, no materialised copy
+    return posc.contiguous()
+
+
+def _emit_args(emit, R, E, dev):
+    """emit = {"pos": tensor, "x16": bool, "tags": (tag of bf16(out + pos), tag of bf16(out))} -> the extra arguments of
+    pcm_*_forward2_hip and the record that the consumer node looks for on its input (``_emitted``)."""
+    if emit is None:
+        return (0, 0, 0, 0), None
+    posc = emit["posc"]
+    sum16 = deferred.take((R, E), torch.bfloat16, dev, emit["tags"][0])
+    x16 = deferred.take((R, E), torch.bfloat16, dev, emit["tags"][1]) if emit["x16"] else None
+    return (posc.data_ptr(), posc.numel(), sum16.data_ptr(), x16.data_ptr() if x16 is not None else 0), \
+        {"pos": emit["pos"], "posc": posc, "sum16": sum16, "x16": x16}
+
+
+EMIT_OPERANDS = os.environ.get("PCM_EMIT_OPERANDS", "1") != "0"  # A/B switch (and tests: bit-identical either way)
+
+
+def emit_for(pos, x_shape, x16, tags):
+    """What a producer node (proj_drln / ffn_ln) needs to write its consumer's bf16 operands in its own launch: the consumer
+    (an in-projection or query-projection node fed with THIS pos object) then skips its add + cast kernel.  None when the
+    shapes do not allow it."""
+    if not EMIT_OPERANDS or pos is None or not pos.is_cuda or pos.dtype != torch.float32 or not (
+            torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16) or not torch.is_grad_enabled():
+        return None
+    E = x_shape[-1]
+    numel = 1
+    for v in x_shape:
+        numel *= int(v)
+    if pos.dim() != len(x_shape) or tuple(pos.shape[1:]) != tuple(x_shape[1:]) or pos.shape[0] not in (1, x_shape[0]):
+        return None
+    posc = _pos_rows(pos, x_shape)
+    if posc.numel() % E or numel % posc.numel():
+        return None
+    return {"pos": pos, "posc": posc, "x16": bool(x16), "tags": tags}
+
+
+def _emitted(x, pos, posc):
+    """The bf16 operands a producer already wrote for this (x, pos) pair, or None."""
+    em = getattr(x, "_pcm_emit", None)
+    if em is None or em["pos"] is not pos or em["posc"].shape != posc.shape or em["sum16"].numel() != x.numel():
+        return None
+    return em
 
 
 def _f32_rows(g, R, E):
@@ -193,7 +261,7 @@ class _ProjDRLN(Function):
     split-K product for dW (rows_linear.weight_grad)."""
 
     @staticmethod
-    def forward(ctx, a, weight, bias, x, gamma, beta, eps, p_drop, seed, site, n_out=1):
+    def forward(ctx, a, weight, bias, x, gamma, beta, eps, p_drop, seed, site, n_out=1, emit=None):
         shape = x.shape
         E = shape[-1]
         if torch.is_autocast_enabled("cuda"):
@@ -207,7 +275,7 @@ class _ProjDRLN(Function):
         x2 = x.reshape(-1, E)
         if not x2.is_contiguous():
             x2 = x2.contiguous()
-        out, s, mean, rstd = _drln_forward(x2, y2, gamma, beta, eps, p_drop, seed, site)
+        out, s, mean, rstd = _drln_forward(x2, y2, gamma, beta, eps, p_drop, seed, site, emit=emit)
         ctx.save_for_backward(a2, wc, s, mean, rstd, gamma)
         ctx.meta = (shape, a.shape, a.dtype, weight.dtype, bias.dtype, y2.dtype, float(p_drop), seed, int(site))
         ctx.side_ok = _goes_to_optimizer(weight)
@@ -229,7 +297,7 @@ class _ProjDRLN(Function):
         want16 = bdt == torch.bfloat16
         dout, dout2 = _two_addends(douts, *s.shape)
         if dout is None:
-            return (None,) * 11
+            return (None,) * 12
         defer = deferred.clear(*ctx.defer)
         res = _drln_backward(dout, s, mean, rstd, gamma, ydt, p_drop, seed, site, dysum_bf16=want16, defer=defer, dout2=dout2)
         dx, dy, sums = res[:3]
@@ -239,16 +307,25 @@ class _ProjDRLN(Function):
                 da = da.to(adt)
             dw = weight_grad(dy, a2, wdt, side=ctx.side_ok, defer=defer, tag="proj_drln")
             db = res[3] if want16 else sums[2].to(bdt)
-        return da, dw, db, dx.view(shape), sums[0], sums[1], None, None, None, None, None
+        return da, dw, db, dx.view(shape), sums[0], sums[1], None, None, None, None, None, None
 
 
-def proj_drln(a, linear, x, norm, dropout, n_out=1):
+def _tag_emitted(outs, emit):
+    rec = emit.get("record") if emit is not None else None
+    if rec is not None:
+        for o in (outs if isinstance(outs, tuple) else (outs,)):
+            o._pcm_emit = rec
+    return outs
+
+
+def proj_drln(a, linear, x, norm, dropout, n_out=1, emit=None):
     """norm(x + dropout(linear(a))); the caller checked ``drln_supported(x, <linear output>, norm)``.  n_out > 1: that many
-    aliases of the result, one per consumer (their gradients are summed inside the backward kernel)."""
+    aliases of the result, one per consumer (their gradients are summed inside the backward kernel).  emit (``emit_for``):
+    the same launch also writes the bf16 operands of the node that will consume the result together with that pos."""
     p = dropout.p if (dropout is not None and dropout.training) else 0.0
     ctx = _ACTIVE
-    return _ProjDRLN.apply(a, linear.weight, linear.bias, x, norm.weight, norm.bias, norm.eps, p,
-                           ctx.seed if p > 0 else None, ctx.next_site(), n_out)
+    return _tag_emitted(_ProjDRLN.apply(a, linear.weight, linear.bias, x, norm.weight, norm.bias, norm.eps, p,
+                                        ctx.seed if p > 0 else None, ctx.next_site(), n_out, emit), emit)
 
 
 def drln_supported(x, y, norm, y_dtype=None):
@@ -271,7 +348,7 @@ class _FFNLN(Function):
     """out = norm(x + dropout_out(linear2(dropout_hidden(relu(linear1(x)))))) -- csrc/ffn.hip."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, eps, p_hidden, p_out, seed, site_a, site_b, n_out=1):
+    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, eps, p_hidden, p_out, seed, site_a, site_b, n_out=1, emit=None):
         L = _lib.load()
         shape = x.shape
         E, Fh = shape[-1], w1.shape[0]
@@ -285,11 +362,14 @@ class _FFNLN(Function):
             hd, s, out = deferred.take((R, Fh), torch.float32, dev, "ffn.hd"), torch.empty(R, E, **f32), deferred.take((R, E), torch.float32, dev, "drln.out")
             mean, rstd = torch.empty(R, **f32), torch.empty(R, **f32)
             sp = seed.data_ptr() if seed is not None else 0
-            rc = L.pcm_ffn_ln_forward_hip(R, E, Fh, x2.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
-                                          gamma.data_ptr(), beta.data_ptr(), float(eps), float(p_hidden), float(p_out), sp,
-                                          int(site_a), int(site_b), hd.data_ptr(), s.data_ptr(), out.data_ptr(), mean.data_ptr(),
-                                          rstd.data_ptr(), _raw_stream())
-        _lib.check(rc, "pcm_ffn_ln_forward_hip")
+            extra, rec = _emit_args(emit, R, E, dev)
+            rc = L.pcm_ffn_ln_forward2_hip(R, E, Fh, x2.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                                           gamma.data_ptr(), beta.data_ptr(), float(eps), float(p_hidden), float(p_out), sp,
+                                           int(site_a), int(site_b), hd.data_ptr(), s.data_ptr(), out.data_ptr(), mean.data_ptr(),
+                                           rstd.data_ptr(), *extra, _raw_stream())
+            if emit is not None:
+                emit["record"] = rec
+        _lib.check(rc, "pcm_ffn_ln_forward2_hip")
         ctx.save_for_backward(x2, w1, w2, gamma, hd, s, mean, rstd)
         ctx.meta = (shape, float(p_hidden), float(p_out), seed, int(site_b))
         ctx.side_ok = _goes_to_optimizer(w1) and _goes_to_optimizer(w2)
@@ -310,7 +390,7 @@ class _FFNLN(Function):
         f32 = dict(dtype=torch.float32, device=dev)
         d2, d2b = _two_addends(douts, R, E)
         if d2 is None:
-            return (None,) * 14
+            return (None,) * 15
         with torch.cuda.device(dev):
             dx, dy, dh = torch.empty(R, E, **f32), deferred.take((R, E), torch.float32, dev, "ffn.dy"), deferred.take((R, Fh), torch.float32, dev, "ffn.dh")
             pw = 3 * E + Fh
@@ -332,7 +412,7 @@ class _FFNLN(Function):
                 dw2 = weight_grad(dy, hd, torch.float32, side=ctx.side_ok, defer=defer, tag="ffn.w2")  # (E, F)   split-K over the rows when there are thousands
                 dw1 = weight_grad(dh, x2, torch.float32, side=ctx.side_ok, defer=defer, tag="ffn.w1")  # (F, E)
         dgamma, dbeta, db2, db1 = sums[:E], sums[E : 2 * E], sums[2 * E : 3 * E], sums[3 * E :]
-        return dx.view(shape), dw1, db1, dw2, db2, dgamma, dbeta, None, None, None, None, None, None, None
+        return dx.view(shape), dw1, db1, dw2, db2, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 def ffn_ln_supported(x, linear1, linear2, norm):
@@ -344,12 +424,13 @@ def ffn_ln_supported(x, linear1, linear2, norm):
     return bool(_lib.load().pcm_ffn_ln_supported(int(x.shape[-1]), int(linear1.weight.shape[0])))
 
 
-def ffn_ln(x, linear1, linear2, norm, dropout_hidden, dropout_out, n_out=1):
+def ffn_ln(x, linear1, linear2, norm, dropout_hidden, dropout_out, n_out=1, emit=None):
     pa = dropout_hidden.p if dropout_hidden.training else 0.0
     pb = dropout_out.p if dropout_out.training else 0.0
     ctx = _ACTIVE
-    return _FFNLN.apply(x, linear1.weight, linear1.bias, linear2.weight, linear2.bias, norm.weight, norm.bias, norm.eps, pa, pb,
-                        ctx.seed if (pa > 0 or pb > 0) else None, ctx.next_site(), ctx.next_site(), n_out)
+    return _tag_emitted(_FFNLN.apply(x, linear1.weight, linear1.bias, linear2.weight, linear2.bias, norm.weight, norm.bias, norm.eps,
+                                     pa, pb, ctx.seed if (pa > 0 or pb > 0) else None, ctx.next_site(), ctx.next_site(), n_out,
+                                     emit), emit)
 
 
 class _SelfAttnInProj(Function):
@@ -367,20 +448,21 @@ class _SelfAttnInProj(Function):
         if not x2.is_contiguous():
             x2 = x2.contiguous()
         rows = x2.shape[0]
-        posc = pos.expand(pos.shape[0], *shape[1:]) if pos.dim() == x.dim() and pos.shape[1:] != shape[1:] else pos
-        if posc.dim() == x.dim() and posc.shape[0] > 1 and posc.stride(0) == 0:
-            posc = posc[:1]  # a batch-broadcast view (query_pos): the kernel broadcasts by index, no materialised copy
-        posc = posc.contiguous()
+        posc = _pos_rows(pos, shape)
         dev = x.device
         bf = torch.bfloat16
         wc = w if w.dtype == bf else w.to(bf)
         bc = b if b.dtype == bf else b.to(bf)
-        with torch.cuda.device(dev):
-            qk_in = deferred.take((rows, E), bf, dev, "in_proj.qk")
-            v_in = deferred.take((rows, E), bf, dev, "in_proj.v")
-            rc = L.pcm_add_cast2_hip(x2.numel(), posc.numel(), x2.data_ptr(), posc.data_ptr(), qk_in.data_ptr(), v_in.data_ptr(),
-                                     _raw_stream())
-        _lib.check(rc, "pcm_add_cast2_hip")
+        em = _emitted(x, pos, posc)
+        if em is not None and em["x16"] is not None:  # the producer of x wrote bf16(x + pos) and bf16(x) in its own launch
+            qk_in, v_in = em["sum16"], em["x16"]
+        else:
+            with torch.cuda.device(dev):
+                qk_in = deferred.take((rows, E), bf, dev, "in_proj.qk")
+                v_in = deferred.take((rows, E), bf, dev, "in_proj.v")
+                rc = L.pcm_add_cast2_hip(x2.numel(), posc.numel(), x2.data_ptr(), posc.data_ptr(), qk_in.data_ptr(), v_in.data_ptr(),
+                                         _raw_stream())
+            _lib.check(rc, "pcm_add_cast2_hip")
         with torch.autocast("cuda", enabled=False):
             qk = torch.nn.functional.linear(qk_in, wc[: 2 * E], bc[: 2 * E]).view(*shape[:-1], 2, E)
             v = torch.nn.functional.linear(v_in, wc[2 * E:], bc[2 * E:]).view(shape)
@@ -471,18 +553,19 @@ class _AddPosLinear(Function):
         x2 = x.reshape(-1, E)
         if not x2.is_contiguous():
             x2 = x2.contiguous()
-        posc = pos
-        if posc.dim() == x.dim() and posc.shape[0] > 1 and posc.stride(0) == 0:
-            posc = posc[:1]
-        posc = posc.contiguous()
+        posc = _pos_rows(pos, shape)
         bf = torch.bfloat16
         wc = w if w.dtype == bf else w.to(bf)
         bc = b if b.dtype == bf else b.to(bf)
-        with torch.cuda.device(x.device):
-            s_in = deferred.take(x2.shape, bf, x.device, "add_pos.s")
-            rc = L.pcm_add_cast2_hip(x2.numel(), posc.numel(), x2.data_ptr(), posc.data_ptr(), s_in.data_ptr(), 0,
-                                     _raw_stream())
-        _lib.check(rc, "pcm_add_cast2_hip")
+        em = _emitted(x, pos, posc)
+        if em is not None:  # the producer of x wrote bf16(x + pos) in its own launch
+            s_in = em["sum16"]
+        else:
+            with torch.cuda.device(x.device):
+                s_in = deferred.take(x2.shape, bf, x.device, "add_pos.s")
+                rc = L.pcm_add_cast2_hip(x2.numel(), posc.numel(), x2.data_ptr(), posc.data_ptr(), s_in.data_ptr(), 0,
+                                         _raw_stream())
+            _lib.check(rc, "pcm_add_cast2_hip")
         with torch.autocast("cuda", enabled=False):
             y = torch.nn.functional.linear(s_in, wc, bc).view(*shape[:-1], wc.shape[0])
         ctx.save_for_backward(s_in, wc)

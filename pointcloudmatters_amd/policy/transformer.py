@@ -45,7 +45,8 @@ def _add_norm(norm: nn.Module, dropout: nn.Module, x: Tensor, y: Tensor) -> Tens
     return norm(_residual(x, dropout(y)))
 
 
-def _attn_add_norm(norm: nn.Module, dropout: nn.Module, x: Tensor, mha: nn.MultiheadAttention, *args, n_out: int = 1, **kwargs):
+def _attn_add_norm(norm: nn.Module, dropout: nn.Module, x: Tensor, mha: nn.MultiheadAttention, *args, n_out: int = 1,
+                   emit_pos: Optional[Tensor] = None, **kwargs):
     """norm(x + dropout(mha(...))): with a FusedContext active the output projection, the residual add and the norm
     are one autograd node (fused_ops.proj_drln); otherwise the plain chain.  n_out = 2: the result twice, for two consumers --
     the fused node hands out two aliases and sums their gradients inside its backward kernel (no add launch)."""
@@ -59,7 +60,9 @@ def _attn_add_norm(norm: nn.Module, dropout: nn.Module, x: Tensor, mha: nn.Multi
             x = aux.get("residual", x)
             ydt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else a.dtype
             if fused_ops.drln_supported(x, None, norm, y_dtype=ydt) and mha.out_proj.bias is not None:
-                return fused_ops.proj_drln(a, mha.out_proj, x, norm, dropout, n_out=n_out)
+                # emit_pos: the query projection that consumes this output with that pos finds its bf16 input ready
+                emit = fused_ops.emit_for(emit_pos, x.shape, False, ("add_pos.s", None)) if emit_pos is not None else None
+                return fused_ops.proj_drln(a, mha.out_proj, x, norm, dropout, n_out=n_out, emit=emit)
             out = _add_norm(norm, dropout, x, linear_rows(a, mha.out_proj.weight, mha.out_proj.bias))
         else:
             out = _add_norm(norm, dropout, x, attention(mha, *args, **kwargs))
@@ -76,7 +79,7 @@ def _attn_add_norm(norm: nn.Module, dropout: nn.Module, x: Tensor, mha: nn.Multi
     return _add_norm(norm, dropout, x, attention(mha, *args, **kwargs))
 
 
-def _ffn_norm(layer, norm: nn.Module, dropout_out: nn.Module, x: Tensor, n_out: int = 1):
+def _ffn_norm(layer, norm: nn.Module, dropout_out: nn.Module, x: Tensor, n_out: int = 1, emit_pos: Optional[Tensor] = None):
     """norm(x + dropout_out(linear2(dropout(act(linear1(x)))))): one fused HIP kernel each way for the shipped
     relu / dim_feedforward = 32 layers when a FusedContext is active, framework ops otherwise.  n_out: see _attn_add_norm."""
     from . import fused_ops
@@ -84,7 +87,9 @@ def _ffn_norm(layer, norm: nn.Module, dropout_out: nn.Module, x: Tensor, n_out: 
     if layer.activation is F.relu and fused_ops.ffn_ln_supported(x, layer.linear1, layer.linear2, norm):
         if n_out > 1 and not torch.is_grad_enabled():
             return (fused_ops.ffn_ln(x, layer.linear1, layer.linear2, norm, layer.dropout, dropout_out),) * n_out
-        return fused_ops.ffn_ln(x, layer.linear1, layer.linear2, norm, layer.dropout, dropout_out, n_out=n_out)
+        # emit_pos: the NEXT layer's in-projection (q = k = out + pos, v = out) finds its bf16 inputs ready
+        emit = fused_ops.emit_for(emit_pos, x.shape, True, ("in_proj.qk", "in_proj.v")) if emit_pos is not None else None
+        return fused_ops.ffn_ln(x, layer.linear1, layer.linear2, norm, layer.dropout, dropout_out, n_out=n_out, emit=emit)
     out = _add_norm(norm, dropout_out, x, layer._ffn(x))
     return out if n_out == 1 else (out,) * n_out
 
@@ -353,7 +358,7 @@ class TransformerEncoderLayer(nn.Module):
     def _ffn(self, x):
         return self.linear2(self.dropout(self.activation(self.linear1(x))))
 
-    def forward(self, src, src_key_padding_mask=None, pos=None):
+    def forward(self, src, src_key_padding_mask=None, pos=None, emit_next=False):
         if self.normalize_before:
             y = self.norm1(src)
             qk = _add_pos(y, pos)
@@ -361,7 +366,7 @@ class TransformerEncoderLayer(nn.Module):
             return _residual(src, self.dropout2(self._ffn(self.norm2(src))))
         src = _attn_add_norm(self.norm1, self.dropout1, src, self.self_attn, None, None, None, src_key_padding_mask, self.training,
                              qk_parts=(src, pos))
-        return _ffn_norm(self, self.norm2, self.dropout2, src)
+        return _ffn_norm(self, self.norm2, self.dropout2, src, emit_pos=pos if emit_next else None)
 
 
 class TransformerDecoderLayer(nn.Module):
@@ -386,7 +391,7 @@ class TransformerDecoderLayer(nn.Module):
     def _ffn(self, x):
         return self.linear2(self.dropout(self.activation(self.linear1(x))))
 
-    def forward(self, tgt, memory, memory_pos, memory_key_padding_mask=None, query_pos=None, kv=None, n_out=1):
+    def forward(self, tgt, memory, memory_pos, memory_key_padding_mask=None, query_pos=None, kv=None, n_out=1, emit_next=False):
         """memory_pos = memory + pos (the cross-attention key input), shared by all layers; ``kv`` = this
         layer's already-projected memory keys / values (or None: project here)."""
         ca = self.multihead_attn
@@ -400,14 +405,15 @@ class TransformerDecoderLayer(nn.Module):
             return _residual(tgt, self.dropout3(self._ffn(self.norm3(tgt))))
         # norm1's output has two consumers (the cross-attention query and the residual): two aliases, see _attn_add_norm
         tgt, tgt_q = _attn_add_norm(self.norm1, self.dropout1, tgt, self.self_attn, None, None, None, None, self.training,
-                                    qk_parts=(tgt, query_pos), n_out=2)
+                                    qk_parts=(tgt, query_pos), n_out=2,
+                                    emit_pos=query_pos if (kv is not None and query_pos is not None) else None)
         if kv is not None and query_pos is not None:  # query = tgt + query_pos is formed inside the projection's node
             tgt = _attn_add_norm(self.norm2, self.dropout2, tgt, ca, tgt_q, memory_pos, memory, memory_key_padding_mask,
                                  self.training, kv=kv, q_parts=(tgt_q, query_pos))
         else:
             tgt = _attn_add_norm(self.norm2, self.dropout2, tgt, ca, _add_pos(tgt_q, query_pos), memory_pos, memory,
                                  memory_key_padding_mask, self.training, kv=kv)
-        return _ffn_norm(self, self.norm3, self.dropout3, tgt, n_out=n_out)
+        return _ffn_norm(self, self.norm3, self.dropout3, tgt, n_out=n_out, emit_pos=query_pos if emit_next else None)
 
 
 def _clones(module, n):
@@ -427,8 +433,8 @@ class TransformerEncoder(nn.Module):
 
     def forward(self, src, src_key_padding_mask=None, pos=None):
         out = src
-        for layer in self.layers:
-            out = layer(out, src_key_padding_mask=src_key_padding_mask, pos=pos)
+        for li, layer in enumerate(self.layers):
+            out = layer(out, src_key_padding_mask=src_key_padding_mask, pos=pos, emit_next=li + 1 < len(self.layers))
         return out if self.norm is None else self.norm(out)
 
 
@@ -485,10 +491,11 @@ class TransformerDecoder(nn.Module):
             if self.return_intermediate and li + 1 < len(layers):
                 # the layer's output feeds the next layer AND the stack of intermediate outputs: two aliases
                 out, out_i = layer(out, memory, memory_pos, memory_key_padding_mask=memory_key_padding_mask, query_pos=query_pos,
-                                   kv=kv, n_out=2)
+                                   kv=kv, n_out=2, emit_next=True)
                 inter.append(out_i)
                 continue
-            out = layer(out, memory, memory_pos, memory_key_padding_mask=memory_key_padding_mask, query_pos=query_pos, kv=kv)
+            out = layer(out, memory, memory_pos, memory_key_padding_mask=memory_key_padding_mask, query_pos=query_pos, kv=kv,
+                        emit_next=li + 1 < len(layers))
             if self.return_intermediate:
                 inter.append(out)
         if self.return_intermediate:

@@ -69,6 +69,23 @@ def test_batched_closing_reductions_change_no_bit(mode, precision, ragged, ff, s
     assert torch.equal(pa, pb)
 
 
+@pytest.mark.parametrize("mode,ragged", [("graph", False), ("hybrid", True), ("flat", True)])
+def test_operands_emitted_by_the_producer_change_no_bit(mode, ragged, hip_device, monkeypatch):
+    """fused_ops.emit_for: the norm / feed-forward kernels write the bf16 inputs of the projection that consumes their output
+    (bf16(out + pos), bf16(out)) in their own launch; that node then skips its add + cast kernel.  Same fp32 values, same
+    rounding: three training steps are torch.equal with and without (7-layer decoder, 2-layer encoders)."""
+    from pointcloudmatters_amd.policy import fused_ops
+
+    monkeypatch.setattr(fused_ops, "EMIT_OPERANDS", True)
+    a, pa = _act_run(mode, "bf16", hip_device, ragged, decoder_layers=3)
+    monkeypatch.setattr(fused_ops, "EMIT_OPERANDS", False)
+    b, pb = _act_run(mode, "bf16", hip_device, ragged, decoder_layers=3)
+    for i, ((la, ga), (lb, gb)) in enumerate(zip(a, b)):
+        assert torch.equal(la, lb), (i, la.item(), lb.item())
+        assert torch.equal(ga, gb), (i, (ga - gb).abs().max().item())
+    assert torch.equal(pa, pb)
+
+
 @pytest.mark.parametrize("mode,precision,staged", [("graph", "bf16", None), ("hybrid", "bf16", None), ("hybrid", "fp32", None),
                                                    ("hybrid", "bf16", True)])
 def test_batched_weight_gradients_agree_and_reproduce(mode, precision, staged, hip_device, monkeypatch):
