@@ -470,6 +470,10 @@ int pcm_reduce_batch_hip(int n, const void *const *partial, const int *nslots, c
 /* first stages of n column sums in one launch per 16: per job the arguments of pcm_colsum_hip as host arrays (g and ld
  * hold 3 entries per job); partial[i] receives pcm_colsum_slots(rows[i], C[i]) rows of ntensors[i]*C[i] sums, closed by
  * pcm_reduce_batch_hip.  Same arithmetic as pcm_colsum_hip. */
+/* n device-to-device copies dst[i][0..nbytes[i]) = src[i][...] in one launch per 32 (host arrays; pairs must not overlap):
+ * the input / index staging of a training step that replays captured graphs (what Lightning's batch transfer + the
+ * reference's per-tensor `.to(device)` do one tensor at a time, maniskill2_act_bc_module.py:64-86) */
+int pcm_copy_batch_hip(int n, void *const *dst, const void *const *src, const long *nbytes, void *stream);
 int pcm_colsum_batch_hip(int n, const long *rows, const int *C, const int *ntensors, const int *in_is_bf16, const void *const *g,
                          const long *ld, void *const *partial, void *stream);
 

@@ -99,6 +99,7 @@ SIGNATURES = {
     "pcm_slab_sum_hip": [_i, ctypes.c_long, _P, _i, _P, _P],
     "pcm_reduce_batch_hip": [_i, _P, _P, _P, _P, _P, _P, _P],
     "pcm_colsum_batch_hip": [_i, _P, _P, _P, _P, _P, _P, _P, _P],
+    "pcm_copy_batch_hip": [_i, _P, _P, _P, _P],
     "pcm_colsum_hip": [ctypes.c_long, _i, _i, _i, _P, ctypes.c_long, _P, ctypes.c_long, _P, ctypes.c_long, _P, _i, _P, _P],
     "pcm_attn_small_supported": [_i, _i, _i],
     "pcm_attn_small_forward_hip": [_i, _i, _i, _i, _P, ctypes.c_long, ctypes.c_long, _P, ctypes.c_long, ctypes.c_long, _P, ctypes.c_long, ctypes.c_long, _P, _f, _f, _P, ctypes.c_uint, _P, _P, _P],
@@ -167,6 +168,30 @@ def raw_stream():
     `torch.cuda.current_stream().cuda_stream`, builds a Stream object and costs ~13 us per call -- 0.2 ms per training step
     over the eager launches of hybrid mode (tools/dbg/host_profile.py); this is one C call."""
     return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
+
+
+def copy_batch(pairs):
+    """dst.copy_(src) for every (dst, src) pair of same-shape, same-dtype, contiguous tensors on ONE device, as one launch
+    per 32 (csrc/tokens.hip pcm_copy_batch_hip) on the current stream; anything else falls back to Tensor.copy_."""
+    import torch
+
+    fast, dev = [], None
+    for d, s in pairs:
+        if (d.is_cuda and s.is_cuda and d.device == s.device and d.dtype == s.dtype and d.shape == s.shape and d.is_contiguous()
+                and s.is_contiguous() and (dev is None or d.device == dev)):
+            dev = d.device
+            if d.numel():
+                fast.append((d, s))
+        else:
+            d.copy_(s, non_blocking=True)
+    if not fast:
+        return
+    n = len(fast)
+    P, Lg = ctypes.c_void_p * n, ctypes.c_long * n
+    with torch.cuda.device(dev):
+        rc = load().pcm_copy_batch_hip(n, P(*[d.data_ptr() for d, _ in fast]), P(*[s.data_ptr() for _, s in fast]),
+                                       Lg(*[d.numel() * d.element_size() for d, _ in fast]), raw_stream())
+    check(rc, "pcm_copy_batch_hip")
 
 
 def check(rc, name):

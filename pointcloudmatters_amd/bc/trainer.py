@@ -519,8 +519,7 @@ class BCTrainer:
 
     @staticmethod
     def _copy_into(static, batch, _pairs=None):
-        """The batch into the captured step's input tensors: one multi-tensor copy per dtype instead of a copy per tensor
-        (15 tensors in an ACT batch)."""
+        """The batch into the captured step's input tensors: one table-driven copy launch instead of a copy per tensor."""
         pairs = [] if _pairs is None else _pairs
         for k, v in batch.items():
             if isinstance(v, dict):
@@ -528,18 +527,9 @@ class BCTrainer:
             elif torch.is_tensor(v) and static[k] is not v:
                 pairs.append((static[k], v))
         if _pairs is None and pairs:
-            same = [(d, s_) for d, s_ in pairs if d.device == s_.device and d.dtype == s_.dtype and d.shape == s_.shape and d.is_cuda]
-            by_dtype = {}
-            for d, s_ in same:
-                by_dtype.setdefault(d.dtype, []).append((d, s_))
-            done = set()
-            for grp in by_dtype.values():
-                if len(grp) > 1:
-                    torch._foreach_copy_([d for d, _ in grp], [s_ for _, s_ in grp], non_blocking=True)
-                    done.update(id(d) for d, _ in grp)
-            for d, s_ in pairs:
-                if id(d) not in done:
-                    d.copy_(s_, non_blocking=True)
+            from .. import _lib
+
+            _lib.copy_batch(pairs)  # one launch for the whole batch (15 tensors in an ACT batch)
 
     def _reset_grads(self):
         opt = self.optimizer
@@ -668,10 +658,12 @@ class BCTrainer:
             boundary = tuple(self._call_policy(ragged, only=self._subset_a_set, stage="tokenize"))  # eager: shapes follow the clouds
         tokens = boundary[0]
         with torch.no_grad():
-            self._static_tokens.copy_(tokens)
-            for dst, src in zip(self._static_extra, boundary[1:]):
-                dst.copy_(src)
-            self._copy_into(self._static_batch, rest)
+            # boundary tensors + the rest of the batch into the captured graphs' inputs: one table-driven copy launch
+            pairs = [(self._static_tokens, tokens)] + list(zip(self._static_extra, boundary[1:]))
+            self._copy_into(self._static_batch, rest, pairs)
+            from .. import _lib
+
+            _lib.copy_batch(pairs)
         first = self.micro % self.accumulate == 0
         for si, g in enumerate(self._graph if first else self._graph_acc):
             g.replay()

@@ -160,14 +160,16 @@ def install_static(owner, p, o, pre):
 
 
 def load_static(owner, pre):
-    """Copy another batch's sampling result into the static index buffers (one multi-tensor copy on the current stream,
-    after waiting for the side stream that produced it)."""
+    """Copy another batch's sampling result into the static index buffers (one table-driven copy launch on the current
+    stream, after waiting for the side stream that produced it)."""
     static = owner._static_pre["pre"]
     if pre is static:
         return
     if pre.get("event") is not None:
         torch.cuda.current_stream(static["idx"].device).wait_event(pre["event"])
-    torch._foreach_copy_(_pre_tensors(static), _pre_tensors(pre))
+    from .. import _lib
+
+    _lib.copy_batch(list(zip(_pre_tensors(static), _pre_tensors(pre))))
 
 
 def prefetch_sampling(owner, pointops, p, o, n_o, mask=None):

@@ -262,3 +262,28 @@ def test_fused_act_loss_matches_the_framework_chain(dt):
         for x, y in zip(got[3:], want[3:]):
             assert (x - y).abs().max().item() <= tol * y.abs().max().item() + 1e-9
     assert torch.count_nonzero(run(True, (1.0, 0.0, 0.0))[3][is_pad]) == 0  # padded steps carry no gradient
+
+
+def test_copy_batch_moves_every_byte():
+    """pcm_copy_batch_hip through _lib.copy_batch: 70 pairs of mixed dtypes and sizes (empty, 1 byte, unaligned views, > 4 KiB,
+    several MiB) in three launches; non-contiguous / cross-dtype pairs take the framework path."""
+    from pointcloudmatters_amd import _lib
+
+    g = torch.Generator().manual_seed(0)
+    pairs, want = [], []
+    for i in range(70):
+        n = [0, 1, 3, 1000, 4096, 4097, 65536 + 5, 3_000_000][i % 8]
+        dt = [torch.float32, torch.int64, torch.uint8, torch.bfloat16, torch.int32, torch.bool][i % 6]
+        src = (torch.randint(0, 200, (n + 3,), generator=g).to(DEV)).to(dt)
+        dst = torch.zeros(n + 3, dtype=dt, device=DEV)
+        off = i % 3  # views starting at odd element offsets: not 16-byte aligned
+        pairs.append((dst[off: off + n], src[off: off + n]))
+        want.append((dst, src, off, n))
+    strided_dst, strided_src = torch.zeros(8, 6, device=DEV)[:, ::2], torch.randn(8, 3, device=DEV)
+    pairs.append((strided_dst, strided_src))  # falls back to Tensor.copy_
+    _lib.copy_batch(pairs)
+    torch.cuda.synchronize()
+    for dst, src, off, n in want:
+        assert torch.equal(dst[off: off + n], src[off: off + n])
+        assert not dst[:off].any() and not dst[off + n:].any()  # nothing outside the requested range
+    assert torch.equal(strided_dst, strided_src)
