@@ -207,3 +207,43 @@ def test_pointnet_accepts_both_spconv_checkpoint_layouts():
         torch.testing.assert_close(dst.conv1[0](feat), y, rtol=1e-6, atol=1e-6)
         for k, v in src.state_dict().items():
             assert torch.equal(dst.state_dict()[k], v), k
+
+
+def test_deferral_window_host_logic():
+    """policy/deferred.py without a GPU: the window's state machine, the batch-size padding rule, and that nothing is ever
+    queued for host tensors (the producer then reduces / multiplies immediately, as outside a window)."""
+    import torch
+
+    from pointcloudmatters_amd.policy import deferred
+
+    assert not deferred.active()
+    assert deferred.begin() and deferred.active()
+    try:
+        assert not deferred.begin()  # a nested begin does not own the window (its caller must not end it)
+        part, out = torch.zeros(4, 8), torch.zeros(8)
+        assert not deferred.push(part, 4, 8, out_f32=out)  # host tensors: never deferred
+        assert deferred.push_wgrad(torch.zeros(6, 3), torch.zeros(6, 5), torch.float32) is None
+        t = deferred.take((2, 3), torch.float32, "cpu", "site")
+        assert t.shape == (2, 3) and not t.is_cuda
+        assert deferred.flush() == 0
+    finally:
+        deferred.end()
+    assert not deferred.active() and not deferred._W and not deferred._P and not deferred._C
+    assert [deferred._padded(n) for n in (1, 2, 3, 4, 5, 7, 8, 13, 14, 15, 16, 17, 21)] == [1, 2, 4, 4, 5, 8, 8, 13, 16, 16, 16, 17, 21]
+    # what autograd receives for a pending result: another tensor object on the same storage
+    base = torch.zeros(3, 4)
+    h = deferred.handout(base)
+    assert h is not base and h.data_ptr() == base.data_ptr() and h.shape == base.shape
+    # targets / clear: a leaf that already holds a gradient forces the immediate path
+    w = torch.nn.Parameter(torch.zeros(2, 2))
+    ok, leaves = deferred.targets(w, None)
+    assert ok and leaves == [w]
+    assert not deferred.clear(ok, leaves)  # no window
+    assert deferred.begin()
+    try:
+        assert deferred.clear(ok, leaves)
+        w.grad = torch.ones(2, 2)
+        assert not deferred.clear(ok, leaves)
+        assert not deferred.clear(*deferred.targets(w * 2))  # a gradient that passes through another node is never left pending
+    finally:
+        deferred.end()
