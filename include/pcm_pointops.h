@@ -474,6 +474,8 @@ int pcm_reduce_batch_hip(int n, const void *const *partial, const int *nslots, c
  * the input / index staging of a training step that replays captured graphs (what Lightning's batch transfer + the
  * reference's per-tensor `.to(device)` do one tensor at a time, maniskill2_act_bc_module.py:64-86) */
 int pcm_copy_batch_hip(int n, void *const *dst, const void *const *src, const long *nbytes, void *stream);
+/* *counters[i] += 1 for n distinct device int64 counters in one launch per 64 (BatchNorm's num_batches_tracked) */
+int pcm_incr_i64_batch_hip(int n, void *const *counters, void *stream);
 int pcm_colsum_batch_hip(int n, const long *rows, const int *C, const int *ntensors, const int *in_is_bf16, const void *const *g,
                          const long *ld, void *const *partial, void *stream);
 

@@ -100,6 +100,7 @@ SIGNATURES = {
     "pcm_reduce_batch_hip": [_i, _P, _P, _P, _P, _P, _P, _P],
     "pcm_colsum_batch_hip": [_i, _P, _P, _P, _P, _P, _P, _P, _P],
     "pcm_copy_batch_hip": [_i, _P, _P, _P, _P],
+    "pcm_incr_i64_batch_hip": [_i, _P, _P],
     "pcm_colsum_hip": [ctypes.c_long, _i, _i, _i, _P, ctypes.c_long, _P, ctypes.c_long, _P, ctypes.c_long, _P, _i, _P, _P],
     "pcm_attn_small_supported": [_i, _i, _i],
     "pcm_attn_small_forward_hip": [_i, _i, _i, _i, _P, ctypes.c_long, ctypes.c_long, _P, ctypes.c_long, ctypes.c_long, _P, ctypes.c_long, ctypes.c_long, _P, _f, _f, _P, ctypes.c_uint, _P, _P, _P],

@@ -417,6 +417,36 @@ __global__ __launch_bounds__(256) void pcm_copy_batch_kernel(CopyBatch b)
 }
 }  // namespace
 
+namespace {
+constexpr int kIncrBatch = 64;
+struct IncrBatch {
+    long *p[kIncrBatch];
+    int n;
+};
+__global__ void pcm_incr_i64_batch_kernel(IncrBatch b)
+{
+    const int i = threadIdx.x;
+    if (i < b.n) *b.p[i] += 1;
+}
+}  // namespace
+
+extern "C" int pcm_incr_i64_batch_hip(int n, void *const *counters, void *stream)
+{
+    // *counters[i] += 1 for n distinct device int64 counters, 64 per launch: BatchNorm's num_batches_tracked of every layer of a
+    // forward pass (torch.nn.BatchNorm1d increments each with its own one-element launch, pointnet.py:32-46)
+    if (n < 0 || (n > 0 && !counters)) return PCM_ERR_BAD_ARG;
+    for (int i = 0; i < n; ++i)
+        if (!counters[i]) return PCM_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    for (int base = 0; base < n; base += kIncrBatch) {
+        IncrBatch b;
+        b.n = n - base < kIncrBatch ? n - base : kIncrBatch;
+        for (int i = 0; i < b.n; ++i) b.p[i] = (long *)counters[base + i];
+        hipLaunchKernelGGL(pcm_incr_i64_batch_kernel, dim3(1), dim3(64), 0, s, b);
+    }
+    return PCM_LAUNCH_STATUS();
+}
+
 extern "C" int pcm_copy_batch_hip(int n, void *const *dst, const void *const *src, const long *nbytes, void *stream)
 {
     // dst[i][0..nbytes[i]) = src[i][0..nbytes[i]) for n device buffers (host arrays of pointers / sizes), 32 per launch.

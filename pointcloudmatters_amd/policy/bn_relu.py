@@ -111,8 +111,9 @@ def bn_relu(y, bn):
         from .sync_bn import wants_sync
 
         z = _BNReLU.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, bn if wants_sync(bn) else None)
-        with torch.no_grad():
-            bn.num_batches_tracked.add_(1)
+        from . import fused_ops
+
+        fused_ops.count_batch(bn)
         return z
     # eval: the affine comes from the running statistics; same apply kernel, differentiable through framework ops
     if torch.is_grad_enabled() and (y.requires_grad or bn.weight.requires_grad):

@@ -34,6 +34,24 @@ class FusedContext:
         # gradients of a position embedding shared by many attention sites are then summed once (GradSink)
         self.defer_pos_grads = False
         self.sinks = []
+        self.counters = []  # BatchNorm num_batches_tracked tensors of this forward pass: incremented together on exit
+
+    def flush_counters(self):
+        cs, self.counters = self.counters, []
+        if not cs:
+            return
+        import ctypes
+
+        seen, uniq = set(), []
+        for c in cs:  # a module called twice must be counted twice: fall back to single increments for repeats
+            if c.data_ptr() in seen:
+                c.add_(1)
+            else:
+                seen.add(c.data_ptr())
+                uniq.append(c)
+        with torch.cuda.device(self.device):
+            rc = _lib.load().pcm_incr_i64_batch_hip(len(uniq), (ctypes.c_void_p * len(uniq))(*[c.data_ptr() for c in uniq]), _raw_stream())
+        _lib.check(rc, "pcm_incr_i64_batch_hip")
 
     def flush_sinks(self):
         for sink in self.sinks:
@@ -60,10 +78,24 @@ def activate(ctx):
         yield ctx
     finally:
         _ACTIVE = prev
+        if ctx is not None and ctx.counters:
+            with torch.no_grad():
+                ctx.flush_counters()
 
 
 def current():
     return _ACTIVE
+
+
+def count_batch(bn):
+    """bn.num_batches_tracked += 1: queued on the active FusedContext (one launch for all layers when it exits), else now."""
+    ctx, c = _ACTIVE, bn.num_batches_tracked
+    if ctx is not None and c is not None and c.is_cuda and c.dtype == torch.int64 and c.device == ctx.device and c.numel() == 1:
+        ctx.counters.append(c)
+        return
+    if c is not None:
+        with torch.no_grad():
+            c.add_(1)
 
 
 class GradSink:

@@ -245,6 +245,7 @@ def sa_fused_forward(owner, p, x, n_p, fps_idx, knn_idx, o=None, n_o=None, istat
 
     z, _ = _SAFused.apply(gf.contiguous(), ent, w[:, :3], bn.weight, bn.bias, bn.running_mean, bn.running_var,
                           bn.eps, bn.momentum, o32, no32, n_max, stats, bn if wants_sync(bn) else None, csr)
-    with torch.no_grad():
-        bn.num_batches_tracked.add_(1)
+    from . import fused_ops
+
+    fused_ops.count_batch(bn)
     return z

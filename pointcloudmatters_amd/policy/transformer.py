@@ -285,6 +285,27 @@ class _PackRows(torch.autograd.Function):
         return tuple(res)
 
 
+_ZEROS = {}
+
+
+def _zeros_like_cached(ref):
+    """zeros_like(ref) without a fill launch per step: the decoder's all-zero input (transformer.py:99) is read-only, so one
+    buffer per (shape, dtype, device) serves every step.  Never cached while a graph is being captured (the buffer would live
+    in that graph's pool); the trainer's eager warm-up runs create it first."""
+    if not ref.is_cuda:
+        return torch.zeros_like(ref)
+    key = (tuple(ref.shape), ref.dtype, ref.device)
+    z = _ZEROS.get(key)
+    if z is None:
+        z = torch.zeros(ref.shape, dtype=ref.dtype, device=ref.device)
+        if torch.cuda.is_current_stream_capturing():
+            return z
+        if len(_ZEROS) > 16:
+            _ZEROS.clear()
+        _ZEROS[key] = z
+    return z
+
+
 def split_packed(w):
     """The three row blocks of a packed (3E, ...) parameter; their gradients may stay pending inside a deferral window (the
     node copies them into the packed gradient at the end of the stage, after everything that produces them)."""
@@ -449,7 +470,7 @@ class TransformerDecoder(nn.Module):
         self.return_intermediate = return_intermediate
         self.batch_memory_kv = True
 
-    def _project_memory(self, memory, memory_pos):
+    def _project_memory(self, memory, pos):
         """Keys / values of the memory for ALL layers with two GEMMs (S x E)(E x L*E) instead of 2L small
         ones -- and, in backward, two input-gradient GEMMs instead of 2L plus 2L-2 accumulations of the
         (B, S, E) memory gradient.  Same per-layer weights, same sums up to fp32 re-association."""
@@ -466,7 +487,15 @@ class TransformerDecoder(nn.Module):
             wq.append(w_q), wk.append(w_k), wv.append(w_v), bq.append(b_q), bk.append(b_k), bv.append(b_v)
         n = len(self.layers)
         wk_all, bk_all, wv_all, bv_all = pack_rows(wk, bk, wv, bv)
-        k_all = shared_unbind(linear_rows(memory_pos, wk_all, bk_all), n)
+        from . import fused_ops
+
+        if pos is not None and fused_ops.add_pos_linear_supported(memory, pos, wk_all, bk_all):
+            # keys = W_k (memory + pos): add + cast in one launch inside the projection's node, input gradient in fp32 straight
+            # out of the GEMM (the framework chain: an add, a cast, and a cast back in backward)
+            keys = fused_ops.add_pos_linear(memory, pos, wk_all, bk_all)
+        else:
+            keys = linear_rows(_add_pos(memory, pos), wk_all, bk_all)
+        k_all = shared_unbind(keys, n)
         v_all = shared_unbind(linear_rows(memory, wv_all, bv_all), n)
         return list(zip(k_all, v_all, wq, bq))
 
@@ -480,11 +509,12 @@ class TransformerDecoder(nn.Module):
 
     def forward(self, tgt, memory, memory_key_padding_mask=None, pos=None, query_pos=None):
         out = tgt
-        memory_pos = _add_pos(memory, pos)
         layers = self.layers if not (self.return_intermediate and self.first_only == "skip") else self.layers[:1]
         if self.batch_memory_kv and len(layers) == len(self.layers):
-            kvs = self._project_memory(memory, memory_pos)
+            kvs = self._project_memory(memory, pos)
+            memory_pos = None  # the layers get their keys / values projected: nobody reads memory + pos
         else:
+            memory_pos = _add_pos(memory, pos)
             kvs = [None] * len(layers)
         inter = []
         for li, (layer, kv) in enumerate(zip(layers, kvs)):
@@ -555,5 +585,5 @@ class Transformer(nn.Module):
             from . import fused_ops
 
             query_pos = fused_ops.defer_grads(query_pos)  # 14 gradient sites -> one sum (no-op unless a training loop opted in)
-        tgt = torch.zeros_like(query_pos)
+        tgt = _zeros_like_cached(query_pos)
         return self.decoder(tgt, memory, memory_key_padding_mask=mask, pos=pos_dec, query_pos=query_pos)
