@@ -479,6 +479,17 @@ int pcm_incr_i64_batch_hip(int n, void *const *counters, void *stream);
 int pcm_colsum_batch_hip(int n, const long *rows, const int *C, const int *ntensors, const int *in_is_bf16, const void *const *g,
                          const long *ld, void *const *partial, void *stream);
 
+/* ---- the CVAE latent head (src/models/components/act/act.py:175-181, act/utils.py:36-39) in one launch each way ------------
+ * latent_info (B, 2D) fp32 or bf16 = [mu | logvar]; z (B, D) fp32 = mu + exp(logvar / 2) * eps with the framework's roundings
+ * under bf16 autocast (the halving in the input dtype, exp / product / sum in fp32); eps_in (B, D) fp32 when the caller
+ * supplies the noise (parity tests), else NULL: drawn from the counter hash of the dropout masks (seed: device int64, site).
+ * Also writes contiguous copies mu, logvar (B, D, input dtype) for the KL term and eps_out / std_out (fp32) for backward.
+ * backward: d_latent_info[:, :D] = T(dz) + dmu, [:, D:] = T((dz*eps)*std)/2 + dlogvar (any of dz / dmu / dlogvar may be NULL). */
+int pcm_cvae_latent_forward_hip(int B, int D, int is_bf16, const void *latent_info, const float *eps_in, const long *seed,
+                                unsigned site, float *z, void *mu, void *logvar, float *eps_out, float *std_out, void *stream);
+int pcm_cvae_latent_backward_hip(int B, int D, int is_bf16, const float *dz, const void *dmu, const void *dlogvar,
+                                 const float *eps, const float *std_, void *d_latent_info, void *stream);
+
 /* ---- the ACT training loss (src/models/components/act/act.py:281-291, loss/misc.py:10-26) in one launch each way -----------
  * a_hat (B, Q, A) fp32 or bf16, actions (B, Q, A) fp32, is_pad (B, Q) bytes (non-zero = padded), mu / logvar (B, D) fp32 or
  * bf16; n = B*Q*A, bd = B*D.  action = mean over ALL n elements of (a_hat - actions)^2 * !is_pad (MSELoss(reduction="none")

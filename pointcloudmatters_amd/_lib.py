@@ -95,6 +95,8 @@ SIGNATURES = {
     "pcm_coord_embed_sine_hip": [ctypes.c_long, _i, _i, _P, _P, _P, _P],
     "pcm_act_loss_forward_hip": [_i, _i, _i, _i, _i, _P, _P, _P, _i, _P, _P, ctypes.c_float, _P, _P, _P, _P, _P],
     "pcm_act_loss_backward_hip": [_i, _i, _P, _P, _P, ctypes.c_float, _P, _P, _P, _i, _P, _i, _P, _P, _P],
+    "pcm_cvae_latent_forward_hip": [_i, _i, _i, _P, _P, _P, ctypes.c_uint, _P, _P, _P, _P, _P, _P],
+    "pcm_cvae_latent_backward_hip": [_i, _i, _i, _P, _P, _P, _P, _P, _P, _P],
     "pcm_colsum_slots": [ctypes.c_long, _i],
     "pcm_slab_sum_hip": [_i, ctypes.c_long, _P, _i, _P, _P],
     "pcm_reduce_batch_hip": [_i, _P, _P, _P, _P, _P, _P, _P],

@@ -357,6 +357,108 @@ extern "C" int pcm_act_loss_backward_hip(int n, int bd, const float *g_loss, con
     return PCM_LAUNCH_STATUS();
 }
 
+namespace {
+// ---- CVAE latent head (act.py:175-181 + act/utils.py:36-39): mu | logvar = split(latent_info), z = mu + exp(logvar / 2) * eps,
+// with the framework's roundings under bf16 autocast reproduced: logvar / 2 in the input dtype, exp and the product in fp32,
+// the sum in fp32.  eps is given (parity tests) or drawn here from the counter hash of the dropout masks (Box-Muller on two
+// hashes of (seed, site, element)): no framework RNG inside the captured step.  Also emits contiguous copies of mu and
+// logvar for the KL term.  One launch each way (the framework chain: 9 forward, ~12 backward launches on 256 elements).
+__device__ __forceinline__ float hash_normal(uint64_t seed, uint32_t site, uint32_t e)
+{
+    const uint32_t k = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9E3779B9u) ^ (site * 0x85EBCA6Bu);
+    const uint32_t h1 = mix32(mix32((2u * e) ^ k) + k), h2 = mix32(mix32((2u * e + 1u) ^ k) + k);
+    const float u1 = ((float)(h1 >> 8) + 1.f) * (1.f / 16777216.f);  // (0, 1]
+    const float u2 = (float)(h2 >> 8) * (1.f / 16777216.f);          // [0, 1)
+    return sqrtf(-2.f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pcm_cvae_latent_fwd_kernel(int B, int D, const T *__restrict__ info, const float *__restrict__ eps_in,
+                                                                  const long *__restrict__ seed_ptr, unsigned site, float *__restrict__ z,
+                                                                  T *__restrict__ mu_c, T *__restrict__ lv_c, float *__restrict__ eps_out,
+                                                                  float *__restrict__ std_out)
+{
+    const int n = B * D;
+    const uint64_t seed = eps_in == nullptr ? (uint64_t)seed_ptr[0] : 0ull;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int b = i / D, d = i - b * D;
+        const T m = info[(size_t)b * 2 * D + d], lv = info[(size_t)b * 2 * D + D + d];
+        T half;
+        pcm_store(&half, pcm_to_float(lv) / 2.f);  // logvar.div(2) in the input dtype
+        const float sd = expf(pcm_to_float(half));
+        const float e = eps_in != nullptr ? eps_in[i] : hash_normal(seed, site, (uint32_t)i);
+        const float prod = sd * e;
+        z[i] = pcm_to_float(m) + prod;
+        mu_c[i] = m, lv_c[i] = lv;
+        eps_out[i] = e, std_out[i] = sd;
+    }
+}
+
+// d_info[b][d] = dz (rounded to T) + dmu ; d_info[b][D + d] = T((dz * eps) * std) / 2 + dlv   (each sum rounded to T: what the
+// engine's accumulation of the two gradients of mu / logvar does)
+template <typename T>
+__global__ __launch_bounds__(256) void pcm_cvae_latent_bwd_kernel(int B, int D, const float *__restrict__ dz, const T *__restrict__ dmu,
+                                                                  const T *__restrict__ dlv, const float *__restrict__ eps,
+                                                                  const float *__restrict__ sd, T *__restrict__ dinfo)
+{
+    const int n = B * D;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int b = i / D, d = i - b * D;
+        float gm = 0.f, gl = 0.f;
+        if (dz != nullptr) {
+            T t;
+            pcm_store(&t, dz[i]);
+            gm = pcm_to_float(t);
+            const float a = dz[i] * eps[i];
+            pcm_store(&t, a * sd[i]);
+            T h;
+            pcm_store(&h, pcm_to_float(t) / 2.f);
+            gl = pcm_to_float(h);
+        }
+        if (dmu != nullptr) gm = dz != nullptr ? gm + pcm_to_float(dmu[i]) : pcm_to_float(dmu[i]);
+        if (dlv != nullptr) gl = dz != nullptr ? gl + pcm_to_float(dlv[i]) : pcm_to_float(dlv[i]);
+        pcm_store(dinfo + (size_t)b * 2 * D + d, gm);
+        pcm_store(dinfo + (size_t)b * 2 * D + D + d, gl);
+    }
+}
+}  // namespace
+
+extern "C" int pcm_cvae_latent_forward_hip(int B, int D, int is_bf16, const void *latent_info, const float *eps_in, const long *seed,
+                                           unsigned site, float *z, void *mu, void *logvar, float *eps_out, float *std_out, void *stream)
+{
+    if (B < 0 || D <= 0 || (long)B * D > 0x7FFFFFFF) return PCM_ERR_BAD_ARG;
+    if (B == 0) return PCM_OK;
+    if (!latent_info || !z || !mu || !logvar || !eps_out || !std_out || (!eps_in && !seed)) return PCM_ERR_BAD_ARG;
+    const int n = B * D;
+    const int blocks = (n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024;
+    hipStream_t st = (hipStream_t)stream;
+    if (is_bf16)
+        hipLaunchKernelGGL(pcm_cvae_latent_fwd_kernel<__hip_bfloat16>, dim3(blocks), dim3(256), 0, st, B, D, (const __hip_bfloat16 *)latent_info,
+                           eps_in, seed, site, z, (__hip_bfloat16 *)mu, (__hip_bfloat16 *)logvar, eps_out, std_out);
+    else
+        hipLaunchKernelGGL(pcm_cvae_latent_fwd_kernel<float>, dim3(blocks), dim3(256), 0, st, B, D, (const float *)latent_info, eps_in, seed,
+                           site, z, (float *)mu, (float *)logvar, eps_out, std_out);
+    return PCM_LAUNCH_STATUS();
+}
+
+extern "C" int pcm_cvae_latent_backward_hip(int B, int D, int is_bf16, const float *dz, const void *dmu, const void *dlogvar,
+                                            const float *eps, const float *std_, void *d_latent_info, void *stream)
+{
+    if (B < 0 || D <= 0 || (long)B * D > 0x7FFFFFFF) return PCM_ERR_BAD_ARG;
+    if (B == 0) return PCM_OK;
+    if (!d_latent_info || (dz && (!eps || !std_))) return PCM_ERR_BAD_ARG;
+    const int n = B * D;
+    const int blocks = (n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024;
+    hipStream_t st = (hipStream_t)stream;
+    if (is_bf16)
+        hipLaunchKernelGGL(pcm_cvae_latent_bwd_kernel<__hip_bfloat16>, dim3(blocks), dim3(256), 0, st, B, D, dz, (const __hip_bfloat16 *)dmu,
+                           (const __hip_bfloat16 *)dlogvar, eps, std_, (__hip_bfloat16 *)d_latent_info);
+    else
+        hipLaunchKernelGGL(pcm_cvae_latent_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, B, D, dz, (const float *)dmu,
+                           (const float *)dlogvar, eps, std_, (float *)d_latent_info);
+    return PCM_LAUNCH_STATUS();
+}
+
 extern "C" int pcm_coord_embed_sine_hip(long m, int H, int npf, const float *coord, const float *dim_t, float *out, void *stream)
 {
     if (m < 0 || H <= 0 || npf <= 0 || (npf & 1) || 3 * npf > H) return PCM_ERR_BAD_ARG;

@@ -167,9 +167,16 @@ class ACTPCD(nn.Module):
             pad = torch.cat([is_pad.new_zeros(bs, 2), is_pad], dim=1)  # CLS / qpos are never padding
             enc_out = self.encoder(enc_in, pos=self.pos_table, src_key_padding_mask=pad)
             latent_info = self.latent_proj(enc_out[:, 0])  # CLS token
-            mu = latent_info[:, : self.latent_dim]
-            logvar = latent_info[:, self.latent_dim :]
-            latent_sample = reparametrize(mu, logvar, data_dict.get("vae_eps", None))
+            from . import fused_ops
+
+            eps = data_dict.get("vae_eps", None)
+            if fused_ops.cvae_latent_supported(latent_info, self.latent_dim, eps):
+                # split + reparametrisation (+ contiguous mu / logvar for the KL term) in one launch each way
+                latent_sample, mu, logvar = fused_ops.cvae_latent(latent_info, eps)
+            else:
+                mu = latent_info[:, : self.latent_dim]
+                logvar = latent_info[:, self.latent_dim :]
+                latent_sample = reparametrize(mu, logvar, eps)
         else:
             mu = logvar = None
             latent_sample = torch.zeros([bs, self.latent_dim], dtype=torch.float32, device=qpos.device)

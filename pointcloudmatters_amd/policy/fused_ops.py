@@ -715,3 +715,62 @@ def act_loss(a_hat, actions, is_pad, mu, logvar, kl_weight):
     """-> (loss, action_loss, kl_loss), the three scalars of ACT.forward_loss."""
     return _ActLoss.apply(a_hat.contiguous(), actions.contiguous(), is_pad.contiguous().view(torch.uint8), mu.contiguous(),
                           logvar.contiguous(), kl_weight)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# CVAE latent head in one launch each way (csrc/tokens.hip pcm_cvae_latent_*): split, reparametrisation, contiguous mu /
+# logvar for the KL term -- and no framework RNG inside the captured step (the noise comes from the dropout masks' counter hash).
+class _CVAELatent(Function):
+    @staticmethod
+    def forward(ctx, info, eps, seed, site):
+        L = _lib.load()
+        B, D2 = info.shape
+        D = D2 // 2
+        dev = info.device
+        info = info.contiguous()
+        bf = info.dtype == torch.bfloat16
+        with torch.cuda.device(dev):
+            z = torch.empty(B, D, dtype=torch.float32, device=dev)
+            mu = torch.empty(B, D, dtype=info.dtype, device=dev)
+            lv = torch.empty(B, D, dtype=info.dtype, device=dev)
+            ws = torch.empty(2, B, D, dtype=torch.float32, device=dev)  # eps | std
+            e = eps.float().contiguous() if eps is not None else None
+            rc = L.pcm_cvae_latent_forward_hip(B, D, int(bf), info.data_ptr(), e.data_ptr() if e is not None else 0,
+                                               seed.data_ptr() if seed is not None else 0, int(site), z.data_ptr(), mu.data_ptr(),
+                                               lv.data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(), _raw_stream())
+        _lib.check(rc, "pcm_cvae_latent_forward_hip")
+        ctx.save_for_backward(ws)
+        ctx.meta = (B, D, info.dtype)
+        ctx.set_materialize_grads(False)
+        return z, mu, lv
+
+    @staticmethod
+    def backward(ctx, dz, dmu, dlv):
+        (ws,) = ctx.saved_tensors
+        B, D, dt = ctx.meta
+        if dz is None and dmu is None and dlv is None:
+            return None, None, None, None
+        L = _lib.load()
+        dev = ws.device
+        with torch.cuda.device(dev):
+            dz = dz.float().contiguous() if dz is not None else None
+            dmu = dmu.to(dt).contiguous() if dmu is not None else None
+            dlv = dlv.to(dt).contiguous() if dlv is not None else None
+            dinfo = torch.empty(B, 2 * D, dtype=dt, device=dev)
+            rc = L.pcm_cvae_latent_backward_hip(B, D, int(dt == torch.bfloat16), dz.data_ptr() if dz is not None else 0,
+                                                dmu.data_ptr() if dmu is not None else 0, dlv.data_ptr() if dlv is not None else 0,
+                                                ws[0].data_ptr(), ws[1].data_ptr(), dinfo.data_ptr(), _raw_stream())
+        _lib.check(rc, "pcm_cvae_latent_backward_hip")
+        return dinfo, None, None, None
+
+
+def cvae_latent_supported(info, latent_dim, eps):
+    return (_ACTIVE is not None and info.is_cuda and info.dim() == 2 and info.shape[1] == 2 * latent_dim
+            and info.dtype in (torch.float32, torch.bfloat16) and (eps is None or (eps.is_cuda and tuple(eps.shape) == (info.shape[0], latent_dim))))
+
+
+def cvae_latent(info, eps=None):
+    """(latent_sample fp32, mu, logvar) from latent_info = [mu | logvar]; eps None: noise from the context's counter hash."""
+    ctx = _ACTIVE
+    return _CVAELatent.apply(info, eps, ctx.seed if eps is None else None, ctx.next_site())
+

@@ -287,3 +287,68 @@ def test_copy_batch_moves_every_byte():
         assert torch.equal(dst[off: off + n], src[off: off + n])
         assert not dst[:off].any() and not dst[off + n:].any()  # nothing outside the requested range
     assert torch.equal(strided_dst, strided_src)
+
+
+@pytest.mark.parametrize("autocast", [True, False])
+def test_cvae_latent_node_matches_the_framework_chain(autocast):
+    """fused_ops.cvae_latent (split + reparametrisation + contiguous mu / logvar, one launch each way) against the chain of
+    act.py:175-181 with the same eps: sample, mu, logvar and the gradient of latent_info (reparametrisation AND KL paths)
+    bit for bit, in fp32 and under bf16 autocast (whose roundings the kernel reproduces)."""
+    from pointcloudmatters_amd.policy import fused_ops
+    from pointcloudmatters_amd.policy.act import reparametrize
+    from pointcloudmatters_amd.policy.losses import KLDivergence
+
+    torch.manual_seed(0)
+    B, D, H = 8, 32, 512
+    x = torch.randn(B, H, device=DEV)
+    lin = nn.Linear(H, 2 * D).to(DEV)
+    eps = torch.randn(B, D, device=DEV)
+    wz = torch.randn(B, D, device=DEV)
+    kl = KLDivergence()
+
+    def run(fused):
+        lin.zero_grad()
+        xx = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast), fused_ops.activate(fused_ops.FusedContext(DEV)):
+            info = lin(xx)
+            info.retain_grad()
+            if fused:
+                assert fused_ops.cvae_latent_supported(info, D, eps)
+                z, mu, lv = fused_ops.cvae_latent(info, eps)
+            else:
+                mu, lv = info[:, :D], info[:, D:]
+                z = reparametrize(mu, lv, eps)
+            loss = (z * wz).sum() + 3.0 * kl(mu, lv)
+        loss.backward()
+        return z.detach(), mu.detach().clone(), lv.detach().clone(), info.grad.clone(), xx.grad.clone()
+
+    a, b = run(True), run(False)
+    assert a[0].dtype == torch.float32 and a[1].dtype == (torch.bfloat16 if autocast else torch.float32)
+    for i, (u, v) in enumerate(zip(a, b)):
+        assert torch.equal(u, v), (i, (u.float() - v.float()).abs().max().item())
+
+
+def test_cvae_latent_noise_is_standard_normal():
+    """Without a supplied eps the noise comes from the counter hash (Box-Muller): mean 0, variance 1, no visible correlation
+    between neighbours, a new draw per seed / site, the same draw for the same (seed, site)."""
+    from pointcloudmatters_amd.policy import fused_ops
+
+    B, D = 4096, 64
+    info = torch.zeros(B, 2 * D, device=DEV)  # mu = 0, logvar = 0: z = eps
+    ctx = fused_ops.FusedContext(DEV)
+    with fused_ops.activate(ctx):
+        z1, _, _ = fused_ops.cvae_latent(info)
+        z2, _, _ = fused_ops.cvae_latent(info)  # next site
+    with fused_ops.activate(ctx):
+        z3, _, _ = fused_ops.cvae_latent(info)  # site counter restarted, same seed: the same draw
+    ctx.set_step(7)
+    with fused_ops.activate(ctx):
+        z4, _, _ = fused_ops.cvae_latent(info)
+    torch.cuda.synchronize()
+    assert torch.equal(z1, z3) and not torch.equal(z1, z2) and not torch.equal(z1, z4)
+    for z in (z1, z2, z4):
+        n = z.numel()
+        assert abs(z.mean().item()) < 4 / n ** 0.5 and abs(z.var().item() - 1) < 0.02
+        assert abs((z[:, 1:] * z[:, :-1]).mean().item()) < 5 / n ** 0.5
+        assert abs((z.abs() < 1).float().mean().item() - 0.6827) < 0.005 and z.abs().max().item() < 6.5
+    assert abs((z1 * z2).mean().item()) < 5 / z1.numel() ** 0.5
