@@ -207,13 +207,16 @@ def _emit_args(emit, R, E, dev):
     if emit is None:
         return (0, 0, 0, 0), None
     posc = emit["posc"]
-    sum16 = deferred.take((R, E), torch.bfloat16, dev, emit["tags"][0])
-    x16 = deferred.take((R, E), torch.bfloat16, dev, emit["tags"][1]) if emit["x16"] else None
+    if emit["x16"]:  # the in-projection's pair: one (2, R, E) buffer, so that it can run as ONE product ([x + pos ; x])
+        sum16, x16 = deferred.take((2, R, E), torch.bfloat16, dev, emit["tags"][0]).unbind(0)
+    else:
+        sum16, x16 = deferred.take((R, E), torch.bfloat16, dev, emit["tags"][0]), None
     return (posc.data_ptr(), posc.numel(), sum16.data_ptr(), x16.data_ptr() if x16 is not None else 0), \
         {"pos": emit["pos"], "posc": posc, "sum16": sum16, "x16": x16}
 
 
 EMIT_OPERANDS = os.environ.get("PCM_EMIT_OPERANDS", "1") != "0"  # A/B switch (and tests: bit-identical either way)
+INPROJ_MERGE_ROWS = int(os.environ.get("PCM_INPROJ_MERGE_ROWS", 2048))  # below this many rows q | k and v come from ONE product
 
 
 def emit_for(pos, x_shape, x16, tags):
@@ -490,14 +493,22 @@ class _SelfAttnInProj(Function):
             qk_in, v_in = em["sum16"], em["x16"]
         else:
             with torch.cuda.device(dev):
-                qk_in = deferred.take((rows, E), bf, dev, "in_proj.qk")
-                v_in = deferred.take((rows, E), bf, dev, "in_proj.v")
+                qk_in, v_in = deferred.take((2, rows, E), bf, dev, "in_proj.qkv").unbind(0)  # adjacent: see the merged product
                 rc = L.pcm_add_cast2_hip(x2.numel(), posc.numel(), x2.data_ptr(), posc.data_ptr(), qk_in.data_ptr(), v_in.data_ptr(),
                                          _raw_stream())
             _lib.check(rc, "pcm_add_cast2_hip")
         with torch.autocast("cuda", enabled=False):
-            qk = torch.nn.functional.linear(qk_in, wc[: 2 * E], bc[: 2 * E]).view(*shape[:-1], 2, E)
-            v = torch.nn.functional.linear(v_in, wc[2 * E:], bc[2 * E:]).view(shape)
+            if (INPROJ_MERGE_ROWS > rows and v_in.data_ptr() - qk_in.data_ptr() == rows * E * 2 and qk_in.is_contiguous()
+                    and v_in.is_contiguous() and qk_in.untyped_storage().data_ptr() == v_in.untyped_storage().data_ptr()):
+                # short activations (the decoder's 800 rows): ONE product [x + pos ; x] (2R, E) @ W^T (E, 3E) instead of two -- twice
+                # the arithmetic (the off-diagonal blocks are discarded), but these products sit at the launch floor: 11 us vs
+                # 10 + 8.  q | k and v are strided views of its result (the attention kernels take row strides).
+                y = torch.nn.functional.linear(torch.as_strided(qk_in, (2 * rows, E), (E, 1)), wc, bc)
+                qk = y[:rows, : 2 * E].unflatten(-1, (2, E)).unflatten(0, shape[:-1])
+                v = y[rows:, 2 * E:].unflatten(0, shape[:-1])
+            else:
+                qk = torch.nn.functional.linear(qk_in, wc[: 2 * E], bc[: 2 * E]).view(*shape[:-1], 2, E)
+                v = torch.nn.functional.linear(v_in, wc[2 * E:], bc[2 * E:]).view(shape)
         ctx.save_for_backward(qk_in, v_in, wc)
         ctx.sink = getattr(pos, "_pcm_sink", None)
         ctx.meta = (shape, pos.shape, w.dtype, b.dtype, pos.requires_grad or ctx.sink is not None)

@@ -88,7 +88,7 @@ def _ffn_norm(layer, norm: nn.Module, dropout_out: nn.Module, x: Tensor, n_out: 
         if n_out > 1 and not torch.is_grad_enabled():
             return (fused_ops.ffn_ln(x, layer.linear1, layer.linear2, norm, layer.dropout, dropout_out),) * n_out
         # emit_pos: the NEXT layer's in-projection (q = k = out + pos, v = out) finds its bf16 inputs ready
-        emit = fused_ops.emit_for(emit_pos, x.shape, True, ("in_proj.qk", "in_proj.v")) if emit_pos is not None else None
+        emit = fused_ops.emit_for(emit_pos, x.shape, True, ("in_proj.qkv", None)) if emit_pos is not None else None
         return fused_ops.ffn_ln(x, layer.linear1, layer.linear2, norm, layer.dropout, dropout_out, n_out=n_out, emit=emit)
     out = _add_norm(norm, dropout_out, x, layer._ffn(x))
     return out if n_out == 1 else (out,) * n_out
