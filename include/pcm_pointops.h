@@ -452,6 +452,10 @@ int pcm_add2_cast2_hip(long n, const void *a_bf16, const void *b_bf16, float *ou
 /* same with a third, fp32 addend c (nullable): out = f32(a) + f32(b) + c */
 int pcm_add3_cast2_hip(long n, const void *a_bf16, const void *b_bf16, const float *c_f32, float *out, float *a_f32,
                        void *stream);
+/* same with the first addend in two parts: out = (f32(a) + f32(a2)) + f32(b) [+ c], a_f32 (nullable) = f32(a) + f32(a2) -- the
+ * three input gradients dq W_q, dk W_k, dv W_v of a self-attention in-projection out of ONE batched product */
+int pcm_add4_cast2_hip(long n, const void *a_bf16, const void *a2_bf16, const void *b_bf16, const float *c_f32, float *out,
+                       float *a_f32, void *stream);
 int pcm_colsum_slots(long rows, int C);
 /* out[e] = sum over nslabs of partial[s*n + e] (fp64, fixed order), written as fp32 or bf16: closes a split-K product */
 int pcm_slab_sum_hip(int nslabs, long n, const float *partial, int out_is_bf16, void *out, void *stream);

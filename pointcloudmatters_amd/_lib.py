@@ -92,6 +92,7 @@ SIGNATURES = {
     "pcm_add2_cast_hip": [ctypes.c_long, _P, _P, _P, _P],
     "pcm_add2_cast2_hip": [ctypes.c_long, _P, _P, _P, _P, _P],
     "pcm_add3_cast2_hip": [ctypes.c_long, _P, _P, _P, _P, _P, _P],
+    "pcm_add4_cast2_hip": [ctypes.c_long, _P, _P, _P, _P, _P, _P, _P],
     "pcm_coord_embed_sine_hip": [ctypes.c_long, _i, _i, _P, _P, _P, _P],
     "pcm_act_loss_forward_hip": [_i, _i, _i, _i, _i, _P, _P, _P, _i, _P, _P, ctypes.c_float, _P, _P, _P, _P, _P],
     "pcm_act_loss_backward_hip": [_i, _i, _P, _P, _P, ctypes.c_float, _P, _P, _P, _i, _P, _i, _P, _P, _P],

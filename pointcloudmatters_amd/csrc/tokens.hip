@@ -42,11 +42,18 @@ __global__ __launch_bounds__(kBlock) void pcm_add_cast2_kernel(long n4, long pos
 
 __global__ __launch_bounds__(kBlock) void pcm_add2_cast_kernel(long n4, const __hip_bfloat16 *__restrict__ a,
                                                                const __hip_bfloat16 *__restrict__ b, float *__restrict__ out,
-                                                               float *__restrict__ a32, const float *__restrict__ c32)
+                                                               float *__restrict__ a32, const float *__restrict__ c32,
+                                                               const __hip_bfloat16 *__restrict__ a2)
 {
     for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (long)gridDim.x * kBlock) {
         float x[4], y[4], o[4];
         load4<__hip_bfloat16>(a + i * 4, x);
+        if (a2 != nullptr) {  // the first addend arrives in two parts (dq W_q + dk W_k of a batched product): a := a + a2
+            float x2[4];
+            load4<__hip_bfloat16>(a2 + i * 4, x2);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[u] += x2[u];
+        }
         load4<__hip_bfloat16>(b + i * 4, y);
 #pragma unroll
         for (int u = 0; u < 4; ++u) o[u] = x[u] + y[u];
@@ -222,7 +229,18 @@ extern "C" int pcm_add3_cast2_hip(long n, const void *a_bf16, const void *b_bf16
     if (n == 0) return PCM_OK;
     if (n < 0 || n % 4) return PCM_ERR_BAD_ARG;
     hipLaunchKernelGGL(pcm_add2_cast_kernel, dim3(ew_grid(n / 4)), dim3(kBlock), 0, (hipStream_t)stream, n / 4,
-                       (const __hip_bfloat16 *)a_bf16, (const __hip_bfloat16 *)b_bf16, out, a_f32, c_f32);
+                       (const __hip_bfloat16 *)a_bf16, (const __hip_bfloat16 *)b_bf16, out, a_f32, c_f32, (const __hip_bfloat16 *)nullptr);
+    return PCM_LAUNCH_STATUS();
+}
+
+extern "C" int pcm_add4_cast2_hip(long n, const void *a_bf16, const void *a2_bf16, const void *b_bf16, const float *c_f32, float *out,
+                                  float *a_f32, void *stream)
+{
+    // out = (f32(a) + f32(a2)) + f32(b) [+ c]; a_f32 (nullable) = f32(a) + f32(a2)
+    if (n == 0) return PCM_OK;
+    if (n < 0 || n % 4 || !a_bf16 || !a2_bf16 || !b_bf16 || !out) return PCM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(pcm_add2_cast_kernel, dim3(ew_grid(n / 4)), dim3(kBlock), 0, (hipStream_t)stream, n / 4,
+                       (const __hip_bfloat16 *)a_bf16, (const __hip_bfloat16 *)b_bf16, out, a_f32, c_f32, (const __hip_bfloat16 *)a2_bf16);
     return PCM_LAUNCH_STATUS();
 }
 

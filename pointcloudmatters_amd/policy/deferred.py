@@ -162,6 +162,17 @@ def take(shape, dtype, device, tag=None):
     return t
 
 
+def _extent_bytes(t):
+    """Bytes from t's first to one past its last element, for the layouts a batched product can address: contiguous, or a
+    2-D row-strided matrix (a column block of a wider buffer: dq | dk of a joint dq | dk | dv gradient).  None otherwise."""
+    es = t.element_size()
+    if t.is_contiguous():
+        return t.numel() * es
+    if t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1] and t.shape[0] > 0:
+        return ((t.shape[0] - 1) * t.stride(0) + t.shape[1]) * es
+    return None
+
+
 def _as_batch(ts, nb):
     """The tensors of `ts` (same shape, contiguous) as one (n', ...) strided view when they sit at a uniform stride in one
     storage: n' = nb if that many slots fit in the storage, else len(ts).  None when they do not line up."""
@@ -170,14 +181,15 @@ def _as_batch(ts, nb):
     if len(ts) < 2:
         return None
     d = ts[1].data_ptr() - p0
-    if d <= 0 or d % es or d < t0.numel() * es or not t0.is_contiguous():
+    ext = _extent_bytes(t0)
+    if ext is None or d <= 0 or d % es or d < ext or any(t.stride() != t0.stride() for t in ts):
         return None
     st = t0.untyped_storage()
     base = st.data_ptr()
     for i, t in enumerate(ts):
         if t.data_ptr() - p0 != i * d or t.untyped_storage().data_ptr() != base:
             return None
-    n = nb if p0 + (nb - 1) * d + t0.numel() * es <= base + st.nbytes() else len(ts)
+    n = nb if p0 + (nb - 1) * d + ext <= base + st.nbytes() else len(ts)
     return torch.as_strided(t0, (n,) + tuple(t0.shape), (d // es,) + tuple(t0.stride()))
 
 
@@ -195,13 +207,13 @@ def push_wgrad(go, x, out_dtype, out=None, tag=None):
     a contiguous (m, k) tensor or slice, when given), or None when the caller should compute it now (no window, batching
     off, or a shape that came fewer than WGRAD_MIN_GROUP times in the last stage that had it)."""
     if _Q is None or not BATCH_WGRADS or not go.is_cuda or go.dtype != x.dtype or go.dtype not in (torch.bfloat16, torch.float32) \
-            or not (go.is_contiguous() and x.is_contiguous()) or (out is not None and not out.is_contiguous()):
+            or go.dim() != 2 or _extent_bytes(go) is None or not x.is_contiguous() or (out is not None and not out.is_contiguous()):
         return None
     if go.dtype == torch.float32 and out_dtype != torch.float32:
         return None
     if max(go.numel(), x.numel()) * go.element_size() > ARENA_MAX_BYTES:
         return None
-    key = (tuple(go.shape), tuple(x.shape), go.dtype, out_dtype, go.device, tag)
+    key = (tuple(go.shape), tuple(x.shape), go.dtype, out_dtype, go.device, tag, tuple(go.stride()))
     want = _EXPECT.get(key, 0)
     grp = _W.get(key)
     if grp is None:

@@ -66,13 +66,21 @@ class _SmallAttn(Function):
         dout = dout.to(torch.bfloat16).contiguous()
         dev = q.device
         with torch.cuda.device(dev):
-            if L == S:  # self-attention: dq | dk side by side, the layout the packed in-projection consumes without a copy
+            from . import fused_ops
+
+            if L == S and ctx.slots[1] is None and B * L < fused_ops.INPROJ_MERGE_ROWS:
+                # short self-attention: dq | dk | dv side by side -- the packed in-projection then gets its three input
+                # gradients from ONE batched product (fused_ops._SelfAttnInProj.backward)
+                dqkv = deferred.take((B, L, 3, E), torch.bfloat16, dev, "attn.dqkv")
+                dq, dk, dv = dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2]
+            elif L == S:  # self-attention: dq | dk side by side, the layout the packed in-projection consumes without a copy
                 dqk = deferred.take((B, L, 2, E), torch.bfloat16, dev, "attn.dqk")
                 dq, dk = dqk[:, :, 0], dqk[:, :, 1]
+                dv = _grad_buffer(ctx.slots[1], B, S, E, dev)
             else:
                 dq = deferred.take((B, L, E), torch.bfloat16, dev, "attn.dq")
                 dk = _grad_buffer(ctx.slots[0], B, S, E, dev)
-            dv = _grad_buffer(ctx.slots[1], B, S, E, dev)
+                dv = _grad_buffer(ctx.slots[1], B, S, E, dev)
             head = (B, heads, L, S, q.data_ptr(), *_st(q), k.data_ptr(), *_st(k), v.data_ptr(), *_st(v),
                     kpm.data_ptr() if kpm is not None else 0, 1.0 / math.sqrt(E // heads), p_drop,
                     seed.data_ptr() if seed is not None else 0, site, out.data_ptr(), dout.data_ptr(), lse.data_ptr())
