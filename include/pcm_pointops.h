@@ -422,6 +422,14 @@ int pcm_col2im_cl_hip(int B, int T, int C, int K, int stride, int pad, int cols_
  * use_given_stat = 2 stops after the local sums (sums[0] = sum (y - y[0]), sums[1] = sum (y - y[0])^2).
  * backward leaves sums = [dbeta | dgamma]; phase 1 stops after those local sums, phase 2 only applies given (all-reduced)
  * sums with `count` = rows of the global batch (<= 0: n). */
+/* synchronised BatchNorm (torch.nn.SyncBatchNorm semantics, configs/trainer/ddp.yaml:9 `sync_batchnorm: true`): the host-side
+ * statistics exchange around the collective as two launches instead of ~28 framework launches per layer.
+ * pack: (mean, M2, count) of this rank from the forward kernels' shifted sums (sums (2, C): sum (y - shift), sum (y - shift)^2;
+ * shift (C) fp32) -> pack (2C + 1).  combine: the gathered packs of all W ranks (W, 2C + 1) -> stat (4, C) of the global batch
+ * (fp64, rank order), running statistics (nullable pair), ratio[0] = count_local / N. */
+int pcm_bn_sync_pack_hip(int C, double count, const float *sums, const float *shift, float *pack, void *stream);
+int pcm_bn_sync_combine_hip(int W, int C, const float *gathered, const float *gamma, const float *beta, float eps, float momentum,
+                            float *running_mean, float *running_var, double count_local, float *stat, float *ratio, void *stream);
 int pcm_bn_relu_supported(long n, int C);
 int pcm_bn_relu_slots(long n, int C);
 int pcm_bn_relu_forward_hip(long n, int C, int is_bf16, const void *y, const float *gamma, const float *beta,

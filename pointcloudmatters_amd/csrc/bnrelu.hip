@@ -285,6 +285,82 @@ inline int ew_grid(long total4)
 
 }  // namespace
 
+namespace {
+// ---- synchronised BatchNorm (policy/sync_bn.py): the statistics exchange around the collective as two launches --------------
+// pack: the rank's per-channel mean, sum of squared deviations and row count from the kernels' shifted sums
+//   d = S1 / n; mean = shift + d; M2 = S2 - S1 * d        (n == 0: an empty rank contributes zeros with count 0)
+__global__ __launch_bounds__(256) void pcm_bn_sync_pack_kernel(int C, double n, const float *__restrict__ sums, const float *__restrict__ shift,
+                                                               float *__restrict__ pack)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c == 0) pack[2 * C] = (float)n;
+    if (c >= C) return;
+    if (n <= 0.0) {
+        pack[c] = 0.f, pack[C + c] = 0.f;
+        return;
+    }
+    const float s1 = sums[c], s2 = sums[C + c];
+    const float d = s1 / (float)n;
+    pack[c] = shift[c] + d;
+    pack[C + c] = s2 - s1 * d;
+}
+
+// combine (Chan et al.): all ranks' (mean, M2, count) -> stat (4, C) = { mean, invstd, a = gamma invstd, b = beta - a mean } of the
+// GLOBAL batch in fp64, the running-statistics update, and ratio = n_loc / N.  Every rank runs the same arithmetic on the same
+// gathered numbers in rank order: identical results everywhere.
+__global__ __launch_bounds__(256) void pcm_bn_sync_combine_kernel(int W, int C, const float *__restrict__ all, const float *__restrict__ gamma,
+                                                                  const float *__restrict__ beta, float eps, float momentum,
+                                                                  float *__restrict__ running_mean, float *__restrict__ running_var,
+                                                                  double n_loc, float *__restrict__ stat, float *__restrict__ ratio)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int P = 2 * C + 1;
+    double n = 0.0;
+    for (int r = 0; r < W; ++r) n += (double)all[(size_t)r * P + 2 * C];
+    if (c == 0) ratio[0] = (float)(n_loc / n);
+    if (c >= C) return;
+    double mean = 0.0;
+    for (int r = 0; r < W; ++r) mean += (double)all[(size_t)r * P + c] * (double)all[(size_t)r * P + 2 * C];
+    mean /= n;
+    double m2 = 0.0;
+    for (int r = 0; r < W; ++r) {
+        const double dm = (double)all[(size_t)r * P + c] - mean;
+        m2 += (double)all[(size_t)r * P + C + c] + (double)all[(size_t)r * P + 2 * C] * dm * dm;
+    }
+    double var = m2 / n;
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    const double a = (double)gamma[c] * invstd;
+    stat[c] = (float)mean;
+    stat[C + c] = (float)invstd;
+    stat[2 * C + c] = (float)a;
+    stat[3 * C + c] = (float)((double)beta[c] - a * mean);
+    if (running_mean != nullptr) {
+        const double unbiased = var * (n / (n - 1.0 > 1.0 ? n - 1.0 : 1.0));
+        running_mean[c] = running_mean[c] * (1.f - momentum) + momentum * (float)mean;
+        running_var[c] = running_var[c] * (1.f - momentum) + momentum * (float)unbiased;
+    }
+}
+}  // namespace
+
+extern "C" int pcm_bn_sync_pack_hip(int C, double count, const float *sums, const float *shift, float *pack, void *stream)
+{
+    if (C <= 0 || count < 0.0 || !pack || (count > 0.0 && (!sums || !shift))) return PCM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(pcm_bn_sync_pack_kernel, dim3((C + 256) / 256), dim3(256), 0, (hipStream_t)stream, C, count, sums, shift, pack);
+    return PCM_LAUNCH_STATUS();
+}
+
+extern "C" int pcm_bn_sync_combine_hip(int W, int C, const float *gathered, const float *gamma, const float *beta, float eps, float momentum,
+                                       float *running_mean, float *running_var, double count_local, float *stat, float *ratio,
+                                       void *stream)
+{
+    if (W <= 0 || C <= 0 || !gathered || !gamma || !beta || !stat || !ratio || (running_mean == nullptr) != (running_var == nullptr))
+        return PCM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(pcm_bn_sync_combine_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, W, C, gathered, gamma, beta, eps,
+                       momentum, running_mean, running_var, count_local, stat, ratio);
+    return PCM_LAUNCH_STATUS();
+}
+
 extern "C" int pcm_bn_relu_supported(long n, int C)
 {
     return (n > 0 && C > 0 && C % 4 == 0 && (C <= kMaxChunk || C % kMaxChunk == 0)) ? 1 : 0;

@@ -15,6 +15,16 @@ def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
+def _fused_sync_ok(bn, sums):
+    """The two-launch statistics exchange (sync_bn.combine_forward_sums): fp32 affine parameters / running statistics on the
+    device of the sums (PCM_SYNC_BN_FUSED=0: the framework-op route, for A/B)."""
+    import os
+
+    return (os.environ.get("PCM_SYNC_BN_FUSED", "1") != "0" and sums.is_cuda and bn.weight.dtype == torch.float32
+            and bn.bias.dtype == torch.float32 and bn.weight.device == sums.device
+            and (bn.running_mean is None or bn.running_mean.dtype == torch.float32))
+
+
 class _BNReLU(Function):
     @staticmethod
     def forward(ctx, y, gamma, beta, running_mean, running_var, eps, momentum, sync_bn):
@@ -50,8 +60,11 @@ class _BNReLU(Function):
                 rc = L.pcm_bn_relu_forward_hip(*args, 0, 0, 2, partial.data_ptr(), sums.data_ptr(), 0, 0, st)
                 _lib.check(rc, "pcm_bn_relu_forward_hip")
                 shift = y[0].float()  # the kernel accumulates around the first row
-                d = sums[0] / n
-                stat, count = S.combine_forward(sync_bn, shift + d, sums[1] - sums[0] * d, n)
+                if _fused_sync_ok(sync_bn, sums):
+                    stat, count = S.combine_forward_sums(sync_bn, sums, shift, n)
+                else:
+                    d = sums[0] / n
+                    stat, count = S.combine_forward(sync_bn, shift + d, sums[1] - sums[0] * d, n)
                 rc = L.pcm_bn_relu_forward_hip(*args, 0, 0, 1, 0, 0, stat.data_ptr(), z.data_ptr(), st)
         _lib.check(rc, "pcm_bn_relu_forward_hip")
         ctx.save_for_backward(y, stat)

@@ -111,8 +111,13 @@ class _SAFused(Function):
                 shift = torch.where(j0 >= 0, gf.index_select(0, j0.clamp(min=0).long().reshape(1))[0].float(),
                                     torch.zeros(H, **f32))
                 rows = float(m) * K
-                d = sums[0] / rows
-                stat, count = S.combine_forward(sync_bn, shift + d, sums[1] - sums[0] * d, rows)
+                from .bn_relu import _fused_sync_ok
+
+                if _fused_sync_ok(sync_bn, sums):
+                    stat, count = S.combine_forward_sums(sync_bn, sums, shift.contiguous(), rows)
+                else:
+                    d = sums[0] / rows
+                    stat, count = S.combine_forward(sync_bn, shift + d, sums[1] - sums[0] * d, rows)
                 launch(8, stat)
         ctx.save_for_backward(gf, ent, wp, stat, sel, asel, istats)
         ctx.csr = csr if (csr is not None and L.pcm_sa_det_supported(K, H)) else None

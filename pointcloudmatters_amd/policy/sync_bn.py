@@ -79,6 +79,34 @@ def combine_forward(bn, mean_loc, m2_loc, count_loc):
     return stat, ratio
 
 
+def combine_forward_sums(bn, sums, shift, count_loc):
+    """combine_forward from the forward kernels' shifted sums (sums (2, C): sum (y - shift), sum (y - shift)^2; shift (C) fp32):
+    two launches around the all_gather (csrc/bnrelu.hip pcm_bn_sync_pack / _combine) instead of ~28 one-element framework
+    launches per layer -- at N > 1 the eager tokenizer is paced by the host, and six layers of that were ~1 ms per step."""
+    from .. import _lib
+    from .._lib import raw_stream
+
+    C = int(sums.shape[1])
+    dev = sums.device
+    L = _lib.load()
+    world = dist.get_world_size(_group(bn))
+    with torch.cuda.device(dev):
+        pack = torch.empty(2 * C + 1, dtype=torch.float32, device=dev)
+        rc = L.pcm_bn_sync_pack_hip(C, float(count_loc), sums.data_ptr(), shift.data_ptr(), pack.data_ptr(), raw_stream())
+        _lib.check(rc, "pcm_bn_sync_pack_hip")
+        gathered = torch.empty(world, 2 * C + 1, dtype=torch.float32, device=dev)
+        dist.all_gather(list(gathered.unbind(0)), pack, group=_group(bn))
+        stat = torch.empty(4, C, dtype=torch.float32, device=dev)
+        ratio = torch.empty((), dtype=torch.float32, device=dev)
+        track = bn.track_running_stats and bn.momentum is not None
+        rc = L.pcm_bn_sync_combine_hip(world, C, gathered.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), float(bn.eps),
+                                       float(bn.momentum if bn.momentum is not None else 0.0),
+                                       bn.running_mean.data_ptr() if track else 0, bn.running_var.data_ptr() if track else 0,
+                                       float(count_loc), stat.data_ptr(), ratio.data_ptr(), raw_stream())
+        _lib.check(rc, "pcm_bn_sync_combine_hip")
+    return stat, ratio
+
+
 def reduce_backward(bn, sums_loc, ratio):
     """(2, C) local {sum dy, sum dy * xhat} -> the same sums over all ranks, pre-scaled by n_loc / N (see combine_forward);
     the local copy stays untouched (it is the weight / bias gradient)."""
