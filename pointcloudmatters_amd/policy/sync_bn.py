@@ -79,6 +79,23 @@ def combine_forward(bn, mean_loc, m2_loc, count_loc):
     return stat, ratio
 
 
+_INTO_TENSOR_OK = {}
+
+
+def _all_gather_rows(out, row, group):
+    """out[r] = row of rank r.  all_gather_into_tensor writes straight into `out` (no staging copies on RCCL); a backend without
+    it (decided once per backend) gets the list form on views of `out`."""
+    key = dist.get_backend(group)
+    if _INTO_TENSOR_OK.get(key, True):
+        try:
+            dist.all_gather_into_tensor(out.view(-1), row, group=group)
+            _INTO_TENSOR_OK[key] = True
+            return
+        except (RuntimeError, NotImplementedError):
+            _INTO_TENSOR_OK[key] = False
+    dist.all_gather(list(out.unbind(0)), row, group=group)
+
+
 def combine_forward_sums(bn, sums, shift, count_loc):
     """combine_forward from the forward kernels' shifted sums (sums (2, C): sum (y - shift), sum (y - shift)^2; shift (C) fp32):
     two launches around the all_gather (csrc/bnrelu.hip pcm_bn_sync_pack / _combine) instead of ~28 one-element framework
@@ -95,7 +112,7 @@ def combine_forward_sums(bn, sums, shift, count_loc):
         rc = L.pcm_bn_sync_pack_hip(C, float(count_loc), sums.data_ptr(), shift.data_ptr(), pack.data_ptr(), raw_stream())
         _lib.check(rc, "pcm_bn_sync_pack_hip")
         gathered = torch.empty(world, 2 * C + 1, dtype=torch.float32, device=dev)
-        dist.all_gather(list(gathered.unbind(0)), pack, group=_group(bn))
+        _all_gather_rows(gathered, pack, _group(bn))
         stat = torch.empty(4, C, dtype=torch.float32, device=dev)
         ratio = torch.empty((), dtype=torch.float32, device=dev)
         track = bn.track_running_stats and bn.momentum is not None
