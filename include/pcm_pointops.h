@@ -425,9 +425,11 @@ int pcm_col2im_cl_hip(int B, int T, int C, int K, int stride, int pad, int cols_
 /* synchronised BatchNorm (torch.nn.SyncBatchNorm semantics, configs/trainer/ddp.yaml:9 `sync_batchnorm: true`): the host-side
  * statistics exchange around the collective as two launches instead of ~28 framework launches per layer.
  * pack: (mean, M2, count) of this rank from the forward kernels' shifted sums (sums (2, C): sum (y - shift), sum (y - shift)^2;
- * shift (C) fp32) -> pack (2C + 1).  combine: the gathered packs of all W ranks (W, 2C + 1) -> stat (4, C) of the global batch
+ * shift = row *row_index of the fp32 / bf16 (rows, C) matrix src -- row 0 when row_index is NULL, zeros when it is negative:
+ * the row the forward kernel accumulated around) -> pack (2C + 1).  combine: the gathered packs of all W ranks (W, 2C + 1) -> stat (4, C) of the global batch
  * (fp64, rank order), running statistics (nullable pair), ratio[0] = count_local / N. */
-int pcm_bn_sync_pack_hip(int C, double count, const float *sums, const float *shift, float *pack, void *stream);
+int pcm_bn_sync_pack_hip(int C, double count, const float *sums, const void *src, int src_is_bf16, const int *row_index, float *pack,
+                         void *stream);
 int pcm_bn_sync_combine_hip(int W, int C, const float *gathered, const float *gamma, const float *beta, float eps, float momentum,
                             float *running_mean, float *running_var, double count_local, float *stat, float *ratio, void *stream);
 int pcm_bn_relu_supported(long n, int C);

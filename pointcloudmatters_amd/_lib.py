@@ -61,7 +61,7 @@ SIGNATURES = {
     "pcm_sa_index_hip": [_i, _i, _P, _P, _P, _P, _P, _i, _i, _P, _P, _P, _P, _P],
     "pcm_sa_fused_backward_hip": [_i, _i, _i, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                   _P, _P, _P, _i, _i, _P, ctypes.c_double, _i, _P],
-    "pcm_bn_sync_pack_hip": [_i, ctypes.c_double, _P, _P, _P, _P],
+    "pcm_bn_sync_pack_hip": [_i, ctypes.c_double, _P, _P, _i, _P, _P, _P],
     "pcm_bn_sync_combine_hip": [_i, _i, _P, _P, _P, _f, _f, _P, _P, ctypes.c_double, _P, _P, _P],
     "pcm_drln_blocks": [ctypes.c_long],
     "pcm_drln_forward_hip": [ctypes.c_long, _i, _i, _P, _P, _P, _P, _f, _f, _P, ctypes.c_uint, _P, _P, _P, _P, _P],

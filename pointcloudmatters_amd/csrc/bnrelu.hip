@@ -289,8 +289,10 @@ namespace {
 // ---- synchronised BatchNorm (policy/sync_bn.py): the statistics exchange around the collective as two launches --------------
 // pack: the rank's per-channel mean, sum of squared deviations and row count from the kernels' shifted sums
 //   d = S1 / n; mean = shift + d; M2 = S2 - S1 * d        (n == 0: an empty rank contributes zeros with count 0)
-__global__ __launch_bounds__(256) void pcm_bn_sync_pack_kernel(int C, double n, const float *__restrict__ sums, const float *__restrict__ shift,
-                                                               float *__restrict__ pack)
+//   shift = row `*row_index` (row 0 when the pointer is NULL; zeros when the index is negative) of the (rows, C) matrix `src`
+//   (fp32 or bf16) that the forward kernel accumulated around: read here, not by a chain of framework indexing launches
+__global__ __launch_bounds__(256) void pcm_bn_sync_pack_kernel(int C, double n, const float *__restrict__ sums, const void *__restrict__ src,
+                                                               int src_is_bf16, const int *__restrict__ row_index, float *__restrict__ pack)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c == 0) pack[2 * C] = (float)n;
@@ -299,9 +301,15 @@ __global__ __launch_bounds__(256) void pcm_bn_sync_pack_kernel(int C, double n, 
         pack[c] = 0.f, pack[C + c] = 0.f;
         return;
     }
+    const long row = row_index != nullptr ? (long)row_index[0] : 0;
+    float sh = 0.f;
+    if (row >= 0) {
+        if (src_is_bf16) sh = __uint_as_float((uint32_t)reinterpret_cast<const uint16_t *>(src)[row * C + c] << 16);
+        else sh = reinterpret_cast<const float *>(src)[row * C + c];
+    }
     const float s1 = sums[c], s2 = sums[C + c];
     const float d = s1 / (float)n;
-    pack[c] = shift[c] + d;
+    pack[c] = sh + d;
     pack[C + c] = s2 - s1 * d;
 }
 
@@ -343,10 +351,12 @@ __global__ __launch_bounds__(256) void pcm_bn_sync_combine_kernel(int W, int C, 
 }
 }  // namespace
 
-extern "C" int pcm_bn_sync_pack_hip(int C, double count, const float *sums, const float *shift, float *pack, void *stream)
+extern "C" int pcm_bn_sync_pack_hip(int C, double count, const float *sums, const void *src, int src_is_bf16, const int *row_index,
+                                    float *pack, void *stream)
 {
-    if (C <= 0 || count < 0.0 || !pack || (count > 0.0 && (!sums || !shift))) return PCM_ERR_BAD_ARG;
-    hipLaunchKernelGGL(pcm_bn_sync_pack_kernel, dim3((C + 256) / 256), dim3(256), 0, (hipStream_t)stream, C, count, sums, shift, pack);
+    if (C <= 0 || count < 0.0 || !pack || (count > 0.0 && (!sums || !src))) return PCM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(pcm_bn_sync_pack_kernel, dim3((C + 256) / 256), dim3(256), 0, (hipStream_t)stream, C, count, sums, src, src_is_bf16,
+                       row_index, pack);
     return PCM_LAUNCH_STATUS();
 }
 

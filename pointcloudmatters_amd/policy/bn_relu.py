@@ -59,10 +59,10 @@ class _BNReLU(Function):
 
                 rc = L.pcm_bn_relu_forward_hip(*args, 0, 0, 2, partial.data_ptr(), sums.data_ptr(), 0, 0, st)
                 _lib.check(rc, "pcm_bn_relu_forward_hip")
-                shift = y[0].float()  # the kernel accumulates around the first row
                 if _fused_sync_ok(sync_bn, sums):
-                    stat, count = S.combine_forward_sums(sync_bn, sums, shift, n)
+                    stat, count = S.combine_forward_sums(sync_bn, sums, y, n)  # the kernel accumulates around the first row of y
                 else:
+                    shift = y[0].float()
                     d = sums[0] / n
                     stat, count = S.combine_forward(sync_bn, shift + d, sums[1] - sums[0] * d, n)
                 rc = L.pcm_bn_relu_forward_hip(*args, 0, 0, 1, 0, 0, stat.data_ptr(), z.data_ptr(), st)

@@ -107,15 +107,16 @@ class _SAFused(Function):
                 from . import sync_bn as S
 
                 launch(1 | 2, stat)
-                j0 = ent.view(torch.int32)[0, 0, 0]
-                shift = torch.where(j0 >= 0, gf.index_select(0, j0.clamp(min=0).long().reshape(1))[0].float(),
-                                    torch.zeros(H, **f32))
                 rows = float(m) * K
                 from .bn_relu import _fused_sync_ok
 
-                if _fused_sync_ok(sync_bn, sums):
-                    stat, count = S.combine_forward_sums(sync_bn, sums, shift.contiguous(), rows)
+                if _fused_sync_ok(sync_bn, sums) and gf.dtype in (torch.float32, torch.bfloat16):
+                    # the kernel accumulated around the first neighbour's Gf row: its index is the first word of `ent`
+                    stat, count = S.combine_forward_sums(sync_bn, sums, gf, rows, row_index=ent.view(torch.int32).reshape(-1)[:1])
                 else:
+                    j0 = ent.view(torch.int32)[0, 0, 0]
+                    shift = torch.where(j0 >= 0, gf.index_select(0, j0.clamp(min=0).long().reshape(1))[0].float(),
+                                        torch.zeros(H, **f32))
                     d = sums[0] / rows
                     stat, count = S.combine_forward(sync_bn, shift + d, sums[1] - sums[0] * d, rows)
                 launch(8, stat)

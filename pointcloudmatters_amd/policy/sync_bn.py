@@ -96,8 +96,9 @@ def _all_gather_rows(out, row, group):
     dist.all_gather(list(out.unbind(0)), row, group=group)
 
 
-def combine_forward_sums(bn, sums, shift, count_loc):
-    """combine_forward from the forward kernels' shifted sums (sums (2, C): sum (y - shift), sum (y - shift)^2; shift (C) fp32):
+def combine_forward_sums(bn, sums, src, count_loc, row_index=None):
+    """combine_forward from the forward kernels' shifted sums (sums (2, C): sum (y - shift), sum (y - shift)^2; shift = row 0 of
+    the (rows, C) fp32 / bf16 matrix `src`, or its row *row_index (a device int32; negative: zeros)):
     two launches around the all_gather (csrc/bnrelu.hip pcm_bn_sync_pack / _combine) instead of ~28 one-element framework
     launches per layer -- at N > 1 the eager tokenizer is paced by the host, and six layers of that were ~1 ms per step."""
     from .. import _lib
@@ -109,7 +110,8 @@ def combine_forward_sums(bn, sums, shift, count_loc):
     world = dist.get_world_size(_group(bn))
     with torch.cuda.device(dev):
         pack = torch.empty(2 * C + 1, dtype=torch.float32, device=dev)
-        rc = L.pcm_bn_sync_pack_hip(C, float(count_loc), sums.data_ptr(), shift.data_ptr(), pack.data_ptr(), raw_stream())
+        rc = L.pcm_bn_sync_pack_hip(C, float(count_loc), sums.data_ptr(), src.data_ptr(), int(src.dtype == torch.bfloat16),
+                                    row_index.data_ptr() if row_index is not None else 0, pack.data_ptr(), raw_stream())
         _lib.check(rc, "pcm_bn_sync_pack_hip")
         gathered = torch.empty(world, 2 * C + 1, dtype=torch.float32, device=dev)
         _all_gather_rows(gathered, pack, _group(bn))
