@@ -183,3 +183,70 @@ def test_a_rank_without_rows_still_joins_the_statistics_exchange(hip_device):
     for r in (0, 1):
         torch.testing.assert_close(torch.from_numpy(got["rm%d" % r]), bn.running_mean.cpu(), rtol=1e-4, atol=1e-6)
     torch.testing.assert_close(torch.from_numpy(got["gw0"]), bn.weight.grad.cpu(), rtol=1e-3, atol=1e-4)
+
+
+def test_sync_statistics_kernels_match_the_framework_formula(hip_device):
+    """pcm_bn_sync_pack_hip / pcm_bn_sync_combine_hip alone (no process group): three pretend ranks with different row counts
+    (one of them empty) against the fp64 framework-op formula of sync_bn.combine_forward."""
+    import ctypes
+
+    import torch
+
+    from pointcloudmatters_amd import _lib
+
+    L = _lib.load()
+    dev = hip_device
+    st = torch.cuda.current_stream().cuda_stream
+    torch.manual_seed(0)
+    C, counts = 96, [1000.0, 0.0, 37.0]
+    gamma, beta = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev)
+    eps, mom = 1e-3, 0.01
+    packs, means, m2s = [], [], []
+    for r, n in enumerate(counts):
+        rows = int(n)
+        for dt in (torch.float32, torch.bfloat16):
+            y = (torch.randn(max(rows, 1), C, device=dev) * 2 + 3 + r).to(dt)
+            sel = torch.tensor([min(5, max(rows, 1) - 1)], dtype=torch.int32, device=dev)
+            shift = y[int(sel[0])].float()
+            yy = y[:rows].float()
+            sums = torch.stack([(yy - shift).sum(0), ((yy - shift) ** 2).sum(0)]) if rows else torch.zeros(2, C, device=dev)
+            pack = torch.empty(2 * C + 1, device=dev)
+            assert L.pcm_bn_sync_pack_hip(C, n, sums.data_ptr(), y.data_ptr(), int(dt == torch.bfloat16), sel.data_ptr(), pack.data_ptr(), st) == 0
+            if rows:
+                torch.testing.assert_close(pack[:C].double(), yy.double().mean(0), rtol=1e-5, atol=1e-5)
+                torch.testing.assert_close(pack[C: 2 * C].double(), ((yy.double() - yy.double().mean(0)) ** 2).sum(0), rtol=2e-3, atol=1e-2)
+            else:
+                assert not pack[: 2 * C].any()
+            assert float(pack[2 * C]) == n
+        packs.append(pack)  # the bf16 variant of this rank
+        means.append(pack[:C].double()), m2s.append(pack[C: 2 * C].double())
+    # row 0 when no index is given, zeros for a negative index
+    y = torch.randn(4, C, device=dev)
+    sums = torch.stack([(y - y[0]).sum(0), ((y - y[0]) ** 2).sum(0)])
+    p0, pneg = torch.empty(2 * C + 1, device=dev), torch.empty(2 * C + 1, device=dev)
+    assert L.pcm_bn_sync_pack_hip(C, 4.0, sums.data_ptr(), y.data_ptr(), 0, 0, p0.data_ptr(), st) == 0
+    torch.testing.assert_close(p0[:C], y.mean(0), rtol=1e-5, atol=1e-6)
+    neg = torch.tensor([-1], dtype=torch.int32, device=dev)
+    assert L.pcm_bn_sync_pack_hip(C, 4.0, sums.data_ptr(), y.data_ptr(), 0, neg.data_ptr(), pneg.data_ptr(), st) == 0
+    torch.testing.assert_close(pneg[:C], sums[0] / 4.0, rtol=1e-6, atol=1e-7)
+
+    gathered = torch.stack(packs).contiguous()
+    rm, rv = torch.randn(C, device=dev), torch.rand(C, device=dev) + 0.5
+    rm0, rv0 = rm.clone(), rv.clone()
+    stat, ratio = torch.empty(4, C, device=dev), torch.empty((), device=dev)
+    assert L.pcm_bn_sync_combine_hip(3, C, gathered.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps, mom, rm.data_ptr(), rv.data_ptr(),
+                                     counts[2], stat.data_ptr(), ratio.data_ptr(), st) == 0
+    n_r = torch.tensor(counts, dtype=torch.float64, device=dev)[:, None]
+    mean_r, m2_r = torch.stack(means), torch.stack(m2s)
+    n = n_r.sum()
+    mean = (mean_r * n_r).sum(0) / n
+    var = ((m2_r + n_r * (mean_r - mean) ** 2).sum(0) / n).clamp_min(0)
+    invstd = torch.rsqrt(var + eps)
+    a = gamma.double() * invstd
+    want = torch.stack([mean, invstd, a, beta.double() - a * mean])
+    torch.testing.assert_close(stat.double(), want, rtol=1e-6, atol=1e-6)
+    assert abs(float(ratio) - counts[2] / float(n)) < 1e-7
+    torch.testing.assert_close(rm, rm0 * (1 - mom) + mom * mean.float(), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(rv, rv0 * (1 - mom) + mom * (var * n / (n - 1)).float(), rtol=1e-6, atol=1e-6)
+    assert L.pcm_bn_sync_combine_hip(0, C, gathered.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps, mom, 0, 0, 1.0, stat.data_ptr(),
+                                     ratio.data_ptr(), st) != 0
