@@ -23,7 +23,10 @@ def build_act_policy(pcd_npoints, pointops=None, sa_impl="reference", overlap_sa
         backbone = PointNeXtBackbone(in_channels=c["in_channels"], width=c.get("pointnext_width", 64), blocks=c.get("pointnext_blocks", 2),
                                      nsample=c["pcd_nsample"], out_channels=512, pointops=pointops, sa_impl=sa_impl)
     else:
-        backbone = PointNet(in_channels=c["in_channels"], num_classes=0)
+        backbone = PointNet(in_channels=c["in_channels"], num_classes=c.get("backbone_num_classes", 0))
+    if c.get("pre_sample", False) and backbone.num_channels != c["hidden_dim"]:
+        # act.py:509-530: with pre_sample the backbone's output IS the token matrix
+        raise ValueError("pre_sample: the backbone's output width (%d) must equal hidden_dim (%d)" % (backbone.num_channels, c["hidden_dim"]))
     transformer = Transformer(
         d_model=c["hidden_dim"], dropout=c["dropout"], nhead=c["nhead"], dim_feedforward=c["dim_feedforward"],
         num_encoder_layers=c["num_encoder_layers"], num_decoder_layers=c["num_decoder_layers"],
@@ -46,7 +49,7 @@ def build_act_policy(pcd_npoints, pointops=None, sa_impl="reference", overlap_sa
         klloss=KLDivergence(), kl_weight=c["kl_weight"], goal_cond_dim=c["goal_cond_dim"],
         pcd_nsample=c["pcd_nsample"], pcd_npoints=pcd_npoints, pointops=pointops, sa_impl=sa_impl,
         overlap_sampling=overlap_sampling, dead_decoder_layers=dead_decoder_layers,
-        use_mask=c.get("use_mask", False), bg_ratio=c.get("bg_ratio", 0.0), **extra,
+        use_mask=c.get("use_mask", False), bg_ratio=c.get("bg_ratio", 0.0), pre_sample=c.get("pre_sample", False), **extra,
     )
 
 
@@ -76,7 +79,8 @@ def build_dp_policy(pcd_npoints, pointops=None, sa_impl="reference", overlap_sam
                             pcd_nsample=c["pcd_nsample"], pcd_npoints=pcd_npoints, pcd_hidden_dim=c["pcd_hidden_dim"],
                             projector_layers=c["projector_layers"], projector_channels=c["projector_channels"],
                             pointops=pointops, sa_impl=sa_impl, overlap_sampling=overlap_sampling,
-                            use_mask=c.get("use_mask", False), bg_ratio=c.get("bg_ratio", 0.0))
+                            use_mask=c.get("use_mask", False), bg_ratio=c.get("bg_ratio", 0.0),
+                            pre_sample=c.get("pre_sample", False), in_channel=c["in_channels"])
     sched = DDPMSchedule(num_train_timesteps=c["num_train_timesteps"], beta_schedule="squaredcos_cap_v2",
                          prediction_type="epsilon")
     pol = DiffusionUnetPcdPolicy(shape_meta=shape_meta, noise_scheduler=sched, obs_encoder=enc, horizon=c["horizon"],

@@ -10,7 +10,10 @@ import torch
 
 
 def make_act_batch(batch, n_points, seed=1000, ragged=False, num_queries=100, action_dim=7, qpos_dim=9,
-                   goal_cond_dim=3, device="cpu", grid_size=0.005):
+                   goal_cond_dim=3, device="cpu", grid_size=0.005, feat_keys=("color", "coord")):
+    """feat_keys: what CollectPCD concatenates into `feat` -- ("color", "coord") for the default configs
+    (configs/data/maniskill2_act_pcd_dataset.yaml:32-34), ("coord",) for the `_wo_rgb` and ("color",) for the `_wo_xyz`
+    experiment variants (e.g. scratch_pointnet_pcd_presample_wo_rgb.yaml:18-31)."""
     rng = np.random.default_rng(seed)
     if ragged:
         sizes = rng.integers(int(0.75 * n_points), int(1.25 * n_points) + 1, size=batch).tolist()
@@ -39,7 +42,7 @@ def make_act_batch(batch, n_points, seed=1000, ragged=False, num_queries=100, ac
         "pcds": {
             "coord": coord_t,
             "grid_coord": torch.from_numpy(grid).to(dev),
-            "feat": torch.cat([torch.from_numpy(color).to(dev), coord_t], dim=1).contiguous(),
+            "feat": torch.cat([{"color": torch.from_numpy(color).to(dev), "coord": coord_t}[k] for k in feat_keys], dim=1).contiguous(),
             "offset": offset,
         },
         "qpos": torch.from_numpy(rng.standard_normal((batch, qpos_dim)).astype(np.float32)).to(dev),
@@ -52,11 +55,11 @@ def make_act_batch(batch, n_points, seed=1000, ragged=False, num_queries=100, ac
 
 
 def make_dp_batch(batch, n_points, seed=1000, ragged=False, horizon=16, n_obs_steps=2, action_dim=7, qpos_dim=9,
-                  device="cpu", goal_dim=0):
+                  device="cpu", goal_dim=0, feat_keys=("color", "coord")):
     """Diffusion-Policy batch: B samples, each with n_obs_steps clouds flattened sample-major
     (sparse_tensor_utils.py:74-75 -> b = B*To clouds), qpos window (B, horizon, qpos_dim), action (B, horizon, Da)."""
     clouds = make_act_batch(batch * n_obs_steps, n_points, seed=seed, ragged=ragged, num_queries=1, action_dim=1,
-                            qpos_dim=1, goal_cond_dim=0, device=device)["pcds"]
+                            qpos_dim=1, goal_cond_dim=0, device=device, feat_keys=feat_keys)["pcds"]
     rng = np.random.default_rng(seed + 1)
     dev = torch.device(device)
     out = {

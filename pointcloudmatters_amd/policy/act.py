@@ -80,8 +80,6 @@ class ACTPCD(nn.Module):
             raise ValueError("ACTPCD needs a point-cloud backbone")
         if not 0.0 <= bg_ratio < 1.0:
             raise ValueError("bg_ratio must be in [0, 1)")
-        if pre_sample:
-            raise NotImplementedError("pre_sample=True is not used by any shipped config")
         if "fps" not in sampling:
             raise NotImplementedError(sampling)
         if pointops is None:
@@ -138,8 +136,17 @@ class ACTPCD(nn.Module):
         self.pcd_nsample = pcd_nsample
         self.pcd_npoints = pcd_npoints
         self.pre_sample = pre_sample
-        self.linear = nn.Linear(3 + backbone.num_channels, hidden_dim, bias=False)
-        self.bn = nn.BatchNorm1d(hidden_dim)
+        if not pre_sample:
+            self.linear = nn.Linear(3 + backbone.num_channels, hidden_dim, bias=False)
+            self.bn = nn.BatchNorm1d(hidden_dim)
+        else:
+            # act.py:369-376: the set-abstraction layer sits IN FRONT of the backbone and keeps the raw feature width
+            # (`backbone.in_channels`; the constructor's own `in_channels` argument is never read by the reference either),
+            # the backbone then runs on the m sampled points and its output IS the token matrix.  Selected by
+            # configs/exp_maniskill2_act_policy/maniskill2_model/scratch_pointnet_pcd_presample{,_wo_rgb,_wo_xyz}.yaml.
+            cin = backbone.in_channels
+            self.linear = nn.Linear(3 + cin, cin, bias=False)
+            self.bn = nn.BatchNorm1d(cin)
         self.pool = nn.MaxPool1d(pcd_nsample)
         self.relu = nn.ReLU(inplace=True)
         self.sampling = sampling
@@ -241,8 +248,16 @@ class ACTPCD(nn.Module):
         # indices first (coordinates only), overlapped with the backbone when on the GPU
         pre = set_abstraction.sample_and_query(self, self.pointops, coord, offset, n_o,
                                                overlap=self.overlap_sampling and coord.is_cuda, mask=self._mask_of(pcd_dict))
-        features = self.backbone(pcd_dict)
-        n_p, tokens, _ = set_abstraction(self, self.pointops, coord, features, offset, n_o, impl=self.sa_impl, pre=pre)
+        if self.pre_sample:
+            # act.py:509-530: sample first (on the raw features), then the backbone on the sampled cloud.  Like the
+            # reference, the cloud dict handed in is rewritten to describe the sampled cloud.
+            n_p, feat, fps_idx = set_abstraction(self, self.pointops, coord, pcd_dict["feat"], offset, n_o, impl=self.sa_impl, pre=pre)
+            pcd_dict["coord"], pcd_dict["feat"], pcd_dict["offset"] = n_p, feat, n_o
+            pcd_dict["grid_coord"] = pcd_dict["grid_coord"][fps_idx.long()]
+            tokens = self.backbone(pcd_dict)
+        else:
+            features = self.backbone(pcd_dict)
+            n_p, tokens, _ = set_abstraction(self, self.pointops, coord, features, offset, n_o, impl=self.sa_impl, pre=pre)
         b = offset.shape[0]
         pcd_pos = coord_embedding_sine(n_p, self.hidden_dim)
         # "(b n) c -> b c 1 n"

@@ -430,8 +430,6 @@ class PCDObsEncoder(_AttrMixin):
                  use_mask=False, bg_ratio=0.0, pcd_hidden_dim=128, projector_layers=2, projector_channels=(128, 128, 128),
                  pre_sample=False, in_channel=6, pointops=None, sa_impl="reference", overlap_sampling=True, **kwargs):
         super().__init__()
-        if pre_sample or not share_pcd_model:
-            raise NotImplementedError("pre_sample / per-key pcd models are not used by any shipped config")
         if not 0.0 <= bg_ratio < 1.0:
             raise ValueError("bg_ratio must be in [0, 1)")
         self.use_mask, self.bg_ratio = use_mask, bg_ratio
@@ -441,21 +439,51 @@ class PCDObsEncoder(_AttrMixin):
             pointops = _hip_pointops
         self._pointops = [pointops]
         self.sa_impl, self.overlap_sampling = sa_impl, overlap_sampling
-        self.key_model_map = nn.ModuleDict({"pcd": pcd_model})
         obs_meta = shape_meta["obs"]
         self.pcd_keys = sorted(k for k, a in obs_meta.items() if a.get("type", "low_dim") == "pcd")
         self.low_dim_keys = sorted(k for k, a in obs_meta.items() if a.get("type", "low_dim") == "low_dim")
+        for k, a in obs_meta.items():
+            if a.get("type", "low_dim") not in ("pcd", "low_dim"):
+                raise RuntimeError(f"Unsupported obs type: {a['type']}")  # pcd_obs_encoder.py:67
+        # pcd_obs_encoder.py:38-63: one shared model under the key "pcd", or one model per point-cloud key (given as a dict,
+        # or deep copies of the one module)
+        key_model_map = nn.ModuleDict()
+        if share_pcd_model:
+            assert isinstance(pcd_model, nn.Module)
+            key_model_map["pcd"] = pcd_model
+        else:
+            import copy
+
+            for k in obs_meta:  # insertion order of shape_meta, like the reference's loop
+                if obs_meta[k].get("type", "low_dim") != "pcd":
+                    continue
+                if isinstance(pcd_model, dict):
+                    key_model_map[k] = pcd_model[k]
+                else:
+                    assert isinstance(pcd_model, nn.Module)
+                    key_model_map[k] = copy.deepcopy(pcd_model)
+        self.key_model_map = key_model_map
+        any_model = pcd_model if isinstance(pcd_model, nn.Module) else next(iter(pcd_model.values()))
         self.key_shape_map = {k: tuple(a["shape"]) for k, a in obs_meta.items()}
         self.shape_meta, self.share_pcd_model, self.n_obs_step = shape_meta, share_pcd_model, n_obs_step
         self.pcd_nsample, self.pcd_npoints = pcd_nsample, pcd_npoints
-        self.linear = nn.Linear(3 + pcd_model.num_channels, pcd_hidden_dim, bias=False)
-        self.bn = nn.BatchNorm1d(pcd_hidden_dim)
+        self.pre_sample = pre_sample
+        if not pre_sample:
+            self.linear = nn.Linear(3 + any_model.num_channels, pcd_hidden_dim, bias=False)
+            self.bn = nn.BatchNorm1d(pcd_hidden_dim)
+        else:
+            # pcd_obs_encoder.py:91-93: the set-abstraction layer runs on the RAW features, in front of the point-cloud model
+            # (configs/exp_maniskill2_diffusion_policy/maniskill2_model/scratch_pointnet_pcd_presample{,_wo_rgb,_wo_xyz}.yaml)
+            self.linear = nn.Linear(3 + in_channel, in_channel, bias=False)
+            self.bn = nn.BatchNorm1d(in_channel)
         self.pool = nn.MaxPool1d(pcd_nsample)
         self.relu = nn.ReLU(inplace=True)
         ch = list(projector_channels)
         proj = []
         for i in range(projector_layers):
-            proj += [nn.Conv1d(pcd_hidden_dim, ch[i], kernel_size=1), nn.BatchNorm1d(ch[i]), nn.ReLU(inplace=True)]
+            # :103-112: with pre_sample the projector's first convolution reads the model's output width
+            cin = pcd_hidden_dim if (i > 0 or not pre_sample) else any_model.num_channels
+            proj += [nn.Conv1d(cin, ch[i], kernel_size=1), nn.BatchNorm1d(ch[i]), nn.ReLU(inplace=True)]
         proj += [nn.MaxPool1d(pcd_npoints), nn.Conv1d(ch[projector_layers - 1], ch[projector_layers], kernel_size=1),
                  nn.BatchNorm1d(ch[projector_layers])]
         self.projector = nn.Sequential(*proj)
@@ -502,12 +530,29 @@ class PCDObsEncoder(_AttrMixin):
     def fused_batchnorms(self):
         return [self.bn] if self.sa_impl == "fused" else []
 
+    def pcd_sampling(self, pxo, mask=None, return_index=False):
+        """pcd_obs_encoder.py:123-198: (p (n,3), x (n,c), o (b)) -> x (m,H), or (n_p, x, n_o, idx) with `return_index`."""
+        p, x, o = pxo
+        n_o = self._new_offsets(o)
+        pre = set_abstraction.sample_and_query(self, self.pointops, p, o, n_o, mask=mask)
+        n_p, feat, idx = set_abstraction(self, self.pointops, p, x, o, n_o, impl=self.sa_impl, pre=pre)
+        if return_index:
+            return n_p, feat, n_o, idx
+        return feat
+
     def sa_tokens(self, pcd_model, pcd_dict):
         """The ragged half: PointNet + set abstraction -> (b*M, C) tokens (fixed shape whatever the cloud sizes)."""
         coord, offset = pcd_dict["coord"], pcd_dict["offset"]
         n_o = self._new_offsets(offset)
         pre = set_abstraction.sample_and_query(self, self.pointops, coord, offset, n_o,
                                                overlap=self.overlap_sampling and coord.is_cuda, mask=self._mask_of(pcd_dict))
+        if self.pre_sample:
+            # pcd_obs_encoder.py:201-218: sample on the raw features, rewrite the cloud dict to the sampled cloud (as the
+            # reference does), then the point-cloud model on the m sampled points
+            n_p, feat, fps_idx = set_abstraction(self, self.pointops, coord, pcd_dict["feat"], offset, n_o, impl=self.sa_impl, pre=pre)
+            pcd_dict["coord"], pcd_dict["feat"], pcd_dict["offset"] = n_p, feat, n_o
+            pcd_dict["grid_coord"] = pcd_dict["grid_coord"][fps_idx.long()]
+            return pcd_model(pcd_dict)
         features = pcd_model(pcd_dict)
         return set_abstraction(self, self.pointops, coord, features, offset, n_o, impl=self.sa_impl, pre=pre)[1]
 
@@ -528,9 +573,12 @@ class PCDObsEncoder(_AttrMixin):
                 x = layer(x.contiguous() if isinstance(layer, nn.BatchNorm1d) else x)
         return x.squeeze(-1)
 
-    def pcd_features(self, pcd_dict):
+    def _model_of(self, key):
+        return self.key_model_map["pcd"] if self.share_pcd_model else self.key_model_map[key]
+
+    def pcd_features(self, pcd_dict, key=None):
         """packed clouds -> (b, C) features: the eager half of the hybrid trainer mode."""
-        return self.encode_pcd(self.key_model_map["pcd"], pcd_dict)
+        return self.encode_pcd(self._model_of(key if key is not None else self.pcd_keys[0]), pcd_dict)
 
     def forward(self, obs_dict):
         feats, batch = [], None
@@ -546,7 +594,7 @@ class PCDObsEncoder(_AttrMixin):
                 assert len(pcd["offset"]) % self.n_obs_step == 0
                 batch = len(pcd["offset"])
                 assert pcd["feat"].shape[1:] == self.key_shape_map[key]
-            feats.append(self.encode_pcd(self.key_model_map["pcd"], pcd).reshape(batch, -1))
+            feats.append(self.encode_pcd(self._model_of(key), pcd).reshape(batch, -1))
         for key in self.low_dim_keys:
             data = obs_dict[key]
             assert batch is None or batch == data.shape[0], (key, batch, data.shape)

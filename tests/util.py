@@ -27,3 +27,42 @@ def make_clouds(sizes, seed=0, mode="uniform", dup_frac=0.05, lattice=0.005):
 
 def new_offsets(ms):
     return torch.from_numpy(np.cumsum(ms).astype(np.int32))
+
+
+def seeded_fill(module, seed, bn_stats=False, skip=("normalizer.",)):
+    """Deterministic weights WITHOUT storing them: every parameter is filled from its own NumPy stream, seeded by
+    (seed, crc32 of the parameter's state-dict name), so two modules with the same parameter names -- the reference class in
+    the build container (tests/golden/make_golden.py) and the product class on the GPU box -- end up with identical
+    weights whatever their construction order.  Matrices ~ N(0, 1/fan_in), norm weights +-(1 + 0.1 N), biases / vectors 0.05 N,
+    embeddings N(0, 0.5).  With `bn_stats` the BatchNorm running statistics get seeded non-trivial values too (eval tests).
+    Returns a float64 checksum (sum over parameters of sum |w| * (1 + index mod 7)) that fixtures store and tests re-check."""
+    import zlib
+
+    check = 0.0
+    with torch.no_grad():
+        items = list(module.named_parameters())
+        if bn_stats:
+            items += [(n, b) for n, b in module.named_buffers() if n.endswith(("running_mean", "running_var"))]
+        for name, p in items:
+            if p.numel() == 0 or name.startswith(tuple(skip)):  # the Diffusion Policy's data normaliser is fitted, not trained
+                continue
+            rng = np.random.default_rng([int(seed), zlib.crc32(name.encode())])
+            v = rng.standard_normal(tuple(p.shape))
+            leaf = name.rsplit(".", 1)[-1]
+            if leaf == "running_var":
+                v = 0.5 + rng.random(tuple(p.shape))
+            elif leaf == "running_mean":
+                v = 0.1 * v
+            elif p.dim() >= 2 and "embed" in name and leaf == "weight":
+                v = 0.5 * v
+            elif p.dim() >= 2:
+                fan_in = int(np.prod(p.shape[1:]))
+                v = v / np.sqrt(fan_in)
+            elif leaf == "weight":  # BatchNorm / LayerNorm / GroupNorm scale; one in five negative (the fused SA layer's min branch)
+                v = (1.0 + 0.1 * v) * np.where(rng.random(tuple(p.shape)) < 0.2, -1.0, 1.0)
+            else:
+                v = 0.05 * v
+            p.copy_(torch.from_numpy(v.astype(np.float32)).to(p.device))
+            flat = np.abs(v.astype(np.float32).astype(np.float64)).ravel()
+            check += float((flat * (1 + (np.arange(flat.size) % 7))).sum())
+    return check
