@@ -21,7 +21,8 @@ ACT_OPTIM = dict(lr=5e-5, weight_decay=0.05, pct_start=0.1, div_factor=100.0, fi
 # (chunk_size 100, action_dim = qpos_dim = 11: position 3 + 6-D rotation + gripper + collision; 512-d task embedding)
 RLBENCH_ACT_MODEL = dict(ACT_MODEL, action_dim=11, qpos_dim=11, goal_cond_dim=512, kl_weight=10.0, rot_type="6d", collision=True,
                          position_loss_weight=10.0)
-RLBENCH_ACT_OPTIM = dict(ACT_OPTIM, lr=1e-4, pct_start=0.15, accumulate_grad_batches=1)
+# exp_rlbench_act_policy/rlbench_model/scratch_pointnet_pcd.yaml:9-12: batch 8, accumulate_grad_batches 4 (tests/test_configs_vs_yaml.py)
+RLBENCH_ACT_OPTIM = dict(ACT_OPTIM, lr=1e-4, pct_start=0.15, accumulate_grad_batches=4)
 
 # Diffusion Policy: /root/reference/configs/model/maniskill2_diffusion_policy_model.yaml:10-60,
 # exp_maniskill2_diffusion_policy/maniskill2_model/scratch_pointnet_pcd.yaml:10-35 (PointNet num_classes 96,

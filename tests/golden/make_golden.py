@@ -715,6 +715,155 @@ def golden_presample(ref):
     np.savez_compressed(os.path.join(OUT, "presample_ref.npz"), **fx)
 
 
+WIDE = dict(hidden_dim=512, nhead=8, dim_feedforward=32, num_encoder_layers=1, num_decoder_layers=2, dropout=0.0, latent_dim=32,
+            num_queries=100, kl_weight=10.0, action_dim=7, qpos_dim=9, goal_cond_dim=3, pcd_nsample=16)
+WIDE_SEED = 51200
+WIDE_DP = dict(down_dims=(128, 256), diffusion_step_embed_dim=128, pcd_num_classes=96, pcd_hidden_dim=96, projector_channels=(96, 128, 128),
+               n_groups=8)
+
+
+def _store_grads(fx, prefix, named_grads):
+    from tests.util import grad_digest
+
+    for name, g in named_grads:
+        for part, v in grad_digest(name, g.numpy()).items():
+            fx[f"{prefix}{name}/{part}"] = v
+
+
+def golden_wide(ref):
+    """The SHIPPED WIDTHS (configs/model/maniskill2_act_pcd_model.yaml:49-68: d = 512, 8 heads, feed-forward 32, 100 queries,
+    latent 32; Diffusion Policy encoder: PointNet head 96, SA 96, projector [96, 128, 128]) through the reference's own
+    ACTPCD / Transformer / PCDObsEncoder / ConditionalUnet1D, so that the fused HIP kernels -- which engage only at these
+    widths (E % 256 == 0, head_dim 64, feed-forward 512 / 32) -- are compared with the REFERENCE and not with a restatement.
+    1 encoder + 2 decoder layers (the second decoder layer is a dead layer, act.py:270), 2 ragged clouds of ~150 points;
+    variant "flash": 128 tokens per cloud -> 131-token sequences (csrc/attn_flash.hip takes query sets > 128), variant
+    "small": 96 -> 99 tokens (csrc/attn_small.hip).  Weights: tests/util.seeded_fill on both sides (checksum stored); stored:
+    inputs, outputs and a digest of EVERY gradient (tests/util.grad_digest).  Batch seeds are searched so that no ReLU
+    pre-activation / arg-max gap of the whole model sits at the rounding level (see _kink_margin)."""
+    from oracle import pointops_cpu
+    from pointcloudmatters_amd.bc import build_act_policy, build_dp_policy, make_act_batch, make_dp_batch
+    from pointcloudmatters_amd.policy import PointNet
+    from tests.util import seeded_fill
+
+    fx = {}
+    c = WIDE
+    eps = torch.randn(2, c["latent_dim"], generator=torch.Generator().manual_seed(25))
+    fx["act.eps"] = eps.numpy()
+    for tag, M in (("flash", 128), ("small", 96)):
+        backbone = PointNet(in_channels=6, num_classes=0)
+        model = _ref_act(ref, c, M, backbone)
+        fx[f"act.{tag}.wsum"] = np.array(seeded_fill(model, WIDE_SEED))
+        ours = build_act_policy(pcd_npoints=M, pointops=pointops_cpu, sa_impl="reference", **c)
+        ours.load_state_dict(model.state_dict(), strict=True)  # same names, same shapes
+        model.train()
+        relus = [blk[1] for blk in (backbone.conv1, backbone.conv2, backbone.conv3, backbone.conv4, backbone.conv5)]
+        relus += [m.linear1 for m in model.modules() if hasattr(m, "linear1") and hasattr(m, "linear2")]
+        best = None
+        for seed in range(300, 1300):
+            batch = make_act_batch(2, 150, seed=seed, ragged=True, num_queries=c["num_queries"])
+
+            def run(b=batch):
+                orig = ref.act.reparametrize
+                ref.act.reparametrize = lambda mu, logvar: mu + logvar.div(2).exp() * eps
+                try:
+                    dd = {k: (dict(v) if isinstance(v, dict) else v) for k, v in b.items()}
+                    dd["pcds"] = {k: v.clone() for k, v in dd["pcds"].items()}
+                    model(dd)
+                finally:
+                    ref.act.reparametrize = orig
+
+            # the SA layer's input is the backbone's output here: compute its margin on those features
+            with torch.no_grad():
+                saved = [{k: v.clone() for k, v in m.state_dict().items()} for m in relus[:5]]
+                feats = backbone({k: v.clone() for k, v in batch["pcds"].items()})
+                for m, sd in zip(relus[:5], saved):
+                    m.load_state_dict(sd)
+            sa = _sa_margin(model, dict(batch["pcds"], feat=feats))
+            if sa < 1e-5:
+                continue
+            margin = _kink_margin(run, relus, model, dict(batch["pcds"], feat=feats))
+            if best is None or margin > best[0]:
+                best = (margin, seed)
+            if margin >= 4e-6:
+                break
+        margin, seed = best
+        batch = make_act_batch(2, 150, seed=seed, ragged=True, num_queries=c["num_queries"])
+        print(f"  act {tag}: batch seed {seed}, margin {margin:.2e}")
+        assert margin >= 2e-6
+        out = _run_ref_act(ref, model, batch, eps)
+        for k, v in batch.items():
+            if isinstance(v, dict):
+                for kk, vv in v.items():
+                    fx[f"act.{tag}.in.pcds.{kk}"] = vv.numpy()
+            else:
+                fx[f"act.{tag}.in.{k}"] = v.numpy()
+        for k in ("a_hat", "is_pad_hat", "mu", "logvar", "loss", "action_loss", "kl_loss", "src", "pos"):
+            fx[f"act.{tag}.out.{k}"] = out[k].detach().numpy()
+        _store_grads(fx, f"act.{tag}.grad.", [(n, p.grad) for n, p in model.named_parameters() if p.grad is not None])
+        fx[f"act.{tag}.grad_none"] = np.array(sorted(n for n, p in model.named_parameters() if p.grad is None))
+        fx[f"act.{tag}.bn_running_mean"], fx[f"act.{tag}.bn_running_var"] = model.bn.running_mean.numpy().copy(), model.bn.running_var.numpy().copy()
+        print(f"wide_ref.npz act {tag}: loss", float(out["loss"].detach()), "src", tuple(out["src"].shape))
+
+    # ---- Diffusion Policy at the shipped encoder widths
+    M = 64
+    shape_meta = {"obs": {"pcds": {"shape": [6], "type": "pcd"}, "qpos": {"shape": [9], "type": "low_dim"}}, "action": {"shape": [7]}}
+    enc = ref.pcd_enc.PCDObsEncoder(shape_meta=shape_meta, pcd_model=PointNet(in_channels=6, num_classes=96), share_pcd_model=True,
+                                    n_obs_step=2, pcd_nsample=16, pcd_npoints=M, pcd_hidden_dim=96, projector_layers=1,
+                                    projector_channels=[96, 128, 128])
+    unet = ref.unet.ConditionalUnet1D(input_dim=7, local_cond_dim=None, global_cond_dim=(128 + 9) * 2, diffusion_step_embed_dim=128,
+                                      down_dims=[128, 256], kernel_size=5, n_groups=8, cond_predict_scale=True)
+    ours = build_dp_policy(pcd_npoints=M, pointops=pointops_cpu, sa_impl="reference", **WIDE_DP)
+    fx["dp.wsum"] = np.array(seeded_fill(ours, WIDE_SEED + 1))
+    sd = ours.state_dict()
+    enc.load_state_dict({k[len("obs_encoder."):]: v for k, v in sd.items() if k.startswith("obs_encoder.")}, strict=True)
+    unet.load_state_dict({k[len("model."):]: v for k, v in sd.items() if k.startswith("model.")}, strict=True)
+    mg = ref.maskgen.LowdimMaskGenerator(action_dim=7, obs_dim=0, max_n_obs_steps=2, fix_obs_steps=True, action_visible=False)
+    enc.train(), unet.train()
+    pn = enc.key_model_map["pcd"]
+    best = None
+    for seed in range(500, 900):
+        dbatch = make_dp_batch(2, 100, seed=seed, ragged=True)
+        with torch.no_grad():
+            saved = {k: v.clone() for k, v in pn.state_dict().items()}
+            feats = pn({k: v.clone() for k, v in dbatch["obs"]["pcds"].items()})
+            pn.load_state_dict(saved)
+        sa = _sa_margin(enc, dict(dbatch["obs"]["pcds"], feat=feats))
+        if sa < 1e-5:
+            continue
+        margin = _kink_margin(lambda b=dbatch: enc.encode_pcd(pn, {k: v.clone() for k, v in b["obs"]["pcds"].items()}),
+                              [blk[1] for blk in (pn.conv1, pn.conv2, pn.conv3, pn.conv4, pn.conv5)] + [enc.projector[1]],
+                              enc, dict(dbatch["obs"]["pcds"], feat=feats))
+        if best is None or margin > best[0]:
+            best = (margin, seed)
+        if margin >= 4e-6:
+            break
+    margin, seed = best
+    dbatch = make_dp_batch(2, 100, seed=seed, ragged=True)
+    print(f"  dp: batch seed {seed}, margin {margin:.2e}")
+    noise = torch.randn(2, 16, 7, generator=torch.Generator().manual_seed(38))
+    timesteps = torch.tensor([12, 88])
+    qpos, action = dbatch["obs"]["qpos"], dbatch["action"]
+    this_nobs = {"qpos": qpos[:, :2].reshape(-1, 9), "pcds": {k: v.clone() for k, v in dbatch["obs"]["pcds"].items()}}
+    global_cond = enc(this_nobs).reshape(2, -1)
+    mask = mg((2, 16, 7))
+    acp = ours.noise_scheduler.alphas_cumprod[timesteps]  # diffusers absent: our restated schedule (parity unpinned)
+    noisy = acp.sqrt()[:, None, None] * action + (1 - acp).sqrt()[:, None, None] * noise
+    noisy[mask] = action[mask]
+    pred = unet(noisy, timesteps, local_cond=None, global_cond=global_cond)
+    loss = torch.nn.functional.mse_loss(pred, noise, reduction="none") * (~mask).float()
+    loss = loss.reshape(2, -1).mean(1).mean()
+    loss.backward()
+    fx["dp.noise"], fx["dp.timesteps"] = noise.numpy(), timesteps.numpy()
+    fx["dp.out.loss"], fx["dp.out.pred"], fx["dp.out.global_cond"] = loss.detach().numpy(), pred.detach().numpy(), global_cond.detach().numpy()
+    for k, v in dbatch["obs"]["pcds"].items():
+        fx[f"dp.in.pcds.{k}"] = v.numpy()
+    fx["dp.in.qpos"], fx["dp.in.action"] = qpos.numpy(), action.numpy()
+    _store_grads(fx, "dp.grad.", [("obs_encoder." + n, p.grad) for n, p in enc.named_parameters() if p.grad is not None]
+                 + [("model." + n, p.grad) for n, p in unet.named_parameters() if p.grad is not None])
+    print("wide_ref.npz dp: loss", float(loss))
+    np.savez_compressed(os.path.join(OUT, "wide_ref.npz"), **fx)
+
+
 def golden_rollout(ref):
     """The policy side of a rollout step, from the reference's own Python:
       * TemporalAgg (src/utils/misc.py:88-141) fed a seeded sequence of action chunks;
@@ -831,6 +980,6 @@ if __name__ == "__main__":
     only = set(sys.argv[1:])  # e.g. `make_golden.py rollout` regenerates one fixture
     for name, fn in (("act", golden_act), ("grouping", golden_grouping), ("misc", golden_misc), ("dp", golden_dp),
                      ("rollout", golden_rollout), ("gridsample", golden_gridsample), ("rlbench", golden_rlbench),
-                     ("dp_rlbench", golden_dp_rlbench), ("mask", golden_mask), ("presample", golden_presample)):
+                     ("dp_rlbench", golden_dp_rlbench), ("mask", golden_mask), ("presample", golden_presample), ("wide", golden_wide)):
         if not only or name in only:
             fn(ref)

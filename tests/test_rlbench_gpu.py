@@ -25,7 +25,7 @@ def test_rlbench_training_step_hybrid_bf16(hip_device):
 
     torch.manual_seed(0)
     pol = build_rlbench_act_policy(pcd_npoints=128, sa_impl="fused", num_encoder_layers=1, num_decoder_layers=2).to(hip_device)
-    tr = BCTrainer(pol, total_steps=100, precision="bf16", device=hip_device, mode="hybrid", optim=dict(RLBENCH_ACT_OPTIM, lr=2e-4))
+    tr = BCTrainer(pol, total_steps=100, precision="bf16", device=hip_device, mode="hybrid", optim=dict(RLBENCH_ACT_OPTIM, lr=2e-4, accumulate_grad_batches=1))  # (the experiment file accumulates 4: 16 micro-batches would be 4 steps)
     batches = [make_act_batch(4, 400, seed=3 + i, ragged=True, device=hip_device, action_dim=11, qpos_dim=11, goal_cond_dim=512)
                for i in range(2)]
     for b in batches:

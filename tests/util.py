@@ -66,3 +66,43 @@ def seeded_fill(module, seed, bn_stats=False, skip=("normalizer.",)):
             flat = np.abs(v.astype(np.float32).astype(np.float64)).ravel()
             check += float((flat * (1 + (np.arange(flat.size) % 7))).sum())
     return check
+
+
+def grad_digest(name, g):
+    """A gradient in a form small enough to commit: tensors of <= 16384 elements whole; larger matrices as their first four rows
+    and columns, two seeded random projections (g v and u g, float64), the Frobenius norm and the largest magnitude.  Any
+    structured error (a missing term, a sign, a transposed block, a wrong row) moves the projections; element noise does not."""
+    import zlib
+
+    g = np.asarray(g, dtype=np.float32)
+    if g.size <= 16384:
+        return {"full": g}
+    g2 = g.reshape(g.shape[0], -1)
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    u, v = rng.standard_normal(g2.shape[0]), rng.standard_normal(g2.shape[1])
+    g64 = g2.astype(np.float64)
+    return {"rows": g2[:4].copy(), "cols": g2[:, :4].copy(), "right": g64 @ v, "left": u @ g64,
+            "fro": np.array(np.sqrt((g64 * g64).sum())), "absmax": np.array(np.abs(g2).max())}
+
+
+def check_grad_digest(name, got, ref, rtol=1e-4, atol=1e-6):
+    """`got`: the full gradient (ndarray); `ref`: dict of the digest's parts as stored.  Element parts are held to
+    rtol * max|g| (+ atol); a projection over d elements to rtol * max|g| * sqrt(d) (element errors of random sign add up like
+    that; a systematic error grows like d); the norm to rtol.  Returns the worst ratio error / bound (for reporting)."""
+    dig = grad_digest(name, got)
+    worst = 0.0
+    if "full" in ref:
+        scale = float(np.abs(ref["full"]).max())
+        err = float(np.abs(dig["full"] - ref["full"]).max()) if ref["full"].size else 0.0
+        bound = rtol * scale + atol
+        assert err <= bound, (name, "full", err, bound)
+        return err / bound
+    scale = float(ref["absmax"])
+    rows, cols = ref["cols"].shape[0], ref["rows"].shape[1]
+    for part, dim in (("rows", 1), ("cols", 1), ("right", cols), ("left", rows)):
+        err = float(np.abs(dig[part] - ref[part]).max())
+        bound = (rtol * scale + atol) * np.sqrt(dim)
+        assert err <= bound, (name, part, err, bound)
+        worst = max(worst, err / bound)
+    assert abs(float(dig["fro"]) - float(ref["fro"])) <= rtol * float(ref["fro"]) + atol, (name, "fro")
+    return worst
