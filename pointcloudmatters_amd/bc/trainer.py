@@ -135,9 +135,12 @@ class BCTrainer:
 
     def __init__(self, policy, total_steps, optim=None, precision="fp32", device=None, distributed=False,
                  sync_batchnorm=True, bucket_cap_mb=32, log_every_n_steps=50, mode="eager", flat_optimizer_cls=None, staged=None,
-                 side_weight_grads=False, external_sampling=True, defer_reductions=None):
+                 side_weight_grads=False, external_sampling=True, defer_reductions=None, allow_eval_submodules=False):
         o = dict(ACT_OPTIM)
         self.side_weight_grads = bool(side_weight_grads)
+        # a submodule the caller froze on purpose (policy.backbone.eval(): fixed BatchNorm statistics) stays in eval mode; see
+        # training_step for what happens to one that is in eval mode by accident
+        self.allow_eval_submodules = bool(allow_eval_submodules)
         # closing reductions batched per backward stage (policy/deferred.py); PCM_DEFER_REDUCTIONS=0 is the A/B switch
         self.defer_reductions = (os.environ.get("PCM_DEFER_REDUCTIONS", "1") != "0") if defer_reductions is None else bool(defer_reductions)
         self.external_sampling = bool(external_sampling)  # graph mode: FPS / kNN outside the captured graph (prefetchable)
@@ -365,7 +368,7 @@ class BCTrainer:
     def _loss_seed(self, loss):
         """d(loss / accumulate) / d loss as a cached device scalar: seeding backward with it replaces the division kernel, the
         ones_like fill of .backward() and the division's backward multiply (three one-element launches per micro-batch)."""
-        key = (loss.device, loss.dtype)
+        key = (loss.device, loss.dtype, self.accumulate)
         seeds = self.__dict__.setdefault("_loss_seeds", {})
         if key not in seeds:
             if loss.is_cuda and torch.cuda.is_current_stream_capturing():
@@ -706,16 +709,20 @@ class BCTrainer:
         # Mode contract.  .train() walks ~230 modules (1 ms of host time), so it runs only when the ROOT module is in eval
         # mode (what policy.eval() / a rollout helper leaves behind).  A submodule the caller put into eval() on its own
         # (a frozen backbone's BatchNorm) therefore STAYS in eval -- Lightning's loop would have forced it back to train
-        # every step.  Every 64th micro-batch the whole tree is checked, so a child that was flipped by evaluation code
-        # without touching the root cannot silently train without BatchNorm updates / dropout for long; captured graphs
-        # bake the mode in at capture time either way.
+        # every step.  On the first and then every 64th micro-batch the tree is checked until something is found: submodules
+        # in eval mode are reported with ONE warning (not an error: freezing is legitimate; BCTrainer(allow_eval_submodules=
+        # True) skips the check).  Captured graphs bake the mode in at capture time either way.
         if not self.module.training:
             self.module.train()
-        elif self.micro % 64 == 0 and not getattr(self, "allow_eval_submodules", False):
+        if self.micro % 64 == 0 and not self.allow_eval_submodules and not self.__dict__.get("_warned_eval"):
             stale = [n for n, m in self.module.named_modules() if not m.training]
             if stale:
-                raise RuntimeError("training_step: submodules in eval mode under a training root: %s ... -- call policy.train(), or set "
-                                   "trainer.allow_eval_submodules = True if they are frozen on purpose" % ", ".join(stale[:4]))
+                import warnings
+
+                self._warned_eval = True
+                warnings.warn("training_step: %d submodule(s) in eval mode under a training root (%s ...): their BatchNorm statistics / "
+                              "dropout are frozen.  Call policy.train() if that is not intended; BCTrainer(allow_eval_submodules=True) "
+                              "silences this." % (len(stale), ", ".join(stale[:4])))
         if prefetch is not None:
             self.prefetch_sampling(prefetch)
         if self._fused_ctx is not None:

@@ -496,8 +496,10 @@ extern "C" int pcm_knn_query_n_hip(int b, int n_max, int m, int nsample, const f
         }
         int rc = PCM_LAUNCH_STATUS();
         if (rc) return rc;
-        static const int skip_exact = getenv("PCM_KNN_SKIP_EXACT") ? atoi(getenv("PCM_KNN_SKIP_EXACT")) : 0;  // tools/mb: count the marked queries
+#ifdef PCM_MB_SWITCHES  // microbenchmark builds only (tools/mb/mb_knn_flags.py counts the marked queries): the shipped library always answers them
+        static const int skip_exact = getenv("PCM_KNN_SKIP_EXACT") ? atoi(getenv("PCM_KNN_SKIP_EXACT")) : 0;
         if (skip_exact) return PCM_OK;
+#endif
         hipLaunchKernelGGL(pcm_knn_exact_kernel, dim3(exact_blocks), dim3(64 * kWaves), 0, st, b, m, nsample, 0, xyz, new_xyz, offset,
                            new_offset, idx, dist2);
         return PCM_LAUNCH_STATUS();

@@ -25,7 +25,10 @@ def knn_query_raw(nsample, xyz, offset, new_xyz=None, new_offset=None):
         idx = torch.empty(m, nsample, dtype=torch.int32, device=xyz.device)
         dist2 = torch.empty(m, nsample, dtype=torch.float32, device=xyz.device)
         o32, no32 = C.i32c(offset), C.i32c(new_offset)
-        n_max = max(C.counts_from_offsets(C.host_offsets(offset)), default=0)  # host copy rides on the tensor: no sync
+        # n_max is only a hint (reserved by the launcher): use the host copy when it rides on the tensor, never read the device
+        # for it (that would be a sync per call, and illegal under stream capture)
+        host = getattr(offset, "_pcm_host", None)
+        n_max = max(C.counts_from_offsets(host), default=0) if host else 0
         rc = L.pcm_knn_query_n_hip(
             int(offset.shape[0]), int(n_max), m, nsample, C.ptr(xyz), C.ptr(new_xyz), C.ptr(o32), C.ptr(no32), C.ptr(idx),
             C.ptr(dist2), C.stream(),

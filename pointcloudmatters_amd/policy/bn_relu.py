@@ -40,8 +40,15 @@ class _BNReLU(Function):
             assert sync_bn is not None, "bn_relu on an empty batch is only meaningful with synchronised statistics"
             from . import sync_bn as S
 
-            zero = torch.zeros(c, dtype=torch.float32, device=dev)
-            stat, count = S.combine_forward(sync_bn, zero, zero, 0)
+            zero = torch.zeros(2, c, dtype=torch.float32, device=dev)
+            if _fused_sync_ok(sync_bn, zero):
+                # the SAME collective API and the SAME combine kernel as the ranks that have rows (count 0: the pack kernel emits
+                # zeros and never reads sums / src): every rank issues all_gather_into_tensor and updates its running
+                # statistics with identical fp32 arithmetic, so the replicas' buffers stay bit-identical
+                with torch.cuda.device(dev):
+                    stat, count = S.combine_forward_sums(sync_bn, zero, zero, 0)
+            else:
+                stat, count = S.combine_forward(sync_bn, zero[0], zero[1], 0)
             ctx.save_for_backward(y, stat)
             ctx.partial, ctx.sync = None, (sync_bn, count)
             return torch.empty_like(y)

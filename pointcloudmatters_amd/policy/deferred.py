@@ -49,8 +49,11 @@ def begin():
 
 def end():
     global _Q, _W
+    import sys
+
     try:
-        flush()
+        if sys.exc_info()[0] is None:  # called from a `finally` while an exception propagates: do not mask it with a flush of
+            flush()                    # half-built queues
     finally:
         _Q = None
         _W = {}
@@ -193,6 +196,25 @@ def _as_batch(ts, nb):
     return torch.as_strided(t0, (n,) + tuple(t0.shape), (d // es,) + tuple(t0.stride()))
 
 
+def _pad_is_free(ov, n):
+    """May a batched product write the padding batches ov[n:] of a strided OUTPUT?  Only when they are never-handed-out slots
+    of one of this window's arenas (`take` keeps a quarter more slots than it hands out, at the top).  Anything else -- a
+    caller's slice of a flat / packed gradient, or arena slots that an earlier flush of this stage already filled and gave
+    to autograd -- must not be touched: the padded batch would rewrite somebody's finished gradient."""
+    es = ov.element_size()
+    step = ov.stride(0) * es
+    ext = _extent_bytes(ov[0])
+    if ext is None or step <= 0:
+        return False
+    lo, hi = ov.data_ptr() + n * step, ov.data_ptr() + (ov.shape[0] - 1) * step + ext
+    base = ov.untyped_storage().data_ptr()
+    for buf, _used, cap in _ARENAS.values():
+        if buf.untyped_storage().data_ptr() == base:
+            slot = buf.stride(0) * buf.element_size()
+            return lo >= buf.data_ptr() + cap * slot and hi <= buf.data_ptr() + buf.shape[0] * slot
+    return False
+
+
 def _padded(n):
     # hipBLASLt's batched kernels are markedly faster at 4 / 8 / 16 batches than at 5, 7 or 14 (800 x 512 x 512 bf16: 14
     # batches 24.7 us, 16 batches 16.9 us; tools/mb/mb_wgrad_batch.py, mb_wgrad_enc.py)
@@ -270,10 +292,13 @@ def _flush_wgrads():
         ov = None
         if len(grp["extra"]) == n and not kw:  # every product has its own destination (slices of packed gradients taken
             ov = _as_batch([d for _, d in grp["extra"]][::-1], nb)  # from an arena): one strided output if they line up
-            if ov is not None and ov.shape[0] != nb:
+            if ov is not None and ov.shape[0] > n and not _pad_is_free(ov, n):
+                ov = ov[:n]  # the slots behind the last destination are not ours to write: unpadded product
+            if ov is not None and ov.shape[0] not in (n, nb):
                 ov = None
         if ov is not None:
-            torch.bmm(a.transpose(1, 2), b, out=ov)
+            k = ov.shape[0]
+            torch.bmm(a[:k].transpose(1, 2), b[:k], out=ov)
         elif not grp["extra"] and n == want and buf is not None and buf.shape[0] == nb and not kw:
             torch.bmm(a.transpose(1, 2), b, out=buf)  # push i was handed buf[want-1-i] = batch n-1-i
         else:

@@ -300,9 +300,11 @@ def _zeros_like_cached(ref):
         z = torch.zeros(ref.shape, dtype=ref.dtype, device=ref.device)
         if torch.cuda.is_current_stream_capturing():
             return z
-        if len(_ZEROS) > 16:
-            _ZEROS.clear()
-        _ZEROS[key] = z
+        # entries are NEVER evicted: a captured hipGraph reads its decoder input by raw address and does not keep the tensor
+        # alive, so freeing one (round-3 code cleared the cache past 16 shapes) could hand its memory to somebody else under a
+        # replaying training graph.  Past 64 shapes (rollouts with many batch sizes) new shapes are simply not cached.
+        if len(_ZEROS) < 64:
+            _ZEROS[key] = z
     return z
 
 

@@ -34,7 +34,11 @@ def test_captured_memsets_replay_correctly(hip_device, n_ints, d32, value):
         out.copy_(buf)
 
     graph, _ = captured(body)
-    assert graph.memset_nodes_replaced == 1
+    from pointcloudmatters_amd._graphs import memset_fix_needed
+
+    # the rewrite is gated on a one-time self-test of the runtime: needed on ROCm 7.2 (then the node is replaced), a no-op on a
+    # runtime whose captured memsets replay correctly -- either way every replay below must be right
+    assert graph.memset_nodes_replaced == (1 if memset_fix_needed() else 0)
     want = (value if d32 else (value & 0xFF) * 0x01010101) + 1
     for _ in range(20):
         graph.replay()
@@ -66,7 +70,9 @@ def test_torch_reductions_inside_a_patched_graph(hip_device):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     graph, res = captured(body)
-    assert graph.memset_nodes_replaced >= 1, "expected ATen's semaphore memsets in the captured graph"
+    from pointcloudmatters_amd._graphs import memset_fix_needed
+
+    assert graph.memset_nodes_replaced >= 1 or not memset_fix_needed(), "expected ATen's semaphore memsets in the captured graph"
     for it in range(1, 400):
         v = float(it % 64) / 64.0
         x.fill_(v)
@@ -79,3 +85,15 @@ def test_torch_reductions_inside_a_patched_graph(hip_device):
         assert abs(s3.mean().item() - (2 * v + 1) * rows) <= 1e-2 * rows, it
         assert abs(tot.item() - (2 * v + 1) * rows * cols) <= 1e-2 * rows * cols, it
         assert bool((s2 == s2[0]).all()), it
+
+
+def test_memset_fix_self_test_is_decided_once_and_overridable(hip_device, monkeypatch):
+    from pointcloudmatters_amd import _graphs
+
+    first = _graphs.memset_fix_needed()
+    assert isinstance(first, bool) and _graphs._NEEDS_FIX[torch.cuda.current_device()] == first
+    assert _graphs.memset_fix_needed() == first  # cached
+    monkeypatch.setenv("PCM_GRAPH_MEMSET_FIX", "0")
+    assert _graphs.memset_fix_needed() is False
+    monkeypatch.setenv("PCM_GRAPH_MEMSET_FIX", "1")
+    assert _graphs.memset_fix_needed() is True
