@@ -71,6 +71,7 @@ def parse():
                     help="where the per-kernel tables and the step trace are written (they are NOT part of the stdout line)")
     ap.add_argument("--cpu-steps", type=int, default=6)
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--cpu-baseline-child", type=int, default=0, help=argparse.SUPPRESS)  # internal: one host measurement at N threads
     return ap.parse_args()
 
 
@@ -362,15 +363,26 @@ def policy_kernels(t, wl, device, hidden=512):
     kk = torch.randn(b, Sk, hidden, **f32).to(torch.bfloat16).requires_grad_(True)
     vv = torch.randn(b, Sk, hidden, **f32).to(torch.bfloat16).requires_grad_(True)
     if small_attn.supported(q, kk, vv, nh, 0.0):
-        o = small_attn.small_attention(q, kk, vv, None, nh, 0.0)
-        go = torch.randn_like(o)
+        # the C entry points themselves (round 3 timed `o.backward(...)`: 105 us of autograd-engine host time around a 33 us
+        # kernel, which is what rocprofv3 showed for the same shape)
+        qd, kd, vd = q.detach(), kk.detach(), vv.detach()
+        o = torch.empty(b, Lq, hidden, dtype=torch.bfloat16, device=device)
+        lse = torch.empty(b, nh, Lq, **f32)
+        go = torch.randn(b, Lq, hidden, **f32).to(torch.bfloat16)
+        dq_, dk_, dv_ = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+        sd = lambda x: (x.stride(0), x.stride(1))  # noqa: E731
+        ahead = (b, nh, Lq, Sk, qd.data_ptr(), *sd(qd), kd.data_ptr(), *sd(kd), vd.data_ptr(), *sd(vd), 0, 1.0 / 8.0, 0.0, 0, 3)
         flops_f = 4 * b * nh * Lq * Sk * 64
 
-        def attn_b():
-            q.grad = kk.grad = vv.grad = None
-            o.backward(go, retain_graph=True)
+        def attn_f():
+            assert L.pcm_attn_small_forward_hip(*ahead, o.data_ptr(), lse.data_ptr(), st) == 0
 
-        t.add("pcm_attn_small_fwd_kernel", timed_events(lambda: small_attention_nograd(small_attn, q, kk, vv, nh), 30), None, "mfma",
+        def attn_b():
+            assert L.pcm_attn_small_backward_hip(*ahead, o.data_ptr(), go.data_ptr(), lse.data_ptr(), dq_.data_ptr(), *sd(dq_),
+                                                 dk_.data_ptr(), *sd(dk_), dv_.data_ptr(), *sd(dv_), st) == 0
+
+        attn_f()
+        t.add("pcm_attn_small_fwd_kernel", timed_events(attn_f, 30), None, "mfma",
               "decoder cross-attention core, %d queries x %d keys x %d (batch, head) pairs; softmax VALU work ~2x the MFMA time at "
               "head_dim 64" % (Lq, Sk, b * nh), flops=flops_f)
         t.add("pcm_attn_small_bwd_kernel", timed_events(attn_b, 30), None, "mfma", "same shape, dQ and dK/dV roles in one launch",
@@ -610,7 +622,10 @@ def pick_roofline(trace, kernels):
             out.update(bound="mfma", achieved=kr["achieved_TFLOPs"], peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s", frac=kr["frac_of_mfma_peak"],
                        traffic=pmc_traffic(key))
         else:
-            out.update(bound="hbm", limited_by=kr["bound"], achieved=kr["achieved_GBs"], peak=HBM_PEAK_GBS, unit="GB/s",
+            # a kernel that is neither HBM- nor MFMA-bound (FPS: a chain of dependent picks; the LDS-bound feed-forward) still gets
+            # its algorithmic bytes priced against the HBM peak -- the contract's fields -- but is LABELLED by what limits it
+            out.update(bound="latency" if kr["bound"] == "latency" else "hbm", limited_by=kr["bound"], achieved=kr["achieved_GBs"],
+                       peak=HBM_PEAK_GBS, unit="GB/s",
                        frac=kr["frac_of_hbm_peak"], traffic=pmc_traffic(key))
             for extra_key in kr:
                 if extra_key.startswith("clocks_per_pick") or extra_key in ("ns_per_pick", "dist_evals_per_s", "picks_per_s_per_cloud"):
@@ -645,32 +660,85 @@ def pmc_traffic(kernel, shape=None, table=None):
     return variants[0].get("hbm_bytes_per_launch") if len(variants) == 1 else None
 
 
-def cpu_baseline(wl, steps, threads=16):
-    """The reference path restated on the host: same harness, device=cpu, pointops = the C oracle
-    (OpenMP), model = plain PyTorch CPU ops in the reference's op order, fp32."""
+def cpu_baseline_child(workload, steps, threads, budget_s):
+    """One measurement of the host path in THIS process (spawned by cpu_baseline with its own OpenMP environment): the same
+    harness, device=cpu, pointops = the C oracle (OpenMP, capped at 16 threads: it parallelises over clouds / query blocks),
+    model = plain PyTorch CPU ops in the reference's op order, fp32.  Prints one JSON object."""
     from oracle import pointops_cpu
-    from pointcloudmatters_amd.bc import BCTrainer, build_act_policy, clone_batch, make_act_batch
+    from oracle.lib import load as load_oracle
+    from pointcloudmatters_amd.bc import WORKLOADS, BCTrainer, build_act_policy, clone_batch, make_act_batch
 
-    # more host threads are SLOWER on this path (measured on the 256-core GPU box at C2: 16 threads
-    # 1.76 s/step, 64 threads 3.3 s/step, 256 threads > 100 s/step), so the baseline uses 16.
-    host_cores = os.cpu_count() or 1
-    used = min(host_cores, threads)
-    torch.set_num_threads(used)
-    os.environ["OMP_NUM_THREADS"] = str(used)
+    wl = WORKLOADS[workload]
+    torch.set_num_threads(threads)
+    lib = load_oracle()
+    if hasattr(lib, "pcm_oracle_set_threads"):
+        lib.pcm_oracle_set_threads(min(threads, 16))
     torch.manual_seed(0)
     policy = build_act_policy(pcd_npoints=wl["pcd_npoints"], pointops=pointops_cpu, sa_impl="reference")
     trainer = BCTrainer(policy, total_steps=1000, precision="fp32", device="cpu", optim=dict(accumulate_grad_batches=1))
     batch = make_act_batch(wl["batch"], wl["n_points"], seed=1000, ragged=wl["ragged"], device="cpu")
+    t_w = time.perf_counter()
     trainer.training_step(clone_batch(batch))  # warm-up
-    t0 = time.perf_counter()
-    for _ in range(steps):
+    t_w = time.perf_counter() - t_w
+    done, t0 = 0, time.perf_counter()
+    while done < steps and (done == 0 or time.perf_counter() - t0 + t_w < budget_s):
         trainer.training_step(clone_batch(batch))
+        done += 1
     dt = time.perf_counter() - t0
-    return {"value": round(wl["batch"] * steps / dt, 4), "unit": "samples/s", "cores": used, "threads": used, "host_cores": host_cores,
-            "kind": "port", "dtype": "fp32",
-            "sample": "%d optimizer steps of the same workload (B=%d, N=%d, M=%d, fp32) after 1 warm-up; %.1f s; %d of the box's %d "
-                      "host cores (more threads are slower on this path)" % (steps, wl["batch"], wl["n_points"], wl["pcd_npoints"], dt, used,
-                                                                              host_cores)}
+    print(json.dumps({"threads": threads, "steps": done, "seconds": round(dt, 3), "s_per_step": round(dt / done, 4)}), flush=True)
+
+
+def cpu_baseline(workload, wl, steps, threads=16):
+    """The host path at several thread counts, each in its own process with a passive OpenMP wait policy (round 3 ran 16
+    threads inside this process and found "more threads are slower": torch's intra-op pool and the oracle's OpenMP team spun
+    against each other); the best one is reported, the others are listed.  Bounded: <= ~12 s of stepping per count."""
+    import subprocess
+
+    host_cores = os.cpu_count() or 1
+    counts = sorted({min(host_cores, c) for c in (threads, 64, host_cores)})
+    tried, best = {}, None
+    for c in counts:
+        env = dict(os.environ, OMP_NUM_THREADS=str(c), MKL_NUM_THREADS=str(c), OMP_WAIT_POLICY="passive", GOMP_SPINCOUNT="0",
+                   OMP_PROC_BIND="false", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", str(c), "--workload", workload,
+                                "--cpu-steps", str(steps)], env=env, capture_output=True, text=True, timeout=90)
+            rec = json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception as e:  # a thread count that cannot finish in time is simply not the best one
+            tried[str(c)] = "failed: %s" % type(e).__name__
+            continue
+        tried[str(c)] = rec["s_per_step"]
+        if best is None or rec["s_per_step"] < best["s_per_step"]:
+            best = rec
+    if best is None:
+        return {"error": "no thread count finished", "threads_tried": tried}
+    return {"value": round(wl["batch"] / best["s_per_step"], 4), "unit": "samples/s", "cores": best["threads"], "threads": best["threads"],
+            "host_cores": host_cores, "kind": "port", "dtype": "fp32", "s_per_step_by_threads": tried,
+            "sample": "%d optimizer steps of the same workload (B=%d, N=%d, M=%d, fp32) after 1 warm-up, %.1f s, at the best of %s "
+                      "threads (each count in its own process, passive OpenMP waits; oracle pointops capped at 16 threads)"
+                      % (best["steps"], wl["batch"], wl["n_points"], wl["pcd_npoints"], best["seconds"], "/".join(str(c) for c in counts))}
+
+
+def act_step_flops(wl, model=None):
+    """Algorithmic FLOP of one ACT training step (SURVEY.md section 8(d) with the fused SA algebra): forward multiply-adds of
+    every GEMM-shaped op x 2, backward priced at twice the forward (x 3 in total).  Per sample, S = M + 3 tokens, E = 512:
+    PointNet N * 82 304 MACs; SA N * 512 * 512 (+ M * K * 3 * 512 for the xyz term); encoder layers 4 E^2 S + 2 S^2 E + 2 S E F;
+    decoder layers (4 E^2 Q + 2 Q^2 E) + (2 E^2 Q + 2 E^2 S + 2 Q S E) + 2 Q E F; CVAE encoder like an encoder layer on T = Q + 2."""
+    from pointcloudmatters_amd.bc import ACT_MODEL
+
+    c = dict(ACT_MODEL if model is None else model)
+    E, F, Q = c["hidden_dim"], c["dim_feedforward"], c["num_queries"]
+    N, M, K = wl["n_points"], wl["pcd_npoints"], c["pcd_nsample"]
+    S, T = M + 2 + int(c["goal_cond_dim"] > 0), Q + 2
+    pointnet = N * (6 * 64 + 64 * 64 + 64 * 64 + 64 * 128 + 128 * 512)
+    sa = N * 512 * E + M * K * 3 * E
+
+    def enc(L):
+        return 4 * E * E * L + 2 * L * L * E + 2 * L * E * F
+
+    dec = (4 * E * E * Q + 2 * Q * Q * E) + (2 * E * E * Q + 2 * E * E * S + 2 * Q * S * E) + 2 * Q * E * F
+    macs = pointnet + sa + c["num_encoder_layers"] * (enc(S) + enc(T)) + c["num_decoder_layers"] * dec
+    return 3 * 2 * macs * wl["batch"]
 
 
 def run_workload(name, args, device, world, rank, steps, warmup, precision=None, mode="auto", trace_steps=0):
@@ -803,6 +871,9 @@ def main():
     args = parse()
     from pointcloudmatters_amd.bc import WORKLOADS
 
+    if args.cpu_baseline_child:
+        cpu_baseline_child(args.workload, args.cpu_steps, args.cpu_baseline_child, budget_s=14.0)
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -880,6 +951,13 @@ def main():
                        "dead_decoder_layers": "n/a" if is_dp else args.dead_decoder_layers},
             "final_loss": round(metrics.get("train/loss", float("nan")), 4),
         }
+        if not is_dp and wl["policy"] == "act":
+            # the whole step against the bf16 MFMA peak: algorithmic FLOP (act_step_flops: GEMM-shaped work, backward = 2 x
+            # forward) / measured step time / (ranks x 2.5 PFLOP/s).  Small by construction at B = 8: the step is a chain of
+            # ~450 launches on 0.5-4 k-row operands
+            fl = act_step_flops(wl)
+            out["step_mfma_frac"] = {"flop_per_step_per_gpu": fl, "tflops": round(fl / (dt / args.steps) / 1e12, 2),
+                                     "peak_tflops": MFMA_BF16_PEAK_TF, "frac": round(fl / (dt / args.steps) / 1e12 / MFMA_BF16_PEAK_TF, 5)}
         if exch is not None:  # how much of the gradient exchange backward did not hide (rank 0, events on the compute stream)
             out["config"]["gradient_exchange_exposed_ms"] = exch
         tables = {}
@@ -916,7 +994,7 @@ def main():
         if extra is not None:
             out["extra"] = extra
         if not args.no_cpu_baseline and world == 1 and not is_dp:
-            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_steps, args.cpu_threads)
+            out["cpu_baseline"] = cpu_baseline(args.workload, wl, args.cpu_steps, args.cpu_threads)
         emit(out, tables, args.tables_out)
     if world > 1:
         dist.barrier()

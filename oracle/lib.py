@@ -14,6 +14,7 @@ _f = ctypes.c_float
 
 _SIGS = {
     "pcm_opt_n_threads_cpu": [_i],
+    "pcm_oracle_set_threads": [_i],
     "pcm_farthest_point_sampling_cpu": [_i, _i, _F, _I, _I, _F, _I],
     "pcm_knn_query_cpu": [_i, _i, _F, _F, _I, _I, _I, _F],
     "pcm_ball_query_cpu": [_i, _i, _f, _f, _F, _F, _I, _I, _I, _F],

@@ -15,6 +15,9 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define PCM_TPB_MAX 1024
 #define PCM_KNN_MAX 128        /* knn_query_cuda_kernel.cu:82-83: float best_dist[128]          */
@@ -576,4 +579,17 @@ int pcm_attention_fusion_step_backward_cpu(int m, int g, int c, const float *wei
                 }
             }
     return 0;
+}
+
+/* Thread count of the oracle's own OpenMP team (bench.py's cpu_baseline leg: the host path's framework ops and the oracle
+ * must not both spin a full machine's worth of threads). */
+int pcm_oracle_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
 }

@@ -91,6 +91,9 @@ int pcm_attention_fusion_step_backward_cpu(int m, int g, int c, const float *wei
                                            float *grad_value, const int *index_target,
                                            const int *index_refer, const float *grad_output);
 
+/* test-infrastructure helper (not a kernel restatement): size of the oracle's OpenMP team */
+int pcm_oracle_set_threads(int n);
+
 #ifdef __cplusplus
 }
 #endif
