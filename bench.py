@@ -781,7 +781,11 @@ def run_workload(name, args, device, world, rank, steps, warmup, precision=None,
         # Data parallel runs take the same mode: every BatchNorm lives in the eager tokenizer, so its statistics are
         # synchronised across ranks (configs/trainer/ddp.yaml:9) with plain collectives, and the gradient slabs of the
         # captured stages are exchanged between graph replays, overlapping the rest of backward.
-        mode = "hybrid" if (wl["ragged"] or world > 1) else "graph"
+        # round 4: equal-size clouds at N > 1 no longer fall back to hybrid when every BatchNorm of the policy is owned by a fused
+        # kernel (the ACT policies): mode "graph" then captures the WHOLE step as a chain of graphs cut at the collectives
+        # (_graphs.SegmentedCapture), which stay plain eager RCCL calls between the replays
+        chainable = world > 1 and not wl["ragged"] and BCTrainer.all_batchnorms_fused(policy) and os.environ.get("PCM_DP_MODE", "graph") == "graph"
+        mode = "hybrid" if (wl["ragged"] or (world > 1 and not chainable)) else "graph"
     trainer = BCTrainer(policy, total_steps=max(steps + warmup + trace_steps, 100), precision=wl["dtype"], device=device,
                         distributed=world > 1, mode=mode, external_sampling=not getattr(args, "sampling_in_graph", False),
                         optim=dict(RLBENCH_DP_OPTIM) if is_rlbdp else (dict(DP_OPTIM) if is_dp else (

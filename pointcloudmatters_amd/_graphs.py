@@ -85,3 +85,118 @@ def captured(fn, pool=None):
         result = fn()
     graph.memset_nodes_replaced = finalize(graph)
     return graph, result
+
+
+# ---- a captured step with collectives in it -------------------------------------------------------------------------------
+# A data-parallel step contains collectives that must NOT be captured (RCCL owns its streams; the driver's 8-GPU run is the first
+# time they meet more than one device): the synchronised BatchNorm statistics of the tokenizer (6 all_gathers forward, 6
+# all_reduces backward, configs/trainer/ddp.yaml:9) and the gradient slabs between the backward stages.  Round 3 therefore ran the
+# whole tokenizer eagerly at N > 1 ("hybrid": ~95 launches + 12 collectives issued from Python per step, host-paced).  Here the
+# step is captured as a CHAIN: capture runs until code reaches a collective, the current graph is closed, the collective is
+# recorded as a plain Python call on the tensors the graphs read / write (static addresses in the shared graph pool), and a new
+# capture begins behind it.  A replayed step is then  g0 | all_gather | g1 | all_gather | ... | gK  : ~16 graph launches and ~15
+# collective launches from the host instead of ~560 kernel launches, every collective still a plain eager RCCL call.
+_CHAIN = None
+
+
+def chain():
+    """The SegmentedCapture that is recording right now (None: run collectives inline)."""
+    return _CHAIN
+
+
+def between(fn):
+    """Run `fn()` -- a collective on tensors that live across graph segments -- now, and, when a chain is recording, cut the
+    capture around it so that it is re-issued eagerly between the two graphs at every replay."""
+    c = _CHAIN
+    if c is None:
+        return fn()
+    return c.between(fn)
+
+
+class SegmentedCapture:
+    def __init__(self, pool=None):
+        self.items = []      # ("graph", CUDAGraph) | ("call", fn) in replay order
+        self.pool = pool
+        self.cur = None
+        self.memset_nodes_replaced = 0
+
+    # -- capture ---------------------------------------------------------------------------------------------------------
+    def __enter__(self):
+        global _CHAIN
+        import threading
+
+        assert _CHAIN is None, "segmented captures do not nest"
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        memset_fix_needed()  # the self-test captures graphs of its own: decide before this capture starts
+        self._thread = threading.get_ident()
+        self._stream = torch.cuda.Stream()
+        self._stream.wait_stream(torch.cuda.current_stream())
+        self._sctx = torch.cuda.stream(self._stream)
+        self._sctx.__enter__()
+        # backward nodes must run on THIS thread: a capture begun in thread-local mode has to be ended by the thread that began
+        # it, and `between` ends / begins captures from inside backward nodes (the SyncBN gradient statistics)
+        self._mt = torch.autograd.set_multithreading_enabled(False)
+        self._mt.__enter__()
+        _CHAIN = self
+        self._begin()
+        return self
+
+    def _begin(self):
+        g = new_graph()
+        kw = {} if self.pool is None else {"pool": self.pool}
+        g.capture_begin(capture_error_mode="thread_local", **kw)
+        self.cur = g
+
+    def _end(self):
+        g, self.cur = self.cur, None
+        g.capture_end()
+        if self.pool is None:
+            self.pool = g.pool()
+        self.memset_nodes_replaced += finalize(g)
+        self.items.append(("graph", g))
+
+    def between(self, fn):
+        import threading
+
+        assert threading.get_ident() == self._thread, "a collective was reached on another thread than the capturing one"
+        self._end()
+        out = fn()  # eager, on the capture stream (not capturing now): pairs up with the other ranks' captures
+        self.items.append(("call", fn))
+        self._begin()
+        return out
+
+    def __exit__(self, et, ev, tb):
+        global _CHAIN
+        _CHAIN = None
+        try:
+            if self.cur is not None:
+                if et is None:
+                    self._end()
+                else:  # leave capture mode whatever happened, keep the original exception
+                    try:
+                        self.cur.capture_end()
+                    except Exception:
+                        pass
+                    self.cur = None
+        finally:
+            self._mt.__exit__(et, ev, tb)
+            self._sctx.__exit__(et, ev, tb)
+            torch.cuda.current_stream().wait_stream(self._stream)
+        return False
+
+    # -- replay ----------------------------------------------------------------------------------------------------------
+    def replay(self):
+        for kind, x in self.items:
+            if kind == "graph":
+                x.replay()
+            else:
+                x()
+
+    @property
+    def n_graphs(self):
+        return sum(1 for k, _ in self.items if k == "graph")
+
+    @property
+    def n_calls(self):
+        return sum(1 for k, _ in self.items if k == "call")

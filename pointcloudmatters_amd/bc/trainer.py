@@ -167,8 +167,15 @@ class BCTrainer:
         # ---- synchronised BatchNorm (configs/trainer/ddp.yaml:9).  eager: torch's SyncBatchNorm.  flat / hybrid: the
         # BatchNorm layers the fused kernels own exchange their statistics themselves (policy/sync_bn.py), every other
         # BatchNorm module becomes a torch SyncBatchNorm -- all of them run OUTSIDE the captured graphs in hybrid mode.
-        # graph mode captures the whole step incl. the tokenizer: per-rank statistics (bench.py uses hybrid for N > 1).
-        self.sync_batchnorm = bool(self.distributed and sync_batchnorm and mode != "graph")
+        # graph mode (round 4): the step is captured as a CHAIN of graphs cut at every collective (_graphs.SegmentedCapture), so
+        # the tokenizer's synchronised statistics and the gradient slabs stay plain eager RCCL calls between graph replays.
+        # That needs every BatchNorm of the policy to be owned by a fused kernel (a torch SyncBatchNorm module would issue its
+        # collectives inside the capture): true for the ACT policies with the fused SA layer; otherwise graph mode keeps
+        # per-rank statistics, as before, and bench.py picks hybrid.
+        self.sync_batchnorm = bool(self.distributed and sync_batchnorm)
+        if self.sync_batchnorm and mode == "graph" and not self.all_batchnorms_fused(policy):
+            self.sync_batchnorm = False
+        self.segmented = bool(mode == "graph" and (self.distributed or os.environ.get("PCM_FORCE_SEGMENTS") == "1"))
         if self.sync_batchnorm:
             if mode == "eager":
                 policy = nn.SyncBatchNorm.convert_sync_batchnorm(policy)
@@ -271,6 +278,16 @@ class BCTrainer:
         self._static_sig = None
         self._works = []
         self._stepping = True
+
+    @staticmethod
+    def all_batchnorms_fused(policy):
+        """Every BatchNorm module of `policy` is in some owner's `fused_batchnorms()` (its statistics exchange is ours to place)."""
+        fused = set()
+        for owner in policy.modules():
+            get = getattr(owner, "fused_batchnorms", None)
+            if get is not None:
+                fused.update(id(m) for m in get())
+        return all(id(m) in fused for m in policy.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm))
 
     # ------------------------------------------------------------------------------------------ stages / exchange
     def _plan_stages(self, stage_defs):
@@ -475,10 +492,31 @@ class BCTrainer:
         return stats
 
     # ---- hipGraph capture helpers ---------------------------------------------------------------
+    def _capture_chain(self, make_gen, nseg):
+        """Data-parallel graph mode: the `nseg` backward stages of a generator captured as ONE chain of graphs that is cut at every
+        collective -- the gradient slab exchange behind each stage (here) and the synchronised BatchNorm statistics inside the
+        tokenizer's forward / backward nodes (policy/sync_bn.py -> _graphs.between).  Returns ([chain], stats)."""
+        from .._graphs import SegmentedCapture
+
+        chain = SegmentedCapture()
+        stats = None
+        with chain:
+            gen = make_gen()
+            for si in range(nseg):
+                _, stats = next(gen)
+                chain.between(lambda si=si: self._exchange(si))
+            for _ in gen:
+                pass
+        self._finish_exchange()  # the capture pass issued real (meaningless) slab all-reduces: join them before anything else
+        return [chain], stats
+
     def _capture_segments(self, make_gen, nseg):
         """Capture the `nseg` segments of a generator into one hipGraph each (shared memory pool: the later graphs use
         what the earlier ones saved for backward).  Returns (graphs, stats tensor)."""
         from .._graphs import finalize, new_graph
+
+        if getattr(self, "segmented", False) and self.mode == "graph":
+            return self._capture_chain(make_gen, nseg)
 
         gen = make_gen()
         graphs, stats, pool = [], None, None
@@ -772,9 +810,12 @@ class BCTrainer:
                     target.load_static_sampling(target.sampling_for(self._pcds_of(batch), overlap=True))
                 self._copy_into(self._static_batch, batch)
                 use_acc = not (first or self._graph_acc is None)
-                for si, g in enumerate(self._graph_acc if use_acc else self._graph):
-                    g.replay()
-                    self._exchange(si)
+                if self.segmented:  # one chain: graphs and the collectives between them, in capture order
+                    (self._graph_acc if use_acc else self._graph)[0].replay()
+                else:
+                    for si, g in enumerate(self._graph_acc if use_acc else self._graph):
+                        g.replay()
+                        self._exchange(si)
                 stats = (self._static_stats_acc if use_acc else self._static_stats).clone()
             else:
                 if first:

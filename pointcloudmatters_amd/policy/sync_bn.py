@@ -56,7 +56,10 @@ def combine_forward(bn, mean_loc, m2_loc, count_loc):
     pack = torch.cat([mean_loc.float(), m2_loc.float(), mean_loc.new_full((1,), float(count_loc), dtype=torch.float32)])
     world = dist.get_world_size(_group(bn))
     parts = [torch.empty_like(pack) for _ in range(world)]
-    dist.all_gather(parts, pack, group=_group(bn))
+    from .. import _graphs
+
+    grp = _group(bn)
+    _graphs.between(lambda: dist.all_gather(parts, pack, group=grp))
     allp = torch.stack(parts)
     n_r = allp[:, 2 * C:].double()                    # (W, 1)
     mean_r, m2_r = allp[:, :C].double(), allp[:, C: 2 * C].double()
@@ -84,16 +87,23 @@ _INTO_TENSOR_OK = {}
 
 def _all_gather_rows(out, row, group):
     """out[r] = row of rank r.  all_gather_into_tensor writes straight into `out` (no staging copies on RCCL); a backend without
-    it (decided once per backend) gets the list form on views of `out`."""
+    it (decided once per backend) gets the list form on views of `out`.  Inside a segmented capture (_graphs.SegmentedCapture)
+    the call is cut out of the graphs and re-issued eagerly between them at every replay."""
+    from .. import _graphs
+
     key = dist.get_backend(group)
-    if _INTO_TENSOR_OK.get(key, True):
-        try:
-            dist.all_gather_into_tensor(out.view(-1), row, group=group)
-            _INTO_TENSOR_OK[key] = True
-            return
-        except (RuntimeError, NotImplementedError):
-            _INTO_TENSOR_OK[key] = False
-    dist.all_gather(list(out.unbind(0)), row, group=group)
+
+    def gather():
+        if _INTO_TENSOR_OK.get(key, True):
+            try:
+                dist.all_gather_into_tensor(out.view(-1), row, group=group)
+                _INTO_TENSOR_OK[key] = True
+                return
+            except (RuntimeError, NotImplementedError):
+                _INTO_TENSOR_OK[key] = False
+        dist.all_gather(list(out.unbind(0)), row, group=group)
+
+    _graphs.between(gather)
 
 
 def combine_forward_sums(bn, sums, src, count_loc, row_index=None):
@@ -129,6 +139,9 @@ def combine_forward_sums(bn, sums, src, count_loc, row_index=None):
 def reduce_backward(bn, sums_loc, ratio):
     """(2, C) local {sum dy, sum dy * xhat} -> the same sums over all ranks, pre-scaled by n_loc / N (see combine_forward);
     the local copy stays untouched (it is the weight / bias gradient)."""
+    from .. import _graphs
+
     g = sums_loc.clone()
-    dist.all_reduce(g, group=_group(bn))
+    grp = _group(bn)
+    _graphs.between(lambda: dist.all_reduce(g, group=grp))  # eager between two graph segments when a step is being captured
     return g * ratio

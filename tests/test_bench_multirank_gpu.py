@@ -22,8 +22,11 @@ def _free_port():
     return port
 
 
-def test_bench_two_ranks_prints_one_line_and_exits(hip_device):
-    env = dict(os.environ, PCM_BENCH_SHARE_GPU="1", OMP_NUM_THREADS="4")
+@pytest.mark.parametrize("dp_mode", ["graph", "hybrid"])
+def test_bench_two_ranks_prints_one_line_and_exits(hip_device, dp_mode):
+    """dp_mode graph: what the driver's N > 1 runs use since round 4 (the whole step as a chain of hipGraphs cut at the collectives);
+    hybrid: the round-3 mode (eager tokenizer), still what ragged batches and the Diffusion Policy take (PCM_DP_MODE selects)."""
+    env = dict(os.environ, PCM_BENCH_SHARE_GPU="1", OMP_NUM_THREADS="4", PCM_DP_MODE=dp_mode)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "3"]
     res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
@@ -33,7 +36,7 @@ def test_bench_two_ranks_prints_one_line_and_exits(hip_device):
     assert len(res.stdout.splitlines()[-1]) < 4096  # the driver keeps a tail of stdout: the line must stay short
     out = lines[0]
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["warmup"] == 3 and out["scaling"] == "weak" and out["higher_is_better"]
-    assert out["config"]["global_batch"] == 16 and out["config"]["parallelism"] == "dp2" and out["config"]["step_mode"] == "hybrid"
+    assert out["config"]["global_batch"] == 16 and out["config"]["parallelism"] == "dp2" and out["config"]["step_mode"] == dp_mode
     assert out["config"]["batchnorm"] == "sync"
     ex = out["config"]["gradient_exchange_exposed_ms"]  # per-step exposed exchange time + the four slabs of the flat gradient
     assert ex["steps"] >= 4 and ex["exposed_ms_mean"] >= 0 and len(ex["slabs_mb"]) == 4 and abs(sum(ex["slabs_mb"]) - 96.4) < 1.0

@@ -31,6 +31,8 @@ def _free_port():
 def _rank_batches(rank, dev, kind="act"):
     from pointcloudmatters_amd.bc import make_act_batch, make_dp_batch
 
+    if kind == "act_graph":  # graph mode: equal-size clouds, the same layout every step
+        return [make_act_batch(2, 300, seed=500 + 10 * i + rank, ragged=False, device=dev, num_queries=10) for i in range(STEPS)]
     if kind == "dp":
         return [make_dp_batch(2, 150, seed=700 + 10 * i + rank, ragged=True, device=dev) for i in range(STEPS)]
     return [make_act_batch(2, 300, seed=500 + 10 * i + rank, ragged=True, device=dev, num_queries=10) for i in range(STEPS)]
@@ -76,11 +78,11 @@ def _build(kind):
     return build_act_policy(pcd_npoints=64, sa_impl="fused", **SMALL), dict(accumulate_grad_batches=1, lr=1e-3)
 
 
-def _train(dev, batches, eps, distributed, kind="act", tsteps=None):
+def _train(dev, batches, eps, distributed, kind="act", tsteps=None, mode="hybrid"):
     from pointcloudmatters_amd.bc import BCTrainer, clone_batch
 
     pol, optim = _build(kind)
-    tr = BCTrainer(pol.to(dev), total_steps=20, precision="fp32", device=dev, mode="hybrid", distributed=distributed, optim=optim)
+    tr = BCTrainer(pol.to(dev), total_steps=20, precision="fp32", device=dev, mode=mode, distributed=distributed, optim=optim)
     losses = []
     for i in range(STEPS):
         b = clone_batch(batches[i])
@@ -130,6 +132,7 @@ def _bn_of(tr, kind):
     return tr.policy.obs_encoder.bn if kind == "dp" else tr.policy.bn
 
 
+
 def _worker(rank, world, port, q, kind):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -146,25 +149,37 @@ def _worker(rank, world, port, q, kind):
             log.flat = self.optimizer.flat_g
 
         trainer_mod.BCTrainer.__init__ = init_and_register
-        tr, losses = _train(dev, _rank_batches(rank, dev, kind), _eps(rank, kind), distributed=True, kind=kind, tsteps=_timesteps(rank))
-        assert tr.mode == "hybrid" and tr.distributed and tr.sync_batchnorm and len(tr._stages) == 4
+        mode = "graph" if kind == "act_graph" else "hybrid"
+        tr, losses = _train(dev, _rank_batches(rank, dev, kind), _eps(rank, kind), distributed=True, kind=kind, tsteps=_timesteps(rank),
+                            mode=mode)
+        assert tr.mode == mode and tr.distributed and tr.sync_batchnorm and len(tr._stages) == 4
+        extra = {}
+        if mode == "graph":
+            # the step is ONE chain: graphs cut at the 6 + 6 synchronised-BatchNorm collectives and the 4 gradient slabs
+            chain = tr._graph[0]
+            assert tr.segmented and len(tr._graph) == 1
+            assert chain.n_calls == 6 + 6 + 4 and chain.n_graphs == chain.n_calls + 1, (chain.n_calls, chain.n_graphs)
+            extra["chain%d" % rank] = np.asarray([chain.n_graphs, chain.n_calls])
         # what the first multi-GPU execution will do, checked here on one device:
         #  * every collective runs OUTSIDE stream capture (the captured graphs stay collective-free);
         #  * per optimizer step exactly one all-reduce per non-empty gradient slab, each slab exchanged once, in stage order
         assert not any(captured for _, _, captured, _ in log.calls), [c for c in log.calls if c[2]]
         slabs = [c for c in log.calls if c[3] and c[0] == "all_reduce"]
         want = [s.slab[1] - s.slab[0] for s in tr._stages if s.slab[1] > s.slab[0]]
-        assert [n for _, n, _, _ in slabs] == want * STEPS, ([n for _, n, _, _ in slabs], want)
+        # (graph mode: the capture pass itself issues one round of slab exchanges -- every rank captures at the same step)
+        assert [n for _, n, _, _ in slabs] == want * (STEPS + (mode == "graph")), ([n for _, n, _, _ in slabs], want)
         assert sum(want) == tr.optimizer.flat_g.numel()
-        q.put({"losses%d" % rank: np.asarray(losses), "params%d" % rank: _named(tr),
+        q.put({**extra, "losses%d" % rank: np.asarray(losses), "params%d" % rank: _named(tr),
                "rm%d" % rank: _bn_of(tr, kind).running_mean.detach().cpu().numpy(),
                "ncoll%d" % rank: np.asarray([len(log.calls), len(slabs)])})
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["act", "dp"])
+@pytest.mark.parametrize("kind", ["act", "dp", "act_graph"])
 def test_two_ranks_in_hybrid_mode_equal_one_process_on_the_whole_batch(hip_device, kind):
+    """kind "act_graph": the same comparison for mode="graph" at N > 1 (round 4) -- the whole step, tokenizer included, replayed
+    as a chain of hipGraphs cut at every collective (_graphs.SegmentedCapture); equal-size clouds."""
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
     port = _free_port()
@@ -172,10 +187,11 @@ def test_two_ranks_in_hybrid_mode_equal_one_process_on_the_whole_batch(hip_devic
     for p in procs:
         p.start()
     got = {}
+    n_keys = 10 if kind == "act_graph" else 8
     for _ in range(3000):
         while not q.empty():
             got.update(q.get())
-        if len(got) >= 8 or any(p.exitcode not in (None, 0) for p in procs):
+        if len(got) >= n_keys or any(p.exitcode not in (None, 0) for p in procs):
             break
         time.sleep(0.1)
     for p in procs:
@@ -183,7 +199,7 @@ def test_two_ranks_in_hybrid_mode_equal_one_process_on_the_whole_batch(hip_devic
         if p.is_alive():
             p.kill()
         assert p.exitcode == 0
-    assert len(got) == 8
+    assert len(got) == n_keys
     assert got["ncoll0"].tolist() == got["ncoll1"].tolist()  # both ranks issued the same collectives
     # replicas stay identical
     assert got["params0"].keys() == got["params1"].keys()
@@ -194,7 +210,8 @@ def test_two_ranks_in_hybrid_mode_equal_one_process_on_the_whole_batch(hip_devic
     b0, b1 = _rank_batches(0, hip_device, kind), _rank_batches(1, hip_device, kind)
     whole = [_concat(x, y) for x, y in zip(b0, b1)]
     eps = torch.cat([_eps(0, kind), _eps(1, kind)], dim=1)
-    tr, losses = _train(hip_device, whole, eps, distributed=False, kind=kind, tsteps=torch.cat([_timesteps(0), _timesteps(1)], dim=1))
+    tr, losses = _train(hip_device, whole, eps, distributed=False, kind=kind, tsteps=torch.cat([_timesteps(0), _timesteps(1)], dim=1),
+                        mode="graph" if kind == "act_graph" else "hybrid")
     mean_losses = (got["losses0"] + got["losses1"]) / 2
     assert mean_losses == pytest.approx(np.asarray(losses), rel=2e-4)
     ref = _named(tr)
