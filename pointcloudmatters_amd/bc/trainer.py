@@ -161,7 +161,9 @@ class BCTrainer:
         freeze_unused_parameters(policy)
         self.policy = policy
         self.module = policy
-        self.distributed = distributed and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        from ..policy.sync_bn import multi_rank
+
+        self.distributed = bool(distributed and multi_rank())
         self.world = dist.get_world_size() if self.distributed else 1
         total_steps = max(int(total_steps), int(2 / o["pct_start"]) + 1)
         # ---- synchronised BatchNorm (configs/trainer/ddp.yaml:9).  eager: torch's SyncBatchNorm.  flat / hybrid: the

@@ -358,6 +358,12 @@ class ACTPCD(nn.Module):
         # its ~200 small kernels fill the gaps of the PointNet / set-abstraction branch.
         fork = self.overlap_sampling and getattr(self, "fork_cvae", True) and data_dict["qpos"].is_cuda
         if fork:
+            from .. import _graphs
+
+            # a step captured as a chain of graphs (data parallel, _graphs.SegmentedCapture) is cut at the tokenizer's BatchNorm
+            # collectives: a capture cannot be ended while a forked stream is still unjoined, so the branch runs in line there
+            fork = _graphs.chain() is None
+        if fork:
             main = torch.cuda.current_stream(data_dict["qpos"].device)
             side = self.__dict__.get("_cvae_stream")
             if side is None:

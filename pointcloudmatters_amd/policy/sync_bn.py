@@ -39,8 +39,19 @@ def enable_sync_batchnorm(policy, process_group=None):
     return policy
 
 
+def multi_rank():
+    """A process group with more than one rank is up.  PCM_DP_SINGLE_RANK=1 (tools/dbg/dp_single_rank.py) also accepts a ONE-rank
+    group: every collective of the data-parallel path is then really issued -- RCCL launch, stream hand-over and all -- on a
+    single GPU, which is how the host / launch overhead of the N > 1 program is measured on a one-GPU box."""
+    import os
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("PCM_DP_SINGLE_RANK") == "1"
+
+
 def wants_sync(bn):
-    return bool(getattr(bn, "_pcm_sync", False)) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return bool(getattr(bn, "_pcm_sync", False)) and multi_rank()
 
 
 def _group(bn):
