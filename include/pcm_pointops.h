@@ -371,6 +371,24 @@ int pcm_ffn_ln_backward2_hip(long R, int E, int F, const float *dout, const floa
                              const float *gamma, float p_hidden, float p_out, const long *seed, unsigned site_b,
                              float *dx, float *dy, float *dh, float *partial, float *sums, void *stream);
 
+/* ---- the same sub-layer on the matrix cores (csrc/ffn_mfma.hip), the bf16-autocast path ---------------------
+ * Same argument lists as pcm_ffn_ln_forward2_hip / pcm_ffn_ln_backward2_hip and the same dropout hash; the two products run as
+ * v_mfma_f32_32x32x16_bf16 (h and y leave their GEMMs as bf16, like F.linear under autocast; transformer.py:253-256, 342-345),
+ * everything stored stays fp32.  One workgroup per 32-row tile: `partial` has pcm_ffn_ln_mfma_blocks(R) rows of 3E + F. */
+int pcm_ffn_ln_mfma_supported(int E, int F);
+int pcm_ffn_ln_mfma_blocks(long R);
+int pcm_ffn_ln_mfma_forward_hip(long R, int E, int F, const float *x, const float *W1, const float *b1, const float *W2,
+                                const float *b2, const float *gamma, const float *beta, float eps, float p_hidden,
+                                float p_out, const long *seed, unsigned site_a, unsigned site_b, float *hd, float *s,
+                                float *out, float *mean, float *rstd, const float *pos, long pos_n, void *sum_bf16,
+                                void *out_bf16, void *stream);
+int pcm_ffn_ln_mfma_backward_hip(long R, int E, int F, const float *dout, const float *dout2, const float *x, const float *s,
+                                 const float *mean, const float *rstd, const float *hd, const float *W1, const float *W2,
+                                 const float *gamma, float p_hidden, float p_out, const long *seed, unsigned site_b,
+                                 float *dx, float *dy, float *dh, float *partial, float *sums, void *stream);
+/* out[e] = sum over the nslots rows of partial (nslots x VH), fp64 accumulation in a fixed order */
+int pcm_ffn_reduce_rows_hip(int nslots, int VH, const float *partial, float *out, void *stream);
+
 /* ---- Diffusion-Policy sampler: one fused DDPM reverse step x_t -> x_{t-1} ------------------------------
  * replaces diffusers' DDPMScheduler.step + the conditioning re-imposition inside `conditional_sample`
  * (src/models/components/diffusion_policy/diffusion_unet_image_policy.py:130-141): epsilon prediction,

@@ -79,6 +79,13 @@ SIGNATURES = {
                                 _P, _P, _P, _P, _P, _P, ctypes.c_long, _P, _P, _P],
     "pcm_ffn_ln_backward2_hip": [ctypes.c_long, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _f, _f, _P, ctypes.c_uint,
                                  _P, _P, _P, _P, _P, _P],
+    "pcm_ffn_ln_mfma_supported": [_i, _i],
+    "pcm_ffn_ln_mfma_blocks": [ctypes.c_long],
+    "pcm_ffn_ln_mfma_forward_hip": [ctypes.c_long, _i, _i, _P, _P, _P, _P, _P, _P, _P, _f, _f, _f, _P, ctypes.c_uint, ctypes.c_uint,
+                                    _P, _P, _P, _P, _P, _P, ctypes.c_long, _P, _P, _P],
+    "pcm_ffn_ln_mfma_backward_hip": [ctypes.c_long, _i, _i, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _f, _f, _P, ctypes.c_uint,
+                                     _P, _P, _P, _P, _P, _P],
+    "pcm_ffn_reduce_rows_hip": [_i, _i, _P, _P, _P],
     "pcm_ddpm_step_hip": [ctypes.c_long, _i, _P, _P, _P, _P, _P, _f, _f, _f, _f, _f, _f, _P, _P],
     "pcm_gn_mish_supported": [_i, _i, _i],
     "pcm_gn_mish_forward_hip": [_i, _i, _i, _i, _i, _P, _P, _P, _f, _i, _i, _P, _i, _P, _P, _P, _P, _P, _P],

@@ -352,6 +352,13 @@ int set_lds(K kernel, size_t bytes)
 }  // namespace
 
 extern "C" int pcm_ffn_ln_supported(int E, int F) { return (F == 32 && (E == 256 || E == 512)) ? 1 : 0; }
+
+extern "C" int pcm_ffn_reduce_rows_hip(int nslots, int VH, const float *partial, float *out, void *stream)
+{
+    if (nslots <= 0 || VH <= 0 || !partial || !out) return PCM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(pcm_ffn_reduce_kernel, dim3((VH + 63) / 64), dim3(512), 0, (hipStream_t)stream, nslots, VH, partial, out);
+    return PCM_LAUNCH_STATUS();
+}
 extern "C" int pcm_ffn_ln_blocks(long R) { return ffn_grid(R); }
 
 extern "C" int pcm_ffn_ln_forward2_hip(long R, int E, int F, const float *x, const float *W1, const float *b1, const float *W2,

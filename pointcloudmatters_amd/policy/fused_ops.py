@@ -379,6 +379,15 @@ def drln(x, y, norm, dropout):
     return _DRLN.apply(x, y, norm.weight, norm.bias, norm.eps, p, ctx.seed if p > 0 else None, ctx.next_site())
 
 
+# csrc/ffn_mfma.hip (the sub-layer's two products on the matrix cores, bf16-autocast roundings) is OPT-IN: measured on MI355X by graph
+# replay (tools/mb/mb_ffn.py) it is 17.0 / 20.2 us forward / backward at 4120 rows against 20.4 / 19.9 us for the fp32 kernel, and
+# 16 / 16 us against 8.8 / 9.2 us at the decoder's 800 rows -- the sub-layer is bound by memory INSTRUCTIONS per CU (a lane = row
+# MFMA layout touches 32 cache lines per load, and a 32-row tile keeps its whole traffic on one CU), not by the 0.3 GFLOP of
+# arithmetic.  PCM_FFN_MFMA=1 enables it from `FFN_MFMA_MIN_ROWS` rows on.
+FFN_MFMA = os.environ.get("PCM_FFN_MFMA", "0") != "0"
+FFN_MFMA_MIN_ROWS = int(os.environ.get("PCM_FFN_MFMA_MIN_ROWS", "2048"))
+
+
 class _FFNLN(Function):
     """out = norm(x + dropout_out(linear2(dropout_hidden(relu(linear1(x)))))) -- csrc/ffn.hip."""
 
@@ -398,15 +407,20 @@ class _FFNLN(Function):
             mean, rstd = torch.empty(R, **f32), torch.empty(R, **f32)
             sp = seed.data_ptr() if seed is not None else 0
             extra, rec = _emit_args(emit, R, E, dev)
-            rc = L.pcm_ffn_ln_forward2_hip(R, E, Fh, x2.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+            # bf16 autocast: the two products are bf16 GEMMs in the reference recipe -> the matrix-core kernel (csrc/ffn_mfma.hip);
+            # fp32 runs keep the fp32 kernel (csrc/ffn.hip).  Opt-in, see FFN_MFMA above
+            mfma = FFN_MFMA and R >= FFN_MFMA_MIN_ROWS and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16 \
+                and bool(L.pcm_ffn_ln_mfma_supported(E, Fh))
+            fwd = L.pcm_ffn_ln_mfma_forward_hip if mfma else L.pcm_ffn_ln_forward2_hip
+            rc = fwd(R, E, Fh, x2.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
                                            gamma.data_ptr(), beta.data_ptr(), float(eps), float(p_hidden), float(p_out), sp,
                                            int(site_a), int(site_b), hd.data_ptr(), s.data_ptr(), out.data_ptr(), mean.data_ptr(),
                                            rstd.data_ptr(), *extra, _raw_stream())
             if emit is not None:
                 emit["record"] = rec
-        _lib.check(rc, "pcm_ffn_ln_forward2_hip")
+        _lib.check(rc, "pcm_ffn_ln_mfma_forward_hip" if mfma else "pcm_ffn_ln_forward2_hip")
         ctx.save_for_backward(x2, w1, w2, gamma, hd, s, mean, rstd)
-        ctx.meta = (shape, float(p_hidden), float(p_out), seed, int(site_b))
+        ctx.meta = (shape, float(p_hidden), float(p_out), seed, int(site_b), mfma)
         ctx.side_ok = _goes_to_optimizer(w1) and _goes_to_optimizer(w2)
         ctx.defer = deferred.targets(w1, b1, w2, b2, gamma, beta)
         if n_out == 1:
@@ -418,7 +432,7 @@ class _FFNLN(Function):
     def backward(ctx, *douts):
         L = _lib.load()
         x2, w1, w2, gamma, hd, s, mean, rstd = ctx.saved_tensors
-        shape, p_hidden, p_out, seed, site_b = ctx.meta
+        shape, p_hidden, p_out, seed, site_b, mfma = ctx.meta
         R, E = x2.shape
         Fh = w1.shape[0]
         dev = x2.device
@@ -429,18 +443,19 @@ class _FFNLN(Function):
         with torch.cuda.device(dev):
             dx, dy, dh = torch.empty(R, E, **f32), deferred.take((R, E), torch.float32, dev, "ffn.dy"), deferred.take((R, Fh), torch.float32, dev, "ffn.dh")
             pw = 3 * E + Fh
-            blocks = L.pcm_ffn_ln_blocks(R)
+            blocks = L.pcm_ffn_ln_mfma_blocks(R) if mfma else L.pcm_ffn_ln_blocks(R)
             partial = torch.empty(blocks * pw, **f32)
             sums = torch.empty(pw, **f32)
             defer = deferred.clear(*ctx.defer)
             defer_sums = defer and R > 0 and deferred.push(partial, blocks, pw, out_f32=sums)
-            rc = L.pcm_ffn_ln_backward2_hip(R, E, Fh, d2.data_ptr(), d2b.data_ptr() if d2b is not None else 0, x2.data_ptr(),
+            bwd = L.pcm_ffn_ln_mfma_backward_hip if mfma else L.pcm_ffn_ln_backward2_hip
+            rc = bwd(R, E, Fh, d2.data_ptr(), d2b.data_ptr() if d2b is not None else 0, x2.data_ptr(),
                                             s.data_ptr(), mean.data_ptr(), rstd.data_ptr(), hd.data_ptr(), w1.data_ptr(),
                                             w2.data_ptr(), gamma.data_ptr(), p_hidden, p_out,
                                             seed.data_ptr() if seed is not None else 0, site_b, dx.data_ptr(), dy.data_ptr(),
                                             dh.data_ptr(), partial.data_ptr(), 0 if defer_sums else sums.data_ptr(),
                                             _raw_stream())
-            _lib.check(rc, "pcm_ffn_ln_backward2_hip")
+            _lib.check(rc, "pcm_ffn_ln_mfma_backward_hip" if mfma else "pcm_ffn_ln_backward2_hip")
             from .rows_linear import weight_grad
 
             with torch.autocast(device_type="cuda", enabled=False):
