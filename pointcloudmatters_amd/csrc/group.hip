@@ -33,7 +33,8 @@ __global__ __launch_bounds__(kBlock) void pcm_grouping_fwd_kernel(long rows, int
                                                                   const int *__restrict__ idx, float *__restrict__ output)
 {
     const int lane = threadIdx.x & 63;
-    for (long r = wave_id(); r < rows; r += wave_count()) {
+    const PcmXcdSplit sp = pcm_xcd_split(rows, kWavesPerBlock);  // see pcm_common.hpp
+    for (long r = sp.first + (threadIdx.x >> 6); r < sp.hi; r += sp.step) {
         const long src = (long)idx[r];
         if (VEC4) {
             const float4 *in4 = reinterpret_cast<const float4 *>(input + src * c);
@@ -69,7 +70,9 @@ __global__ __launch_bounds__(kBlock) void pcm_group_xyz_feat_fwd_kernel(long row
 {
     const int lane = threadIdx.x & 63;
     const int w = c + xc;
-    for (long r = wave_id(); r < rows; r += wave_count()) {
+    // XCD x gathers for the x-th eighth of the output rows = whole clouds: a feature row is fetched by one L2, not by eight
+    const PcmXcdSplit sp = pcm_xcd_split(rows, kWavesPerBlock);
+    for (long r = sp.first + (threadIdx.x >> 6); r < sp.hi; r += sp.step) {
         const int src = idx[r];
         const long q = r / nsample;
         float *out = output + r * w;
@@ -110,9 +113,9 @@ extern "C" int pcm_grouping_forward_hip(int m, int nsample, int c, const float *
     hipStream_t st = (hipStream_t)stream;
     const bool vec4 = (c % 4 == 0) && (((uintptr_t)input | (uintptr_t)output) % 16 == 0);
     if (vec4)
-        hipLaunchKernelGGL(pcm_grouping_fwd_kernel<true>, dim3(grid_for_rows(rows)), dim3(kBlock), 0, st, rows, c, input, idx, output);
+        hipLaunchKernelGGL(pcm_grouping_fwd_kernel<true>, dim3(pcm_xcd_grid(grid_for_rows(rows))), dim3(kBlock), 0, st, rows, c, input, idx, output);
     else
-        hipLaunchKernelGGL(pcm_grouping_fwd_kernel<false>, dim3(grid_for_rows(rows)), dim3(kBlock), 0, st, rows, c, input, idx, output);
+        hipLaunchKernelGGL(pcm_grouping_fwd_kernel<false>, dim3(pcm_xcd_grid(grid_for_rows(rows))), dim3(kBlock), 0, st, rows, c, input, idx, output);
     return PCM_LAUNCH_STATUS();
 }
 
@@ -134,7 +137,7 @@ extern "C" int pcm_group_xyz_feat_forward_hip(int m, int nsample, int c, const f
     const long rows = (long)m * nsample;
     if (rows == 0) return PCM_OK;
     const int xc = (xyz != nullptr && new_xyz != nullptr) ? 3 : 0;
-    hipLaunchKernelGGL(pcm_group_xyz_feat_fwd_kernel, dim3(grid_for_rows(rows)), dim3(kBlock), 0, (hipStream_t)stream, rows,
+    hipLaunchKernelGGL(pcm_group_xyz_feat_fwd_kernel, dim3(pcm_xcd_grid(grid_for_rows(rows))), dim3(kBlock), 0, (hipStream_t)stream, rows,
                        nsample, c, xc, xyz, new_xyz, feat, idx, output);
     return PCM_LAUNCH_STATUS();
 }

@@ -57,6 +57,33 @@ __device__ __forceinline__ uint32_t pcm_cvt_pk_bf16(float lo, float hi)
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, pcm_bf2));
 }
 
+// ---- XCD-aware work split -----------------------------------------------------------------------------------------------------
+// MI355X dispatches workgroup b to XCD b % 8, and every XCD has its own 4 MiB L2.  A gather kernel whose consecutive workgroups
+// take consecutive rows therefore spreads every cloud over all eight L2s, and each source row / record line is fetched from
+// HBM (or the Infinity Cache) up to eight times (PMC: 1.7-3.6x the algorithmic bytes, profiles/r03_bench_tables.json).  With
+// this split XCD x owns the x-th contiguous eighth of the rows -- whole clouds, in the packed layout -- so a source line is
+// fetched by ONE L2.  Launchers round the grid to a multiple of 8 (pcm_xcd_grid); results do not change (same per-row code).
+struct PcmXcdSplit {
+    long lo, hi;     // this workgroup's row range [lo, hi)
+    long first, step;  // first row of this workgroup's first item and the row stride between its passes, for `per_block` rows per pass
+};
+__device__ __forceinline__ PcmXcdSplit pcm_xcd_split(long rows, long per_block)
+{
+    PcmXcdSplit s;
+    if ((gridDim.x & 7) != 0 || gridDim.x < 8) {  // not split: one range, blocks strided over it
+        s.lo = 0, s.hi = rows, s.first = (long)blockIdx.x * per_block, s.step = (long)gridDim.x * per_block;
+        return s;
+    }
+    const long xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, per = gridDim.x >> 3;
+    const long chunk = (rows + 7) >> 3;
+    s.lo = xcd * chunk;
+    s.hi = s.lo + chunk < rows ? s.lo + chunk : rows;
+    s.first = s.lo + lb * per_block;
+    s.step = per * per_block;
+    return s;
+}
+static inline int pcm_xcd_grid(long blocks) { return (int)(blocks >= 8 ? (blocks + 7) / 8 * 8 : (blocks < 1 ? 1 : blocks)); }
+
 __device__ __forceinline__ int pcm_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 // Squared distance in the reference's order: (a-b)*(a-b) for x, y, z summed left to right.

@@ -219,10 +219,15 @@ __global__ __launch_bounds__(kBlock) void pcm_sa_bwd1_gather_kernel(int n, int K
     const int grp = threadIdx.x / G, sub = threadIdx.x % G;
     float *row = tile + (size_t)grp * H;
     const int KS = K + 1;
-    const int npass = (n + gridDim.x * GPB - 1) / (gridDim.x * GPB);  // same trip count for every group of a wave
+    // XCD x scatters into the x-th eighth of the points = whole clouds: all runs of a query's (channel, delta) records are then read
+    // through ONE L2 (round 3: consecutive workgroups took consecutive points, a record line was fetched by ~4 XCDs: PMC 3.57x at H = 96)
+    const PcmXcdSplit sp = pcm_xcd_split(n, GPB);
+    const long span = sp.hi > sp.lo ? sp.hi - sp.lo : 0;  // uniform inside a workgroup: every group of a wave makes the same trips
+    const int npass = (int)((span + sp.step - 1) / sp.step);
     for (int pass = 0; pass < npass; ++pass) {
-        const int j = (pass * gridDim.x + blockIdx.x) * GPB + grp;
-        const bool on = j < n;
+        const long jl = sp.first + (long)pass * sp.step + grp;
+        const int j = (int)jl;
+        const bool on = jl < sp.hi;
         for (int c = sub; c < H; c += G) row[c] = 0.f;
         wave_lds_sync();
         const int t0 = on ? start[j] : 0, t1 = on ? start[j + 1] : 0;
@@ -363,6 +368,7 @@ extern "C" int pcm_sa_bwd1_det_hip(int m, int n, int K, int H, const float *dz, 
         const int gpb = kBlock / G;
         long blocks = ((long)n + gpb - 1) / gpb;
         if (blocks > 256L * 32) blocks = 256L * 32;
+        blocks = pcm_xcd_grid(blocks);
         const size_t lds = (size_t)gpb * H * sizeof(float);
 #define PCM_GATHER(GG) hipLaunchKernelGGL(pcm_sa_bwd1_gather_kernel<GG>, dim3((int)blocks), dim3(kBlock), lds, st, n, K, H, start, list, goff, cperm, dperm, D)
         if (G == 64) PCM_GATHER(64); else if (G == 32) PCM_GATHER(32); else PCM_GATHER(16);

@@ -235,9 +235,9 @@ __global__ __launch_bounds__(kBlock) void pcm_segment_sum_kernel(SegArgs a)
     constexpr int UN = 4;  // entries in flight
     const int lpr = 1 << a.lpr_log2;
     const int sub = threadIdx.x & (lpr - 1);
-    const long group = ((long)blockIdx.x * kBlock + threadIdx.x) >> a.lpr_log2;
-    const long ngroups = ((long)gridDim.x * kBlock) >> a.lpr_log2;
-    for (long j = group; j < a.n_dst; j += ngroups) {
+    // XCD x sums the x-th eighth of the destination rows (pcm_common.hpp): the source rows of a cloud go through one L2
+    const PcmXcdSplit sp = pcm_xcd_split(a.n_dst, kBlock >> a.lpr_log2);
+    for (long j = sp.first + (threadIdx.x >> a.lpr_log2); j < sp.hi; j += sp.step) {
         long t0, t1;
         if (a.start) {
             t0 = a.start[j];
@@ -413,7 +413,7 @@ extern "C" int pcm_segment_sum_hip(long n_dst, int c, const int *start, int segl
     if (l2 < 2) l2 = 2;
     a.lpr_log2 = l2;
     const long per_block = kBlock >> l2;
-    const int grid = blocks_for(n_dst, per_block, 256L * 32);
+    const int grid = pcm_xcd_grid(blocks_for(n_dst, per_block, 256L * 32));
     hipStream_t st = (hipStream_t)stream;
 #define PCM_SEG_LAUNCH(V, S) hipLaunchKernelGGL((pcm_segment_sum_kernel<V, S>), dim3(grid), dim3(kBlock), 0, st, a)
     if (vec4) {
