@@ -21,6 +21,7 @@
  */
 #ifndef PCM_POINTOPS_H
 #define PCM_POINTOPS_H
+#include <stddef.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -72,6 +73,12 @@ int pcm_ball_query_hip(int m, int nsample, float min_radius, float max_radius, c
 int pcm_ball_query_b_hip(int b, int m, int nsample, float min_radius, float max_radius, const float *xyz,
                          const float *new_xyz, const int *offset, const int *new_offset, int *idx,
                          float *dist2, void *stream);
+/* same results through two kernels and a caller-provided workspace (candidate collection at full occupancy, then the heap replay;
+ * csrc/ball.hip).  pcm_ball_query_ws_bytes(m) bytes of device memory, contents irrelevant; 0 = use pcm_ball_query_b_hip. */
+size_t pcm_ball_query_ws_bytes(int m);
+int pcm_ball_query_ws_hip(int b, int m, int nsample, float min_radius, float max_radius, const float *xyz,
+                          const float *new_xyz, const int *offset, const int *new_offset, int *idx, float *dist2,
+                          void *ws, size_t ws_bytes, void *stream);
 
 /* ---- K4 random ball query -------------------------------------------------------------------
  * replaces random_ball_query_cuda_launcher   random_ball_query/random_ball_query_cuda_kernel.h

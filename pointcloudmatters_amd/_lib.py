@@ -26,6 +26,8 @@ SIGNATURES = {
     "pcm_ball_query_hip": [_i, _i, _f, _f, _P, _P, _P, _P, _P, _P, _P],
     "pcm_random_ball_query_hip": [_i, _i, _f, _f, _P, _P, _P, _P, _P, _P, _P, _P],
     "pcm_ball_query_b_hip": [_i, _i, _i, _f, _f, _P, _P, _P, _P, _P, _P, _P],
+    "pcm_ball_query_ws_bytes": [_i],
+    "pcm_ball_query_ws_hip": [_i, _i, _i, _f, _f, _P, _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _P],
     "pcm_random_ball_query_b_hip": [_i, _i, _i, _f, _f, _P, _P, _P, _P, _P, _P, _P, _P],
     "pcm_grouping_forward_hip": [_i, _i, _i, _P, _P, _P, _P],
     "pcm_grouping_backward_hip": [_i, _i, _i, _P, _P, _P, _P],
@@ -132,7 +134,7 @@ SIGNATURES = {
 
 # functions that return a size (long); everything else returns an int status
 LONG_RESULTS = ("pcm_scatter_plan_ws_ints", "pcm_scatter_plan_sorted_scratch_ints", "pcm_sa_index_det_scratch_ints",
-                "pcm_sa_bwd1_det_ws_bytes")
+                "pcm_sa_bwd1_det_ws_bytes", "pcm_ball_query_ws_bytes")
 
 _LIB = None
 

@@ -286,6 +286,167 @@ __global__ __launch_bounds__(64) void pcm_ball_query_lanes_kernel(int m, int nsa
     }
 }
 
+// ---- split variant (round 4): candidate COLLECTION at full occupancy, heap replay out of LDS in a second, short kernel ----------
+// The lane-per-query kernel above keeps 36 KiB of candidate columns in LDS for its whole life, so three waves fit a CU and the
+// 4096-point scan -- a chain of dependent instructions -- runs with ONE wave per SIMD: ~290 clocks per point, 1.0 ms for 65 536
+// queries.  The scan needs no LDS at all: every lane of a wave (= 64 consecutive queries) tests the SAME point at the same
+// time, so the point's coordinates are wave-uniform and come through the scalar cache (s_load), and the rare appends (1-2 %
+// of the points) go straight to a workspace in global memory, lane-major so that equal slots of neighbouring queries share
+// lines.  With no LDS and ~40 VGPRs a CU holds 32 waves and the scan runs at the VALU rate (~11 vector instructions per point).
+// When there are few queries, S = 2 / 4 / 8 waves split each query's cloud into S scan-order segments with their own slot ranges;
+// reading the segments back in order restores the reference's scan order.  The replay kernel then loads each query's list into
+// LDS columns (lane = query, as above), replays heap_sort-without-heapify literally and writes the rows; queries with more than
+// kLaneCap candidates are flagged and redone by the wave-per-query kernel, exactly as before.
+// workspace: cnt (S, m) int32 | dist (S * cap_S, m) f32 | index (S * cap_S, m) u16 (cloud-local); cap_S = ball_seg_cap(S) slots per
+// segment (a segment that overflows flags its query like a query with more than kLaneCap candidates)
+__host__ __device__ inline int ball_seg_cap(int S) { return S == 1 ? kLaneCap : (S == 2 ? 80 : (S == 4 ? 64 : 48)); }
+__global__ __launch_bounds__(256) void pcm_ball_collect_kernel(int m, int S, float min_radius, float max_radius,
+                                                               const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                                                               const int *__restrict__ offset, const int *__restrict__ new_offset, int b,
+                                                               int *__restrict__ wcnt, float *__restrict__ wd, unsigned short *__restrict__ wi)
+{
+    const int lane = threadIdx.x & 63;
+    const int gw = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));  // global wave: (query block, segment)
+    const int nqb = (m + 63) >> 6;
+    if (gw >= nqb * S) return;
+    const int qblock = gw / S, seg = gw - qblock * S;
+    const int qb = qblock * 64;
+    const int q = qb + lane;
+    const bool live = q < m;
+    const int qq = live ? q : m - 1;
+    const float qx = new_xyz[(size_t)qq * 3 + 0], qy = new_xyz[(size_t)qq * 3 + 1], qz = new_xyz[(size_t)qq * 3 + 2];
+    const float max_r2 = max_radius * max_radius, min_r2 = min_radius * min_radius;
+    const int last = qb + 63 < m ? qb + 63 : m - 1;
+    const int c_first = pcm_cloud_of(qb, new_offset, b), c_last = pcm_cloud_of(last, new_offset, b);
+    int cnt = 0;
+    const int cap = ball_seg_cap(S);
+    float *myd = wd + (size_t)seg * cap * m + qq;
+    unsigned short *myi = wi + (size_t)seg * cap * m + qq;
+    for (int c = c_first; c <= c_last; ++c) {  // wave-uniform: a block of 64 queries rarely straddles clouds
+        const int start = c == 0 ? 0 : offset[c - 1], end = offset[c];
+        const int qs = c == 0 ? 0 : new_offset[c - 1], qe = new_offset[c];
+        const bool mine = live && q >= qs && q < qe;
+        const long len = end - start;
+        if (len > 65535) {  // cloud-local indices would not fit 16 bits: leave these queries to the wave-per-query kernel
+            if (mine) cnt = cap + 1;
+            continue;
+        }
+        const int p0 = start + (int)(len * seg / S), p1 = start + (int)(len * (seg + 1) / S);
+        if (!mine) continue;  // (lanes of other clouds sit this cloud out: exec mask, the loop bounds stay uniform)
+        // p is wave-uniform: the coordinates come through the scalar cache, eight points (three s_load_dwordx8) in flight before the
+        // first use; per point 3 v_sub + 5 v_mul / v_add against SGPR operands and three compares
+        int p = p0;
+        for (; p + 8 <= p1; p += 8) {
+            float c8[24];
+            const float *src = xyz + (size_t)p * 3;
+#pragma unroll
+            for (int i = 0; i < 24; ++i) c8[i] = src[i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float d2 = pcm_sqdist(qx, qy, qz, c8[3 * u], c8[3 * u + 1], c8[3 * u + 2]);
+                if (in_ball_f(d2, min_r2, max_r2)) {
+                    if (cnt < cap) {
+                        myd[(size_t)cnt * m] = d2;
+                        myi[(size_t)cnt * m] = (unsigned short)(p + u - start);
+                    }
+                    ++cnt;
+                }
+            }
+        }
+        for (; p < p1; ++p) {
+            const float d2 = pcm_sqdist(qx, qy, qz, xyz[(size_t)p * 3 + 0], xyz[(size_t)p * 3 + 1], xyz[(size_t)p * 3 + 2]);
+            if (in_ball_f(d2, min_r2, max_r2)) {
+                if (cnt < cap) {
+                    myd[(size_t)cnt * m] = d2;
+                    myi[(size_t)cnt * m] = (unsigned short)(p - start);
+                }
+                ++cnt;
+            }
+        }
+    }
+    if (live) wcnt[(size_t)seg * m + q] = cnt;
+}
+
+__global__ __launch_bounds__(64) void pcm_ball_replay_kernel(int m, int S, int nsample, const int *__restrict__ offset,
+                                                             const int *__restrict__ new_offset, int b, const int *__restrict__ wcnt,
+                                                             const float *__restrict__ wd, const unsigned short *__restrict__ wi,
+                                                             int *__restrict__ idx, float *__restrict__ dist2)
+{
+    __shared__ float cd[kLaneCap][64];
+    __shared__ unsigned short ci[kLaneCap][64];
+    const int lane = threadIdx.x;
+    for (int qb = blockIdx.x * 64; qb < m; qb += gridDim.x * 64) {
+        const int q = qb + lane;
+        const bool live = q < m;
+        if (!live) continue;  // no barrier below: every lane owns its LDS column
+        const int c = pcm_cloud_of(q, new_offset, b);
+        const int my_start = c == 0 ? 0 : offset[c - 1];
+        int cnt = 0;
+        bool over = false;
+        const int cap = ball_seg_cap(S);
+        for (int sg = 0; sg < S; ++sg) {  // segments in scan order
+            const int n_s = wcnt[(size_t)sg * m + q];
+            if (n_s > cap) over = true;
+            const int take = n_s < cap ? n_s : cap;
+            const float *sd = wd + (size_t)sg * cap * m + q;
+            const unsigned short *si = wi + (size_t)sg * cap * m + q;
+            for (int k = 0; k < take; ++k) {
+                if (cnt < kLaneCap) cd[cnt][lane] = sd[(size_t)k * m], ci[cnt][lane] = si[(size_t)k * m];
+                ++cnt;
+            }
+        }
+        int *oi = idx + (size_t)q * nsample;
+        float *od = dist2 + (size_t)q * nsample;
+        if (over || cnt > kLaneCap) {
+            oi[0] = -2;  // redone by the wave-per-query kernel
+            continue;
+        }
+        // heap_sort (:33-42) on the un-heapified candidate array, literally -- with the element that travels down the heap held in
+        // registers: swap(0, i) + reheap(i) moves a[i] to the root and sifts it down, every child that beats it moving up one level.
+        // The reference swaps at every level; holding the traveller and writing it once where it stops leaves the same array, with
+        // one LDS round trip per level (the two children) instead of three.
+        for (int i = cnt - 1; i > 0; --i) {
+            const float dr = cd[i][lane];
+            const unsigned short xr = ci[i][lane];
+            cd[i][lane] = cd[0][lane], ci[i][lane] = ci[0][lane];
+            int root = 0, child = 1;
+            while (child < i) {
+                // both children in one LDS round trip (child + 1 <= i is always a valid slot; it only counts below i)
+                float dc = cd[child][lane];
+                const float dc1 = cd[child + 1][lane];
+                if (child + 1 < i && dc1 > dc) child++, dc = dc1;
+                if (dr > dc) break;
+                cd[root][lane] = dc, ci[root][lane] = ci[child][lane];
+                root = child;
+                child = root * 2 + 1;
+            }
+            cd[root][lane] = dr, ci[root][lane] = xr;
+        }
+        if (cnt <= nsample) {
+            for (int i = 0; i < nsample; ++i) {
+                oi[i] = i < cnt ? my_start + (int)ci[i][lane] : -1;
+                od[i] = i < cnt ? cd[i][lane] : 1e10f;
+            }
+        } else {
+            const float sep = (float)cnt / nsample;  // :115
+            for (int i = 0; i < nsample; ++i) {
+                const int index = (int)(sep * i);  // :118
+                oi[i] = my_start + (int)ci[index][lane];
+                od[i] = (float)(my_start + (int)ci[index][lane]);  // :120 (sic): the reference stores the index as dist2
+            }
+        }
+    }
+}
+
+inline int ball_split_segments(int m)
+{
+    static const int forced = getenv("PCM_BALL_S") ? atoi(getenv("PCM_BALL_S")) : 0;  // A/B switch for tools/mb/mb_ball.py
+    if (forced == 1 || forced == 2 || forced == 4 || forced == 8) return forced;
+    int S = 1;  // >= 4 waves per SIMD (1024 SIMDs x 64 lanes): the scan hides its scalar-load latency (C5: S = 1 / 2 / 4 / 8 -> 611 / 420 / 345 / 327 us)
+    while (S < 8 && (long)m * S < 262144) S *= 2;
+    return S;
+}
+
 __global__ __launch_bounds__(256) void pcm_random_ball_query_kernel(int m, int nsample, float min_radius, float max_radius,
                                                                     const int *__restrict__ order,
                                                                     const float *__restrict__ xyz,
@@ -362,6 +523,42 @@ extern "C" int pcm_ball_query_b_hip(int b, int m, int nsample, float min_radius,
     }
     hipLaunchKernelGGL(pcm_ball_query_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, m, nsample, min_radius,
                        max_radius, xyz, new_xyz, offset, new_offset, b, idx, dist2, 0);
+    return PCM_LAUNCH_STATUS();
+}
+
+// Split path with a caller-provided workspace (the reference ABI has no room for one, so pcm_ball_query(_b)_hip keep the single-kernel
+// paths).  pcm_ball_query_ws_bytes(m) = 0 means "too few queries to pay for two launches": call pcm_ball_query_b_hip.
+extern "C" size_t pcm_ball_query_ws_bytes(int m)
+{
+    if (m < 8192) return 0;  // measured: 4096 queries x 1024 points 26 us in one kernel, 54 us split
+    const size_t S = (size_t)ball_split_segments(m);
+    return S * (size_t)m * 4 + S * ball_seg_cap((int)S) * (size_t)m * 4 + S * ball_seg_cap((int)S) * (size_t)m * 2 + 64;
+}
+
+extern "C" int pcm_ball_query_ws_hip(int b, int m, int nsample, float min_radius, float max_radius, const float *xyz,
+                                     const float *new_xyz, const int *offset, const int *new_offset, int *idx, float *dist2,
+                                     void *ws, size_t ws_bytes, void *stream)
+{
+    if (m < 0 || nsample < 1 || b <= 0) return PCM_ERR_BAD_ARG;
+    if (m == 0) return PCM_OK;
+    const size_t need = pcm_ball_query_ws_bytes(m);
+    if (need == 0 || ws == nullptr || ws_bytes < need)
+        return pcm_ball_query_b_hip(b, m, nsample, min_radius, max_radius, xyz, new_xyz, offset, new_offset, idx, dist2, stream);
+    hipStream_t st = (hipStream_t)stream;
+    const int S = ball_split_segments(m);
+    int *wcnt = static_cast<int *>(ws);
+    float *wd = reinterpret_cast<float *>(wcnt + (size_t)S * m);
+    unsigned short *wi = reinterpret_cast<unsigned short *>(wd + (size_t)S * ball_seg_cap(S) * m);
+    const long waves = (long)((m + 63) / 64) * S;
+    hipLaunchKernelGGL(pcm_ball_collect_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, m, S, min_radius, max_radius, xyz,
+                       new_xyz, offset, new_offset, b, wcnt, wd, wi);
+    int rblocks = (m + 63) / 64;
+    if (rblocks > 256 * 8) rblocks = 256 * 8;
+    hipLaunchKernelGGL(pcm_ball_replay_kernel, dim3(rblocks), dim3(64), 0, st, m, S, nsample, offset, new_offset, b, wcnt, wd, wi, idx,
+                       dist2);
+    int blocks = m < 256 * 16 ? m : 256 * 16;
+    hipLaunchKernelGGL(pcm_ball_query_kernel, dim3(blocks), dim3(64), 0, st, m, nsample, min_radius, max_radius, xyz, new_xyz, offset,
+                       new_offset, b, idx, dist2, 1);  // the flagged leftovers (> kLaneCap candidates, clouds above 65 535 points)
     return PCM_LAUNCH_STATUS();
 }
 

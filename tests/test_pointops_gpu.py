@@ -184,6 +184,51 @@ def test_ball_query_bit_exact_with_many_queries(hip_device, sizes, ms, nsample, 
     assert torch.equal(gd.cpu(), wd)
 
 
+BALL_SPLIT = [
+    # the split path (collect + replay kernels, csrc/ball.hip) at every segment count S: m * S >= 262 144 picks S
+    ([1100] * 8, [1024] * 8, 16, 0.1, 0.0, "uniform"),                        # 8 192 queries -> S = 8, segments of ~137 points
+    ([4096] * 8, [2048] * 8, 16, 0.1, 0.0, "uniform"),                        # REF-like: 16 384 queries, S = 8
+    ([900, 2500, 1300, 4000] * 9, [800, 2100, 1200, 3000] * 9, 8, 0.09, 0.02, "lattice"),  # 63 900 queries, S = 8, ragged, exact ties, blocks straddle clouds
+    ([1024] * 80, [900] * 80, 16, 0.08, 0.0, "dup"),                          # 72 000 queries -> S = 4, duplicated points
+    ([600] * 300, [500] * 300, 5, 0.15, 0.0, "uniform"),                      # 150 000 queries -> S = 2
+    ([2048] * 20, [1700] * 20, 32, 0.25, 0.0, "uniform"),                     # most queries beyond the replay's 96 slots: flagged, redone wave-per-query
+    ([300, 3000, 300], [300, 8000, 300], 16, 0.3, 0.0, "uniform"),            # one dense cloud: segment caps overflow for some queries only
+]
+
+
+@pytest.mark.parametrize("sizes,ms,nsample,rmax,rmin,mode", BALL_SPLIT)
+def test_ball_query_split_path_bit_exact(hip_device, sizes, ms, nsample, rmax, rmin, mode):
+    """From 8192 queries on `ball_query` runs as candidate collection (scalar-cache point reads, appends to a workspace) + heap replay
+    out of LDS columns + the wave-per-query kernel for flagged queries: same bits as the oracle and as the single-kernel entry point."""
+    from pointcloudmatters_amd import _lib
+    from pointcloudmatters_amd.pointops.query import ball_query_raw
+    from oracle import lib as olib
+
+    xyz, off = make_clouds(sizes, seed=19, mode=mode)
+    noff = new_offsets(ms)
+    m = sum(ms)
+    assert m >= 8192 and _lib.load().pcm_ball_query_ws_bytes(m) > 0
+    starts = [0] + off.tolist()[:-1]
+    sel = torch.cat([st + (torch.arange(mq) * 7919) % n for st, n, mq in zip(starts, sizes, ms)])
+    new_xyz = xyz[sel].contiguous()
+    wi = torch.zeros(m, nsample, dtype=torch.int32)
+    wd = torch.zeros(m, nsample, dtype=torch.float32)
+    rc = olib.load().pcm_ball_query_cpu(m, nsample, rmin, rmax, xyz.data_ptr(), new_xyz.data_ptr(), off.data_ptr(), noff.data_ptr(),
+                                        wi.data_ptr(), wd.data_ptr())
+    assert rc in (0, 2)
+    d = hip_device
+    gx, go, gq, gno = xyz.to(d), off.to(d), new_xyz.to(d), noff.to(d)
+    gi, gd = ball_query_raw(nsample, rmax, rmin, gx, go, gq, gno)
+    assert torch.equal(gi.cpu(), wi) and torch.equal(gd.cpu(), wd)
+    # the reference-ABI entry point (no workspace: one kernel) gives the same rows
+    L = _lib.load()
+    bi, bd = torch.empty_like(gi), torch.empty_like(gd)
+    assert L.pcm_ball_query_b_hip(len(ms), m, nsample, rmin, rmax, gx.data_ptr(), gq.data_ptr(), go.data_ptr(), gno.data_ptr(), bi.data_ptr(),
+                                  bd.data_ptr(), _lib.raw_stream()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(bi, gi) and torch.equal(bd, gd)
+
+
 @pytest.mark.parametrize("sizes,ms,nsample,rmax,rmin", [([1024] * 4, [256] * 4, 16, 0.1, 0.0), ([300, 20], [50, 20], 8, 0.3, 0.05)])
 def test_random_ball_query_bit_exact(hip_device, sizes, ms, nsample, rmax, rmin):
     from pointcloudmatters_amd.pointops.query import random_ball_query_raw
