@@ -68,6 +68,10 @@ WORKLOADS = {
     # configs[4] as the reference's RLBench Diffusion-Policy experiment really runs it: 512-d task embedding as goal, 11-d
     # action / proprioception, two micro-batches of 16 per optimizer step, ragged fused clouds (mode="hybrid")
     "RLBDP": dict(policy="dp_rlbench", batch=16, n_points=4096, pcd_npoints=2048, dtype="bf16", ragged=True),
+    # the `scratch_pointnet_pcd_presample.yaml` experiments at the C2 / REF shapes: SA layer on the raw features, PointNet on the
+    # sampled points (policy.pre_sample, act.py:509-530)
+    "C2P": dict(policy="act", batch=8, n_points=1024, pcd_npoints=512, dtype="bf16", ragged=False, pre_sample=True),
+    "REFP": dict(policy="act", batch=8, n_points=4096, pcd_npoints=2048, dtype="bf16", ragged=True, pre_sample=True),
     # C2 with ragged clouds: the headline shape as real data delivers it (mode="hybrid")
     "C2R": dict(policy="act", batch=8, n_points=1024, pcd_npoints=512, dtype="bf16", ragged=True),
     # C3 with ragged clouds (what GridSamplePCD really delivers): exercises mode="hybrid" for the Diffusion-Policy trainer

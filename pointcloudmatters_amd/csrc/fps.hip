@@ -371,7 +371,15 @@ extern "C" int pcm_farthest_point_sampling_hip(int b, int n, const float *xyz, c
         if (need <= 4 && small_t == 64) return launch_reg<64, 16, 4, true>(b, xyz, offset, new_offset, idx, L, st);
         if (need <= 4 && small_t == 128) return launch_reg<128, 8, 3, true>(b, xyz, offset, new_offset, idx, L, st);
         if (need <= 4) return launch_reg<256, 4, 2, true>(b, xyz, offset, new_offset, idx, L, st);
-        if (need <= 8) return launch_reg<256, 8, 2, true>(b, xyz, offset, new_offset, idx, L, st);
+        static const int big_t = getenv("PCM_FPS_BIG_T") ? atoi(getenv("PCM_FPS_BIG_T")) : 256;  // A/B switch for tools/mb (2048 < n <= 4096)
+        if (need <= 8) {
+            if (big_t == 512) return launch_reg<512, 4, 1, true>(b, xyz, offset, new_offset, idx, L, st);
+            if (big_t == 128) return launch_reg<128, 16, 3, true>(b, xyz, offset, new_offset, idx, L, st);
+            return launch_reg<256, 8, 2, true>(b, xyz, offset, new_offset, idx, L, st);
+        }
+        if (big_t == 512) return launch_reg<512, 8, 1, true>(b, xyz, offset, new_offset, idx, L, st);
+        if (big_t == 1024) return launch_reg<1024, 4, 0, true>(b, xyz, offset, new_offset, idx, L, st);
+        if (big_t == 128) return launch_reg<128, 32, 3, true>(b, xyz, offset, new_offset, idx, L, st);
         return launch_reg<256, 16, 2, true>(b, xyz, offset, new_offset, idx, L, st);
     }
     if (n <= 1024 * 8) {

@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import pointcloudmatters_amd.pointops as po  # noqa: E402
 
 dev = "cuda"
-for name, (b, n, mq) in {"C2": (8, 1024, 512), "C3": (128, 1024, 256), "C4": (8, 2048, 1024)}.items():
+for name, (b, n, mq) in {"C2": (8, 1024, 512), "C3": (128, 1024, 256), "C4": (8, 2048, 1024), "C5": (32, 4096, 2048), "roll": (1, 4096, 2048), "roll2": (2, 4096, 2048)}.items():
     g = torch.Generator(device=dev).manual_seed(1)
     xyz = torch.rand(b * n, 3, device=dev, generator=g)
     off = torch.arange(1, b + 1, device=dev, dtype=torch.int32) * n
