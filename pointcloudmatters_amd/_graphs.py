@@ -104,6 +104,13 @@ def chain():
     return _CHAIN
 
 
+def cuts():
+    """True while a chain is recording that CUTS the capture at collectives (no stream may stay forked across such a cut)."""
+    import os
+
+    return _CHAIN is not None and os.environ.get("PCM_DP_CAPTURE_COLLECTIVES") != "1"
+
+
 def between(fn):
     """Run `fn()` -- a collective on tensors that live across graph segments -- now, and, when a chain is recording, cut the
     capture around it so that it is re-issued eagerly between the two graphs at every replay."""
@@ -157,8 +164,13 @@ class SegmentedCapture:
         self.items.append(("graph", g))
 
     def between(self, fn):
+        import os
         import threading
 
+        if os.environ.get("PCM_DP_CAPTURE_COLLECTIVES") == "1":
+            # EXPERIMENT (off by default): leave the collective INSIDE the capture -- RCCL's launch and its stream hand-over become
+            # graph nodes, no cut.  Works with a one-rank group on one GPU (tools/dbg/dp_single_rank.py); never run on > 1 device.
+            return fn()
         assert threading.get_ident() == self._thread, "a collective was reached on another thread than the capturing one"
         self._end()
         out = fn()  # eager, on the capture stream (not capturing now): pairs up with the other ranks' captures

@@ -365,7 +365,7 @@ class ACTPCD(nn.Module):
             # (Measured and dropped: the branch as a graph of its own, replayed on a second stream beside the tokenizer's segments
             # and joined in front of the decoder -- 5.55 ms against 5.34 ms in line at C2, 7.29 against 7.08 at C4: two more cuts
             # and a cross-stream fork / join per step cost more than the 0.3 ms of overlap they buy.)
-            fork = _graphs.chain() is None
+            fork = not _graphs.cuts()
         if fork:
             main = torch.cuda.current_stream(data_dict["qpos"].device)
             side = self.__dict__.get("_cvae_stream")

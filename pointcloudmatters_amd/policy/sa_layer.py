@@ -130,7 +130,7 @@ def sample_and_query(owner, pointops, p, o, n_o, overlap=False, mask=None):
     if overlap and p.is_cuda:
         from .. import _graphs
 
-        overlap = _graphs.chain() is None  # no forked stream across the cuts of a segmented capture (see ACTPCD.forward)
+        overlap = not _graphs.cuts()  # no forked stream across the cuts of a segmented capture (see ACTPCD.forward)
     if not (overlap and p.is_cuda):
         idx, n_p, knn_idx, istats = run()
         return {"idx": idx, "n_p": n_p, "knn_idx": knn_idx, "istats": istats, "event": None}
