@@ -46,11 +46,19 @@ def build(force=False):
     return _SO
 
 
+def build_sanitized():
+    """oracle/libpcm_oracle_asan.so: the same source with -fsanitize=address,undefined (tests/test_oracle_sanitized.py)."""
+    subprocess.check_call(["make", "-C", _HERE, "libpcm_oracle_asan.so"], stdout=subprocess.DEVNULL)
+    return os.path.join(_HERE, "libpcm_oracle_asan.so")
+
+
 def load():
     global _LIB
     if _LIB is None:
-        build()
-        lib = ctypes.CDLL(_SO)
+        so = os.environ.get("PCM_ORACLE_LIB")  # another build of the same source (the sanitized one)
+        if not so:
+            so = build()
+        lib = ctypes.CDLL(so)
         for name, args in _SIGS.items():
             fn = getattr(lib, name)
             fn.argtypes = args

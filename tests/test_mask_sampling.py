@@ -56,7 +56,9 @@ def _check_dp(pointops, sa_impl, device="cpu"):
     enc = pol.obs_encoder.to(device).train()
     pcds = dict(batch["obs"]["pcds"], mask=torch.from_numpy(mx["dp.mask"]).to(device))
     feat = enc({"qpos": batch["obs"]["qpos"][:, :2].reshape(-1, 9), "pcds": pcds})
-    np.testing.assert_allclose(feat.detach().float().cpu().numpy(), mx["dp.bg25.feat"], rtol=RTOL, atol=ATOL)
+    # atol 5e-5 on features of magnitude ~0.1: the CPU GEMMs' summation order follows the thread count (one element of 294 moves by
+    # 1.7e-5 between 1 / 8 and 2 / 4 OpenMP threads); indices are compared exactly elsewhere, this line pins the arithmetic
+    np.testing.assert_allclose(feat.detach().float().cpu().numpy(), mx["dp.bg25.feat"], rtol=RTOL, atol=5e-5)
     (feat * torch.sin(torch.arange(feat.numel(), device=feat.device).float()).view_as(feat)).sum().backward()
     ref = mx["dp.bg25.grad.linear.weight"]
     g = enc.linear.weight.grad.cpu().numpy()
