@@ -29,6 +29,14 @@
 
 #pragma clang fp contract(fast)
 
+#ifdef PCM_FFN_CLOCKS  // tools/mb/experiments/mb_ffn_clocks.py: where does a tile's time go?  (never defined in the product build)
+__device__ long long pcm_ffn_clk[2][8][16];
+#define STAMP(k, i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) pcm_ffn_clk[k][threadIdx.x >> 6][i] = clock64(); } while (0)
+extern "C" int pcm_ffn_clocks_read(long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pcm_ffn_clk), sizeof(pcm_ffn_clk)); }
+#else
+#define STAMP(k, i) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int kNW = 8;          // waves per workgroup = per 32-row tile: a lane's serial work (its share of one row) is E / 16 values
@@ -216,6 +224,7 @@ __global__ __launch_bounds__(kT) void pcm_ffn_ln_mfma_fwd_kernel(long R, const f
     const int cbase = wave * G::CW;
     const int c_lane = cbase + 4 * h;  // first channel of this lane; its channels: c_lane + 32 mt + 8 q + i
     // hidden unit j = 8 q + 4 h + i -> pair (8 q + 4 h) / 2 + {0, 1};  channel c_lane + 32 mt + 8 q + i -> pair c_lane / 2 + 16 mt + 4 q + {0, 1}
+    STAMP(0, 0);
     const Drop da = make_drop(pa, seed_ptr, site_a, (uint32_t)rr, (uint32_t)(2 * h));
     const Drop db = make_drop(pb, seed_ptr, site_b, (uint32_t)rr, (uint32_t)(c_lane >> 1));
 
@@ -240,17 +249,20 @@ __global__ __launch_bounds__(kT) void pcm_ffn_ln_mfma_fwd_kernel(long R, const f
         for (int q = 0; q < 4; ++q) w2v[mt][q] = *reinterpret_cast<const float4 *>(w2row + 8 * q);
     }
     // ---- H^T (partial over this wave's channels) = W1[:, range] . X[rows, range]^T ----------------------------------------
+    STAMP(0, 1);
     f16v acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
 #pragma unroll
     for (int s = 0; s < G::S; ++s) acc1 = PCM_MFMA16(cvt8(w1v[s][0], w1v[s][1]), cvt8(xv[s][0], xv[s][1]), acc1);
+    STAMP(0, 2);
     // the second product's bias: issued before the first barrier (the registers of the W1 operands are free now)
 #pragma unroll
     for (int mt = 0; mt < G::MT; ++mt)
 #pragma unroll
         for (int q = 0; q < 4; ++q) b2v[mt][q] = *reinterpret_cast<const float4 *>(b2 + c_lane + 32 * mt + 8 * q);
     cross_wave_sum(acc1, red, wave, lane);
+    STAMP(0, 3);
     // ---- bias, relu, dropout_a; register r = 4 q + i <-> hidden unit 8 q + 4 h + i ----------------------------------------------
     float hd[16];
 #pragma unroll
@@ -270,6 +282,7 @@ __global__ __launch_bounds__(kT) void pcm_ffn_ln_mfma_fwd_kernel(long R, const f
     }
     const bf8 hb0 = as_bf8(make_uint4(pcm_cvt_pk_bf16(hd[0], hd[1]), pcm_cvt_pk_bf16(hd[2], hd[3]), pcm_cvt_pk_bf16(hd[4], hd[5]), pcm_cvt_pk_bf16(hd[6], hd[7])));
     const bf8 hb1 = as_bf8(make_uint4(pcm_cvt_pk_bf16(hd[8], hd[9]), pcm_cvt_pk_bf16(hd[10], hd[11]), pcm_cvt_pk_bf16(hd[12], hd[13]), pcm_cvt_pk_bf16(hd[14], hd[15])));
+    STAMP(0, 4);
     // ---- Y^T = W2[range, :] . Hd^T; residual, dropout_b, LayerNorm ------------------------------------------------------------
     float sv[G::NV];
     float sum = 0.f;
@@ -298,6 +311,7 @@ __global__ __launch_bounds__(kT) void pcm_ffn_ln_mfma_fwd_kernel(long R, const f
             }
         }
     }
+    STAMP(0, 5);
     // the epilogue's operands (LayerNorm affine, position rows of the emitted operands): issued before the statistics barriers
     float4 gv[G::MT][4], tv[G::MT][4];
 #pragma unroll
@@ -320,6 +334,7 @@ __global__ __launch_bounds__(kT) void pcm_ffn_ln_mfma_fwd_kernel(long R, const f
 #pragma unroll
     for (int j = 0; j < G::NV; ++j) sq += (sv[j] - mu) * (sv[j] - mu);
     const float rstd = rsqrtf(row_total(sq, slot[1], wave, n) * (1.f / E) + eps);
+    STAMP(0, 6);
     if (!ok) return;
     float *sl = s_out + row * E + c_lane, *ol = out + row * E + c_lane;
     __hip_bfloat16 *s16l = sum16 != nullptr ? sum16 + row * E + c_lane : nullptr, *x16l = x16 != nullptr ? x16 + row * E + c_lane : nullptr;
@@ -342,6 +357,7 @@ __global__ __launch_bounds__(kT) void pcm_ffn_ln_mfma_fwd_kernel(long R, const f
         }
     }
     if (wave == 0 && h == 0) mean_out[row] = mu, rstd_out[row] = rstd;
+    STAMP(0, 7);
 }
 
 // partial layout per workgroup (= per 32-row tile): [ dgamma(E) | dbeta(E) | db2(E) | db1(F) ]
