@@ -380,10 +380,10 @@ def drln(x, y, norm, dropout):
 
 
 # csrc/ffn_mfma.hip (the sub-layer's two products on the matrix cores, bf16-autocast roundings) is OPT-IN: measured on MI355X by graph
-# replay (tools/mb/mb_ffn.py) it is 17.0 / 20.2 us forward / backward at 4120 rows against 20.4 / 19.9 us for the fp32 kernel, and
-# 16 / 16 us against 8.8 / 9.2 us at the decoder's 800 rows -- the sub-layer is bound by memory INSTRUCTIONS per CU (a lane = row
-# MFMA layout touches 32 cache lines per load, and a 32-row tile keeps its whole traffic on one CU), not by the 0.3 GFLOP of
-# arithmetic.  PCM_FFN_MFMA=1 enables it from `FFN_MFMA_MIN_ROWS` rows on.
+# replay (tools/mb/mb_ffn.py) it is 18.0 / 18.1 us forward / backward at 4120 rows against 20.5 / 20.1 us for the fp32 kernel, and
+# 10.4 / 9.2 us against 8.8 / 9.2 us at the decoder's 800 rows -- a 16-row tile is a chain of dependent latencies (operand loads,
+# three LDS exchanges with barriers) with one wave per SIMD, ~26 k clocks whatever the row count, not 0.3 GFLOP
+# of arithmetic.  PCM_FFN_MFMA=1 enables it from `FFN_MFMA_MIN_ROWS` rows on.
 FFN_MFMA = os.environ.get("PCM_FFN_MFMA", "0") != "0"
 FFN_MFMA_MIN_ROWS = int(os.environ.get("PCM_FFN_MFMA_MIN_ROWS", "2048"))
 

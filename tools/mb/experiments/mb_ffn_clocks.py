@@ -20,7 +20,7 @@ L.pcm_ffn_clocks_read.argtypes = [P]
 dev = torch.device("cuda", 0)
 f32 = dict(dtype=torch.float32, device=dev)
 E, F = 512, 32
-names = ["issue loads", "mfma1 (waits for x, W1)", "cross-wave sum", "relu/dropout a", "mfma2 + residual + dropout b", "epilogue loads",
+names = ["issue loads + dropout keys (waits for the seed)", "mfma1 (waits for x, W1)", "cross-wave sum", "relu/dropout a", "mfma2 + residual + dropout b", "epilogue loads",
          "row statistics (2 barriers)", "normalise + stores"]
 for R in (800, 4120):
     x = torch.randn(R, E, **f32)
@@ -39,7 +39,7 @@ for R in (800, 4120):
     buf = (ctypes.c_longlong * (2 * 8 * 16))()
     assert L.pcm_ffn_clocks_read(buf) == 0
     print(f"R = {R}: clocks between stamps, per wave of workgroup 0 (forward)")
-    for w in range(8):
+    for w in range(4):
         c = [buf[(0 * 8 + w) * 16 + i] for i in range(8)]
         print("  wave", w, " ".join(f"{c[i + 1] - c[i]:7d}" for i in range(7)), " total", c[7] - c[0])
     print("   phases:", " | ".join(names[:7]))
