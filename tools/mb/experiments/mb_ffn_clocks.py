@@ -39,7 +39,9 @@ for R in (800, 4120):
     buf = (ctypes.c_longlong * (2 * 8 * 16))()
     assert L.pcm_ffn_clocks_read(buf) == 0
     print(f"R = {R}: clocks between stamps, per wave of workgroup 0 (forward)")
-    for w in range(4):
-        c = [buf[(0 * 8 + w) * 16 + i] for i in range(8)]
-        print("  wave", w, " ".join(f"{c[i + 1] - c[i]:7d}" for i in range(7)), " total", c[7] - c[0])
+    for it in range(2):
+        print("  pass", it, "(cold code)" if it == 0 else "(same code again, another tile: cold data)")
+        for w in range(4):
+            c = [buf[(it * 8 + w) * 16 + i] for i in range(8)]
+            print("    wave", w, " ".join(f"{c[i + 1] - c[i]:7d}" for i in range(7)), " total", c[7] - c[0])
     print("   phases:", " | ".join(names[:7]))
