@@ -588,6 +588,22 @@ int pcm_adamw_flat_hip(long n, float *p, const float *g, float *m, float *v, con
                        const float *partials, int npartials, float *norm_out, void *p_bf16,
                        void *stream);
 
+/* Gradient hand-off into the flat fp32 gradient buffer (and the packed-gradient assembly copies), n jobs per call, 96 per launch, job
+ * tables passed by value (capturable).  Replaces the per-tensor accumulate / bucket copies of the reference's loop
+ * (src/models/maniskill2_act_bc_module.py:64-86 under Lightning + DDP).  kind[i]:
+ *   PCM_XFER_ZERO      dst[i][0..numel) = 0                  (fp32 destination, src ignored)
+ *   PCM_XFER_SET_BF16  dst (fp32) = src (bf16)               PCM_XFER_SET_F32   dst (fp32) = src (fp32)
+ *   PCM_XFER_ADD_BF16  dst (fp32) += src (bf16, exact widen) PCM_XFER_ADD_F32   dst (fp32) += src (fp32)
+ *   PCM_XFER_COPY_2B   raw copy of numel 2-byte elements
+ * Jobs must not overlap; numel < 2^31 each.  Any alignment is accepted (16-byte aligned pairs take the vector path). */
+#define PCM_XFER_ZERO 0
+#define PCM_XFER_SET_BF16 1
+#define PCM_XFER_SET_F32 2
+#define PCM_XFER_ADD_BF16 3
+#define PCM_XFER_ADD_F32 4
+#define PCM_XFER_COPY_2B 5
+int pcm_xfer_batch_hip(int n, void *const *dst, const void *const *src, const long *numel, const int *kind, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -123,7 +123,17 @@ class FlatAdamW:
         kernel per parameter.  `subset` (ascending parameter indices) restricts the hand-off to those parameters (the
         hybrid trainer collects the captured half and the eager half of a step separately)."""
         by_dtype = {}
+        jobs, alive = [], []  # pcm_xfer_batch_hip jobs (dst, src, numel, kind); `alive` keeps the sources until the launch is enqueued
         zero_from = zero_to = None  # run of adjacent gradient slots without a gradient this step: one fill for the run
+        fast_ok = self.flat_g.is_cuda
+        gbase = self.flat_g.data_ptr()
+
+        def zero_run(a, b):
+            if fast_ok:
+                jobs.append((gbase + 4 * a, 0, b - a, _lib.XFER_ZERO))
+            else:
+                self.flat_g[a:b].zero_()
+
         for k in (range(len(self.params)) if subset is None else subset):
             p = self.params[k]
             g = self._stash[k] if self.shadow[k] is not None else p.grad
@@ -134,33 +144,36 @@ class FlatAdamW:
                         zero_to = o + p.numel()
                     else:
                         if zero_from is not None:
-                            self.flat_g[zero_from:zero_to].zero_()
+                            zero_run(zero_from, zero_to)
                         zero_from, zero_to = o, o + p.numel()
                 continue
-            d, s_ = by_dtype.setdefault(g.dtype, ([], []))
-            d.append(self.g_views[k])
-            s_.append(g)
+            if fast_ok and g.is_contiguous() and g.device == self.flat_g.device and g.dtype in (torch.bfloat16, torch.float32) \
+                    and g.numel() == p.numel():
+                bf = g.dtype == torch.bfloat16
+                kind = (_lib.XFER_SET_BF16 if bf else _lib.XFER_SET_F32) if first else (_lib.XFER_ADD_BF16 if bf else _lib.XFER_ADD_F32)
+                jobs.append((self.g_views[k].data_ptr(), g.data_ptr(), g.numel(), kind))
+                alive.append(g)
+            else:
+                d, s_ = by_dtype.setdefault(g.dtype, ([], []))
+                d.append(self.g_views[k])
+                s_.append(g)
             self._stash[k] = None
             p.grad = None
         if zero_from is not None:
-            self.flat_g[zero_from:zero_to].zero_()
-        for dsts, srcs in by_dtype.values():
+            zero_run(zero_from, zero_to)
+        if jobs:
+            # ONE table-driven launch per 96 tensors (csrc/optim.hip): zero runs, bf16 -> fp32 and fp32 copies (first micro-batch of an
+            # accumulation window) or adds (the later ones; the bf16 value is widened exactly, same sums as a cast-then-add)
+            with torch.cuda.device(self.flat_g.device):
+                _lib.xfer_batch(jobs)
+            del alive
+        for dsts, srcs in by_dtype.values():  # anything the kernel does not take (non-contiguous gradients)
             if first:
                 torch._foreach_copy_(dsts, srcs)
             elif srcs[0].dtype == torch.float32:
                 torch._foreach_add_(dsts, srcs)
             else:
-                # bf16 gradients into the fp32 buffer.  Large tensors: one mixed-dtype add each (reads 2 B + 4 B, writes 4 B
-                # per element -- the cast-then-add route moved 18 B and ran a cast kernel per tensor); the many small ones
-                # stay on the multi-tensor path.  Same sums either way (the bf16 value is widened exactly).
-                small_d, small_s = [], []
-                for d, s_ in zip(dsts, srcs):
-                    if s_.numel() >= (1 << 18):
-                        d.add_(s_)
-                    else:
-                        small_d.append(d), small_s.append(s_.to(torch.float32))
-                if small_d:
-                    torch._foreach_add_(small_d, small_s)
+                torch._foreach_add_(dsts, [s_.to(torch.float32) for s_ in srcs])
 
     # ---- device side (capturable) -----------------------------------------------------------------
     def zero_grad(self):

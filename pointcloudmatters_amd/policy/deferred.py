@@ -359,12 +359,8 @@ def _flush_copies():
     if not _P:
         return
     q, _P = _P, []
-    by = {}
-    for d, s_ in q:
-        by.setdefault((d.dtype, s_.dtype, d.device), []).append((d, s_))
-    for grp in by.values():
-        torch._foreach_copy_([d for d, _ in grp], [s_ for _, s_ in grp])
-        STATS["launches"] += 1
+    _lib.copy_pairs(q)  # same-dtype contiguous pairs: one table-driven launch per 96 (csrc/optim.hip); the rest: multi-tensor copies
+    STATS["launches"] += 1
 
 
 @torch.no_grad()

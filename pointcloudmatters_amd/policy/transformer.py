@@ -265,11 +265,16 @@ class _PackRows(torch.autograd.Function):
             out = torch.empty((rows * n,) + tuple(grp[0].shape[1:]), dtype=grp[0].dtype, device=grp[0].device)
             pairs += [(out[i * rows: (i + 1) * rows], t) for i, t in enumerate(grp)]
             outs.append(out)
-        by = {}
-        for d, s_ in pairs:
-            by.setdefault(d.dtype, []).append((d, s_))
-        for grp in by.values():
-            torch._foreach_copy_([d for d, _ in grp], [s_ for _, s_ in grp])
+        if pairs and pairs[0][0].is_cuda:
+            from .. import _lib
+
+            _lib.copy_pairs(pairs)  # one table-driven launch (csrc/optim.hip pcm_xfer_batch_hip)
+        else:
+            by = {}
+            for d, s_ in pairs:
+                by.setdefault(d.dtype, []).append((d, s_))
+            for grp in by.values():
+                torch._foreach_copy_([d for d, _ in grp], [s_ for _, s_ in grp])
         ctx.sizes = sizes
         ctx.rows = [t.shape[0] for t in ts]
         return tuple(outs)
