@@ -1,0 +1,110 @@
+"""GPU: kernels give the same bits when ANOTHER stream keeps the matrix cores busy.
+
+Round 4 found (tools/dbg/fps_beside_graph.py) that on this MI355X / ROCm 7.2 stack packed-fp32 VALU instructions with
+a broadcast operand half (v_pk_add_f32 ... op_sel, what the compiler emits for `vector - scalar`) return wrong values in a wave that shares
+its SIMD with the MFMA kernels of another stream: farthest-point sampling next to a replayed GEMM graph diverged from the oracle in 298 of
+300 runs, and the training step -- whose FPS / kNN run one batch ahead on a side stream -- used wrong neighbour lists in ~40 % of its
+steps whenever the host ran ahead of the device.  The library is therefore built without packed-fp32 instructions (csrc/Makefile NO_PK);
+these tests pin the behaviour: results beside a busy device == results on an idle device, and two un-synchronised training runs in two
+processes end with identical parameters."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _gemm_graph(dev, n=200):
+    a = torch.randn(2048, 2048, device=dev, dtype=torch.bfloat16)
+    (a @ a)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            for _ in range(n):
+                a @ a
+    torch.cuda.synchronize()
+    return g, a
+
+
+def test_sampling_kernels_beside_a_busy_device_equal_the_idle_result(hip_device):
+    from pointcloudmatters_amd import pointops
+
+    torch.manual_seed(0)
+    B, N, M, K = 8, 1024, 512, 16
+    p = torch.rand(B * N, 3, device=hip_device)
+    o = torch.arange(1, B + 1, device=hip_device, dtype=torch.int32) * N
+    n_o = torch.arange(1, B + 1, device=hip_device, dtype=torch.int32) * M
+    o._pcm_host, n_o._pcm_host = [N * (i + 1) for i in range(B)], [M * (i + 1) for i in range(B)]
+    ref = pointops.farthest_point_sampling(p, o, n_o)
+    q = p[ref.long()]
+    ref_knn, _ = pointops.knn_query(K, p, o, q, n_o)
+    ref_ball, _ = pointops.ball_query(K, 0.2, 0.0, p, o, q, n_o)
+    torch.cuda.synchronize()
+    g, _keep = _gemm_graph(hip_device)
+    side = torch.cuda.Stream()
+    out = []
+    for _ in range(60):  # no host synchronisation inside the loop: the side stream's kernels run while the GEMM graph replays
+        g.replay()
+        with torch.cuda.stream(side):
+            out.append((pointops.farthest_point_sampling(p, o, n_o), pointops.knn_query(K, p, o, q, n_o)[0],
+                        pointops.ball_query(K, 0.2, 0.0, p, o, q, n_o)[0]))
+    torch.cuda.synchronize()
+    bad = [sum(int(not torch.equal(t[i], r)) for t in out) for i, r in enumerate((ref, ref_knn, ref_ball))]
+    assert bad == [0, 0, 0], "results beside a busy device differ from the idle run (FPS, kNN, ball query): %s of 60" % bad
+
+
+def test_fused_rows_kernels_beside_a_busy_device_equal_the_idle_result(hip_device):
+    """The row kernels of the transformer tail (LayerNorm(x + dropout(y)), the feed-forward sub-layer) on a side stream -- where the CVAE
+    encoder's branch of the training step runs -- next to the GEMM graph."""
+    import torch.nn as nn
+
+    from pointcloudmatters_amd.policy import fused_ops
+
+    torch.manual_seed(1)
+    E, R = 512, 816
+    l1, l2, norm = nn.Linear(E, 32).to(hip_device), nn.Linear(32, E).to(hip_device), nn.LayerNorm(E).to(hip_device)
+    x = torch.randn(R, E, device=hip_device)
+    y = torch.randn(R, E, device=hip_device).to(torch.bfloat16)
+    ctx = fused_ops.FusedContext(hip_device)
+
+    def run():
+        ctx.site = 0
+        with fused_ops.activate(ctx), torch.autocast("cuda", dtype=torch.bfloat16), torch.no_grad():
+            a = fused_ops.drln(x, y, norm, nn.Dropout(0.1))
+            b = fused_ops.ffn_ln(x, l1, l2, norm, nn.Dropout(0.1), nn.Dropout(0.1))
+        return a, b
+
+    ctx.set_step(3)
+    ref = run()
+    torch.cuda.synchronize()
+    g, _keep = _gemm_graph(hip_device)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    out = []
+    for _ in range(40):
+        g.replay()
+        with torch.cuda.stream(side):
+            out.append(run())
+    torch.cuda.synchronize()
+    bad = [sum(int(not torch.equal(t[i], ref[i])) for t in out) for i in range(2)]
+    assert bad == [0, 0], bad
+
+
+def test_unsynchronised_training_runs_in_two_processes_end_identically():
+    """40 graph-mode bf16 steps at the C2 shape with the next batch's sampling prefetched and NO host synchronisation, twice, in two fresh
+    processes: every step read the right static index buffers and the final parameters are bit-identical (tools/dbg/repro_trace.py)."""
+    lines = []
+    for _ in range(2):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dbg", "repro_trace.py"), "40"], cwd=ROOT, capture_output=True, text=True,
+                           timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines.append(r.stdout.strip().splitlines()[-1])
+    assert "differ from the first occurrence of the same batch: 0 of 36" in lines[0], lines[0]
+    assert lines[0] == lines[1], lines
