@@ -108,3 +108,57 @@ def test_unsynchronised_training_runs_in_two_processes_end_identically():
         lines.append(r.stdout.strip().splitlines()[-1])
     assert "differ from the first occurrence of the same batch: 0 of 36" in lines[0], lines[0]
     assert lines[0] == lines[1], lines
+
+
+def test_attention_and_sa_layer_beside_a_busy_device_equal_the_idle_result(hip_device):
+    """MFMA attention (short query sets: attn_small; long ones: attn_flash), forward + backward with dropout, and the fused set-abstraction
+    layer forward + backward, on a side stream next to the GEMM graph: outputs and gradients bit-equal to the idle device's."""
+    from pointcloudmatters_amd import pointops
+    from pointcloudmatters_amd.policy import fused_ops, small_attn
+    from pointcloudmatters_amd.bc import build_act_policy
+
+    torch.manual_seed(2)
+    dev = hip_device
+    cases = []
+    for B, H, L, S in ((8, 8, 100, 100), (8, 8, 100, 515), (4, 8, 515, 515)):
+        E = H * 64
+        q = torch.randn(B, L, E, device=dev).bfloat16().requires_grad_(True)
+        k = torch.randn(B, S, E, device=dev).bfloat16().requires_grad_(True)
+        v = torch.randn(B, S, E, device=dev).bfloat16().requires_grad_(True)
+        cases.append((q, k, v, H, torch.randn(B, L, E, device=dev).bfloat16()))
+    ctx = fused_ops.FusedContext(dev)
+    ctx.set_step(5)
+    pol = build_act_policy(pcd_npoints=256, sa_impl="fused").to(dev).train()
+    n, b = 512, 4
+    p = torch.rand(b * n, 3, device=dev)
+    x = torch.randn(b * n, pol.backbone.num_channels if hasattr(pol.backbone, "num_channels") else 512, device=dev, requires_grad=True)
+    o = torch.arange(1, b + 1, device=dev, dtype=torch.int32) * n
+    o._pcm_host = [n * (i + 1) for i in range(b)]
+    bn_state = {kk: vv.clone() for kk, vv in pol.bn.state_dict().items()}
+
+    def run():
+        outs = []
+        ctx.site = 0
+        with fused_ops.activate(ctx):
+            for q, k, v, H, g in cases:
+                out = small_attn.small_attention(q, k, v, None, H, 0.1)
+                outs += [out.detach()] + [t.detach() for t in torch.autograd.grad(out, (q, k, v), g)]
+        pol.bn.load_state_dict(bn_state)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            n_p, feat, _ = pol.pcd_sampling([p, x, o])
+        gx, gw = torch.autograd.grad(feat, (x, pol.linear.weight), torch.ones_like(feat))
+        return outs + [n_p.detach(), feat.detach(), gx, gw]
+
+    ref = run()
+    torch.cuda.synchronize()
+    g, _keep = _gemm_graph(dev)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    results = []
+    for _ in range(25):
+        g.replay()
+        with torch.cuda.stream(side):
+            results.append(run())
+    torch.cuda.synchronize()
+    bad = [sum(int(not torch.equal(r[i], ref[i])) for r in results) for i in range(len(ref))]
+    assert not any(bad), "tensors that differ from the idle run, per output: %s of 25" % bad
