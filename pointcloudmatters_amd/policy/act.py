@@ -42,6 +42,15 @@ def reparametrize(mu, logvar, eps=None):
     return mu + std * eps
 
 
+
+def _lin(module, x):
+    """module(x) for the policy's small nn.Linear layers through rows_linear.linear_rows: same forward; in training on the GPU its
+    backward forms the bias gradient with the library's column sums instead of the framework's bf16 reduction (rows_linear.bias_grad)."""
+    from .rows_linear import linear_rows
+
+    return linear_rows(x, module.weight, module.bias)
+
+
 class ACTPCD(nn.Module):
     def __init__(
         self,
@@ -167,13 +176,13 @@ class ACTPCD(nn.Module):
         bs = qpos.shape[0]
         data_dict["is_training"] = is_training
         if is_training and not self.ignore_vae:
-            action_embed = self.encoder_action_proj(actions)  # (B, T, C)
-            qpos_embed = self.encoder_joint_proj(qpos).unsqueeze(1)  # (B, 1, C)
+            action_embed = _lin(self.encoder_action_proj, actions)  # (B, T, C)
+            qpos_embed = _lin(self.encoder_joint_proj, qpos).unsqueeze(1)  # (B, 1, C)
             cls_embed = self.cls_embed.weight.unsqueeze(0).expand(bs, -1, -1)  # (B, 1, C)
             enc_in = torch.cat([cls_embed, qpos_embed, action_embed], dim=1)  # (B, T+2, C)
             pad = torch.cat([is_pad.new_zeros(bs, 2), is_pad], dim=1)  # CLS / qpos are never padding
             enc_out = self.encoder(enc_in, pos=self.pos_table, src_key_padding_mask=pad)
-            latent_info = self.latent_proj(enc_out[:, 0])  # CLS token
+            latent_info = _lin(self.latent_proj, enc_out[:, 0])  # CLS token
             from . import fused_ops
 
             eps = data_dict.get("vae_eps", None)
@@ -189,7 +198,7 @@ class ACTPCD(nn.Module):
             latent_sample = torch.zeros([bs, self.latent_dim], dtype=torch.float32, device=qpos.device)
         data_dict["mu"] = mu
         data_dict["logvar"] = logvar
-        data_dict["latent_input"] = self.latent_out_proj(latent_sample)
+        data_dict["latent_input"] = _lin(self.latent_out_proj, latent_sample)
         return data_dict
 
     # ------------------------------------------------------------------ tokenizer (act.py:384-551)
@@ -273,7 +282,7 @@ class ACTPCD(nn.Module):
         if self.goal_cond_dim > 0:
             if data_dict["goal_cond"].dim() > 2:
                 data_dict["goal_cond"] = data_dict["goal_cond"].reshape(data_dict["goal_cond"].shape[0], -1)
-            goal_cond = self.proj_goal_cond_emb(data_dict["goal_cond"])
+            goal_cond = _lin(self.proj_goal_cond_emb, data_dict["goal_cond"])
         if "pcd_embed" in data_dict:  # tokens computed by an earlier stage (BCTrainer mode="hybrid")
             pcd_tokens, pcd_pos = data_dict["pcd_embed"]
         else:
@@ -281,7 +290,7 @@ class ACTPCD(nn.Module):
         from . import staging
 
         pcd_tokens = staging.cut("tokens", pcd_tokens)  # the tokenizer's backward is the last stage
-        proprio_input = self.input_proj_robot_state(qpos).unsqueeze(0)
+        proprio_input = _lin(self.input_proj_robot_state, qpos).unsqueeze(0)
         if goal_cond is not None:
             proprio_input = torch.cat([proprio_input, goal_cond.unsqueeze(0)], dim=0)
         data_dict["src"] = pcd_tokens
@@ -296,8 +305,8 @@ class ACTPCD(nn.Module):
             data_dict["src"], None, self.query_embed.weight, data_dict["pos"], data_dict["latent_input"],
             data_dict["proprio_input"], self.additional_pos_embed.weight,
         )[0]  # only the FIRST decoder layer's (normed) output feeds the heads, act.py:270
-        data_dict["a_hat"] = self.action_head(hs)
-        data_dict["is_pad_hat"] = self.is_pad_head(hs)
+        data_dict["a_hat"] = _lin(self.action_head, hs)
+        data_dict["is_pad_hat"] = _lin(self.is_pad_head, hs)
         return data_dict
 
     def forward_loss(self, data_dict):
@@ -418,7 +427,7 @@ class ACTRLBenchPCD(ACTPCD):
             data_dict["src"], None, self.query_embed.weight, data_dict["pos"], data_dict["latent_input"],
             data_dict["proprio_input"], self.additional_pos_embed.weight,
         )[0]
-        a_hat = self.action_head(hs)  # (B, num_queries, action_dim)
+        a_hat = _lin(self.action_head, hs)  # (B, num_queries, action_dim)
         position = a_hat[..., :3]
         if self.collision:  # (..., gripper, collision) are the last two entries
             gripper = torch.sigmoid(a_hat[..., -2:])
@@ -431,7 +440,7 @@ class ACTRLBenchPCD(ACTPCD):
 
             rot = matrix_to_quaternion(rotation_6d_to_matrix(rot.float()))
         data_dict["a_hat"] = torch.cat([position, rot, gripper], dim=-1)
-        data_dict["is_pad_hat"] = self.is_pad_head(hs)
+        data_dict["is_pad_hat"] = _lin(self.is_pad_head, hs)
         return data_dict
 
     def forward_loss(self, data_dict):

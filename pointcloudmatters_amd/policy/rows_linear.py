@@ -168,7 +168,10 @@ def bias_grad(go, out_dtype, defer=False):
     rows, C = go.shape
     if not go.is_cuda or rows == 0 or C % 4 or go.dtype not in (torch.bfloat16, torch.float32) \
             or out_dtype not in (torch.bfloat16, torch.float32) or not go.is_contiguous():
-        return go.sum(dim=0).to(out_dtype)
+        # fp32 accumulation through the framework's fp32 reduction: its bf16 column-sum kernel is one of the kernels that return wrong
+        # values beside another stream's MFMA work on this stack (packed-fp32 hazard, DESIGN.md section 2: (816, 512).sum(0) in bf16
+        # wrong in 28 of 50 runs beside a GEMM graph, the fp32 reductions in 0)
+        return (go.float() if go.is_cuda and go.dtype == torch.bfloat16 else go).sum(dim=0).to(out_dtype)
     from .. import _lib
     from . import deferred
 
@@ -255,7 +258,15 @@ class _LinearRows(Function):
 def linear_rows(x, weight, bias=None):
     """Drop-in for F.linear(x, weight, bias) on activations with many rows (any leading shape)."""
     rows = x.numel() // max(1, x.shape[-1])
-    if not x.is_cuda or rows < MIN_ROWS or not torch.is_grad_enabled() or not (
+    if not x.is_cuda or not torch.is_grad_enabled() or not (
             weight.requires_grad or x.requires_grad or (bias is not None and bias.requires_grad)):
         return F.linear(x, weight, bias)
+    if rows < MIN_ROWS:
+        # short activations: the plain products are as fast, but under bf16 autocast the framework would reduce the bias gradient with
+        # its bf16 column-sum kernel (see bias_grad): keep the node, whose backward sums through csrc/tokens.hip, when there is a bias
+        # gradient to form
+        safe = bias is not None and bias.requires_grad and rows > 0 and torch.is_autocast_enabled("cuda") \
+            and torch.get_autocast_dtype("cuda") == torch.bfloat16
+        if not safe:
+            return F.linear(x, weight, bias)
     return _LinearRows.apply(x, weight, bias)

@@ -49,3 +49,46 @@ def _tier(item):
 def pytest_collection_modifyitems(config, items):
     order = {id(it): i for i, it in enumerate(items)}
     items.sort(key=lambda it: (_tier(it), order[id(it)]))
+
+
+# PCM_TEST_BUSY=1: run the (GPU) tests while a background thread keeps the matrix cores busy on another stream -- a replayed graph of
+# library GEMMs, the load under which round 4's packed-fp32 hazard showed (tests/test_concurrency_gpu.py).  Bit-exact comparisons with
+# the CPU oracle / fixtures then also hold "beside a busy device".  Off by default: the suite takes ~3x longer.
+@pytest.fixture(scope="session", autouse=True)
+def _busy_device():
+    if os.environ.get("PCM_TEST_BUSY") != "1":
+        yield
+        return
+    import threading
+
+    import torch
+
+    if not torch.cuda.is_available():
+        yield
+        return
+    dev = torch.device("cuda:0")
+    a = torch.randn(2048, 2048, device=dev, dtype=torch.bfloat16)
+    (a @ a)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            for _ in range(100):
+                a @ a
+    torch.cuda.synchronize()
+    stop = threading.Event()
+
+    def loop():
+        bg = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(bg):
+            while not stop.is_set():
+                g.replay()
+                bg.synchronize()  # one graph in flight at a time: the tests' own launches keep getting queue slots
+
+    t = threading.Thread(target=loop, daemon=True)
+    t.start()
+    yield
+    stop.set()
+    t.join(timeout=30)

@@ -162,3 +162,37 @@ def test_attention_and_sa_layer_beside_a_busy_device_equal_the_idle_result(hip_d
     torch.cuda.synchronize()
     bad = [sum(int(not torch.equal(r[i], ref[i])) for r in results) for i in range(len(ref))]
     assert not any(bad), "tensors that differ from the idle run, per output: %s of 25" % bad
+
+
+def test_bias_gradients_do_not_use_the_frameworks_bf16_column_sum(hip_device):
+    """The framework's OWN bf16 column-sum kernel is one of the kernels the hazard hits ((816, 512).sum(0) wrong in 28 of 50 runs beside a
+    GEMM graph; tools/dbg/busy_which_side.py), so no bias gradient of the training step may come from it: rows_linear.bias_grad sums
+    through csrc/tokens.hip (or, for widths it does not take, through the framework's fp32 reduction), and linear_rows keeps its own
+    autograd node for short activations under bf16 autocast.  Here: both routes beside the GEMM graph == the idle results, and the
+    autograd graph of a short bf16 linear is the library's node."""
+    from pointcloudmatters_amd.policy import rows_linear
+
+    torch.manual_seed(3)
+    go = torch.randn(816, 512, device=hip_device).to(torch.bfloat16)
+    go7 = torch.randn(800, 7, device=hip_device).to(torch.bfloat16)
+    ref = (rows_linear.bias_grad(go, torch.bfloat16), rows_linear.bias_grad(go7, torch.bfloat16))
+    assert torch.equal(ref[1], go7.float().sum(0).to(torch.bfloat16))
+    torch.cuda.synchronize()
+    g, _keep = _gemm_graph(hip_device)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    out = []
+    for _ in range(40):
+        g.replay()
+        with torch.cuda.stream(side):
+            out.append((rows_linear.bias_grad(go, torch.bfloat16), rows_linear.bias_grad(go7, torch.bfloat16)))
+    torch.cuda.synchronize()
+    assert [sum(int(not torch.equal(o[i], ref[i])) for o in out) for i in range(2)] == [0, 0]
+    lin = torch.nn.Linear(7, 512).to(hip_device)
+    x = torch.randn(8, 100, 7, device=hip_device)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = rows_linear.linear_rows(x, lin.weight, lin.bias)
+    assert type(y.grad_fn).__name__ == "_LinearRowsBackward"
+    y.float().square().sum().backward()
+    want = torch.autograd.grad((torch.nn.functional.linear(x, lin.weight.to(torch.bfloat16).float(), lin.bias).square().sum()), lin.bias)[0]
+    assert (lin.bias.grad - want).abs().max().item() <= 2e-2 * want.abs().max().item()
