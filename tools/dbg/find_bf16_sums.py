@@ -6,14 +6,21 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-from pointcloudmatters_amd.bc import WORKLOADS, BCTrainer, build_act_policy, clone_batch, make_act_batch  # noqa: E402
+from pointcloudmatters_amd.bc import (DP_OPTIM, WORKLOADS, BCTrainer, build_act_policy, build_dp_policy, clone_batch, make_act_batch,  # noqa: E402
+                                          make_dp_batch)
 
 dev = torch.device("cuda", 0)
-wl = WORKLOADS["C2"]
+WL = os.environ.get("WL", "C2")
+wl = WORKLOADS[WL]
 torch.manual_seed(1000)
-policy = build_act_policy(pcd_npoints=wl["pcd_npoints"], sa_impl="fused").to(dev)
-tr = BCTrainer(policy, total_steps=50, precision="bf16", device=dev, mode="flat", optim=dict(accumulate_grad_batches=1))
-batch = make_act_batch(wl["batch"], wl["n_points"], seed=1000, ragged=False, device=dev)
+if wl["policy"] == "dp":
+    policy = build_dp_policy(pcd_npoints=wl["pcd_npoints"], sa_impl="fused").to(dev)
+    tr = BCTrainer(policy, total_steps=50, precision="bf16", device=dev, mode="flat", optim=dict(DP_OPTIM))
+    batch = make_dp_batch(wl["batch"], wl["n_points"], seed=1000, ragged=False, device=dev)
+else:
+    policy = build_act_policy(pcd_npoints=wl["pcd_npoints"], sa_impl="fused").to(dev)
+    tr = BCTrainer(policy, total_steps=50, precision="bf16", device=dev, mode="flat", optim=dict(accumulate_grad_batches=1))
+    batch = make_act_batch(wl["batch"], wl["n_points"], seed=1000, ragged=False, device=dev)
 for _ in range(3):
     tr.training_step(clone_batch(batch))
 torch.cuda.synchronize()
