@@ -298,8 +298,10 @@ extern "C" int pcm_xfer_batch_hip(int n, void *const *dst, const void *const *sr
         if (numel[i] < 0 || numel[i] > 0x7FFFFFFFL || kind[i] < PCM_XFER_ZERO || kind[i] > PCM_XFER_COPY_2B) return PCM_ERR_BAD_ARG;
         if (numel[i] > 0 && (!dst[i] || (kind[i] != PCM_XFER_ZERO && !src[i]))) return PCM_ERR_BAD_ARG;
     }
+    if (n == 0) return PCM_OK;
     hipStream_t s = (hipStream_t)stream;
     int i = 0;
+    bool launched = false;
     while (i < n) {
         XferBatch b;
         b.n = 0;
@@ -312,7 +314,10 @@ extern "C" int pcm_xfer_batch_hip(int n, void *const *dst, const void *const *sr
         }
         if (chunks > 0x7FFFFFFF) return PCM_ERR_BAD_ARG;
         b.chunk0[b.n] = (int)chunks;
-        if (b.n) hipLaunchKernelGGL(pcm_xfer_batch_kernel, dim3((unsigned)chunks), dim3(256), 0, s, b);
+        if (b.n) {
+            hipLaunchKernelGGL(pcm_xfer_batch_kernel, dim3((unsigned)chunks), dim3(256), 0, s, b);
+            launched = true;
+        }
     }
-    return PCM_LAUNCH_STATUS();
+    return launched ? PCM_LAUNCH_STATUS() : PCM_OK;  // only empty jobs: nothing was launched, nothing to report
 }

@@ -64,3 +64,22 @@ def test_public_api_names_match_reference():
                  "farthest_point_sampling", "subtraction", "ball_query_and_group", "batch2offset",
                  "knn_query_and_group", "offset2batch", "query_and_group"):
         assert callable(getattr(po, name))
+
+
+def test_host_side_argument_checks_need_no_gpu():
+    """Entry points validate their arguments before any launch: the rejections (and the empty calls) are testable here."""
+    from pointcloudmatters_amd import _lib
+
+    L = _lib.load()
+    P, Lg, I = ctypes.c_void_p * 1, ctypes.c_long * 1, ctypes.c_int * 1
+    fake = 0x1000  # never dereferenced: the calls below are rejected first
+    assert L.pcm_xfer_batch_hip(0, None, None, None, None, None) == 0
+    assert L.pcm_xfer_batch_hip(-1, None, None, None, None, None) == 1
+    assert L.pcm_xfer_batch_hip(1, P(fake), P(fake), Lg(16), I(6), None) == 1      # unknown kind
+    assert L.pcm_xfer_batch_hip(1, P(fake), P(None), Lg(16), I(_lib.XFER_SET_BF16), None) == 1  # missing source
+    assert L.pcm_xfer_batch_hip(1, P(None), P(fake), Lg(16), I(_lib.XFER_ZERO), None) == 1      # missing destination
+    assert L.pcm_xfer_batch_hip(1, P(fake), P(fake), Lg(-4), I(_lib.XFER_ZERO), None) == 1
+    assert L.pcm_xfer_batch_hip(1, P(fake), P(fake), Lg(1 << 31), I(_lib.XFER_ZERO), None) == 1  # job too long for one table entry
+    assert L.pcm_ffn_ln_mfma_supported(512, 32) == 1 and L.pcm_ffn_ln_mfma_supported(384, 32) == 0
+    assert L.pcm_ffn_ln_mfma_blocks(4120) == 258 and L.pcm_ffn_ln_mfma_blocks(1) == 1  # one partial row per 16-row tile
+    assert L.pcm_ball_query_ws_bytes(512) == 0 and L.pcm_ball_query_ws_bytes(65536) > 0
