@@ -9,6 +9,9 @@
  *     0                success (kernel(s) enqueued on `stream`; asynchronous like the reference)
  *     PCM_ERR_*        argument rejected before any launch (cases that are UB in the reference)
  *     >= 1000          1000 + hipError_t from the launch
+ * Arguments are checked before the runtime is touched: negative sizes are rejected, and an empty call (no rows / no jobs)
+ * returns PCM_OK without a launch or a status query (tests/test_capi.py sweeps every entry point below for both, on a host
+ * without a device).
  * Plain pointers and sizes only: no torch types, no C++ types.  All pointers are DEVICE pointers
  * (HBM), row-major, fp32 data / int32 indices, packed "(n,3) + cumulative offset" layout
  * (cloud i = [offset[i-1], offset[i]), offset[-1] := 0).

@@ -58,7 +58,8 @@ extern "C" int pcm_ddpm_step_hip(long n, int eps_is_bf16, const void *eps, const
                                  float sqrt_one_minus_abar, float coef_x0, float coef_xt, float sigma, float clip,
                                  float *prev, void *stream)
 {
-    if (n <= 0) return 0;
+    if (n < 0) return PCM_ERR_BAD_ARG;
+    if (n == 0) return PCM_OK;
     if (cond_mask != nullptr && cond == nullptr) return PCM_ERR_BAD_ARG;
     long blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;

@@ -299,7 +299,8 @@ extern "C" int pcm_gn_mish_forward_hip(int B, int T, int C, int G, int x_is_bf16
                                        int res_is_bf16, const void *res, const float *conv_bias, float *y, float *mean, float *rstd,
                                        void *stream)
 {
-    if (B <= 0) return PCM_OK;
+    if (B < 0) return PCM_ERR_BAD_ARG;
+    if (B == 0) return PCM_OK;
     if (film_mode < 0 || film_mode > 2 || (film_mode && !film)) return PCM_ERR_BAD_ARG;
     if (!pcm_gn_mish_supported(T, C, G)) return PCM_ERR_UNSUPPORTED;
     const size_t lds = ((size_t)T * (C / G) + 4) * sizeof(float);
@@ -328,7 +329,8 @@ extern "C" int pcm_gn_mish_backward_hip(int B, int T, int C, int G, int x_is_bf1
                                         int film_is_bf16, const void *film, const float *conv_bias, const float *dy, void *dx,
                                         float *dgb_partial, float *dfilm, void *stream)
 {
-    if (B <= 0) return PCM_OK;
+    if (B < 0) return PCM_ERR_BAD_ARG;
+    if (B == 0) return PCM_OK;
     if (film_mode < 0 || film_mode > 2 || (film_mode && (!film || !dfilm))) return PCM_ERR_BAD_ARG;
     if (!pcm_gn_mish_supported(T, C, G)) return PCM_ERR_UNSUPPORTED;
     const size_t lds = ((size_t)2 * T * (C / G) + 5 * kBlock + 4 + 2 * (C / G)) * sizeof(float);

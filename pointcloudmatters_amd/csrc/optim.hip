@@ -170,6 +170,10 @@ extern "C" int pcm_optim_partials_capacity(void) { return kMaxPartials; }
 extern "C" int pcm_grad_sumsq_hip(long n, const float *g, float *partials, int *npartials_out, void *stream)
 {
     if (n < 0 || ((uintptr_t)g % 16) != 0) return PCM_ERR_BAD_ARG;
+    if (n == 0) {  // no elements: no partial sums (pcm_adamw_flat_hip accepts npartials = 0)
+        if (npartials_out) *npartials_out = 0;
+        return PCM_OK;
+    }
     const long n4 = n / 4;
     const int grid = stream_grid(n4);
     if (npartials_out) *npartials_out = grid;
@@ -182,6 +186,7 @@ extern "C" int pcm_adamw_flat_hip(long n, float *p, const float *g, float *m, fl
 {
     if (n < 0 || npartials < 0 || npartials > kMaxPartials) return PCM_ERR_BAD_ARG;
     if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16) != 0) return PCM_ERR_BAD_ARG;
+    if (n == 0) return PCM_OK;  // nothing to update (norm_out is left untouched)
     const long n4 = n / 4;
     static const int grid_env = getenv("PCM_ADAM_GRID") ? atoi(getenv("PCM_ADAM_GRID")) : 0;  // A/B switch for tools/mb
     // seven address streams (p, m, v, g in; p, m, v, bf16 mirror out): FEWER workgroups keep them more DRAM-page-friendly.

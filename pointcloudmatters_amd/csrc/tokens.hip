@@ -557,6 +557,7 @@ extern "C" int pcm_incr_i64_batch_hip(int n, void *const *counters, void *stream
     if (n < 0 || (n > 0 && !counters)) return PCM_ERR_BAD_ARG;
     for (int i = 0; i < n; ++i)
         if (!counters[i]) return PCM_ERR_BAD_ARG;
+    if (n == 0) return PCM_OK;
     hipStream_t s = (hipStream_t)stream;
     for (int base = 0; base < n; base += kIncrBatch) {
         IncrBatch b;
@@ -574,6 +575,7 @@ extern "C" int pcm_copy_batch_hip(int n, void *const *dst, const void *const *sr
     if (n < 0 || (n > 0 && (!dst || !src || !nbytes))) return PCM_ERR_BAD_ARG;
     for (int i = 0; i < n; ++i)
         if (nbytes[i] < 0 || (nbytes[i] > 0 && (!dst[i] || !src[i]))) return PCM_ERR_BAD_ARG;
+    if (n == 0) return PCM_OK;
     hipStream_t s = (hipStream_t)stream;
     for (int base = 0; base < n; base += kCopyBatch) {
         CopyBatch b;
@@ -603,6 +605,7 @@ extern "C" int pcm_colsum_batch_hip(int n, const long *rows, const int *C, const
         for (int t = 0; t < ntensors[i]; ++t)
             if (!g[3 * i + t]) return PCM_ERR_BAD_ARG;
     }
+    if (n == 0) return PCM_OK;
     hipStream_t s = (hipStream_t)stream;
     for (int base = 0; base < n; base += kColsumBatch) {
         ColsumBatch b;
@@ -630,12 +633,13 @@ extern "C" int pcm_reduce_batch_hip(int n, const void *const *partial, const int
     if (n < 0 || (n > 0 && (!partial || !nslots || !width || !out_f32 || !out_bf16 || !bf16_from))) return PCM_ERR_BAD_ARG;
     for (int i = 0; i < n; ++i)
         if (!partial[i] || nslots[i] <= 0 || width[i] < 0 || (!out_f32[i] && !out_bf16[i]) || bf16_from[i] < 0) return PCM_ERR_BAD_ARG;
+    if (n == 0) return PCM_OK;
     hipStream_t s = (hipStream_t)stream;
     for (int base = 0; base < n; base += kReduceBatch) {
         ReduceBatch b;
         b.n = 0;
         long blocks = 0;
-        for (int i = base; i < n && b.n < kReduceBatch; ++i) {
+        for (int i = base; i < n && i < base + kReduceBatch; ++i) {  // (a zero-width job is skipped, never visited twice)
             if (width[i] == 0) continue;
             ReduceDesc &d = b.d[b.n++];
             d.partial = (const float *)partial[i], d.out = (float *)out_f32[i], d.out16 = (__hip_bfloat16 *)out_bf16[i];

@@ -83,3 +83,48 @@ def test_host_side_argument_checks_need_no_gpu():
     assert L.pcm_ffn_ln_mfma_supported(512, 32) == 1 and L.pcm_ffn_ln_mfma_supported(384, 32) == 0
     assert L.pcm_ffn_ln_mfma_blocks(4120) == 258 and L.pcm_ffn_ln_mfma_blocks(1) == 1  # one partial row per 16-row tile
     assert L.pcm_ball_query_ws_bytes(512) == 0 and L.pcm_ball_query_ws_bytes(65536) > 0
+
+
+def _prototypes():
+    """(name, [argument declarations]) of every `int pcm_*_hip(...)` the header declares (comments stripped)."""
+    text = open(os.path.join(ROOT, "include", "pcm_pointops.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    out = []
+    for name, arglist in re.findall(r"^int (pcm_\w+_hip)\(([^;]*?)\);", text, flags=re.M | re.S):
+        out.append((name, [" ".join(a.split()) for a in arglist.split(",")]))
+    return out
+
+
+def _call_with_sizes(fn, decls, size):
+    """Every pointer NULL, every float 1.0, every integer argument = `size`."""
+    args = []
+    for d in decls:
+        if "*" in d:
+            args.append(None)
+        elif d.startswith("float"):
+            args.append(ctypes.c_float(1.0))
+        elif d.startswith("double"):
+            args.append(ctypes.c_double(1.0))
+        elif d.startswith("long") or d.startswith("unsigned long"):
+            args.append(ctypes.c_long(size))
+        else:
+            args.append(ctypes.c_int(size))
+    fn.restype, fn.argtypes = ctypes.c_int, None
+    return fn(*args)
+
+
+def test_every_entry_point_rejects_negative_sizes_and_takes_empty_calls_without_the_runtime():
+    """The status contract of include/pcm_pointops.h over EVERY launcher it declares (the reference's launchers return void and
+    run into undefined behaviour on such arguments): negative sizes are PCM_ERR_BAD_ARG / PCM_ERR_UNSUPPORTED, never PCM_OK; an
+    all-zero call is either empty (PCM_OK) or rejected (nsample = 0 ...), and neither asks the HIP runtime for anything -- there is
+    no device here, so a status >= PCM_ERR_HIP_BASE would show that it did.  No pointer is dereferenced on these paths."""
+    lib = ctypes.CDLL(os.path.join(ROOT, "pointcloudmatters_amd", "lib", "libpcm_pointops.so"))
+    protos = _prototypes()
+    assert len(protos) >= 70 and {"pcm_farthest_point_sampling_hip", "pcm_knn_query_hip", "pcm_xfer_batch_hip"} <= {n for n, _ in protos}
+    bad = []
+    for name, decls in protos:
+        neg = _call_with_sizes(getattr(lib, name), decls, -1)
+        zero = _call_with_sizes(getattr(lib, name), decls, 0)
+        if neg not in (1, 2) or zero not in (0, 1, 2):
+            bad.append((name, neg, zero))
+    assert not bad, bad
