@@ -128,3 +128,37 @@ def test_every_entry_point_rejects_negative_sizes_and_takes_empty_calls_without_
         if neg not in (1, 2) or zero not in (0, 1, 2):
             bad.append((name, neg, zero))
     assert not bad, bad
+
+
+def test_header_is_plain_c_and_a_c_program_links_against_the_library(tmp_path):
+    """The boundary is a C ABI, not a C++ one: include/pcm_pointops.h compiles as strict C99 (and as C++17), and a C program that
+    takes the address of EVERY declared function links against libpcm_pointops.so with gcc alone and runs the host-only entry points
+    (no torch, no hipcc, no device): what a cgo / JNI / ctypes binding on the reference's side relies on."""
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not found")
+    inc, libdir = os.path.join(ROOT, "include"), os.path.join(ROOT, "pointcloudmatters_amd", "lib")
+    names = declared_symbols()
+    src = tmp_path / "abi.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <string.h>\n#include "pcm_pointops.h"\n'
+        "typedef void (*fn_t)(void);\n"
+        "static const fn_t table[] = {\n" + "".join(f"    (fn_t){n},\n" for n in names) + "};\n"
+        "int main(void) {\n"
+        "    size_t i, n = sizeof table / sizeof table[0];\n"
+        "    for (i = 0; i < n; ++i) if (!table[i]) return 2;\n"
+        '    if (!strstr(pcm_version(), "gfx950")) return 3;\n'
+        "    if (pcm_opt_n_threads(1000) != 512 || pcm_opt_n_threads(4096) != 1024) return 4;\n"
+        "    if (pcm_knn_query_hip(-1, 16, 0, 0, 0, 0, 0, 0, 0) != PCM_ERR_BAD_ARG) return 5;\n"
+        "    if (pcm_farthest_point_sampling_hip(0, 0, 0, 0, 0, 0, 0, 0) != PCM_OK) return 6;\n"
+        '    printf("%u symbols\\n", (unsigned)n);\n    return 0;\n}\n')
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", inc, str(src), "-o", str(exe),
+                           "-L", libdir, "-lpcm_pointops", "-Wl,-rpath," + libdir])
+    out = subprocess.check_output([str(exe)], text=True)
+    assert out.strip() == f"{len(names)} symbols"
+    cxx = tmp_path / "abi.cpp"
+    cxx.write_text('#include "pcm_pointops.h"\nint main() { return pcm_opt_n_threads(64) == 64 ? 0 : 1; }\n')
+    subprocess.check_call(["g++", "-std=c++17", "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", inc, str(cxx)])
