@@ -118,7 +118,10 @@ def test_every_entry_point_rejects_negative_sizes_and_takes_empty_calls_without_
     run into undefined behaviour on such arguments): negative sizes are PCM_ERR_BAD_ARG / PCM_ERR_UNSUPPORTED, never PCM_OK; an
     all-zero call is either empty (PCM_OK) or rejected (nsample = 0 ...), and neither asks the HIP runtime for anything -- there is
     no device here, so a status >= PCM_ERR_HIP_BASE would show that it did.  No pointer is dereferenced on these paths."""
-    lib = ctypes.CDLL(os.path.join(ROOT, "pointcloudmatters_amd", "lib", "libpcm_pointops.so"))
+    from pointcloudmatters_amd import _lib
+
+    _lib.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
     protos = _prototypes()
     assert len(protos) >= 70 and {"pcm_farthest_point_sampling_hip", "pcm_knn_query_hip", "pcm_xfer_batch_hip"} <= {n for n, _ in protos}
     bad = []
@@ -139,7 +142,10 @@ def test_header_is_plain_c_and_a_c_program_links_against_the_library(tmp_path):
 
     if shutil.which("gcc") is None:
         pytest.skip("gcc not found")
-    inc, libdir = os.path.join(ROOT, "include"), os.path.join(ROOT, "pointcloudmatters_amd", "lib")
+    from pointcloudmatters_amd import _lib
+
+    _lib.build()
+    inc, libdir = os.path.join(ROOT, "include"), os.path.dirname(_lib.LIB_PATH)
     names = declared_symbols()
     src = tmp_path / "abi.c"
     src.write_text(
