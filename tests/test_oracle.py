@@ -191,3 +191,29 @@ def test_attention_steps_against_torch():
     gout = torch.randn(n, gg, c, generator=g)
     for x, y in zip(torch.autograd.grad(out, (aw, v), gout), torch.autograd.grad(want, (aw, v), gout)):
         torch.testing.assert_close(x, y, rtol=1e-4, atol=1e-5)
+
+
+def test_oracle_equals_twin_on_a_random_sweep():
+    """A seeded slice of tools/fuzz_oracle_twin.py (1007 cases without a mismatch in round 4): ragged clouds, M > N, exact ties (lattice,
+    duplicates), k in 1..32, inner radii, random-order ball query -- C oracle == Python twin, indices AND distances, bit for bit."""
+    rng = np.random.default_rng(11)
+    for _ in range(24):
+        b = int(rng.integers(1, 4))
+        sizes = [int(rng.choice([1, 2, 3, 7, 31, 33, 64, 65, 100, 129, 200])) for _ in range(b)]
+        ms = [int(rng.integers(1, max(2, s + 3))) for s in sizes]
+        mode = str(rng.choice(["uniform", "lattice", "dup"]))
+        seed = int(rng.integers(0, 1 << 30))
+        xyz, off = make_clouds(sizes, seed=seed, mode=mode, lattice=float(rng.choice([0.05, 0.1, 0.2])))
+        noff = new_offsets(ms)
+        sel = po.farthest_point_sampling(xyz, off, noff)
+        assert np.array_equal(sel.numpy(), tw.fps(xyz.numpy(), off.numpy(), noff.numpy())), (sizes, ms, mode, seed)
+        q = xyz[sel.long()].contiguous()
+        k = int(rng.choice([1, 3, 8, 16, 32]))
+        r, rmin = float(rng.choice([0.05, 0.1, 0.2, 0.5])), float(rng.choice([0.0, 0.01, 0.03]))
+        order = po.make_random_order(off, generator=torch.Generator().manual_seed(seed & 0xFFFF))
+        for got, want in (
+                (po.knn_query_raw(k, xyz, off, q, noff), tw.knn(k, xyz.numpy(), q.numpy(), off.numpy(), noff.numpy())),
+                (po.ball_query_raw(k, r, rmin, xyz, off, q, noff), tw.ball(k, rmin, r, xyz.numpy(), q.numpy(), off.numpy(), noff.numpy())),
+                (po.random_ball_query_raw(k, r, rmin, xyz, off, q, noff, order),
+                 tw.random_ball(k, rmin, r, order.numpy(), xyz.numpy(), q.numpy(), off.numpy(), noff.numpy()))):
+            assert np.array_equal(got[0].numpy(), want[0]) and np.array_equal(got[1].numpy(), want[1]), (sizes, ms, mode, seed, k, r, rmin)
