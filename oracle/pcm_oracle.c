@@ -19,6 +19,15 @@
 #include <omp.h>
 #endif
 
+/* One accumulation step of the squared distance.  Default (the arithmetic contract of SURVEY F9, and what every parity test uses):
+ * the product and the sum rounded separately.  -DPCM_ORACLE_FMAD builds the SENSITIVITY variant only (libpcm_oracle_fmad.so,
+ * tools/fmad_sensitivity.py): the fused form a CUDA compiler's default -fmad=true makes of the same source expression. */
+#ifdef PCM_ORACLE_FMAD
+#define PCM_ACC(d, a) fmaf((a), (a), (d))
+#else
+#define PCM_ACC(d, a) ((d) + (a) * (a))
+#endif
+
 #define PCM_TPB_MAX 1024
 #define PCM_KNN_MAX 128        /* knn_query_cuda_kernel.cu:82-83: float best_dist[128]          */
 #define PCM_BALL_CAND_MAX 2048 /* ball_query_cuda_kernel.cu:86-87: float candi_dist[2048]      */
@@ -80,8 +89,8 @@ int pcm_farthest_point_sampling_cpu(int b, int n_max, const float *xyz, const in
                 const float z2 = xyz[k * 3 + 2];
                 const float dx = x2 - x1, dy = y2 - y1, dz = z2 - z1;
                 float d = dx * dx;
-                d = d + dy * dy;
-                d = d + dz * dz; /* :54, left-to-right, no FMA */
+                d = PCM_ACC(d, dy);
+                d = PCM_ACC(d, dz); /* :54, left-to-right, no FMA */
                 const float tk = tmp[k];
                 const float d2 = d < tk ? d : tk; /* min(d, tmp[k]) :55 */
                 tmp[k] = d2;
@@ -179,8 +188,8 @@ int pcm_knn_query_cpu(int m, int nsample, const float *xyz, const float *new_xyz
             const float dy = new_y - xyz[i * 3 + 1];
             const float dz = new_z - xyz[i * 3 + 2];
             float d2 = dx * dx;
-            d2 = d2 + dy * dy;
-            d2 = d2 + dz * dz; /* :91 */
+            d2 = PCM_ACC(d2, dy);
+            d2 = PCM_ACC(d2, dz); /* :91 */
             if (d2 < best_dist[0]) { /* :92 strict < */
                 best_dist[0] = d2;
                 best_idx[0] = i;
@@ -232,8 +241,8 @@ int pcm_ball_query_cpu(int m, int nsample, float min_radius, float max_radius,
             const float dy = new_y - xyz[i * 3 + 1];
             const float dz = new_z - xyz[i * 3 + 2];
             float d2 = dx * dx;
-            d2 = d2 + dy * dy;
-            d2 = d2 + dz * dz;
+            d2 = PCM_ACC(d2, dy);
+            d2 = PCM_ACC(d2, dz);
             if ((double)d2 <= 1e-5 || (d2 >= min_radius2 && d2 < max_radius2)) {
                 if (candi_num >= PCM_BALL_CAND_MAX) {
                     bad = 1;
@@ -301,8 +310,8 @@ int pcm_random_ball_query_cpu(int m, int nsample, float min_radius, float max_ra
             const float dy = new_y - xyz[o * 3 + 1];
             const float dz = new_z - xyz[o * 3 + 2];
             float d2 = dx * dx;
-            d2 = d2 + dy * dy;
-            d2 = d2 + dz * dz;
+            d2 = PCM_ACC(d2, dy);
+            d2 = PCM_ACC(d2, dz);
             if ((double)d2 <= 1e-5 || (d2 >= min_radius2 && d2 < max_radius2)) {
                 dist2[q * nsample + cnt] = d2;
                 idx[q * nsample + cnt] = o;
