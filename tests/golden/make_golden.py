@@ -31,7 +31,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 REF = "/root/reference"
-OUT = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get("PCM_GOLDEN_OUT") or os.path.dirname(os.path.abspath(__file__))  # PCM_GOLDEN_OUT: regenerate elsewhere (tools/check_golden_regen.py)
 sys.path.insert(0, ROOT)
 
 
