@@ -120,6 +120,13 @@ def plan_slabs(stage_params, lead_end, numel):
     return slabs
 
 
+def undecayed_parameters(module):
+    """The trainable parameters the reference's `build_optimizer_v2` leaves WITHOUT weight decay (`param_groups_weight_decay`,
+    src/utils/optimizer.py:152-170, reached by the Diffusion-Policy modules, maniskill2_dp_bc_module.py:326-327): at most one dimension, or
+    a name that ends in `.bias`.  Pinned by tests/golden/optim_ref.npz, which the reference's own function produced."""
+    return [p for n, p in module.named_parameters() if p.requires_grad and (p.ndim <= 1 or n.endswith(".bias"))]
+
+
 class BCTrainer:
     """mode:
       "eager"  torch.optim.AdamW + OneCycleLR, DistributedDataParallel (+ SyncBatchNorm) when
@@ -212,7 +219,7 @@ class BCTrainer:
         params = ordered
         if o.get("filter_bias_and_bn", False) and o["weight_decay"]:
             # build_optimizer_v2 -> param_groups_weight_decay (src/utils/optimizer.py:152-170, 296-300)
-            nd_ids = {id(p) for n, p in self.policy.named_parameters() if p.requires_grad and (p.ndim <= 1 or n.endswith(".bias"))}
+            nd_ids = {id(p) for p in undecayed_parameters(self.policy)}
             decay = [p for p in ordered if id(p) not in nd_ids]
             no_decay = [p for p in ordered if id(p) in nd_ids]
             # decayed group first and in backward order: its stage slabs are what the exchange overlaps; the small

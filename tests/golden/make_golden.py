@@ -945,6 +945,76 @@ def golden_rollout(ref):
     print("rollout_ref.npz ok; |action_pred| max", float(np.abs(traj).max()))
 
 
+def golden_optim(ref):
+    """configure_optimizers through the REFERENCE's own builders (maniskill2_act_bc_module.py:347-367 -> build_optimizer + build_scheduler;
+    maniskill2_dp_bc_module.py:326-344 -> build_optimizer_v2 + build_scheduler), with the YAML values of
+    configs/model/maniskill2_{act_pcd,diffusion_policy}_model.yaml:10-24.  omegaconf is absent: a dict with attribute access stands in for
+    the DictConfig (import-time names + `to_container`); the registry, the scheduler subclass and the grouping functions are the
+    reference's files, loaded by path.  Stored: the parameter NAMES of every group with its hyper-parameters, and the learning rate /
+    beta1 in effect at every optimizer step of a 200-step cycle."""
+    import copy
+
+    from tests.util import optimizer_zoo
+
+    class Cfg(dict):  # DictConfig stand-in: attribute access over a dict (deepcopy-able, `in`, .get, .copy, .keys)
+        __getattr__ = dict.__getitem__
+        __setattr__ = dict.__setitem__
+
+        def __deepcopy__(self, memo):
+            return Cfg({k: copy.deepcopy(v, memo) for k, v in self.items()})
+
+    om = types.ModuleType("omegaconf")
+    om.DictConfig = Cfg
+    om.OmegaConf = types.SimpleNamespace(to_container=lambda cfg, resolve=False: dict(cfg))
+    sys.modules["omegaconf"] = om
+    _load("src.utils.misc", f"{REF}/src/utils/misc.py")
+    _load("src.utils.registry", f"{REF}/src/utils/registry.py")
+    sched = _load("src.utils.scheduler", f"{REF}/src/utils/scheduler.py")
+    optim = _load("src.utils.optimizer", f"{REF}/src/utils/optimizer.py")
+
+    # the reference's scheduler subclasses still pass `verbose=` (scheduler.py:118-139), which torch 2.10 removed from the base class: the
+    # BASE initialiser is wrapped to drop it (torch side, like the torchvision stub); the reference subclass itself runs unmodified
+    base_init = torch.optim.lr_scheduler.OneCycleLR.__init__
+
+    def tolerant_init(self, *a, verbose=False, **kw):
+        return base_init(self, *a, **kw)
+
+    torch.optim.lr_scheduler.OneCycleLR.__init__ = tolerant_init
+
+    fx, T = {}, 200
+    for tag, builder, ocfg, scfg in (
+            ("act", lambda c, m: optim.build_optimizer(c, m, None), Cfg(type="AdamW", lr=0.00005, weight_decay=0.05),
+             Cfg(type="OneCycleLR", max_lr=0.00005, pct_start=0.1, anneal_strategy="cos", div_factor=100.0, final_div_factor=1000.0)),
+            ("dp", lambda c, m: optim.build_optimizer_v2(c, m), Cfg(type="AdamW", betas=[0.9, 0.95], lr=0.0001, weight_decay=0.0001),
+             Cfg(type="OneCycleLR", max_lr=0.0001, pct_start=0.15, anneal_strategy="cos", div_factor=100.0, final_div_factor=1000.0))):
+        zoo = optimizer_zoo()
+        names = {id(p): n for n, p in zoo.named_parameters()}
+        opt = builder(ocfg, zoo)
+        assert type(opt) is torch.optim.AdamW
+        fx[f"{tag}.n_groups"] = np.array(len(opt.param_groups))
+        for gi, g in enumerate(opt.param_groups):
+            fx[f"{tag}.group{gi}.names"] = np.array([names[id(p)] for p in g["params"]])
+            fx[f"{tag}.group{gi}.weight_decay"] = np.array(g["weight_decay"], np.float64)
+            fx[f"{tag}.group{gi}.eps"] = np.array(g["eps"], np.float64)
+            fx[f"{tag}.group{gi}.beta2"] = np.array(g["betas"][1], np.float64)
+        scfg.total_steps = T  # the module sets trainer.estimated_stepping_batches here
+        sch = optim.build_scheduler if hasattr(optim, "build_scheduler") else sched.build_scheduler
+        sch = sch(scfg, optimizer=opt)
+        assert isinstance(sch, torch.optim.lr_scheduler.OneCycleLR)
+        lr, b1 = np.zeros((T, len(opt.param_groups))), np.zeros((T, len(opt.param_groups)))
+        for k in range(T):
+            for gi, g in enumerate(opt.param_groups):
+                lr[k, gi], b1[k, gi] = g["lr"], g["betas"][0]
+            opt.step()
+            if k + 1 < T:
+                sch.step()
+        fx[f"{tag}.lr"], fx[f"{tag}.beta1"] = lr, b1
+    torch.optim.lr_scheduler.OneCycleLR.__init__ = base_init
+    np.savez_compressed(os.path.join(OUT, "optim_ref.npz"), **fx)
+    print("optim_ref.npz: act groups", int(fx["act.n_groups"]), "dp groups", int(fx["dp.n_groups"]), "lr[0], lr[peak], lr[-1] =",
+          fx["act.lr"][0, 0], fx["act.lr"].max(), fx["act.lr"][-1, 0])
+
+
 def golden_gridsample(ref):
     """GridSamplePCD (fnv, train, return_grid_coord) + NormalizeColorPCD from transformpcd.py, run as shipped on three
     seeded clouds (NumPy 2.2.6 here: coord / np.array(grid_size) promotes to float64)."""
@@ -980,6 +1050,7 @@ if __name__ == "__main__":
     only = set(sys.argv[1:])  # e.g. `make_golden.py rollout` regenerates one fixture
     for name, fn in (("act", golden_act), ("grouping", golden_grouping), ("misc", golden_misc), ("dp", golden_dp),
                      ("rollout", golden_rollout), ("gridsample", golden_gridsample), ("rlbench", golden_rlbench),
-                     ("dp_rlbench", golden_dp_rlbench), ("mask", golden_mask), ("presample", golden_presample), ("wide", golden_wide)):
+                     ("dp_rlbench", golden_dp_rlbench), ("mask", golden_mask), ("presample", golden_presample), ("wide", golden_wide),
+                     ("optim", golden_optim)):
         if not only or name in only:
             fn(ref)

@@ -120,3 +120,37 @@ def digest_rel_error(name, got, ref):
     e = max(float(np.abs(dig["rows"] - ref["rows"]).max()), float(np.abs(dig["cols"] - ref["cols"]).max()),
             float(np.abs(dig["right"] - ref["right"]).max()) / np.sqrt(cols), float(np.abs(dig["left"] - ref["left"]).max()) / np.sqrt(rows))
     return e / (s + 1e-30), s
+
+
+def optimizer_zoo():
+    """A module whose parameter NAMES and shapes cover every case of the reference's weight-decay grouping rule
+    (src/utils/optimizer.py:152-170): matrices, biases, 1-d norm weights, convolution kernels, an embedding table, bare
+    parameters of 1 and 3 dimensions, a parameter whose name merely ENDS in '.bias' but is a matrix, and a frozen one.
+    Used by tests/golden/make_golden.py::golden_optim (through the reference's build_optimizer / build_optimizer_v2) and by
+    tests/test_optim_ref.py (through the trainer's grouping)."""
+    import torch.nn as nn
+
+    class Odd(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.bias = nn.Parameter(torch.zeros(4, 4))  # name 'odd.bias', 2-d: the name rule wins
+
+    class Zoo(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = nn.Linear(6, 8)
+            self.lin_nobias = nn.Linear(8, 8, bias=False)
+            self.ln = nn.LayerNorm(8)
+            self.bn = nn.BatchNorm1d(8)
+            self.gn = nn.GroupNorm(2, 8)
+            self.conv = nn.Conv1d(8, 8, 3)
+            self.emb = nn.Embedding(5, 8)
+            self.pos_table = nn.Parameter(torch.zeros(1, 3, 8))
+            self.scale = nn.Parameter(torch.ones(8))
+            self.odd = Odd()
+            self.frozen = nn.Linear(8, 2)
+            for p in self.frozen.parameters():
+                p.requires_grad_(False)
+
+    torch.manual_seed(0)
+    return Zoo()
