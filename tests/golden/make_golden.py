@@ -1015,6 +1015,49 @@ def golden_optim(ref):
           fx["act.lr"][0, 0], fx["act.lr"].max(), fx["act.lr"][-1, 0])
 
 
+def golden_normalizer(ref):
+    """LinearNormalizer (src/utils/diffusion_policy/normalizer.py:14-300) as the Diffusion-Policy datasets build it: per key through
+    `get_range_normalizer_from_stat` (src/utils/normalize_utils.py:7-21; maniskill2_single_task_pcd_dp.py:96-111), and through `fit`.
+    One action dimension is constant (the `ignore_dim` branch).  zarr is absent: an empty `zarr.Array` class satisfies the isinstance checks."""
+    z = types.ModuleType("zarr")
+    z.Array = type("Array", (), {})
+    sys.modules["zarr"] = z
+    dpu = sys.modules["src.utils.diffusion_policy"]
+    mix = _load("src.utils.diffusion_policy.dict_of_tensor_mixin", f"{REF}/src/utils/diffusion_policy/dict_of_tensor_mixin.py")
+    dpu.DictOfTensorMixin = mix.DictOfTensorMixin
+    nz = _load("src.utils.diffusion_policy.normalizer", f"{REF}/src/utils/diffusion_policy/normalizer.py")
+    dpu.LinearNormalizer, dpu.SingleFieldLinearNormalizer = nz.LinearNormalizer, nz.SingleFieldLinearNormalizer
+    nu = _load("src.utils.normalize_utils", f"{REF}/src/utils/normalize_utils.py")
+
+    rng = np.random.default_rng(21)
+    action = (rng.normal(size=(64, 16, 7)) * np.array([0.05, 0.05, 0.05, 0.3, 0.3, 0.3, 1.0])).astype(np.float32)
+    action[..., 6] = 1.0  # a gripper that never moves: range < range_eps
+    qpos = (rng.normal(size=(64, 2, 9)) * 1.5 + 0.3).astype(np.float32)
+    fx = {"action": action, "qpos": qpos}
+
+    def stat(a):
+        f = torch.from_numpy(a).reshape(-1, a.shape[-1])
+        return {"min": f.min(0).values.numpy(), "max": f.max(0).values.numpy(), "mean": f.mean(0).numpy(), "std": f.std(0).numpy()}
+
+    a = nz.LinearNormalizer()
+    a["action"] = nu.get_range_normalizer_from_stat(stat(action))
+    a["qpos"] = nu.get_range_normalizer_from_stat(stat(qpos))
+    b = nz.LinearNormalizer()
+    b.fit({"action": action, "qpos": qpos})
+    for tag, n in (("stat", a), ("fit", b)):
+        sd = n.state_dict()
+        fx[f"{tag}.keys"] = np.array(sorted(sd))
+        for k, v in sd.items():
+            fx[f"{tag}.sd.{k}"] = v.detach().numpy()
+        out = n.normalize({"action": torch.from_numpy(action[:5]), "qpos": torch.from_numpy(qpos[:5])})
+        fx[f"{tag}.norm.action"], fx[f"{tag}.norm.qpos"] = out["action"].detach().numpy(), out["qpos"].detach().numpy()
+        y = torch.from_numpy(rng.uniform(-1, 1, size=(4, 16, 7)).astype(np.float32)) if tag == "stat" else torch.from_numpy(fx["y"])
+        fx["y"] = y.numpy()
+        fx[f"{tag}.unnorm.action"] = n["action"].unnormalize(y).detach().numpy()
+    np.savez_compressed(os.path.join(OUT, "normalizer_ref.npz"), **fx)
+    print("normalizer_ref.npz:", len(fx), "arrays; action scale", fx["stat.sd.params_dict.action.scale"])
+
+
 def golden_gridsample(ref):
     """GridSamplePCD (fnv, train, return_grid_coord) + NormalizeColorPCD from transformpcd.py, run as shipped on three
     seeded clouds (NumPy 2.2.6 here: coord / np.array(grid_size) promotes to float64)."""
@@ -1051,6 +1094,6 @@ if __name__ == "__main__":
     for name, fn in (("act", golden_act), ("grouping", golden_grouping), ("misc", golden_misc), ("dp", golden_dp),
                      ("rollout", golden_rollout), ("gridsample", golden_gridsample), ("rlbench", golden_rlbench),
                      ("dp_rlbench", golden_dp_rlbench), ("mask", golden_mask), ("presample", golden_presample), ("wide", golden_wide),
-                     ("optim", golden_optim)):
+                     ("optim", golden_optim), ("normalizer", golden_normalizer)):
         if not only or name in only:
             fn(ref)
