@@ -1058,6 +1058,125 @@ def golden_normalizer(ref):
     print("normalizer_ref.npz:", len(fx), "arrays; action scale", fx["stat.sd.params_dict.action.scale"])
 
 
+def golden_wrappers(ref):
+    """The reference's pointops PYTHON layer (libs/pointops/functions/*.py: autograd Functions, the interpolation weights, sqrt of
+    dist2, the -1 masks of grouping, the *_and_group helpers), executed UNMODIFIED as the package `pointops`, over the C oracle's kernels:
+    `pointops._C` is a 16-function stub that forwards the pybind argument lists (pointops_api.cpp:15-32) to oracle/pcm_oracle.c, and
+    `torch.cuda.{Int,Float}Tensor` -- the wrappers' only CUDA dependence -- are pointed at the CPU tensor types while this runs.
+    Pins the WRAPPER level of oracle/pointops_cpu.py (and through it of the product's pointops/*.py) to the reference's own code; the
+    kernels under it stay pinned by restatement only."""
+    from oracle import lib as olib
+
+    L = olib.load()
+    stub = types.ModuleType("pointops._C")
+
+    def forward_to(cname):
+        fn = getattr(L, cname)
+
+        scalar = [t is not olib._F for t in olib._SIGS[cname]]  # int / float parameters (pointer parameters are void*)
+
+        def call(*args):
+            conv = []
+            for a, is_scalar in zip(args, scalar):
+                if torch.is_tensor(a) and is_scalar:
+                    conv.append(a.item())  # pybind's int caster takes a 0-dim integer tensor (sampling.py:15-20 passes n_max as one)
+                elif torch.is_tensor(a):
+                    assert a.is_contiguous() and not a.is_cuda
+                    conv.append(a.data_ptr())
+                else:
+                    conv.append(a)
+            assert len(conv) == len(scalar), (cname, len(conv), len(scalar))
+            rc = fn(*conv)
+            if rc != 0:
+                raise RuntimeError(f"{cname} returned {rc}")
+
+        return call
+
+    for name in olib._SIGS:
+        if name.endswith("_cpu") and name not in ("pcm_opt_n_threads_cpu",):
+            op = name[len("pcm_"):-len("_cpu")]
+            setattr(stub, op + "_cuda", forward_to(name))
+    saved = {k: sys.modules.get(k) for k in ("pointops", "pointops._C")}
+    saved_types = (torch.cuda.IntTensor, torch.cuda.FloatTensor)
+    torch.cuda.IntTensor, torch.cuda.FloatTensor = torch.IntTensor, torch.FloatTensor
+    sys.modules["pointops._C"] = stub
+    fdir = f"{REF}/libs/pointops/functions"
+    spec = importlib.util.spec_from_file_location("pointops", f"{fdir}/__init__.py", submodule_search_locations=[fdir])
+    po = importlib.util.module_from_spec(spec)
+    sys.modules["pointops"] = po
+    try:
+        spec.loader.exec_module(po)
+        sys.path.insert(0, ROOT)
+        from tests.util import make_clouds, new_offsets
+
+        fx = {}
+        g = torch.Generator().manual_seed(17)
+        xyz, off = make_clouds([120, 75, 200], seed=17)
+        noff = new_offsets([40, 30, 64])
+        n, c = xyz.shape[0], 5
+        feat = torch.randn(n, c, generator=g)
+        fx["xyz"], fx["offset"], fx["new_offset"], fx["feat"] = xyz.numpy(), off.numpy(), noff.numpy(), feat.numpy()
+        sel = po.farthest_point_sampling(xyz, off, noff)
+        fx["fps.idx"] = sel.numpy()
+        q = xyz[sel.long()].contiguous()
+        for tag, out in (("knn", po.knn_query(8, xyz, off, q, noff)), ("knn_self", po.knn_query(4, xyz, off)),
+                         ("ball", po.ball_query(8, 0.15, 0.02, xyz, off, q, noff))):
+            fx[f"{tag}.idx"], fx[f"{tag}.dist"] = out[0].numpy(), out[1].numpy()
+        torch.manual_seed(5)
+        ridx, rdist = po.random_ball_query(8, 0.15, 0.02, xyz, off, q, noff)
+        torch.manual_seed(5)  # the order the wrapper drew (query.py:46-52), for callers that take it as an argument
+        order, prev = [], 0
+        for e in off.tolist():
+            order.append(torch.randperm(e - prev, dtype=torch.int32) + prev)
+            prev = e
+        fx["rball.order"], fx["rball.idx"], fx["rball.dist"] = torch.cat(order).numpy(), ridx.numpy(), rdist.numpy()
+        kidx = torch.from_numpy(fx["knn.idx"])
+
+        def with_grads(tag, fn, inputs):
+            leaves = [t.clone().requires_grad_(True) for t in inputs]
+            out = fn(*leaves)
+            w = torch.randn(out.shape, generator=g)
+            grads = torch.autograd.grad((out * w).sum(), leaves, allow_unused=True)
+            fx[f"{tag}.out"], fx[f"{tag}.w"] = out.detach().numpy(), w.numpy()
+            for i, (t, gr) in enumerate(zip(inputs, grads)):
+                fx[f"{tag}.in{i}"] = t.numpy()
+                if gr is not None:  # (the relation step returns no gradient for its weight vector, attention.py:62)
+                    fx[f"{tag}.grad{i}"] = gr.numpy()
+
+        with_grads("grouping2", lambda f: po.grouping2(f, kidx), [feat])  # grouping.py:62: grouping2 = Grouping.apply (input, idx)
+        with_grads("grouping_xyz", lambda f: po.grouping(kidx, f, xyz, q, with_xyz=True), [feat])
+        with_grads("interp", lambda f: po.interpolation(q, xyz, f, noff, off, k=3), [feat[: q.shape[0]].contiguous()])
+        with_grads("interp2", lambda f: po.interpolation2(q, xyz, f, noff, off, 3), [feat[: q.shape[0]].contiguous()])
+        m = q.shape[0]
+        sidx = po.knn_query(6, xyz, off)[0]
+        with_grads("subtraction", lambda a, b: po.subtraction(a, b, sidx), [feat, torch.randn(n, c, generator=g)])
+        with_grads("aggregation", lambda a, pz, wt: po.aggregation(a, pz, wt, sidx),
+                   [torch.randn(n, 8, generator=g), torch.randn(n, 6, 8, generator=g), torch.randn(n, 6, 4, generator=g)])
+        fx["sidx"] = sidx.numpy()
+        it = torch.randint(0, n, (300,), generator=g).int()
+        ir = torch.randint(0, n, (300,), generator=g).int()
+        fx["attn.index_target"], fx["attn.index_refer"] = it.numpy(), ir.numpy()
+        with_grads("attn_relation", lambda a, b, wt: po.attention_relation_step(a, b, wt, it, ir),
+                   [torch.randn(n, 2, 4, generator=g), torch.randn(n, 2, 4, generator=g), torch.randn(4, generator=g)])
+        with_grads("attn_fusion", lambda wt, v: po.attention_fusion_step(wt, v, it, ir),
+                   [torch.randn(300, 2, generator=g), torch.randn(n, 2, 4, generator=g)])
+        for tag, fn in (("knn_group", lambda f: po.knn_query_and_group(f, xyz, off, q, noff, nsample=8, with_xyz=True)),
+                        ("ball_group", lambda f: po.ball_query_and_group(f, xyz, off, q, noff, max_radio=0.15, min_radio=0.02,
+                                                                         nsample=8, with_xyz=True))):
+            out = fn(feat)
+            out = out[0] if isinstance(out, tuple) else out
+            fx[f"{tag}.out"] = out.numpy()
+        np.savez_compressed(os.path.join(OUT, "wrappers_ref.npz"), **fx)
+        print("wrappers_ref.npz:", len(fx), "arrays; m =", m, "; ball rows with -1:", int((fx["ball.idx"] < 0).any(1).sum()))
+    finally:
+        torch.cuda.IntTensor, torch.cuda.FloatTensor = saved_types
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
 def golden_gridsample(ref):
     """GridSamplePCD (fnv, train, return_grid_coord) + NormalizeColorPCD from transformpcd.py, run as shipped on three
     seeded clouds (NumPy 2.2.6 here: coord / np.array(grid_size) promotes to float64)."""
@@ -1094,6 +1213,6 @@ if __name__ == "__main__":
     for name, fn in (("act", golden_act), ("grouping", golden_grouping), ("misc", golden_misc), ("dp", golden_dp),
                      ("rollout", golden_rollout), ("gridsample", golden_gridsample), ("rlbench", golden_rlbench),
                      ("dp_rlbench", golden_dp_rlbench), ("mask", golden_mask), ("presample", golden_presample), ("wide", golden_wide),
-                     ("optim", golden_optim), ("normalizer", golden_normalizer)):
+                     ("optim", golden_optim), ("normalizer", golden_normalizer), ("wrappers", golden_wrappers)):
         if not only or name in only:
             fn(ref)

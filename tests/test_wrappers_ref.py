@@ -1,0 +1,73 @@
+"""CPU: the WRAPPER level of the oracle (oracle/pointops_cpu.py -- what the GPU parity tests hold the product's pointops/*.py to) against
+tests/golden/wrappers_ref.npz, which the reference's own Python layer produced (libs/pointops/functions/*.py executed unmodified as the
+package `pointops` over the C oracle's kernels; generator: tests/golden/make_golden.py::golden_wrappers): sqrt of dist2, the -1 masks,
+the interpolation weights, every autograd Function's forward AND backward wiring, the *_and_group helpers."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pointops_cpu as po
+
+FX = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wrappers_ref.npz"))
+T = lambda k: torch.from_numpy(FX[k])  # noqa: E731
+
+
+def _clouds():
+    xyz, off, noff = T("xyz"), T("offset"), T("new_offset")
+    sel = po.farthest_point_sampling(xyz, off, noff)
+    return xyz, off, noff, sel, xyz[sel.long()].contiguous()
+
+
+def test_sampling_and_queries_equal_the_reference_wrappers():
+    xyz, off, noff, sel, q = _clouds()
+    assert np.array_equal(sel.numpy(), FX["fps.idx"])
+    for tag, out in (("knn", po.knn_query(8, xyz, off, q, noff)), ("knn_self", po.knn_query(4, xyz, off)),
+                     ("ball", po.ball_query(8, 0.15, 0.02, xyz, off, q, noff)),
+                     ("rball", po.random_ball_query(8, 0.15, 0.02, xyz, off, q, noff, order=T("rball.order")))):
+        assert np.array_equal(out[0].numpy(), FX[f"{tag}.idx"]), tag
+        assert np.array_equal(out[1].numpy(), FX[f"{tag}.dist"]), tag  # sqrt(dist2), query.py:23 / :69 / :107
+    assert (FX["ball.idx"] < 0).any()  # rows shorter than nsample carry -1 (and 1e5 = sqrt(1e10) distances)
+
+
+def _check(tag, fn, n_in):
+    leaves = [T(f"{tag}.in{i}").clone().requires_grad_(True) for i in range(n_in)]
+    out = fn(*leaves)
+    np.testing.assert_allclose(out.detach().numpy(), FX[f"{tag}.out"], rtol=1e-6, atol=1e-6, err_msg=tag)
+    grads = torch.autograd.grad((out * T(f"{tag}.w")).sum(), leaves, allow_unused=True)
+    for i, g in enumerate(grads):
+        key = f"{tag}.grad{i}"
+        if key in FX.files:
+            np.testing.assert_allclose(g.numpy(), FX[key], rtol=1e-5, atol=1e-6, err_msg=key)
+        else:  # the reference returns no gradient here (attention.py:62): ours must not invent one
+            assert g is None or float(g.abs().max()) == 0.0, key
+
+
+@pytest.mark.parametrize("tag", ["grouping2", "grouping_xyz", "interp", "interp2", "subtraction", "aggregation", "attn_relation",
+                                 "attn_fusion"])
+def test_autograd_functions_equal_the_reference_wrappers(tag):
+    xyz, off, noff, sel, q = _clouds()
+    kidx, sidx = T("knn.idx"), T("sidx")
+    it, ir = T("attn.index_target"), T("attn.index_refer")
+    fn, n_in = {
+        "grouping2": (lambda f: po.grouping2(f, kidx), 1),
+        "grouping_xyz": (lambda f: po.grouping(kidx, f, xyz, q, with_xyz=True), 1),
+        "interp": (lambda f: po.interpolation(q, xyz, f, noff, off, k=3), 1),
+        "interp2": (lambda f: po.interpolation2(q, xyz, f, noff, off, 3), 1),
+        "subtraction": (lambda a, b: po.subtraction(a, b, sidx), 2),
+        "aggregation": (lambda a, pz, wt: po.aggregation(a, pz, wt, sidx), 3),
+        "attn_relation": (lambda a, b, wt: po.attention_relation_step(a, b, wt, it, ir), 3),
+        "attn_fusion": (lambda wt, v: po.attention_fusion_step(wt, v, it, ir), 2),
+    }[tag]
+    _check(tag, fn, n_in)
+
+
+def test_query_and_group_helpers_equal_the_reference_wrappers():
+    xyz, off, noff, sel, q = _clouds()
+    feat = T("feat")
+    a = po.knn_query_and_group(feat, xyz, off, q, noff, nsample=8, with_xyz=True)
+    b = po.ball_query_and_group(feat, xyz, off, q, noff, max_radio=0.15, min_radio=0.02, nsample=8, with_xyz=True)
+    for tag, out in (("knn_group", a), ("ball_group", b)):
+        out = out[0] if isinstance(out, tuple) else out
+        np.testing.assert_allclose(out.numpy(), FX[f"{tag}.out"], rtol=1e-6, atol=1e-6, err_msg=tag)
