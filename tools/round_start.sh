@@ -19,7 +19,7 @@ cut -c1-400 "$OUT/bench.json"
 SCR=/tmp/pcm_pending
 rm -rf $SCR && mkdir -p $SCR && cp -r . $SCR/ 2>/dev/null
 cd $SCR && rm -rf gpurun_out && patch -p1 -s < tools/dbg/pending_rowslinear.patch \
-  && timeout 900 python -m pytest -q -p no:cacheprovider tests/test_rows_linear_gpu.py tests/test_unet_ops_gpu.py tests/test_wide_fixture.py \
+  && timeout 900 python -m pytest -q -p no:cacheprovider tests/test_wrappers_ref_gpu.py tests/test_rows_linear_gpu.py tests/test_unet_ops_gpu.py tests/test_wide_fixture.py \
        tests/test_concurrency_gpu.py tests/test_policy_gpu.py tests/test_pointnet2_gpu.py tests/test_rlbench_gpu.py tests/test_presample.py \
        > "$OUT/pending_rowslinear.log" 2>&1
 echo "pending patch rc=$?" | tee -a "$OUT/pending_rowslinear.log"
