@@ -1166,6 +1166,10 @@ def golden_wrappers(ref):
             out = fn(feat)
             out = out[0] if isinstance(out, tuple) else out
             fx[f"{tag}.out"] = out.numpy()
+        # query_and_group (utils.py:42-99): dilated neighbourhoods; the middle cloud (75 points) is smaller than 1 + 7 * 12 = 85 -> soft dilation
+        for tag, dil in (("qg_d0", 0), ("qg_d1", 1), ("qg_soft", 11)):
+            out, gidx = po.query_and_group(8, xyz, q, feat, None, off, noff, dilation=dil, with_feat=True, with_xyz=True)
+            fx[f"{tag}.out"], fx[f"{tag}.idx"] = out.numpy(), gidx.numpy()
         np.savez_compressed(os.path.join(OUT, "wrappers_ref.npz"), **fx)
         print("wrappers_ref.npz:", len(fx), "arrays; m =", m, "; ball rows with -1:", int((fx["ball.idx"] < 0).any(1).sum()))
     finally:

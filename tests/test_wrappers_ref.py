@@ -71,3 +71,12 @@ def test_query_and_group_helpers_equal_the_reference_wrappers():
     for tag, out in (("knn_group", a), ("ball_group", b)):
         out = out[0] if isinstance(out, tuple) else out
         np.testing.assert_allclose(out.numpy(), FX[f"{tag}.out"], rtol=1e-6, atol=1e-6, err_msg=tag)
+
+
+@pytest.mark.parametrize("tag,dilation", [("qg_d0", 0), ("qg_d1", 1), ("qg_soft", 11)])
+def test_dilated_query_and_group_equals_the_reference_wrapper(tag, dilation):
+    # utils.py:42-99; "qg_soft": the 75-point cloud is smaller than 1 + 7 * 12 neighbours -> the soft-dilation branch (:74-77)
+    xyz, off, noff, sel, q = _clouds()
+    out, gidx = po.query_and_group(8, xyz, q, T("feat"), None, off, noff, dilation=dilation, with_feat=True, with_xyz=True)
+    assert np.array_equal(gidx.numpy(), FX[f"{tag}.idx"])
+    np.testing.assert_allclose(out.numpy(), FX[f"{tag}.out"], rtol=1e-6, atol=1e-6)
