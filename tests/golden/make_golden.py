@@ -945,16 +945,10 @@ def golden_rollout(ref):
     print("rollout_ref.npz ok; |action_pred| max", float(np.abs(traj).max()))
 
 
-def golden_optim(ref):
-    """configure_optimizers through the REFERENCE's own builders (maniskill2_act_bc_module.py:347-367 -> build_optimizer + build_scheduler;
-    maniskill2_dp_bc_module.py:326-344 -> build_optimizer_v2 + build_scheduler), with the YAML values of
-    configs/model/maniskill2_{act_pcd,diffusion_policy}_model.yaml:10-24.  omegaconf is absent: a dict with attribute access stands in for
-    the DictConfig (import-time names + `to_container`); the registry, the scheduler subclass and the grouping functions are the
-    reference's files, loaded by path.  Stored: the parameter NAMES of every group with its hyper-parameters, and the learning rate /
-    beta1 in effect at every optimizer step of a 200-step cycle."""
+def _install_optim_builders():
+    """The reference's optimizer / scheduler builders, loaded by path.  omegaconf is absent: a dict with attribute access stands in for the
+    DictConfig (import-time names + `to_container`).  Returns (Cfg class, optimizer module, scheduler module, restore function)."""
     import copy
-
-    from tests.util import optimizer_zoo
 
     class Cfg(dict):  # DictConfig stand-in: attribute access over a dict (deepcopy-able, `in`, .get, .copy, .keys)
         __getattr__ = dict.__getitem__
@@ -971,7 +965,6 @@ def golden_optim(ref):
     _load("src.utils.registry", f"{REF}/src/utils/registry.py")
     sched = _load("src.utils.scheduler", f"{REF}/src/utils/scheduler.py")
     optim = _load("src.utils.optimizer", f"{REF}/src/utils/optimizer.py")
-
     # the reference's scheduler subclasses still pass `verbose=` (scheduler.py:118-139), which torch 2.10 removed from the base class: the
     # BASE initialiser is wrapped to drop it (torch side, like the torchvision stub); the reference subclass itself runs unmodified
     base_init = torch.optim.lr_scheduler.OneCycleLR.__init__
@@ -980,6 +973,23 @@ def golden_optim(ref):
         return base_init(self, *a, **kw)
 
     torch.optim.lr_scheduler.OneCycleLR.__init__ = tolerant_init
+
+    def restore():
+        torch.optim.lr_scheduler.OneCycleLR.__init__ = base_init
+
+    return Cfg, optim, sched, restore
+
+
+def golden_optim(ref):
+    """configure_optimizers through the REFERENCE's own builders (maniskill2_act_bc_module.py:347-367 -> build_optimizer + build_scheduler;
+    maniskill2_dp_bc_module.py:326-344 -> build_optimizer_v2 + build_scheduler), with the YAML values of
+    configs/model/maniskill2_{act_pcd,diffusion_policy}_model.yaml:10-24.  omegaconf is absent: a dict with attribute access stands in for
+    the DictConfig (import-time names + `to_container`); the registry, the scheduler subclass and the grouping functions are the
+    reference's files, loaded by path.  Stored: the parameter NAMES of every group with its hyper-parameters, and the learning rate /
+    beta1 in effect at every optimizer step of a 200-step cycle."""
+    from tests.util import optimizer_zoo
+
+    Cfg, optim, sched, restore = _install_optim_builders()
 
     fx, T = {}, 200
     for tag, builder, ocfg, scfg in (
@@ -1009,7 +1019,7 @@ def golden_optim(ref):
             if k + 1 < T:
                 sch.step()
         fx[f"{tag}.lr"], fx[f"{tag}.beta1"] = lr, b1
-    torch.optim.lr_scheduler.OneCycleLR.__init__ = base_init
+    restore()
     np.savez_compressed(os.path.join(OUT, "optim_ref.npz"), **fx)
     print("optim_ref.npz: act groups", int(fx["act.n_groups"]), "dp groups", int(fx["dp.n_groups"]), "lr[0], lr[peak], lr[-1] =",
           fx["act.lr"][0, 0], fx["act.lr"].max(), fx["act.lr"][-1, 0])
@@ -1181,6 +1191,61 @@ def golden_wrappers(ref):
                 sys.modules[k] = v
 
 
+def golden_trajectory(ref):
+    """Six optimizer steps of the reference's training recipe, end to end: the reference `ACTPCD` (weights of act_pcd_small.npz), the
+    optimizer and scheduler from the reference's `build_optimizer` / `build_scheduler` (maniskill2_act_bc_module.py:347-367), and per step what
+    Lightning's automatic optimisation does with `gradient_clip_val: 0.5` (configs/trainer/default.yaml): zero_grad, forward, backward,
+    clip_grad_norm_, optimizer.step, scheduler.step.  lr is raised to 1e-3 so that six steps move the weights visibly."""
+    from pointcloudmatters_amd.bc import make_act_batch
+
+    Cfg, optim, sched, restore = _install_optim_builders()
+    pcd_npoints = 32
+    ours = build_ours(pcd_npoints, seed=1234)
+    model = build_reference_actpcd(ref, ours, pcd_npoints)
+    model.train()
+    opt = optim.build_optimizer(Cfg(type="AdamW", lr=0.001, weight_decay=0.05), model, None)
+    sch = sched.build_scheduler(Cfg(type="OneCycleLR", max_lr=0.001, pct_start=0.1, anneal_strategy="cos", div_factor=100.0,
+                                    final_div_factor=1000.0, total_steps=40), optimizer=opt)
+    batches = [make_act_batch(3, 180, seed=77 + i, ragged=True, num_queries=SMALL["num_queries"]) for i in range(2)]
+    eps = [torch.randn(3, SMALL["latent_dim"], generator=torch.Generator().manual_seed(5 + i)) for i in range(2)]
+    fx = {"eps0": eps[0].numpy(), "eps1": eps[1].numpy()}
+    for i, b in enumerate(batches):
+        for k, v in b.items():
+            if isinstance(v, dict):
+                for kk, vv in v.items():
+                    fx[f"in{i}.pcds.{kk}"] = vv.numpy()
+            else:
+                fx[f"in{i}.{k}"] = v.numpy()
+    orig = ref.act.reparametrize
+    losses, norms, lrs = [], [], []
+    try:
+        for step in range(6):
+            e = eps[step % 2]
+            ref.act.reparametrize = lambda mu, logvar, e=e: mu + logvar.div(2).exp() * e
+            b = batches[step % 2]
+            dd = {k: (dict(v) if isinstance(v, dict) else v.clone()) for k, v in b.items()}
+            dd["pcds"] = {k: v.clone() for k, v in dd["pcds"].items()}
+            opt.zero_grad()
+            out = model(dd)
+            out["loss"].backward()
+            norms.append(float(torch.nn.utils.clip_grad_norm_(model.parameters(), 0.5)))
+            lrs.append(opt.param_groups[0]["lr"])
+            opt.step()
+            sch.step()
+            losses.append(float(out["loss"]))
+    finally:
+        ref.act.reparametrize = orig
+        restore()
+    fx["loss"], fx["grad_norm"], fx["lr"] = np.array(losses), np.array(norms), np.array(lrs)
+    sd = model.state_dict()
+    for k in ("linear.weight", "bn.weight", "bn.running_mean", "backbone.conv1.0.weight", "transformer.encoder.layers.0.linear1.weight",
+              "transformer.decoder.layers.0.multihead_attn.out_proj.weight", "transformer.decoder.layers.2.linear1.weight",
+              "action_head.weight", "action_head.bias", "query_embed.weight"):
+        fx[f"final.{k}"] = sd[k].numpy()
+    np.savez_compressed(os.path.join(OUT, "trajectory_ref.npz"), **fx)
+    print("trajectory_ref.npz: losses", [round(x, 4) for x in losses], "grad norms", [round(x, 2) for x in norms])
+
+
 def golden_gridsample(ref):
     """GridSamplePCD (fnv, train, return_grid_coord) + NormalizeColorPCD from transformpcd.py, run as shipped on three
     seeded clouds (NumPy 2.2.6 here: coord / np.array(grid_size) promotes to float64)."""
@@ -1217,6 +1282,6 @@ if __name__ == "__main__":
     for name, fn in (("act", golden_act), ("grouping", golden_grouping), ("misc", golden_misc), ("dp", golden_dp),
                      ("rollout", golden_rollout), ("gridsample", golden_gridsample), ("rlbench", golden_rlbench),
                      ("dp_rlbench", golden_dp_rlbench), ("mask", golden_mask), ("presample", golden_presample), ("wide", golden_wide),
-                     ("optim", golden_optim), ("normalizer", golden_normalizer), ("wrappers", golden_wrappers)):
+                     ("optim", golden_optim), ("normalizer", golden_normalizer), ("wrappers", golden_wrappers), ("trajectory", golden_trajectory)):
         if not only or name in only:
             fn(ref)

@@ -1,0 +1,46 @@
+"""CPU: six optimizer steps of the training recipe against tests/golden/trajectory_ref.npz -- the reference's
+`ACTPCD` trained by the reference's own `build_optimizer` / `build_scheduler` with Lightning's step order and `gradient_clip_val: 0.5`
+(generator: tests/golden/make_golden.py::golden_trajectory).  The product side is `BCTrainer` with the oracle's pointops on the CPU; the GPU
+modes are held to this same trainer by tests/test_policy_gpu.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+FX = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trajectory_ref.npz"))
+
+
+def _batch(i):
+    b = {"pcds": {}}
+    pre = f"in{i}."
+    for k in FX.files:
+        if k.startswith(pre + "pcds."):
+            b["pcds"][k[len(pre) + 5:]] = torch.from_numpy(FX[k])
+        elif k.startswith(pre):
+            b[k[len(pre):]] = torch.from_numpy(FX[k])
+    b["vae_eps"] = torch.from_numpy(FX[f"eps{i}"])
+    return b
+
+
+@pytest.mark.parametrize("sa_impl", ["reference", "torch"])
+def test_six_training_steps_follow_the_reference_recipe(sa_impl):
+    from oracle import pointops_cpu
+    from pointcloudmatters_amd.bc import BCTrainer, clone_batch
+    from tests.test_golden_cpu import build_small_policy, load_act_fixture
+
+    _, _, weights = load_act_fixture()  # the same seeded weights the generator started from
+    pol = build_small_policy(pointops_cpu, sa_impl, weights)
+    tr = BCTrainer(pol, total_steps=40, precision="fp32", device="cpu", mode="eager", optim=dict(lr=1e-3, accumulate_grad_batches=1))
+    losses = []
+    for step in range(6):
+        assert tr.optimizer.param_groups[0]["lr"] == pytest.approx(float(FX["lr"][step]), rel=1e-12)
+        losses.append(float(tr.training_step(clone_batch(_batch(step % 2)))["loss"]))
+    np.testing.assert_allclose(losses, FX["loss"], rtol=1e-5)  # measured 2.3e-7 over the six steps (north_star: 1e-4)
+    assert losses[-1] < 0.5 * losses[0]  # and it trains: 23.4 -> 9.0 in the reference
+    sd = pol.state_dict()
+    for k in FX.files:
+        if k.startswith("final."):
+            ref = FX[k]
+            got = sd[k[6:]].numpy()
+            assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-7, k  # measured 2.1e-6
