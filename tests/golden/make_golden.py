@@ -1246,6 +1246,83 @@ def golden_trajectory(ref):
     print("trajectory_ref.npz: losses", [round(x, 4) for x in losses], "grad norms", [round(x, 2) for x in norms])
 
 
+def golden_dp_trajectory(ref):
+    """Six optimizer steps of the Diffusion-Policy recipe: the reference `PCDObsEncoder` + `ConditionalUnet1D` + `LowdimMaskGenerator`
+    composed as compute_loss does (as in golden_dp; weights of dp_pcd_small.npz), optimizer from the reference's `build_optimizer_v2` with the
+    YAML's optimizer section INCLUDING its `betas: [0.9, 0.95]` (maniskill2_diffusion_policy_model.yaml:10-14) -- which the builder does not
+    forward --, scheduler from `build_scheduler` (pct_start 0.15), Lightning's step order with the 0.5 clip.  lr raised to 1e-3."""
+    from oracle import pointops_cpu
+    from pointcloudmatters_amd.bc import build_dp_policy, make_dp_batch
+    from pointcloudmatters_amd.policy import PointNet
+
+    Cfg, optim, sched, restore = _install_optim_builders()
+    pcd_npoints = 32
+    torch.manual_seed(4321)
+    ours = build_dp_policy(pcd_npoints=pcd_npoints, pointops=pointops_cpu, sa_impl="reference", **DP_SMALL)
+    sd = ours.state_dict()
+    shape_meta = {"obs": {"pcds": {"shape": [6], "type": "pcd"}, "qpos": {"shape": [9], "type": "low_dim"}}, "action": {"shape": [7]}}
+
+    class RefPolicy(torch.nn.Module):  # the attribute names of DiffusionUnetImagePolicy (diffusion_unet_image_policy.py:84-86): same parameter names
+        def __init__(self):
+            super().__init__()
+            self.obs_encoder = ref.pcd_enc.PCDObsEncoder(
+                shape_meta=shape_meta, pcd_model=PointNet(in_channels=6, num_classes=24), share_pcd_model=True, n_obs_step=2,
+                pcd_nsample=16, pcd_npoints=pcd_npoints, pcd_hidden_dim=24, projector_layers=1, projector_channels=[24, 40, 40])
+            self.model = ref.unet.ConditionalUnet1D(input_dim=7, local_cond_dim=None, global_cond_dim=(40 + 9) * 2,
+                                                    diffusion_step_embed_dim=16, down_dims=[16, 32, 64], kernel_size=5, n_groups=8,
+                                                    cond_predict_scale=True)
+
+    pol = RefPolicy()
+    pol.obs_encoder.load_state_dict({k[len("obs_encoder."):]: v for k, v in sd.items() if k.startswith("obs_encoder.")}, strict=True)
+    pol.model.load_state_dict({k[len("model."):]: v for k, v in sd.items() if k.startswith("model.")}, strict=True)
+    pol.train()
+    mg = ref.maskgen.LowdimMaskGenerator(action_dim=7, obs_dim=0, max_n_obs_steps=2, fix_obs_steps=True, action_visible=False)
+    opt = optim.build_optimizer_v2(Cfg(type="AdamW", betas=[0.9, 0.95], lr=0.001, weight_decay=0.0001), pol)
+    sch = sched.build_scheduler(Cfg(type="OneCycleLR", max_lr=0.001, pct_start=0.15, anneal_strategy="cos", div_factor=100.0,
+                                    final_div_factor=1000.0, total_steps=40), optimizer=opt)
+    batches = [make_dp_batch(3, 150, seed=11 + i, ragged=True) for i in range(2)]
+    g = torch.Generator().manual_seed(8)
+    noises = [torch.randn(3, 16, 7, generator=g) for _ in range(2)]
+    tsteps = [torch.tensor([3, 57, 99]), torch.tensor([0, 20, 80])]
+    fx = {}
+    for i, b in enumerate(batches):
+        for k, v in b["obs"]["pcds"].items():
+            fx[f"in{i}.pcds.{k}"] = v.numpy()
+        fx[f"in{i}.qpos"], fx[f"in{i}.action"] = b["obs"]["qpos"].numpy(), b["action"].numpy()
+        fx[f"in{i}.noise"], fx[f"in{i}.timesteps"] = noises[i].numpy(), tsteps[i].numpy()
+    losses, norms = [], []
+    try:
+        for step in range(6):
+            b, noise, timesteps = batches[step % 2], noises[step % 2], tsteps[step % 2]
+            qpos, action = b["obs"]["qpos"], b["action"]
+            this_nobs = {"qpos": qpos[:, :2].reshape(-1, 9), "pcds": {k: v.clone() for k, v in b["obs"]["pcds"].items()}}
+            opt.zero_grad()
+            global_cond = pol.obs_encoder(this_nobs).reshape(3, -1)
+            mask = mg((3, 16, 7))
+            acp = ours.noise_scheduler.alphas_cumprod[timesteps]  # diffusers absent: our restated schedule (parity unpinned)
+            noisy = acp.sqrt()[:, None, None] * action + (1 - acp).sqrt()[:, None, None] * noise
+            noisy[mask] = action[mask]
+            pred = pol.model(noisy, timesteps, local_cond=None, global_cond=global_cond)
+            loss = (torch.nn.functional.mse_loss(pred, noise, reduction="none") * (~mask).float()).reshape(3, -1).mean(1).mean()
+            loss.backward()
+            norms.append(float(torch.nn.utils.clip_grad_norm_(pol.parameters(), 0.5)))
+            opt.step()
+            sch.step()
+            losses.append(float(loss))
+    finally:
+        restore()
+    fx["loss"], fx["grad_norm"] = np.array(losses), np.array(norms)
+    fx["beta2"] = np.array([g_["betas"][1] for g_ in opt.param_groups])
+    fsd = pol.state_dict()
+    for k in ("obs_encoder.linear.weight", "obs_encoder.projector.0.weight", "obs_encoder.key_model_map.pcd.conv1.0.weight",
+              "model.diffusion_step_encoder.1.weight", "model.diffusion_step_encoder.1.bias", "model.down_modules.0.0.blocks.0.block.0.weight",
+              "model.mid_modules.1.cond_encoder.1.weight", "model.final_conv.1.weight", "model.final_conv.1.bias",
+              "model.up_modules.0.0.blocks.0.block.1.weight"):
+        fx[f"final.{k}"] = fsd[k].numpy()
+    np.savez_compressed(os.path.join(OUT, "dp_trajectory_ref.npz"), **fx)
+    print("dp_trajectory_ref.npz: losses", [round(x, 4) for x in losses], "grad norms", [round(x, 2) for x in norms], "beta2", fx["beta2"])
+
+
 def golden_gridsample(ref):
     """GridSamplePCD (fnv, train, return_grid_coord) + NormalizeColorPCD from transformpcd.py, run as shipped on three
     seeded clouds (NumPy 2.2.6 here: coord / np.array(grid_size) promotes to float64)."""
@@ -1282,6 +1359,6 @@ if __name__ == "__main__":
     for name, fn in (("act", golden_act), ("grouping", golden_grouping), ("misc", golden_misc), ("dp", golden_dp),
                      ("rollout", golden_rollout), ("gridsample", golden_gridsample), ("rlbench", golden_rlbench),
                      ("dp_rlbench", golden_dp_rlbench), ("mask", golden_mask), ("presample", golden_presample), ("wide", golden_wide),
-                     ("optim", golden_optim), ("normalizer", golden_normalizer), ("wrappers", golden_wrappers), ("trajectory", golden_trajectory)):
+                     ("optim", golden_optim), ("normalizer", golden_normalizer), ("wrappers", golden_wrappers), ("trajectory", golden_trajectory), ("dp_trajectory", golden_dp_trajectory)):
         if not only or name in only:
             fn(ref)
