@@ -35,6 +35,7 @@ def test_dp_recipe_grouping_equals_the_reference_function():
     # build_optimizer_v2 does not forward the YAML's betas [0.9, 0.95] (optimizer.py:304-318): the reference trains with torch's defaults
     assert float(FX["dp.group0.beta2"]) == float(FX["dp.group1.beta2"]) == DP_OPTIM["betas"][1] == 0.999
     assert DP_OPTIM["yaml_betas"] == (0.9, 0.95)
+    assert float(FX["dp.group0.eps"]) == float(FX["dp.group1.eps"]) == 1e-8  # FlatAdamW's default too (bc/flat_optim.py)
     nd = {id(p) for p in undecayed_parameters(zoo)}
     ours_nd = [n for n, p in zoo.named_parameters() if id(p) in nd]
     ours_d = [n for n, p in zoo.named_parameters() if p.requires_grad and id(p) not in nd]
