@@ -3,7 +3,8 @@
 Re-runs tests/golden/make_golden.py (which imports the reference classes from /root/reference) into a scratch directory and compares
 every array of every .npz with the committed one: bit-equal, or -- for floating-point arrays -- the largest relative difference
 (the generator pins torch to one thread; what is left is library-level reduction order).  Exit code 1 on a missing key / array, a shape
-or dtype change, an integer difference, or a float difference above 1e-6 of the array's scale.
+or dtype change, an integer difference, or a float difference above 2e-5 of the array's scale (bit-equal on the machine that wrote the fixtures; another CPU
+may pick other GEMM kernels, and the fixture tests themselves hold the product to 1e-4).
     python tools/check_golden_regen.py [fixture names as make_golden.py takes them]
 """
 import os
@@ -37,7 +38,7 @@ def compare(old_dir, new_dir):
             else:
                 rel = float(np.abs(x.astype(np.float64) - y.astype(np.float64)).max() / max(float(np.abs(x).max()), 1e-30))
                 worst = max(worst, rel)
-                if rel > 1e-6:
+                if rel > 2e-5:
                     bad.append((fn, k, "relative difference", rel))
     return bad, worst, n_arrays, n_equal
 
@@ -54,7 +55,7 @@ def main():
         bad, worst, n, eq = compare(GOLD, tmp)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    print(f"{n} arrays: {eq} bit-equal, largest relative difference among the others {worst:.3g}; {len(bad)} beyond 1e-6")
+    print(f"{n} arrays: {eq} bit-equal, largest relative difference among the others {worst:.3g}; {len(bad)} beyond 2e-5")
     for b in bad[:20]:
         print("  ", b)
     return 1 if bad else 0
