@@ -76,14 +76,14 @@ def test_six_diffusion_policy_steps_follow_the_reference_recipe():
 
     assert list(DFX["beta2"]) == [0.999, 0.999]
     losses, sd = _dp_run(dict(DP_OPTIM, lr=1e-3))
-    np.testing.assert_allclose(losses, DFX["loss"], rtol=1e-4)
+    np.testing.assert_allclose(losses, DFX["loss"], rtol=5e-4)  # measured 2.2e-5 on the machine that wrote the fixture
     worst = 0.0
     for k in DFX.files:
         if k.startswith("final."):
             ref, got = DFX[k], sd[k[6:]].numpy()
             worst = max(worst, float(np.abs(got - ref).max() / np.abs(ref).max()))
-    assert worst <= 2e-4, worst  # measured 3.5e-5 (losses 2.2e-5); with the YAML betas: 9.6e-3 (losses 6.1e-3)
+    assert worst <= 1e-3, worst  # measured 3.5e-5; with the YAML betas: 9.6e-3 (losses 6.1e-3)
     # the same run with the YAML's betas: the first update is identical (Adam's bias correction), the trajectory then leaves the reference's
     wrong, sd2 = _dp_run(dict(DP_OPTIM, lr=1e-3, betas=DP_OPTIM["yaml_betas"]))
     dev = max(float(np.abs(sd2[k[6:]].numpy() - DFX[k]).max() / np.abs(DFX[k]).max()) for k in DFX.files if k.startswith("final."))
-    assert dev > 10 * max(worst, 1e-5), (dev, worst)
+    assert dev > 3e-3 and dev > 3 * worst, (dev, worst)
