@@ -873,7 +873,9 @@ def emit(out, tables, tables_path):
             os.makedirs(os.path.dirname(os.path.abspath(tables_path)), exist_ok=True)
             with open(tables_path, "w") as f:
                 json.dump(dict(tables, headline={k: v for k, v in out.items()}), f, indent=1)
-            out["tables"] = os.path.relpath(tables_path, ROOT)
+            # scratch on the GPU box (the driver does not pull it): the copies that are judged are the ones tools/collect_bench.sh
+            # puts under profiles/ (profiles/rNN_bench_tables.json), from this same command
+            out["tables"] = os.path.relpath(tables_path, ROOT) + " (scratch; tracked copy: profiles/rNN_bench_tables.json)"
         except OSError as e:  # read-only tree: the headline must still print
             out["tables"] = "not written: %s" % e
     sys.stdout.flush()

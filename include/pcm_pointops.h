@@ -315,6 +315,12 @@ int pcm_attn_flash_backward_stages_hip(int B, int H, int L, int S, const void *q
  * with a garbage pattern on ROCm 7.2; ATen reductions zero their semaphores with one).  *n_replaced (may be NULL)
  * receives the number of nodes replaced. */
 int pcm_graph_replace_memsets(void *graph, int *n_replaced);
+/* HIP runtime version the library is bound to (HIP_VERSION encoding) and a plain asynchronous memset issued through that same
+ * binding (d32 == 0: `count` bytes, else `count` dwords): what the host side uses to decide whether the rewrite above is needed
+ * (pointcloudmatters_amd/_graphs.py: always on runtimes <= 7.2.x, where the defect was found; a captured-memset self-test
+ * decides on newer ones). */
+int pcm_hip_runtime_version(int *version);
+int pcm_memset_async(void *dst, int value, long count, int d32, void *stream);
 
 /* ---- fused  out = LayerNorm(x + dropout(y))  ------------------------------------------------------------
  * replaces the `x = x + dropout(y); x = norm(x)` tail of every post-norm transformer sub-layer
@@ -383,8 +389,9 @@ int pcm_ffn_ln_backward2_hip(long R, int E, int F, const float *dout, const floa
 
 /* ---- the same sub-layer on the matrix cores (csrc/ffn_mfma.hip), the bf16-autocast path ---------------------
  * Same argument lists as pcm_ffn_ln_forward2_hip / pcm_ffn_ln_backward2_hip and the same dropout hash; the two products run as
- * v_mfma_f32_32x32x16_bf16 (h and y leave their GEMMs as bf16, like F.linear under autocast; transformer.py:253-256, 342-345),
- * everything stored stays fp32.  One workgroup per 32-row tile: `partial` has pcm_ffn_ln_mfma_blocks(R) rows of 3E + F. */
+ * v_mfma_f32_16x16x32_bf16 (h and y leave their GEMMs as bf16, like F.linear under autocast; transformer.py:253-256, 342-345),
+ * everything stored stays fp32.  Rows are processed in 16-row tiles: `partial` has pcm_ffn_ln_mfma_blocks(R) = ceil(R / 16) rows of
+ * 3E + F -- always size it from that function, never from a tile height assumed by the caller. */
 int pcm_ffn_ln_mfma_supported(int E, int F);
 int pcm_ffn_ln_mfma_blocks(long R);
 int pcm_ffn_ln_mfma_forward_hip(long R, int E, int F, const float *x, const float *W1, const float *b1, const float *W2,

@@ -19,13 +19,24 @@ def new_graph():
 
 
 _NEEDS_FIX = {}  # device index -> does this runtime replay captured memset nodes wrongly?  (decided once per process)
+KNOWN_BAD_UP_TO = 7 * 10000000 + 2 * 100000 + 99999  # HIP_VERSION encoding: every 7.2.x and older (found on 7.2.26015)
+
+
+def runtime_version():
+    """HIP_VERSION-encoded version of the runtime libpcm_pointops.so is bound to (the one whose graphs are being patched)."""
+    v = ctypes.c_int(0)
+    _lib.check(_lib.load().pcm_hip_runtime_version(ctypes.byref(v)), "pcm_hip_runtime_version")
+    return v.value
 
 
 def memset_fix_needed(device=None):
-    """One-time self-test, per device: capture raw hipMemset(D32)Async nodes of several sizes / patterns WITHOUT the rewrite,
-    replay each graph eight times and compare with the pattern.  True (rewrite every captured memset node) if any replay is
-    wrong -- the case on ROCm 7.2, where the nodes replay a corrupted pattern from the second launch on --, False on a runtime
-    where they replay correctly, so the workaround retires itself.  PCM_GRAPH_MEMSET_FIX=1 / 0 overrides the test."""
+    """Rewrite every captured memset node?  PCM_GRAPH_MEMSET_FIX=1 / 0 overrides.  Otherwise:
+      * runtimes up to 7.2.x (where the defect was found: replays >= 1 of a captured memset write a stale host pattern): ALWAYS.
+        The rewrite costs one kernel node per memset; a probe of five shapes cannot prove a size- or pattern-dependent defect absent,
+        and a false negative would corrupt every training graph silently;
+      * newer runtimes: a one-time self-test per device -- raw hipMemset(D32)Async nodes of several sizes / patterns captured WITHOUT
+        the rewrite, each graph replayed eight times and compared with the pattern -- so that the workaround retires itself once the
+        runtime is fixed.  The memsets are issued through libpcm_pointops.so's own binding of the runtime (pcm_memset_async)."""
     import os
 
     forced = os.environ.get("PCM_GRAPH_MEMSET_FIX", "auto")
@@ -34,9 +45,16 @@ def memset_fix_needed(device=None):
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     if dev.index in _NEEDS_FIX:
         return _NEEDS_FIX[dev.index]
-    hip = ctypes.CDLL("libamdhip64.so")
-    hip.hipMemsetAsync.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
-    hip.hipMemsetD32Async.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
+    if runtime_version() <= KNOWN_BAD_UP_TO:
+        _NEEDS_FIX[dev.index] = True
+        return True
+    _NEEDS_FIX[dev.index] = bad = memset_self_test(dev)
+    return bad
+
+
+def memset_self_test(dev):
+    """True if a captured memset node replays wrongly on `dev` (see memset_fix_needed)."""
+    lib = _lib.load()
     bad = False
     with torch.cuda.device(dev):
         for n_ints, d32, value in ((1, False, 0), (16, False, 0), (1024, True, 0), (1000, True, 0x01020304), (77, False, 0x5A)):
@@ -45,8 +63,8 @@ def memset_fix_needed(device=None):
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize(dev)
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                st = torch.cuda.current_stream().cuda_stream
-                rc = hip.hipMemsetD32Async(buf.data_ptr(), value, n_ints, st) if d32 else hip.hipMemsetAsync(buf.data_ptr(), value, n_ints * 4, st)
+                st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+                rc = lib.pcm_memset_async(ctypes.c_void_p(buf.data_ptr()), value, n_ints if d32 else n_ints * 4, 1 if d32 else 0, st)
                 buf.add_(1)
                 out.copy_(buf)
             if rc != 0:
@@ -62,7 +80,6 @@ def memset_fix_needed(device=None):
             del g
             if bad:
                 break
-    _NEEDS_FIX[dev.index] = bad
     return bad
 
 

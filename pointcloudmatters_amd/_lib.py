@@ -127,6 +127,8 @@ SIGNATURES = {
     "pcm_attn_flash_backward_stages_hip": [_i, _i, _i, _i, _P, ctypes.c_long, ctypes.c_long, _P, ctypes.c_long, ctypes.c_long, _P, ctypes.c_long, ctypes.c_long, _P, _f, _f, _P, ctypes.c_uint,
                                            _P, _P, _P, _P, _P, ctypes.c_long, ctypes.c_long, _P, ctypes.c_long, ctypes.c_long, _P, ctypes.c_long, ctypes.c_long, _i, _P],
     "pcm_graph_replace_memsets": [_P, _P],
+    "pcm_hip_runtime_version": [_P],
+    "pcm_memset_async": [_P, ctypes.c_int, ctypes.c_long, ctypes.c_int, _P],
     "pcm_optim_partials_capacity": [],
     "pcm_grad_sumsq_hip": [ctypes.c_long, _P, _P, _P, _P],
     "pcm_adamw_flat_hip": [ctypes.c_long, _P, _P, _P, _P, _P, _P, _i, _P, _P, _P],

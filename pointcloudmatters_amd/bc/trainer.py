@@ -172,7 +172,12 @@ class BCTrainer:
 
         self.distributed = bool(distributed and multi_rank())
         self.world = dist.get_world_size() if self.distributed else 1
-        total_steps = max(int(total_steps), int(2 / o["pct_start"]) + 1)
+        # total_steps is used as given (the reference hands Lightning's estimated_stepping_batches to torch's OneCycleLR,
+        # src/utils/scheduler.py:101-143).  That scheduler divides by `pct_start * total_steps - 1`: the one value it cannot take is
+        # zero (a negative first-phase end just means "no warm-up phase"); torch dies there with ZeroDivisionError, here with a message.
+        total_steps = int(total_steps)
+        if total_steps <= 0 or float(o["pct_start"] * total_steps) - 1 == 0:
+            raise ValueError(f"OneCycleLR cannot form a cycle of total_steps={total_steps} with pct_start={o['pct_start']}")
         # ---- synchronised BatchNorm (configs/trainer/ddp.yaml:9).  eager: torch's SyncBatchNorm.  flat / hybrid: the
         # BatchNorm layers the fused kernels own exchange their statistics themselves (policy/sync_bn.py), every other
         # BatchNorm module becomes a torch SyncBatchNorm -- all of them run OUTSIDE the captured graphs in hybrid mode.
@@ -183,6 +188,12 @@ class BCTrainer:
         # per-rank statistics, as before, and bench.py picks hybrid.
         self.sync_batchnorm = bool(self.distributed and sync_batchnorm)
         if self.sync_batchnorm and mode == "graph" and not self.all_batchnorms_fused(policy):
+            import warnings
+
+            warnings.warn("BCTrainer(mode='graph', distributed=True, sync_batchnorm=True): this policy has BatchNorm modules no fused "
+                          "kernel owns, so a captured step cannot exchange their statistics -- training continues with PER-RANK BatchNorm "
+                          "statistics (the reference's configs/trainer/ddp.yaml:9 asks for synchronised ones).  Use mode='hybrid' to "
+                          "keep them synchronised.", RuntimeWarning, stacklevel=2)
             self.sync_batchnorm = False
         self.segmented = bool(mode == "graph" and (self.distributed or os.environ.get("PCM_FORCE_SEGMENTS") == "1"))
         if self.sync_batchnorm:
@@ -428,13 +439,15 @@ class BCTrainer:
         # closing reductions of the fused backward kernels batched per backward stage (policy/deferred.py): only where the
         # gradients are handed over explicitly, i.e. nothing reads one before `collect`
         window = bool(collect and self.defer_reductions and not rows_linear.SIDE.active) and deferred.begin()
+        failed = True  # stays True when the body raises or the generator is closed before its last stage (GeneratorExit)
         try:
             yield from self._segments_inner(make_out, first, stages, leaf, collect)
+            failed = False
         finally:
             rows_linear.join_side()
             rows_linear.SIDE.active = False
             if window:
-                deferred.end()
+                deferred.end(failed=failed)
 
     def _segments_inner(self, make_out, first, stages, leaf, collect):
         from ..policy import deferred, rows_linear, staging

@@ -440,7 +440,7 @@ __global__ __launch_bounds__(64) void pcm_ball_replay_kernel(int m, int S, int n
 
 inline int ball_split_segments(int m)
 {
-    static const int forced = getenv("PCM_BALL_S") ? atoi(getenv("PCM_BALL_S")) : 0;  // A/B switch for tools/mb/mb_ball.py
+    static const int forced = pcm_mb_switch("PCM_BALL_S", 0);  // A/B switch for tools/mb/mb_ball.py
     if (forced == 1 || forced == 2 || forced == 4 || forced == 8) return forced;
     int S = 1;  // >= 4 waves per SIMD (1024 SIMDs x 64 lanes): the scan hides its scalar-load latency (C5: S = 1 / 2 / 4 / 8 -> 611 / 420 / 345 / 327 us)
     while (S < 8 && (long)m * S < 262144) S *= 2;
@@ -508,7 +508,7 @@ extern "C" int pcm_ball_query_b_hip(int b, int m, int nsample, float min_radius,
     if (m < 0 || nsample < 1 || b < 0) return PCM_ERR_BAD_ARG;
     if (m == 0) return PCM_OK;
     int blocks = m < 256 * 16 ? m : 256 * 16;
-    static const int force_wave = getenv("PCM_BALL_WAVE") ? atoi(getenv("PCM_BALL_WAVE")) : 0;  // A/B switch for tools/mb
+    static const int force_wave = pcm_mb_switch("PCM_BALL_WAVE", 0);  // A/B switch for tools/mb
     if (b > 0 && m >= 32768 && !force_wave) {
         // enough queries to fill the chip with 64-query waves (48 KiB of LDS each: three per CU): lane-per-query kernel, then
         // the flagged leftovers.  Measured, radius 0.1, nsample 16 (wave-per-query -> lanes): 128 x 1024 points / 65 536 queries

@@ -84,7 +84,7 @@ __device__ __forceinline__ uint32_t fps_block_argmax(uint32_t bits, uint32_t pri
     return fps_unprio(~(uint32_t)key, L);
 }
 
-typedef float fps_f2 __attribute__((ext_vector_type(2)));  // v_pk_add_f32 / v_pk_mul_f32 operands (no FMA: contract off)
+typedef float fps_f2 __attribute__((ext_vector_type(2)));  // a point pair; the build has no packed-fp32 instructions (Makefile NO_PK): two scalar chains
 
 // Wave-wide unsigned max in 6 DPP-fused instructions + 1 readlane (the builtin form costs a v_mov + s_nop + v_mov_dpp +
 // v_max per step and 4 readlanes): quad swaps, row_half_mirror, row_mirror leave every row's maximum in all of its lanes,
@@ -112,8 +112,9 @@ __device__ __forceinline__ uint32_t fps_wave_max_fast(uint32_t v)
 // ---------------------------------------------------------------------------------------------
 // Register-resident kernel: N_i <= T*PPT for every cloud.  The pick loop is bound by instruction issue of ONE wave per
 // SIMD (~6 clocks per dependent instruction), so it is written to be short:
-//  (a) distance update on point PAIRS with packed fp32 math (same roundings as the scalar chain: sub, mul, add, mul, add,
-//      one at a time), v_min for the running distance, one compare + two selects for the thread's candidate;
+//  (a) distance update on point PAIRS, written on two-element vectors (sub, mul, add, mul, add, one rounding at a time; the build
+//      compiles them to scalar v_sub / v_mul / v_add -- packed fp32 instructions are disabled, Makefile NO_PK -- so the pair form only
+//      keeps two independent chains in flight), v_min for the running distance, one compare + two selects for the thread's candidate;
 //  (b) wave maximum of the candidates' distance bits: 6 fused DPP instructions + 1 readlane;
 //  (c) a ballot finds the owning lane; only an exact tie inside the wave (wave-uniform branch, rare) computes the
 //      reference's tie order (prio) and reduces it;
@@ -367,11 +368,11 @@ extern "C" int pcm_farthest_point_sampling_hip(int b, int n, const float *xyz, c
         // BS == 1024: four reference threads per thread
         // n <= 1024: 128 threads x 8 points (two waves to synchronise per pick instead of four) measured 476 vs 498 ns / pick
         // at 8 x 1024 and 482 vs 562 at 128 x 1024; ONE wave x 16 points is slower again (599: the in-thread chain dominates)
-        static const int small_t = getenv("PCM_FPS_SMALL_T") ? atoi(getenv("PCM_FPS_SMALL_T")) : 128;  // A/B switch for tools/mb
+        static const int small_t = pcm_mb_switch("PCM_FPS_SMALL_T", 128);  // A/B switch for tools/mb
         if (need <= 4 && small_t == 64) return launch_reg<64, 16, 4, true>(b, xyz, offset, new_offset, idx, L, st);
         if (need <= 4 && small_t == 128) return launch_reg<128, 8, 3, true>(b, xyz, offset, new_offset, idx, L, st);
         if (need <= 4) return launch_reg<256, 4, 2, true>(b, xyz, offset, new_offset, idx, L, st);
-        static const int big_t = getenv("PCM_FPS_BIG_T") ? atoi(getenv("PCM_FPS_BIG_T")) : 256;  // A/B switch for tools/mb (2048 < n <= 4096)
+        static const int big_t = pcm_mb_switch("PCM_FPS_BIG_T", 256);  // A/B switch for tools/mb (2048 < n <= 4096)
         if (need <= 8) {
             if (big_t == 512) return launch_reg<512, 4, 1, true>(b, xyz, offset, new_offset, idx, L, st);
             if (big_t == 128) return launch_reg<128, 16, 3, true>(b, xyz, offset, new_offset, idx, L, st);
@@ -386,7 +387,7 @@ extern "C" int pcm_farthest_point_sampling_hip(int b, int n, const float *xyz, c
         // 4096 < n_max <= 8192 (BS = 1024).  The 1024-thread kernel pays 16 waves' worth of slots per pick (1.24 us / pick on
         // a ragged 8 x ~4096 batch); fewer, fatter threads keep the pick latency of the 4096-point variant:
         // 256 threads x 24 / 32 points (four reference threads folded into one) or 512 x 12 / 16 (two).
-        static const int t512 = getenv("PCM_FPS_T512") ? atoi(getenv("PCM_FPS_T512")) : 0;  // A/B switch for tools/mb
+        static const int t512 = pcm_mb_switch("PCM_FPS_T512", 0);  // A/B switch for tools/mb
         if (t512 == 2) return launch_reg<1024, 8, 0, true>(b, xyz, offset, new_offset, idx, L, st);
         if (n <= 256 * 24) {
             if (t512) return launch_reg<512, 12, 1, true>(b, xyz, offset, new_offset, idx, L, st);

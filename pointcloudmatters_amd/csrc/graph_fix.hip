@@ -103,3 +103,22 @@ extern "C" int pcm_graph_replace_memsets(void *graph_, int *n_replaced)
     if (n_replaced) *n_replaced = replaced;
     return PCM_OK;
 }
+
+// The HIP runtime this library is bound to (HIP_VERSION encoding: major * 10000000 + minor * 100000 + patch).  _graphs.py keeps the
+// rewrite unconditionally on runtimes up to the one it was found on (7.2.x) and lets a self-test retire it only on newer ones.
+extern "C" int pcm_hip_runtime_version(int *version)
+{
+    if (!version) return PCM_ERR_BAD_ARG;
+    return pcm_status(hipRuntimeGetVersion(version));
+}
+
+// hipMemsetAsync (d32 == 0: `count` bytes of the low byte of `value`) / hipMemsetD32Async (d32 != 0: `count` dwords) issued through
+// THIS library's runtime binding -- what the self-test of _graphs.memset_fix_needed captures: a second, separately dlopen()ed copy
+// of the runtime must never be handed torch's stream handle.
+extern "C" int pcm_memset_async(void *dst, int value, long count, int d32, void *stream)
+{
+    if (count < 0 || (count > 0 && !dst)) return PCM_ERR_BAD_ARG;
+    if (count == 0) return PCM_OK;
+    return pcm_status(d32 ? hipMemsetD32Async((hipDeviceptr_t)dst, value, (size_t)count, (hipStream_t)stream)
+                          : hipMemsetAsync(dst, value, (size_t)count, (hipStream_t)stream));
+}

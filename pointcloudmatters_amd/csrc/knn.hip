@@ -479,8 +479,8 @@ extern "C" int pcm_knn_query_n_hip(int b, int n_max, int m, int nsample, const f
             // 32 x 4096, m = 65536: 394 / 351 / 342; 8 ragged x ~4096, m = 16384: 107 / 106 / 127.  The kernel is bound by the
             // serial insertion chain (vector -> scalar -> vector dependencies, ~K ln(N/K) insertions per query), not by the
             // cloud reads: more queries per wave save L2 traffic but leave fewer independent waves to hide that latency.
-            static const int forced = getenv("PCM_KNN_Q") ? atoi(getenv("PCM_KNN_Q")) : 0;  // A/B switch for tools/mb
-            static const int twopass = getenv("PCM_KNN_TWOPASS") ? atoi(getenv("PCM_KNN_TWOPASS")) : 1;
+            static const int forced = pcm_mb_switch("PCM_KNN_Q", 0);  // A/B switch for tools/mb
+            static const int twopass = pcm_mb_switch("PCM_KNN_TWOPASS", 1);
             if (twopass) {
                 int blocks2 = (m + kWaves - 1) / kWaves;
                 if (blocks2 > 256 * 32) blocks2 = 256 * 32;
@@ -497,7 +497,7 @@ extern "C" int pcm_knn_query_n_hip(int b, int n_max, int m, int nsample, const f
         int rc = PCM_LAUNCH_STATUS();
         if (rc) return rc;
 #ifdef PCM_MB_SWITCHES  // microbenchmark builds only (tools/mb/mb_knn_flags.py counts the marked queries): the shipped library always answers them
-        static const int skip_exact = getenv("PCM_KNN_SKIP_EXACT") ? atoi(getenv("PCM_KNN_SKIP_EXACT")) : 0;
+        static const int skip_exact = pcm_mb_switch("PCM_KNN_SKIP_EXACT", 0);
         if (skip_exact) return PCM_OK;
 #endif
         hipLaunchKernelGGL(pcm_knn_exact_kernel, dim3(exact_blocks), dim3(64 * kWaves), 0, st, b, m, nsample, 0, xyz, new_xyz, offset,

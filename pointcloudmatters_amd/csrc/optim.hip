@@ -188,13 +188,11 @@ extern "C" int pcm_adamw_flat_hip(long n, float *p, const float *g, float *m, fl
     if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16) != 0) return PCM_ERR_BAD_ARG;
     if (n == 0) return PCM_OK;  // nothing to update (norm_out is left untouched)
     const long n4 = n / 4;
-    static const int grid_env = getenv("PCM_ADAM_GRID") ? atoi(getenv("PCM_ADAM_GRID")) : 0;  // A/B switch for tools/mb
     // seven address streams (p, m, v, g in; p, m, v, bf16 mirror out): FEWER workgroups keep them more DRAM-page-friendly.
     // Measured (us, 24.1 M / 255.6 M parameters): 1024 blocks 122 / 1634, 512: 121 / 1416, 256: 140 / 1366.
     int grid = stream_grid(n4);
     const int cap = n4 >= (32L << 20) ? 256 : 512;
     if (grid > cap) grid = cap;
-    if (grid_env > 0 && (long)grid_env * kBlock <= n4) grid = grid_env;
     hipLaunchKernelGGL(pcm_adamw_flat_kernel<3>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, n4, n, p, g, m, v,
                        hyper, partials, npartials, norm_out, (__hip_bfloat16 *)p_bf16);
     return PCM_LAUNCH_STATUS();

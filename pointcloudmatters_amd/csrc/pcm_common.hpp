@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/pcm_pointops.h"
 
@@ -10,6 +11,19 @@
 
 static inline int pcm_status(hipError_t e) { return e == hipSuccess ? PCM_OK : PCM_ERR_HIP_BASE + (int)e; }
 #define PCM_LAUNCH_STATUS() pcm_status(hipGetLastError())
+
+// A/B switches of the microbenchmarks (tools/mb): the environment is read only in a build made with `make MB=1`
+// (-DPCM_MB_SWITCHES); the shipped library never reads the environment and always takes the measured default.
+static inline int pcm_mb_switch(const char *name, int dflt)
+{
+#ifdef PCM_MB_SWITCHES
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
+}
 
 // ---- cross-lane primitives ------------------------------------------------------------------
 // DPP controls (cdna4 ISA): quad_perm[a,b,c,d] = a|b<<2|c<<4|d<<6, row_half_mirror 0x141,

@@ -51,15 +51,15 @@ def ball_query_raw(nsample, max_radius, min_radius, xyz, offset, new_xyz=None, n
         idx = torch.empty(m, nsample, dtype=torch.int32, device=xyz.device)
         dist2 = torch.empty(m, nsample, dtype=torch.float32, device=xyz.device)
         o32, no32 = C.i32c(offset), C.i32c(new_offset)
-        # two kernels and a workspace from 2048 queries on (candidate collection at full occupancy, then the heap replay:
-        # csrc/ball.hip); the single-kernel path below that
+        # two kernels and a workspace where pcm_ball_query_ws_bytes(m) > 0 (from 8192 queries on: candidate collection at full
+        # occupancy, then the heap replay, csrc/ball.hip); the single-kernel path below that
         nbytes = int(L.pcm_ball_query_ws_bytes(m))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=xyz.device) if nbytes else None
         rc = L.pcm_ball_query_ws_hip(
             int(no32.shape[0]), m, nsample, float(min_radius), float(max_radius), C.ptr(xyz), C.ptr(new_xyz), C.ptr(o32), C.ptr(no32),
             C.ptr(idx), C.ptr(dist2), ws.data_ptr() if ws is not None else 0, nbytes, C.stream(),
         )
-    C._lib.check(rc, "pcm_ball_query_b_hip")
+    C._lib.check(rc, "pcm_ball_query_ws_hip")
     return idx, dist2
 
 

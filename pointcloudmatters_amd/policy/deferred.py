@@ -47,13 +47,15 @@ def begin():
     return False
 
 
-def end():
+def end(failed=False):
+    """Close the window.  `failed=True` (the caller's body raised, or its generator was closed early): the queues are half-built,
+    drop them without a closing flush so that the original exception is not masked.  The caller says so explicitly -- the ambient
+    `sys.exc_info()` is also set when a healthy step runs inside someone else's `except` block (an out-of-memory retry loop)."""
     global _Q, _W
-    import sys
 
     try:
-        if sys.exc_info()[0] is None:  # called from a `finally` while an exception propagates: do not mask it with a flush of
-            flush()                    # half-built queues
+        if not failed:
+            flush()
     finally:
         _Q = None
         _W = {}

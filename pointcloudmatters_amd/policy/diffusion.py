@@ -25,6 +25,7 @@ from .rows_linear import linear_rows
 from .sa_layer import set_abstraction
 from .unet_ops import conv1d_cl, conv_transpose1d_cl, gn_mish_cl
 from .._lib import raw_stream as _raw_stream
+from .rows_linear import RowsLinear
 
 
 # ----------------------------------------------------------------------------- U-Net pieces
@@ -123,7 +124,7 @@ class ConditionalResidualBlock1D(nn.Module):
         self.cond_predict_scale = cond_predict_scale
         self.out_channels = out_channels
         film = out_channels * 2 if cond_predict_scale else out_channels
-        self.cond_encoder = nn.Sequential(nn.Mish(), nn.Linear(cond_dim, film), _AddTrailingDim())
+        self.cond_encoder = nn.Sequential(nn.Mish(), RowsLinear(cond_dim, film), _AddTrailingDim())
         self.residual_conv = nn.Conv1d(in_channels, out_channels, 1) if in_channels != out_channels else nn.Identity()
 
     def forward_cl(self, x, mish_cond):
@@ -147,7 +148,7 @@ class ConditionalUnet1D(nn.Module):
         dims = [input_dim] + list(down_dims)
         dsed = diffusion_step_embed_dim
         self.diffusion_step_encoder = nn.Sequential(
-            SinusoidalPosEmb(dsed), nn.Linear(dsed, dsed * 4), nn.Mish(), nn.Linear(dsed * 4, dsed))
+            SinusoidalPosEmb(dsed), RowsLinear(dsed, dsed * 4), nn.Mish(), RowsLinear(dsed * 4, dsed))
         cond_dim = dsed + (global_cond_dim or 0)
         kw = dict(cond_dim=cond_dim, kernel_size=kernel_size, n_groups=n_groups, cond_predict_scale=cond_predict_scale)
         pairs = list(zip(dims[:-1], dims[1:]))

@@ -12,6 +12,7 @@ CUDA library absent from the reference tree: parity of this restatement is unpin
 import torch.nn as nn
 
 from .rows_linear import linear_rows
+from .rows_linear import RowsLinear
 
 
 def _block(cin, cout):
@@ -29,7 +30,7 @@ class PointNet(nn.Module):
         self.conv4 = _block(64, 128)
         self.conv5 = _block(128, 512)
         # pointnet.py:57-61: a biased 512 -> num_classes projection without BN/ReLU, or identity
-        self.final = nn.Linear(512, num_classes, bias=True) if num_classes > 0 else nn.Identity()
+        self.final = RowsLinear(512, num_classes, bias=True) if num_classes > 0 else nn.Identity()
         self.num_channels = num_classes if num_classes > 0 else 512
 
     def forward(self, input_dict):

@@ -27,6 +27,7 @@ import torch.nn as nn
 from .pointnet import PointNet
 from .rows_linear import linear_rows
 from .sa_layer import coord_embedding_sine, set_abstraction
+from .rows_linear import RowsLinear
 
 
 def _query_offsets(owner, o, npoints):
@@ -249,7 +250,7 @@ class PatchBertObsEncoder(nn.Module):
         self.tokenizer = PatchTokenizer(in_channels, num_groups, group_size, hidden_dim, pointops=pointops, sa_impl=sa_impl)
         self.encoder = TransformerEncoder(d_model=hidden_dim, nhead=nhead, dim_feedforward=4 * hidden_dim, dropout=0.0,
                                           num_layers=depth)
-        self.proj = nn.Linear(2 * hidden_dim, out_channels)
+        self.proj = RowsLinear(2 * hidden_dim, out_channels)
         self.n_obs_step, self._out_channels = n_obs_step, out_channels
         self.overlap_sampling = False
 

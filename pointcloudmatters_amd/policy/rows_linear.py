@@ -270,3 +270,12 @@ def linear_rows(x, weight, bias=None):
         if not safe:
             return F.linear(x, weight, bias)
     return _LinearRows.apply(x, weight, bias)
+
+
+class RowsLinear(torch.nn.Linear):
+    """nn.Linear whose forward goes through ``linear_rows``: identical results and state-dict keys; in training on the GPU under bf16
+    autocast the backward forms the bias gradient with the library's column sums (``bias_grad``) instead of the framework's bf16
+    reduction kernel -- one of the kernels that miscompute beside another stream's MFMA work on this stack."""
+
+    def forward(self, x):
+        return linear_rows(x, self.weight, self.bias)

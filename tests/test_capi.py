@@ -113,6 +113,21 @@ def _call_with_sizes(fn, decls, size):
     return fn(*args)
 
 
+def test_runtime_version_and_memset_entry_points_need_no_gpu():
+    """pcm_hip_runtime_version / pcm_memset_async (csrc/graph_fix.hip): what _graphs.memset_fix_needed decides on.  The version is the
+    runtime the LIBRARY is bound to -- in a process that imported torch first, the copy torch ships -- and anything up to 7.2.x keeps
+    the captured-memset rewrite on without a probe."""
+    from pointcloudmatters_amd import _graphs, _lib
+
+    L = _lib.load()
+    v = _graphs.runtime_version()
+    assert 6 * 10000000 <= v < 99 * 10000000
+    assert L.pcm_hip_runtime_version(None) == 1
+    assert L.pcm_memset_async(None, 0, -1, 0, None) == 1 and L.pcm_memset_async(None, 0, 0, 1, None) == 0
+    assert L.pcm_memset_async(None, 0, 4, 0, None) == 1  # missing destination
+    assert _graphs.KNOWN_BAD_UP_TO == 70299999
+
+
 def test_every_entry_point_rejects_negative_sizes_and_takes_empty_calls_without_the_runtime():
     """The status contract of include/pcm_pointops.h over EVERY launcher it declares (the reference's launchers return void and
     run into undefined behaviour on such arguments): negative sizes are PCM_ERR_BAD_ARG / PCM_ERR_UNSUPPORTED, never PCM_OK; an

@@ -129,7 +129,7 @@ def test_diffusion_policy_training_steps_are_bit_reproducible(mode, hip_device):
     def run():
         torch.manual_seed(0)
         pol = build_dp_policy(pcd_npoints=32, sa_impl="fused", **DP_SMALL).to(hip_device)
-        tr = BCTrainer(pol, total_steps=20, precision="fp32", device=hip_device, mode=mode, optim=dict(DP_OPTIM, lr=1e-4, betas=DP_OPTIM["yaml_betas"]))
+        tr = BCTrainer(pol, total_steps=20, precision="fp32", device=hip_device, mode=mode, optim=dict(DP_OPTIM, lr=1e-4))
         out = []
         for i in range(3):
             b = clone_batch(batches[i % 2])

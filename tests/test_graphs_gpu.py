@@ -93,6 +93,13 @@ def test_memset_fix_self_test_is_decided_once_and_overridable(hip_device, monkey
     first = _graphs.memset_fix_needed()
     assert isinstance(first, bool) and _graphs._NEEDS_FIX[torch.cuda.current_device()] == first
     assert _graphs.memset_fix_needed() == first  # cached
+    version = _graphs.runtime_version()
+    assert version >= 6 * 10000000
+    if version <= _graphs.KNOWN_BAD_UP_TO:  # the runtimes the defect was found on: no probe can switch the rewrite off
+        assert first is True
+    observed = _graphs.memset_self_test(hip_device)  # memsets through the library's own runtime binding (pcm_memset_async)
+    assert isinstance(observed, bool)
+    print(f"captured-memset self-test on HIP runtime {version}: {'replays wrongly' if observed else 'replays correctly'}")
     monkeypatch.setenv("PCM_GRAPH_MEMSET_FIX", "0")
     assert _graphs.memset_fix_needed() is False
     monkeypatch.setenv("PCM_GRAPH_MEMSET_FIX", "1")

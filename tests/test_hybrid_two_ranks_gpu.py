@@ -74,7 +74,7 @@ def _build(kind):
     if kind == "dp":
         from tests.golden.make_golden import DP_SMALL
 
-        return build_dp_policy(pcd_npoints=32, sa_impl="fused", **DP_SMALL), dict(DP_OPTIM, lr=1e-3, betas=DP_OPTIM["yaml_betas"])
+        return build_dp_policy(pcd_npoints=32, sa_impl="fused", **DP_SMALL), dict(DP_OPTIM, lr=1e-3)
     return build_act_policy(pcd_npoints=64, sa_impl="fused", **SMALL), dict(accumulate_grad_batches=1, lr=1e-3)
 
 

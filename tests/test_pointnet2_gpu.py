@@ -206,7 +206,7 @@ def test_hierarchical_workloads_train(workload):
     if wl["policy"] == "dp":
         # the workload's own shapes (16 samples x 2 clouds x 4096 points -> 128 patches); only the U-Net is narrowed
         pol = build_dp_policy(pcd_npoints=wl["pcd_npoints"], sa_impl="fused", obs_encoder=wl["obs_encoder"], down_dims=(64, 128, 256)).to(DEV)
-        tr = BCTrainer(pol, total_steps=100, precision="bf16", device=DEV, mode="graph", optim=dict(DP_OPTIM, lr=1e-3, betas=DP_OPTIM["yaml_betas"]))
+        tr = BCTrainer(pol, total_steps=100, precision="bf16", device=DEV, mode="graph", optim=dict(DP_OPTIM, lr=1e-3))
         batch = make_dp_batch(wl["batch"], wl["n_points"], seed=2, device=DEV)
     else:
         # the workload's own shapes (8 clouds x 2048 points -> 1024 tokens); the transformer depth is cut to keep the test short

@@ -151,7 +151,7 @@ def test_dp_training_step(hip_device, mode):
 
     torch.manual_seed(0)
     pol = build_dp_policy(pcd_npoints=64, sa_impl="torch", down_dims=(64, 128, 256)).to(hip_device)
-    tr = BCTrainer(pol, total_steps=100, precision="bf16", device=hip_device, optim=dict(DP_OPTIM, lr=1e-3, betas=DP_OPTIM["yaml_betas"]), mode=mode)
+    tr = BCTrainer(pol, total_steps=100, precision="bf16", device=hip_device, optim=dict(DP_OPTIM, lr=1e-3), mode=mode)
     batch = make_dp_batch(8, 256, seed=2, device=hip_device)
     first = None
     for i in range(25):
@@ -338,7 +338,7 @@ def test_hybrid_mode_matches_flat_mode_for_the_diffusion_policy(hip_device):
     for mode in ("flat", "hybrid"):
         torch.manual_seed(0)
         pol = build_dp_policy(pcd_npoints=32, sa_impl="fused", **DP_SMALL).to(hip_device)
-        tr = BCTrainer(pol, total_steps=20, precision="fp32", device=hip_device, mode=mode, optim=dict(DP_OPTIM, lr=1e-5, betas=DP_OPTIM["yaml_betas"]))
+        tr = BCTrainer(pol, total_steps=20, precision="fp32", device=hip_device, mode=mode, optim=dict(DP_OPTIM, lr=1e-5))
         losses, grads = [], []
         for i in range(4):
             b = clone_batch(batches[i % 3])
@@ -551,7 +551,7 @@ def test_dp_hybrid_bf16_full_batch_stays_finite(hip_device):
     wl = WORKLOADS["C3R"]
     torch.manual_seed(1000)
     pol = build_dp_policy(pcd_npoints=wl["pcd_npoints"], sa_impl="fused", down_dims=(128, 256, 512)).to(hip_device)
-    tr = BCTrainer(pol, total_steps=100, precision="bf16", device=hip_device, mode="hybrid", optim=dict(DP_OPTIM, betas=DP_OPTIM["yaml_betas"]))
+    tr = BCTrainer(pol, total_steps=100, precision="bf16", device=hip_device, mode="hybrid", optim=dict(DP_OPTIM))
     batches = [make_dp_batch(wl["batch"], wl["n_points"], seed=1000 + 97 * i, ragged=True, device=hip_device) for i in range(4)]
     for i in range(24):
         out = tr.training_step(clone_batch(batches[i % 4]))
@@ -616,7 +616,7 @@ def test_backward_stages_for_the_diffusion_policy(hip_device):
     for mode, staged in (("flat", False), ("flat", True), ("hybrid", True)):
         torch.manual_seed(0)
         pol = build_dp_policy(pcd_npoints=32, sa_impl="fused", **DP_SMALL).to(hip_device)
-        tr = BCTrainer(pol, total_steps=20, precision="fp32", device=hip_device, mode=mode, staged=staged, optim=dict(DP_OPTIM, lr=1e-6, betas=DP_OPTIM["yaml_betas"]))
+        tr = BCTrainer(pol, total_steps=20, precision="fp32", device=hip_device, mode=mode, staged=staged, optim=dict(DP_OPTIM, lr=1e-6))
         assert len(tr._stages) == (4 if staged else 1)
         losses, grads = [], []
         for i in range(4):
@@ -656,7 +656,7 @@ def test_graph_mode_with_sampling_outside_the_graph_matches_sampling_inside(kind
         g = torch.Generator().manual_seed(3)
         extra = {"noise": torch.randn(3, 16, 7, generator=g).to(hip_device), "timesteps": torch.tensor([3, 57, 99], device=hip_device)}
         build = lambda: build_dp_policy(pcd_npoints=32, sa_impl="fused", **DP_SMALL)
-        optim = dict(DP_OPTIM, lr=1e-5, betas=DP_OPTIM["yaml_betas"])
+        optim = dict(DP_OPTIM, lr=1e-5)
     runs = {}
     for external, use_prefetch in ((False, False), (True, False), (True, True)):
         torch.manual_seed(0)

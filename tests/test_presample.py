@@ -191,7 +191,7 @@ def test_presample_yaml_shapes_build_and_train(hip_device, policy, cin):
 
     def run(sa_impl, mode):
         pol = build(sa_impl)
-        optim = dict(accumulate_grad_batches=1) if policy == "act" else dict(DP_OPTIM, betas=DP_OPTIM["yaml_betas"])  # (trajectory tolerances below were set on hardware with these)
+        optim = dict(accumulate_grad_batches=1) if policy == "act" else dict(DP_OPTIM)  # (trajectory tolerances below were set on hardware with these)
         tr = BCTrainer(pol, total_steps=50, precision="fp32", device=hip_device, mode=mode, optim=optim)
         return [float(tr.training_step(clone_batch(batch(i)))["loss"]) for i in range(3)]
 

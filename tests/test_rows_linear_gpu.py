@@ -139,3 +139,33 @@ def test_pending_results_reach_leaf_parameters_intact():
     gw, gb = lin.weight.grad.clone(), lin.bias.grad.clone()
     torch.testing.assert_close(gb.double(), go.double().sum(0), rtol=1e-5, atol=1e-3)
     torch.testing.assert_close(gw.double(), go.double().t() @ x.double(), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("rows,cin,cout", [(8, 256, 1024), (8, 1024, 256), (64, 512, 7), (1, 128, 128)])
+def test_rows_linear_module_matches_nn_linear(rows, cin, cout):
+    """RowsLinear == nn.Linear: same state-dict keys, same fp32 results / gradients; under bf16 autocast the backward node is the
+    library's (its bias gradient comes from the column-sum kernel of csrc/tokens.hip, not the framework's bf16 reduction)."""
+    from pointcloudmatters_amd.policy.rows_linear import RowsLinear
+
+    torch.manual_seed(rows + cout)
+    ours, ref = RowsLinear(cin, cout).to(DEV), nn.Linear(cin, cout).to(DEV)
+    assert list(ours.state_dict()) == list(ref.state_dict())
+    ref.load_state_dict(ours.state_dict())
+    x = torch.randn(rows, cin, device=DEV, requires_grad=True)
+    x2 = x.detach().clone().requires_grad_(True)
+    g = torch.randn(rows, cout, device=DEV)
+    ours(x).backward(g)
+    ref(x2).backward(g)
+    torch.testing.assert_close(ours(x), ref(x2), rtol=1e-5, atol=1e-5)
+    for a, r in ((x.grad, x2.grad), (ours.weight.grad, ref.weight.grad), (ours.bias.grad, ref.bias.grad)):
+        assert (a - r).norm().item() <= 1e-5 * r.norm().item() + 1e-6
+    ours.zero_grad(); ref.zero_grad()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = ours(x.detach())
+        want = ref(x.detach())
+    assert type(y.grad_fn).__name__ == "_LinearRowsBackward"
+    y.backward(g.bfloat16())
+    want.backward(g.bfloat16())
+    exact = g.bfloat16().float().sum(0)
+    assert (ours.bias.grad - exact).norm() <= 1.05 * (ref.bias.grad - exact).norm() + 2e-2 * exact.norm()
+    assert (ours.weight.grad - ref.weight.grad).norm() <= 2e-2 * ref.weight.grad.norm() + 1e-6

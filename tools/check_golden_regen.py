@@ -19,9 +19,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
-def compare(old_dir, new_dir):
+def compare(old_dir, new_dir, names=None):
     bad, worst, n_arrays, n_equal = [], 0.0, 0, 0
     for fn in sorted(f for f in os.listdir(old_dir) if f.endswith(".npz")):
+        if names is not None and fn not in names:
+            continue
         a, b = np.load(os.path.join(old_dir, fn), allow_pickle=False), np.load(os.path.join(new_dir, fn), allow_pickle=False)
         if set(a.files) != set(b.files):
             bad.append((fn, "keys differ", sorted(set(a.files) ^ set(b.files))[:5]))
@@ -47,12 +49,20 @@ def main():
     assert os.path.isdir("/root/reference"), "build container only (needs /root/reference)"
     tmp = tempfile.mkdtemp(prefix="pcm_golden_")
     try:
-        for f in os.listdir(GOLD):
-            if f.endswith(".npz"):  # later generators read earlier fixtures (inputs shared between them)
-                shutil.copy(os.path.join(GOLD, f), tmp)
+        committed = sorted(f for f in os.listdir(GOLD) if f.endswith(".npz"))
+        for f in committed:  # later generators read earlier fixtures (inputs shared between them) ...
+            shutil.copy(os.path.join(GOLD, f), tmp)
+            os.utime(os.path.join(tmp, f), (0, 0))  # ... but a copy the run did NOT rewrite must not be compared with itself
         env = dict(os.environ, PCM_GOLDEN_OUT=tmp)
         subprocess.check_call([sys.executable, os.path.join(GOLD, "make_golden.py")] + sys.argv[1:], env=env)
-        bad, worst, n, eq = compare(GOLD, tmp)
+        rewritten = {f for f in committed if os.stat(os.path.join(tmp, f)).st_mtime > 1}
+        stale = [f for f in committed if f not in rewritten]
+        bad, worst, n, eq = compare(GOLD, tmp, rewritten)
+        if not sys.argv[1:]:  # a full run must reproduce EVERY committed fixture (a generator that raised early, a conditional write)
+            bad += [(f, "not rewritten by the regeneration run") for f in stale]
+        elif not rewritten:
+            bad.append(("no fixture was rewritten", sys.argv[1:]))
+        print(f"{len(rewritten)} of {len(committed)} fixtures regenerated" + (f" (not selected: {', '.join(stale)})" if stale else ""))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     print(f"{n} arrays: {eq} bit-equal, largest relative difference among the others {worst:.3g}; {len(bad)} beyond 2e-5")

@@ -1,4 +1,6 @@
-"""FPS device time per call at the bench shapes (torch.profiler).  PCM_FPS_SMALL_T=64|128 python tools/mb/mb_fps.py"""
+"""FPS device time per call at the bench shapes (torch.profiler).  PCM_FPS_SMALL_T=64|128 python tools/mb/mb_fps.py
+(the switches exist only in the microbenchmark build: `make -C pointcloudmatters_amd/csrc mb`, then
+PCM_POINTOPS_LIB=$PWD/pointcloudmatters_amd/lib_mb/libpcm_pointops.so)"""
 import os
 import sys
 

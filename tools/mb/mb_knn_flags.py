@@ -1,5 +1,7 @@
 """How many queries the fast kNN kernel hands to the exact kernel (ties among the nsample+1 smallest, buffer overflow):
-PCM_KNN_SKIP_EXACT=1 python tools/mb/mb_knn_flags.py"""
+PCM_KNN_SKIP_EXACT=1 python tools/mb/mb_knn_flags.py
+(the switches exist only in the microbenchmark build: `make -C pointcloudmatters_amd/csrc mb`, then
+PCM_POINTOPS_LIB=$PWD/pointcloudmatters_amd/lib_mb/libpcm_pointops.so)"""
 import os
 import sys
 
