@@ -37,6 +37,7 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak, same guide
+TOKENIZER_BF16 = False      # --tokenizer-bf16: the tokenizer under autocast too (the recipe up to round 4; policy/precision.py says why not)
 CLOCK_MHZ = 2400.0          # peak engine clock: converts FPS pick latency to clocks
 
 # shapes whose gather / scatter operands exceed L2 (and mostly the 256 MiB Infinity Cache lines they touch per launch)
@@ -61,6 +62,8 @@ def parse():
     ap.add_argument("--sampling-in-graph", action="store_true",
                     help="graph mode: capture FPS / kNN inside the graph (round-1 behaviour) instead of running them one batch ahead")
     ap.add_argument("--no-prefetch", action="store_true", help="do not hand the next batch to the trainer early (hybrid / flat / eager modes)")
+    ap.add_argument("--tokenizer-bf16", action="store_true",
+                    help="run the tokenizer (PointNet + SA layer + projector) under bf16 autocast as well; default: fp32 (policy/precision.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel legs (kernels, kernels_hbm, step_trace, roofline)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra lines (fp32 GPU run, REF shape)")
@@ -153,16 +156,18 @@ def pointops_and_sa_kernels(t, shape, device):
     t.add("pcm_knn_twopass_kernel(+exact)", ms, 12 * n_tot + 12 * m + 8 * m * k, "alu",
           "%.1f M distance evaluations; sampling side stream" % (evals / 1e6), extra={"dist_evals_per_s": round(evals / ms * 1e3, 1)})
 
-    # ---- fused set-abstraction layer, one kernel at a time (bf16 Gf as under autocast) ----------------
+    # ---- fused set-abstraction layer, one kernel at a time, in the dtype the step's tokenizer computes in: fp32 by default
+    # (policy/precision.py keeps the tokenizer out of the bf16 autocast region), bf16 with --tokenizer-bf16 ----------------
     st = torch.cuda.current_stream().cuda_stream
     f32 = dict(dtype=torch.float32, device=device)
-    gf = torch.randn(n_tot, H, **f32).to(torch.bfloat16)
+    tok_bf, tok_es, tok_name = (1, 2, "bf16") if TOKENIZER_BF16 else (0, 4, "float")
+    gf = torch.randn(n_tot, H, **f32).to(torch.bfloat16 if tok_bf else torch.float32)
     wp, gamma, beta = torch.randn(H, 3, **f32) * 0.1, torch.rand(H, **f32) + 0.5, torch.zeros(H, **f32)
     gamma[::3] *= -1.0  # a third of the channels take the min branch
     rm, rv = torch.zeros(H, **f32), torch.ones(H, **f32)
     sel = torch.empty(m, H, **f32)
     asel = torch.empty(m, H, dtype=torch.uint8, device=device)
-    slots = max(L.pcm_sa_fused_slots(m, H, 1, k), L.pcm_sa_fused_slots(m, H, 0, 1), L.pcm_sa_fused_slots(n_tot, H, 1, 1), b,
+    slots = max(L.pcm_sa_fused_slots(m, H, tok_bf, k), L.pcm_sa_fused_slots(m, H, 0, 1), L.pcm_sa_fused_slots(n_tot, H, tok_bf, 1), b,
                 L.pcm_sa_bwd1_det_slots(m)) + L.pcm_sa_fused_reduce_scratch_rows()
     partial = torch.empty(slots * 5 * H, **f32)
     sums, stat, z = torch.empty(2, H, **f32), torch.empty(4, H, **f32), torch.empty(m, H, **f32)
@@ -177,7 +182,7 @@ def pointops_and_sa_kernels(t, shape, device):
     o32 = off.to(torch.int32)
 
     def fwd(mask):
-        rc = L.pcm_sa_fused_forward_hip(m, k, H, 1, gf.data_ptr(), ent.data_ptr(),
+        rc = L.pcm_sa_fused_forward_hip(m, k, H, tok_bf, gf.data_ptr(), ent.data_ptr(),
                                         wp.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.1, rm.data_ptr(), rv.data_ptr(),
                                         sel.data_ptr(), asel.data_ptr(), partial.data_ptr(),
                                         sums.data_ptr(), stat.data_ptr(), z.data_ptr(), mask, st)
@@ -194,7 +199,7 @@ def pointops_and_sa_kernels(t, shape, device):
     def bwd(mask):
         if not lds_ch and (mask & 2):
             D.zero_()
-        rc = L.pcm_sa_fused_backward_hip(m, n_tot, k, H, 1, gf.data_ptr(), ent.data_ptr(),
+        rc = L.pcm_sa_fused_backward_hip(m, n_tot, k, H, tok_bf, gf.data_ptr(), ent.data_ptr(),
                                          wp.data_ptr(), stat.data_ptr(), dz.data_ptr(), sel.data_ptr(), asel.data_ptr(),
                                          D.data_ptr(), cnt.data_ptr(), S.data_ptr(), RM.data_ptr(),
                                          partial.data_ptr(), red1.data_ptr(), red2.data_ptr(), dgf.data_ptr(), dwp.data_ptr(),
@@ -206,7 +211,7 @@ def pointops_and_sa_kernels(t, shape, device):
     fwd(0)
     bwd(0)
     rows = m * k
-    t.add("pcm_sa_fwd_kernel<bf16>", timed_events(lambda: fwd(1), 30), n_tot * H * 2 + 16 * rows + m * H * 5, "hbm",
+    t.add("pcm_sa_fwd_kernel<%s>" % tok_name, timed_events(lambda: fwd(1), 30), n_tot * H * tok_es + 16 * rows + m * H * 5, "hbm",
           "gather of %d rows x %d ch (every Gf row counted once; VALU-bound: ~9 fp32 ops per gathered element); writes the "
           "selected extremum (4 B) + its slot (1 B) per (query, channel)" % (rows, H))
     t.add("pcm_sa_apply_kernel", timed_events(lambda: fwd(8), 30), m * H * 8, "hbm", "z = relu(a*sel + b): 4 B read, 4 B written")
@@ -240,7 +245,7 @@ def pointops_and_sa_kernels(t, shape, device):
               "per point: runs of (channel, delta) added in list order into an LDS row; D written once")
         index()  # back to the atomic kernels' statistics for the rows below
         bwd(0)
-    t.add("pcm_sa_bwd2_kernel<bf16>", timed_events(lambda: bwd(8), 30), n_tot * H * (2 + 4 + 2) + 16 * n_tot, "hbm", "dense n*H pass")
+    t.add("pcm_sa_bwd2_kernel<%s>" % tok_name, timed_events(lambda: bwd(8), 30), n_tot * H * (tok_es + 4 + tok_es) + 16 * n_tot, "hbm", "dense n*H pass")
     t.add("pcm_sa_reduce_kernel", timed_events(lambda: bwd(4), 30), slots * 5 * H * 4, "hbm", "fp64 reduction of per-block partial rows")
 
     # ---- API kernels that materialise the grouped tensor (pointops.grouping; not on the fused path) ----
@@ -418,27 +423,28 @@ def policy_kernels(t, wl, device, hidden=512):
     t.add("pcm_attn_flash_bwd_dkv_kernel", timed_events(lambda: fl_b(2), 20), None, "mfma", note + "; S, dP, dV, dK: 4 GEMMs", flops=4 * unit)
     t.add("pcm_attn_flash_bwd_dq_kernel", timed_events(lambda: fl_b(4), 20), None, "mfma", note + "; S, dP, dQ: 3 GEMMs", flops=3 * unit)
 
-    # ---- PointNet layer tail: BatchNorm1d + ReLU over the packed point features (widest layer: n x 512, bf16) ----
+    # ---- PointNet layer tail: BatchNorm1d + ReLU over the packed point features (widest layer: n x 512, tokenizer dtype) ----
     Cb = 512
-    yb = torch.randn(n_tot, Cb, **f32).to(torch.bfloat16)
-    zb, dzb, dyb = torch.empty_like(yb), torch.randn(n_tot, Cb, **f32).to(torch.bfloat16), torch.empty_like(yb)
+    tok_dt = torch.bfloat16 if tok_bf else torch.float32
+    yb = torch.randn(n_tot, Cb, **f32).to(tok_dt)
+    zb, dzb, dyb = torch.empty_like(yb), torch.randn(n_tot, Cb, **f32).to(tok_dt), torch.empty_like(yb)
     gb, bb = torch.rand(Cb, **f32) + 0.5, torch.zeros(Cb, **f32)
     rmb, rvb = torch.zeros(Cb, **f32), torch.ones(Cb, **f32)
     pb = torch.empty(L.pcm_bn_relu_slots(n_tot, Cb) * 2 * Cb, **f32)
     sb, stb = torch.empty(2, Cb, **f32), torch.empty(4, Cb, **f32)
 
     def bn_f():
-        assert L.pcm_bn_relu_forward_hip(n_tot, Cb, 1, yb.data_ptr(), gb.data_ptr(), bb.data_ptr(), 1e-3, 0.01, rmb.data_ptr(),
+        assert L.pcm_bn_relu_forward_hip(n_tot, Cb, tok_bf, yb.data_ptr(), gb.data_ptr(), bb.data_ptr(), 1e-3, 0.01, rmb.data_ptr(),
                                          rvb.data_ptr(), 0, pb.data_ptr(), sb.data_ptr(), stb.data_ptr(), zb.data_ptr(), st) == 0
 
     def bn_b():
-        assert L.pcm_bn_relu_backward_hip(n_tot, Cb, 1, yb.data_ptr(), dzb.data_ptr(), stb.data_ptr(), pb.data_ptr(), sb.data_ptr(),
+        assert L.pcm_bn_relu_backward_hip(n_tot, Cb, tok_bf, yb.data_ptr(), dzb.data_ptr(), stb.data_ptr(), pb.data_ptr(), sb.data_ptr(),
                                           dyb.data_ptr(), 0, 0.0, st) == 0
 
     bn_f()
-    t.add("pcm_bn_relu forward (colsum+reduce+stats+apply)", timed_events(bn_f, 30), n_tot * Cb * 6, "hbm",
-          "BatchNorm1d(batch stats)+ReLU on (n, 512) bf16: y read twice, z written once")
-    t.add("pcm_bn_relu backward (colsum+reduce+apply)", timed_events(bn_b, 30), n_tot * Cb * 10, "hbm",
+    t.add("pcm_bn_relu forward (colsum+reduce+stats+apply)", timed_events(bn_f, 30), n_tot * Cb * 3 * tok_es, "hbm",
+          "BatchNorm1d(batch stats)+ReLU on (n, 512) %s: y read twice, z written once" % tok_name)
+    t.add("pcm_bn_relu backward (colsum+reduce+apply)", timed_events(bn_b, 30), n_tot * Cb * 5 * tok_es, "hbm",
           "y and dz read twice, dy written once")
 
     # ---- Diffusion-Policy U-Net blocks, channels-last (C3 shape: 64 samples x 16 steps x 1024 channels) ----------
@@ -785,6 +791,10 @@ def run_workload(name, args, device, world, rank, steps, warmup, precision=None,
         if opt_key in wl:
             extra[opt_key] = wl[opt_key]
     policy = build(pcd_npoints=wl["pcd_npoints"], sa_impl=sa_impl, **extra).to(device)
+    if TOKENIZER_BF16:
+        from pointcloudmatters_amd.policy.precision import set_tokenizer_fp32
+
+        set_tokenizer_fp32(policy, False)
     if mode == "auto":
         # ragged clouds: the tokenizer runs eagerly, everything behind the fixed-size token matrix replays as hipGraphs.
         # Data parallel runs take the same mode: every BatchNorm lives in the eager tokenizer, so its statistics are
@@ -886,6 +896,8 @@ def main():
     args = parse()
     from pointcloudmatters_amd.bc import WORKLOADS
 
+    global TOKENIZER_BF16
+    TOKENIZER_BF16 = bool(args.tokenizer_bf16)
     if args.cpu_baseline_child:
         cpu_baseline_child(args.workload, args.cpu_steps, args.cpu_baseline_child, budget_s=14.0)
         return
@@ -963,7 +975,10 @@ def main():
                        "batchnorm": "sync" if trainer.sync_batchnorm else "per-rank",
                        "gradient_exchange": getattr(trainer, "exchange_description", "one all-reduce after backward") if world > 1 else "single GPU",
                        "accumulate_grad_batches": trainer.accumulate, "optimizer_step_every_step": trainer.accumulate == 1,
-                       "dead_decoder_layers": "n/a" if is_dp else args.dead_decoder_layers},
+                       "dead_decoder_layers": "n/a" if is_dp else args.dead_decoder_layers,
+                       "precision_recipe": "fp32" if wl["dtype"] != "bf16" else (
+                           "bf16 autocast everywhere but pointops" if TOKENIZER_BF16
+                           else "bf16 autocast: transformer / U-Net GEMMs + attention; tokenizer + pointops fp32")},
             "final_loss": round(metrics.get("train/loss", float("nan")), 4),
         }
         if not is_dp and wl["policy"] == "act":

@@ -48,7 +48,9 @@ def bf16_consumed_parameters(policy, fused_ffn=False):
     from .. import _lib
     from ..policy.transformer import TransformerDecoderLayer, TransformerEncoderLayer
 
-    ids, skip = set(), set()
+    from ..policy.precision import fp32_tokenizer_parameter_ids
+
+    ids, skip = set(), fp32_tokenizer_parameter_ids(policy)  # the tokenizer's weights are consumed in fp32 (policy/precision.py)
     if fused_ffn:  # the fused feed-forward kernel (csrc/ffn.hip) consumes the fp32 masters directly
         for mod in policy.modules():
             if isinstance(mod, (TransformerEncoderLayer, TransformerDecoderLayer)) and mod.activation is torch.nn.functional.relu \

@@ -251,7 +251,19 @@ class ACTPCD(nn.Module):
     def load_static_sampling(self, pre):
         set_abstraction.load_static(self, pre)
 
+    tokenizer_fp32 = True  # policy/precision.py: the tokenizer stays in fp32 under bf16 autocast
+
+    def tokenizer_modules(self):
+        """Modules whose parameters the tokenizer consumes (no bf16 mirror for them while `tokenizer_fp32`)."""
+        return [self.backbone, self.linear, self.bn]
+
     def forward_pcd_embed(self, pcd_dict):
+        from .precision import tokenizer_autocast
+
+        with tokenizer_autocast(self, pcd_dict["coord"]):
+            return self._forward_pcd_embed(pcd_dict)
+
+    def _forward_pcd_embed(self, pcd_dict):
         coord, offset = pcd_dict["coord"], pcd_dict["offset"]
         n_o = self._new_offsets(offset)
         # indices first (coordinates only), overlapped with the backbone when on the GPU

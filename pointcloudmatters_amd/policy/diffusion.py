@@ -557,7 +557,18 @@ class PCDObsEncoder(_AttrMixin):
         features = pcd_model(pcd_dict)
         return set_abstraction(self, self.pointops, coord, features, offset, n_o, impl=self.sa_impl, pre=pre)[1]
 
+    tokenizer_fp32 = True  # policy/precision.py: PointNet + SA layer + projector stay in fp32 under bf16 autocast
+
+    def tokenizer_modules(self):
+        return [self]  # everything this encoder owns (point-cloud models, SA linear / bn, projector)
+
     def encode_pcd(self, pcd_model, pcd_dict):
+        from .precision import tokenizer_autocast
+
+        with tokenizer_autocast(self, pcd_dict["coord"] if "coord" in pcd_dict else pcd_dict["sa_tokens"]):
+            return self._encode_pcd(pcd_model, pcd_dict)
+
+    def _encode_pcd(self, pcd_model, pcd_dict):
         x = pcd_dict["sa_tokens"] if "sa_tokens" in pcd_dict else self.sa_tokens(pcd_model, pcd_dict)
         x = x.view(-1, self.pcd_npoints, x.shape[-1]).transpose(1, 2)  # "(b n) c -> b c n"
         for layer in self.projector:  # 1x1 convolutions as GEMMs (MIOpen falls back to naive bf16 kernels here)

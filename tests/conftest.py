@@ -29,7 +29,7 @@ _FILE_TIER = {
     "test_oracle": 0, "test_golden_cpu": 0, "test_capi": 0, "test_gridsample_cpu": 0, "test_rollout_cpu": 0, "test_rlbench_cpu": 0,
     "test_pointops_gpu": 0, "test_pointops_fuzz_gpu": 0, "test_pointops_misc_gpu": 0, "test_segsum_gpu": 0, "test_gridsample_gpu": 0,
     "test_rollout_gpu": 0, "test_rlbench_gpu": 0, "test_wide_fixture": 0, "test_presample": 0, "test_wrappers_ref_gpu": 0,
-    "test_wrappers_ref": 0, "test_optim_ref": 0, "test_normalizer_ref": 0, "test_trajectory_ref": 0, "test_mask_sampling": 0,
+    "test_bf16_fixture": 0, "test_wrappers_ref": 0, "test_optim_ref": 0, "test_normalizer_ref": 0, "test_trajectory_ref": 0, "test_mask_sampling": 0,
     "test_sa_fused_gpu": 1, "test_bn_relu_gpu": 1, "test_drln_gpu": 1, "test_tokens_gpu": 1, "test_small_attn_gpu": 1,
     "test_flash_attn_gpu": 1, "test_rows_linear_gpu": 1, "test_unet_ops_gpu": 1, "test_pointnet2_gpu": 1, "test_graphs_gpu": 1,
     "test_host_logic": 1, "test_concurrency_gpu": 1, "test_xfer_gpu": 1, "test_ffn_mfma_gpu": 1, "test_build_flags": 1,
@@ -37,6 +37,15 @@ _FILE_TIER = {
     "test_policy_gpu": 2, "test_sync_bn_gpu": 2, "test_hybrid_two_ranks_gpu": 2, "test_bench_multirank_gpu": 2, "test_ddp_gloo": 2,
     "test_determinism_gpu": 2,
 }
+# Tier 3: GPU tests written while the GPU pool was closed to the build (rounds 4 / 5) that have NOT yet had a green run on hardware.
+# They run LAST, so that under `pytest -x` a first-contact failure of one of them cannot hide the evidence of the tiers above;
+# an entry moves out of this table after its first green hardware run.  (module, substring of the test name; "" = whole module)
+_FIRST_CONTACT = (
+    ("test_wrappers_ref_gpu", ""),
+    ("test_bf16_fixture", "_gpu"),
+    ("test_rows_linear_gpu", "test_rows_linear_module_matches_nn_linear"),
+    ("test_graphs_gpu", "test_memset_fix_self_test_is_decided_once_and_overridable"),
+)
 _TIER0_NAMES = ("matches_reference", "matches_cpu_oracle", "vs_torch")  # fixture / oracle parity tests inside test_policy_gpu.py
 
 
@@ -45,6 +54,8 @@ def _tier(item):
     tier = _FILE_TIER.get(mod, 1)
     if mod == "test_policy_gpu" and any(s in item.name for s in _TIER0_NAMES):
         tier = 0
+    if any(mod == m and sub in item.name for m, sub in _FIRST_CONTACT):
+        tier = 3
     return tier
 
 

@@ -864,6 +864,190 @@ def golden_wide(ref):
     np.savez_compressed(os.path.join(OUT, "wide_ref.npz"), **fx)
 
 
+WIDE_BF16_B = 8  # samples of the bf16 fixture (the flip-prone layers see 8x more rows than in wide_ref.npz)
+
+
+def _fp32_island(fn):
+    """`fn` with autocast switched off inside: how the REFERENCE's tokenizer is kept in fp32 for the bf16 yardstick run (the
+    product does the same through policy/precision.py)."""
+    def inner(*a, **k):
+        with torch.autocast("cpu", enabled=False):
+            return fn(*a, **k)
+    return inner
+
+
+def _digest_errors(named_got, fx, prefix):
+    from tests.util import digest_rel_error
+
+    out = {}
+    for name, g in named_got:
+        ref = {k[len(prefix) + len(name) + 1:]: fx[k] for k in fx if k.startswith(prefix + name + "/")}
+        out[name] = digest_rel_error(name, g.numpy(), ref)
+    return out
+
+
+def golden_wide_bf16(ref):
+    """The fixture the TIMED configuration (bf16 autocast, fused kernels) is held to -- tests/test_bf16_fixture.py.
+
+    wide_ref.npz pins the fused kernels in fp32 at 1e-4; its two-sample batches cannot pin bf16: one flipped ReLU gate of the CVAE
+    encoder's CLS row owns 1/64 of a gradient matrix there (44 % measured on hardware, profiles/r04_wide_bf16_errors.log).  Here:
+      * the same reference classes at the shipped widths (WIDE / WIDE_DP), WIDE_BF16_B samples;
+      * stored: inputs, the fp32 reference outputs and a digest of EVERY fp32 gradient (the truth), and per tensor the error of
+        the reference's OWN bf16 evaluation against that truth ("yard."): torch.autocast(bf16) around the reference model with its
+        tokenizer (backbone + pcd_sampling / encode_pcd) kept in fp32 -- the precision recipe of policy/precision.py;
+      * the batch seed is searched so that this yardstick run AND a second one on inputs jittered by 1e-3 (another rounding
+        realisation) stay below 4 % on every tensor: no gate of the batch sits within a bf16 rounding of its kink, so a 10 % bound on
+        the product's bf16 path is a statement about its arithmetic and not about a coin flip.
+    Also stored: the yardstick with the tokenizer under autocast ("yard_all."), the evidence for that recipe."""
+    from oracle import pointops_cpu
+    from pointcloudmatters_amd.bc import build_dp_policy, make_act_batch, make_dp_batch
+    from pointcloudmatters_amd.policy import PointNet
+    from tests.util import seeded_fill
+
+    fx, c, B, M = {}, WIDE, WIDE_BF16_B, 128
+    eps = torch.randn(B, c["latent_dim"], generator=torch.Generator().manual_seed(26))
+    fx["act.eps"] = eps.numpy()
+
+    def act_model(fp32_tokenizer):
+        backbone = PointNet(in_channels=6, num_classes=0)
+        model = _ref_act(ref, c, M, backbone)
+        wsum = seeded_fill(model, WIDE_SEED)
+        model.train()
+        if fp32_tokenizer:
+            backbone.forward, model.pcd_sampling = _fp32_island(backbone.forward), _fp32_island(model.pcd_sampling)
+        return model, wsum
+
+    def act_grads(batch, bf16, fp32_tokenizer=True):
+        model, wsum = act_model(fp32_tokenizer)
+        with torch.autocast("cpu", dtype=torch.bfloat16, enabled=bf16):
+            out = _run_ref_act(ref, model, batch, eps)
+        return model, wsum, out, [(n, p.grad.detach().float()) for n, p in model.named_parameters() if p.grad is not None]
+
+    def jitter(batch, rel=1e-3):
+        g = torch.Generator().manual_seed(5)
+        out = {k: (dict(v) if isinstance(v, dict) else v) for k, v in batch.items()}
+        for k in ("qpos", "actions", "goal_cond"):
+            out[k] = batch[k] * (1 + rel * torch.randn(batch[k].shape, generator=g))
+        return out
+
+    best = None
+    for seed in range(2300, 2340):
+        batch = make_act_batch(B, 150, seed=seed, ragged=True, num_queries=c["num_queries"])
+        _, _, _, g32 = act_grads(batch, False)
+        tmp = {}
+        _store_grads(tmp, "t.", g32)
+        worst = 0.0
+        for b2 in (batch, jitter(batch)):
+            errs = _digest_errors(act_grads(b2, True)[3], tmp, "t.")
+            worst = max(worst, max(e for e, scale in errs.values() if scale >= 1e-6))
+        if best is None or worst < best[0]:
+            best = (worst, seed)
+        if worst < 0.04:
+            break
+    worst, seed = best
+    print(f"  act: batch seed {seed}, worst bf16 error of the reference (fp32 tokenizer, two realisations) {worst:.3f}")
+    assert worst < 0.06, worst
+    batch = make_act_batch(B, 150, seed=seed, ragged=True, num_queries=c["num_queries"])
+    model, wsum, out, g32 = act_grads(batch, False)
+    fx["act.wsum"] = np.array(wsum)
+    for k, v in batch.items():
+        if isinstance(v, dict):
+            for kk, vv in v.items():
+                fx[f"act.in.pcds.{kk}"] = vv.numpy()
+        else:
+            fx[f"act.in.{k}"] = v.numpy()
+    for k in ("a_hat", "mu", "logvar", "loss", "action_loss", "kl_loss", "src"):
+        fx[f"act.out.{k}"] = out[k].detach().numpy()
+    _store_grads(fx, "act.grad.", g32)
+    for tag, fp32_tok in (("yard", True), ("yard_all", False)):
+        _, _, out16, g16 = act_grads(batch, True, fp32_tok)
+        for name, (e, scale) in _digest_errors(g16, fx, "act.grad.").items():
+            fx[f"act.{tag}.{name}"] = np.array(e if scale >= 1e-6 else 0.0)
+        fx[f"act.{tag}_out.loss"] = out16["loss"].detach().float().numpy()
+    ya = max(float(fx[k]) for k in fx if k.startswith("act.yard."))
+    yb = max(float(fx[k]) for k in fx if k.startswith("act.yard_all."))
+    print(f"wide_bf16_ref.npz act: loss {float(out['loss'].detach()):.4f}; reference in bf16: worst tensor {ya:.3f} (fp32 tokenizer) / {yb:.3f} (all autocast)")
+
+    # ---- Diffusion Policy (our classes are pinned to the reference's at 1e-4 by wide_ref.npz / dp_pcd_small.npz; the reference
+    # encoder + U-Net are driven directly here, as in golden_wide)
+    Md = 64
+    shape_meta = {"obs": {"pcds": {"shape": [6], "type": "pcd"}, "qpos": {"shape": [9], "type": "low_dim"}}, "action": {"shape": [7]}}
+    ours = build_dp_policy(pcd_npoints=Md, pointops=pointops_cpu, sa_impl="reference", **WIDE_DP)
+    fx["dp.wsum"] = np.array(seeded_fill(ours, WIDE_SEED + 1))
+    sd = ours.state_dict()
+    mgen = ref.maskgen.LowdimMaskGenerator(action_dim=7, obs_dim=0, max_n_obs_steps=2, fix_obs_steps=True, action_visible=False)
+    noise = torch.randn(B, 16, 7, generator=torch.Generator().manual_seed(39))
+    timesteps = torch.randint(0, 100, (B,), generator=torch.Generator().manual_seed(40))
+
+    def dp_grads(dbatch, bf16, fp32_tokenizer=True):
+        enc = ref.pcd_enc.PCDObsEncoder(shape_meta=shape_meta, pcd_model=PointNet(in_channels=6, num_classes=96), share_pcd_model=True,
+                                        n_obs_step=2, pcd_nsample=16, pcd_npoints=Md, pcd_hidden_dim=96, projector_layers=1,
+                                        projector_channels=[96, 128, 128])
+        unet = ref.unet.ConditionalUnet1D(input_dim=7, local_cond_dim=None, global_cond_dim=(128 + 9) * 2, diffusion_step_embed_dim=128,
+                                          down_dims=[128, 256], kernel_size=5, n_groups=8, cond_predict_scale=True)
+        enc.load_state_dict({k[len("obs_encoder."):]: v for k, v in sd.items() if k.startswith("obs_encoder.")}, strict=True)
+        unet.load_state_dict({k[len("model."):]: v for k, v in sd.items() if k.startswith("model.")}, strict=True)
+        enc.train(), unet.train()
+        if fp32_tokenizer:
+            enc.encode_pcd = _fp32_island(enc.encode_pcd)
+        qpos, action = dbatch["obs"]["qpos"], dbatch["action"]
+        with torch.autocast("cpu", dtype=torch.bfloat16, enabled=bf16):
+            this_nobs = {"qpos": qpos[:, :2].reshape(-1, 9), "pcds": {k: v.clone() for k, v in dbatch["obs"]["pcds"].items()}}
+            global_cond = enc(this_nobs).reshape(B, -1)
+            mask = mgen((B, 16, 7))
+            acp = ours.noise_scheduler.alphas_cumprod[timesteps]  # diffusers absent: our restated schedule (parity unpinned)
+            noisy = acp.sqrt()[:, None, None] * action + (1 - acp).sqrt()[:, None, None] * noise
+            noisy[mask] = action[mask]
+            pred = unet(noisy, timesteps, local_cond=None, global_cond=global_cond)
+            loss = torch.nn.functional.mse_loss(pred.float(), noise, reduction="none") * (~mask).float()
+            loss = loss.reshape(B, -1).mean(1).mean()
+        loss.backward()
+        grads = [("obs_encoder." + n, p.grad.detach().float()) for n, p in enc.named_parameters() if p.grad is not None] \
+            + [("model." + n, p.grad.detach().float()) for n, p in unet.named_parameters() if p.grad is not None]
+        return loss.detach().float(), pred.detach().float(), grads
+
+    def djitter(dbatch, rel=1e-3):
+        g = torch.Generator().manual_seed(6)
+        out = dict(dbatch, obs=dict(dbatch["obs"]))
+        out["obs"]["qpos"] = dbatch["obs"]["qpos"] * (1 + rel * torch.randn(dbatch["obs"]["qpos"].shape, generator=g))
+        out["action"] = dbatch["action"] * (1 + rel * torch.randn(dbatch["action"].shape, generator=g))
+        return out
+
+    best = None
+    for seed in range(2500, 2530):
+        dbatch = make_dp_batch(B, 100, seed=seed, ragged=True)
+        tmp = {}
+        _store_grads(tmp, "t.", dp_grads(dbatch, False)[2])
+        worst = 0.0
+        for b2 in (dbatch, djitter(dbatch)):
+            errs = _digest_errors(dp_grads(b2, True)[2], tmp, "t.")
+            worst = max(worst, max(e for e, scale in errs.values() if scale >= 1e-6))
+        if best is None or worst < best[0]:
+            best = (worst, seed)
+        if worst < 0.04:
+            break
+    worst, seed = best
+    print(f"  dp: batch seed {seed}, worst bf16 error of the reference (fp32 tokenizer, two realisations) {worst:.3f}")
+    assert worst < 0.06, worst
+    dbatch = make_dp_batch(B, 100, seed=seed, ragged=True)
+    loss, pred, g32 = dp_grads(dbatch, False)
+    fx["dp.noise"], fx["dp.timesteps"] = noise.numpy(), timesteps.numpy()
+    fx["dp.out.loss"], fx["dp.out.pred"] = loss.numpy(), pred.numpy()
+    for k, v in dbatch["obs"]["pcds"].items():
+        fx[f"dp.in.pcds.{k}"] = v.numpy()
+    fx["dp.in.qpos"], fx["dp.in.action"] = dbatch["obs"]["qpos"].numpy(), dbatch["action"].numpy()
+    _store_grads(fx, "dp.grad.", g32)
+    for tag, fp32_tok in (("yard", True), ("yard_all", False)):
+        l16, _, g16 = dp_grads(dbatch, True, fp32_tok)
+        for name, (e, scale) in _digest_errors(g16, fx, "dp.grad.").items():
+            fx[f"dp.{tag}.{name}"] = np.array(e if scale >= 1e-6 else 0.0)
+        fx[f"dp.{tag}_out.loss"] = l16.numpy()
+    ya = max(float(fx[k]) for k in fx if k.startswith("dp.yard."))
+    yb = max(float(fx[k]) for k in fx if k.startswith("dp.yard_all."))
+    print(f"wide_bf16_ref.npz dp: loss {float(loss):.5f}; reference in bf16: worst tensor {ya:.3f} (fp32 tokenizer) / {yb:.3f} (all autocast)")
+    np.savez_compressed(os.path.join(OUT, "wide_bf16_ref.npz"), **fx)
+
+
 def golden_rollout(ref):
     """The policy side of a rollout step, from the reference's own Python:
       * TemporalAgg (src/utils/misc.py:88-141) fed a seeded sequence of action chunks;
@@ -1358,7 +1542,7 @@ if __name__ == "__main__":
     only = set(sys.argv[1:])  # e.g. `make_golden.py rollout` regenerates one fixture
     for name, fn in (("act", golden_act), ("grouping", golden_grouping), ("misc", golden_misc), ("dp", golden_dp),
                      ("rollout", golden_rollout), ("gridsample", golden_gridsample), ("rlbench", golden_rlbench),
-                     ("dp_rlbench", golden_dp_rlbench), ("mask", golden_mask), ("presample", golden_presample), ("wide", golden_wide),
+                     ("dp_rlbench", golden_dp_rlbench), ("mask", golden_mask), ("presample", golden_presample), ("wide", golden_wide), ("wide_bf16", golden_wide_bf16),
                      ("optim", golden_optim), ("normalizer", golden_normalizer), ("wrappers", golden_wrappers), ("trajectory", golden_trajectory), ("dp_trajectory", golden_dp_trajectory)):
         if not only or name in only:
             fn(ref)
