@@ -12,13 +12,32 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# PCM_WAVESIM=1 (development aid; tests/test_wavesim_parity.py is the curated form): run `-m gpu` tests on HOST tensors against the
+# product's kernel sources compiled for the CPU wave64 model (tests/wavesim/).  `hip_device` then is the CPU and module-level `DEV`
+# constants are rewritten; tests that need the real runtime (streams, graphs, events, library GEMMs on the device) fail or are slow.
+_WAVESIM = os.environ.get("PCM_WAVESIM") == "1"
+
+
 @pytest.fixture(scope="session")
 def hip_device():
     import torch
 
+    if _WAVESIM:
+        return torch.device("cpu")
     if not torch.cuda.is_available():
         pytest.skip("no HIP device")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _wavesim_backend():
+    if not _WAVESIM:
+        yield
+        return
+    from tests.wavesim.backend import simulated_device
+
+    with simulated_device(claim_cuda=os.environ.get("PCM_WAVESIM_CLAIM_CUDA") == "1"):
+        yield
 
 
 # Run order (matters under `pytest -x`, which the round-end GPU run uses): evidence first.  Tier 0 = parity against the
@@ -29,7 +48,7 @@ _FILE_TIER = {
     "test_oracle": 0, "test_golden_cpu": 0, "test_capi": 0, "test_gridsample_cpu": 0, "test_rollout_cpu": 0, "test_rlbench_cpu": 0,
     "test_pointops_gpu": 0, "test_pointops_fuzz_gpu": 0, "test_pointops_misc_gpu": 0, "test_segsum_gpu": 0, "test_gridsample_gpu": 0,
     "test_rollout_gpu": 0, "test_rlbench_gpu": 0, "test_wide_fixture": 0, "test_presample": 0, "test_wrappers_ref_gpu": 0,
-    "test_bf16_fixture": 0, "test_wrappers_ref": 0, "test_optim_ref": 0, "test_normalizer_ref": 0, "test_trajectory_ref": 0, "test_mask_sampling": 0,
+    "test_bf16_fixture": 0, "test_wavesim_parity": 0, "test_wrappers_ref": 0, "test_optim_ref": 0, "test_normalizer_ref": 0, "test_trajectory_ref": 0, "test_mask_sampling": 0,
     "test_sa_fused_gpu": 1, "test_bn_relu_gpu": 1, "test_drln_gpu": 1, "test_tokens_gpu": 1, "test_small_attn_gpu": 1,
     "test_flash_attn_gpu": 1, "test_rows_linear_gpu": 1, "test_unet_ops_gpu": 1, "test_pointnet2_gpu": 1, "test_graphs_gpu": 1,
     "test_host_logic": 1, "test_concurrency_gpu": 1, "test_xfer_gpu": 1, "test_ffn_mfma_gpu": 1, "test_build_flags": 1,
@@ -60,6 +79,10 @@ def _tier(item):
 
 
 def pytest_collection_modifyitems(config, items):
+    if _WAVESIM:
+        for mod in {it.module for it in items}:
+            if getattr(mod, "DEV", None) in ("cuda", "cuda:0"):
+                mod.DEV = "cpu"
     order = {id(it): i for i, it in enumerate(items)}
     items.sort(key=lambda it: (_tier(it), order[id(it)]))
 

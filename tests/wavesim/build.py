@@ -1,0 +1,98 @@
+"""Builds tests/wavesim/_build/libpcm_wavesim.so: the product's kernel sources (pointcloudmatters_amd/csrc/*.hip) compiled for the HOST
+against the wave64 execution model of wavesim.hpp, exporting the same extern "C" entry points as libpcm_pointops.so -- with host
+pointers in place of device pointers.  TESTS ONLY (tests/test_wavesim_parity.py); nothing in the product can load it.
+
+The sources are compiled as they are, except for these mechanical rewrites of constructs a host compiler cannot take:
+  1. `extern __shared__ <type> name[];`            -> `<type> *name = (<type> *)wavesim::dyn_smem();`   (dynamic LDS)
+  2. fps.hip `fps_wave_max_fast`: the inline-assembly DPP ladder (6 x v_max_u32_dpp + readlane) -> `pcm_wave_max_u32`, the same
+     wave maximum written with the DPP builtin in pcm_common.hpp (the model executes DPP controls, not assembly text)
+  3. `asm volatile("" ...)` scheduling fences (ffn.hip)  -> removed
+  4. attn_small.hip: a wave that stores a tile to ITS OWN LDS region and reads it back relies on the hardware executing one wave's LDS
+     operations in order (no barrier, by design).  The model runs lanes one after another, so the hand-off gets an explicit
+     `__builtin_amdgcn_wave_barrier()` behind `tile_store(vr, Vs, lane);`
+Compiler: the ROCm clang++ in host mode (ext_vector_type, __builtin_convertvector on __bf16), -ffp-contract=off like the device build.
+"""
+import hashlib
+import os
+import re
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "pointcloudmatters_amd", "csrc")
+OUT = os.path.join(HERE, "_build")
+LIB = os.path.join(OUT, "libpcm_wavesim.so")
+CLANG = os.environ.get("WAVESIM_CXX", "/opt/rocm/lib/llvm/bin/clang++")
+# every kernel file of the library except graph_fix.hip (hipGraph surgery: runtime API, no kernel logic)
+SOURCES = ["fps.hip", "knn.hip", "ball.hip", "group.hip", "misc_ops.hip", "segsum.hip", "voxel.hip", "sa_scatter.hip", "sa_fused.hip",
+           "bnrelu.hip", "drln.hip", "tokens.hip", "gnmish.hip", "ddpm.hip", "optim.hip", "ffn.hip", "ffn_mfma.hip", "attn_small.hip",
+           "attn_flash.hip"]
+FLAGS = ["-x", "c++", "-std=c++17", "-O1", "-g0", "-ffp-contract=off", "-fPIC", "-fno-strict-aliasing", "-Wno-everything",
+         "-I", os.path.join(HERE, "include"), "-I", CSRC]
+
+_DYN = re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?([A-Za-z_][A-Za-z0-9_ ]*?)\s*\b([A-Za-z_][A-Za-z0-9_]*)\s*\[\s*\]\s*;")
+_FPS_ASM = re.compile(r"(__device__ __forceinline__ uint32_t fps_wave_max_fast\(uint32_t v\)\s*\{).*?\n\}\n", re.S)
+_FENCE = re.compile(r"asm volatile\(\"\"[^;]*\);")
+
+
+def rewrite(name, text):
+    text = _DYN.sub(lambda m: f"{m.group(1)} *{m.group(2)} = ({m.group(1)} *)wavesim::dyn_smem();", text)
+    if name == "fps.hip":
+        text, n = _FPS_ASM.subn(r"\1\n    return pcm_wave_max_u32(v);  // tests/wavesim/build.py, rewrite 2\n}\n", text)
+        assert n == 1, "fps_wave_max_fast not found"
+    if name == "attn_small.hip":
+        text, n = re.subn(r"(tile_store\(vr, Vs, lane\);)", r"\1 __builtin_amdgcn_wave_barrier();  /* tests/wavesim/build.py, rewrite 4 */", text)
+        assert n == 2, n
+    text = _FENCE.sub("/* scheduling fence removed (tests/wavesim/build.py, rewrite 3) */;", text)
+    assert "asm" not in re.sub(r"//.*", "", text).replace("assume", ""), f"{name}: inline assembly left after the rewrites"
+    return text
+
+
+def build(verbose=False, sources=None):
+    """Idempotent and safe to call from several processes at once (pytest-xdist workers): serialised by a lock file."""
+    import fcntl
+
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        return _build(verbose, sources)
+
+
+def _build(verbose, sources):
+    if not os.path.exists(CLANG):
+        raise RuntimeError(f"{CLANG} not found (set WAVESIM_CXX)")
+    objs, jobs = [], []
+    deps = [os.path.join(HERE, f) for f in ("wavesim.hpp", "include/hip/hip_runtime.h", "include/hip/hip_bf16.h", "build.py")] + \
+           [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")] + [os.path.join(ROOT, "include", "pcm_pointops.h")]
+    stamp = hashlib.sha1(b"".join(open(d, "rb").read() for d in sorted(deps))).hexdigest()[:12]
+    for name in (sources or SOURCES):
+        src = rewrite(name, open(os.path.join(CSRC, name)).read())
+        key = hashlib.sha1((stamp + src).encode()).hexdigest()[:16]
+        cpp, obj = os.path.join(OUT, name.replace(".hip", ".sim.cpp")), os.path.join(OUT, name.replace(".hip", f".{key}.o"))
+        objs.append(obj)
+        if not os.path.exists(obj):
+            open(cpp, "w").write(src)
+            jobs.append((name, subprocess.Popen([CLANG] + FLAGS + ["-c", cpp, "-o", obj], stderr=subprocess.PIPE, text=True)))
+    core = os.path.join(OUT, f"wavesim.{stamp}.o")
+    if not os.path.exists(core):
+        jobs.append(("wavesim.cpp", subprocess.Popen([CLANG, "-std=c++17", "-O2", "-fPIC", "-c", os.path.join(HERE, "wavesim.cpp"), "-o", core],
+                                                     stderr=subprocess.PIPE, text=True)))
+    failed = []
+    for name, p in jobs:
+        err = p.communicate()[1]
+        if p.returncode != 0:
+            failed.append((name, err))
+        elif verbose and err.strip():
+            print(err, file=sys.stderr)
+    if failed:
+        raise RuntimeError("\n".join(f"--- {n}\n{e[-6000:]}" for n, e in failed))
+    if jobs or not os.path.exists(LIB):
+        tmp = LIB + ".tmp.%d" % os.getpid()
+        subprocess.check_call([CLANG, "-shared", "-fPIC", "-o", tmp] + objs + [core])
+        os.replace(tmp, LIB)  # processes that already mapped the previous file keep it
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(verbose=True, sources=sys.argv[1:] or None))

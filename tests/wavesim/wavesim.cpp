@@ -1,0 +1,320 @@
+// wavesim.cpp -- scheduler, barrier and cross-lane resolver of the CPU wave64 model (tests only; see wavesim.hpp).
+#include "wavesim.hpp"
+
+#include <sys/mman.h>
+
+namespace wavesim {
+
+Lane *g_cur = nullptr;
+Block *g_blk = nullptr;
+void *g_sched_sp = nullptr;
+char *g_dyn_smem = nullptr;
+size_t g_dyn_smem_bytes = 0;
+long g_stat_switches = 0, g_stat_cross = 0, g_stat_barriers = 0;
+
+static const std::function<void()> *g_body = nullptr;
+static const size_t kStack = 256 * 1024;  // per work-item (the exact kNN kernel keeps 2 x 128-entry lists per lane)
+static std::vector<char *> g_stack_pool;
+
+asm(R"(
+.text
+.globl wavesim_switch
+.type wavesim_switch,@function
+wavesim_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size wavesim_switch,.-wavesim_switch
+)");
+
+static void fiber_main()
+{
+    (*g_body)();
+    g_cur->state = DONE;
+    yield_to_scheduler();
+    std::fprintf(stderr, "wavesim: a finished work-item was resumed\n");
+    std::abort();
+}
+
+static char *get_stack(size_t i)
+{
+    while (g_stack_pool.size() <= i) {
+        void *p = mmap(nullptr, kStack, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (p == MAP_FAILED) { std::perror("wavesim: mmap"); std::abort(); }
+        g_stack_pool.push_back((char *)p);
+    }
+    return g_stack_pool[i];
+}
+
+static void prepare(Lane &l, size_t i)
+{
+    l.stack = get_stack(i);
+    // initial frame for wavesim_switch: six callee-saved registers, then the "return address" = fiber_main.  At fiber_main's
+    // entry rsp must be 8 mod 16 (as after a call): top is 16-aligned, one dummy slot above the return address.
+    uintptr_t top = ((uintptr_t)l.stack + kStack) & ~(uintptr_t)15;
+    uint64_t *sp = (uint64_t *)top;
+    *--sp = 0;                         // dummy (fake return address of fiber_main; never used)
+    *--sp = (uint64_t)&fiber_main;     // popped by `ret`
+    for (int r = 0; r < 6; ++r) *--sp = 0;
+    l.sp = sp;
+    l.state = READY;
+}
+
+void syncthreads()
+{
+    g_cur->state = AT_BARRIER;
+    g_cur->barrier_pred = false;
+    yield_to_scheduler();
+}
+
+int syncthreads_or(int pred)
+{
+    g_cur->state = AT_BARRIER;
+    g_cur->barrier_pred = pred != 0;
+    yield_to_scheduler();
+    return g_blk->barrier_or ? 1 : 0;
+}
+
+// ---- DPP source-lane selection (CDNA ISA "DPP_CTRL"); returns -1 when the selected lane is out of range (invalid source) ----
+static int dpp_source(int lane, int ctrl)
+{
+    const int row = lane & ~15, r = lane & 15;
+    if (ctrl >= 0x000 && ctrl <= 0x0FF) {  // quad_perm
+        const int q = lane & ~3, sel = (ctrl >> (2 * (lane & 3))) & 3;
+        return q + sel;
+    }
+    if (ctrl >= 0x101 && ctrl <= 0x10F) { const int s = r + (ctrl & 15); return s < 16 ? row + s : -1; }        // row_shl
+    if (ctrl >= 0x111 && ctrl <= 0x11F) { const int s = r - (ctrl & 15); return s >= 0 ? row + s : -1; }        // row_shr
+    if (ctrl >= 0x121 && ctrl <= 0x12F) { return row + ((r - (ctrl & 15)) & 15); }                              // row_ror
+    if (ctrl == 0x130) return lane + 1 < 64 ? lane + 1 : -1;   // wave_shl:1
+    if (ctrl == 0x134) return (lane + 1) & 63;                 // wave_rol:1
+    if (ctrl == 0x138) return lane - 1 >= 0 ? lane - 1 : -1;   // wave_shr:1
+    if (ctrl == 0x13C) return (lane - 1) & 63;                 // wave_ror:1
+    if (ctrl == 0x140) return row + (15 - r);                  // row_mirror
+    if (ctrl == 0x141) return row + ((r & 8) | (7 - (r & 7))); // row_half_mirror
+    if (ctrl == 0x142) return lane >= 16 ? row - 1 : -1;       // row_bcast:15 (lane 15 of the previous row, to the whole row)
+    if (ctrl == 0x143) return (lane >= 32) ? ((lane & 32) - 1) : -1;                         // row_bcast:31
+    std::fprintf(stderr, "wavesim: DPP control 0x%x not modelled\n", ctrl);
+    std::abort();
+}
+
+static float bf16_to_f(uint16_t b)
+{
+    uint32_t u = (uint32_t)b << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+static void resolve_mfma(std::vector<Lane *> &g)
+{
+    // all 64 lanes must take part in a matrix instruction
+    if (g.size() != 64) { std::fprintf(stderr, "wavesim: MFMA with %zu active lanes\n", g.size()); std::abort(); }
+    Lane *by[64];
+    for (Lane *l : g) by[l->lane] = l;
+    const int shape = (int)g[0]->arg[0];
+    // operand element (row i / column j, reduction index k) -> (lane, register) per the CDNA3/4 ISA layouts:
+    //   32x32xK: A[i][k] in lane i + 32 * (k / KL), element k % KL;  B[k][j] in lane j + 32 * (k / KL), element k % KL;
+    //            D[i][j] in lane j + 32 * ((i / 4) % 2), register 4 * (i / 8) + i % 4                       (KL = K / 2)
+    //   16x16xK: A[i][k] in lane i + 16 * (k / KL), element k % KL;  B likewise;  D[i][j] in lane j + 16 * (i / 4), register i % 4   (KL = K / 4)
+    int M, K, KL, NR;
+    if (shape == MFMA_32x32x8_BF16_1K) M = 32, K = 8, KL = 4, NR = 16;
+    else if (shape == MFMA_32x32x16_BF16) M = 32, K = 16, KL = 8, NR = 16;
+    else M = 16, K = 32, KL = 8, NR = 4;
+    const int groups = 64 / M;  // lanes groups along k
+    (void)groups;
+    static float D[32][32];
+    for (int i = 0; i < M; ++i)
+        for (int j = 0; j < M; ++j) {
+            int dl, dr;
+            if (M == 32) dl = j + 32 * ((i / 4) % 2), dr = 4 * (i / 8) + i % 4;
+            else dl = j + 16 * (i / 4), dr = i % 4;
+            const float *cin = (const float *)by[dl]->pin + 8;  // layout of the deposit: a (16 B) | b (16 B) | c (NR floats)
+            float acc = cin[dr];
+            for (int k = 0; k < K; ++k) {
+                const uint16_t *a = (const uint16_t *)by[i + M * (k / KL)]->pin;
+                const uint16_t *b = (const uint16_t *)by[j + M * (k / KL)]->pin + 8;
+                acc += bf16_to_f(a[k % KL]) * bf16_to_f(b[k % KL]);
+            }
+            D[i][j] = acc;
+            (void)NR;
+        }
+    for (int i = 0; i < M; ++i)
+        for (int j = 0; j < M; ++j) {
+            int dl, dr;
+            if (M == 32) dl = j + 32 * ((i / 4) % 2), dr = 4 * (i / 8) + i % 4;
+            else dl = j + 16 * (i / 4), dr = i % 4;
+            ((float *)by[dl]->pout)[dr] = D[i][j];
+        }
+}
+
+static void resolve_group(std::vector<Lane *> &g)
+{
+    ++g_stat_cross;
+    const Op op = g[0]->op;
+    Lane *by[64] = {};
+    uint64_t active = 0;
+    for (Lane *l : g) by[l->lane] = l, active |= 1ull << l->lane;
+    switch (op) {
+    case OP_SHFL:  // arg0 = source lane (already reduced to the wave by the caller)
+        for (Lane *l : g) { const int s = (int)l->arg[0] & 63; l->out = by[s] ? by[s]->in[0] : 0; }
+        break;
+    case OP_BPERMUTE:
+        for (Lane *l : g) { const int s = (int)(l->arg[0] >> 2) & 63; l->out = by[s] ? by[s]->in[0] : 0; }
+        break;
+    case OP_DPP:  // in0 = src, in1 = old; arg0 = ctrl, arg1 = row_mask, arg2 = bank_mask, arg3 = bound_ctrl
+        for (Lane *l : g) {
+            const int ctrl = (int)l->arg[0], rm = (int)l->arg[1], bm = (int)l->arg[2];
+            const bool enabled = ((rm >> (l->lane >> 4)) & 1) && ((bm >> ((l->lane >> 2) & 3)) & 1);
+            if (!enabled) { l->out = l->in[1]; continue; }
+            int s = dpp_source(l->lane, ctrl);
+            if (s < 0 || !by[s]) l->out = l->arg[3] ? 0 : l->in[1];  // invalid / inactive source: 0 with bound_ctrl, else keep `old`
+            else l->out = by[s]->in[0];
+        }
+        break;
+    case OP_BALLOT: {
+        uint64_t m = 0;
+        for (Lane *l : g) if (l->in[0]) m |= 1ull << l->lane;
+        for (Lane *l : g) l->out = m;
+        break;
+    }
+    case OP_ANY_ALL: {  // arg0: 0 = any, 1 = all
+        bool any = false, all = true;
+        for (Lane *l : g) any |= l->in[0] != 0, all &= l->in[0] != 0;
+        for (Lane *l : g) l->out = l->arg[0] ? all : any;
+        break;
+    }
+    case OP_READLANE:
+        for (Lane *l : g) {
+            const int s = (int)l->arg[0] & 63;
+            if (!by[s]) { std::fprintf(stderr, "wavesim: readlane from inactive lane %d (stale register on hardware)\n", s); std::abort(); }
+            l->out = by[s]->in[0];
+        }
+        break;
+    case OP_READFIRST: {
+        const int s = __builtin_ctzll(active);
+        for (Lane *l : g) l->out = by[s]->in[0];
+        break;
+    }
+    case OP_TR16:  // element j of lane i (in-group index) = element i % 4 of what lane 16 g + 4 j + i / 4 loaded
+        for (Lane *l : g) {
+            const int grp = l->lane & ~15, i = l->lane & 15;
+            uint64_t r = 0;
+            for (int j = 0; j < 4; ++j) {
+                Lane *src = by[grp + 4 * j + i / 4];
+                const uint64_t e = src ? (src->in[0] >> (16 * (i % 4))) & 0xFFFF : 0;
+                r |= e << (16 * j);
+            }
+            l->out = r;
+        }
+        break;
+    case OP_WAVE_BARRIER:
+        break;
+    case OP_MFMA:
+        resolve_mfma(g);
+        break;
+    }
+    for (Lane *l : g) l->state = READY;
+}
+
+static void run_block(Block &b)
+{
+    g_blk = &b;
+    const size_t n = b.lanes.size();
+    size_t done = 0;
+    while (done < n) {
+        bool ran = false;
+        for (size_t i = 0; i < n; ++i) {
+            Lane &l = b.lanes[i];
+            if (l.state != READY) continue;
+            ran = true;
+            g_cur = &l;
+            ++g_stat_switches;
+            wavesim_switch(&g_sched_sp, l.sp);
+            if (l.state == DONE) ++done;
+        }
+        if (ran) continue;
+        // nobody can run: resolve cross-lane operations wave by wave, then the barrier
+        bool progressed = false;
+        const int waves = (int)((n + 63) / 64);
+        for (int w = 0; w < waves; ++w) {
+            std::vector<Lane *> waiting;
+            for (size_t i = (size_t)w * 64; i < n && i < (size_t)(w + 1) * 64; ++i)
+                if (b.lanes[i].state == AT_CROSS) waiting.push_back(&b.lanes[i]);
+            if (waiting.empty()) continue;
+            // ONE site per wave per pass: the earliest in program order (ties: the first lane's)
+            Lane *first = waiting[0];
+            for (Lane *l : waiting) if (l->order < first->order) first = l;
+            std::vector<Lane *> grp;
+            for (Lane *l : waiting) if (l->site == first->site && l->op == first->op) grp.push_back(l);
+            resolve_group(grp);
+            progressed = true;
+        }
+        if (progressed) continue;
+        size_t at_barrier = 0;
+        bool any_pred = false;
+        for (Lane &l : b.lanes) if (l.state == AT_BARRIER) ++at_barrier, any_pred |= l.barrier_pred;
+        if (at_barrier && at_barrier + done == n) {
+            ++g_stat_barriers;
+            b.barrier_or = any_pred;
+            for (Lane &l : b.lanes) if (l.state == AT_BARRIER) l.state = READY;
+            continue;
+        }
+        std::fprintf(stderr, "wavesim: deadlock in block (%u,%u,%u): %zu of %zu work-items done, %zu at the barrier\n", b.bid.x, b.bid.y,
+                     b.bid.z, done, n, at_barrier);
+        std::abort();
+    }
+}
+
+void launch(const std::function<void()> &body, dim3 grid, dim3 block, size_t dyn_bytes)
+{
+    if (g_blk != nullptr) { std::fprintf(stderr, "wavesim: nested launch\n"); std::abort(); }
+    const size_t threads = (size_t)block.x * block.y * block.z;
+    if (threads == 0 || threads > 1024) { std::fprintf(stderr, "wavesim: bad block size %zu\n", threads); std::abort(); }
+    if (dyn_bytes > 160 * 1024) { std::fprintf(stderr, "wavesim: %zu bytes of dynamic LDS > 160 KiB\n", dyn_bytes); std::abort(); }
+    if (g_dyn_smem_bytes < 160 * 1024) {
+        g_dyn_smem = (char *)std::aligned_alloc(256, 160 * 1024);
+        g_dyn_smem_bytes = 160 * 1024;
+    }
+    g_body = &body;
+    Block b;
+    b.bdim = block, b.gdim = grid;
+    b.lanes.resize(threads);
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bx = 0; bx < grid.x; ++bx) {
+                b.bid = dim3(bx, by, bz);
+                size_t i = 0;
+                for (unsigned tz = 0; tz < block.z; ++tz)
+                    for (unsigned ty = 0; ty < block.y; ++ty)
+                        for (unsigned tx = 0; tx < block.x; ++tx, ++i) {
+                            Lane &l = b.lanes[i];
+                            l.tid = dim3(tx, ty, tz);
+                            l.linear = (int)i, l.lane = (int)(i & 63), l.wave = (int)(i >> 6);
+                            prepare(l, i);
+                        }
+                run_block(b);
+            }
+    g_body = nullptr;
+    g_cur = nullptr;
+    g_blk = nullptr;
+}
+
+}  // namespace wavesim
+
+extern "C" void wavesim_stats(long *out)
+{
+    out[0] = wavesim::g_stat_switches, out[1] = wavesim::g_stat_cross, out[2] = wavesim::g_stat_barriers;
+}
