@@ -354,6 +354,19 @@ int pcm_drln_backward2_hip(long R, int E, int y_is_bf16, const float *dout, cons
                            unsigned site, float *dx, void *dy, float *partial, float *dgamma_dbeta, void *dysum_bf16,
                            void *stream);
 
+/* ---- the attention output projection, the residual add and the norm as ONE kernel on the matrix cores (csrc/proj_ln.hip) ----------
+ *   out = LayerNorm(x + dropout(a W^T + bias))      transformer.py:244-256 (encoder), :296-346 (decoder): out_proj of
+ *   nn.MultiheadAttention followed by `src = src + self.dropout1(src2); src = self.norm1(src)`
+ * a (R, K) bf16 with row stride a_ls elements (a multiple of 8), W (E, K) bf16 row-major (nn.Linear.weight under autocast), bias (E)
+ * bf16 or fp32 (nullable); the product is rounded to bf16 like the library GEMM's output under autocast, everything else and every
+ * other argument as pcm_drln_forward2_hip -- same dropout counter hash, so pcm_drln_backward2_hip is the backward of both.
+ * E in {256, 512, 768, 1024}, K a multiple of 32 up to 1024 (pcm_proj_drln_mfma_supported), 16-byte aligned a and W. */
+int pcm_proj_drln_mfma_supported(int E, int K);
+int pcm_proj_drln_mfma_forward_hip(long R, int E, int K, const void *a_bf16, long a_ls, const void *w_bf16, const void *bias,
+                                   int bias_is_bf16, const float *x, const float *gamma, const float *beta, float eps, float p_drop,
+                                   const long *seed, unsigned site, float *s, float *out, float *mean, float *rstd, const float *pos,
+                                   long pos_n, void *sum_bf16, void *out_bf16, void *stream);
+
 /* ---- fused feed-forward sub-layer  out = LayerNorm(x + dropout(W2 dropout(relu(W1 x + b1)) + b2)) ------------
  * replaces linear1 -> relu -> dropout -> linear2 -> dropout -> add -> norm of every transformer layer
  * (src/models/components/act/transformer.py:253-256, 342-345) for the shipped dim_feedforward = 32

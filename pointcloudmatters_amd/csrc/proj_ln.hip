@@ -1,0 +1,218 @@
+// proj_ln.hip -- out = LayerNorm(x + dropout(a W^T + b)) as ONE kernel on the matrix cores (gfx950, v_mfma_f32_16x16x32_bf16).
+//
+// The tail of every attention sub-layer of the ACT transformer
+//   (/root/reference/src/models/components/act/transformer.py:244-256 encoder, :296-346 decoder: `src2 = self.self_attn(...)[0]` -- whose
+//    last step is the output projection of nn.MultiheadAttention -- `src = src + self.dropout1(src2); src = self.norm1(src)`)
+// ran as a library GEMM (800 x 512 x 512 in the decoder: 6-9 us, 2 % of the MFMA peak: a launch-floor-bound product) followed by
+// csrc/drln.hip (7.5 us, reads the GEMM's output back from HBM / L2).  22 such pairs per ACT step.
+//
+// Design, for the ~800-row case ("a row tile's whole K = 512 A panel resident in LDS and B streamed once per workgroup"):
+//  * one workgroup = 16 rows x ALL E columns (LayerNorm needs whole rows), 8 waves; wave w owns columns [w E/8, (w+1) E/8);
+//  * the A panel (16 x K bf16, <= 32 KiB) is loaded ONCE into LDS (rows padded by 8 elements: the 16-byte operand reads of the 16
+//    rows fall into different banks); the weight is never staged: the B operand of the 16x16x32 instruction is 8 consecutive k of one
+//    output column = 16 contiguous bytes of W's row (W is (E, K) row-major, the nn.Linear layout) -- each lane fetches its operand
+//    straight from L2 into registers, two k-steps ahead of the matrix instruction that consumes it (W = 512 KiB stays L2 resident;
+//    per workgroup it is streamed exactly once: 16 k-steps x 4 column tiles x 16 bytes per lane);
+//  * the accumulators (+ bias, rounded to bf16 like the library GEMM's output under autocast) go to an LDS tile, ONE barrier, then
+//    each wave finishes two rows exactly like csrc/drln.hip: s = x + keep * y / (1 - p) with the same counter-based mask
+//    (so pcm_drln_backward2_hip is this kernel's backward), row mean / variance by wave reductions, the affine map, and the
+//    consumer's bf16 operands (out + pos, out) in the same pass.  All global traffic of the epilogue is whole-row, 16 bytes per lane.
+// Bound: streaming W through one CU's L2 port (E K 2 bytes / 64 B per clock = 3.4 us at E = K = 512) -- about the time of the GEMM
+// alone today, with the second kernel and the round trip of y gone.
+// Algorithmic bytes per row: 2 K (a) + 4 E (x) + 8 E (s, out) [+ 4 E (sum16, out16)]; the weight E K 2 once per 16 rows from L2.
+#include "pcm_attn.hpp"
+
+namespace {
+
+constexpr int kTM = 16;          // rows per workgroup
+constexpr int kWavesP = 8;       // waves per workgroup
+constexpr int kThreadsP = 64 * kWavesP;
+constexpr int kAPad = 8;         // bf16 elements of padding per A row
+constexpr int kYPad = 4;         // floats of padding per y row
+
+typedef float f4v __attribute__((ext_vector_type(4)));
+#define PCM_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+
+__device__ __forceinline__ bf8 ldg_bf8(const u16 *p)  // 16 bytes, global
+{
+    return as_bf8(*reinterpret_cast<const uint4 *>(p));
+}
+
+template <int E>
+__global__ __launch_bounds__(kThreadsP) void pcm_proj_drln_fwd_kernel(
+    long R, int K, const u16 *__restrict__ a, long a_ls, const u16 *__restrict__ W, const void *__restrict__ bias, int bias_is_bf16,
+    const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta, float eps, float p_drop,
+    const long *__restrict__ seed_ptr, unsigned site, float *__restrict__ s_out, float *__restrict__ out, float *__restrict__ mean_out,
+    float *__restrict__ rstd_out, const float *__restrict__ pos, long pos_n, __hip_bfloat16 *__restrict__ sum16,
+    __hip_bfloat16 *__restrict__ x16)
+{
+    constexpr int NT = E / (16 * kWavesP);  // 16-column tiles per wave
+    constexpr int NCH = E / 256;            // float4 chunks per lane in the row phase
+    constexpr int YS = E + kYPad;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int AS = K + kAPad;
+    u16 *As = reinterpret_cast<u16 *>(smem);                                   // [kTM][AS] bf16
+    float *Ys = reinterpret_cast<float *>(smem + (size_t)kTM * AS * 2);        // [kTM][YS] fp32 (16-byte aligned: AS % 8 == 0)
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const long r0 = (long)blockIdx.x * kTM;
+
+    // ---- A panel -> LDS (rows past R are zero)
+    const int chunks = K / 8;  // 16-byte pieces per row
+    for (int c = tid; c < kTM * chunks; c += kThreadsP) {
+        const int i = c / chunks, kc = c % chunks;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r0 + i < R) v = *reinterpret_cast<const uint4 *>(a + (r0 + i) * a_ls + kc * 8);
+        *reinterpret_cast<uint4 *>(As + i * AS + kc * 8) = v;
+    }
+
+    // ---- products: wave w, column tiles t = 0 .. NT-1 at n0 + 16 t; operands of k-step kt: k = 32 kt + 8 (lane / 16) .. + 7
+    const int n0 = w * (E / kWavesP), li = lane & 15, lk = 8 * (lane >> 4);
+    const u16 *wrow[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) wrow[t] = W + (long)(n0 + 16 * t + li) * K + lk;
+    f4v acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f4v{0.f, 0.f, 0.f, 0.f};
+    const int ksteps = K / 32;
+    bf8 b0[NT], b1[NT];  // the operands of k-steps kt and kt + 1 (in flight while step kt - 1 is multiplied)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        b0[t] = ldg_bf8(wrow[t]);
+        b1[t] = ksteps > 1 ? ldg_bf8(wrow[t] + 32) : b0[t];
+    }
+    __syncthreads();  // A panel complete
+    for (int kt = 0; kt < ksteps; ++kt) {
+        bf8 b2[NT];
+        const bool more = kt + 2 < ksteps;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b2[t] = more ? ldg_bf8(wrow[t] + 32 * (kt + 2)) : b1[t];
+        const bf8 af = lds_bf8(As + li * AS + 32 * kt + lk);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = PCM_MFMA_16x16x32(af, b0[t], acc[t]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b0[t] = b1[t], b1[t] = b2[t];
+    }
+
+    // ---- y = bf16(acc + bias) -> LDS tile.  Accumulator register r of `lane`: row 4 (lane / 16) + r, column n0 + 16 t + lane % 16
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int col = n0 + 16 * t + li;
+        const float bv = bias == nullptr ? 0.f
+                         : (bias_is_bf16 ? bf2f(reinterpret_cast<const u16 *>(bias)[col]) : reinterpret_cast<const float *>(bias)[col]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float y = acc[t][r] + bv;
+            Ys[(4 * (lane >> 4) + r) * YS + col] = __uint_as_float(pcm_cvt_pk_bf16(y, 0.f) << 16);  // rounded to bf16, kept as fp32
+        }
+    }
+    __syncthreads();
+
+    // ---- rows: wave w finishes rows w and w + 8 of the tile (csrc/drln.hip's row code on the LDS-resident y)
+    const bool drop = p_drop > 0.f;
+    const uint64_t seed = drop ? (uint64_t)seed_ptr[0] : 0ull;
+    const uint32_t thr = drop ? (uint32_t)((double)p_drop * 4294967296.0) : 0u;
+    const float scale = drop ? 1.f / (1.f - p_drop) : 1.f;
+    for (int i = w; i < kTM; i += kWavesP) {
+        const long r = r0 + i;
+        if (r >= R) break;  // wave-uniform
+        float s[NCH][4];
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int col = c * 256 + lane * 4;
+            const long e0 = r * E + col;
+            float xv[4], yv[4];
+            load4<float>(x + e0, xv);
+            load4<float>(Ys + i * YS + col, yv);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float yy = keep_elem(seed, site, (uint64_t)(e0 + v), thr) ? yv[v] * scale : 0.f;
+                s[c][v] = xv[v] + yy;
+                sum += s[c][v];
+            }
+        }
+        const float mu = wave_sum(sum) * (1.f / E);
+        float sq = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float d = s[c][v] - mu;
+                sq += d * d;
+            }
+        const float rstd = rsqrtf(wave_sum(sq) * (1.f / E) + eps);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int col = c * 256 + lane * 4;
+            const long e0 = r * E + col;
+            float g[4], b[4], o[4];
+            load4<float>(gamma + col, g);
+            load4<float>(beta + col, b);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) o[v] = (s[c][v] - mu) * rstd * g[v] + b[v];
+            store4<float>(s_out + e0, s[c]);
+            store4<float>(out + e0, o);
+            if (sum16 != nullptr) {
+                float p[4], q[4];
+                load4<float>(pos + (r * E) % pos_n + col, p);  // E divides pos_n: a row never wraps
+#pragma unroll
+                for (int v = 0; v < 4; ++v) q[v] = o[v] + p[v];
+                store4<__hip_bfloat16>(sum16 + e0, q);
+            }
+            if (x16 != nullptr) store4<__hip_bfloat16>(x16 + e0, o);
+        }
+        if (lane == 0) mean_out[r] = mu, rstd_out[r] = rstd;
+    }
+}
+
+inline size_t proj_smem_bytes(int E, int K) { return (size_t)kTM * (K + kAPad) * 2 + (size_t)kTM * (E + kYPad) * 4; }
+
+template <int E>
+int launch_proj(long R, int K, const void *a, long a_ls, const void *W, const void *bias, int bias_is_bf16, const float *x,
+                const float *gamma, const float *beta, float eps, float p_drop, const long *seed, unsigned site, float *s, float *out,
+                float *mean, float *rstd, const float *pos, long pos_n, void *sum16, void *x16, hipStream_t st)
+{
+    const size_t smem = proj_smem_bytes(E, K);
+    const long blocks = (R + kTM - 1) / kTM;
+    if (smem > 64 * 1024) {  // E = K = 1024: 97 KiB of the CU's 160
+        const int rc = pcm_status(hipFuncSetAttribute(reinterpret_cast<const void *>(pcm_proj_drln_fwd_kernel<E>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(pcm_proj_drln_fwd_kernel<E>, dim3((unsigned)blocks), dim3(kThreadsP), smem, st, R, K, (const u16 *)a, a_ls,
+                       (const u16 *)W, bias, bias_is_bf16, x, gamma, beta, eps, p_drop, seed, site, s, out, mean, rstd, pos, pos_n,
+                       (__hip_bfloat16 *)sum16, (__hip_bfloat16 *)x16);
+    return PCM_LAUNCH_STATUS();
+}
+
+}  // namespace
+
+// E: multiples of 256 up to 1024 (the row phase's float4 chunks; E / 128 column tiles per wave); K: multiples of 32 up to 1024
+extern "C" int pcm_proj_drln_mfma_supported(int E, int K)
+{
+    return (E == 256 || E == 512 || E == 768 || E == 1024) && K >= 32 && K <= 1024 && K % 32 == 0;
+}
+
+extern "C" int pcm_proj_drln_mfma_forward_hip(long R, int E, int K, const void *a_bf16, long a_ls, const void *w_bf16, const void *bias,
+                                              int bias_is_bf16, const float *x, const float *gamma, const float *beta, float eps,
+                                              float p_drop, const long *seed, unsigned site, float *s, float *out, float *mean,
+                                              float *rstd, const float *pos, long pos_n, void *sum_bf16, void *out_bf16, void *stream)
+{
+    if (R < 0 || E <= 0 || K <= 0 || a_ls < K || !(p_drop >= 0.f && p_drop < 1.f)) return PCM_ERR_BAD_ARG;
+    if (!pcm_proj_drln_mfma_supported(E, K)) return PCM_ERR_UNSUPPORTED;
+    if (R == 0) return PCM_OK;
+    if (!a_bf16 || !w_bf16 || !x || !gamma || !beta || !s || !out || !mean || !rstd || (p_drop > 0.f && !seed)) return PCM_ERR_BAD_ARG;
+    if (sum_bf16 != nullptr && (pos == nullptr || pos_n <= 0 || pos_n % E != 0)) return PCM_ERR_BAD_ARG;
+    if ((a_ls % 8) != 0 || (((uintptr_t)a_bf16 | (uintptr_t)w_bf16) % 16) != 0) return PCM_ERR_BAD_ARG;  // 16-byte operand loads
+    hipStream_t st = (hipStream_t)stream;
+#define PCM_PROJ(EE)                                                                                                              \
+    return launch_proj<EE>(R, K, a_bf16, a_ls, w_bf16, bias, bias_is_bf16, x, gamma, beta, eps, p_drop, seed, site, s, out, mean, \
+                           rstd, pos, pos_n, sum_bf16, out_bf16, st)
+    switch (E) {
+    case 256: PCM_PROJ(256);
+    case 512: PCM_PROJ(512);
+    case 768: PCM_PROJ(768);
+    default: PCM_PROJ(1024);
+    }
+#undef PCM_PROJ
+}

@@ -191,6 +191,44 @@ def _drln_forward(x2, y2, gamma, beta, eps, p_drop, seed, site, emit=None):
     return out, s, mean, rstd
 
 
+# csrc/proj_ln.hip: the output projection, the residual add and the norm as ONE matrix-core kernel (forward; the backward stays
+# pcm_drln_backward2_hip + the two products).  Written in round 5 while the GPU pool was closed to the build: verified on the host wave64
+# model (tests/test_proj_ln_gpu.py through tests/test_wavesim_parity.py), NOT yet timed -- opt-in until it is (PCM_PROJ_MFMA=1);
+# PCM_PROJ_MFMA_MAX_ROWS bounds the row count it takes (a 16-row tile per workgroup streams the whole weight: meant for the ~800-row
+# decoder / CVAE-encoder sites, the 4120-row encoder sites stay with the library product unless the bound is raised).
+PROJ_MFMA = os.environ.get("PCM_PROJ_MFMA", "0") != "0"
+PROJ_MFMA_MAX_ROWS = int(os.environ.get("PCM_PROJ_MFMA_MAX_ROWS", "1024"))
+
+
+def _proj_mfma_ok(a2, wc, bc, x2):
+    R, E = x2.shape
+    return (PROJ_MFMA and a2.is_cuda and 0 < R <= PROJ_MFMA_MAX_ROWS and a2.dtype == torch.bfloat16 and wc.dtype == torch.bfloat16
+            and bc.dtype in (torch.bfloat16, torch.float32) and x2.dtype == torch.float32 and wc.is_contiguous() and bc.is_contiguous()
+            and a2.stride(-1) == 1 and a2.stride(0) % 8 == 0 and a2.data_ptr() % 16 == 0 and wc.data_ptr() % 16 == 0
+            and bool(_lib.load().pcm_proj_drln_mfma_supported(int(E), int(wc.shape[1]))))
+
+
+def _proj_drln_forward(a2, wc, bc, x2, gamma, beta, eps, p_drop, seed, site, emit=None):
+    """out, s, mean, rstd of LayerNorm(x2 + dropout(a2 @ wc^T + bc)) from one launch (csrc/proj_ln.hip)."""
+    L = _lib.load()
+    R, E = x2.shape
+    dev = x2.device
+    with torch.cuda.device(dev):
+        s = torch.empty_like(x2)
+        out = deferred.take(x2.shape, x2.dtype, dev, "drln.out")
+        mean = torch.empty(R, dtype=torch.float32, device=dev)
+        rstd = torch.empty(R, dtype=torch.float32, device=dev)
+        extra, rec = _emit_args(emit, R, E, dev)
+        rc = L.pcm_proj_drln_mfma_forward_hip(R, E, int(wc.shape[1]), a2.data_ptr(), int(a2.stride(0)), wc.data_ptr(), bc.data_ptr(),
+                                              int(bc.dtype == torch.bfloat16), x2.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                              float(eps), float(p_drop), seed.data_ptr() if seed is not None else 0, int(site),
+                                              s.data_ptr(), out.data_ptr(), mean.data_ptr(), rstd.data_ptr(), *extra, _raw_stream())
+    _lib.check(rc, "pcm_proj_drln_mfma_forward_hip")
+    if emit is not None:
+        emit["record"] = rec
+    return out, s, mean, rstd
+
+
 def _pos_rows(pos, x_shape):
     """`pos` as the contiguous fp32 block that the add + cast kernels broadcast over the leading rows of x (shape x_shape):
     trailing dimensions expanded to x's, a batch-broadcast view reduced to its single row block."""
@@ -305,14 +343,19 @@ class _ProjDRLN(Function):
         else:
             ac, wc, bc = a, weight, bias
         a2 = ac.reshape(-1, ac.shape[-1])
-        with torch.autocast("cuda", enabled=False):
-            y2 = torch.nn.functional.linear(a2, wc, bc)
         x2 = x.reshape(-1, E)
         if not x2.is_contiguous():
             x2 = x2.contiguous()
-        out, s, mean, rstd = _drln_forward(x2, y2, gamma, beta, eps, p_drop, seed, site, emit=emit)
+        if _proj_mfma_ok(a2, wc, bc, x2):
+            ydt = torch.bfloat16  # the kernel rounds the product to bf16, like the library GEMM under autocast
+            out, s, mean, rstd = _proj_drln_forward(a2, wc, bc, x2, gamma, beta, eps, p_drop, seed, site, emit=emit)
+        else:
+            with torch.autocast("cuda", enabled=False):
+                y2 = torch.nn.functional.linear(a2, wc, bc)
+            ydt = y2.dtype
+            out, s, mean, rstd = _drln_forward(x2, y2, gamma, beta, eps, p_drop, seed, site, emit=emit)
         ctx.save_for_backward(a2, wc, s, mean, rstd, gamma)
-        ctx.meta = (shape, a.shape, a.dtype, weight.dtype, bias.dtype, y2.dtype, float(p_drop), seed, int(site))
+        ctx.meta = (shape, a.shape, a.dtype, weight.dtype, bias.dtype, ydt, float(p_drop), seed, int(site))
         ctx.side_ok = _goes_to_optimizer(weight)
         ok, leaves = deferred.targets(weight, bias, gamma, beta)
         ctx.defer = (ok and bias.dtype in (torch.bfloat16, torch.float32), leaves)

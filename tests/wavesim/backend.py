@@ -97,6 +97,31 @@ def simulated_device(claim_cuda=False):
     patch(torch.cuda, "Event", _Event)
     patch(torch.cuda, "stream", lambda s: contextlib.nullcontext())
     patch(torch.cuda, "current_device", lambda: 0)
+    patch(torch.Tensor, "record_stream", lambda self, stream: None)
+
+    # torch.autocast("cuda") is switched off by torch itself on a host without a device.  The product's fused nodes ask
+    # torch.is_autocast_enabled("cuda") / get_autocast_dtype("cuda") and cast by hand, everything else relies on the dispatcher's
+    # autocast: both are served from the HOST autocast state while the model is active ("cuda" regions become "cpu" regions).
+    real_autocast, real_enabled, real_dtype = torch.autocast, torch.is_autocast_enabled, torch.get_autocast_dtype
+
+    class _Autocast(real_autocast):
+        def __init__(self, device_type, *a, **k):
+            super().__init__("cpu" if device_type == "cuda" else device_type, *a, **k)
+
+    # torch.mm / bmm(..., out_dtype=fp32) (bf16 operands, fp32 result) exist for the device backend only: same values on the host
+    real_mm, real_bmm = torch.mm, torch.bmm
+
+    def mm(a, b, out_dtype=None, **k):
+        return real_mm(a, b, **k) if out_dtype is None else real_mm(a.to(out_dtype), b.to(out_dtype), **k)
+
+    def bmm(a, b, out_dtype=None, **k):
+        return real_bmm(a, b, **k) if out_dtype is None else real_bmm(a.to(out_dtype), b.to(out_dtype), **k)
+
+    patch(torch, "mm", mm)
+    patch(torch, "bmm", bmm)
+    patch(torch, "autocast", _Autocast)
+    patch(torch, "is_autocast_enabled", lambda device_type=None: real_enabled("cpu" if device_type in (None, "cuda") else device_type))
+    patch(torch, "get_autocast_dtype", lambda device_type: real_dtype("cpu" if device_type == "cuda" else device_type))
     for mod in list(sys.modules.values()):
         name = getattr(mod, "__name__", "")
         if name.startswith("pointcloudmatters_amd") and hasattr(mod, "_raw_stream"):

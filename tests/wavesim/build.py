@@ -27,7 +27,7 @@ CLANG = os.environ.get("WAVESIM_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 # every kernel file of the library except graph_fix.hip (hipGraph surgery: runtime API, no kernel logic)
 SOURCES = ["fps.hip", "knn.hip", "ball.hip", "group.hip", "misc_ops.hip", "segsum.hip", "voxel.hip", "sa_scatter.hip", "sa_fused.hip",
            "bnrelu.hip", "drln.hip", "tokens.hip", "gnmish.hip", "ddpm.hip", "optim.hip", "ffn.hip", "ffn_mfma.hip", "attn_small.hip",
-           "attn_flash.hip"]
+           "attn_flash.hip", "proj_ln.hip"]
 FLAGS = ["-x", "c++", "-std=c++17", "-O1", "-g0", "-ffp-contract=off", "-fPIC", "-fno-strict-aliasing", "-Wno-everything",
          "-I", os.path.join(HERE, "include"), "-I", CSRC]
 
