@@ -425,6 +425,7 @@ def policy_kernels(t, wl, device, hidden=512):
 
     # ---- PointNet layer tail: BatchNorm1d + ReLU over the packed point features (widest layer: n x 512, tokenizer dtype) ----
     Cb = 512
+    tok_bf, tok_es, tok_name = (1, 2, "bf16") if TOKENIZER_BF16 else (0, 4, "float")
     tok_dt = torch.bfloat16 if tok_bf else torch.float32
     yb = torch.randn(n_tot, Cb, **f32).to(tok_dt)
     zb, dzb, dyb = torch.empty_like(yb), torch.randn(n_tot, Cb, **f32).to(tok_dt), torch.empty_like(yb)

@@ -194,6 +194,12 @@ def load():
     return lib
 
 
+def on_hip(device):
+    """Is `device` (a torch.device) the HIP device?  One place for the question the trainer and the flat optimizer ask before they
+    take the library path -- the product has no CPU path, they raise otherwise."""
+    return device.type == "cuda"
+
+
 def raw_stream():
     """hipStream_t (as an int) of torch's current stream on the current device.  The public route,
     `torch.cuda.current_stream().cuda_stream`, builds a Stream object and costs ~13 us per call -- 0.2 ms per training step

@@ -35,7 +35,7 @@ class FlatAdamW:
         params = [p for g in groups for p in g[0]]
         assert params, "no trainable parameters"
         dev = params[0].device
-        if dev.type != "cuda":
+        if not _lib.on_hip(dev):
             raise _lib.PointopsLibraryError("FlatAdamW runs on the HIP device only (CPU runs use torch.optim.AdamW)")
         assert all(p.dtype == torch.float32 and p.device == dev for p in params)
         self.lib = _lib.load()

@@ -23,6 +23,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
+from .. import _lib
 from .configs import ACT_OPTIM
 
 
@@ -164,7 +165,7 @@ class BCTrainer:
         self.log_every_n_steps = log_every_n_steps
         if mode not in ("eager", "flat", "graph", "hybrid"):
             raise ValueError(mode)
-        if self.device.type != "cuda" and mode != "eager" and (flat_optimizer_cls is None or mode == "graph"):
+        if not _lib.on_hip(self.device) and mode != "eager" and (flat_optimizer_cls is None or mode == "graph"):
             raise ValueError("flat/graph modes run on the HIP device only")
         self.mode = mode
         freeze_unused_parameters(policy)
@@ -208,7 +209,7 @@ class BCTrainer:
                 enable_sync_batchnorm(policy)
         # fused transformer tail ops (csrc/drln.hip, ffn.hip) need a device-resident dropout seed: flat / graph modes
         self._fused_ctx = None
-        if mode != "eager" and self.device.type == "cuda":
+        if mode != "eager" and _lib.on_hip(self.device):
             from ..policy.fused_ops import FusedContext
 
             self._fused_ctx = FusedContext(self.device)
@@ -240,13 +241,13 @@ class BCTrainer:
             params = [{"params": decay, "weight_decay": o["weight_decay"]}, {"params": no_decay, "weight_decay": 0.0}]
         if mode == "eager":
             if self.distributed:
-                ids = [self.device.index] if self.device.type == "cuda" else None
+                ids = [self.device.index] if _lib.on_hip(self.device) else None
                 self.module = nn.parallel.DistributedDataParallel(
                     self.policy, device_ids=ids, gradient_as_bucket_view=True, bucket_cap_mb=bucket_cap_mb,
                 )
             # build_optimizer(cfg, policy, None): one group, every parameter decayed (src/utils/optimizer.py:33-37)
             self.optimizer = torch.optim.AdamW(params, lr=o["lr"], weight_decay=o["weight_decay"], betas=betas,
-                                               fused=self.device.type == "cuda")
+                                               fused=_lib.on_hip(self.device))
             self.scheduler = torch.optim.lr_scheduler.OneCycleLR(
                 self.optimizer, max_lr=o["lr"], total_steps=total_steps, pct_start=o["pct_start"],
                 anneal_strategy="cos", div_factor=o["div_factor"], final_div_factor=o["final_div_factor"],
@@ -340,7 +341,7 @@ class BCTrainer:
     def _finish_exchange(self):
         """Join the slab all-reduces before the optimizer reads the gradients.  Two events bracket the join on the compute
         stream: their distance is the part of the gradient exchange that backward did NOT hide (exchange_stats())."""
-        timed = bool(self._works) and self.device.type == "cuda"
+        timed = bool(self._works) and _lib.on_hip(self.device)
         if timed:
             ring = self.__dict__.setdefault("_exchange_events", [])
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
