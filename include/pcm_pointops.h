@@ -367,6 +367,19 @@ int pcm_proj_drln_mfma_forward_hip(long R, int E, int K, const void *a_bf16, lon
                                    const long *seed, unsigned site, float *s, float *out, float *mean, float *rstd, const float *pos,
                                    long pos_n, void *sum_bf16, void *out_bf16, void *stream);
 
+/* out = A W^T + bias for short activations on the matrix cores, operand preparation fused in (csrc/proj_ln.hip): the in-projections of
+ * nn.MultiheadAttention and the cross-attention query projection (transformer.py:244-262, 296-346: `q = k = with_pos_embed(x, pos)`).
+ * A: a_is_f32 == 0: bf16 (R, K), row stride a_ls elements, for the output columns [0, pos_cols), and a_alt_bf16 (nullable, same layout)
+ * for the others; a_is_f32 == 1: fp32 x (R, K), row stride a_ls, converted to bf16 on the way in, with pos (nullable; pos_n fp32
+ * elements, a multiple of K, broadcast over the leading rows) ADDED first for the output columns [0, pos_cols) -- q and k of the packed
+ * in-projection -- and not for the others (v); emit_pos_bf16 / emit_x_bf16 (nullable, (R, K) bf16 contiguous) receive bf16(x + pos) /
+ * bf16(x), the operands of the backward's weight-gradient products.  W (N, K) bf16 row-major; bias (N) bf16 / fp32 / NULL; out (R, N)
+ * bf16 or fp32 with row stride out_ls.  K % 32 == 0 (<= 1024), N % 8 == 0, pos_cols a multiple of 256 or >= N. */
+int pcm_linear_mfma_supported(int N, int K, int pos_cols);
+int pcm_linear_mfma_forward_hip(long R, int N, int K, const void *a, int a_is_f32, long a_ls, const void *a_alt_bf16, const float *pos,
+                                long pos_n, int pos_cols, const void *w_bf16, const void *bias, int bias_is_bf16, void *out,
+                                int out_is_bf16, long out_ls, void *emit_pos_bf16, void *emit_x_bf16, void *stream);
+
 /* ---- fused feed-forward sub-layer  out = LayerNorm(x + dropout(W2 dropout(relu(W1 x + b1)) + b2)) ------------
  * replaces linear1 -> relu -> dropout -> linear2 -> dropout -> add -> norm of every transformer layer
  * (src/models/components/act/transformer.py:253-256, 342-345) for the shipped dim_feedforward = 32

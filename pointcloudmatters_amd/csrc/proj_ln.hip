@@ -216,3 +216,178 @@ extern "C" int pcm_proj_drln_mfma_forward_hip(long R, int E, int K, const void *
     }
 #undef PCM_PROJ
 }
+
+// ================================================================================================================================
+// pcm_linear_mfma: out = A W^T + bias for SHORT activations (R up to ~1000 rows: the decoder's and the CVAE encoder's in-projections
+// and the cross-attention query projection, transformer.py:244-262, 296-346), with the operand preparation fused in:
+//   * A is either bf16 (one matrix, or two: `a` for the output columns below `pos_cols`, `a_alt` for the others -- the operands a
+//     producer kernel already emitted), or fp32 x with the position embedding added on the way into LDS -- bf16(x + pos) for the
+//     columns below `pos_cols` (q and k of nn.MultiheadAttention's packed in-projection), bf16(x) for the others (v) -- which is what
+//     csrc/tokens.hip's add + cast kernels and the doubled-row product `[x + pos ; x] W^T` did in two launches and twice the FLOPs;
+//     the two bf16 operands can be written out as well (emit_*: the backward's weight-gradient products need them);
+//   * same streaming scheme as the kernel above: a 16-row A panel in LDS, the weight's rows straight from L2 into the 16x16x32 B
+//     operands two k-steps ahead; no LayerNorm here, so the columns are split too: one workgroup = 16 rows x 256 columns, 4 waves;
+//   * the accumulators (+ bias) are rounded once to the output type and leave through LDS as whole 16-byte pieces of a row.
+// ================================================================================================================================
+namespace {
+
+constexpr int kLW = 4;             // waves per workgroup
+constexpr int kLThreads = 64 * kLW;
+constexpr int kLN = 256;           // columns per workgroup
+constexpr int kLT = kLN / (16 * kLW);  // 16-column tiles per wave (4)
+
+template <bool OUT_BF16>
+__global__ __launch_bounds__(kLThreads) void pcm_linear_mfma_kernel(long R, int N, int K, const void *__restrict__ a, int a_is_f32,
+                                                                    long a_ls, const u16 *__restrict__ a_alt, const float *__restrict__ pos,
+                                                                    long pos_n, int pos_cols, const u16 *__restrict__ W,
+                                                                    const void *__restrict__ bias, int bias_is_bf16, void *__restrict__ out,
+                                                                    long out_ls, u16 *__restrict__ emit_pos16, u16 *__restrict__ emit_x16)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
+    const int AS = K + kAPad;
+    u16 *As = reinterpret_cast<u16 *>(smem2);  // [kTM][AS] bf16; reused for the output tile after the products
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const long r0 = (long)blockIdx.x * kTM;
+    const int c0 = blockIdx.y * kLN;           // first output column of this workgroup
+    const bool below = c0 < pos_cols;          // this workgroup's columns see the FIRST operand (x + pos, or `a`)
+    const bool with_pos = a_is_f32 && pos != nullptr && below;
+    // the bf16 operands are the backward's weight-gradient operands: written out once, by the first column block of either kind
+    u16 *emit = nullptr;
+    if (a_is_f32) emit = with_pos ? (blockIdx.y == 0 ? emit_pos16 : nullptr) : ((c0 == (pos != nullptr ? pos_cols : 0)) ? emit_x16 : nullptr);
+
+    // ---- A panel -> LDS as bf16 (rows past R are zero)
+    if (a_is_f32) {
+        const float *x = reinterpret_cast<const float *>(a);
+        const int chunks = K / 4;  // float4 pieces per row
+        for (int c = tid; c < kTM * chunks; c += kLThreads) {
+            const int i = c / chunks, kc = c % chunks;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (r0 + i < R) {
+                load4<float>(x + (r0 + i) * a_ls + kc * 4, v);
+                if (with_pos) {
+                    float p[4];
+                    load4<float>(pos + ((r0 + i) * (long)K) % pos_n + kc * 4, p);  // K divides pos_n: a row never wraps
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] += p[u];
+                }
+            }
+            const uint2 pk = make_uint2(pcm_cvt_pk_bf16(v[0], v[1]), pcm_cvt_pk_bf16(v[2], v[3]));
+            *reinterpret_cast<uint2 *>(As + i * AS + kc * 4) = pk;
+            if (emit != nullptr && r0 + i < R) *reinterpret_cast<uint2 *>(emit + (r0 + i) * (long)K + kc * 4) = pk;
+        }
+    } else {
+        const u16 *ab = (!below && a_alt != nullptr) ? a_alt : reinterpret_cast<const u16 *>(a);
+        const int chunks = K / 8;
+        for (int c = tid; c < kTM * chunks; c += kLThreads) {
+            const int i = c / chunks, kc = c % chunks;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (r0 + i < R) v = *reinterpret_cast<const uint4 *>(ab + (r0 + i) * a_ls + kc * 8);
+            *reinterpret_cast<uint4 *>(As + i * AS + kc * 8) = v;
+        }
+    }
+
+    // ---- products (columns past N: the weight row index is clamped, the results are not stored)
+    const int n0 = c0 + w * (kLN / kLW), li = lane & 15, lk = 8 * (lane >> 4);
+    const u16 *wrow[kLT];
+#pragma unroll
+    for (int t = 0; t < kLT; ++t) {
+        int col = n0 + 16 * t + li;
+        col = col < N ? col : N - 1;
+        wrow[t] = W + (long)col * K + lk;
+    }
+    f4v acc[kLT];
+#pragma unroll
+    for (int t = 0; t < kLT; ++t) acc[t] = f4v{0.f, 0.f, 0.f, 0.f};
+    const int ksteps = K / 32;
+    bf8 b0[kLT], b1[kLT];
+#pragma unroll
+    for (int t = 0; t < kLT; ++t) {
+        b0[t] = ldg_bf8(wrow[t]);
+        b1[t] = ksteps > 1 ? ldg_bf8(wrow[t] + 32) : b0[t];
+    }
+    __syncthreads();  // A panel complete
+    for (int kt = 0; kt < ksteps; ++kt) {
+        bf8 b2[kLT];
+        const bool more = kt + 2 < ksteps;
+#pragma unroll
+        for (int t = 0; t < kLT; ++t) b2[t] = more ? ldg_bf8(wrow[t] + 32 * (kt + 2)) : b1[t];
+        const bf8 af = lds_bf8(As + li * AS + 32 * kt + lk);
+#pragma unroll
+        for (int t = 0; t < kLT; ++t) acc[t] = PCM_MFMA_16x16x32(af, b0[t], acc[t]);
+#pragma unroll
+        for (int t = 0; t < kLT; ++t) b0[t] = b1[t], b1[t] = b2[t];
+    }
+    __syncthreads();  // every wave is done with the A panel: the same LDS now takes the output tile
+
+    // ---- + bias -> output tile in LDS [kTM][kLN] (fp32, or bf16 packed two per word), then whole 16-byte pieces to global
+    constexpr int OS = OUT_BF16 ? kLN + 8 : kLN + 4;  // elements per LDS row (padding keeps the scattered accumulator stores apart)
+    u16 *Ob = reinterpret_cast<u16 *>(smem2);
+    float *Of = reinterpret_cast<float *>(smem2);
+#pragma unroll
+    for (int t = 0; t < kLT; ++t) {
+        const int lc = w * (kLN / kLW) + 16 * t + li, col = c0 + lc;
+        float bv = 0.f;
+        if (bias != nullptr && col < N)
+            bv = bias_is_bf16 ? bf2f(reinterpret_cast<const u16 *>(bias)[col]) : reinterpret_cast<const float *>(bias)[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float y = acc[t][r] + bv;
+            const int row = 4 * (lane >> 4) + r;
+            if (OUT_BF16) Ob[row * OS + lc] = (u16)(pcm_cvt_pk_bf16(y, 0.f) & 0xFFFFu);
+            else Of[row * OS + lc] = y;
+        }
+    }
+    __syncthreads();
+    constexpr int EPB = OUT_BF16 ? 8 : 4;           // elements per 16-byte piece
+    constexpr int pieces = kLN / EPB;               // pieces per row
+    for (int c = tid; c < kTM * pieces; c += kLThreads) {
+        const int i = c / pieces, pc = c % pieces, col = c0 + pc * EPB;
+        if (r0 + i >= R || col >= N) continue;      // N % 8 == 0: a piece is inside or outside as a whole
+        if (OUT_BF16)
+            *reinterpret_cast<uint4 *>(reinterpret_cast<u16 *>(out) + (r0 + i) * out_ls + col) = *reinterpret_cast<const uint4 *>(Ob + i * OS + pc * EPB);
+        else
+            *reinterpret_cast<uint4 *>(reinterpret_cast<float *>(out) + (r0 + i) * out_ls + col) = *reinterpret_cast<const uint4 *>(Of + i * OS + pc * EPB);
+    }
+}
+
+inline size_t linear_smem_bytes(int K, int out_bf16)
+{
+    const size_t a = (size_t)kTM * (K + kAPad) * 2, o = out_bf16 ? (size_t)kTM * (kLN + 8) * 2 : (size_t)kTM * (kLN + 4) * 4;
+    return a > o ? a : o;
+}
+
+}  // namespace
+
+// K: multiples of 32 up to 1024; N: a multiple of 8; pos_cols: 0, N or a multiple of 256 (a workgroup's 256 columns see ONE operand)
+extern "C" int pcm_linear_mfma_supported(int N, int K, int pos_cols)
+{
+    return N > 0 && N % 8 == 0 && K >= 32 && K <= 1024 && K % 32 == 0 && pos_cols >= 0 && (pos_cols % kLN == 0 || pos_cols >= N);
+}
+
+extern "C" int pcm_linear_mfma_forward_hip(long R, int N, int K, const void *a, int a_is_f32, long a_ls, const void *a_alt_bf16,
+                                           const float *pos, long pos_n, int pos_cols, const void *w_bf16, const void *bias,
+                                           int bias_is_bf16, void *out, int out_is_bf16, long out_ls, void *emit_pos_bf16,
+                                           void *emit_x_bf16, void *stream)
+{
+    if (R < 0 || N <= 0 || K <= 0 || a_ls < K || out_ls < N) return PCM_ERR_BAD_ARG;
+    if (!pcm_linear_mfma_supported(N, K, pos_cols)) return PCM_ERR_UNSUPPORTED;
+    if (R == 0) return PCM_OK;
+    if (!a || !w_bf16 || !out) return PCM_ERR_BAD_ARG;
+    if (pos != nullptr && (!a_is_f32 || pos_n <= 0 || pos_n % K != 0)) return PCM_ERR_BAD_ARG;
+    if (a_alt_bf16 != nullptr && (a_is_f32 || ((uintptr_t)a_alt_bf16 % 16) != 0)) return PCM_ERR_BAD_ARG;  // second bf16 operand only
+    if ((emit_pos_bf16 != nullptr || emit_x_bf16 != nullptr) && !a_is_f32) return PCM_ERR_BAD_ARG;
+    if (emit_pos_bf16 != nullptr && (pos == nullptr || pos_cols <= 0)) return PCM_ERR_BAD_ARG;
+    if (emit_x_bf16 != nullptr && pos != nullptr && pos_cols >= N) return PCM_ERR_BAD_ARG;  // no column block sees plain x
+    const long a_align = a_is_f32 ? 4 : 8, o_align = out_is_bf16 ? 8 : 4;  // 16-byte loads / stores
+    if (a_ls % a_align || out_ls % o_align || (((uintptr_t)a | (uintptr_t)w_bf16 | (uintptr_t)out) % 16) != 0) return PCM_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)((R + kTM - 1) / kTM), (unsigned)((N + kLN - 1) / kLN));
+    const size_t smem = linear_smem_bytes(K, out_is_bf16);
+    if (out_is_bf16)
+        hipLaunchKernelGGL(pcm_linear_mfma_kernel<true>, grid, dim3(kLThreads), smem, st, R, N, K, a, a_is_f32, a_ls, (const u16 *)a_alt_bf16, pos,
+                           pos_n, pos_cols, (const u16 *)w_bf16, bias, bias_is_bf16, out, out_ls, (u16 *)emit_pos_bf16, (u16 *)emit_x_bf16);
+    else
+        hipLaunchKernelGGL(pcm_linear_mfma_kernel<false>, grid, dim3(kLThreads), smem, st, R, N, K, a, a_is_f32, a_ls, (const u16 *)a_alt_bf16, pos,
+                           pos_n, pos_cols, (const u16 *)w_bf16, bias, bias_is_bf16, out, out_ls, (u16 *)emit_pos_bf16, (u16 *)emit_x_bf16);
+    return PCM_LAUNCH_STATUS();
+}

@@ -200,6 +200,33 @@ PROJ_MFMA = os.environ.get("PCM_PROJ_MFMA", "0") != "0"
 PROJ_MFMA_MAX_ROWS = int(os.environ.get("PCM_PROJ_MFMA_MAX_ROWS", "1024"))
 
 
+LINEAR_MFMA = os.environ.get("PCM_LINEAR_MFMA", "0") != "0"  # csrc/proj_ln.hip pcm_linear_mfma: same status as PROJ_MFMA (opt-in, untimed)
+
+
+def _linear_mfma(rows, wc, bc, out, *, a16=None, a16_alt=None, x32=None, posc=None, pos_cols=0, emit_pos16=None, emit_x16=None):
+    """out (rows, N) = A @ wc^T + bc through csrc/proj_ln.hip's pcm_linear_mfma: A = bf16 operands (a16 for the output columns below
+    pos_cols, a16_alt for the others) or fp32 x32 (+ posc below pos_cols), whose bf16 forms go to emit_* as well."""
+    N, K = wc.shape
+    a = a16 if a16 is not None else x32
+    ptr = lambda t: 0 if t is None else t.data_ptr()  # noqa: E731
+    with torch.cuda.device(out.device):
+        rc = _lib.load().pcm_linear_mfma_forward_hip(rows, int(N), int(K), a.data_ptr(), int(a16 is None), int(a.stride(0)), ptr(a16_alt),
+                                                     ptr(posc), posc.numel() if posc is not None else 0, int(pos_cols), wc.data_ptr(),
+                                                     ptr(bc), int(bc is not None and bc.dtype == torch.bfloat16), out.data_ptr(),
+                                                     int(out.dtype == torch.bfloat16), int(out.stride(0)), ptr(emit_pos16), ptr(emit_x16),
+                                                     _raw_stream())
+    _lib.check(rc, "pcm_linear_mfma_forward_hip")
+    return out
+
+
+def _linear_mfma_ok(rows, wc, bc, pos_cols, *operands):
+    N, K = wc.shape
+    return (LINEAR_MFMA and 0 < rows <= PROJ_MFMA_MAX_ROWS and wc.is_cuda and wc.dtype == torch.bfloat16 and wc.is_contiguous()
+            and (bc is None or (bc.is_contiguous() and bc.dtype in (torch.bfloat16, torch.float32)))
+            and all(t is None or (t.stride(-1) == 1 and t.data_ptr() % 16 == 0 and t.stride(0) % 8 == 0) for t in operands)
+            and wc.data_ptr() % 16 == 0 and bool(_lib.load().pcm_linear_mfma_supported(int(N), int(K), int(pos_cols))))
+
+
 def _proj_mfma_ok(a2, wc, bc, x2):
     R, E = x2.shape
     return (PROJ_MFMA and a2.is_cuda and 0 < R <= PROJ_MFMA_MAX_ROWS and a2.dtype == torch.bfloat16 and wc.dtype == torch.bfloat16
@@ -547,16 +574,30 @@ class _SelfAttnInProj(Function):
         wc = w if w.dtype == bf else w.to(bf)
         bc = b if b.dtype == bf else b.to(bf)
         em = _emitted(x, pos, posc)
-        if em is not None and em["x16"] is not None:  # the producer of x wrote bf16(x + pos) and bf16(x) in its own launch
+        have16 = em is not None and em["x16"] is not None  # the producer of x wrote bf16(x + pos) and bf16(x) in its own launch
+        mfma = _linear_mfma_ok(rows, wc, bc, 2 * E, em["sum16"], em["x16"]) if have16 else _linear_mfma_ok(rows, wc, bc, 2 * E, x2)
+        if have16:
             qk_in, v_in = em["sum16"], em["x16"]
         else:
             with torch.cuda.device(dev):
                 qk_in, v_in = deferred.take((2, rows, E), bf, dev, "in_proj.qkv").unbind(0)  # adjacent: see the merged product
-                rc = L.pcm_add_cast2_hip(x2.numel(), posc.numel(), x2.data_ptr(), posc.data_ptr(), qk_in.data_ptr(), v_in.data_ptr(),
-                                         _raw_stream())
-            _lib.check(rc, "pcm_add_cast2_hip")
+                if not mfma:
+                    rc = L.pcm_add_cast2_hip(x2.numel(), posc.numel(), x2.data_ptr(), posc.data_ptr(), qk_in.data_ptr(), v_in.data_ptr(),
+                                             _raw_stream())
+                    _lib.check(rc, "pcm_add_cast2_hip")
         with torch.autocast("cuda", enabled=False):
-            if (INPROJ_MERGE_ROWS > rows and v_in.data_ptr() - qk_in.data_ptr() == rows * E * 2 and qk_in.is_contiguous()
+            if mfma:
+                # ONE launch: the add + casts happen on the way into LDS (or the emitted operands are read), q | k | v in one (rows, 3E)
+                # matrix without the doubled-row trick below; the bf16 operands are written out for the weight-gradient products
+                with torch.cuda.device(dev):
+                    y = torch.empty(rows, 3 * E, dtype=bf, device=dev)
+                if have16:
+                    _linear_mfma(rows, wc, bc, y, a16=qk_in, a16_alt=v_in, pos_cols=2 * E)
+                else:
+                    _linear_mfma(rows, wc, bc, y, x32=x2, posc=posc, pos_cols=2 * E, emit_pos16=qk_in, emit_x16=v_in)
+                qk = y[:, : 2 * E].unflatten(-1, (2, E)).unflatten(0, shape[:-1])
+                v = y[:, 2 * E:].unflatten(0, shape[:-1])
+            elif (INPROJ_MERGE_ROWS > rows and v_in.data_ptr() - qk_in.data_ptr() == rows * E * 2 and qk_in.is_contiguous()
                     and v_in.is_contiguous() and qk_in.untyped_storage().data_ptr() == v_in.untyped_storage().data_ptr()):
                 # short activations (the decoder's 800 rows): ONE product [x + pos ; x] (2R, E) @ W^T (E, 3E) instead of two -- twice
                 # the arithmetic (the off-diagonal blocks are discarded), but these products sit at the launch floor: 11 us vs
@@ -678,16 +719,28 @@ class _AddPosLinear(Function):
         wc = w if w.dtype == bf else w.to(bf)
         bc = b if b.dtype == bf else b.to(bf)
         em = _emitted(x, pos, posc)
+        rows, N = x2.shape[0], wc.shape[0]
+        mfma = _linear_mfma_ok(rows, wc, bc, N, em["sum16"] if em is not None else x2)
         if em is not None:  # the producer of x wrote bf16(x + pos) in its own launch
             s_in = em["sum16"]
         else:
             with torch.cuda.device(x.device):
                 s_in = deferred.take(x2.shape, bf, x.device, "add_pos.s")
-                rc = L.pcm_add_cast2_hip(x2.numel(), posc.numel(), x2.data_ptr(), posc.data_ptr(), s_in.data_ptr(), 0,
-                                         _raw_stream())
-            _lib.check(rc, "pcm_add_cast2_hip")
+                if not mfma:
+                    rc = L.pcm_add_cast2_hip(x2.numel(), posc.numel(), x2.data_ptr(), posc.data_ptr(), s_in.data_ptr(), 0,
+                                             _raw_stream())
+                    _lib.check(rc, "pcm_add_cast2_hip")
         with torch.autocast("cuda", enabled=False):
-            y = torch.nn.functional.linear(s_in, wc, bc).view(*shape[:-1], wc.shape[0])
+            if mfma:  # one launch; bf16(x + pos) is still written out: it is the weight-gradient product's operand
+                with torch.cuda.device(x.device):
+                    y = torch.empty(rows, N, dtype=bf, device=x.device)
+                if em is not None:
+                    _linear_mfma(rows, wc, bc, y, a16=s_in, pos_cols=N)
+                else:
+                    _linear_mfma(rows, wc, bc, y, x32=x2, posc=posc, pos_cols=N, emit_pos16=s_in)
+                y = y.view(*shape[:-1], N)
+            else:
+                y = torch.nn.functional.linear(s_in, wc, bc).view(*shape[:-1], wc.shape[0])
         ctx.save_for_backward(s_in, wc)
         ctx.meta = (shape, pos.shape, w.dtype, b.dtype)
         ctx.side_ok = _goes_to_optimizer(w)

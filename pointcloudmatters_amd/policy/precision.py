@@ -17,7 +17,9 @@ Every layer of the tokenizer is a Linear followed by a training-mode BatchNorm: 
 deviation of its input, while bf16 rounds that input relative to its MAGNITUDE (mean included), and the backward pass subtracts two
 nearly equal sums.  Six such layers in sequence turn a 2^-9 rounding into gradients that are tens of per cent off -- in ANY bf16
 evaluation, the framework's included -- and the U-Net then trains on a perturbed condition.  The tokenizer is 1 - 3 % of the step's
-FLOPs and bound by gathers, not by the matrix cores, so bf16 buys next to nothing there.
+FLOPs and bound by gathers, not by the matrix cores, so bf16 buys next to nothing there.  A half-way recipe does not help: bf16
+OPERANDS with fp32 accumulation and fp32 outputs in the tokenizer's products (what a bf16-in / fp32-out GEMM would give at bf16 speed)
+leave the worst tensor at 21 - 28 % (same log, rows "bS" / "bs"): the chain amplifies a 2^-9 perturbation wherever it enters.
 
 `tokenizer_fp32` is a class attribute of ACTPCD / PCDObsEncoder (True); set it to False on an instance (or through
 `set_tokenizer_fp32`) for the previous behaviour, autocast everywhere.

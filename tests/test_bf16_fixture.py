@@ -173,16 +173,33 @@ def _fused_bf16(pol, batch, dev):
 
 
 @pytest.mark.gpu
-def test_act_bf16_fused_within_ten_percent_of_the_reference_gpu(hip_device):
+@pytest.mark.parametrize("mfma_chain", [False, True])
+def test_act_bf16_fused_within_ten_percent_of_the_reference_gpu(hip_device, monkeypatch, mfma_chain):
+    """mfma_chain: the projection chains through csrc/proj_ln.hip (output projection + residual + norm, in-projections with the
+    position add fused in: opt-in, PCM_PROJ_MFMA / PCM_LINEAR_MFMA) -- the same bound holds for them."""
     import pointcloudmatters_amd.pointops as po
+    from pointcloudmatters_amd import _lib
+    from pointcloudmatters_amd.policy import fused_ops
 
+    monkeypatch.setattr(fused_ops, "PROJ_MFMA", mfma_chain)
+    monkeypatch.setattr(fused_ops, "LINEAR_MFMA", mfma_chain)
+    seen, orig = [], _lib.check
+
+    def check(rc, what, *a, **kw):
+        seen.append(what)
+        return orig(rc, what, *a, **kw)
+
+    monkeypatch.setattr(_lib, "check", check)
     fx, pol, batch = _act_case(po, "fused", device=hip_device)
     out = _fused_bf16(pol, batch, hip_device)
+    # decoder (800 rows) + CVAE encoder (816 rows) sites take the new kernels; the 1048-row encoder site stays with the library
+    assert (seen.count("pcm_proj_drln_mfma_forward_hip") >= 4 and seen.count("pcm_linear_mfma_forward_hip") >= 4) == mfma_chain, \
+        (seen.count("pcm_proj_drln_mfma_forward_hip"), seen.count("pcm_linear_mfma_forward_hip"))
     for k in ("a_hat", "mu", "logvar", "loss", "action_loss", "kl_loss", "src"):
         ref = fx[f"act.out.{k}"]
         assert np.abs(out[k].detach().float().cpu().numpy() - ref).max() <= OUT_RTOL * np.abs(ref).max(), k
     med, worst = _judge(fx, "act", _errors(fx, "act.grad.", pol), 90, 75)
-    print(f"act bf16 fused vs fp32 reference: median {med:.4f}, worst tensor {worst:.4f}")
+    print(f"act bf16 fused (mfma_chain={mfma_chain}) vs fp32 reference: median {med:.4f}, worst tensor {worst:.4f}")
     assert med < 0.02
 
 

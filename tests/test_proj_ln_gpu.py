@@ -175,3 +175,128 @@ def test_fused_node_with_and_without_the_matrix_core_kernel(monkeypatch, p):
         assert (got - want).abs().max().item() <= 2e-2 * scale + 1e-6, (name, (got - want).abs().max().item(), scale)
     # the residual stream is where a different mask would show: dropped positions pass x's gradient only
     assert (runs[True][2] - runs[False][2]).abs().mean().item() <= 2e-3 * runs[False][2].abs().mean().item() + 1e-7
+
+
+# ------------------------------------------------------------------------------------------------------- pcm_linear_mfma
+def _linear(a, W, bias, pos=None, pos_cols=0, out_dtype=torch.bfloat16, a_ls=None, out=None, a_alt=None, emit=(None, None)):
+    from pointcloudmatters_amd import _lib
+
+    L = _lib.load()
+    R, K = a.shape[0], W.shape[1]
+    N = W.shape[0]
+    if out is None:
+        out = torch.empty(R, N, dtype=out_dtype, device=a.device)
+    ptr = lambda t: 0 if t is None else t.data_ptr()  # noqa: E731
+    rc = L.pcm_linear_mfma_forward_hip(R, N, K, ptr(a), int(a.dtype == torch.float32), a_ls if a_ls is not None else a.stride(0), ptr(a_alt),
+                                       ptr(pos), pos.numel() if pos is not None else 0, pos_cols, ptr(W), ptr(bias),
+                                       int(bias is not None and bias.dtype == torch.bfloat16), ptr(out), int(out.dtype == torch.bfloat16),
+                                       out.stride(0), ptr(emit[0]), ptr(emit[1]), _lib.raw_stream())
+    _lib.check(rc, "pcm_linear_mfma_forward_hip")
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("R,N,K", [(800, 1536, 512), (816, 512, 512), (37, 264, 64), (1, 8, 32), (100, 768, 1024)])
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
+def test_linear_from_bf16_rows(R, N, K, out_dtype):
+    a, W, bias, *_ = _inputs(R, N, K, 11 * R + N)
+    got = _linear(a, W, bias, out_dtype=out_dtype)
+    want = a.double() @ W.double().t() + bias.double()
+    if out_dtype == torch.float32:
+        torch.testing.assert_close(got.double(), want, rtol=2e-5, atol=2e-5 * K ** 0.5)
+    else:  # one rounding to bf16 of an fp32 sum: within one bf16 step of the exact value
+        assert ((got.double() - want).abs() <= want.abs().clamp_min(1e-2) * 2.0 ** -7).all()
+
+
+def test_in_projection_with_position_embedding_fused():
+    """q | k | v = in_proj([x + pos ; x]): what csrc/tokens.hip's add + cast launch and the doubled-row product did -- columns below
+    pos_cols (q, k) see bf16(x + pos), the others (v) bf16(x); pos is the decoder's (100, 1, E) query_pos broadcast over the batch."""
+    E, B, Lq = 512, 8, 100
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(Lq * B, E, generator=g).to(DEV)
+    pos = torch.randn(Lq, E, generator=g).to(DEV)  # rows (query, batch)-major would need an expanded pos; here batch-major rows: block of Lq
+    W = (torch.randn(3 * E, E, generator=g) / E ** 0.5).bfloat16().to(DEV)
+    bias = (0.1 * torch.randn(3 * E, generator=g)).bfloat16().to(DEV)
+    got = _linear(x, W, bias, pos=pos, pos_cols=2 * E)
+    xp = (x + pos.repeat(B, 1)).bfloat16().double()
+    want_qk = xp @ W[: 2 * E].double().t() + bias[: 2 * E].double()
+    want_v = x.bfloat16().double() @ W[2 * E:].double().t() + bias[2 * E:].double()
+    want = torch.cat([want_qk, want_v], 1)
+    assert ((got.double() - want).abs() <= want.abs().clamp_min(1e-2) * 2.0 ** -7).all()
+    # the query projection of the cross-attention: every column sees x + pos; fp32 operand without pos = a plain cast
+    q = _linear(x, W[:E].contiguous(), bias[:E].contiguous(), pos=pos, pos_cols=E)
+    assert torch.equal(q, got[:, :E].contiguous())
+    v = _linear(x, W[2 * E:].contiguous(), bias[2 * E:].contiguous())
+    assert torch.equal(v, got[:, 2 * E:].contiguous())
+    # the bf16 operands written out by the same launch (the backward's weight-gradient operands) ...
+    e_pos, e_x = torch.empty(Lq * B, E, dtype=torch.bfloat16, device=DEV), torch.empty(Lq * B, E, dtype=torch.bfloat16, device=DEV)
+    again = _linear(x, W, bias, pos=pos, pos_cols=2 * E, emit=(e_pos, e_x))
+    assert torch.equal(again, got)
+    assert torch.equal(e_pos, (x + pos.repeat(B, 1)).bfloat16()) and torch.equal(e_x, x.bfloat16())
+    # ... and the same product from operands a producer emitted: two bf16 matrices
+    assert torch.equal(_linear(e_pos, W, bias, pos_cols=2 * E, a_alt=e_x), got)
+
+
+def test_linear_strided_operands_and_contract():
+    from pointcloudmatters_amd import _lib
+
+    L = _lib.load()
+    R, N, K = 50, 512, 256
+    a, W, bias, *_ = _inputs(R, N, K, 5)
+    wide_a = torch.zeros(R, K + 32, dtype=torch.bfloat16, device=DEV)
+    wide_a[:, :K] = a
+    wide_o = torch.full((R, N + 16), 7.0, dtype=torch.bfloat16, device=DEV)
+    ref = _linear(a, W, bias)
+    _linear(wide_a[:, :K], W, bias, out=wide_o[:, :N])
+    assert torch.equal(wide_o[:, :N], ref) and bool((wide_o[:, N:] == 7.0).all())  # nothing written past a row's N columns
+    assert L.pcm_linear_mfma_supported(1536, 512, 1024) == 1 and L.pcm_linear_mfma_supported(1536, 512, 100) == 0
+    assert L.pcm_linear_mfma_supported(12, 512, 0) == 0 and L.pcm_linear_mfma_supported(512, 48, 0) == 0
+    assert L.pcm_linear_mfma_forward_hip(-1, 512, 512, 0, 0, 512, 0, 0, 0, 0, 0, 0, 0, 0, 1, 512, 0, 0, 0) == 1
+    assert L.pcm_linear_mfma_forward_hip(0, 512, 512, 0, 0, 512, 0, 0, 0, 0, 0, 0, 0, 0, 1, 512, 0, 0, 0) == 0
+
+
+@pytest.mark.parametrize("batch_first_pos", [False, True])
+def test_in_projection_nodes_with_and_without_the_matrix_core_kernel(monkeypatch, batch_first_pos):
+    """fused_ops.self_attn_in_proj and add_pos_linear (one autograd node each) with LINEAR_MFMA on against the add + cast launch and the
+    library product(s): q / k / v and every gradient equal up to one bf16 rounding of the products."""
+    import torch.nn as nn
+
+    from pointcloudmatters_amd.policy import fused_ops
+
+    torch.manual_seed(8)
+    E, B, Lq = 512, 8, 100
+    mha = nn.MultiheadAttention(E, 8).to(DEV)
+    lin = nn.Linear(E, E).to(DEV)
+    x0 = torch.randn(B, Lq, E, device=DEV)
+    pos0 = torch.randn(1 if batch_first_pos else B, Lq, E, device=DEV)
+    gq, gk, gv, gy = (torch.randn(B, Lq, E, device=DEV).bfloat16() for _ in range(4))
+    called, orig = [], fused_ops._lib.check
+
+    def check(rc, what, *args, **kw):
+        called.append(what)
+        return orig(rc, what, *args, **kw)
+
+    monkeypatch.setattr(fused_ops._lib, "check", check)
+    runs = {}
+    for flag in (False, True):
+        monkeypatch.setattr(fused_ops, "LINEAR_MFMA", flag)
+        x, pos = x0.clone().requires_grad_(True), pos0.clone().requires_grad_(True)
+        for p_ in list(mha.parameters()) + list(lin.parameters()):
+            p_.grad = None
+        ctx = fused_ops.FusedContext(torch.device(DEV))
+        called.clear()
+        with fused_ops.activate(ctx), torch.autocast("cuda", dtype=torch.bfloat16):
+            assert fused_ops.self_attn_in_proj_supported(x, pos, mha) and fused_ops.add_pos_linear_supported(x, pos, lin.weight, lin.bias)
+            q, k, v, xr = fused_ops.self_attn_in_proj(x, pos, mha)
+            y = fused_ops.add_pos_linear(xr, pos, lin.weight, lin.bias)
+        assert (called.count("pcm_linear_mfma_forward_hip") == 2) == flag, called
+        assert ("pcm_add_cast2_hip" in called) != flag, called
+        ((q * gq).float().sum() + (k * gk).float().sum() + (v * gv).float().sum() + (y * gy).float().sum()).backward()
+        torch.cuda.synchronize()
+        runs[flag] = [q.float(), k.float(), v.float(), y.float(), x.grad, pos.grad, mha.in_proj_weight.grad.float(), mha.in_proj_bias.grad.float(),
+                      lin.weight.grad.float(), lin.bias.grad.float()]
+    for got, want, name in zip(runs[True], runs[False], ("q", "k", "v", "y", "dx", "dpos", "dW_in", "db_in", "dW", "db")):
+        scale = want.abs().max().item()
+        assert (got - want).abs().max().item() <= 2e-2 * scale + 1e-6, (name, (got - want).abs().max().item(), scale)
+    for i in range(4):  # the forward values differ only by the summation order inside one bf16 rounding
+        assert (runs[True][i] - runs[False][i]).abs().mean().item() <= 2e-3 * runs[False][i].abs().mean().item()
