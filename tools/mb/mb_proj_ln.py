@@ -1,0 +1,77 @@
+"""csrc/proj_ln.hip against what it replaces, by graph replay (device time per launch, no host launch cost):
+  A  out_proj + residual + norm:  library bf16 product (F.linear) + pcm_drln_forward_hip      vs  pcm_proj_drln_mfma_forward_hip
+  B  packed in-projection:        pcm_add_cast2_hip + the doubled-row product [x + pos ; x] W^T  vs  pcm_linear_mfma_forward_hip (fp32 x + pos in)
+  C  query projection:            pcm_add_cast2_hip + library product                          vs  pcm_linear_mfma_forward_hip
+at the row counts of the ACT step (decoder 800, CVAE encoder 816, encoder 4120 at C2).  Written in round 5 while the GPU pool was closed:
+the FIRST thing to run when it opens --   python tools/mb/mb_proj_ln.py > gpurun_out/mb_proj_ln.log"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from bench import timed_events  # noqa: E402
+from pointcloudmatters_amd import _lib  # noqa: E402
+
+L = _lib.load()
+dev = torch.device("cuda", 0)
+f32, bf = dict(dtype=torch.float32, device=dev), dict(dtype=torch.bfloat16, device=dev)
+E = 512
+
+
+def graphed(fn, n=20):
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(n):
+                fn(torch.cuda.current_stream().cuda_stream)
+    return timed_events(g.replay, 20) * 1e3 / n
+
+
+for R in (800, 816, 4120):
+    a = torch.randn(R, E, **f32).bfloat16()
+    W, b = (torch.randn(E, E, **f32) / E ** 0.5).bfloat16(), torch.zeros(E, **bf)
+    W3, b3 = (torch.randn(3 * E, E, **f32) / E ** 0.5).bfloat16(), torch.zeros(3 * E, **bf)
+    x, pos = torch.randn(R, E, **f32), torch.randn(100 if R % 100 == 0 else R, E, **f32)
+    gamma, beta = torch.ones(E, **f32), torch.zeros(E, **f32)
+    seed = torch.zeros(1, dtype=torch.int64, device=dev)
+    s, out, mean, rstd = torch.empty(R, E, **f32), torch.empty(R, E, **f32), torch.empty(R, **f32), torch.empty(R, **f32)
+    y16 = torch.empty(R, E, **bf)
+    pair = torch.empty(2, R, E, **bf)
+    y3, y1 = torch.empty(R, 3 * E, **bf), torch.empty(R, E, **bf)
+
+    def lib_a(st):
+        torch.nn.functional.linear(a, W, b, )  # result allocated by the framework, like in the step
+        assert L.pcm_drln_forward_hip(R, E, 1, x.data_ptr(), y16.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.1, seed.data_ptr(), 3,
+                                      s.data_ptr(), out.data_ptr(), mean.data_ptr(), rstd.data_ptr(), st) == 0
+
+    def new_a(st):
+        assert L.pcm_proj_drln_mfma_forward_hip(R, E, E, a.data_ptr(), E, W.data_ptr(), b.data_ptr(), 1, x.data_ptr(), gamma.data_ptr(),
+                                                beta.data_ptr(), 1e-5, 0.1, seed.data_ptr(), 3, s.data_ptr(), out.data_ptr(), mean.data_ptr(),
+                                                rstd.data_ptr(), 0, 0, 0, 0, st) == 0
+
+    def lib_b(st):
+        assert L.pcm_add_cast2_hip(x.numel(), pos.numel(), x.data_ptr(), pos.data_ptr(), pair[0].data_ptr(), pair[1].data_ptr(), st) == 0
+        torch.nn.functional.linear(pair.view(2 * R, E), W3, b3)
+
+    def new_b(st):
+        assert L.pcm_linear_mfma_forward_hip(R, 3 * E, E, x.data_ptr(), 1, E, 0, pos.data_ptr(), pos.numel(), 2 * E, W3.data_ptr(), b3.data_ptr(), 1,
+                                             y3.data_ptr(), 1, 3 * E, pair[0].data_ptr(), pair[1].data_ptr(), st) == 0
+
+    def lib_c(st):
+        assert L.pcm_add_cast2_hip(x.numel(), pos.numel(), x.data_ptr(), pos.data_ptr(), pair[0].data_ptr(), 0, st) == 0
+        torch.nn.functional.linear(pair[0], W, b)
+
+    def new_c(st):
+        assert L.pcm_linear_mfma_forward_hip(R, E, E, x.data_ptr(), 1, E, 0, pos.data_ptr(), pos.numel(), E, W.data_ptr(), b.data_ptr(), 1,
+                                             y1.data_ptr(), 1, E, pair[0].data_ptr(), 0, st) == 0
+
+    for fn in (lib_a, new_a, lib_b, new_b, lib_c, new_c):
+        fn(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    t = {fn.__name__: graphed(fn) for fn in (lib_a, new_a, lib_b, new_b, lib_c, new_c)}
+    print(f"R={R:5d}  A out_proj+res+norm: library pair {t['lib_a']:6.1f} us  proj_ln {t['new_a']:6.1f} us   "
+          f"B in-projection: add_cast + doubled product {t['lib_b']:6.1f} us  linear_mfma {t['new_b']:6.1f} us   "
+          f"C query projection: {t['lib_c']:6.1f} us  linear_mfma {t['new_c']:6.1f} us", flush=True)
