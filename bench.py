@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--no-prefetch", action="store_true", help="do not hand the next batch to the trainer early (hybrid / flat / eager modes)")
     ap.add_argument("--tokenizer-bf16", action="store_true",
                     help="run the tokenizer (PointNet + SA layer + projector) under bf16 autocast as well; default: fp32 (policy/precision.py)")
+    ap.add_argument("--no-chain-selection", action="store_true",
+                    help="skip the untimed A/B of csrc/proj_ln.hip's projection chain against the library products (then: library products)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel legs (kernels, kernels_hbm, step_trace, roofline)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra lines (fp32 GPU run, REF shape)")
@@ -755,8 +757,9 @@ def act_step_flops(wl, model=None):
     return 3 * 2 * macs * wl["batch"]
 
 
-def run_workload(name, args, device, world, rank, steps, warmup, precision=None, mode="auto", trace_steps=0):
-    """Build the policy + trainer of workload `name`, run warm-up + `steps` timed steps."""
+def run_workload(name, args, device, world, rank, steps, warmup, precision=None, mode="auto", trace_steps=0, losses=None):
+    """Build the policy + trainer of workload `name`, run warm-up + `steps` timed steps.  `losses` (a list): receives the loss of every
+    WARM-UP step as a float (cloned on the device per step, read back after the warm-up: nothing touches the timed region)."""
     from pointcloudmatters_amd.bc import (DP_OPTIM, RLBENCH_ACT_MODEL, RLBENCH_ACT_OPTIM, RLBENCH_DP_MODEL, RLBENCH_DP_OPTIM, BCTrainer,
                                           WORKLOADS, build_act_policy, build_dp_policy, build_rlbench_act_policy, clone_batch,
                                           make_act_batch, make_dp_batch)
@@ -817,13 +820,18 @@ def run_workload(name, args, device, world, rank, steps, warmup, precision=None,
         # the next batch is handed over early, as a prefetching data loader would: its FPS + kNN + SA index pass run one step
         # ahead on the side stream (in graph mode through static index buffers; every batch is sampled exactly once)
         nxt = None if args.no_prefetch else batches[(i + 1) % len(batches)]
-        trainer.training_step(clone_batch(batches[i % len(batches)]), prefetch=nxt)
+        return trainer.training_step(clone_batch(batches[i % len(batches)]), prefetch=nxt)
 
+    kept = []
     for i in range(warmup):
-        step(i)
+        out = step(i)
+        if losses is not None and isinstance(out, dict) and "loss" in out:
+            kept.append(out["loss"].detach().float().clone())
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    if losses is not None:
+        losses.extend(float(v) for v in kept)
     t0 = time.perf_counter()
     for i in range(steps):
         step(i)
@@ -893,6 +901,52 @@ def emit(out, tables, tables_path):
     print(compact_line(out), flush=True)
 
 
+def choose_projection_chain(args, device, world, rank):
+    """csrc/proj_ln.hip (round 5) offers the ~800-row attention projections of the ACT step as one matrix-core launch each instead of a
+    library product + a small kernel.  It was written while no GPU was available to the build: verified on a host model, never timed.
+    So the choice is made HERE, before the timed region, the way a GEMM autotuner makes it: a few untimed steps of the SAME workload
+    with the chain off and on (same seeds, same batches, same dropout counters); the chain is kept only if (a) its losses follow the
+    library path's to 1 % at every step -- both paths compute the same function, one bf16 rounding apart -- and (b) it is at least 1 %
+    faster.  PCM_PROJ_MFMA / PCM_LINEAR_MFMA in the environment (either value) switch the selection off and are obeyed as given.
+    Every rank makes the same measurement; rank 0's verdict is broadcast so that all ranks run the same kernels."""
+    from pointcloudmatters_amd.bc import WORKLOADS
+    from pointcloudmatters_amd.policy import fused_ops
+
+    info = {"selected": "library products (default)", "reason": "not applicable to this workload"}
+    wl = WORKLOADS[args.workload]
+    if "PCM_PROJ_MFMA" in os.environ or "PCM_LINEAR_MFMA" in os.environ:
+        info.update(selected="mfma" if (fused_ops.PROJ_MFMA or fused_ops.LINEAR_MFMA) else "library products", reason="set by the environment")
+        return info
+    if wl["policy"] not in ("act", "act_rlbench") or wl["dtype"] != "bf16" or args.mode == "eager" or args.no_chain_selection:
+        return info
+    trial = {}
+    for on in (False, True):
+        fused_ops.PROJ_MFMA = fused_ops.LINEAR_MFMA = on
+        try:
+            torch.cuda.empty_cache()
+            losses = []
+            d, tr, step_fn, _, _ = run_workload(args.workload, args, device, world, rank, 12, 6, mode=args.mode, trace_steps=0, losses=losses)
+            trial[on] = (d / 12 * 1e3, losses)
+            del tr, step_fn
+        except Exception as e:  # a kernel that does not even run loses
+            trial[on] = (float("inf"), ["%s: %s" % (type(e).__name__, e)])
+    fused_ops.PROJ_MFMA = fused_ops.LINEAR_MFMA = False
+    (t_lib, l_lib), (t_new, l_new) = trial[False], trial[True]
+    same = (t_new != float("inf") and len(l_lib) == len(l_new) and len(l_lib) > 0
+            and all(abs(a - b) <= 1e-2 * abs(a) + 1e-6 for a, b in zip(l_lib, l_new)))
+    take = bool(same and t_new < 0.99 * t_lib)
+    if world > 1:
+        flag = torch.tensor([1 if take else 0], device=device)
+        dist.broadcast(flag, 0)
+        take = bool(flag.item())
+    fused_ops.PROJ_MFMA = fused_ops.LINEAR_MFMA = take
+    info.update(selected="mfma (csrc/proj_ln.hip)" if take else "library products",
+                reason="measured before the timed region: %.3f ms/step with the chain, %.3f without; losses %s" % (
+                    t_new, t_lib, "agree to 1 %" if same else "DISAGREE or the chain failed: " + str(l_new[:1])[:120]),
+                ms_library=round(t_lib, 3), ms_mfma=(round(t_new, 3) if t_new != float("inf") else None))
+    return info
+
+
 def main():
     args = parse()
     from pointcloudmatters_amd.bc import WORKLOADS
@@ -925,6 +979,7 @@ def main():
             print(json.dumps({"kernels": kernel_rooflines(WORKLOADS[args.workload], device)}), flush=True)
         return
 
+    chain = choose_projection_chain(args, device, world, rank)
     dt, trainer, step, wl, sa_impl = run_workload(args.workload, args, device, world, rank, args.steps, args.warmup, mode=args.mode,
                                                   trace_steps=8)
     metrics = trainer.metrics()
@@ -977,6 +1032,7 @@ def main():
                        "gradient_exchange": getattr(trainer, "exchange_description", "one all-reduce after backward") if world > 1 else "single GPU",
                        "accumulate_grad_batches": trainer.accumulate, "optimizer_step_every_step": trainer.accumulate == 1,
                        "dead_decoder_layers": "n/a" if is_dp else args.dead_decoder_layers,
+                       "projection_chain": chain,
                        "precision_recipe": "fp32" if wl["dtype"] != "bf16" else (
                            "bf16 autocast everywhere but pointops" if TOKENIZER_BF16
                            else "bf16 autocast: transformer / U-Net GEMMs + attention; tokenizer + pointops fp32")},
