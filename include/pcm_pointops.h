@@ -500,6 +500,14 @@ int pcm_bn_relu_forward_hip(long n, int C, int is_bf16, const void *y, const flo
                             int use_given_stat, float *partial, float *sums, float *stat, void *z, void *stream);
 int pcm_bn_relu_backward_hip(long n, int C, int is_bf16, const void *y, const void *dz, const float *stat,
                              float *partial, float *sums, void *dy, int phase, double count, void *stream);
+/* the same pair with the activation as an argument: relu != 0 is pcm_bn_relu_*; relu == 0 is BatchNorm1d alone -- the last layer of the
+ * Diffusion Policy's projector (pcd_obs_encoder.py:100-120) -- so that every BatchNorm of PCDObsEncoder is owned by these kernels
+ * (synchronised statistics inside them, no torch.nn.SyncBatchNorm module left: the data-parallel step can be captured as a chain) */
+int pcm_bn_act_forward_hip(long n, int C, int is_bf16, int relu, const void *y, const float *gamma, const float *beta, float eps,
+                           float momentum, float *running_mean, float *running_var, int use_given_stat, float *partial, float *sums,
+                           float *stat, void *z, void *stream);
+int pcm_bn_act_backward_hip(long n, int C, int is_bf16, int relu, const void *y, const void *dz, const float *stat, float *partial,
+                            float *sums, void *dy, int phase, double count, void *stream);
 
 /* ---- GPU-side GridSamplePCD keys (the data-path step before the hot path) --------------------------------
  * replaces the per-cloud NumPy arithmetic of src/data/components/transformpcd.py:684-701, 776-790 for a packed

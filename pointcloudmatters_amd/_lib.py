@@ -106,6 +106,8 @@ SIGNATURES = {
     "pcm_bn_relu_slots": [ctypes.c_long, _i],
     "pcm_bn_relu_forward_hip": [ctypes.c_long, _i, _i, _P, _P, _P, _f, _f, _P, _P, _i, _P, _P, _P, _P, _P],
     "pcm_bn_relu_backward_hip": [ctypes.c_long, _i, _i, _P, _P, _P, _P, _P, _P, _i, ctypes.c_double, _P],
+    "pcm_bn_act_forward_hip": [ctypes.c_long, _i, _i, _i, _P, _P, _P, _f, _f, _P, _P, _i, _P, _P, _P, _P, _P],
+    "pcm_bn_act_backward_hip": [ctypes.c_long, _i, _i, _i, _P, _P, _P, _P, _P, _P, _i, ctypes.c_double, _P],
     "pcm_voxel_keys_hip": [_i, _i, _P, _P, ctypes.c_double, _P, _P, _P, _P, _P],
     "pcm_add_cast2_hip": [ctypes.c_long, ctypes.c_long, _P, _P, _P, _P, _P],
     "pcm_add2_cast_hip": [ctypes.c_long, _P, _P, _P, _P],

@@ -37,7 +37,7 @@ struct RowMap {
     }
 };
 
-// MODE 0: (y, y^2)        MODE 1: (g, g*xhat)
+// MODE 0: (y, y^2)        MODE 1: (g, g*xhat), g = dz behind the ReLU gate        MODE 2: the same without a gate (BatchNorm alone)
 template <typename T, int MODE>
 __global__ __launch_bounds__(kBlock) void pcm_bn_colsum_kernel(long n, int C, int chunkW, long rows_per_slot,
                                                                const T *__restrict__ y, const T *__restrict__ dz,
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(kBlock) void pcm_bn_colsum_kernel(long n, int C, in
     float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
     if (act) {
         float mean[4], invstd[4], a[4], b[4];
-        if (MODE == 1) {
+        if (MODE != 0) {
             load4<float>(stat + c0, mean);
             load4<float>(stat + C + c0, invstd);
             load4<float>(stat + 2 * C + c0, a);
@@ -75,7 +75,9 @@ __global__ __launch_bounds__(kBlock) void pcm_bn_colsum_kernel(long n, int C, in
                 load4<T>(dz + r * C + c0, d);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const float g = (a[u] * v[u] + b[u] > 0.f) ? d[u] : 0.f;
+                    float g;
+                    if constexpr (MODE == 2) g = d[u];
+                    else g = (a[u] * v[u] + b[u] > 0.f) ? d[u] : 0.f;
                     s0[u] += g;
                     s1[u] += g * ((v[u] - mean[u]) * invstd[u]);
                 }
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(kBlock) void pcm_bn_stats_kernel(int C, double coun
     bn_stats_of<T>(c, C, count, eps, momentum, y, sums[c], sums[C + c], gamma, beta, stat, running_mean, running_var);
 }
 
-template <typename T>
+template <typename T, bool RELU = true>
 __global__ __launch_bounds__(kBlock) void pcm_bn_relu_apply_kernel(long total4, int C, const T *__restrict__ y,
                                                                    const float *__restrict__ stat, T *__restrict__ z)
 {
@@ -224,13 +226,14 @@ __global__ __launch_bounds__(kBlock) void pcm_bn_relu_apply_kernel(long total4, 
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const float t = a[u] * v[u] + b[u];
-            o[u] = t > 0.f ? t : 0.f;
+            if constexpr (RELU) o[u] = t > 0.f ? t : 0.f;
+            else o[u] = t;
         }
         store4<T>(z + e, o);
     }
 }
 
-template <typename T>
+template <typename T, bool RELU = true>
 __global__ __launch_bounds__(kBlock) void pcm_bn_relu_bwd_apply_kernel(long total4, int C, float inv_n, const T *__restrict__ y,
                                                                        const T *__restrict__ dz, const float *__restrict__ stat,
                                                                        const float *__restrict__ sums, T *__restrict__ dy)
@@ -249,7 +252,9 @@ __global__ __launch_bounds__(kBlock) void pcm_bn_relu_bwd_apply_kernel(long tota
         load4<float>(sums + C + c, sgx);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const float g = (a[u] * v[u] + b[u] > 0.f) ? d[u] : 0.f;
+            float g;
+            if constexpr (RELU) g = (a[u] * v[u] + b[u] > 0.f) ? d[u] : 0.f;
+            else g = d[u];
             const float xhat = (v[u] - mean[u]) * invstd[u];
             o[u] = a[u] * (g - sg[u] * inv_n - xhat * (sgx[u] * inv_n));
         }
@@ -382,9 +387,11 @@ extern "C" int pcm_bn_relu_slots(long n, int C)
     return plan_for(n, C).nslots;
 }
 
-extern "C" int pcm_bn_relu_forward_hip(long n, int C, int is_bf16, const void *y, const float *gamma, const float *beta,
-                                       float eps, float momentum, float *running_mean, float *running_var,
-                                       int use_given_stat, float *partial, float *sums, float *stat, void *z, void *stream)
+// BatchNorm1d over rows with (relu != 0) or without the ReLU behind it: the Diffusion Policy's projector ends with a bare BatchNorm
+// (/root/reference/src/models/components/diffusion_policy/vision/pcd_obs_encoder.py:100-120)
+extern "C" int pcm_bn_act_forward_hip(long n, int C, int is_bf16, int relu, const void *y, const float *gamma, const float *beta,
+                                      float eps, float momentum, float *running_mean, float *running_var, int use_given_stat,
+                                      float *partial, float *sums, float *stat, void *z, void *stream)
 {
     if (n == 0) return PCM_OK;
     if (!pcm_bn_relu_supported(n, C)) return PCM_ERR_UNSUPPORTED;
@@ -422,16 +429,31 @@ extern "C" int pcm_bn_relu_forward_hip(long n, int C, int is_bf16, const void *y
         }
     }
     const long total4 = n * C / 4;
-    if (is_bf16)
+    if (is_bf16 && relu)
         hipLaunchKernelGGL(pcm_bn_relu_apply_kernel<bf>, dim3(ew_grid(total4)), dim3(kBlock), 0, s, total4, C, (const bf *)y, stat, (bf *)z);
-    else
+    else if (is_bf16)
+        hipLaunchKernelGGL((pcm_bn_relu_apply_kernel<bf, false>), dim3(ew_grid(total4)), dim3(kBlock), 0, s, total4, C, (const bf *)y, stat,
+                           (bf *)z);
+    else if (relu)
         hipLaunchKernelGGL(pcm_bn_relu_apply_kernel<float>, dim3(ew_grid(total4)), dim3(kBlock), 0, s, total4, C, (const float *)y, stat,
                            (float *)z);
+    else
+        hipLaunchKernelGGL((pcm_bn_relu_apply_kernel<float, false>), dim3(ew_grid(total4)), dim3(kBlock), 0, s, total4, C, (const float *)y,
+                           stat, (float *)z);
     return PCM_LAUNCH_STATUS();
 }
 
-extern "C" int pcm_bn_relu_backward_hip(long n, int C, int is_bf16, const void *y, const void *dz, const float *stat,
-                                        float *partial, float *sums, void *dy, int phase, double count, void *stream)
+extern "C" int pcm_bn_relu_forward_hip(long n, int C, int is_bf16, const void *y, const float *gamma, const float *beta,
+                                       float eps, float momentum, float *running_mean, float *running_var,
+                                       int use_given_stat, float *partial, float *sums, float *stat, void *z, void *stream)
+{
+    return pcm_bn_act_forward_hip(n, C, is_bf16, 1, y, gamma, beta, eps, momentum, running_mean, running_var, use_given_stat, partial, sums,
+                                  stat, z, stream);
+}
+
+
+extern "C" int pcm_bn_act_backward_hip(long n, int C, int is_bf16, int relu, const void *y, const void *dz, const float *stat,
+                                       float *partial, float *sums, void *dy, int phase, double count, void *stream)
 {
     // phase: 0 = whole backward; 1 = local sums only (sums = {sum g, sum g * xhat}); 2 = apply only with the given sums
     // (all-reduced across ranks by the caller) and `count` = rows of the GLOBAL batch (<= 0: n)
@@ -445,22 +467,42 @@ extern "C" int pcm_bn_relu_backward_hip(long n, int C, int is_bf16, const void *
     const float inv_n = (float)(1.0 / (count > 0.0 ? count : (double)n));
     if (is_bf16) {
         if (phase != 2) {
-            hipLaunchKernelGGL((pcm_bn_colsum_kernel<bf, 1>), grid, dim3(kBlock), 0, s, n, C, p.chunkW, p.rows_per_slot, (const bf *)y,
-                               (const bf *)dz, stat, partial);
+            if (relu)
+                hipLaunchKernelGGL((pcm_bn_colsum_kernel<bf, 1>), grid, dim3(kBlock), 0, s, n, C, p.chunkW, p.rows_per_slot, (const bf *)y,
+                                   (const bf *)dz, stat, partial);
+            else
+                hipLaunchKernelGGL((pcm_bn_colsum_kernel<bf, 2>), grid, dim3(kBlock), 0, s, n, C, p.chunkW, p.rows_per_slot, (const bf *)y,
+                                   (const bf *)dz, stat, partial);
             hipLaunchKernelGGL(pcm_bn_reduce_kernel, dim3((2 * C + 63) / 64), dim3(64 * kRedWaves), 0, s, p.nslots, 2 * C, partial, sums);
         }
-        if (phase != 1)
+        if (phase != 1 && relu)
             hipLaunchKernelGGL(pcm_bn_relu_bwd_apply_kernel<bf>, dim3(ew_grid(total4)), dim3(kBlock), 0, s, total4, C, inv_n, (const bf *)y,
                                (const bf *)dz, stat, sums, (bf *)dy);
+        else if (phase != 1)
+            hipLaunchKernelGGL((pcm_bn_relu_bwd_apply_kernel<bf, false>), dim3(ew_grid(total4)), dim3(kBlock), 0, s, total4, C, inv_n,
+                               (const bf *)y, (const bf *)dz, stat, sums, (bf *)dy);
     } else {
         if (phase != 2) {
-            hipLaunchKernelGGL((pcm_bn_colsum_kernel<float, 1>), grid, dim3(kBlock), 0, s, n, C, p.chunkW, p.rows_per_slot,
-                               (const float *)y, (const float *)dz, stat, partial);
+            if (relu)
+                hipLaunchKernelGGL((pcm_bn_colsum_kernel<float, 1>), grid, dim3(kBlock), 0, s, n, C, p.chunkW, p.rows_per_slot,
+                                   (const float *)y, (const float *)dz, stat, partial);
+            else
+                hipLaunchKernelGGL((pcm_bn_colsum_kernel<float, 2>), grid, dim3(kBlock), 0, s, n, C, p.chunkW, p.rows_per_slot,
+                                   (const float *)y, (const float *)dz, stat, partial);
             hipLaunchKernelGGL(pcm_bn_reduce_kernel, dim3((2 * C + 63) / 64), dim3(64 * kRedWaves), 0, s, p.nslots, 2 * C, partial, sums);
         }
-        if (phase != 1)
+        if (phase != 1 && relu)
             hipLaunchKernelGGL(pcm_bn_relu_bwd_apply_kernel<float>, dim3(ew_grid(total4)), dim3(kBlock), 0, s, total4, C, inv_n,
+                               (const float *)y, (const float *)dz, stat, sums, (float *)dy);
+        else if (phase != 1)
+            hipLaunchKernelGGL((pcm_bn_relu_bwd_apply_kernel<float, false>), dim3(ew_grid(total4)), dim3(kBlock), 0, s, total4, C, inv_n,
                                (const float *)y, (const float *)dz, stat, sums, (float *)dy);
     }
     return PCM_LAUNCH_STATUS();
+}
+
+extern "C" int pcm_bn_relu_backward_hip(long n, int C, int is_bf16, const void *y, const void *dz, const float *stat,
+                                        float *partial, float *sums, void *dy, int phase, double count, void *stream)
+{
+    return pcm_bn_act_backward_hip(n, C, is_bf16, 1, y, dz, stat, partial, sums, dy, phase, count, stream);
 }

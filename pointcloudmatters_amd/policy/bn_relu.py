@@ -27,13 +27,14 @@ def _fused_sync_ok(bn, sums):
 
 class _BNReLU(Function):
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, eps, momentum, sync_bn):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, eps, momentum, sync_bn, relu=True):
         L = _lib.load()
         n, c = y.shape
         y = y.contiguous()
         dev = y.device
         st = _raw_stream()
         count = None
+        ctx.relu = bool(relu)
         if n == 0:
             # a rank without rows (ragged data-parallel batches): nothing to launch, but with synchronised statistics the rank
             # must still take part in the collectives -- with count 0, like torch's SyncBatchNorm -- or its peers block forever
@@ -57,14 +58,14 @@ class _BNReLU(Function):
             partial = torch.empty(L.pcm_bn_relu_slots(n, c) * 2 * c, **f32)
             sums, stat = torch.empty(2, c, **f32), torch.empty(4, c, **f32)
             z = torch.empty_like(y)
-            args = (n, c, int(y.dtype == torch.bfloat16), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), float(momentum))
+            args = (n, c, int(y.dtype == torch.bfloat16), int(bool(relu)), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), float(momentum))
             if sync_bn is None:
-                rc = L.pcm_bn_relu_forward_hip(*args, _ptr(running_mean), _ptr(running_var), 0, partial.data_ptr(), sums.data_ptr(),
+                rc = L.pcm_bn_act_forward_hip(*args, _ptr(running_mean), _ptr(running_var), 0, partial.data_ptr(), sums.data_ptr(),
                                                stat.data_ptr(), z.data_ptr(), st)
             else:  # synchronised BatchNorm (policy/sync_bn.py): local sums -> statistics of all ranks -> apply
                 from . import sync_bn as S
 
-                rc = L.pcm_bn_relu_forward_hip(*args, 0, 0, 2, partial.data_ptr(), sums.data_ptr(), 0, 0, st)
+                rc = L.pcm_bn_act_forward_hip(*args, 0, 0, 2, partial.data_ptr(), sums.data_ptr(), 0, 0, st)
                 _lib.check(rc, "pcm_bn_relu_forward_hip")
                 if _fused_sync_ok(sync_bn, sums):
                     stat, count = S.combine_forward_sums(sync_bn, sums, y, n)  # the kernel accumulates around the first row of y
@@ -72,7 +73,7 @@ class _BNReLU(Function):
                     shift = y[0].float()
                     d = sums[0] / n
                     stat, count = S.combine_forward(sync_bn, shift + d, sums[1] - sums[0] * d, n)
-                rc = L.pcm_bn_relu_forward_hip(*args, 0, 0, 1, 0, 0, stat.data_ptr(), z.data_ptr(), st)
+                rc = L.pcm_bn_act_forward_hip(*args, 0, 0, 1, 0, 0, stat.data_ptr(), z.data_ptr(), st)
         _lib.check(rc, "pcm_bn_relu_forward_hip")
         ctx.save_for_backward(y, stat)
         ctx.partial = partial
@@ -90,7 +91,7 @@ class _BNReLU(Function):
             sync_bn, count = ctx.sync
             sums = torch.zeros(2, c, dtype=torch.float32, device=y.device)
             S.reduce_backward(sync_bn, sums, count)
-            return torch.empty_like(y), sums[1], sums[0], None, None, None, None, None
+            return torch.empty_like(y), sums[1], sums[0], None, None, None, None, None, None
         dz = dz.contiguous()
         if dz.dtype != y.dtype:
             dz = dz.to(y.dtype)
@@ -99,19 +100,19 @@ class _BNReLU(Function):
             sums = torch.empty(2, c, dtype=torch.float32, device=dev)
             dy = torch.empty_like(y)
             st = _raw_stream()
-            args = (n, c, int(y.dtype == torch.bfloat16), y.data_ptr(), dz.data_ptr(), stat.data_ptr(), ctx.partial.data_ptr())
+            args = (n, c, int(y.dtype == torch.bfloat16), int(ctx.relu), y.data_ptr(), dz.data_ptr(), stat.data_ptr(), ctx.partial.data_ptr())
             sync_bn, count = ctx.sync
             if sync_bn is None:
-                rc = L.pcm_bn_relu_backward_hip(*args, sums.data_ptr(), dy.data_ptr(), 0, 0.0, st)
+                rc = L.pcm_bn_act_backward_hip(*args, sums.data_ptr(), dy.data_ptr(), 0, 0.0, st)
             else:  # local sums stay the parameter gradients; the input gradient uses the sums / count of all ranks
                 from . import sync_bn as S
 
-                rc = L.pcm_bn_relu_backward_hip(*args, sums.data_ptr(), 0, 1, 0.0, st)
+                rc = L.pcm_bn_act_backward_hip(*args, sums.data_ptr(), 0, 1, 0.0, st)
                 _lib.check(rc, "pcm_bn_relu_backward_hip")
                 gsums = S.reduce_backward(sync_bn, sums, count)  # count = n_loc / N: the kernel's 1 / n_loc becomes 1 / N
-                rc = L.pcm_bn_relu_backward_hip(*args, gsums.data_ptr(), dy.data_ptr(), 2, 0.0, st)
+                rc = L.pcm_bn_act_backward_hip(*args, gsums.data_ptr(), dy.data_ptr(), 2, 0.0, st)
         _lib.check(rc, "pcm_bn_relu_backward_hip")
-        return dy, sums[1], sums[0], None, None, None, None, None
+        return dy, sums[1], sums[0], None, None, None, None, None, None
 
 
 def supported(y, bn):
@@ -125,19 +126,20 @@ def supported(y, bn):
             and bool(_lib.load().pcm_bn_relu_supported(int(y.shape[0]), int(y.shape[1]))))
 
 
-def bn_relu(y, bn):
-    """relu(bn(y)); the caller checked ``supported(y, bn)``."""
+def bn_relu(y, bn, relu=True):
+    """relu(bn(y)) -- or bn(y) alone with relu=False (the last layer of the Diffusion Policy's projector) --; the caller checked
+    ``supported(y, bn)``."""
     if bn.training:
         from .sync_bn import wants_sync
 
-        z = _BNReLU.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, bn if wants_sync(bn) else None)
+        z = _BNReLU.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, bn if wants_sync(bn) else None, relu)
         from . import fused_ops
 
         fused_ops.count_batch(bn)
         return z
     # eval: the affine comes from the running statistics; same apply kernel, differentiable through framework ops
     if torch.is_grad_enabled() and (y.requires_grad or bn.weight.requires_grad):
-        return torch.relu(bn(y))
+        return torch.relu(bn(y)) if relu else bn(y)
     L = _lib.load()
     n, c = y.shape
     y = y.contiguous()
@@ -146,8 +148,7 @@ def bn_relu(y, bn):
         a = bn.weight.float() * invstd
         stat = torch.stack([bn.running_mean.float(), invstd, a, bn.bias.float() - a * bn.running_mean.float()]).contiguous()
         z = torch.empty_like(y)
-        rc = L.pcm_bn_relu_forward_hip(n, c, int(y.dtype == torch.bfloat16), y.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(),
-                                       float(bn.eps), 0.0, 0, 0, 1, 0, 0, stat.data_ptr(), z.data_ptr(),
-                                       _raw_stream())
+        rc = L.pcm_bn_act_forward_hip(n, c, int(y.dtype == torch.bfloat16), int(bool(relu)), y.data_ptr(), bn.weight.data_ptr(),
+                                      bn.bias.data_ptr(), float(bn.eps), 0.0, 0, 0, 1, 0, 0, stat.data_ptr(), z.data_ptr(), _raw_stream())
     _lib.check(rc, "pcm_bn_relu_forward_hip")
     return z

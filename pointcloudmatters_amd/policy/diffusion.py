@@ -16,6 +16,7 @@ The set-abstraction layer is the same code path as ACT's (policy/sa_layer.py), f
 pointops; everything dense goes through hipBLASLt / MIOpen via torch.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -26,6 +27,10 @@ from .sa_layer import set_abstraction
 from .unet_ops import conv1d_cl, conv_transpose1d_cl, gn_mish_cl
 from .._lib import raw_stream as _raw_stream
 from .rows_linear import RowsLinear
+
+
+# the projector of PCDObsEncoder in row layout through csrc/bnrelu.hip (round 5; PCM_PROJECTOR_ROWS=0: the module path, for A/B)
+PROJECTOR_ROWS = os.environ.get("PCM_PROJECTOR_ROWS", "1") != "0"
 
 
 # ----------------------------------------------------------------------------- U-Net pieces
@@ -529,7 +534,46 @@ class PCDObsEncoder(_AttrMixin):
         set_abstraction.load_static(self, pre)
 
     def fused_batchnorms(self):
-        return [self.bn] if self.sa_impl == "fused" else []
+        """BatchNorm layers owned by fused kernels: the SA layer's, and (round 5) the projector's -- every BatchNorm of this encoder, so
+        that no torch.nn.SyncBatchNorm module is left under data parallelism (`BCTrainer.all_batchnorms_fused`)."""
+        if self.sa_impl != "fused":
+            return []
+        return [self.bn] + [m for m in self.projector if isinstance(m, nn.BatchNorm1d)]
+
+    def _projector_rows(self, x):
+        """The projector (pcd_obs_encoder.py:100-120: [Conv1d(k=1) -> BatchNorm1d -> ReLU] x layers -> MaxPool1d(M) -> Conv1d(k=1) ->
+        BatchNorm1d) in ROW layout: tokens stay (b * M, C) -- a 1x1 convolution is a per-row product, BatchNorm1d over (b, C, M) is a
+        BatchNorm over the b * M rows, the pool a maximum over each cloud's M rows -- so the BatchNorms run in csrc/bnrelu.hip (the last
+        one without its ReLU: pcm_bn_act_*), exchange their statistics themselves when synchronised, and the transposes disappear.
+        Returns (b, C_out), or None when a layer does not qualify (host tensors, eval-mode autograd, odd widths: the module path)."""
+        from . import bn_relu as fused
+
+        layers = list(self.projector)
+        if self.sa_impl != "fused" or not x.is_cuda or x.dim() != 2 or x.shape[0] % self.pcd_npoints:
+            return None
+        i = 0
+        while i < len(layers):
+            layer = layers[i]
+            if isinstance(layer, nn.Conv1d):
+                if layer.kernel_size[0] != 1 or layer.stride[0] != 1 or layer.padding[0] != 0:
+                    return None
+                x = linear_rows(x, layer.weight[:, :, 0], layer.bias)
+            elif isinstance(layer, nn.BatchNorm1d):
+                relu = i + 1 < len(layers) and isinstance(layers[i + 1], nn.ReLU)
+                if type(layer) is not nn.BatchNorm1d or not fused.supported(x, layer):
+                    return None
+                x = fused.bn_relu(x, layer, relu=relu)
+                i += 1 if relu else 0
+            elif isinstance(layer, nn.MaxPool1d):
+                if not (layer.kernel_size == self.pcd_npoints and layer.stride == layer.kernel_size and layer.padding == 0
+                        and layer.dilation == 1 and not layer.ceil_mode):
+                    return None
+                # .max(dim): like the pooling kernel the gradient goes to ONE position, the first maximum
+                x = x.view(-1, self.pcd_npoints, x.shape[-1]).max(dim=1).values
+            else:
+                return None
+            i += 1
+        return x
 
     def pcd_sampling(self, pxo, mask=None, return_index=False):
         """pcd_obs_encoder.py:123-198: (p (n,3), x (n,c), o (b)) -> x (m,H), or (n_p, x, n_o, idx) with `return_index`."""
@@ -570,6 +614,10 @@ class PCDObsEncoder(_AttrMixin):
 
     def _encode_pcd(self, pcd_model, pcd_dict):
         x = pcd_dict["sa_tokens"] if "sa_tokens" in pcd_dict else self.sa_tokens(pcd_model, pcd_dict)
+        if PROJECTOR_ROWS and self.training:
+            rows = self._projector_rows(x)
+            if rows is not None:
+                return rows
         x = x.view(-1, self.pcd_npoints, x.shape[-1]).transpose(1, 2)  # "(b n) c -> b c n"
         for layer in self.projector:  # 1x1 convolutions as GEMMs (MIOpen falls back to naive bf16 kernels here)
             if isinstance(layer, nn.Conv1d):

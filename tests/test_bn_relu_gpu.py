@@ -116,3 +116,70 @@ def test_bn_relu_large_mean_small_spread_is_stable():
     want = torch.relu(ref(y))
     torch.testing.assert_close(z, want, rtol=2e-3, atol=2e-3)  # fp32 inputs at 1e2 with spread 5e-2: 1e-3-level conditioning
     torch.testing.assert_close(ours.running_var, ref.running_var, rtol=1e-3, atol=1e-6)
+
+
+@pytest.mark.parametrize("n,c", [(7, 64), (4096, 128), (128, 96), (333, 24)])
+def test_bn_without_relu_matches_torch_fp32(n, c):
+    """relu=False (csrc/bnrelu.hip pcm_bn_act_*): BatchNorm1d alone -- the last layer of the Diffusion Policy's projector."""
+    from pointcloudmatters_amd.policy import bn_relu as fused
+
+    ours, ref = _pair(c, n + c)
+    y = (torch.randn(n, c, device=DEV) * 1.7 + 0.3).requires_grad_(True)
+    assert fused.supported(y, ours)
+    z = fused.bn_relu(y, ours, relu=False)
+    want = ref(y)
+    assert bool((z < 0).any())  # no clamp
+    torch.testing.assert_close(z, want, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(ours.running_mean, ref.running_mean, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(ours.running_var, ref.running_var, rtol=1e-5, atol=1e-6)
+    g = torch.randn_like(want)
+    got = torch.autograd.grad(z, (y, ours.weight, ours.bias), g)
+    exp = torch.autograd.grad(want, (y, ref.weight, ref.bias), g)
+    for a, r, name in zip(got, exp, ("dy", "dgamma", "dbeta")):
+        scale = r.abs().max().item() + 1e-12
+        assert (a - r).abs().max().item() <= 1e-4 * scale + 1e-6, (name, (a - r).abs().max().item(), scale)
+    ours.eval(), ref.eval()
+    with torch.no_grad():
+        torch.testing.assert_close(fused.bn_relu(y.detach(), ours, relu=False), ref(y.detach()), rtol=1e-4, atol=1e-5)
+
+
+def test_diffusion_policy_projector_in_row_layout_equals_the_module_path(monkeypatch):
+    """PCDObsEncoder's projector through csrc/bnrelu.hip in row layout (round 5) against the nn.Sequential it replaces: same features,
+    same gradients; every BatchNorm of the policy is then owned by a fused kernel (what a captured data-parallel step needs)."""
+    import pointcloudmatters_amd.pointops as po
+    from pointcloudmatters_amd.bc import BCTrainer, build_dp_policy, make_dp_batch
+    from pointcloudmatters_amd.policy import diffusion
+    from tests.golden.make_golden import DP_SMALL
+
+    batch = make_dp_batch(3, 200, seed=12, ragged=True, device=DEV)
+    runs, called = {}, []
+    from pointcloudmatters_amd import _lib
+
+    orig = _lib.check
+
+    def check(rc, what, *a, **kw):
+        called.append(what)
+        return orig(rc, what, *a, **kw)
+
+    monkeypatch.setattr(_lib, "check", check)
+    for rows in (False, True):
+        monkeypatch.setattr(diffusion, "PROJECTOR_ROWS", rows)
+        torch.manual_seed(0)
+        pol = build_dp_policy(pcd_npoints=32, pointops=po, sa_impl="fused", **DP_SMALL).to(DEV).train()
+        assert BCTrainer.all_batchnorms_fused(pol)
+        called.clear()
+        enc = pol.obs_encoder
+        feats = enc.pcd_features({k: v.clone() for k, v in batch["obs"]["pcds"].items()})
+        n_bn = called.count("pcm_bn_relu_forward_hip")
+        (feats * torch.linspace(-1, 1, feats.numel(), device=DEV).view_as(feats)).sum().backward()
+        runs[rows] = (feats.detach(), {n: p.grad.detach().clone() for n, p in enc.named_parameters() if p.grad is not None},
+                      {n: b.detach().clone() for n, b in enc.named_buffers() if "running" in n}, n_bn)
+    assert runs[True][3] == runs[False][3] + 2  # the projector's two BatchNorms joined the PointNet's and the SA layer's
+    torch.testing.assert_close(runs[True][0], runs[False][0], rtol=1e-4, atol=1e-5)
+    assert runs[True][1].keys() == runs[False][1].keys()
+    gscale = max(r.abs().max().item() for r in runs[False][1].values())
+    for n in runs[False][1]:  # (convolution biases in front of a BatchNorm have a true gradient of zero: rounding noise on both sides)
+        a, r = runs[True][1][n], runs[False][1][n]
+        assert (a - r).abs().max().item() <= 1e-4 * max(r.abs().max().item(), 1e-2 * gscale) + 1e-6, n
+    for n in runs[False][2]:
+        torch.testing.assert_close(runs[True][2][n], runs[False][2][n], rtol=1e-4, atol=1e-6, msg=n)

@@ -33,6 +33,8 @@ def _rank_batches(rank, dev, kind="act"):
 
     if kind == "act_graph":  # graph mode: equal-size clouds, the same layout every step
         return [make_act_batch(2, 300, seed=500 + 10 * i + rank, ragged=False, device=dev, num_queries=10) for i in range(STEPS)]
+    if kind == "dp_graph":  # graph mode: equal-size clouds
+        return [make_dp_batch(2, 150, seed=700 + 10 * i + rank, ragged=False, device=dev) for i in range(STEPS)]
     if kind == "dp":
         return [make_dp_batch(2, 150, seed=700 + 10 * i + rank, ragged=True, device=dev) for i in range(STEPS)]
     return [make_act_batch(2, 300, seed=500 + 10 * i + rank, ragged=True, device=dev, num_queries=10) for i in range(STEPS)]
@@ -40,7 +42,7 @@ def _rank_batches(rank, dev, kind="act"):
 
 def _eps(rank, kind="act"):
     g = torch.Generator().manual_seed(40 + rank)
-    if kind == "dp":  # the DDPM noise of every step (timesteps are fixed per rank below)
+    if kind.startswith("dp"):  # the DDPM noise of every step (timesteps are fixed per rank below)
         return torch.randn(STEPS, 2, 16, 7, generator=g)
     return torch.randn(STEPS, 2, 8, generator=g)
 
@@ -71,7 +73,7 @@ def _build(kind):
     from pointcloudmatters_amd.bc.configs import DP_OPTIM
 
     torch.manual_seed(0)
-    if kind == "dp":
+    if kind.startswith("dp"):
         from tests.golden.make_golden import DP_SMALL
 
         return build_dp_policy(pcd_npoints=32, sa_impl="fused", **DP_SMALL), dict(DP_OPTIM, lr=1e-3)
@@ -86,7 +88,7 @@ def _train(dev, batches, eps, distributed, kind="act", tsteps=None, mode="hybrid
     losses = []
     for i in range(STEPS):
         b = clone_batch(batches[i])
-        if kind == "dp":
+        if kind.startswith("dp"):
             b["noise"], b["timesteps"] = eps[i].to(dev), tsteps[i].to(dev)
         else:
             b["vae_eps"] = eps[i].to(dev)
@@ -129,7 +131,7 @@ def _named(tr):
 
 
 def _bn_of(tr, kind):
-    return tr.policy.obs_encoder.bn if kind == "dp" else tr.policy.bn
+    return tr.policy.obs_encoder.bn if kind.startswith("dp") else tr.policy.bn
 
 
 
@@ -149,16 +151,23 @@ def _worker(rank, world, port, q, kind):
             log.flat = self.optimizer.flat_g
 
         trainer_mod.BCTrainer.__init__ = init_and_register
-        mode = "graph" if kind == "act_graph" else "hybrid"
+        mode = "graph" if kind.endswith("_graph") else "hybrid"
         tr, losses = _train(dev, _rank_batches(rank, dev, kind), _eps(rank, kind), distributed=True, kind=kind, tsteps=_timesteps(rank),
                             mode=mode)
         assert tr.mode == mode and tr.distributed and tr.sync_batchnorm and len(tr._stages) == 4
         extra = {}
         if mode == "graph":
-            # the step is ONE chain: graphs cut at the 6 + 6 synchronised-BatchNorm collectives and the 4 gradient slabs
+            # the step is ONE chain: graphs cut at the synchronised-BatchNorm collectives (one forward, one backward per fused
+            # BatchNorm: ACT 6 + 6; Diffusion Policy 8 + 8 since round 5 owns the projector's two) and the non-empty gradient slabs
+            from pointcloudmatters_amd.bc import BCTrainer
+
+            assert BCTrainer.all_batchnorms_fused(tr.policy)
+            n_bn = sum(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) for m in tr.policy.modules())
+            n_slabs = sum(1 for st in tr._stages if st.slab[1] > st.slab[0])
+            assert n_bn == (8 if kind.startswith("dp") else 6)
             chain = tr._graph[0]
             assert tr.segmented and len(tr._graph) == 1
-            assert chain.n_calls == 6 + 6 + 4 and chain.n_graphs == chain.n_calls + 1, (chain.n_calls, chain.n_graphs)
+            assert chain.n_calls == 2 * n_bn + n_slabs and chain.n_graphs == chain.n_calls + 1, (chain.n_calls, chain.n_graphs)
             extra["chain%d" % rank] = np.asarray([chain.n_graphs, chain.n_calls])
         # what the first multi-GPU execution will do, checked here on one device:
         #  * every collective runs OUTSIDE stream capture (the captured graphs stay collective-free);
@@ -176,7 +185,7 @@ def _worker(rank, world, port, q, kind):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["act", "dp", "act_graph"])
+@pytest.mark.parametrize("kind", ["act", "dp", "act_graph", "dp_graph"])
 def test_two_ranks_in_hybrid_mode_equal_one_process_on_the_whole_batch(hip_device, kind):
     """kind "act_graph": the same comparison for mode="graph" at N > 1 (round 4) -- the whole step, tokenizer included, replayed
     as a chain of hipGraphs cut at every collective (_graphs.SegmentedCapture); equal-size clouds."""
@@ -187,7 +196,7 @@ def test_two_ranks_in_hybrid_mode_equal_one_process_on_the_whole_batch(hip_devic
     for p in procs:
         p.start()
     got = {}
-    n_keys = 10 if kind == "act_graph" else 8
+    n_keys = 10 if kind.endswith("_graph") else 8
     for _ in range(3000):
         while not q.empty():
             got.update(q.get())
@@ -211,7 +220,7 @@ def test_two_ranks_in_hybrid_mode_equal_one_process_on_the_whole_batch(hip_devic
     whole = [_concat(x, y) for x, y in zip(b0, b1)]
     eps = torch.cat([_eps(0, kind), _eps(1, kind)], dim=1)
     tr, losses = _train(hip_device, whole, eps, distributed=False, kind=kind, tsteps=torch.cat([_timesteps(0), _timesteps(1)], dim=1),
-                        mode="graph" if kind == "act_graph" else "hybrid")
+                        mode="graph" if kind.endswith("_graph") else "hybrid")
     mean_losses = (got["losses0"] + got["losses1"]) / 2
     assert mean_losses == pytest.approx(np.asarray(losses), rel=2e-4)
     ref = _named(tr)
