@@ -928,6 +928,9 @@ def choose_projection_chain(args, device, world, rank):
             d, tr, step_fn, _, _ = run_workload(args.workload, args, device, world, rank, 12, 6, mode=args.mode, trace_steps=0, losses=losses)
             trial[on] = (d / 12 * 1e3, losses)
             del tr, step_fn
+            import gc
+
+            gc.collect()  # the trial's graphs and their memory pools go before the next trainer is built
         except Exception as e:  # a kernel that does not even run loses
             trial[on] = (float("inf"), ["%s: %s" % (type(e).__name__, e)])
     fused_ops.PROJ_MFMA = fused_ops.LINEAR_MFMA = False
