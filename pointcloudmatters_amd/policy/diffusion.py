@@ -618,6 +618,9 @@ class PCDObsEncoder(_AttrMixin):
             rows = self._projector_rows(x)
             if rows is not None:
                 return rows
+        if self.training and any(getattr(m, "_pcm_sync", False) for m in self.projector if isinstance(m, nn.BatchNorm1d)):
+            raise RuntimeError("the projector's BatchNorms are marked for synchronised statistics, which only the fused row-layout path "
+                               "implements (policy/sync_bn.py); its input does not qualify for that path")
         x = x.view(-1, self.pcd_npoints, x.shape[-1]).transpose(1, 2)  # "(b n) c -> b c n"
         for layer in self.projector:  # 1x1 convolutions as GEMMs (MIOpen falls back to naive bf16 kernels here)
             if isinstance(layer, nn.Conv1d):
