@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--no-prefetch", action="store_true", help="do not hand the next batch to the trainer early (hybrid / flat / eager modes)")
     ap.add_argument("--tokenizer-bf16", action="store_true",
                     help="run the tokenizer (PointNet + SA layer + projector) under bf16 autocast as well; default: fp32 (policy/precision.py)")
+    ap.add_argument("--chain-trial", default="12,6", help=argparse.SUPPRESS)  # steps,warm-up of each selection trial (tools/dbg/bench_on_model.py shortens them)
     ap.add_argument("--no-chain-selection", action="store_true",
                     help="skip the untimed A/B of csrc/proj_ln.hip's projection chain against the library products (then: library products)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -915,38 +916,56 @@ def choose_projection_chain(args, device, world, rank):
     info = {"selected": "library products (default)", "reason": "not applicable to this workload"}
     wl = WORKLOADS[args.workload]
     if "PCM_PROJ_MFMA" in os.environ or "PCM_LINEAR_MFMA" in os.environ:
-        info.update(selected="mfma" if (fused_ops.PROJ_MFMA or fused_ops.LINEAR_MFMA) else "library products", reason="set by the environment")
+        info.update(selected="mfma (as set)" if (fused_ops.PROJ_MFMA or fused_ops.LINEAR_MFMA) else "library products", reason="set by the environment")
         return info
     if wl["policy"] not in ("act", "act_rlbench") or wl["dtype"] != "bf16" or args.mode == "eager" or args.no_chain_selection:
         return info
-    trial = {}
-    for on in (False, True):
-        fused_ops.PROJ_MFMA = fused_ops.LINEAR_MFMA = on
+    # candidates: the library products; the chain at the short sites (<= 1024 rows: decoder, CVAE encoder); the chain at the long sites too
+    # (the encoder's rows, 64-row tiles) -- short and long sites can win or lose independently
+    cands = (("library products", False, False, False), ("mfma at the short sites (csrc/proj_ln.hip)", True, True, False),
+             ("mfma at the short and the long sites (csrc/proj_ln.hip)", True, True, True))
+
+    def set_flags(proj, lin, long_):
+        fused_ops.PROJ_MFMA, fused_ops.LINEAR_MFMA, fused_ops.PROJ_MFMA_LONG = proj, lin, long_
+
+    trial = []
+    for name, proj, lin, long_ in cands:
+        set_flags(proj, lin, long_)
         try:
             torch.cuda.empty_cache()
             losses = []
-            d, tr, step_fn, _, _ = run_workload(args.workload, args, device, world, rank, 12, 6, mode=args.mode, trace_steps=0, losses=losses)
-            trial[on] = (d / 12 * 1e3, losses)
+            n_steps, n_warm = (int(v) for v in args.chain_trial.split(","))
+            d, tr, step_fn, _, _ = run_workload(args.workload, args, device, world, rank, n_steps, n_warm, mode=args.mode, trace_steps=0,
+                                                losses=losses)
+            trial.append((d / n_steps * 1e3, losses))
             del tr, step_fn
             import gc
 
             gc.collect()  # the trial's graphs and their memory pools go before the next trainer is built
         except Exception as e:  # a kernel that does not even run loses
-            trial[on] = (float("inf"), ["%s: %s" % (type(e).__name__, e)])
-    fused_ops.PROJ_MFMA = fused_ops.LINEAR_MFMA = False
-    (t_lib, l_lib), (t_new, l_new) = trial[False], trial[True]
-    same = (t_new != float("inf") and len(l_lib) == len(l_new) and len(l_lib) > 0
-            and all(abs(a - b) <= 1e-2 * abs(a) + 1e-6 for a, b in zip(l_lib, l_new)))
-    take = bool(same and t_new < 0.99 * t_lib)
+            trial.append((float("inf"), ["%s: %s" % (type(e).__name__, e)]))
+    set_flags(False, False, False)
+    t_lib, l_lib = trial[0]
+
+    def same(losses):
+        return (len(l_lib) == len(losses) and len(l_lib) > 0 and all(isinstance(b, float) for b in losses)
+                and all(abs(a - b) <= 1e-2 * abs(a) + 1e-6 for a, b in zip(l_lib, losses)))
+
+    best = 0
+    for i in (1, 2):
+        if trial[i][0] != float("inf") and same(trial[i][1]) and trial[i][0] < 0.99 * trial[best][0]:
+            best = i
     if world > 1:
-        flag = torch.tensor([1 if take else 0], device=device)
+        flag = torch.tensor([best], device=device)
         dist.broadcast(flag, 0)
-        take = bool(flag.item())
-    fused_ops.PROJ_MFMA = fused_ops.LINEAR_MFMA = take
-    info.update(selected="mfma (csrc/proj_ln.hip)" if take else "library products",
-                reason="measured before the timed region: %.3f ms/step with the chain, %.3f without; losses %s" % (
-                    t_new, t_lib, "agree to 1 %" if same else "DISAGREE or the chain failed: " + str(l_new[:1])[:120]),
-                ms_library=round(t_lib, 3), ms_mfma=(round(t_new, 3) if t_new != float("inf") else None))
+        best = int(flag.item())
+    set_flags(*cands[best][1:])
+    ms = [None if t == float("inf") else round(t, 3) for t, _ in trial]
+    info.update(selected=cands[best][0],
+                reason="measured before the timed region, ms/step: library %s, short sites %s (losses %s), short + long sites %s (losses %s)" % (
+                    ms[0], ms[1], "agree to 1 %" if same(trial[1][1]) else "DISAGREE / failed: " + str(trial[1][1][:1])[:80],
+                    ms[2], "agree to 1 %" if same(trial[2][1]) else "DISAGREE / failed: " + str(trial[2][1][:1])[:80]),
+                ms_library=ms[0], ms_mfma_short=ms[1], ms_mfma_short_long=ms[2])
     return info
 
 

@@ -38,7 +38,10 @@ __device__ __forceinline__ bf8 ldg_bf8(const u16 *p)  // 16 bytes, global
     return as_bf8(*reinterpret_cast<const uint4 *>(p));
 }
 
-template <int E>
+// MT = 16-row tiles per workgroup: 1 for the ~800-row sites (50 workgroups, the weight streamed 50 times), 4 for the long ones (the
+// encoder's 4120 / 8216 / 16408 rows: every B operand fetched from L2 feeds FOUR matrix instructions, the weight streams R / 64 times;
+// the product tile then waits in LDS as bf16 -- the value it is rounded to anyway -- to fit 64 rows into the CU's 160 KiB).
+template <int E, int MT>
 __global__ __launch_bounds__(kThreadsP) void pcm_proj_drln_fwd_kernel(
     long R, int K, const u16 *__restrict__ a, long a_ls, const u16 *__restrict__ W, const void *__restrict__ bias, int bias_is_bf16,
     const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta, float eps, float p_drop,
@@ -46,19 +49,23 @@ __global__ __launch_bounds__(kThreadsP) void pcm_proj_drln_fwd_kernel(
     float *__restrict__ rstd_out, const float *__restrict__ pos, long pos_n, __hip_bfloat16 *__restrict__ sum16,
     __hip_bfloat16 *__restrict__ x16)
 {
+    constexpr int TM = kTM * MT;            // rows per workgroup
     constexpr int NT = E / (16 * kWavesP);  // 16-column tiles per wave
     constexpr int NCH = E / 256;            // float4 chunks per lane in the row phase
-    constexpr int YS = E + kYPad;
+    constexpr bool YB = MT > 1;             // product tile kept as bf16
+    constexpr int YS = E + (YB ? 8 : kYPad);  // elements per row of the product tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int AS = K + kAPad;
-    u16 *As = reinterpret_cast<u16 *>(smem);                                   // [kTM][AS] bf16
-    float *Ys = reinterpret_cast<float *>(smem + (size_t)kTM * AS * 2);        // [kTM][YS] fp32 (16-byte aligned: AS % 8 == 0)
+    u16 *As = reinterpret_cast<u16 *>(smem);                                   // [TM][AS] bf16
+    unsigned char *ybase = smem + (size_t)TM * AS * 2;                         // 16-byte aligned: AS % 8 == 0
+    float *Ys = reinterpret_cast<float *>(ybase);                              // [TM][YS] fp32   (MT == 1)
+    u16 *Yb = reinterpret_cast<u16 *>(ybase);                                  // [TM][YS] bf16   (MT > 1)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const long r0 = (long)blockIdx.x * kTM;
+    const long r0 = (long)blockIdx.x * TM;
 
     // ---- A panel -> LDS (rows past R are zero)
     const int chunks = K / 8;  // 16-byte pieces per row
-    for (int c = tid; c < kTM * chunks; c += kThreadsP) {
+    for (int c = tid; c < TM * chunks; c += kThreadsP) {
         const int i = c / chunks, kc = c % chunks;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (r0 + i < R) v = *reinterpret_cast<const uint4 *>(a + (r0 + i) * a_ls + kc * 8);
@@ -70,9 +77,11 @@ __global__ __launch_bounds__(kThreadsP) void pcm_proj_drln_fwd_kernel(
     const u16 *wrow[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) wrow[t] = W + (long)(n0 + 16 * t + li) * K + lk;
-    f4v acc[NT];
+    f4v acc[MT][NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = f4v{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[m][t] = f4v{0.f, 0.f, 0.f, 0.f};
     const int ksteps = K / 32;
     bf8 b0[NT], b1[NT];  // the operands of k-steps kt and kt + 1 (in flight while step kt - 1 is multiplied)
 #pragma unroll
@@ -86,33 +95,41 @@ __global__ __launch_bounds__(kThreadsP) void pcm_proj_drln_fwd_kernel(
         const bool more = kt + 2 < ksteps;
 #pragma unroll
         for (int t = 0; t < NT; ++t) b2[t] = more ? ldg_bf8(wrow[t] + 32 * (kt + 2)) : b1[t];
-        const bf8 af = lds_bf8(As + li * AS + 32 * kt + lk);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = PCM_MFMA_16x16x32(af, b0[t], acc[t]);
+        for (int m = 0; m < MT; ++m) {
+            const bf8 af = lds_bf8(As + (16 * m + li) * AS + 32 * kt + lk);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[m][t] = PCM_MFMA_16x16x32(af, b0[t], acc[m][t]);
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t) b0[t] = b1[t], b1[t] = b2[t];
     }
 
-    // ---- y = bf16(acc + bias) -> LDS tile.  Accumulator register r of `lane`: row 4 (lane / 16) + r, column n0 + 16 t + lane % 16
+    // ---- y = bf16(acc + bias) -> LDS tile.  Accumulator register r of `lane`, row tile m: row 16 m + 4 (lane / 16) + r,
+    // column n0 + 16 t + lane % 16
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int col = n0 + 16 * t + li;
         const float bv = bias == nullptr ? 0.f
                          : (bias_is_bf16 ? bf2f(reinterpret_cast<const u16 *>(bias)[col]) : reinterpret_cast<const float *>(bias)[col]);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float y = acc[t][r] + bv;
-            Ys[(4 * (lane >> 4) + r) * YS + col] = __uint_as_float(pcm_cvt_pk_bf16(y, 0.f) << 16);  // rounded to bf16, kept as fp32
-        }
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t yb = pcm_cvt_pk_bf16(acc[m][t][r] + bv, 0.f) & 0xFFFFu;  // rounded to bf16
+                const int row = 16 * m + 4 * (lane >> 4) + r;
+                if (YB) Yb[row * YS + col] = (u16)yb;
+                else Ys[row * YS + col] = __uint_as_float(yb << 16);
+            }
     }
     __syncthreads();
 
-    // ---- rows: wave w finishes rows w and w + 8 of the tile (csrc/drln.hip's row code on the LDS-resident y)
+    // ---- rows: wave w finishes rows w, w + 8, ... of the tile (csrc/drln.hip's row code on the LDS-resident y)
     const bool drop = p_drop > 0.f;
     const uint64_t seed = drop ? (uint64_t)seed_ptr[0] : 0ull;
     const uint32_t thr = drop ? (uint32_t)((double)p_drop * 4294967296.0) : 0u;
     const float scale = drop ? 1.f / (1.f - p_drop) : 1.f;
-    for (int i = w; i < kTM; i += kWavesP) {
+    for (int i = w; i < TM; i += kWavesP) {
         const long r = r0 + i;
         if (r >= R) break;  // wave-uniform
         float s[NCH][4];
@@ -123,7 +140,8 @@ __global__ __launch_bounds__(kThreadsP) void pcm_proj_drln_fwd_kernel(
             const long e0 = r * E + col;
             float xv[4], yv[4];
             load4<float>(x + e0, xv);
-            load4<float>(Ys + i * YS + col, yv);
+            if (YB) load4<__hip_bfloat16>(reinterpret_cast<const __hip_bfloat16 *>(Yb + i * YS + col), yv);
+            else load4<float>(Ys + i * YS + col, yv);
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const float yy = keep_elem(seed, site, (uint64_t)(e0 + v), thr) ? yv[v] * scale : 0.f;
@@ -165,21 +183,28 @@ __global__ __launch_bounds__(kThreadsP) void pcm_proj_drln_fwd_kernel(
     }
 }
 
-inline size_t proj_smem_bytes(int E, int K) { return (size_t)kTM * (K + kAPad) * 2 + (size_t)kTM * (E + kYPad) * 4; }
+inline size_t proj_smem_bytes(int E, int K, int MT)
+{
+    const size_t rows = (size_t)kTM * MT;
+    return rows * (K + kAPad) * 2 + (MT > 1 ? rows * (E + 8) * 2 : rows * (E + kYPad) * 4);
+}
 
-template <int E>
+// rows from which the 64-row tile is taken (below: 16-row tiles, more workgroups for the short activations)
+constexpr long kLongRows = 2048;
+
+template <int E, int MT>
 int launch_proj(long R, int K, const void *a, long a_ls, const void *W, const void *bias, int bias_is_bf16, const float *x,
                 const float *gamma, const float *beta, float eps, float p_drop, const long *seed, unsigned site, float *s, float *out,
                 float *mean, float *rstd, const float *pos, long pos_n, void *sum16, void *x16, hipStream_t st)
 {
-    const size_t smem = proj_smem_bytes(E, K);
-    const long blocks = (R + kTM - 1) / kTM;
-    if (smem > 64 * 1024) {  // E = K = 1024: 97 KiB of the CU's 160
-        const int rc = pcm_status(hipFuncSetAttribute(reinterpret_cast<const void *>(pcm_proj_drln_fwd_kernel<E>),
+    const size_t smem = proj_smem_bytes(E, K, MT);
+    const long rows = (long)kTM * MT, blocks = (R + rows - 1) / rows;
+    if (smem > 64 * 1024) {  // E = K = 1024, or the 64-row tile: up to 133 KiB (E = K = 512) of the CU's 160
+        const int rc = pcm_status(hipFuncSetAttribute(reinterpret_cast<const void *>(pcm_proj_drln_fwd_kernel<E, MT>),
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(pcm_proj_drln_fwd_kernel<E>, dim3((unsigned)blocks), dim3(kThreadsP), smem, st, R, K, (const u16 *)a, a_ls,
+    hipLaunchKernelGGL((pcm_proj_drln_fwd_kernel<E, MT>), dim3((unsigned)blocks), dim3(kThreadsP), smem, st, R, K, (const u16 *)a, a_ls,
                        (const u16 *)W, bias, bias_is_bf16, x, gamma, beta, eps, p_drop, seed, site, s, out, mean, rstd, pos, pos_n,
                        (__hip_bfloat16 *)sum16, (__hip_bfloat16 *)x16);
     return PCM_LAUNCH_STATUS();
@@ -205,9 +230,13 @@ extern "C" int pcm_proj_drln_mfma_forward_hip(long R, int E, int K, const void *
     if (sum_bf16 != nullptr && (pos == nullptr || pos_n <= 0 || pos_n % E != 0)) return PCM_ERR_BAD_ARG;
     if ((a_ls % 8) != 0 || (((uintptr_t)a_bf16 | (uintptr_t)w_bf16) % 16) != 0) return PCM_ERR_BAD_ARG;  // 16-byte operand loads
     hipStream_t st = (hipStream_t)stream;
-#define PCM_PROJ(EE)                                                                                                              \
-    return launch_proj<EE>(R, K, a_bf16, a_ls, w_bf16, bias, bias_is_bf16, x, gamma, beta, eps, p_drop, seed, site, s, out, mean, \
-                           rstd, pos, pos_n, sum_bf16, out_bf16, st)
+    // the 64-row tile needs rows * (K + 8) * 2 + rows * (E + 8) * 2 bytes of LDS: E + K <= 1232 (E = K = 512: 133 KiB)
+    const bool wide = R >= kLongRows && (size_t)proj_smem_bytes(E, K, 4) <= 160 * 1024;
+#define PCM_PROJ(EE)                                                                                                                   \
+    return wide ? launch_proj<EE, 4>(R, K, a_bf16, a_ls, w_bf16, bias, bias_is_bf16, x, gamma, beta, eps, p_drop, seed, site, s, out,  \
+                                     mean, rstd, pos, pos_n, sum_bf16, out_bf16, st)                                                   \
+                : launch_proj<EE, 1>(R, K, a_bf16, a_ls, w_bf16, bias, bias_is_bf16, x, gamma, beta, eps, p_drop, seed, site, s, out,  \
+                                     mean, rstd, pos, pos_n, sum_bf16, out_bf16, st)
     switch (E) {
     case 256: PCM_PROJ(256);
     case 512: PCM_PROJ(512);

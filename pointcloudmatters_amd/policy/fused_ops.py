@@ -198,6 +198,10 @@ def _drln_forward(x2, y2, gamma, beta, eps, p_drop, seed, site, emit=None):
 # decoder / CVAE-encoder sites, the 4120-row encoder sites stay with the library product unless the bound is raised).
 PROJ_MFMA = os.environ.get("PCM_PROJ_MFMA", "0") != "0"
 PROJ_MFMA_MAX_ROWS = int(os.environ.get("PCM_PROJ_MFMA_MAX_ROWS", "1024"))
+# the LONG sites as well (the encoder's 4120 / 8216 / 16408 rows: from 2048 rows on the kernel takes 64-row tiles, every weight operand
+# feeding four matrix instructions); a separate switch because short and long sites can win or lose independently
+PROJ_MFMA_LONG = os.environ.get("PCM_PROJ_MFMA_LONG", "0") != "0"
+PROJ_MFMA_LONG_ROWS = 2048  # csrc/proj_ln.hip kLongRows
 
 
 LINEAR_MFMA = os.environ.get("PCM_LINEAR_MFMA", "0") != "0"  # csrc/proj_ln.hip pcm_linear_mfma: same status as PROJ_MFMA (opt-in, untimed)
@@ -229,7 +233,8 @@ def _linear_mfma_ok(rows, wc, bc, pos_cols, *operands):
 
 def _proj_mfma_ok(a2, wc, bc, x2):
     R, E = x2.shape
-    return (PROJ_MFMA and a2.is_cuda and 0 < R <= PROJ_MFMA_MAX_ROWS and a2.dtype == torch.bfloat16 and wc.dtype == torch.bfloat16
+    return (PROJ_MFMA and a2.is_cuda and (0 < R <= PROJ_MFMA_MAX_ROWS or (PROJ_MFMA_LONG and R >= PROJ_MFMA_LONG_ROWS))
+            and a2.dtype == torch.bfloat16 and wc.dtype == torch.bfloat16
             and bc.dtype in (torch.bfloat16, torch.float32) and x2.dtype == torch.float32 and wc.is_contiguous() and bc.is_contiguous()
             and a2.stride(-1) == 1 and a2.stride(0) % 8 == 0 and a2.data_ptr() % 16 == 0 and wc.data_ptr() % 16 == 0
             and bool(_lib.load().pcm_proj_drln_mfma_supported(int(E), int(wc.shape[1]))))

@@ -59,7 +59,8 @@ def _inputs(R, E, K, seed, bias_dtype=torch.bfloat16):
 
 
 # decoder / CVAE-encoder / ragged row counts, every supported width, K != E, a tile with a single row, fp32 and missing bias
-CASES = [(800, 512, 512, torch.bfloat16), (816, 512, 512, torch.bfloat16), (37, 256, 256, torch.float32), (1, 512, 512, None),
+# ... and the 64-row tile taken from 2048 rows on (the encoder's 4120 rows, a ragged tail, a narrow and a wide reduction)
+CASES = [(4120, 512, 512, torch.bfloat16), (2051, 256, 512, torch.float32), (2048, 512, 64, None), (800, 512, 512, torch.bfloat16), (816, 512, 512, torch.bfloat16), (37, 256, 256, torch.float32), (1, 512, 512, None),
          (100, 768, 256, torch.bfloat16), (48, 1024, 1024, torch.bfloat16), (515, 512, 64, torch.bfloat16), (16, 256, 32, torch.float32)]
 
 
@@ -81,7 +82,7 @@ def test_projection_residual_norm_matches_the_formula(R, E, K, bias_dtype):
     torch.testing.assert_close(rstd.double(), (var + 1e-5).rsqrt().squeeze(1), rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("R,E,K", [(800, 512, 512), (70, 256, 512)])
+@pytest.mark.parametrize("R,E,K", [(800, 512, 512), (70, 256, 512), (2115, 512, 512)])
 @pytest.mark.parametrize("p", [0.0, 0.1])
 def test_same_masks_and_results_as_product_plus_drln(R, E, K, p):
     """Fed the product this kernel itself formed (recovered from s with dropout off), csrc/drln.hip must give the same s / out / mean /
@@ -105,7 +106,12 @@ def test_same_masks_and_results_as_product_plus_drln(R, E, K, p):
 
 def test_consumer_operands_and_row_stride():
     """sum16 = bf16(out + pos) with pos broadcast over the leading rows, out16 = bf16(out); `a` as a strided view (row stride > K)."""
-    R, E, K = 200, 512, 512
+    _consumer_operands(200)
+    _consumer_operands(2100)  # the 64-row tile
+
+
+def _consumer_operands(R):
+    E, K = 512, 512
     a, W, bias, x, gamma, beta = _inputs(R, E, K, 3)
     pos = torch.randn(100, E, generator=torch.Generator().manual_seed(4)).to(DEV)  # the decoder's query_pos: 100 queries, batch-major rows
     wide = torch.zeros(R, K + 64, dtype=torch.bfloat16, device=DEV)
@@ -131,8 +137,9 @@ def test_argument_contract():
     assert L.pcm_proj_drln_mfma_forward_hip(16, 384, 512, 0, 512, *z[2:]) == 2  # unsupported width
 
 
+@pytest.mark.parametrize("B", [8, 24])  # 800 rows: 16-row tiles; 2400 rows: the 64-row tile (PROJ_MFMA_LONG)
 @pytest.mark.parametrize("p", [0.0, 0.1])
-def test_fused_node_with_and_without_the_matrix_core_kernel(monkeypatch, p):
+def test_fused_node_with_and_without_the_matrix_core_kernel(monkeypatch, p, B):
     """fused_ops.proj_drln (the autograd node of every attention sub-layer's tail) with PROJ_MFMA on against the same node with the
     library product + csrc/drln.hip: same dropout masks, outputs and all gradients equal up to the bf16 rounding of the product."""
     import torch.nn as nn
@@ -140,7 +147,8 @@ def test_fused_node_with_and_without_the_matrix_core_kernel(monkeypatch, p):
     from pointcloudmatters_amd.policy import fused_ops
 
     torch.manual_seed(5)
-    E, B, Lq = 512, 8, 100
+    E, Lq = 512, 100
+    monkeypatch.setattr(fused_ops, "PROJ_MFMA_LONG", True)
     lin, norm, drop = nn.Linear(E, E).to(DEV), nn.LayerNorm(E).to(DEV), nn.Dropout(p)
     with torch.no_grad():
         norm.weight.uniform_(0.5, 1.5), norm.bias.uniform_(-0.2, 0.2)

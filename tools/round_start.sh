@@ -19,7 +19,7 @@ echo "smoke rc=$?"; tail -1 "$OUT/smoke.log"
 timeout 300 python tools/mb/mb_proj_ln.py > "$OUT/mb_proj_ln.log" 2>&1
 echo "mb_proj_ln rc=$?"; cat "$OUT/mb_proj_ln.log" | tail -4
 # the same bench with the MFMA projection chain on (opt-in until this number exists)
-PCM_PROJ_MFMA=1 PCM_LINEAR_MFMA=1 timeout 600 python bench.py --no-cpu-baseline --no-roofline --no-extra > "$OUT/bench_mfma_chain.json" 2> "$OUT/bench_mfma_chain.err"
+PCM_PROJ_MFMA=1 PCM_LINEAR_MFMA=1 PCM_PROJ_MFMA_LONG=1 timeout 600 python bench.py --no-cpu-baseline --no-roofline --no-extra > "$OUT/bench_mfma_chain.json" 2> "$OUT/bench_mfma_chain.err"
 echo "bench (mfma chain) rc=$?"; cut -c1-200 "$OUT/bench_mfma_chain.json"
 timeout 600 python bench.py --tokenizer-bf16 --no-cpu-baseline --no-roofline --no-extra > "$OUT/bench_tokenizer_bf16.json" 2> "$OUT/bench_tokenizer_bf16.err"
 echo "bench (tokenizer bf16, the round-4 recipe) rc=$?"; cut -c1-200 "$OUT/bench_tokenizer_bf16.json"
