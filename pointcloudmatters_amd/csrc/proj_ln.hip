@@ -265,18 +265,20 @@ constexpr int kLThreads = 64 * kLW;
 constexpr int kLN = 256;           // columns per workgroup
 constexpr int kLT = kLN / (16 * kLW);  // 16-column tiles per wave (4)
 
-template <bool OUT_BF16>
+// MT = 16-row tiles per workgroup (1: short activations; 4: from 2048 rows on, each weight operand feeds four matrix instructions)
+template <bool OUT_BF16, int MT>
 __global__ __launch_bounds__(kLThreads) void pcm_linear_mfma_kernel(long R, int N, int K, const void *__restrict__ a, int a_is_f32,
                                                                     long a_ls, const u16 *__restrict__ a_alt, const float *__restrict__ pos,
                                                                     long pos_n, int pos_cols, const u16 *__restrict__ W,
                                                                     const void *__restrict__ bias, int bias_is_bf16, void *__restrict__ out,
                                                                     long out_ls, u16 *__restrict__ emit_pos16, u16 *__restrict__ emit_x16)
 {
+    constexpr int TM = kTM * MT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
     const int AS = K + kAPad;
-    u16 *As = reinterpret_cast<u16 *>(smem2);  // [kTM][AS] bf16; reused for the output tile after the products
+    u16 *As = reinterpret_cast<u16 *>(smem2);  // [TM][AS] bf16; reused for the output tile after the products
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const long r0 = (long)blockIdx.x * kTM;
+    const long r0 = (long)blockIdx.x * TM;
     const int c0 = blockIdx.y * kLN;           // first output column of this workgroup
     const bool below = c0 < pos_cols;          // this workgroup's columns see the FIRST operand (x + pos, or `a`)
     const bool with_pos = a_is_f32 && pos != nullptr && below;
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(kLThreads) void pcm_linear_mfma_kernel(long R, int 
     if (a_is_f32) {
         const float *x = reinterpret_cast<const float *>(a);
         const int chunks = K / 4;  // float4 pieces per row
-        for (int c = tid; c < kTM * chunks; c += kLThreads) {
+        for (int c = tid; c < TM * chunks; c += kLThreads) {
             const int i = c / chunks, kc = c % chunks;
             float v[4] = {0.f, 0.f, 0.f, 0.f};
             if (r0 + i < R) {
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(kLThreads) void pcm_linear_mfma_kernel(long R, int 
     } else {
         const u16 *ab = (!below && a_alt != nullptr) ? a_alt : reinterpret_cast<const u16 *>(a);
         const int chunks = K / 8;
-        for (int c = tid; c < kTM * chunks; c += kLThreads) {
+        for (int c = tid; c < TM * chunks; c += kLThreads) {
             const int i = c / chunks, kc = c % chunks;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (r0 + i < R) v = *reinterpret_cast<const uint4 *>(ab + (r0 + i) * a_ls + kc * 8);
@@ -324,9 +326,11 @@ __global__ __launch_bounds__(kLThreads) void pcm_linear_mfma_kernel(long R, int 
         col = col < N ? col : N - 1;
         wrow[t] = W + (long)col * K + lk;
     }
-    f4v acc[kLT];
+    f4v acc[MT][kLT];
 #pragma unroll
-    for (int t = 0; t < kLT; ++t) acc[t] = f4v{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < kLT; ++t) acc[m][t] = f4v{0.f, 0.f, 0.f, 0.f};
     const int ksteps = K / 32;
     bf8 b0[kLT], b1[kLT];
 #pragma unroll
@@ -340,15 +344,18 @@ __global__ __launch_bounds__(kLThreads) void pcm_linear_mfma_kernel(long R, int 
         const bool more = kt + 2 < ksteps;
 #pragma unroll
         for (int t = 0; t < kLT; ++t) b2[t] = more ? ldg_bf8(wrow[t] + 32 * (kt + 2)) : b1[t];
-        const bf8 af = lds_bf8(As + li * AS + 32 * kt + lk);
 #pragma unroll
-        for (int t = 0; t < kLT; ++t) acc[t] = PCM_MFMA_16x16x32(af, b0[t], acc[t]);
+        for (int m = 0; m < MT; ++m) {
+            const bf8 af = lds_bf8(As + (16 * m + li) * AS + 32 * kt + lk);
+#pragma unroll
+            for (int t = 0; t < kLT; ++t) acc[m][t] = PCM_MFMA_16x16x32(af, b0[t], acc[m][t]);
+        }
 #pragma unroll
         for (int t = 0; t < kLT; ++t) b0[t] = b1[t], b1[t] = b2[t];
     }
     __syncthreads();  // every wave is done with the A panel: the same LDS now takes the output tile
 
-    // ---- + bias -> output tile in LDS [kTM][kLN] (fp32, or bf16 packed two per word), then whole 16-byte pieces to global
+    // ---- + bias -> output tile in LDS [TM][kLN] (fp32, or bf16 packed two per word), then whole 16-byte pieces to global
     constexpr int OS = OUT_BF16 ? kLN + 8 : kLN + 4;  // elements per LDS row (padding keeps the scattered accumulator stores apart)
     u16 *Ob = reinterpret_cast<u16 *>(smem2);
     float *Of = reinterpret_cast<float *>(smem2);
@@ -359,17 +366,19 @@ __global__ __launch_bounds__(kLThreads) void pcm_linear_mfma_kernel(long R, int 
         if (bias != nullptr && col < N)
             bv = bias_is_bf16 ? bf2f(reinterpret_cast<const u16 *>(bias)[col]) : reinterpret_cast<const float *>(bias)[col];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float y = acc[t][r] + bv;
-            const int row = 4 * (lane >> 4) + r;
-            if (OUT_BF16) Ob[row * OS + lc] = (u16)(pcm_cvt_pk_bf16(y, 0.f) & 0xFFFFu);
-            else Of[row * OS + lc] = y;
-        }
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float y = acc[m][t][r] + bv;
+                const int row = 16 * m + 4 * (lane >> 4) + r;
+                if (OUT_BF16) Ob[row * OS + lc] = (u16)(pcm_cvt_pk_bf16(y, 0.f) & 0xFFFFu);
+                else Of[row * OS + lc] = y;
+            }
     }
     __syncthreads();
     constexpr int EPB = OUT_BF16 ? 8 : 4;           // elements per 16-byte piece
     constexpr int pieces = kLN / EPB;               // pieces per row
-    for (int c = tid; c < kTM * pieces; c += kLThreads) {
+    for (int c = tid; c < TM * pieces; c += kLThreads) {
         const int i = c / pieces, pc = c % pieces, col = c0 + pc * EPB;
         if (r0 + i >= R || col >= N) continue;      // N % 8 == 0: a piece is inside or outside as a whole
         if (OUT_BF16)
@@ -379,10 +388,28 @@ __global__ __launch_bounds__(kLThreads) void pcm_linear_mfma_kernel(long R, int 
     }
 }
 
-inline size_t linear_smem_bytes(int K, int out_bf16)
+inline size_t linear_smem_bytes(int K, int out_bf16, int MT)
 {
-    const size_t a = (size_t)kTM * (K + kAPad) * 2, o = out_bf16 ? (size_t)kTM * (kLN + 8) * 2 : (size_t)kTM * (kLN + 4) * 4;
+    const size_t rows = (size_t)kTM * MT;
+    const size_t a = rows * (K + kAPad) * 2, o = out_bf16 ? rows * (kLN + 8) * 2 : rows * (kLN + 4) * 4;
     return a > o ? a : o;
+}
+
+template <bool OUT_BF16, int MT>
+int launch_linear(long R, int N, int K, const void *a, int a_is_f32, long a_ls, const void *a_alt, const float *pos, long pos_n, int pos_cols,
+                  const void *W, const void *bias, int bias_is_bf16, void *out, long out_ls, void *e_pos, void *e_x, hipStream_t st)
+{
+    const long rows = (long)kTM * MT;
+    const dim3 grid((unsigned)((R + rows - 1) / rows), (unsigned)((N + kLN - 1) / kLN));
+    const size_t smem = linear_smem_bytes(K, OUT_BF16, MT);
+    if (smem > 64 * 1024) {
+        const int rc = pcm_status(hipFuncSetAttribute(reinterpret_cast<const void *>(pcm_linear_mfma_kernel<OUT_BF16, MT>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL((pcm_linear_mfma_kernel<OUT_BF16, MT>), grid, dim3(kLThreads), smem, st, R, N, K, a, a_is_f32, a_ls, (const u16 *)a_alt,
+                       pos, pos_n, pos_cols, (const u16 *)W, bias, bias_is_bf16, out, out_ls, (u16 *)e_pos, (u16 *)e_x);
+    return PCM_LAUNCH_STATUS();
 }
 
 }  // namespace
@@ -410,13 +437,15 @@ extern "C" int pcm_linear_mfma_forward_hip(long R, int N, int K, const void *a, 
     const long a_align = a_is_f32 ? 4 : 8, o_align = out_is_bf16 ? 8 : 4;  // 16-byte loads / stores
     if (a_ls % a_align || out_ls % o_align || (((uintptr_t)a | (uintptr_t)w_bf16 | (uintptr_t)out) % 16) != 0) return PCM_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((unsigned)((R + kTM - 1) / kTM), (unsigned)((N + kLN - 1) / kLN));
-    const size_t smem = linear_smem_bytes(K, out_is_bf16);
-    if (out_is_bf16)
-        hipLaunchKernelGGL(pcm_linear_mfma_kernel<true>, grid, dim3(kLThreads), smem, st, R, N, K, a, a_is_f32, a_ls, (const u16 *)a_alt_bf16, pos,
-                           pos_n, pos_cols, (const u16 *)w_bf16, bias, bias_is_bf16, out, out_ls, (u16 *)emit_pos_bf16, (u16 *)emit_x_bf16);
-    else
-        hipLaunchKernelGGL(pcm_linear_mfma_kernel<false>, grid, dim3(kLThreads), smem, st, R, N, K, a, a_is_f32, a_ls, (const u16 *)a_alt_bf16, pos,
-                           pos_n, pos_cols, (const u16 *)w_bf16, bias, bias_is_bf16, out, out_ls, (u16 *)emit_pos_bf16, (u16 *)emit_x_bf16);
-    return PCM_LAUNCH_STATUS();
+    const bool wide = R >= kLongRows && linear_smem_bytes(K, out_is_bf16, 4) <= 160 * 1024;  // K <= 1024: at most 129 KiB
+#define PCM_LIN(OB, MT)                                                                                                               \
+    return launch_linear<OB, MT>(R, N, K, a, a_is_f32, a_ls, a_alt_bf16, pos, pos_n, pos_cols, w_bf16, bias, bias_is_bf16, out, out_ls, \
+                                 emit_pos_bf16, emit_x_bf16, st)
+    if (out_is_bf16) {
+        if (wide) PCM_LIN(true, 4);
+        PCM_LIN(true, 1);
+    }
+    if (wide) PCM_LIN(false, 4);
+    PCM_LIN(false, 1);
+#undef PCM_LIN
 }

@@ -204,7 +204,8 @@ def _linear(a, W, bias, pos=None, pos_cols=0, out_dtype=torch.bfloat16, a_ls=Non
     return out
 
 
-@pytest.mark.parametrize("R,N,K", [(800, 1536, 512), (816, 512, 512), (37, 264, 64), (1, 8, 32), (100, 768, 1024)])
+@pytest.mark.parametrize("R,N,K", [(800, 1536, 512), (816, 512, 512), (37, 264, 64), (1, 8, 32), (100, 768, 1024),
+                                   (4120, 1536, 512), (2051, 264, 64), (2048, 512, 1024)])  # the last three: 64-row tiles
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
 def test_linear_from_bf16_rows(R, N, K, out_dtype):
     a, W, bias, *_ = _inputs(R, N, K, 11 * R + N)
@@ -216,10 +217,11 @@ def test_linear_from_bf16_rows(R, N, K, out_dtype):
         assert ((got.double() - want).abs() <= want.abs().clamp_min(1e-2) * 2.0 ** -7).all()
 
 
-def test_in_projection_with_position_embedding_fused():
+@pytest.mark.parametrize("B", [8, 24])  # 800 rows / 2400 rows (64-row tiles)
+def test_in_projection_with_position_embedding_fused(B):
     """q | k | v = in_proj([x + pos ; x]): what csrc/tokens.hip's add + cast launch and the doubled-row product did -- columns below
     pos_cols (q, k) see bf16(x + pos), the others (v) bf16(x); pos is the decoder's (100, 1, E) query_pos broadcast over the batch."""
-    E, B, Lq = 512, 8, 100
+    E, Lq = 512, 100
     g = torch.Generator().manual_seed(21)
     x = torch.randn(Lq * B, E, generator=g).to(DEV)
     pos = torch.randn(Lq, E, generator=g).to(DEV)  # rows (query, batch)-major would need an expanded pos; here batch-major rows: block of Lq
@@ -263,8 +265,9 @@ def test_linear_strided_operands_and_contract():
     assert L.pcm_linear_mfma_forward_hip(0, 512, 512, 0, 0, 512, 0, 0, 0, 0, 0, 0, 0, 0, 1, 512, 0, 0, 0) == 0
 
 
+@pytest.mark.parametrize("B", [8, 24])
 @pytest.mark.parametrize("batch_first_pos", [False, True])
-def test_in_projection_nodes_with_and_without_the_matrix_core_kernel(monkeypatch, batch_first_pos):
+def test_in_projection_nodes_with_and_without_the_matrix_core_kernel(monkeypatch, batch_first_pos, B):
     """fused_ops.self_attn_in_proj and add_pos_linear (one autograd node each) with LINEAR_MFMA on against the add + cast launch and the
     library product(s): q / k / v and every gradient equal up to one bf16 rounding of the products."""
     import torch.nn as nn
@@ -272,7 +275,8 @@ def test_in_projection_nodes_with_and_without_the_matrix_core_kernel(monkeypatch
     from pointcloudmatters_amd.policy import fused_ops
 
     torch.manual_seed(8)
-    E, B, Lq = 512, 8, 100
+    E, Lq = 512, 100
+    monkeypatch.setattr(fused_ops, "PROJ_MFMA_LONG", True)
     mha = nn.MultiheadAttention(E, 8).to(DEV)
     lin = nn.Linear(E, E).to(DEV)
     x0 = torch.randn(B, Lq, E, device=DEV)
