@@ -225,7 +225,9 @@ def _linear_mfma(rows, wc, bc, out, *, a16=None, a16_alt=None, x32=None, posc=No
 
 def _linear_mfma_ok(rows, wc, bc, pos_cols, *operands):
     N, K = wc.shape
-    return (LINEAR_MFMA and (0 < rows <= PROJ_MFMA_MAX_ROWS or (PROJ_MFMA_LONG and rows >= PROJ_MFMA_LONG_ROWS)) and wc.is_cuda and wc.dtype == torch.bfloat16 and wc.is_contiguous()
+    # long sites: only the in-projections (N = 3E) and narrower products; the decoder's stacked memory projection (4120 x 3584 x 512 at C2)
+    # is a large GEMM that the library's LDS-tiled kernels serve well
+    return (LINEAR_MFMA and (0 < rows <= PROJ_MFMA_MAX_ROWS or (PROJ_MFMA_LONG and rows >= PROJ_MFMA_LONG_ROWS and N <= 2048)) and wc.is_cuda and wc.dtype == torch.bfloat16 and wc.is_contiguous()
             and (bc is None or (bc.is_contiguous() and bc.dtype in (torch.bfloat16, torch.float32)))
             and all(t is None or (t.stride(-1) == 1 and t.data_ptr() % 16 == 0 and t.stride(0) % 8 == 0) for t in operands)
             and wc.data_ptr() % 16 == 0 and bool(_lib.load().pcm_linear_mfma_supported(int(N), int(K), int(pos_cols))))
