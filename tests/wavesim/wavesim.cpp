@@ -234,9 +234,30 @@ static void run_block(Block &b)
     g_blk = &b;
     const size_t n = b.lanes.size();
     size_t done = 0;
+    // Lanes run one after another; a missing barrier between a producer and a consumer of LDS data shows only if the consumer happens to
+    // run FIRST.  WAVESIM_ORDER=reverse | shuffle[:seed] runs the ready lanes in another order (default: ascending), so that a kernel can
+    // be tested under several interleavings -- every correctly synchronised kernel must give the same results under all of them.
+    static std::vector<size_t> order;
+    if (order.size() != n) {
+        order.resize(n);
+        for (size_t i = 0; i < n; ++i) order[i] = i;
+        const char *mode = std::getenv("WAVESIM_ORDER");
+        if (mode && !std::strncmp(mode, "reverse", 7)) {
+            for (size_t i = 0; i < n; ++i) order[i] = n - 1 - i;
+        } else if (mode && !std::strncmp(mode, "shuffle", 7)) {
+            uint64_t st = 0x9E3779B97F4A7C15ull ^ (mode[7] == ':' ? std::strtoull(mode + 8, nullptr, 10) : 1);
+            for (size_t i = n - 1; i > 0; --i) {
+                st ^= st << 13, st ^= st >> 7, st ^= st << 17;
+                const size_t j = (size_t)(st % (i + 1));
+                const size_t t = order[i];
+                order[i] = order[j], order[j] = t;
+            }
+        }
+    }
     while (done < n) {
         bool ran = false;
-        for (size_t i = 0; i < n; ++i) {
+        for (size_t oi = 0; oi < n; ++oi) {
+            const size_t i = order[oi];
             Lane &l = b.lanes[i];
             if (l.state != READY) continue;
             ran = true;
