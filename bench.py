@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--no-prefetch", action="store_true", help="do not hand the next batch to the trainer early (hybrid / flat / eager modes)")
     ap.add_argument("--tokenizer-bf16", action="store_true",
                     help="run the tokenizer (PointNet + SA layer + projector) under bf16 autocast as well; default: fp32 (policy/precision.py)")
+    ap.add_argument("--emit-warmup-losses", action="store_true", help=argparse.SUPPRESS)  # a selection trial: add the warm-up losses to the line
+    ap.add_argument("--chain-trial-timeout", type=float, default=240.0, help=argparse.SUPPRESS)  # seconds per selection trial (child process)
     ap.add_argument("--chain-trial", default="12,6", help=argparse.SUPPRESS)  # steps,warm-up of each selection trial (tools/dbg/bench_on_model.py shortens them)
     ap.add_argument("--no-chain-selection", action="store_true",
                     help="skip the untimed A/B of csrc/proj_ln.hip's projection chain against the library products (then: library products)")
@@ -909,7 +911,8 @@ def choose_projection_chain(args, device, world, rank):
     with the chain off and on (same seeds, same batches, same dropout counters); the chain is kept only if (a) its losses follow the
     library path's to 1 % at every step -- both paths compute the same function, one bf16 rounding apart -- and (b) it is at least 1 %
     faster.  PCM_PROJ_MFMA / PCM_LINEAR_MFMA in the environment (either value) switch the selection off and are obeyed as given.
-    Every rank makes the same measurement; rank 0's verdict is broadcast so that all ranks run the same kernels."""
+    Each candidate is measured in a child process of its own, so that a fault in a kernel that has never met the hardware cannot take
+    the headline run with it."""
     from pointcloudmatters_amd.bc import WORKLOADS
     from pointcloudmatters_amd.policy import fused_ops
 
@@ -928,21 +931,32 @@ def choose_projection_chain(args, device, world, rank):
     def set_flags(proj, lin, long_):
         fused_ops.PROJ_MFMA, fused_ops.LINEAR_MFMA, fused_ops.PROJ_MFMA_LONG = proj, lin, long_
 
+    # Each candidate runs in its OWN PROCESS (one rank; N > 1 keeps the library products unless the environment says otherwise): the new
+    # kernels have never run on hardware, and a device fault or a hang in one of them must cost that candidate, not the headline run.
+    # The child is this same file with the switches in its environment (obeyed as given, see above) and prints its warm-up losses.
+    if world > 1:
+        info.update(selected="library products", reason="N > 1: no selection (set PCM_PROJ_MFMA / PCM_LINEAR_MFMA / PCM_PROJ_MFMA_LONG to choose)")
+        return info
+    import subprocess
+
+    n_steps, n_warm = (int(v) for v in args.chain_trial.split(","))
     trial = []
     for name, proj, lin, long_ in cands:
-        set_flags(proj, lin, long_)
+        env = dict(os.environ, PCM_PROJ_MFMA="1" if proj else "0", PCM_LINEAR_MFMA="1" if lin else "0", PCM_PROJ_MFMA_LONG="1" if long_ else "0")
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--mode", args.mode, "--sa-impl", args.sa_impl,
+               "--dead-decoder-layers", args.dead_decoder_layers, "--steps", str(n_steps), "--warmup", str(n_warm), "--no-cpu-baseline",
+               "--no-roofline", "--no-extra", "--emit-warmup-losses"]
+        cmd += ["--tokenizer-bf16"] if args.tokenizer_bf16 else []
+        cmd += ["--no-prefetch"] if args.no_prefetch else []
+        cmd += ["--sampling-in-graph"] if getattr(args, "sampling_in_graph", False) else []
         try:
-            torch.cuda.empty_cache()
-            losses = []
-            n_steps, n_warm = (int(v) for v in args.chain_trial.split(","))
-            d, tr, step_fn, _, _ = run_workload(args.workload, args, device, world, rank, n_steps, n_warm, mode=args.mode, trace_steps=0,
-                                                losses=losses)
-            trial.append((d / n_steps * 1e3, losses))
-            del tr, step_fn
-            import gc
-
-            gc.collect()  # the trial's graphs and their memory pools go before the next trainer is built
-        except Exception as e:  # a kernel that does not even run loses
+            res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=args.chain_trial_timeout)
+            line = [ln for ln in res.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+            if res.returncode != 0 or not line:
+                raise RuntimeError("exit code %s: %s" % (res.returncode, (res.stderr or res.stdout)[-200:].replace("\n", " ")))
+            out = json.loads(line[-1])
+            trial.append((float(out["ms_per_step"]), [float(v) for v in out.get("warmup_losses", [])]))
+        except Exception as e:  # a candidate that crashes, hangs or prints nothing loses
             trial.append((float("inf"), ["%s: %s" % (type(e).__name__, e)]))
     set_flags(False, False, False)
     t_lib, l_lib = trial[0]
@@ -955,10 +969,6 @@ def choose_projection_chain(args, device, world, rank):
     for i in (1, 2):
         if trial[i][0] != float("inf") and same(trial[i][1]) and trial[i][0] < 0.99 * trial[best][0]:
             best = i
-    if world > 1:
-        flag = torch.tensor([best], device=device)
-        dist.broadcast(flag, 0)
-        best = int(flag.item())
     set_flags(*cands[best][1:])
     ms = [None if t == float("inf") else round(t, 3) for t, _ in trial]
     info.update(selected=cands[best][0],
@@ -1002,8 +1012,9 @@ def main():
         return
 
     chain = choose_projection_chain(args, device, world, rank)
+    warm_losses = [] if args.emit_warmup_losses else None
     dt, trainer, step, wl, sa_impl = run_workload(args.workload, args, device, world, rank, args.steps, args.warmup, mode=args.mode,
-                                                  trace_steps=8)
+                                                  trace_steps=8, losses=warm_losses)
     metrics = trainer.metrics()
     exch = trainer.exchange_stats() if world > 1 and hasattr(trainer, "exchange_stats") else None
     is_dp = wl["policy"] in ("dp", "dp_rlbench")
@@ -1060,6 +1071,8 @@ def main():
                            else "bf16 autocast: transformer / U-Net GEMMs + attention; tokenizer + pointops fp32")},
             "final_loss": round(metrics.get("train/loss", float("nan")), 4),
         }
+        if warm_losses is not None:
+            out["warmup_losses"] = [round(v, 6) for v in warm_losses]
         if not is_dp and wl["policy"] == "act":
             # the whole step against the bf16 MFMA peak: algorithmic FLOP (act_step_flops: GEMM-shaped work, backward = 2 x
             # forward) / measured step time / (ranks x 2.5 PFLOP/s).  Small by construction at B = 8: the step is a chain of

@@ -11,7 +11,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 timeout 1200 python -m pytest tests -m gpu -q -p no:cacheprovider > "$OUT/gpu_tests.log" 2>&1
 echo "suite rc=$?" | tee -a "$OUT/gpu_tests.log"
 tail -3 "$OUT/gpu_tests.log"
-timeout 600 python bench.py --tables-out "$OUT/bench_tables.json" > "$OUT/bench.json" 2> "$OUT/bench.err"
+timeout 900 python bench.py --tables-out "$OUT/bench_tables.json" > "$OUT/bench.json" 2> "$OUT/bench.err"
 echo "bench rc=$?"
 cut -c1-400 "$OUT/bench.json"
 timeout 300 python __graft_entry__.py smoke > "$OUT/smoke.log" 2>&1
