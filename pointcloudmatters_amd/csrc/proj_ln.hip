@@ -83,26 +83,38 @@ __global__ __launch_bounds__(kThreadsP) void pcm_proj_drln_fwd_kernel(
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[m][t] = f4v{0.f, 0.f, 0.f, 0.f};
     const int ksteps = K / 32;
-    bf8 b0[NT], b1[NT];  // the operands of k-steps kt and kt + 1 (in flight while step kt - 1 is multiplied)
+    // Three operand buffers in rotation, the loop unrolled by three so that every buffer index is a compile-time constant: the
+    // operands of k-step kt + 2 are requested before step kt is multiplied and nothing is ever moved between registers (a rotation by
+    // moves forces a full `s_waitcnt vmcnt(0)` per step: seen in the first version's ISA).  Loads past the last step re-read it.
+    bf8 bq[3][NT];
+    auto fetch = [&](bf8(&dst)[NT], int kt) {
+        const int kk = kt < ksteps ? kt : ksteps - 1;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        b0[t] = ldg_bf8(wrow[t]);
-        b1[t] = ksteps > 1 ? ldg_bf8(wrow[t] + 32) : b0[t];
-    }
-    __syncthreads();  // A panel complete
-    for (int kt = 0; kt < ksteps; ++kt) {
-        bf8 b2[NT];
-        const bool more = kt + 2 < ksteps;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) b2[t] = more ? ldg_bf8(wrow[t] + 32 * (kt + 2)) : b1[t];
+        for (int t = 0; t < NT; ++t) dst[t] = ldg_bf8(wrow[t] + 32 * kk);
+    };
+    auto multiply = [&](const bf8(&cur)[NT], int kt) {
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const bf8 af = lds_bf8(As + (16 * m + li) * AS + 32 * kt + lk);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[m][t] = PCM_MFMA_16x16x32(af, b0[t], acc[m][t]);
+            for (int t = 0; t < NT; ++t) acc[m][t] = PCM_MFMA_16x16x32(af, cur[t], acc[m][t]);
         }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) b0[t] = b1[t], b1[t] = b2[t];
+    };
+    fetch(bq[0], 0);
+    fetch(bq[1], 1);
+    __syncthreads();  // A panel complete
+    int kt = 0;
+    for (; kt + 2 < ksteps; kt += 3) {
+        fetch(bq[2], kt + 2);
+        multiply(bq[0], kt);
+        fetch(bq[0], kt + 3);
+        multiply(bq[1], kt + 1);
+        fetch(bq[1], kt + 4);
+        multiply(bq[2], kt + 2);
+    }
+    if (kt < ksteps) {
+        multiply(bq[0], kt);
+        if (kt + 1 < ksteps) multiply(bq[1], kt + 1);
     }
 
     // ---- y = bf16(acc + bias) -> LDS tile.  Accumulator register r of `lane`, row tile m: row 16 m + 4 (lane / 16) + r,
@@ -230,18 +242,24 @@ extern "C" int pcm_proj_drln_mfma_forward_hip(long R, int E, int K, const void *
     if (sum_bf16 != nullptr && (pos == nullptr || pos_n <= 0 || pos_n % E != 0)) return PCM_ERR_BAD_ARG;
     if ((a_ls % 8) != 0 || (((uintptr_t)a_bf16 | (uintptr_t)w_bf16) % 16) != 0) return PCM_ERR_BAD_ARG;  // 16-byte operand loads
     hipStream_t st = (hipStream_t)stream;
-    // the 64-row tile needs rows * (K + 8) * 2 + rows * (E + 8) * 2 bytes of LDS: E + K <= 1232 (E = K = 512: 133 KiB)
-    const bool wide = R >= kLongRows && (size_t)proj_smem_bytes(E, K, 4) <= 160 * 1024;
-#define PCM_PROJ(EE)                                                                                                                   \
-    return wide ? launch_proj<EE, 4>(R, K, a_bf16, a_ls, w_bf16, bias, bias_is_bf16, x, gamma, beta, eps, p_drop, seed, site, s, out,  \
-                                     mean, rstd, pos, pos_n, sum_bf16, out_bf16, st)                                                   \
-                : launch_proj<EE, 1>(R, K, a_bf16, a_ls, w_bf16, bias, bias_is_bf16, x, gamma, beta, eps, p_drop, seed, site, s, out,  \
-                                     mean, rstd, pos, pos_n, sum_bf16, out_bf16, st)
+    // the 64-row tile needs rows * (K + 8) * 2 + rows * (E + 8) * 2 bytes of LDS: E + K <= 1232 (E = K = 512: 133 KiB); E = 1024 keeps the
+    // 16-row tile (four row tiles of 8 column tiles would need more than 256 registers)
+    const bool wide = R >= kLongRows && E <= 768 && (size_t)proj_smem_bytes(E, K, 4) <= 160 * 1024;
+#define PCM_PROJ(EE, MM)                                                                                                             \
+    return launch_proj<EE, MM>(R, K, a_bf16, a_ls, w_bf16, bias, bias_is_bf16, x, gamma, beta, eps, p_drop, seed, site, s, out, mean, \
+                               rstd, pos, pos_n, sum_bf16, out_bf16, st)
     switch (E) {
-    case 256: PCM_PROJ(256);
-    case 512: PCM_PROJ(512);
-    case 768: PCM_PROJ(768);
-    default: PCM_PROJ(1024);
+    case 256:
+        if (wide) PCM_PROJ(256, 4);
+        PCM_PROJ(256, 1);
+    case 512:
+        if (wide) PCM_PROJ(512, 4);
+        PCM_PROJ(512, 1);
+    case 768:
+        if (wide) PCM_PROJ(768, 4);
+        PCM_PROJ(768, 1);
+    default:
+        PCM_PROJ(1024, 1);
     }
 #undef PCM_PROJ
 }
@@ -332,26 +350,35 @@ __global__ __launch_bounds__(kLThreads) void pcm_linear_mfma_kernel(long R, int 
 #pragma unroll
         for (int t = 0; t < kLT; ++t) acc[m][t] = f4v{0.f, 0.f, 0.f, 0.f};
     const int ksteps = K / 32;
-    bf8 b0[kLT], b1[kLT];
+    bf8 bq[3][kLT];  // three operand buffers in rotation, loop unrolled by three: see pcm_proj_drln_fwd_kernel
+    auto fetch = [&](bf8(&dst)[kLT], int kt) {
+        const int kk = kt < ksteps ? kt : ksteps - 1;
 #pragma unroll
-    for (int t = 0; t < kLT; ++t) {
-        b0[t] = ldg_bf8(wrow[t]);
-        b1[t] = ksteps > 1 ? ldg_bf8(wrow[t] + 32) : b0[t];
-    }
-    __syncthreads();  // A panel complete
-    for (int kt = 0; kt < ksteps; ++kt) {
-        bf8 b2[kLT];
-        const bool more = kt + 2 < ksteps;
-#pragma unroll
-        for (int t = 0; t < kLT; ++t) b2[t] = more ? ldg_bf8(wrow[t] + 32 * (kt + 2)) : b1[t];
+        for (int t = 0; t < kLT; ++t) dst[t] = ldg_bf8(wrow[t] + 32 * kk);
+    };
+    auto multiply = [&](const bf8(&cur)[kLT], int kt) {
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const bf8 af = lds_bf8(As + (16 * m + li) * AS + 32 * kt + lk);
 #pragma unroll
-            for (int t = 0; t < kLT; ++t) acc[m][t] = PCM_MFMA_16x16x32(af, b0[t], acc[m][t]);
+            for (int t = 0; t < kLT; ++t) acc[m][t] = PCM_MFMA_16x16x32(af, cur[t], acc[m][t]);
         }
-#pragma unroll
-        for (int t = 0; t < kLT; ++t) b0[t] = b1[t], b1[t] = b2[t];
+    };
+    fetch(bq[0], 0);
+    fetch(bq[1], 1);
+    __syncthreads();  // A panel complete
+    int kt = 0;
+    for (; kt + 2 < ksteps; kt += 3) {
+        fetch(bq[2], kt + 2);
+        multiply(bq[0], kt);
+        fetch(bq[0], kt + 3);
+        multiply(bq[1], kt + 1);
+        fetch(bq[1], kt + 4);
+        multiply(bq[2], kt + 2);
+    }
+    if (kt < ksteps) {
+        multiply(bq[0], kt);
+        if (kt + 1 < ksteps) multiply(bq[1], kt + 1);
     }
     __syncthreads();  // every wave is done with the A panel: the same LDS now takes the output tile
 
