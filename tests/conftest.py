@@ -48,7 +48,7 @@ _FILE_TIER = {
     "test_oracle": 0, "test_golden_cpu": 0, "test_capi": 0, "test_gridsample_cpu": 0, "test_rollout_cpu": 0, "test_rlbench_cpu": 0,
     "test_pointops_gpu": 0, "test_pointops_fuzz_gpu": 0, "test_pointops_misc_gpu": 0, "test_segsum_gpu": 0, "test_gridsample_gpu": 0,
     "test_rollout_gpu": 0, "test_rlbench_gpu": 0, "test_wide_fixture": 0, "test_presample": 0, "test_wrappers_ref_gpu": 0,
-    "test_bf16_fixture": 0, "test_wavesim_parity": 0, "test_two_ranks_on_the_model": 2, "test_wrappers_ref": 0, "test_optim_ref": 0, "test_normalizer_ref": 0, "test_trajectory_ref": 0, "test_mask_sampling": 0,
+    "test_bf16_fixture": 0, "test_wavesim_parity": 0, "test_two_ranks_on_the_model": 2, "test_wavesim_sanitized": 1, "test_wrappers_ref": 0, "test_optim_ref": 0, "test_normalizer_ref": 0, "test_trajectory_ref": 0, "test_mask_sampling": 0,
     "test_sa_fused_gpu": 1, "test_bn_relu_gpu": 1, "test_drln_gpu": 1, "test_tokens_gpu": 1, "test_small_attn_gpu": 1,
     "test_flash_attn_gpu": 1, "test_rows_linear_gpu": 1, "test_unet_ops_gpu": 1, "test_pointnet2_gpu": 1, "test_graphs_gpu": 1,
     "test_host_logic": 1, "test_concurrency_gpu": 1, "test_xfer_gpu": 1, "test_ffn_mfma_gpu": 1, "test_proj_ln_gpu": 1, "test_build_flags": 1,

@@ -21,15 +21,29 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "pointcloudmatters_amd", "csrc")
-OUT = os.path.join(HERE, "_build")
+# WAVESIM_SANITIZE=1: the same library with AddressSanitizer + UndefinedBehaviorSanitizer instrumentation of the KERNEL SOURCES (own
+# directory; the process needs the clang runtime preloaded: asan_runtime()).  Device-side sanitizers cannot run on this pool (no xnack);
+# on the model an access one element outside a global buffer, an LDS array or the dynamic LDS block aborts the test.
+SANITIZE = os.environ.get("WAVESIM_SANITIZE") == "1"
+OUT = os.path.join(HERE, "_build", "asan") if SANITIZE else os.path.join(HERE, "_build")
 LIB = os.path.join(OUT, "libpcm_wavesim.so")
+SAN_FLAGS = ["-fsanitize=address,undefined", "-fno-sanitize=vptr,function,alignment", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer",
+             "-shared-libsan"] if SANITIZE else []
+
+
+def asan_runtime():
+    import glob
+
+    hits = glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so")
+    return hits[0] if hits else None
+
 CLANG = os.environ.get("WAVESIM_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 # every kernel file of the library except graph_fix.hip (hipGraph surgery: runtime API, no kernel logic)
 SOURCES = ["fps.hip", "knn.hip", "ball.hip", "group.hip", "misc_ops.hip", "segsum.hip", "voxel.hip", "sa_scatter.hip", "sa_fused.hip",
            "bnrelu.hip", "drln.hip", "tokens.hip", "gnmish.hip", "ddpm.hip", "optim.hip", "ffn.hip", "ffn_mfma.hip", "attn_small.hip",
            "attn_flash.hip", "proj_ln.hip"]
-FLAGS = ["-x", "c++", "-std=c++17", "-O1", "-g0", "-ffp-contract=off", "-fPIC", "-fno-strict-aliasing", "-Wno-everything",
-         "-I", os.path.join(HERE, "include"), "-I", CSRC]
+FLAGS = ["-x", "c++", "-std=c++17", "-O1", "-g0" if not SANITIZE else "-g1", "-ffp-contract=off", "-fPIC", "-fno-strict-aliasing", "-Wno-everything",
+         "-I", os.path.join(HERE, "include"), "-I", CSRC] + SAN_FLAGS
 
 _DYN = re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?([A-Za-z_][A-Za-z0-9_ ]*?)\s*\b([A-Za-z_][A-Za-z0-9_]*)\s*\[\s*\]\s*;")
 _FPS_ASM = re.compile(r"(__device__ __forceinline__ uint32_t fps_wave_max_fast\(uint32_t v\)\s*\{).*?\n\}\n", re.S)
@@ -65,7 +79,7 @@ def _build(verbose, sources):
     objs, jobs = [], []
     deps = [os.path.join(HERE, f) for f in ("wavesim.hpp", "include/hip/hip_runtime.h", "include/hip/hip_bf16.h", "build.py")] + \
            [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")] + [os.path.join(ROOT, "include", "pcm_pointops.h")]
-    stamp = hashlib.sha1(b"".join(open(d, "rb").read() for d in sorted(deps))).hexdigest()[:12]
+    stamp = hashlib.sha1(b"".join(open(d, "rb").read() for d in sorted(deps)) + (b"asan" if SANITIZE else b"")).hexdigest()[:12]
     for name in (sources or SOURCES):
         src = rewrite(name, open(os.path.join(CSRC, name)).read())
         key = hashlib.sha1((stamp + src).encode()).hexdigest()[:16]
@@ -76,7 +90,7 @@ def _build(verbose, sources):
             jobs.append((name, subprocess.Popen([CLANG] + FLAGS + ["-c", cpp, "-o", obj], stderr=subprocess.PIPE, text=True)))
     core = os.path.join(OUT, f"wavesim.{stamp}.o")
     if not os.path.exists(core):
-        jobs.append(("wavesim.cpp", subprocess.Popen([CLANG, "-std=c++17", "-O2", "-fPIC", "-c", os.path.join(HERE, "wavesim.cpp"), "-o", core],
+        jobs.append(("wavesim.cpp", subprocess.Popen([CLANG, "-std=c++17", "-O2", "-fPIC"] + SAN_FLAGS + ["-c", os.path.join(HERE, "wavesim.cpp"), "-o", core],
                                                      stderr=subprocess.PIPE, text=True)))
     failed = []
     for name, p in jobs:
@@ -89,7 +103,7 @@ def _build(verbose, sources):
         raise RuntimeError("\n".join(f"--- {n}\n{e[-6000:]}" for n, e in failed))
     if jobs or not os.path.exists(LIB):
         tmp = LIB + ".tmp.%d" % os.getpid()
-        subprocess.check_call([CLANG, "-shared", "-fPIC", "-o", tmp] + objs + [core])
+        subprocess.check_call([CLANG, "-shared", "-fPIC"] + SAN_FLAGS + ["-o", tmp] + objs + [core])
         os.replace(tmp, LIB)  # processes that already mapped the previous file keep it
     return LIB
 
