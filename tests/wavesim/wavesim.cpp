@@ -326,6 +326,10 @@ void launch(const std::function<void()> &body, dim3 grid, dim3 block, size_t dyn
                             l.linear = (int)i, l.lane = (int)(i & 63), l.wave = (int)(i >> 6);
                             prepare(l, i);
                         }
+                // WAVESIM_POISON=1: the dynamic LDS block holds NaN / -1 patterns when a workgroup starts (on hardware it holds whatever the
+                // previous workgroup left): a kernel that reads dynamic LDS it has not written shows up as a wrong result
+                static const bool poison = std::getenv("WAVESIM_POISON") != nullptr;
+                if (poison && dyn_bytes) std::memset(g_dyn_smem, 0xFF, dyn_bytes);
                 run_block(b);
             }
     g_body = nullptr;
