@@ -187,6 +187,10 @@ def load():
             f"or `make -C {CSRC_DIR}` (hipcc --offload-arch=gfx950). There is no CPU fallback."
         )
     lib = ctypes.CDLL(LIB_PATH)
+    if hasattr(lib, "wavesim_stats"):
+        # tests/wavesim's host model exports the same entry points for HOST pointers: test infrastructure, never a product path
+        raise PointopsLibraryError(f"{LIB_PATH} is the host wave64 model of tests/wavesim (test infrastructure): the product loads the "
+                                   "gfx950 build only. There is no CPU fallback.")
     for name, args in SIGNATURES.items():
         try:
             fn = getattr(lib, name)

@@ -113,6 +113,23 @@ def _call_with_sizes(fn, decls, size):
     return fn(*args)
 
 
+def test_product_loader_refuses_the_host_model_library():
+    """PCM_POINTOPS_LIB selects another BUILD of the gfx950 library (the sanitizer build); pointed at tests/wavesim's host model -- the same
+    entry points for host pointers -- the loader refuses: the model is test infrastructure, the product has no CPU path."""
+    import subprocess
+    import sys
+
+    from tests.wavesim import build
+
+    if not os.path.exists(build.CLANG):
+        pytest.skip("needs the ROCm clang++")
+    so = build.build()
+    code = ("import sys; sys.path.insert(0, %r)\nfrom pointcloudmatters_amd import _lib\n"
+            "try:\n    _lib.load()\nexcept _lib.PointopsLibraryError as e:\n    print('REFUSED', 'host wave64 model' in str(e))\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PCM_POINTOPS_LIB=so), capture_output=True, text=True, timeout=300)
+    assert "REFUSED True" in out.stdout, out.stdout + out.stderr
+
+
 def test_runtime_version_and_memset_entry_points_need_no_gpu():
     """pcm_hip_runtime_version / pcm_memset_async (csrc/graph_fix.hip): what _graphs.memset_fix_needed decides on.  The version is the
     runtime the LIBRARY is bound to -- in a process that imported torch first, the copy torch ships -- and anything up to 7.2.x keeps
