@@ -51,7 +51,7 @@ _FILE_TIER = {
     "test_bf16_fixture": 0, "test_wavesim_parity": 0, "test_two_ranks_on_the_model": 2, "test_wavesim_sanitized": 1, "test_wrappers_ref": 0, "test_optim_ref": 0, "test_normalizer_ref": 0, "test_trajectory_ref": 0, "test_mask_sampling": 0,
     "test_sa_fused_gpu": 1, "test_bn_relu_gpu": 1, "test_drln_gpu": 1, "test_tokens_gpu": 1, "test_small_attn_gpu": 1,
     "test_flash_attn_gpu": 1, "test_rows_linear_gpu": 1, "test_unet_ops_gpu": 1, "test_pointnet2_gpu": 1, "test_graphs_gpu": 1,
-    "test_host_logic": 1, "test_concurrency_gpu": 1, "test_xfer_gpu": 1, "test_ffn_mfma_gpu": 1, "test_proj_ln_gpu": 1, "test_build_flags": 1,
+    "test_host_logic": 1, "test_concurrency_gpu": 1, "test_xfer_gpu": 1, "test_ffn_mfma_gpu": 1, "test_proj_ln_gpu": 1, "test_pk_hazard_gpu": 1, "test_build_flags": 1,
     "test_configs_vs_yaml": 1, "test_golden_regen": 1, "test_oracle_sanitized": 1,
     "test_policy_gpu": 2, "test_sync_bn_gpu": 2, "test_hybrid_two_ranks_gpu": 2, "test_bench_multirank_gpu": 2, "test_ddp_gloo": 2,
     "test_determinism_gpu": 2,
@@ -62,6 +62,7 @@ _FILE_TIER = {
 _FIRST_CONTACT = (
     ("test_wrappers_ref_gpu", ""),
     ("test_proj_ln_gpu", ""),
+    ("test_pk_hazard_gpu", ""),
     ("test_hybrid_two_ranks_gpu", "dp_graph"),
     ("test_bn_relu_gpu", "test_bn_without_relu"),
     ("test_bn_relu_gpu", "test_diffusion_policy_projector_in_row_layout"),

@@ -1,0 +1,76 @@
+"""GPU: the packed-fp32 hazard of this MI355X / ROCm stack as a recorded measurement (round-4 VERDICT item 8).
+
+tools/dbg/pk_hazard/pk_hazard.hip evaluates v_pk_add / mul / fma_f32 variants in a loop and compares every result IN REGISTER with the
+scalar computation (no memory race possible); tools/dbg/pk_hazard/run.py found in round 4 that the variants with an operand-half select
+(`op_sel` / `op_sel_hi`: what the compiler emits for `vector - scalar`) return wrong values when their wave shares a SIMD with another
+stream's MFMA kernels, and never on an idle device -- the reason csrc/Makefile builds the library without packed-fp32 instructions (NO_PK).
+This test re-measures it on every hardware run:
+  * the PLAIN packed add must be exact, idle and beside a replayed graph of library GEMMs (a wrong result there would be a new defect);
+  * the op_sel variants are RECORDED (printed, and written to gpurun_out/pk_hazard.log): a runtime / firmware update that fixes or widens
+    the hazard becomes visible in the GPU test log instead of in a training run's loss curve."""
+import ctypes
+import os
+import subprocess
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tools", "dbg", "pk_hazard", "pk_hazard.hip")
+NAMES = ["v_pk_add_f32 (plain)", "v_pk_add_f32 op_sel_hi:[1,0]", "v_pk_add_f32 op_sel_hi:[1,0] neg", "v_pk_add_f32 op_sel:[0,1] neg",
+         "v_pk_mul_f32 op_sel_hi:[1,0]", "v_pk_fma_f32 op_sel_hi:[1,0,1]", "v_pk_add_f32 op_sel:[0,1]", "v_pk_add_f32 op_sel:[1,0]",
+         "v_pk_mul_f32 op_sel:[0,1]", "v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,0]", "v_pk_add_f32 neg_lo:[0,1] neg_hi:[0,1]"]
+
+
+def test_plain_packed_add_is_exact_and_the_op_sel_variants_are_recorded(hip_device, tmp_path):
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not installed on this box")
+    so = str(tmp_path / "libpk_hazard.so")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", SRC, "-o", so], timeout=600)
+    L = ctypes.CDLL(so)
+    L.pk_launch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    dev = hip_device
+    torch.manual_seed(0)
+    blocks, iters, reps = 64, 4000, 10
+    x = torch.rand(blocks * 128 * 2, device=dev)
+    amat = torch.randn(2048, 2048, device=dev, dtype=torch.bfloat16)
+    amat @ amat
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s2 = torch.cuda.Stream()
+    s2.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s2):
+        with torch.cuda.graph(g, stream=s2):
+            for _ in range(100):
+                amat @ amat
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    rows = []
+    for v, name in enumerate(NAMES):
+        res = {}
+        for load in ("idle", "beside GEMMs"):
+            outs = []
+            for _ in range(reps):
+                if load != "idle":
+                    g.replay()
+                with torch.cuda.stream(side):
+                    bad = torch.zeros(blocks * 128, dtype=torch.int32, device=dev)
+                    assert L.pk_launch(v, blocks, iters, x.data_ptr(), bad.data_ptr(), side.cuda_stream) == 0
+                outs.append(bad)
+            torch.cuda.synchronize()
+            res[load] = sum(int(o.sum()) for o in outs)
+        rows.append((name, res["idle"], res["beside GEMMs"]))
+    n = reps * blocks * 128 * iters
+    text = "\n".join(f"{name:44s} wrong results: idle {a:>10d}   beside GEMMs {b:>10d}   of {n:.2e} evaluations each" for name, a, b in rows)
+    print("\n" + text)
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, "pk_hazard.log"), "w") as f:
+            f.write(text + "\n")
+    except OSError:
+        pass
+    assert rows[0][1] == 0 and rows[0][2] == 0, "the PLAIN packed add miscomputes: " + str(rows[0])
+    assert all(a == 0 for _, a, _ in rows), "a packed variant miscomputes on an IDLE device: " + text
