@@ -129,7 +129,6 @@ def simulated_device(claim_cuda=False):
     patch(_lib, "raw_stream", lambda: 0)
     if claim_cuda:
         patch(_lib, "on_hip", lambda device: True)  # the trainer / flat optimizer take the library path on host tensors
-    if claim_cuda:
         torch.Tensor.is_cuda = property(lambda self: True)
     try:
         yield torch.device("cpu")
