@@ -10,6 +10,10 @@ The sources are compiled as they are, except for these mechanical rewrites of co
   4. attn_small.hip: a wave that stores a tile to ITS OWN LDS region and reads it back relies on the hardware executing one wave's LDS
      operations in order (no barrier, by design).  The model runs lanes one after another, so the hand-off gets an explicit
      `__builtin_amdgcn_wave_barrier()` behind `tile_store(vr, Vs, lane);`
+  5. knn.hip `pcm_knn_exact_kernel`: the same reliance inside ONE wave -- the 64 lanes initialise the LDS heap and all of them read its
+     root in the next statement; lane 0 sorts the heap and all lanes store it.  On hardware a wave's (volatile) LDS operations execute
+     in program order for all its lanes at once; in the model the two hand-offs get a `__builtin_amdgcn_wave_barrier()` each (behind the
+     initialisation loop and behind lane 0's sort), otherwise the result depends on WAVESIM_ORDER
 Compiler: the ROCm clang++ in host mode (ext_vector_type, __builtin_convertvector on __bf16), -ffp-contract=off like the device build.
 """
 import hashlib
@@ -58,6 +62,11 @@ def rewrite(name, text):
     if name == "attn_small.hip":
         text, n = re.subn(r"(tile_store\(vr, Vs, lane\);)", r"\1 __builtin_amdgcn_wave_barrier();  /* tests/wavesim/build.py, rewrite 4 */", text)
         assert n == 2, n
+    if name == "knn.hip":
+        wb = " __builtin_amdgcn_wave_barrier();  /* tests/wavesim/build.py, rewrite 5 */"
+        text, n1 = re.subn(r"(for \(int i = lane; i < nsample; i \+= 64\) bd\[i\] = 1e10f, bi\[i\] = -1;)", r"\1" + wb, text)
+        text, n2 = re.subn(r"(reheap\(i\);\n            \}\n        \})", r"\1" + wb, text)
+        assert (n1, n2) == (1, 1), (n1, n2)
     text = _FENCE.sub("/* scheduling fence removed (tests/wavesim/build.py, rewrite 3) */;", text)
     assert "asm" not in re.sub(r"//.*", "", text).replace("assume", ""), f"{name}: inline assembly left after the rewrites"
     return text

@@ -47,11 +47,13 @@ template <class T> inline hipError_t hipMemcpyFromSymbol(void *dst, const T &sym
 inline hipError_t hipRuntimeGetVersion(int *v) { *v = 0; return hipSuccess; }
 
 template <class... KA, class... A>
-inline void hipLaunchKernelGGL(void (*kernel)(KA...), dim3 grid, dim3 block, size_t dyn_bytes, hipStream_t, A... args)
+inline void wavesim_launch_ggl(void (*kernel)(KA...), dim3 grid, dim3 block, size_t dyn_bytes, hipStream_t, A... args)
 {
     std::function<void()> body = [=]() { kernel(args...); };
     wavesim::launch(body, grid, block, dyn_bytes);
 }
+// the launch census (wavesim_census_*: tools/dbg/launch_census.py) keys on the kernel expression as written at the call site
+#define hipLaunchKernelGGL(kernel, ...) (wavesim::note_launch(#kernel), wavesim_launch_ggl(kernel, __VA_ARGS__))
 
 // ---- vector types -----------------------------------------------------------------------------------------------------------------
 struct alignas(8) float2 { float x, y; };

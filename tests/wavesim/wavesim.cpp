@@ -3,6 +3,9 @@
 
 #include <sys/mman.h>
 
+#include <map>
+#include <string>
+
 namespace wavesim {
 
 Lane *g_cur = nullptr;
@@ -337,7 +340,25 @@ void launch(const std::function<void()> &body, dim3 grid, dim3 block, size_t dyn
     g_blk = nullptr;
 }
 
+static std::map<std::string, long> g_census;
+
+void note_launch(const char *kernel_expr) { ++g_census[kernel_expr]; }
+
 }  // namespace wavesim
+
+// launch census: "kernel expression\tcount\n" per kernel since the last reset; returns the number of bytes the full text needs
+extern "C" void wavesim_census_reset() { wavesim::g_census.clear(); }
+extern "C" long wavesim_census(char *buf, long cap)
+{
+    std::string out;
+    for (const auto &kv : wavesim::g_census) out += kv.first + "\t" + std::to_string(kv.second) + "\n";
+    if (buf && cap > 0) {
+        const long n = (long)out.size() < cap - 1 ? (long)out.size() : cap - 1;
+        std::memcpy(buf, out.data(), (size_t)n);
+        buf[n] = 0;
+    }
+    return (long)out.size() + 1;
+}
 
 extern "C" void wavesim_stats(long *out)
 {

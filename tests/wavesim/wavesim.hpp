@@ -110,6 +110,7 @@ template <class T> inline T from_bits(uint64_t b)
 }
 
 void launch(const std::function<void()> &body, dim3 grid, dim3 block, size_t dyn_bytes);
+void note_launch(const char *kernel_expr);  // launch census: counts per call-site kernel expression
 void syncthreads();
 int syncthreads_or(int pred);
 
