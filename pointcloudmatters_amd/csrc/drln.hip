@@ -49,6 +49,14 @@ __global__ __launch_bounds__(kBlock) void pcm_drln_fwd_kernel(long R, const floa
     for (long r = wave0; r < R; r += nwaves) {
         float s[NCH][4];
         float sum = 0.f;
+        // the position rows of the emitted operand are requested together with x and y (the first version asked for them behind the
+        // two reductions, one 64-bit modulo and one exposed round trip per chunk)
+        float pv[NCH][4];
+        if (sum16 != nullptr) {
+            const long p0 = (r * E) % pos_n;  // E divides pos_n: a row never wraps
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) load4<float>(pos + p0 + c * 256 + lane * 4, pv[c]);
+        }
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const long e0 = r * E + c * 256 + lane * 4;
@@ -83,10 +91,9 @@ __global__ __launch_bounds__(kBlock) void pcm_drln_fwd_kernel(long R, const floa
             // the consumer's bf16 operands, emitted here instead of by its own add + cast launch (pcm_add_cast2_hip):
             // sum16 = bf16(out + pos) (pos broadcast over the leading rows), x16 = bf16(out)
             if (sum16 != nullptr) {
-                float p[4], q[4];
-                load4<float>(pos + (r * E) % pos_n + c * 256 + lane * 4, p);  // E divides pos_n: a row never wraps
+                float q[4];
 #pragma unroll
-                for (int v = 0; v < 4; ++v) q[v] = o[v] + p[v];
+                for (int v = 0; v < 4; ++v) q[v] = o[v] + pv[c][v];
                 store4<__hip_bfloat16>(sum16 + e0, q);
             }
             if (x16 != nullptr) store4<__hip_bfloat16>(x16 + e0, o);
@@ -123,18 +130,28 @@ __global__ __launch_bounds__(kBlock) void pcm_drln_bwd_kernel(long R, const floa
         const float mu = mean[r], rs = rstd[r];
         float gd[NCH][4], xh[NCH][4];
         float s1 = 0.f, s2 = 0.f;
+        // every load of the row is requested before the first value is used (written chunk by chunk, the second gradient's
+        // `if` made the compiler wait for each chunk's loads in turn: NCH round trips in series instead of one)
+        float dvs[NCH][4], svs[NCH][4];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const long e0 = r * E + c * 256 + lane * 4;
-            float dv[4], sv[4];
-            load4<float>(dout + e0, dv);
-            if (dout2 != nullptr) {  // the output had two consumers: their gradients are summed here, not by an add launch
-                float d2[4];
-                load4<float>(dout2 + e0, d2);
+            load4<float>(dout + e0, dvs[c]);
+            load4<float>(s + e0, svs[c]);
+        }
+        if (dout2 != nullptr) {  // the output had two consumers: their gradients are summed here, not by an add launch
+            float d2[NCH][4];
 #pragma unroll
-                for (int v = 0; v < 4; ++v) dv[v] += d2[v];
-            }
-            load4<float>(s + e0, sv);
+            for (int c = 0; c < NCH; ++c) load4<float>(dout2 + r * E + c * 256 + lane * 4, d2[c]);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) dvs[c][v] += d2[c][v];
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const float(&dv)[4] = dvs[c];
+            const float(&sv)[4] = svs[c];
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 xh[c][v] = (sv[v] - mu) * rs;

@@ -38,6 +38,50 @@ __device__ __forceinline__ bf8 ldg_bf8(const u16 *p)  // 16 bytes, global
     return as_bf8(*reinterpret_cast<const uint4 *>(p));
 }
 
+// Row offset of activation row r inside a position table of pos_rows rows (pos_rows >= 1; r0 % pos_rows is taken once per workgroup,
+// a row of the tile adds at most a few wraps: no 64-bit division per element).
+__device__ __forceinline__ long pos_row(long base, int i, long pos_rows)
+{
+    long pr = base + i;
+    while (pr >= pos_rows) pr -= pos_rows;
+    return pr;
+}
+
+// A panel (TM rows of K bf16, rows past R zero) -> LDS with ALL of a thread's 16-byte loads in flight before the first LDS store.
+// The first version's `for (c = tid; c < TM * chunks; c += T) { load; store }` compiled to one load, `s_waitcnt vmcnt(0)`, one store
+// per iteration: 2 (projection, 16 rows) to 16 (linear, 64 rows) L2 round trips in series before the first matrix instruction.
+// Fast path: the threads tile the panel as (T / cpr rows) x (cpr pieces), cpr = K / 8 pieces per row, when cpr divides T (K = 256,
+// 512, 1024 ...); thread (i0, kc) then owns rows i0, i0 + T / cpr, ... of piece kc: no division inside the loop.
+template <int TM, int T, int U>
+__device__ __forceinline__ void panel_bf16(const u16 *__restrict__ a, long a_ls, long r0, long R, int K, u16 *__restrict__ As, int AS, int tid)
+{
+    const int cpr = K / 8;
+    if (T % cpr == 0) {
+        const int rpp = T / cpr, i0 = tid / cpr, kc = tid - i0 * cpr;
+        for (int ib = i0; ib < TM; ib += U * rpp) {
+            uint4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = ib + u * rpp;
+                v[u] = make_uint4(0, 0, 0, 0);
+                if (i < TM && r0 + i < R) v[u] = *reinterpret_cast<const uint4 *>(a + (r0 + i) * a_ls + kc * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = ib + u * rpp;
+                if (i < TM) *reinterpret_cast<uint4 *>(As + i * AS + kc * 8) = v[u];
+            }
+        }
+    } else {  // any K % 32 == 0
+        for (int c = tid; c < TM * cpr; c += T) {
+            const int i = c / cpr, kc = c % cpr;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (r0 + i < R) v = *reinterpret_cast<const uint4 *>(a + (r0 + i) * a_ls + kc * 8);
+            *reinterpret_cast<uint4 *>(As + i * AS + kc * 8) = v;
+        }
+    }
+}
+
 // MT = 16-row tiles per workgroup: 1 for the ~800-row sites (50 workgroups, the weight streamed 50 times), 4 for the long ones (the
 // encoder's 4120 / 8216 / 16408 rows: every B operand fetched from L2 feeds FOUR matrix instructions, the weight streams R / 64 times;
 // the product tile then waits in LDS as bf16 -- the value it is rounded to anyway -- to fit 64 rows into the CU's 160 KiB).
@@ -46,10 +90,12 @@ __global__ __launch_bounds__(kThreadsP) void pcm_proj_drln_fwd_kernel(
     long R, int K, const u16 *__restrict__ a, long a_ls, const u16 *__restrict__ W, const void *__restrict__ bias, int bias_is_bf16,
     const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta, float eps, float p_drop,
     const long *__restrict__ seed_ptr, unsigned site, float *__restrict__ s_out, float *__restrict__ out, float *__restrict__ mean_out,
-    float *__restrict__ rstd_out, const float *__restrict__ pos, long pos_n, __hip_bfloat16 *__restrict__ sum16,
+    float *__restrict__ rstd_out, const float *__restrict__ pos, long pos_rows, __hip_bfloat16 *__restrict__ sum16,
     __hip_bfloat16 *__restrict__ x16)
 {
     constexpr int TM = kTM * MT;            // rows per workgroup
+    constexpr int RPW = TM / kWavesP;       // rows a wave finishes in the row phase (2 or 8)
+    constexpr bool EARLY = MT == 1;         // the rows' x values are requested BEFORE the products (16 registers); MT = 4: behind them
     constexpr int NT = E / (16 * kWavesP);  // 16-column tiles per wave
     constexpr int NCH = E / 256;            // float4 chunks per lane in the row phase
     constexpr bool YB = MT > 1;             // product tile kept as bf16
@@ -62,15 +108,6 @@ __global__ __launch_bounds__(kThreadsP) void pcm_proj_drln_fwd_kernel(
     u16 *Yb = reinterpret_cast<u16 *>(ybase);                                  // [TM][YS] bf16   (MT > 1)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const long r0 = (long)blockIdx.x * TM;
-
-    // ---- A panel -> LDS (rows past R are zero)
-    const int chunks = K / 8;  // 16-byte pieces per row
-    for (int c = tid; c < TM * chunks; c += kThreadsP) {
-        const int i = c / chunks, kc = c % chunks;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (r0 + i < R) v = *reinterpret_cast<const uint4 *>(a + (r0 + i) * a_ls + kc * 8);
-        *reinterpret_cast<uint4 *>(As + i * AS + kc * 8) = v;
-    }
 
     // ---- products: wave w, column tiles t = 0 .. NT-1 at n0 + 16 t; operands of k-step kt: k = 32 kt + 8 (lane / 16) .. + 7
     const int n0 = w * (E / kWavesP), li = lane & 15, lk = 8 * (lane >> 4);
@@ -102,6 +139,41 @@ __global__ __launch_bounds__(kThreadsP) void pcm_proj_drln_fwd_kernel(
     };
     fetch(bq[0], 0);
     fetch(bq[1], 1);
+    // ---- everything the epilogue reads from global memory is requested HERE, under the product phase (the first version asked for it
+    // row by row after the products: one exposed L2 / HBM round trip per row and wave).  x of this wave's rows (EARLY), the bias of its
+    // columns, gamma / beta of the row phase's columns.
+    uint32_t braw[NT];  // raw bits; converted where they are used (a conversion here would wait for each load in turn)
+    if (bias == nullptr) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) braw[t] = 0u;
+    } else if (bias_is_bf16) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) braw[t] = reinterpret_cast<const u16 *>(bias)[n0 + 16 * t + li];
+    } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) braw[t] = reinterpret_cast<const uint32_t *>(bias)[n0 + 16 * t + li];
+    }
+    float xs[RPW][NCH][4], gs[NCH][4], bs[NCH][4];
+    auto fetch_rows = [&]() {
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) {
+            const long r = r0 + w + kWavesP * j;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                if (r < R) load4<float>(x + r * E + c * 256 + lane * 4, xs[j][c]);
+                else xs[j][c][0] = xs[j][c][1] = xs[j][c][2] = xs[j][c][3] = 0.f;
+            }
+        }
+    };
+    if (EARLY) fetch_rows();
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        load4<float>(gamma + c * 256 + lane * 4, gs[c]);
+        load4<float>(beta + c * 256 + lane * 4, bs[c]);
+    }
+    // ---- A panel -> LDS (rows past R are zero), every load of a thread in flight at once -- and BEHIND the first weight operands and
+    // the epilogue's inputs in program order, so that the panel's round trip is theirs too (one exposed latency before the products)
+    panel_bf16<TM, kThreadsP, (MT == 1 ? 2 : 8)>(a, a_ls, r0, R, K, As, AS, tid);
     __syncthreads();  // A panel complete
     int kt = 0;
     for (; kt + 2 < ksteps; kt += 3) {
@@ -122,8 +194,7 @@ __global__ __launch_bounds__(kThreadsP) void pcm_proj_drln_fwd_kernel(
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int col = n0 + 16 * t + li;
-        const float bv = bias == nullptr ? 0.f
-                         : (bias_is_bf16 ? bf2f(reinterpret_cast<const u16 *>(bias)[col]) : reinterpret_cast<const float *>(bias)[col]);
+        const float bv = __uint_as_float(bias != nullptr && bias_is_bf16 ? braw[t] << 16 : braw[t]);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -134,64 +205,76 @@ __global__ __launch_bounds__(kThreadsP) void pcm_proj_drln_fwd_kernel(
                 else Ys[row * YS + col] = __uint_as_float(yb << 16);
             }
     }
+    if (!EARLY) fetch_rows();  // the accumulators' registers are free now: all RPW rows' x in flight across the barrier
     __syncthreads();
 
-    // ---- rows: wave w finishes rows w, w + 8, ... of the tile (csrc/drln.hip's row code on the LDS-resident y)
+    // ---- rows: wave w finishes rows w, w + 8, ... of the tile (csrc/drln.hip's row code on the LDS-resident y).  Straight-line code
+    // over the wave's RPW rows -- rows past R compute on zeros and store nothing -- so that the rows' dependent chains (hash, two
+    // wave reductions each) interleave instead of running one after another.
     const bool drop = p_drop > 0.f;
     const uint64_t seed = drop ? (uint64_t)seed_ptr[0] : 0ull;
     const uint32_t thr = drop ? (uint32_t)((double)p_drop * 4294967296.0) : 0u;
     const float scale = drop ? 1.f / (1.f - p_drop) : 1.f;
-    for (int i = w; i < TM; i += kWavesP) {
+    const long pbase = sum16 != nullptr ? r0 % pos_rows : 0;  // wave-uniform, once
+    float mus[RPW], rstds[RPW];
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+        const int i = w + kWavesP * j;
         const long r = r0 + i;
-        if (r >= R) break;  // wave-uniform
-        float s[NCH][4];
         float sum = 0.f;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int col = c * 256 + lane * 4;
             const long e0 = r * E + col;
-            float xv[4], yv[4];
-            load4<float>(x + e0, xv);
+            float yv[4];
             if (YB) load4<__hip_bfloat16>(reinterpret_cast<const __hip_bfloat16 *>(Yb + i * YS + col), yv);
             else load4<float>(Ys + i * YS + col, yv);
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const float yy = keep_elem(seed, site, (uint64_t)(e0 + v), thr) ? yv[v] * scale : 0.f;
-                s[c][v] = xv[v] + yy;
-                sum += s[c][v];
+                xs[j][c][v] = xs[j][c][v] + yy;  // s = x + dropout(y)
+                sum += xs[j][c][v];
             }
         }
-        const float mu = wave_sum(sum) * (1.f / E);
+        mus[j] = wave_sum(sum) * (1.f / E);
+    }
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
         float sq = 0.f;
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const float d = s[c][v] - mu;
+                const float d = xs[j][c][v] - mus[j];
                 sq += d * d;
             }
-        const float rstd = rsqrtf(wave_sum(sq) * (1.f / E) + eps);
+        rstds[j] = rsqrtf(wave_sum(sq) * (1.f / E) + eps);
+    }
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const int col = c * 256 + lane * 4;
-            const long e0 = r * E + col;
-            float g[4], b[4], o[4];
-            load4<float>(gamma + col, g);
-            load4<float>(beta + col, b);
+    for (int j = 0; j < RPW; ++j) {
+        const int i = w + kWavesP * j;
+        const long r = r0 + i;
+        if (r < R) {  // wave-uniform
 #pragma unroll
-            for (int v = 0; v < 4; ++v) o[v] = (s[c][v] - mu) * rstd * g[v] + b[v];
-            store4<float>(s_out + e0, s[c]);
-            store4<float>(out + e0, o);
-            if (sum16 != nullptr) {
-                float p[4], q[4];
-                load4<float>(pos + (r * E) % pos_n + col, p);  // E divides pos_n: a row never wraps
+            for (int c = 0; c < NCH; ++c) {
+                const int col = c * 256 + lane * 4;
+                const long e0 = r * E + col;
+                float o[4];
 #pragma unroll
-                for (int v = 0; v < 4; ++v) q[v] = o[v] + p[v];
-                store4<__hip_bfloat16>(sum16 + e0, q);
+                for (int v = 0; v < 4; ++v) o[v] = (xs[j][c][v] - mus[j]) * rstds[j] * gs[c][v] + bs[c][v];
+                store4<float>(s_out + e0, xs[j][c]);
+                store4<float>(out + e0, o);
+                if (sum16 != nullptr) {
+                    float p[4], q[4];
+                    load4<float>(pos + pos_row(pbase, i, pos_rows) * E + col, p);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) q[v] = o[v] + p[v];
+                    store4<__hip_bfloat16>(sum16 + e0, q);
+                }
+                if (x16 != nullptr) store4<__hip_bfloat16>(x16 + e0, o);
             }
-            if (x16 != nullptr) store4<__hip_bfloat16>(x16 + e0, o);
+            if (lane == 0) mean_out[r] = mus[j], rstd_out[r] = rstds[j];
         }
-        if (lane == 0) mean_out[r] = mu, rstd_out[r] = rstd;
     }
 }
 
@@ -217,8 +300,8 @@ int launch_proj(long R, int K, const void *a, long a_ls, const void *W, const vo
         if (rc) return rc;
     }
     hipLaunchKernelGGL((pcm_proj_drln_fwd_kernel<E, MT>), dim3((unsigned)blocks), dim3(kThreadsP), smem, st, R, K, (const u16 *)a, a_ls,
-                       (const u16 *)W, bias, bias_is_bf16, x, gamma, beta, eps, p_drop, seed, site, s, out, mean, rstd, pos, pos_n,
-                       (__hip_bfloat16 *)sum16, (__hip_bfloat16 *)x16);
+                       (const u16 *)W, bias, bias_is_bf16, x, gamma, beta, eps, p_drop, seed, site, s, out, mean, rstd, pos,
+                       pos != nullptr && pos_n >= E ? pos_n / E : 1, (__hip_bfloat16 *)sum16, (__hip_bfloat16 *)x16);
     return PCM_LAUNCH_STATUS();
 }
 
@@ -242,9 +325,10 @@ extern "C" int pcm_proj_drln_mfma_forward_hip(long R, int E, int K, const void *
     if (sum_bf16 != nullptr && (pos == nullptr || pos_n <= 0 || pos_n % E != 0)) return PCM_ERR_BAD_ARG;
     if ((a_ls % 8) != 0 || (((uintptr_t)a_bf16 | (uintptr_t)w_bf16) % 16) != 0) return PCM_ERR_BAD_ARG;  // 16-byte operand loads
     hipStream_t st = (hipStream_t)stream;
-    // the 64-row tile needs rows * (K + 8) * 2 + rows * (E + 8) * 2 bytes of LDS: E + K <= 1232 (E = K = 512: 133 KiB); E = 1024 keeps the
-    // 16-row tile (four row tiles of 8 column tiles would need more than 256 registers)
-    const bool wide = R >= kLongRows && E <= 768 && (size_t)proj_smem_bytes(E, K, 4) <= 160 * 1024;
+    // the 64-row tile needs rows * (K + 8) * 2 + rows * (E + 8) * 2 bytes of LDS: E + K <= 1232 (E = K = 512: 133 KiB); E = 768 / 1024 keep the
+    // 16-row tile (eight rows of 768 values per wave in flight for the row phase, or four row tiles of 8 column tiles, need more than
+    // 256 registers: the 768-wide 64-row variant spilled 44 bytes)
+    const bool wide = R >= kLongRows && E <= 512 && (size_t)proj_smem_bytes(E, K, 4) <= 160 * 1024;
 #define PCM_PROJ(EE, MM)                                                                                                             \
     return launch_proj<EE, MM>(R, K, a_bf16, a_ls, w_bf16, bias, bias_is_bf16, x, gamma, beta, eps, p_drop, seed, site, s, out, mean, \
                                rstd, pos, pos_n, sum_bf16, out_bf16, st)
@@ -256,7 +340,6 @@ extern "C" int pcm_proj_drln_mfma_forward_hip(long R, int E, int K, const void *
         if (wide) PCM_PROJ(512, 4);
         PCM_PROJ(512, 1);
     case 768:
-        if (wide) PCM_PROJ(768, 4);
         PCM_PROJ(768, 1);
     default:
         PCM_PROJ(1024, 1);
@@ -287,7 +370,7 @@ constexpr int kLT = kLN / (16 * kLW);  // 16-column tiles per wave (4)
 template <bool OUT_BF16, int MT>
 __global__ __launch_bounds__(kLThreads) void pcm_linear_mfma_kernel(long R, int N, int K, const void *__restrict__ a, int a_is_f32,
                                                                     long a_ls, const u16 *__restrict__ a_alt, const float *__restrict__ pos,
-                                                                    long pos_n, int pos_cols, const u16 *__restrict__ W,
+                                                                    long pos_rows, int pos_cols, const u16 *__restrict__ W,
                                                                     const void *__restrict__ bias, int bias_is_bf16, void *__restrict__ out,
                                                                     long out_ls, u16 *__restrict__ emit_pos16, u16 *__restrict__ emit_x16)
 {
@@ -303,37 +386,6 @@ __global__ __launch_bounds__(kLThreads) void pcm_linear_mfma_kernel(long R, int 
     // the bf16 operands are the backward's weight-gradient operands: written out once, by the first column block of either kind
     u16 *emit = nullptr;
     if (a_is_f32) emit = with_pos ? (blockIdx.y == 0 ? emit_pos16 : nullptr) : ((c0 == (pos != nullptr ? pos_cols : 0)) ? emit_x16 : nullptr);
-
-    // ---- A panel -> LDS as bf16 (rows past R are zero)
-    if (a_is_f32) {
-        const float *x = reinterpret_cast<const float *>(a);
-        const int chunks = K / 4;  // float4 pieces per row
-        for (int c = tid; c < TM * chunks; c += kLThreads) {
-            const int i = c / chunks, kc = c % chunks;
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (r0 + i < R) {
-                load4<float>(x + (r0 + i) * a_ls + kc * 4, v);
-                if (with_pos) {
-                    float p[4];
-                    load4<float>(pos + ((r0 + i) * (long)K) % pos_n + kc * 4, p);  // K divides pos_n: a row never wraps
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) v[u] += p[u];
-                }
-            }
-            const uint2 pk = make_uint2(pcm_cvt_pk_bf16(v[0], v[1]), pcm_cvt_pk_bf16(v[2], v[3]));
-            *reinterpret_cast<uint2 *>(As + i * AS + kc * 4) = pk;
-            if (emit != nullptr && r0 + i < R) *reinterpret_cast<uint2 *>(emit + (r0 + i) * (long)K + kc * 4) = pk;
-        }
-    } else {
-        const u16 *ab = (!below && a_alt != nullptr) ? a_alt : reinterpret_cast<const u16 *>(a);
-        const int chunks = K / 8;
-        for (int c = tid; c < TM * chunks; c += kLThreads) {
-            const int i = c / chunks, kc = c % chunks;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (r0 + i < R) v = *reinterpret_cast<const uint4 *>(ab + (r0 + i) * a_ls + kc * 8);
-            *reinterpret_cast<uint4 *>(As + i * AS + kc * 8) = v;
-        }
-    }
 
     // ---- products (columns past N: the weight row index is clamped, the results are not stored)
     const int n0 = c0 + w * (kLN / kLW), li = lane & 15, lk = 8 * (lane >> 4);
@@ -366,6 +418,75 @@ __global__ __launch_bounds__(kLThreads) void pcm_linear_mfma_kernel(long R, int 
     };
     fetch(bq[0], 0);
     fetch(bq[1], 1);
+    // the bias of this lane's columns, requested under the products (was: round trips behind them); raw bits, converted at the use
+    uint32_t braw[kLT];
+    if (bias == nullptr) {
+#pragma unroll
+        for (int t = 0; t < kLT; ++t) braw[t] = 0u;
+    } else if (bias_is_bf16) {
+#pragma unroll
+        for (int t = 0; t < kLT; ++t) {
+            const int col = n0 + 16 * t + li;
+            braw[t] = reinterpret_cast<const u16 *>(bias)[col < N ? col : N - 1];
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < kLT; ++t) {
+            const int col = n0 + 16 * t + li;
+            braw[t] = reinterpret_cast<const uint32_t *>(bias)[col < N ? col : N - 1];
+        }
+    }
+    // ---- A panel -> LDS as bf16 (rows past R are zero); every load of a thread in flight before the first conversion / LDS store, and
+    // behind the first weight operands in program order (one exposed round trip before the products, not two)
+    constexpr int U = 8;
+    if (a_is_f32) {
+        const float *x = reinterpret_cast<const float *>(a);
+        const int cpr = K / 4;  // float4 pieces per row
+        const long pbase = with_pos ? r0 % pos_rows : 0;  // once per workgroup (the first version: a 64-bit modulo per piece)
+        auto convert = [&](int i, int kc, float (&v)[4], const float (&p)[4]) {
+            if (with_pos) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] += p[u];
+            }
+            const uint2 pk = make_uint2(pcm_cvt_pk_bf16(v[0], v[1]), pcm_cvt_pk_bf16(v[2], v[3]));
+            *reinterpret_cast<uint2 *>(As + i * AS + kc * 4) = pk;
+            if (emit != nullptr && r0 + i < R) *reinterpret_cast<uint2 *>(emit + (r0 + i) * (long)K + kc * 4) = pk;
+        };
+        if (kLThreads % cpr == 0) {  // K = 256, 512, 1024: thread (i0, kc) owns rows i0, i0 + T / cpr, ... of piece kc
+            const int rpp = kLThreads / cpr, i0 = tid / cpr, kc = tid - i0 * cpr;
+            for (int ib = i0; ib < TM; ib += U * rpp) {
+                float v[U][4], p[U][4];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int i = ib + u * rpp;
+                    v[u][0] = v[u][1] = v[u][2] = v[u][3] = 0.f;
+                    p[u][0] = p[u][1] = p[u][2] = p[u][3] = 0.f;
+                    if (i < TM && r0 + i < R) {
+                        load4<float>(x + (r0 + i) * a_ls + kc * 4, v[u]);
+                        if (with_pos) load4<float>(pos + pos_row(pbase, i, pos_rows) * K + kc * 4, p[u]);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int i = ib + u * rpp;
+                    if (i < TM) convert(i, kc, v[u], p[u]);
+                }
+            }
+        } else {
+            for (int c = tid; c < TM * cpr; c += kLThreads) {
+                const int i = c / cpr, kc = c % cpr;
+                float v[4] = {0.f, 0.f, 0.f, 0.f}, p[4] = {0.f, 0.f, 0.f, 0.f};
+                if (r0 + i < R) {
+                    load4<float>(x + (r0 + i) * a_ls + kc * 4, v);
+                    if (with_pos) load4<float>(pos + pos_row(pbase, i, pos_rows) * K + kc * 4, p);
+                }
+                convert(i, kc, v, p);
+            }
+        }
+    } else {
+        const u16 *ab = (!below && a_alt != nullptr) ? a_alt : reinterpret_cast<const u16 *>(a);
+        panel_bf16<TM, kLThreads, U>(ab, a_ls, r0, R, K, As, AS, tid);
+    }
     __syncthreads();  // A panel complete
     int kt = 0;
     for (; kt + 2 < ksteps; kt += 3) {
@@ -388,10 +509,8 @@ __global__ __launch_bounds__(kLThreads) void pcm_linear_mfma_kernel(long R, int 
     float *Of = reinterpret_cast<float *>(smem2);
 #pragma unroll
     for (int t = 0; t < kLT; ++t) {
-        const int lc = w * (kLN / kLW) + 16 * t + li, col = c0 + lc;
-        float bv = 0.f;
-        if (bias != nullptr && col < N)
-            bv = bias_is_bf16 ? bf2f(reinterpret_cast<const u16 *>(bias)[col]) : reinterpret_cast<const float *>(bias)[col];
+        const int lc = w * (kLN / kLW) + 16 * t + li;
+        const float bv = __uint_as_float(bias != nullptr && bias_is_bf16 ? braw[t] << 16 : braw[t]);  // columns past N are not stored
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -435,7 +554,8 @@ int launch_linear(long R, int N, int K, const void *a, int a_is_f32, long a_ls, 
         if (rc) return rc;
     }
     hipLaunchKernelGGL((pcm_linear_mfma_kernel<OUT_BF16, MT>), grid, dim3(kLThreads), smem, st, R, N, K, a, a_is_f32, a_ls, (const u16 *)a_alt,
-                       pos, pos_n, pos_cols, (const u16 *)W, bias, bias_is_bf16, out, out_ls, (u16 *)e_pos, (u16 *)e_x);
+                       pos, pos != nullptr && pos_n >= K ? pos_n / K : 1, pos_cols, (const u16 *)W, bias, bias_is_bf16, out, out_ls, (u16 *)e_pos,
+                       (u16 *)e_x);
     return PCM_LAUNCH_STATUS();
 }
 

@@ -26,6 +26,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="C2")
 ap.add_argument("--chain", default="off", choices=("off", "short", "long"))
 ap.add_argument("--copies", action="store_true")
+ap.add_argument("--sites", action="store_true", help="list every non-GEMM framework operator with its call site and shape")
+ap.add_argument("--tiny", action="store_true", help="B = 2 x 256 points -> 64 tokens (seconds instead of minutes; the encoder then takes attn_small)")
 ap.add_argument("--json", default=None)
 args = ap.parse_args()
 os.environ["PCM_PROJ_MFMA"] = os.environ["PCM_LINEAR_MFMA"] = "0" if args.chain == "off" else "1"
@@ -45,6 +47,8 @@ GEMM = ("mm.", "bmm.", "addmm.", "baddbmm.", "linear.", "matmul.", "_scaled_mm",
 COPY = ("copy_.", "clone.", "contiguous.", "_to_copy.")
 ops = collections.Counter()
 sites = collections.Counter()
+fsites = collections.Counter()
+gsites = collections.Counter()
 
 
 def where():
@@ -65,12 +69,19 @@ class Census(TorchDispatchMode):
             if t is not None and t.numel() <= 1 and kind != "gemm":
                 kind = kind + " (one element)"
             ops[(kind, name)] += 1
+            if kind == "gemm":
+                shp2 = " x ".join(str(tuple(x.shape)) for x in a if isinstance(x, torch.Tensor))
+                gsites[(name, where(), shp2)] += 1
+            if kind != "gemm":
+                fsites[(name, where(), tuple(t.shape) if t is not None else (), str(t.dtype).replace("torch.", "") if t is not None else "")] += 1
             if kind.startswith("copy"):
                 sites[(name, where(), tuple(t.shape) if t is not None else (), str(t.dtype).replace("torch.", "") if t is not None else "")] += 1
         return func(*a, **(kw or {}))
 
 
 wl = WORKLOADS[args.workload]
+if args.tiny:
+    wl = dict(wl, batch=2, n_points=256, pcd_npoints=64)
 assert wl["policy"] == "act", "census covers the ACT workloads"
 lib = library()
 lib.wavesim_census.restype = ctypes.c_long
@@ -111,6 +122,14 @@ if args.copies:
     print("copy-like operators by site:")
     for (name, w, shp, dt), c in sorted(sites.items(), key=lambda kv: -kv[1]):
         print("   %3d  %-18s %-58s %s %s" % (c, name, w, shp, dt))
+if args.sites:
+    print("non-GEMM framework operators by site:")
+    for (name, w, shp, dt), c in sorted(fsites.items(), key=lambda kv: (kv[0][0], -kv[1])):
+        print("   %3d  %-28s %-58s %s %s" % (c, name, w, shp, dt))
+if args.sites:
+    print("matrix products by site:")
+    for (name, w, shp), c in sorted(gsites.items(), key=lambda kv: (kv[0][1], kv[0][2])):
+        print("   %3d  %-14s %-52s %s" % (c, name, w, shp))
 if args.json:
     import json
 
