@@ -60,19 +60,15 @@ __global__ __launch_bounds__(kBlock) void pcm_bn_colsum_kernel(long n, int C, in
         }
         float sh[4] = {0.f, 0.f, 0.f, 0.f};
         if (MODE == 0) load4<T>(y + c0, sh);  // shift by row 0: sum (y - sh), sum (y - sh)^2 do not cancel when |mean| >> std
-        for (long r = r_begin + mp.rsub; r < r_end; r += mp.rpp) {
-            float v[4];
-            load4<T>(y + r * C + c0, v);
+        auto accumulate = [&](const float(&v)[4], const float(&d)[4]) {
             if (MODE == 0) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const float d = v[u] - sh[u];
-                    s0[u] += d;
-                    s1[u] += d * d;
+                    const float dd = v[u] - sh[u];
+                    s0[u] += dd;
+                    s1[u] += dd * dd;
                 }
             } else {
-                float d[4];
-                load4<T>(dz + r * C + c0, d);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     float g;
@@ -82,6 +78,26 @@ __global__ __launch_bounds__(kBlock) void pcm_bn_colsum_kernel(long n, int C, in
                     s1[u] += g * ((v[u] - mean[u]) * invstd[u]);
                 }
             }
+        };
+        // four rows in flight, accumulated in row order: same sums as the one-row loop, which waited for every row's loads in turn
+        // (tools/isa_load_chains.py: >= 8 exposed round trips in series per thread)
+        long r = r_begin + mp.rsub;
+        for (; r + 3 * mp.rpp < r_end; r += 4 * (long)mp.rpp) {
+            float v[4][4], d[4][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                load4<T>(y + (r + q * (long)mp.rpp) * C + c0, v[q]);
+                if (MODE != 0) load4<T>(dz + (r + q * (long)mp.rpp) * C + c0, d[q]);
+                else d[q][0] = d[q][1] = d[q][2] = d[q][3] = 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) accumulate(v[q], d[q]);
+        }
+        for (; r < r_end; r += mp.rpp) {
+            float v[4], d[4] = {0.f, 0.f, 0.f, 0.f};
+            load4<T>(y + r * C + c0, v);
+            if (MODE != 0) load4<T>(dz + r * C + c0, d);
+            accumulate(v, d);
         }
     }
 #pragma unroll

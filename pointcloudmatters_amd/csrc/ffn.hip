@@ -323,8 +323,7 @@ __global__ __launch_bounds__(512) void pcm_ffn_reduce_kernel(int nslots, int VH,
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + lane;
     double acc = 0.0;
-    if (e < VH)
-        for (int s = wave; s < nslots; s += 8) acc += (double)partial[(size_t)s * VH + e];
+    if (e < VH) acc = pcm_slot_sum(partial, (size_t)VH, e, wave, 8, nslots);
     red[wave][lane] = acc;
     __syncthreads();
     if (wave == 0 && e < VH) {

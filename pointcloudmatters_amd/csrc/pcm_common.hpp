@@ -98,6 +98,25 @@ __device__ __forceinline__ PcmXcdSplit pcm_xcd_split(long rows, long per_block)
 }
 static inline int pcm_xcd_grid(long blocks) { return (int)(blocks >= 8 ? (blocks + 7) / 8 * 8 : (blocks < 1 ? 1 : blocks)); }
 
+// Closing reduction of partial rows: sum over slots s0, s0 + step, ... (< nslots) of partial[s * VH + e] in fp64, IN THAT ORDER, with
+// eight loads in flight.  The plain loop `acc += partial[s * VH + e]` compiles to load - s_waitcnt vmcnt(0) - add per slot: one exposed
+// L2 round trip per slot and wave (tools/isa_load_chains.py), 30-130 in series for the 256-1030 partial rows of an ACT step's reductions.
+// The values are added in the same order as before: the sums are bit-identical.
+__device__ __forceinline__ double pcm_slot_sum(const float *__restrict__ partial, size_t VH, int e, int s0, int step, int nslots)
+{
+    double acc = 0.0;
+    int s = s0;
+    for (; s + 7 * step < nslots; s += 8 * step) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(s + u * step) * VH + e];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += (double)v[u];
+    }
+    for (; s < nslots; s += step) acc += (double)partial[(size_t)s * VH + e];
+    return acc;
+}
+
 __device__ __forceinline__ int pcm_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 // Squared distance in the reference's order: (a-b)*(a-b) for x, y, z summed left to right.

@@ -84,13 +84,25 @@ __device__ __forceinline__ void colsum_body(long rows, int C, long rows_per_slot
     const long r0 = (long)slot * rows_per_slot;
     const long r1 = r0 + rows_per_slot < rows ? r0 + rows_per_slot : rows;
     float s[4] = {0.f, 0.f, 0.f, 0.f};
-    if (act)
-        for (long r = r0 + rsub; r < r1; r += rpp) {
+    if (act) {
+        // four rows in flight, added in row order (the one-row loop waited for every load in turn: >= 8 round trips in series per thread)
+        long r = r0 + rsub;
+        for (; r + 3 * rpp < r1; r += 4 * (long)rpp) {
+            float v[4][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) load4<T>(g + (r + q * (long)rpp) * ld + col4 * 4, v[q]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) s[u] += v[q][u];
+        }
+        for (; r < r1; r += rpp) {
             float v[4];
             load4<T>(g + r * ld + col4 * 4, v);
 #pragma unroll
             for (int u = 0; u < 4; ++u) s[u] += v[u];
         }
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) lds[u * kBlock + threadIdx.x] = s[u];
     __syncthreads();
@@ -152,8 +164,7 @@ __global__ __launch_bounds__(512) void pcm_colsum_reduce_kernel(int nslots, int 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + lane;
     double acc = 0.0;
-    if (e < VH)
-        for (int s = wave; s < nslots; s += 8) acc += (double)partial[(size_t)s * VH + e];
+    if (e < VH) acc = pcm_slot_sum(partial, (size_t)VH, e, wave, 8, nslots);
     red[wave][lane] = acc;
     __syncthreads();
     if (wave == 0 && e < VH) {
@@ -191,8 +202,7 @@ __global__ __launch_bounds__(512) void pcm_reduce_batch_kernel(ReduceBatch b)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e = ((int)blockIdx.x - D.blk0) * 64 + lane;
     double acc = 0.0;
-    if (e < VH)
-        for (int s = wave; s < nslots; s += 8) acc += (double)partial[(size_t)s * VH + e];
+    if (e < VH) acc = pcm_slot_sum(partial, (size_t)VH, e, wave, 8, nslots);
     red[wave][lane] = acc;
     __syncthreads();
     if (wave == 0 && e < VH) {
