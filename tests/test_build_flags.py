@@ -58,3 +58,52 @@ def test_shipped_library_reads_no_environment():
     if os.path.exists(lib) and nm:
         syms = subprocess.run([nm, "-D", "--undefined-only", lib], capture_output=True, text=True, timeout=60).stdout
         assert "getenv" not in syms
+
+
+def _main_loop_loads(asm, kernel_substr):
+    """Largest number of global loads inside ONE innermost loop of the kernels whose mangled name contains `kernel_substr`."""
+    lines = asm.splitlines()
+    starts = [i for i, l in enumerate(lines) if re.match(r"^_Z\w+:", l)]
+    best = {}
+    for k, i in enumerate(starts):
+        name = lines[i].split(":")[0]
+        if kernel_substr not in name:
+            continue
+        end = starts[k + 1] if k + 1 < len(starts) else len(lines)
+        body, top = lines[i:end], 0
+        for h, l in enumerate(body):
+            m = re.match(r"^(\.LBB\d+_\d+):.*Inner Loop Header", l)
+            if m:
+                back = [j for j in range(h + 1, len(body)) if re.search(r"s_cbranch\w*\s+%s\b" % re.escape(m.group(1)), body[j])]
+                if back:
+                    top = max(top, sum("global_load" in x for x in body[h:back[-1] + 1]))
+        best[name] = top
+    return best
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not installed")
+@pytest.mark.parametrize("src,kernel,least", [
+    ("tokens.hip", "pcm_reduce_batch_kernel", 8),      # closing reductions: eight partial rows in flight (pcm_slot_sum)
+    ("tokens.hip", "pcm_colsum_batch_kernel", 4),      # column sums: four rows in flight
+    ("drln.hip", "pcm_drln_reduce_kernel", 8),
+    ("sa_fused.hip", "pcm_sa_reduce_kernel", 8),
+    ("proj_ln.hip", "pcm_linear_mfma_kernelILb1ELi1E", 8),   # fp32 A panel: eight rows (+ their position rows) in flight
+])
+def test_latency_bound_loops_keep_their_loads_in_flight(src, kernel, least, tmp_path):
+    """Round 5's static audit (tools/isa_load_chains.py): these loops compiled to load - s_waitcnt vmcnt(0) - use, one exposed L2 round
+    trip per iteration.  They were rewritten to request several rows first and consume them in the same order; this keeps a refactoring
+    (or a compiler update) from quietly serialising them again.  Also: csrc/proj_ln.hip has no scratch (its 768-wide 64-row variant
+    spilled and was dropped)."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    out = tmp_path / (src + ".s")
+    r = subprocess.run([hipcc] + _flags() + ["--cuda-device-only", "-S", os.path.join(CSRC, src), "-o", str(out)], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    asm = out.read_text()
+    found = _main_loop_loads(asm, kernel)
+    assert found, "kernel %s not found in %s" % (kernel, src)
+    for name, loads in found.items():
+        assert loads >= least, "%s: at most %d global loads in flight in any inner loop (want >= %d)" % (name, loads, least)
+    if src == "proj_ln.hip":
+        sizes = [int(v) for v in re.findall(r"\.private_segment_fixed_size:\s*(\d+)", asm)]
+        assert sizes and max(sizes) == 0, "scratch in csrc/proj_ln.hip: %s" % sizes
