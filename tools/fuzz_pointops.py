@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """Long randomized parity campaign of the index kernels against the CPU oracle (bit-exact), beyond the 24 seeded cases of
 tests/test_pointops_fuzz_gpu.py: FPS, kNN, ball query and random ball query on ragged batches with tie-heavy data.
-Usage (on the GPU box): python tools/fuzz_pointops.py --seconds 240 [--seed0 0].  Exit status 1 on the first mismatch."""
+Usage (on the GPU box): python tools/fuzz_pointops.py --seconds 240 [--seed0 0].  Exit status 1 on the first mismatch.
+--model runs the same campaign on the HOST wave64 model (tests/wavesim: the kernel sources compiled for the CPU; no GPU needed, sizes capped
+so that a layout takes seconds): evidence about the kernels' logic, also under WAVESIM_ORDER=reverse|shuffle:N (another lane interleaving)."""
 import argparse
 import os
 import sys
@@ -20,19 +22,28 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed0", type=int, default=0)
+    ap.add_argument("--model", action="store_true", help="run on the host wave64 model instead of cuda:0")
     a = ap.parse_args()
+    if a.model:
+        from tests.wavesim.backend import simulated_device
+
+        with simulated_device() as dev:
+            return campaign(a, dev, scales=[2, 9, 70, 400, 1100, 2100], m_cap=600)
+    return campaign(a, torch.device("cuda", 0), scales=[2, 9, 70, 400, 1100, 2100, 4200, 9000], m_cap=2500)
+
+
+def campaign(a, d, scales, m_cap):
     import pointcloudmatters_amd.pointops as po
     from oracle import pointops_cpu as ref
     from pointcloudmatters_amd.pointops.query import ball_query_raw, knn_query_raw, random_ball_query_raw
 
-    d = torch.device("cuda", 0)
     t0, n_cases, seed = time.time(), 0, a.seed0
     while time.time() - t0 < a.seconds:
         rng = np.random.default_rng(50_000 + seed)
         b = int(rng.integers(1, 10))
-        scale = int(rng.choice([2, 9, 70, 400, 1100, 2100, 4200, 9000]))
+        scale = int(rng.choice(scales))
         sizes = [int(rng.integers(1, scale + 1)) for _ in range(b)]
-        ms = [int(rng.integers(1, min(max(2 * s, 2), 2500) + 1)) for s in sizes]
+        ms = [int(rng.integers(1, min(max(2 * s, 2), m_cap) + 1)) for s in sizes]
         mode = str(rng.choice(["uniform", "lattice", "dup"]))
         lattice = float(rng.choice([0.003, 0.02, 0.1, 0.3]))
         xyz, off = make_clouds(sizes, seed=seed, mode=mode, lattice=lattice)
@@ -66,7 +77,8 @@ def main():
                 return 1
         n_cases += 1
         seed += 1
-    print(f"fuzz ok: {n_cases} random layouts (seeds {a.seed0}..{seed - 1}), FPS / kNN / ball / random-ball bit-exact vs the oracle")
+    where = "host wave64 model%s" % ((", WAVESIM_ORDER=" + os.environ["WAVESIM_ORDER"]) if os.environ.get("WAVESIM_ORDER") else "") if a.model else "cuda:0"
+    print(f"fuzz ok on {where}: {n_cases} random layouts (seeds {a.seed0}..{seed - 1}), FPS / kNN / ball / random-ball bit-exact vs the oracle")
     return 0
 
 
