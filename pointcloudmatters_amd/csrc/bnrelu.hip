@@ -232,9 +232,12 @@ template <typename T, bool RELU = true>
 __global__ __launch_bounds__(kBlock) void pcm_bn_relu_apply_kernel(long total4, int C, const T *__restrict__ y,
                                                                    const float *__restrict__ stat, T *__restrict__ z)
 {
+    asm volatile("" ::"s"(gridDim.x), "s"(total4), "s"(C), "s"(y), "s"(stat), "s"(z));  // "Kernel heads", pcm_common.hpp
+    const unsigned c4n = (unsigned)C / 4u;
     for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < total4; i += (long)gridDim.x * kBlock) {
         const long e = i * 4;
-        const int c = (int)(e % C);
+        // channel of element e = 4 i: a 32-bit remainder whenever the tensor has fewer than 2^32 four-element pieces (always, here)
+        const int c = total4 <= 0xFFFFFFFFl ? (int)(((unsigned)i % c4n) * 4u) : (int)(e % C);
         float v[4], a[4], b[4], o[4];
         load4<T>(y + e, v);
         load4<float>(stat + 2 * C + c, a);
@@ -254,9 +257,11 @@ __global__ __launch_bounds__(kBlock) void pcm_bn_relu_bwd_apply_kernel(long tota
                                                                        const T *__restrict__ dz, const float *__restrict__ stat,
                                                                        const float *__restrict__ sums, T *__restrict__ dy)
 {
+    asm volatile("" ::"s"(gridDim.x), "s"(total4), "s"(C), "s"(inv_n), "s"(y), "s"(dz), "s"(stat), "s"(sums), "s"(dy));  // "Kernel heads", pcm_common.hpp
+    const unsigned c4n = (unsigned)C / 4u;
     for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < total4; i += (long)gridDim.x * kBlock) {
         const long e = i * 4;
-        const int c = (int)(e % C);
+        const int c = total4 <= 0xFFFFFFFFl ? (int)(((unsigned)i % c4n) * 4u) : (int)(e % C);
         float v[4], d[4], mean[4], invstd[4], a[4], b[4], sg[4], sgx[4], o[4];
         load4<T>(y + e, v);
         load4<T>(dz + e, d);

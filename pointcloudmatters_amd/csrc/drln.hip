@@ -34,6 +34,8 @@ __global__ __launch_bounds__(kBlock) void pcm_drln_fwd_kernel(long R, const floa
                                                               __hip_bfloat16 *__restrict__ sum16, __hip_bfloat16 *__restrict__ x16)
 {
     constexpr int E = NCH * 256;
+    // every kernel argument in registers HERE: one batch of kernarg loads, one wait ("Kernel heads" in pcm_common.hpp)
+    asm volatile("" ::"s"(gridDim.x), "s"(R), "s"(x), "s"(y), "s"(gamma), "s"(beta), "s"(eps), "s"(p_drop), "s"(seed_ptr), "s"(site), "s"(s_out), "s"(out), "s"(mean_out), "s"(rstd_out), "s"(pos), "s"(pos_n), "s"(sum16), "s"(x16));
     const int lane = threadIdx.x & 63;
     const long wave0 = (long)blockIdx.x * kWaves + (threadIdx.x >> 6), nwaves = (long)gridDim.x * kWaves;
     const bool drop = p_drop > 0.f;
@@ -63,9 +65,14 @@ __global__ __launch_bounds__(kBlock) void pcm_drln_fwd_kernel(long R, const floa
             float xv[4], yv[4];
             load4<float>(x + e0, xv);
             load4<T>(y + e0, yv);
+            // the seed is first touched HERE, behind the row's loads in program order: its own load (issued at the kernel's entry) is
+            // then waited for with the row's loads in flight instead of in front of them (the opaque asm keeps the compiler from hoisting
+            // the hash constants -- and with them the wait -- back in front of the loop)
+            uint64_t seed_r = seed;
+            asm volatile("" : "+v"(seed_r));
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const float yy = (keep_elem(seed, site, (uint64_t)(e0 + v), thr)) ? yv[v] * scale : 0.f;
+                const float yy = (keep_elem(seed_r, site, (uint64_t)(e0 + v), thr)) ? yv[v] * scale : 0.f;
                 s[c][v] = xv[v] + yy;
                 sum += s[c][v];
             }
@@ -113,6 +120,7 @@ __global__ __launch_bounds__(kBlock) void pcm_drln_bwd_kernel(long R, const floa
 {
     constexpr int E = NCH * 256;
     __shared__ float lds[kWaves][3][E];
+    asm volatile("" ::"s"(gridDim.x), "s"(R), "s"(dout), "s"(dout2), "s"(s), "s"(mean), "s"(rstd), "s"(gamma), "s"(p_drop), "s"(seed_ptr), "s"(site), "s"(dx), "s"(dy), "s"(partial));  // "Kernel heads", pcm_common.hpp
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long wave0 = (long)blockIdx.x * kWaves + wave, nwaves = (long)gridDim.x * kWaves;
     const bool drop = p_drop > 0.f;
@@ -163,6 +171,8 @@ __global__ __launch_bounds__(kBlock) void pcm_drln_bwd_kernel(long R, const floa
             }
         }
         const float m1 = wave_sum(s1) * (1.f / E), m2 = wave_sum(s2) * (1.f / E);
+        uint64_t seed_r = seed;  // first touched behind the row's loads: "Kernel heads", pcm_common.hpp
+        asm volatile("" : "+v"(seed_r));
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const long e0 = r * E + c * 256 + lane * 4;
@@ -170,7 +180,7 @@ __global__ __launch_bounds__(kBlock) void pcm_drln_bwd_kernel(long R, const floa
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 o[v] = rs * (gd[c][v] - m1 - xh[c][v] * m2);
-                oy[v] = (keep_elem(seed, site, (uint64_t)(e0 + v), thr)) ? o[v] * scale : 0.f;
+                oy[v] = (keep_elem(seed_r, site, (uint64_t)(e0 + v), thr)) ? o[v] * scale : 0.f;
                 dys[c][v] += oy[v];  // column sums of dy = the bias gradient of the projection that produced y
             }
             store4<float>(dx + e0, o);

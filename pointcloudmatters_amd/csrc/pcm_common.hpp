@@ -98,6 +98,15 @@ __device__ __forceinline__ PcmXcdSplit pcm_xcd_split(long rows, long per_block)
 }
 static inline int pcm_xcd_grid(long blocks) { return (int)(blocks >= 8 ? (blocks + 7) / 8 * 8 : (blocks < 1 ? 1 : blocks)); }
 
+// Kernel heads.  The compiler sinks every kernel-argument load (s_load from the kernarg segment) to the block that first uses the
+// argument; a kernel that tests `p_drop > 0` before it reads `seed_ptr`, the seed, R and then the rest starts with a CHAIN of four or
+// five dependent scalar round trips before its first vector load is even issued (read in the ISA of csrc/drln.hip; the phase clocks of
+// csrc/ffn_mfma.hip measured "kernel arguments -> seed -> operand loads" at ~5 k clocks in round 4).  An empty asm statement that names
+// the arguments as scalar inputs at the top of the kernel --   asm volatile("" ::"s"(R), "s"(x), ...);   -- forces all of them into
+// registers there: the loads leave as one batch, one wait.  The dropout seed (a load THROUGH one of those arguments) is taken off the
+// chain the same way from the other side: it is first touched behind the row's vector loads (`asm volatile("" : "+v"(seed_r))` keeps
+// the hash constants from being hoisted in front of them again).  tests/wavesim strips both (build.py rewrite 3).
+
 // Closing reduction of partial rows: sum over slots s0, s0 + step, ... (< nslots) of partial[s * VH + e] in fp64, IN THAT ORDER, with
 // eight loads in flight.  The plain loop `acc += partial[s * VH + e]` compiles to load - s_waitcnt vmcnt(0) - add per slot: one exposed
 // L2 round trip per slot and wave (tools/isa_load_chains.py), 30-130 in series for the 256-1030 partial rows of an ACT step's reductions.

@@ -93,6 +93,8 @@ __global__ __launch_bounds__(kThreadsP) void pcm_proj_drln_fwd_kernel(
     float *__restrict__ rstd_out, const float *__restrict__ pos, long pos_rows, __hip_bfloat16 *__restrict__ sum16,
     __hip_bfloat16 *__restrict__ x16)
 {
+    // every argument in registers at the entry: one batch of kernarg loads ("Kernel heads", pcm_common.hpp)
+    asm volatile("" ::"s"(R), "s"(K), "s"(a), "s"(a_ls), "s"(W), "s"(bias), "s"(bias_is_bf16), "s"(x), "s"(gamma), "s"(beta), "s"(eps), "s"(p_drop), "s"(seed_ptr), "s"(site), "s"(s_out), "s"(out), "s"(mean_out), "s"(rstd_out), "s"(pos), "s"(pos_rows), "s"(sum16), "s"(x16));
     constexpr int TM = kTM * MT;            // rows per workgroup
     constexpr int RPW = TM / kWavesP;       // rows a wave finishes in the row phase (2 or 8)
     constexpr bool EARLY = MT == 1;         // the rows' x values are requested BEFORE the products (16 registers); MT = 4: behind them
@@ -374,6 +376,7 @@ __global__ __launch_bounds__(kLThreads) void pcm_linear_mfma_kernel(long R, int 
                                                                     const void *__restrict__ bias, int bias_is_bf16, void *__restrict__ out,
                                                                     long out_ls, u16 *__restrict__ emit_pos16, u16 *__restrict__ emit_x16)
 {
+    asm volatile("" ::"s"(R), "s"(N), "s"(K), "s"(a), "s"(a_is_f32), "s"(a_ls), "s"(a_alt), "s"(pos), "s"(pos_rows), "s"(pos_cols), "s"(W), "s"(bias), "s"(bias_is_bf16), "s"(out), "s"(out_ls), "s"(emit_pos16), "s"(emit_x16));  // "Kernel heads", pcm_common.hpp
     constexpr int TM = kTM * MT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
     const int AS = K + kAPad;
