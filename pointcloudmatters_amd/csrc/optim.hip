@@ -219,11 +219,9 @@ struct XferBatch {
 __global__ __launch_bounds__(256) void pcm_xfer_batch_kernel(XferBatch b)
 {
     const int c = blockIdx.x;
-    int lo = 0, hi = b.n - 1;  // the job whose chunk range holds c (wave-uniform: scalar loads from the argument segment)
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (b.chunk0[mid] <= c) lo = mid; else hi = mid - 1;
-    }
+    // the job whose chunk range holds c: one lane-indexed load of the table + a ballot (was a bisection: 7 dependent scalar loads)
+    const int lo = pcm_job_of(c, b.n, [&](int j) { return b.chunk0[j]; });
+    asm volatile("" ::"s"((int)b.kind[lo]), "s"(b.chunk0[lo]), "s"(b.numel[lo]), "s"(b.dst[lo]), "s"(b.src[lo]));  // one batch: "Kernel heads", pcm_common.hpp
     const int kind = b.kind[lo];
     const long e0 = (long)(c - b.chunk0[lo]) * kXferChunk;
     const int len = b.numel[lo] - e0 < kXferChunk ? (int)(b.numel[lo] - e0) : kXferChunk;

@@ -107,6 +107,24 @@ static inline int pcm_xcd_grid(long blocks) { return (int)(blocks >= 8 ? (blocks
 // chain the same way from the other side: it is first touched behind the row's vector loads (`asm volatile("" : "+v"(seed_r))` keeps
 // the hash constants from being hoisted in front of them again).  tests/wavesim strips both (build.py rewrite 3).
 
+// Job lookup of the table-driven batch kernels (tokens.hip, optim.hip): the index of the job whose first workgroup `first(j)` is the
+// last one <= blk, for n <= 128 jobs with ascending first(j), first(0) == 0.  `first` reads the table in the kernel-argument segment
+// with a LANE-dependent index: one vector load per 64 jobs, one ballot -- the scalar loop `for (j = 1; j < n; ++j) if (blk >= first(j))
+// i = j;` it replaces was n - 1 dependent scalar loads (s_load, s_waitcnt lgkmcnt(0), compare: up to 31 round trips in series at the head
+// of a 6-25 us kernel; the bisection of pcm_xfer_batch_kernel: 7).
+template <class F>
+__device__ __forceinline__ int pcm_job_of(int blk, int n, F first)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    int cnt = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int j = base + lane;
+        const bool le = j >= 1 && j < n && first(j) <= blk;
+        cnt += __popcll(__ballot(le));
+    }
+    return cnt;
+}
+
 // Closing reduction of partial rows: sum over slots s0, s0 + step, ... (< nslots) of partial[s * VH + e] in fp64, IN THAT ORDER, with
 // eight loads in flight.  The plain loop `acc += partial[s * VH + e]` compiles to load - s_waitcnt vmcnt(0) - add per slot: one exposed
 // L2 round trip per slot and wave (tools/isa_load_chains.py), 30-130 in series for the 256-1030 partial rows of an ACT step's reductions.
