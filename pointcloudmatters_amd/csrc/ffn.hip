@@ -108,6 +108,9 @@ __global__ __launch_bounds__(kThreads) void pcm_ffn_ln_fwd_kernel(long R, const 
     static_assert(F == 32 && E % 256 == 0, "specialised for dim_feedforward = 32");
     constexpr int PER = E / 64;
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    // every argument in registers at the entry, i.e. their loads travel UNDER the weight staging ("Kernel heads", pcm_common.hpp; the
+    // compiler had put them -- R, the pointers, the seed through its pointer: five dependent scalar round trips -- behind the barrier)
+    asm volatile("" ::"s"(gridDim.x), "s"(R), "s"(x), "s"(W1), "s"(b1), "s"(W2), "s"(b2), "s"(gamma), "s"(beta), "s"(eps), "s"(pa), "s"(pb), "s"(seed_ptr), "s"(site_a), "s"(site_b), "s"(hd_out), "s"(s_out), "s"(out), "s"(mean_out), "s"(rstd_out), "s"(pos), "s"(pos_n), "s"(sum16), "s"(x16));
     float *w1 = lds, *w2t = lds + F * E;
     stage_weights<E, F>(w1, w2t, W1, W2);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -210,6 +213,7 @@ __global__ __launch_bounds__(kThreads) void pcm_ffn_ln_bwd_kernel(long R, const 
     constexpr int PER = E / 64;
     constexpr int PW = 3 * E + F;
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    asm volatile("" ::"s"(gridDim.x), "s"(R), "s"(dout), "s"(dout2), "s"(x), "s"(s), "s"(mean), "s"(rstd), "s"(hd), "s"(W1), "s"(W2), "s"(gamma), "s"(pa), "s"(pb), "s"(seed_ptr), "s"(site_b), "s"(dx), "s"(dy), "s"(dh_out), "s"(partial));  // "Kernel heads", pcm_common.hpp
     float *w1 = lds, *w2t = lds + F * E;
     stage_weights<E, F>(w1, w2t, W1, W2);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
