@@ -86,6 +86,9 @@ __device__ __forceinline__ void fwd_tile(const u16 *Ks, const u16 *Vs, const bf8
                                          int kt, int lane, const AttnParams &P, const unsigned char *mask, const DropCfg &dc, uint32_t rb)
 {
     const int h8 = 8 * (lane >> 5), h4 = 4 * (lane >> 5);
+    // the tile's 32 mask bytes: ONE load (lane t and t + 32 read key t), turned into a wave mask behind the matrix instructions below; the
+    // 16 short-circuit conditions used to load `mask[key]` one by one, each with a full wait (tile_visible, pcm_attn.hpp)
+    const unsigned mbyte = tile_mask_byte(mask, kt * KT - (lane & 32), P.S, lane);
     // every LDS operand of this tile is requested up front: the reads drain while the matrix cores and the softmax run
     bf8 ka[4], va0[2], va1[2];
 #pragma unroll
@@ -104,14 +107,11 @@ __device__ __forceinline__ void fwd_tile(const u16 *Ks, const u16 *Vs, const bf8
     const bool edge = (kt + 1) * KT > P.S || mask != nullptr;
     const float scale2 = P.scale * 1.44269504088896f;  // scores in the log2 domain: the exponentials are bare v_exp_f32
     float tmax = -INFINITY;
+    const lanemask visb = edge ? tile_visible(mbyte, kt * KT - (lane & 32), P.S, lane) >> h4 : ~0ull;  // bit crow(r, 0) <-> this lane's row r
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         s[r] *= scale2;
-        if (edge) {
-            const int key = kt * KT + crow(r, lane);
-            const bool vis = key < P.S && !(mask != nullptr && mask[key] != 0);
-            s[r] = vis ? s[r] : -INFINITY;
-        }
+        if (edge) s[r] = ((visb >> ((r & 3) + 8 * (r >> 2))) & 1ull) ? s[r] : -INFINITY;
         tmax = fmaxf(tmax, s[r]);
     }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
@@ -328,6 +328,7 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_small_bwd_kernel(AttnParams P,
         for (int kt = w; kt < nkt; kt += NW) {
             tile_store(kr, Ks, lane);
             tile_store(vr, Vs, lane);
+            const unsigned mbyte = tile_mask_byte(mask, kt * KT - (lane & 32), P.S, lane);  // one load per tile, before the prefetch (tile_visible, pcm_attn.hpp)
             if (kt + NW < nkt) {
                 tile_fetch(kr, kb, P.k_ls, (kt + NW) * KT, P.S, lane);
                 tile_fetch(vr, vb, P.v_ls, (kt + NW) * KT, P.S, lane);
@@ -342,6 +343,7 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_small_bwd_kernel(AttnParams P,
                 dp = PCM_MFMA(lds_s4(Vs + off), gf[sl], dp);
             }
             const bool edge = (kt + 1) * KT > P.S || mask != nullptr;
+            const lanemask visb = edge ? tile_visible(mbyte, kt * KT - (lane & 32), P.S, lane) >> (4 * (lane >> 5)) : ~0ull;
             float ds[16];
             if (DROP) {
 #pragma unroll
@@ -355,11 +357,7 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_small_bwd_kernel(AttnParams P,
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float pr = __builtin_amdgcn_exp2f(s[r] * scale2 - lq2);
-                if (edge) {
-                    const int key = kt * KT + crow(r, lane);
-                    const bool vis = key < P.S && !(mask != nullptr && mask[key] != 0);
-                    pr = vis ? pr : 0.f;
-                }
+                if (edge) pr = ((visb >> ((r & 3) + 8 * (r >> 2))) & 1ull) ? pr : 0.f;
                 ds[r] = pr * (dp[r] - Dq) * P.scale;
             }
 #pragma unroll

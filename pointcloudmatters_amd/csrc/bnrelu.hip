@@ -44,6 +44,7 @@ __global__ __launch_bounds__(kBlock) void pcm_bn_colsum_kernel(long n, int C, in
                                                                const float *__restrict__ stat, float *__restrict__ partial)
 {
     __shared__ float lds[8 * kBlock];
+    asm volatile("" ::"s"(n), "s"(C), "s"(chunkW), "s"(rows_per_slot), "s"(y), "s"(dz), "s"(stat), "s"(partial));  // "Kernel heads", pcm_common.hpp
     const RowMap mp(chunkW);
     const int c0 = blockIdx.y * chunkW + mp.col4 * 4;
     const bool act = mp.active && c0 < C;
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(64 * kRedWaves) void pcm_bn_reduce_kernel(int nslot
                                                                          float *__restrict__ out)
 {
     __shared__ double red[kRedWaves][64];
+    asm volatile("" ::"s"(nslots), "s"(VH), "s"(partial), "s"(out));  // "Kernel heads", pcm_common.hpp
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + lane;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;  // four independent chains: four loads in flight per lane
@@ -187,6 +189,7 @@ __global__ __launch_bounds__(64 * kRedWaves) void pcm_bn_reduce_stats_kernel(int
                                                                                float *__restrict__ running_var)
 {
     __shared__ double red[2][kRedWaves][64];
+    asm volatile("" ::"s"(nslots), "s"(C), "s"(partial), "s"(sums), "s"(count), "s"(eps), "s"(momentum), "s"(y), "s"(gamma), "s"(beta), "s"(stat), "s"(running_mean), "s"(running_var));  // "Kernel heads", pcm_common.hpp
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     const int VH = 2 * C;

@@ -74,6 +74,21 @@ __device__ __forceinline__ int crow(int r, int lane)  // accumulator register r 
     return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
 }
 
+// Visibility of the 64 keys key0 .. key0 + 63 of one batch row: the byte each lane has loaded for ITS key (tile_mask_byte: one coalesced
+// load per tile, requested before the tile's key / value prefetch so that waiting for it leaves those loads in flight) becomes a wave
+// mask, bit t <-> key key0 + t.  The masked kernels used to read `mask[key]` inside the 32 short-circuit conditions of a tile: 32 times
+// global_load_ubyte + s_waitcnt vmcnt(0) in series (each wait also drained the prefetch) -- read in the ISA in round 5.
+__device__ __forceinline__ unsigned tile_mask_byte(const unsigned char *mask, int key0, int S, int lane)
+{
+    const int key = key0 + lane;
+    return (mask != nullptr && key < S) ? (unsigned)mask[key] : 0u;
+}
+__device__ __forceinline__ unsigned long long tile_visible(unsigned mask_byte, int key0, int S, int lane)
+{
+    asm volatile("" : "+v"(mask_byte));  // the comparison stays HERE, behind the tile's matrix instructions (the compiler had moved it -- and the wait -- up to the load)
+    return __ballot(key0 + lane < S && mask_byte == 0u);
+}
+
 // dropout on the attention weights.  One 32-bit hash serves the PAIR of adjacent keys (2j, 2j+1) of a query:
 //   h = mixp(rowbase(b, h, q) + j * C);  keep(2j) = (h & 0xFFFF) >= thr16,  keep(2j+1) = (h >> 16) >= thr16,
 // thr16 = round(p * 65536) (|p_eff - p| < 8e-6).  mixp uses a 24-bit multiply (full-rate v_mul_u32_u24; the 32-bit

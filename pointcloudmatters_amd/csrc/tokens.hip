@@ -166,6 +166,7 @@ __global__ __launch_bounds__(512) void pcm_colsum_reduce_kernel(int nslots, int 
                                                                 TO *__restrict__ out)
 {
     __shared__ double red[8][64];
+    asm volatile("" ::"s"(nslots), "s"(VH), "s"(partial), "s"(out));  // "Kernel heads", pcm_common.hpp
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + lane;
     double acc = 0.0;
