@@ -24,3 +24,9 @@ echo "bench (mfma chain) rc=$?"; cut -c1-200 "$OUT/bench_mfma_chain.json"
 timeout 600 python bench.py --tokenizer-bf16 --no-cpu-baseline --no-roofline --no-extra > "$OUT/bench_tokenizer_bf16.json" 2> "$OUT/bench_tokenizer_bf16.err"
 echo "bench (tokenizer bf16, the round-4 recipe) rc=$?"; cut -c1-200 "$OUT/bench_tokenizer_bf16.json"
 cp -f "$GRAFT_REPO_ROOT/gpurun_out/pk_hazard.log" "$OUT/pk_hazard.log" 2>/dev/null  # written by tests/test_pk_hazard_gpu.py: copy to profiles/rNN_pk_hazard.log
+# the rocprofv3 kernel trace of the default bench step (pass A of tools/collect_profiles.sh): the per-kernel table profiles/rNN_summary.md is
+# built from (tools/summarize_profiles.py) -- in this call already, in case it is the only one the round gets
+( cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv \
+    -d "gpurun_out/profiles_raw/$TAG/bench" -o bench -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-extra \
+    > "$OUT/rocprof_bench.log" 2>&1 )
+echo "rocprofv3 bench rc=$?"; ls gpurun_out/profiles_raw/$TAG/bench 2>/dev/null | head -5
