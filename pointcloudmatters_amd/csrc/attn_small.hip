@@ -263,9 +263,9 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_small_bwd_kernel(AttnParams P,
                                                                 long dk_bs, long dk_ls, u16 *__restrict__ dv, long dv_bs, long dv_ls)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[BWD_LDS];
-    // every argument in registers at the entry: one batch of kernarg loads ("Kernel heads", pcm_common.hpp)
-    asm volatile("" ::"s"(P.q), "s"(P.k), "s"(P.v), "s"(P.q_bs), "s"(P.q_ls), "s"(P.k_bs), "s"(P.k_ls), "s"(P.v_bs), "s"(P.v_ls), "s"(P.kpm), "s"(P.B), "s"(P.H), "s"(P.L), "s"(P.S), "s"(P.scale), "s"(P.p_drop), "s"(P.seed), "s"(P.site), "s"(out), "s"(dout), "s"(lse), "s"(dq), "s"(dq_bs), "s"(dq_ls), "s"(dk), "s"(dk_bs), "s"(dk_ls), "s"(dv));
-    asm volatile("" ::"s"(dv_bs), "s"(dv_ls));
+    // the arguments the kernel's first loads need, in registers at the entry: one batch of kernarg loads ("Kernel heads", pcm_common.hpp;
+    // the output pointers and strides are left to the compiler: naming all 31 arguments made it spill 26 scalar registers to lanes)
+    asm volatile("" ::"s"(P.q), "s"(P.k), "s"(P.v), "s"(P.q_bs), "s"(P.q_ls), "s"(P.k_bs), "s"(P.k_ls), "s"(P.v_bs), "s"(P.v_ls), "s"(P.kpm), "s"(P.H), "s"(P.L), "s"(P.S), "s"(P.p_drop), "s"(P.seed), "s"(out), "s"(dout), "s"(lse));
     const int bh = blockIdx.x, b = bh / P.H, h = bh % P.H;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int E = P.H * HD;
