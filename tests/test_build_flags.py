@@ -107,3 +107,45 @@ def test_latency_bound_loops_keep_their_loads_in_flight(src, kernel, least, tmp_
     if src == "proj_ln.hip":
         sizes = [int(v) for v in re.findall(r"\.private_segment_fixed_size:\s*(\d+)", asm)]
         assert sizes and max(sizes) == 0, "scratch in csrc/proj_ln.hip: %s" % sizes
+
+
+def _scalar_waits_before_first_vector_load(asm, kernel_substr):
+    """For each kernel whose mangled name contains `kernel_substr`: how many times the head waits for outstanding scalar loads
+    (s_load ... s_waitcnt lgkmcnt(0)) before its first vector load is issued = dependent scalar round trips on the launch's critical path."""
+    lines = asm.splitlines()
+    starts = [i for i, l in enumerate(lines) if re.match(r"^_Z\w+:", l)]
+    out = {}
+    for k, i in enumerate(starts):
+        name = lines[i].split(":")[0]
+        if kernel_substr not in name:
+            continue
+        end = starts[k + 1] if k + 1 < len(starts) else len(lines)
+        waits, pending = 0, False
+        for l in lines[i:end]:
+            t = l.split(";")[0]
+            if "s_load_" in t:
+                pending = True
+            if re.search(r"s_waitcnt.*lgkmcnt\(0\)", t) and pending:
+                waits, pending = waits + 1, False
+            if re.search(r"global_load|buffer_load", t):
+                break
+        out[name] = waits
+    return out
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not installed")
+@pytest.mark.parametrize("src,kernel", [("drln.hip", "pcm_drln_fwd_kernelI14__hip_bfloat16Li2E"), ("drln.hip", "pcm_drln_bwd_kernelI14__hip_bfloat16Li2E"),
+                                        ("ffn.hip", "pcm_ffn_ln_fwd_kernelILi512ELi32E"), ("proj_ln.hip", "pcm_proj_drln_fwd_kernelILi512ELi1E")])
+def test_kernel_heads_load_their_arguments_in_one_batch(src, kernel, tmp_path):
+    """"Kernel heads" (csrc/pcm_common.hpp): the compiler sinks each kernel-argument load to its first use, which gave the row kernels a chain
+    of 4-5 dependent scalar round trips (p_drop -> seed pointer -> seed -> R -> the rest) before their first vector load; naming the arguments
+    in an empty asm at the entry makes it one batch.  At most ONE wait for scalar loads before the first vector load (the old code: 4-5)."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    out = tmp_path / (src + ".s")
+    r = subprocess.run([hipcc] + _flags() + ["--cuda-device-only", "-S", os.path.join(CSRC, src), "-o", str(out)], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    found = _scalar_waits_before_first_vector_load(out.read_text(), kernel)
+    assert found, "kernel %s not found in %s" % (kernel, src)
+    for name, waits in found.items():
+        assert waits <= 1, "%s: %d dependent scalar round trips before the first vector load" % (name, waits)
