@@ -6,7 +6,9 @@ The sources are compiled as they are, except for these mechanical rewrites of co
   1. `extern __shared__ <type> name[];`            -> `<type> *name = (<type> *)wavesim::dyn_smem();`   (dynamic LDS)
   2. fps.hip `fps_wave_max_fast`: the inline-assembly DPP ladder (6 x v_max_u32_dpp + readlane) -> `pcm_wave_max_u32`, the same
      wave maximum written with the DPP builtin in pcm_common.hpp (the model executes DPP controls, not assembly text)
-  3. `asm volatile("" ...)` scheduling fences (ffn.hip)  -> removed
+  3. `asm volatile("" ...)` statements -> removed: scheduling fences (ffn.hip) and the "Kernel heads" statements of pcm_common.hpp (empty asm
+     that names kernel arguments as register inputs, or makes the dropout seed / a mask byte opaque at its use): they emit no instruction and
+     change no value, only where the device compiler places loads and waits
   4. attn_small.hip: a wave that stores a tile to ITS OWN LDS region and reads it back relies on the hardware executing one wave's LDS
      operations in order (no barrier, by design).  The model runs lanes one after another, so the hand-off gets an explicit
      `__builtin_amdgcn_wave_barrier()` behind `tile_store(vr, Vs, lane);`
