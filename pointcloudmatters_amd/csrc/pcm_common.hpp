@@ -125,6 +125,24 @@ __device__ __forceinline__ int pcm_job_of(int blk, int n, F first)
     return cnt;
 }
 
+// The two offset tables of a batch of at most 64 clouds, one entry per LANE (two vector loads, in flight together), and the lookups the
+// index kernels need from them in registers: cloud of a query (= number of clouds whose last query index + 1 is <= q: the same answer as
+// pcm_cloud_of) by a ballot, table entries by v_readlane.  The kernels used to bisect `new_offset` with dependent scalar loads (2 x log2 b)
+// and then read four more entries one after another: ~12 scalar round trips in series before the first point was requested.
+struct PcmCloudTable {
+    int off, noff;  // offset[lane], new_offset[lane] (INT_MAX past b)
+    bool ok;        // b <= 64: the table is valid (otherwise the callers keep pcm_cloud_of and plain loads)
+    __device__ __forceinline__ PcmCloudTable(const int *__restrict__ offset, const int *__restrict__ new_offset, int b, int lane)
+    {
+        ok = b > 0 && b <= 64;
+        off = (ok && lane < b) ? offset[lane] : 0x7FFFFFFF;
+        noff = (ok && lane < b) ? new_offset[lane] : 0x7FFFFFFF;
+    }
+    __device__ __forceinline__ int cloud_of(int q) const { return __popcll(__ballot(noff <= q)); }
+    __device__ __forceinline__ int offset_at(int c) const { return __builtin_amdgcn_readlane(off, c); }
+    __device__ __forceinline__ int new_offset_at(int c) const { return __builtin_amdgcn_readlane(noff, c); }
+};
+
 // Closing reduction of partial rows: sum over slots s0, s0 + step, ... (< nslots) of partial[s * VH + e] in fp64, IN THAT ORDER, with
 // eight loads in flight.  The plain loop `acc += partial[s * VH + e]` compiles to load - s_waitcnt vmcnt(0) - add per slot: one exposed
 // L2 round trip per slot and wave (tools/isa_load_chains.py), 30-130 in series for the 256-1030 partial rows of an ACT step's reductions.
