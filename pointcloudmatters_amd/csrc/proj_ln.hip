@@ -252,30 +252,47 @@ __global__ __launch_bounds__(kThreadsP) void pcm_proj_drln_fwd_kernel(
             }
         rstds[j] = rsqrtf(wave_sum(sq) * (1.f / E) + eps);
     }
+    // the emitted operand's position rows: requested for a GROUP of the wave's rows before the group's first store (inside the per-row
+    // `if` each load was waited for on the spot: 2 x RPW round trips in series); groups of 4 rows for the 64-row tile (all 8 at once
+    // spilled); a row past R reads the position row of the tile's first row
+    constexpr int G = RPW < 4 ? RPW : 4;
 #pragma unroll
-    for (int j = 0; j < RPW; ++j) {
-        const int i = w + kWavesP * j;
-        const long r = r0 + i;
-        if (r < R) {  // wave-uniform
+    for (int g0 = 0; g0 < RPW; g0 += G) {
+        float ps[G][NCH][4];
+        if (sum16 != nullptr) {
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                const int col = c * 256 + lane * 4;
-                const long e0 = r * E + col;
-                float o[4];
+            for (int jj = 0; jj < G; ++jj) {
+                const int i = w + kWavesP * (g0 + jj);
+                const long prow = pos_row(pbase, r0 + i < R ? i : 0, pos_rows);
 #pragma unroll
-                for (int v = 0; v < 4; ++v) o[v] = (xs[j][c][v] - mus[j]) * rstds[j] * gs[c][v] + bs[c][v];
-                store4<float>(s_out + e0, xs[j][c]);
-                store4<float>(out + e0, o);
-                if (sum16 != nullptr) {
-                    float p[4], q[4];
-                    load4<float>(pos + pos_row(pbase, i, pos_rows) * E + col, p);
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) q[v] = o[v] + p[v];
-                    store4<__hip_bfloat16>(sum16 + e0, q);
-                }
-                if (x16 != nullptr) store4<__hip_bfloat16>(x16 + e0, o);
+                for (int c = 0; c < NCH; ++c) load4<float>(pos + prow * E + c * 256 + lane * 4, ps[jj][c]);
             }
-            if (lane == 0) mean_out[r] = mus[j], rstd_out[r] = rstds[j];
+        }
+#pragma unroll
+        for (int jj = 0; jj < G; ++jj) {
+            const int j = g0 + jj;
+            const int i = w + kWavesP * j;
+            const long r = r0 + i;
+            if (r < R) {  // wave-uniform
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const int col = c * 256 + lane * 4;
+                    const long e0 = r * E + col;
+                    float o[4];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) o[v] = (xs[j][c][v] - mus[j]) * rstds[j] * gs[c][v] + bs[c][v];
+                    store4<float>(s_out + e0, xs[j][c]);
+                    store4<float>(out + e0, o);
+                    if (sum16 != nullptr) {
+                        float q[4];
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) q[v] = o[v] + ps[jj][c][v];
+                        store4<__hip_bfloat16>(sum16 + e0, q);
+                    }
+                    if (x16 != nullptr) store4<__hip_bfloat16>(x16 + e0, o);
+                }
+                if (lane == 0) mean_out[r] = mus[j], rstd_out[r] = rstds[j];
+            }
         }
     }
 }
