@@ -2,7 +2,13 @@
 `s_waitcnt vmcnt(0)` -- each iteration is then an exposed L2 / HBM round trip (how round 5 found the A-panel loops of csrc/proj_ln.hip
 and the late position-row loads of csrc/drln.hip without a GPU).  Heuristic, for reading -- not a pass/fail gate.
 
-    python tools/isa_load_chains.py [file.hip ...]        (default: every kernel file of pointcloudmatters_amd/csrc)"""
+    python tools/isa_load_chains.py [--heads] [--sites] [file.hip ...]        (default: every kernel file of pointcloudmatters_amd/csrc)
+
+--heads: instead, per kernel, the number of times its head waits for outstanding SCALAR loads (s_load ... s_waitcnt lgkmcnt(0)) before the
+         first vector load is issued (>= 2 listed): dependent scalar round trips at the start of every launch -- kernel arguments the
+         compiler sank to their first use, a seed / an offset table read through a pointer, a job table searched by a scalar loop.
+--sites: instead, per kernel, the number of vector loads that are followed by a full `s_waitcnt vmcnt(0)` before the next load is issued
+         (>= 6 listed): load-and-wait inside per-element conditions (the attention kernels' `mask[key]`, FPS's per-point prologue)."""
 import os
 import re
 import subprocess
@@ -57,7 +63,54 @@ def audit(path):
     return rows
 
 
+def per_kernel(path, fn):
+    with tempfile.TemporaryDirectory() as td:
+        asm = os.path.join(td, "k.s")
+        subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + [path, "-o", asm], cwd=os.path.dirname(path), check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        lines = open(asm).read().splitlines()
+    starts = [i for i, l in enumerate(lines) if re.match(r"^_Z\w+:", l)]
+    for k, i in enumerate(starts):
+        end = starts[k + 1] if k + 1 < len(starts) else len(lines)
+        ins = [l.split(";")[0].strip() for l in lines[i:end] if l.startswith("\t") and not l.strip().startswith((".", ";"))]
+        name = subprocess.run(["c++filt", lines[i].split(":")[0]], capture_output=True, text=True).stdout.strip()
+        yield name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:80], fn(ins)
+
+
+def head_waits(ins):
+    waits, pending = 0, False
+    for t in ins:
+        if t.startswith("s_load_"):
+            pending = True
+        if re.match(r"s_waitcnt.*lgkmcnt\(0\)", t) and pending:
+            waits, pending = waits + 1, False
+        if t.startswith(("global_load", "buffer_load")):
+            break
+    return waits
+
+
+def wait_sites(ins):
+    n = 0
+    for k, t in enumerate(ins):
+        if t.startswith("global_load"):
+            for t2 in ins[k + 1:k + 6]:
+                if t2.startswith("global_load"):
+                    break
+                if re.match(r"s_waitcnt vmcnt\(0\)", t2):
+                    n += 1
+                    break
+    return n
+
+
+mode = "heads" if "--heads" in sys.argv else ("sites" if "--sites" in sys.argv else "loops")
+sys.argv = [a for a in sys.argv if a not in ("--heads", "--sites")]
 files = sys.argv[1:] or sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip") and f != "graph_fix.hip")
 for f in files:
+    if mode != "loops":
+        fn, least, what = (head_waits, 2, "scalar round trips before the first vector load") if mode == "heads" else (wait_sites, 6, "load-then-full-wait sites")
+        for name, v in per_kernel(os.path.abspath(f), fn):
+            if v >= least:
+                print("%-16s %3d %s   %s" % (os.path.basename(f), v, what, name))
+        continue
     for name, loads, n in audit(os.path.abspath(f)):
         print("%-16s %-72s loads in flight %d, loop body %d lines" % (os.path.basename(f), name, loads, n))
