@@ -149,3 +149,40 @@ def test_kernel_heads_load_their_arguments_in_one_batch(src, kernel, tmp_path):
     assert found, "kernel %s not found in %s" % (kernel, src)
     for name, waits in found.items():
         assert waits <= 1, "%s: %d dependent scalar round trips before the first vector load" % (name, waits)
+
+
+def _load_then_full_wait_sites(asm):
+    """Per kernel: vector loads followed by a full `s_waitcnt vmcnt(0)` before the next load is issued (load-and-wait in a per-element condition)."""
+    lines = asm.splitlines()
+    starts = [i for i, l in enumerate(lines) if re.match(r"^_Z\w+:", l)]
+    out = {}
+    for k, i in enumerate(starts):
+        end = starts[k + 1] if k + 1 < len(starts) else len(lines)
+        ins = [l.split(";")[0].strip() for l in lines[i:end] if l.startswith("\t") and not l.strip().startswith((".", ";"))]
+        n = 0
+        for j, t in enumerate(ins):
+            if t.startswith("global_load"):
+                for t2 in ins[j + 1:j + 6]:
+                    if t2.startswith("global_load"):
+                        break
+                    if re.match(r"s_waitcnt vmcnt\(0\)", t2):
+                        n += 1
+                        break
+        out[lines[i].split(":")[0]] = n
+    return out
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not installed")
+@pytest.mark.parametrize("src,allowed", [("attn_flash.hip", 5), ("fps.hip", 5)])
+def test_no_load_and_wait_per_element(src, allowed, tmp_path):
+    """The masked attention kernels read `mask[key]` inside the 32 short-circuit conditions of a tile (48 x global_load_ubyte + full wait in
+    the forward kernel), FPS loaded each of a thread's points with a full wait (8-32 per kernel): round 5 replaced both by one batch of
+    loads.  No kernel of these files may have more than a handful of load-then-full-wait sites again."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    out = tmp_path / (src + ".s")
+    r = subprocess.run([hipcc] + _flags() + ["--cuda-device-only", "-S", os.path.join(CSRC, src), "-o", str(out)], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    worst = _load_then_full_wait_sites(out.read_text())
+    bad = {k: v for k, v in worst.items() if v > allowed}
+    assert not bad, bad
