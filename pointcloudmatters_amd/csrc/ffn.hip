@@ -137,15 +137,25 @@ __global__ __launch_bounds__(kThreads) void pcm_ffn_ln_fwd_kernel(long R, const 
         }
         float part[F];
 #pragma unroll
-        for (int jj = 0; jj < F; ++jj) {
-            float acc = 0.f;
+        for (int j0 = 0; j0 < F; j0 += 8) {
+            float4 wq[8][PER / 4];
 #pragma unroll
-            for (int t = 0; t < PER; t += 4) {
-                const float4 w = *reinterpret_cast<const float4 *>(w1r + jj * E + col_of(lane, t));
-                acc += xv[t] * w.x + xv[t + 1] * w.y + xv[t + 2] * w.z + xv[t + 3] * w.w;
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int t = 0; t < PER; t += 4) wq[u][t / 4] = *reinterpret_cast<const float4 *>(w1r + (j0 + u) * E + col_of(lane, t));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                float acc = 0.f;
+#pragma unroll
+                for (int t = 0; t < PER; t += 4) {
+                    const float4 w = wq[u][t / 4];
+                    acc += xv[t] * w.x + xv[t + 1] * w.y + xv[t + 2] * w.z + xv[t + 3] * w.w;
+                }
+                part[j0 + u] = acc;
             }
-            part[jj] = acc;
-            if (jj % 8 == 7) asm volatile("" ::: "memory");  // at most 16 ds_read_b128 in flight: bounds live VGPRs
+            // schedule of this group: its 16 LDS reads first, then its 128 VALU operations
+            __builtin_amdgcn_sched_group_barrier(0x100, 8 * (PER / 4), 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 8 * 2 * PER, 0);
         }
         float h = butterfly32(part, lane) + bias1;
         h = h > 0.f ? h : 0.f;
@@ -155,14 +165,23 @@ __global__ __launch_bounds__(kThreads) void pcm_ffn_ln_fwd_kernel(long R, const 
 #pragma unroll
         for (int t = 0; t < PER; ++t) s[t] = bias2[t];
 #pragma unroll
-        for (int jj = 0; jj < F; ++jj) {
-            const float hj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hd), 2 * jj));
+        for (int j0 = 0; j0 < F; j0 += 8) {
+            float4 wq[8][PER / 4];
 #pragma unroll
-            for (int t = 0; t < PER; t += 4) {
-                const float4 w = *reinterpret_cast<const float4 *>(w2r + jj * (E + kPad) + col_of(lane, t));
-                s[t] += hj * w.x, s[t + 1] += hj * w.y, s[t + 2] += hj * w.z, s[t + 3] += hj * w.w;
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int t = 0; t < PER; t += 4) wq[u][t / 4] = *reinterpret_cast<const float4 *>(w2r + (j0 + u) * (E + kPad) + col_of(lane, t));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float hj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hd), 2 * (j0 + u)));
+#pragma unroll
+                for (int t = 0; t < PER; t += 4) {
+                    const float4 w = wq[u][t / 4];
+                    s[t] += hj * w.x, s[t + 1] += hj * w.y, s[t + 2] += hj * w.z, s[t + 3] += hj * w.w;
+                }
             }
-            if (jj % 8 == 7) asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_group_barrier(0x100, 8 * (PER / 4), 0);  // this group's 16 LDS reads first ...
+            __builtin_amdgcn_sched_group_barrier(0x002, 8 * (2 * PER + 1), 0);  // ... then its arithmetic
         }
         float sum = 0.f;
 #pragma unroll
@@ -269,15 +288,24 @@ __global__ __launch_bounds__(kThreads) void pcm_ffn_ln_bwd_kernel(long R, const 
         }
         float part[F];
 #pragma unroll
-        for (int jj = 0; jj < F; ++jj) {
-            float acc = 0.f;
+        for (int j0 = 0; j0 < F; j0 += 8) {  // 16 LDS reads requested together, then consumed (see the forward kernel)
+            float4 wq[8][PER / 4];
 #pragma unroll
-            for (int t = 0; t < PER; t += 4) {
-                const float4 w = *reinterpret_cast<const float4 *>(w2r + jj * (E + kPad) + col_of(lane, t));
-                acc += dyv[t] * w.x + dyv[t + 1] * w.y + dyv[t + 2] * w.z + dyv[t + 3] * w.w;
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int t = 0; t < PER; t += 4) wq[u][t / 4] = *reinterpret_cast<const float4 *>(w2r + (j0 + u) * (E + kPad) + col_of(lane, t));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                float acc = 0.f;
+#pragma unroll
+                for (int t = 0; t < PER; t += 4) {
+                    const float4 w = wq[u][t / 4];
+                    acc += dyv[t] * w.x + dyv[t + 1] * w.y + dyv[t + 2] * w.z + dyv[t + 3] * w.w;
+                }
+                part[j0 + u] = acc;
             }
-            part[jj] = acc;
-            if (jj % 8 == 7) asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_group_barrier(0x100, 8 * (PER / 4), 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 8 * 2 * PER, 0);
         }
         const float dhd = butterfly32(part, lane);
         const float hdv = hd[r * F + j];
@@ -287,14 +315,23 @@ __global__ __launch_bounds__(kThreads) void pcm_ffn_ln_bwd_kernel(long R, const 
             db1 += dh;
         }
 #pragma unroll
-        for (int jj = 0; jj < F; ++jj) {
-            const float dj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dh), 2 * jj));
+        for (int j0 = 0; j0 < F; j0 += 8) {
+            float4 wq[8][PER / 4];
 #pragma unroll
-            for (int t = 0; t < PER; t += 4) {
-                const float4 w = *reinterpret_cast<const float4 *>(w1r + jj * E + col_of(lane, t));
-                ds[t] += dj * w.x, ds[t + 1] += dj * w.y, ds[t + 2] += dj * w.z, ds[t + 3] += dj * w.w;
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int t = 0; t < PER; t += 4) wq[u][t / 4] = *reinterpret_cast<const float4 *>(w1r + (j0 + u) * E + col_of(lane, t));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float dj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dh), 2 * (j0 + u)));
+#pragma unroll
+                for (int t = 0; t < PER; t += 4) {
+                    const float4 w = wq[u][t / 4];
+                    ds[t] += dj * w.x, ds[t + 1] += dj * w.y, ds[t + 2] += dj * w.z, ds[t + 3] += dj * w.w;
+                }
             }
-            if (jj % 8 == 7) asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_group_barrier(0x100, 8 * (PER / 4), 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 8 * (2 * PER + 1), 0);
         }
 #pragma unroll
         for (int t = 0; t < PER; t += 4) {

@@ -86,6 +86,7 @@ inline void __threadfence_block() {}
 #define __builtin_amdgcn_s_barrier() wavesim::syncthreads()
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(mask, size, sync) ((void)0)  /* scheduling directive: no instruction, no value */
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_wave_barrier() ((void)wavesim::cross(wavesim::OP_WAVE_BARRIER, WS_SITE, 0, 0))
 
