@@ -64,11 +64,7 @@ def parse():
     ap.add_argument("--no-prefetch", action="store_true", help="do not hand the next batch to the trainer early (hybrid / flat / eager modes)")
     ap.add_argument("--tokenizer-bf16", action="store_true",
                     help="run the tokenizer (PointNet + SA layer + projector) under bf16 autocast as well; default: fp32 (policy/precision.py)")
-    ap.add_argument("--emit-warmup-losses", action="store_true", help=argparse.SUPPRESS)  # a selection trial: add the warm-up losses to the line
-    ap.add_argument("--chain-trial-timeout", type=float, default=240.0, help=argparse.SUPPRESS)  # seconds per selection trial (child process)
-    ap.add_argument("--chain-trial", default="12,6", help=argparse.SUPPRESS)  # steps,warm-up of each selection trial (tools/dbg/bench_on_model.py shortens them)
-    ap.add_argument("--no-chain-selection", action="store_true",
-                    help="skip the untimed A/B of csrc/proj_ln.hip's projection chain against the library products (then: library products)")
+    ap.add_argument("--emit-warmup-losses", action="store_true", help=argparse.SUPPRESS)  # A/B aid: add the warm-up losses to the line
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel legs (kernels, kernels_hbm, step_trace, roofline)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra lines (fp32 GPU run, REF shape)")
@@ -904,79 +900,17 @@ def emit(out, tables, tables_path):
     print(compact_line(out), flush=True)
 
 
-def choose_projection_chain(args, device, world, rank):
+def projection_chain_setting():
     """csrc/proj_ln.hip (round 5) offers the ~800-row attention projections of the ACT step as one matrix-core launch each instead of a
-    library product + a small kernel.  It was written while no GPU was available to the build: verified on a host model, never timed.
-    So the choice is made HERE, before the timed region, the way a GEMM autotuner makes it: a few untimed steps of the SAME workload
-    with the chain off and on (same seeds, same batches, same dropout counters); the chain is kept only if (a) its losses follow the
-    library path's to 1 % at every step -- both paths compute the same function, one bf16 rounding apart -- and (b) it is at least 1 %
-    faster.  PCM_PROJ_MFMA / PCM_LINEAR_MFMA in the environment (either value) switch the selection off and are obeyed as given.
-    Each candidate is measured in a child process of its own, so that a fault in a kernel that has never met the hardware cannot take
-    the headline run with it."""
-    from pointcloudmatters_amd.bc import WORKLOADS
+    library product + a small kernel.  It has never run on hardware (the GPU pool was closed to the build in rounds 4 - 6), so the headline
+    stays on the library products: no run-time selection (round 5 had an untimed A/B in child processes here; removed -- the kernel set
+    of the timed line must not be decided at run time, round-5 VERDICT weak 3 / ADVICE).  The chain is opt-in through the environment
+    (PCM_PROJ_MFMA / PCM_LINEAR_MFMA / PCM_PROJ_MFMA_LONG, obeyed as given by policy/fused_ops.py); the line records what ran."""
     from pointcloudmatters_amd.policy import fused_ops
 
-    info = {"selected": "library products (default)", "reason": "not applicable to this workload"}
-    wl = WORKLOADS[args.workload]
-    if "PCM_PROJ_MFMA" in os.environ or "PCM_LINEAR_MFMA" in os.environ:
-        info.update(selected="mfma (as set)" if (fused_ops.PROJ_MFMA or fused_ops.LINEAR_MFMA) else "library products", reason="set by the environment")
-        return info
-    if wl["policy"] not in ("act", "act_rlbench") or wl["dtype"] != "bf16" or args.mode == "eager" or args.no_chain_selection:
-        return info
-    # candidates: the library products; the chain at the short sites (<= 1024 rows: decoder, CVAE encoder); the chain at the long sites too
-    # (the encoder's rows, 64-row tiles) -- short and long sites can win or lose independently
-    cands = (("library products", False, False, False), ("mfma at the short sites (csrc/proj_ln.hip)", True, True, False),
-             ("mfma at the short and the long sites (csrc/proj_ln.hip)", True, True, True))
-
-    def set_flags(proj, lin, long_):
-        fused_ops.PROJ_MFMA, fused_ops.LINEAR_MFMA, fused_ops.PROJ_MFMA_LONG = proj, lin, long_
-
-    # Each candidate runs in its OWN PROCESS (one rank; N > 1 keeps the library products unless the environment says otherwise): the new
-    # kernels have never run on hardware, and a device fault or a hang in one of them must cost that candidate, not the headline run.
-    # The child is this same file with the switches in its environment (obeyed as given, see above) and prints its warm-up losses.
-    if world > 1:
-        info.update(selected="library products", reason="N > 1: no selection (set PCM_PROJ_MFMA / PCM_LINEAR_MFMA / PCM_PROJ_MFMA_LONG to choose)")
-        return info
-    import subprocess
-
-    n_steps, n_warm = (int(v) for v in args.chain_trial.split(","))
-    trial = []
-    for name, proj, lin, long_ in cands:
-        env = dict(os.environ, PCM_PROJ_MFMA="1" if proj else "0", PCM_LINEAR_MFMA="1" if lin else "0", PCM_PROJ_MFMA_LONG="1" if long_ else "0")
-        cmd = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--mode", args.mode, "--sa-impl", args.sa_impl,
-               "--dead-decoder-layers", args.dead_decoder_layers, "--steps", str(n_steps), "--warmup", str(n_warm), "--no-cpu-baseline",
-               "--no-roofline", "--no-extra", "--emit-warmup-losses"]
-        cmd += ["--tokenizer-bf16"] if args.tokenizer_bf16 else []
-        cmd += ["--no-prefetch"] if args.no_prefetch else []
-        cmd += ["--sampling-in-graph"] if getattr(args, "sampling_in_graph", False) else []
-        try:
-            res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=args.chain_trial_timeout)
-            line = [ln for ln in res.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
-            if res.returncode != 0 or not line:
-                raise RuntimeError("exit code %s: %s" % (res.returncode, (res.stderr or res.stdout)[-200:].replace("\n", " ")))
-            out = json.loads(line[-1])
-            trial.append((float(out["ms_per_step"]), [float(v) for v in out.get("warmup_losses", [])]))
-        except Exception as e:  # a candidate that crashes, hangs or prints nothing loses
-            trial.append((float("inf"), ["%s: %s" % (type(e).__name__, e)]))
-    set_flags(False, False, False)
-    t_lib, l_lib = trial[0]
-
-    def same(losses):
-        return (len(l_lib) == len(losses) and len(l_lib) > 0 and all(isinstance(b, float) for b in losses)
-                and all(abs(a - b) <= 1e-2 * abs(a) + 1e-6 for a, b in zip(l_lib, losses)))
-
-    best = 0
-    for i in (1, 2):
-        if trial[i][0] != float("inf") and same(trial[i][1]) and trial[i][0] < 0.99 * trial[best][0]:
-            best = i
-    set_flags(*cands[best][1:])
-    ms = [None if t == float("inf") else round(t, 3) for t, _ in trial]
-    info.update(selected=cands[best][0],
-                reason="measured before the timed region, ms/step: library %s, short sites %s (losses %s), short + long sites %s (losses %s)" % (
-                    ms[0], ms[1], "agree to 1 %" if same(trial[1][1]) else "DISAGREE / failed: " + str(trial[1][1][:1])[:80],
-                    ms[2], "agree to 1 %" if same(trial[2][1]) else "DISAGREE / failed: " + str(trial[2][1][:1])[:80]),
-                ms_library=ms[0], ms_mfma_short=ms[1], ms_mfma_short_long=ms[2])
-    return info
+    on = bool(fused_ops.PROJ_MFMA or fused_ops.LINEAR_MFMA)
+    return {"selected": ("mfma (csrc/proj_ln.hip)%s" % (", long sites too" if fused_ops.PROJ_MFMA_LONG else "")) if on else "library products",
+            "reason": "set by the environment" if on else "default: csrc/proj_ln.hip is opt-in until it has a hardware run"}
 
 
 def main():
@@ -1011,7 +945,7 @@ def main():
             print(json.dumps({"kernels": kernel_rooflines(WORKLOADS[args.workload], device)}), flush=True)
         return
 
-    chain = choose_projection_chain(args, device, world, rank)
+    chain = projection_chain_setting()
     warm_losses = [] if args.emit_warmup_losses else None
     dt, trainer, step, wl, sa_impl = run_workload(args.workload, args, device, world, rank, args.steps, args.warmup, mode=args.mode,
                                                   trace_steps=8, losses=warm_losses)

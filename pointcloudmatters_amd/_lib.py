@@ -157,10 +157,11 @@ class PointopsLibraryError(RuntimeError):
 
 
 def build(verbose=False):
-    """Compile the HIP sources for gfx950 with hipcc (csrc/Makefile).  Cross-compiles without a GPU."""
+    """Compile the HIP sources for gfx950 with hipcc (csrc/Makefile).  Cross-compiles without a GPU.  Two targets: the shipped library
+    (lib/) and `next` (lib_next/: round 5's untimed rewrites of ten files, selected only by PCM_POINTOPS_LIB for the A/B on hardware)."""
     import sys
 
-    r = subprocess.run(["make", "-C", CSRC_DIR, "-j8"], stdout=None if verbose else subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+    r = subprocess.run(["make", "-C", CSRC_DIR, "-j8", "all", "next"], stdout=None if verbose else subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
     # the device-only subtarget feature of csrc/Makefile (NO_PK) makes the HOST half of every hipcc call print
     # "'-packed-fp32-ops' is not a recognized feature for this target (ignoring feature)": expected, dropped here
     noise = "is not a recognized feature for this target"

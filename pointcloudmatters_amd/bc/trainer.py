@@ -269,6 +269,11 @@ class BCTrainer:
             self._shadow_names = None
             if precision == "bf16" and hasattr(self.optimizer, "enable_bf16_mirror"):
                 self.optimizer.enable_bf16_mirror(bf16_consumed_parameters(self.policy, fused_ffn=self._fused_ctx is not None))
+                # the mirror set depends on `tokenizer_fp32` (policy/precision.py) AS IT IS NOW: the flag must be set before the trainer
+                # is built; training_step checks that it has not been flipped since (round-5 ADVICE)
+                from ..policy.precision import tokenizer_owners
+
+                self._tokenizer_flags = [(m, bool(getattr(m, "tokenizer_fp32", True))) for m in tokenizer_owners(self.policy)]
                 index = {id(p): k for k, p in enumerate(self.optimizer.params)}
                 self._shadow_names = [(n, p, index[id(p)]) for n, p in self.policy.named_parameters()
                                       if id(p) in index and self.optimizer.shadow[index[id(p)]] is not None]
@@ -777,6 +782,12 @@ class BCTrainer:
         # True) skips the check).  Captured graphs bake the mode in at capture time either way.
         if not self.module.training:
             self.module.train()
+        if self.micro % 64 == 0:
+            for m, flag in self.__dict__.get("_tokenizer_flags", ()):
+                if bool(getattr(m, "tokenizer_fp32", True)) != flag:
+                    raise RuntimeError("tokenizer_fp32 of %s changed after the trainer was built: the optimizer's bf16 mirrors were derived "
+                                       "from the old value -- set the flag (policy/precision.set_tokenizer_fp32) BEFORE constructing "
+                                       "BCTrainer" % type(m).__name__)
         if self.micro % 64 == 0 and not self.allow_eval_submodules and not self.__dict__.get("_warned_eval"):
             stale = [n for n, m in self.module.named_modules() if not m.training]
             if stale:

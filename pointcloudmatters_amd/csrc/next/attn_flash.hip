@@ -173,6 +173,7 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_flash_fwd_kernel(AttnParams P,
         // waves 0 / 1: keys 0..31 / 32..63 of every tile against the same (remainder) queries
         for (int kt = 0; kt < ntiles; ++kt) {
             const u16 *Kt = smem + (kt & 1) * TILE, *Vt = smem + (2 + (kt & 1)) * TILE;
+            const unsigned mbyte = tile_mask_byte(mask, kt * TR, P.S, lane);  // before the prefetch: see tile_visible
             if (kt + 1 < ntiles) {
                 stage_fetch(kr, kb, P.k_ls, (kt + 1) * TR, P.S, tid);
                 stage_fetch(vr, vb, P.v_ls, (kt + 1) * TR, P.S, tid);
@@ -192,11 +193,9 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_flash_fwd_kernel(AttnParams P,
                     va1[jj] = cat8(lds_tr(vs + lo.tr[0][1]), lds_tr(vs + lo.tr[1][1]));
                 }
                 if (key0 + 32 > P.S || mask != nullptr) {
+                    const lanemask vb = tile_visible(mbyte, kt * TR, P.S, lane) >> (32 * w + 4 * hl);  // bit crow(r, 0) <-> this lane's row r
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int key = key0 + crow(r, lane);
-                        s[r] = (key < P.S && !(mask != nullptr && mask[key] != 0)) ? s[r] : -INFINITY;
-                    }
+                    for (int r = 0; r < 16; ++r) s[r] = ((vb >> ((r & 3) + 8 * (r >> 2))) & 1ull) ? s[r] : -INFINITY;
                 }
                 float tmax = -INFINITY;
 #pragma unroll
@@ -265,6 +264,7 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_flash_fwd_kernel(AttnParams P,
     } else
     for (int kt = 0; kt < ntiles; ++kt) {
         const u16 *Kt = smem + (kt & 1) * TILE, *Vt = smem + (2 + (kt & 1)) * TILE;
+        const unsigned mbyte = tile_mask_byte(mask, kt * TR, P.S, lane);  // before the prefetch: see tile_visible
         if (kt + 1 < ntiles) {
             stage_fetch(kr, kb, P.k_ls, (kt + 1) * TR, P.S, tid);
             stage_fetch(vr, vb, P.v_ls, (kt + 1) * TR, P.S, tid);
@@ -290,13 +290,12 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_flash_fwd_kernel(AttnParams P,
         // the running maximum is kept on the RAW scores (scale > 0 commutes with max): the scale is folded into the
         // exponent's FMA, exp2(s * scale2 - m * scale2), instead of costing one multiply per score
         if (edge) {
+            const lanemask vis = tile_visible(mbyte, kt * TR, P.S, lane) >> (4 * hl);  // bit crow(r, 0) (+ 32) <-> this lane's row r
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int key = kt * TR + crow(r, lane);
-                const bool v0 = key < P.S && !(mask != nullptr && mask[key] != 0);
-                const bool v1 = key + 32 < P.S && !(mask != nullptr && mask[key + 32] != 0);
-                s0[r] = v0 ? s0[r] : -INFINITY;
-                s1[r] = v1 ? s1[r] : -INFINITY;
+                const int sh = (r & 3) + 8 * (r >> 2);
+                s0[r] = ((vis >> sh) & 1ull) ? s0[r] : -INFINITY;
+                s1[r] = ((vis >> (sh + 32)) & 1ull) ? s1[r] : -INFINITY;
             }
         }
         float tmax = -INFINITY;
@@ -425,11 +424,13 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_flash_bwd_dq_kernel(AttnParams
     __syncthreads();
     for (int kt = 0; kt < ntiles; ++kt) {
         const u16 *Kt = smem + (kt & 1) * TILE, *Vt = smem + (2 + (kt & 1)) * TILE;
+        const unsigned mbyte = tile_mask_byte(mask, kt * TR, P.S, lane);  // before the prefetch: see tile_visible (pcm_attn.hpp)
         if (kt + 1 < ntiles) {
             stage_fetch(kr, kb, P.k_ls, (kt + 1) * TR, P.S, tid);
             stage_fetch(vr, vb, P.v_ls, (kt + 1) * TR, P.S, tid);
         }
         const bool edge = (kt + 1) * TR > P.S || mask != nullptr;
+        const lanemask vis = edge ? tile_visible(mbyte, kt * TR, P.S, lane) >> (4 * hl) : ~0ull;  // bit crow(r, 0) + 32 kh <-> row r of half kh
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {  // 32 keys at a time
             if (rem && kh != w) continue;  // rem mode: wave 0 / 1 owns key half 0 / 1, waves 2 and 3 only stage
@@ -462,11 +463,7 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_flash_bwd_dq_kernel(AttnParams
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], scale2, -lq2));
-                if (edge) {
-                    const int key = kt * TR + 32 * kh + crow(r, lane);
-                    const bool vis = key < P.S && !(mask != nullptr && mask[key] != 0);
-                    pr = vis ? pr : 0.f;
-                }
+                if (edge) pr = ((vis >> ((r & 3) + 8 * (r >> 2) + 32 * kh)) & 1ull) ? pr : 0.f;
                 ds[r] = pr * (dp[r] - Dq);  // the constant factor scale / (1 - p_drop) is applied once, to the finished dQ
             }
             // dQ^T += K^T dS^T: slab jj = keys 16 jj .. of this 32-key half

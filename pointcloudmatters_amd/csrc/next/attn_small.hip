@@ -86,6 +86,9 @@ __device__ __forceinline__ void fwd_tile(const u16 *Ks, const u16 *Vs, const bf8
                                          int kt, int lane, const AttnParams &P, const unsigned char *mask, const DropCfg &dc, uint32_t rb)
 {
     const int h8 = 8 * (lane >> 5), h4 = 4 * (lane >> 5);
+    // the tile's 32 mask bytes: ONE load (lane t and t + 32 read key t), turned into a wave mask behind the matrix instructions below; the
+    // 16 short-circuit conditions used to load `mask[key]` one by one, each with a full wait (tile_visible, pcm_attn.hpp)
+    const unsigned mbyte = tile_mask_byte(mask, kt * KT - (lane & 32), P.S, lane);
     // every LDS operand of this tile is requested up front: the reads drain while the matrix cores and the softmax run
     bf8 ka[4], va0[2], va1[2];
 #pragma unroll
@@ -104,14 +107,11 @@ __device__ __forceinline__ void fwd_tile(const u16 *Ks, const u16 *Vs, const bf8
     const bool edge = (kt + 1) * KT > P.S || mask != nullptr;
     const float scale2 = P.scale * 1.44269504088896f;  // scores in the log2 domain: the exponentials are bare v_exp_f32
     float tmax = -INFINITY;
+    const lanemask visb = edge ? tile_visible(mbyte, kt * KT - (lane & 32), P.S, lane) >> h4 : ~0ull;  // bit crow(r, 0) <-> this lane's row r
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         s[r] *= scale2;
-        if (edge) {
-            const int key = kt * KT + crow(r, lane);
-            const bool vis = key < P.S && !(mask != nullptr && mask[key] != 0);
-            s[r] = vis ? s[r] : -INFINITY;
-        }
+        if (edge) s[r] = ((visb >> ((r & 3) + 8 * (r >> 2))) & 1ull) ? s[r] : -INFINITY;
         tmax = fmaxf(tmax, s[r]);
     }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
@@ -158,6 +158,7 @@ __global__ __launch_bounds__(WG) void pcm_attn_small_fwd_kernel(AttnParams P, u1
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[NW * 2 * TILE_U16 * 2 > NW * (64 * 32 + 64) * 4 ? NW * 2 * TILE_U16 * 2
                                                                                                          : NW * (64 * 32 + 64) * 4];
+    asm volatile("" ::"s"(P.q), "s"(P.k), "s"(P.v), "s"(P.q_bs), "s"(P.q_ls), "s"(P.k_bs), "s"(P.k_ls), "s"(P.v_bs), "s"(P.v_ls), "s"(P.kpm), "s"(P.B), "s"(P.H), "s"(P.L), "s"(P.S), "s"(P.scale), "s"(P.p_drop), "s"(P.seed), "s"(P.site), "s"(out), "s"(lse));  // "Kernel heads", pcm_common.hpp
     const int bh = blockIdx.x, b = bh / P.H, h = bh % P.H;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     u16 *Ks = reinterpret_cast<u16 *>(smem) + w * 2 * TILE_U16, *Vs = Ks + TILE_U16;
@@ -263,6 +264,9 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_small_bwd_kernel(AttnParams P,
                                                                 long dk_bs, long dk_ls, u16 *__restrict__ dv, long dv_bs, long dv_ls)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[BWD_LDS];
+    // the arguments the kernel's first loads need, in registers at the entry: one batch of kernarg loads ("Kernel heads", pcm_common.hpp;
+    // the output pointers and strides are left to the compiler: naming all 31 arguments made it spill 26 scalar registers to lanes)
+    asm volatile("" ::"s"(P.q), "s"(P.k), "s"(P.v), "s"(P.q_bs), "s"(P.q_ls), "s"(P.k_bs), "s"(P.k_ls), "s"(P.v_bs), "s"(P.v_ls), "s"(P.kpm), "s"(P.H), "s"(P.L), "s"(P.S), "s"(P.p_drop), "s"(P.seed), "s"(out), "s"(dout), "s"(lse));
     const int bh = blockIdx.x, b = bh / P.H, h = bh % P.H;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int E = P.H * HD;
@@ -326,6 +330,7 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_small_bwd_kernel(AttnParams P,
             tile_store(kr, Ks, lane);
             tile_store(vr, Vs, lane);
             __builtin_amdgcn_wave_barrier();  // the wave reads this tile back below: one wave's LDS operations execute in order on the hardware; the statement keeps the compiler (and the host model, tests/wavesim) to it -- emits no instruction
+            const unsigned mbyte = tile_mask_byte(mask, kt * KT - (lane & 32), P.S, lane);  // one load per tile, before the prefetch (tile_visible, pcm_attn.hpp)
             if (kt + NW < nkt) {
                 tile_fetch(kr, kb, P.k_ls, (kt + NW) * KT, P.S, lane);
                 tile_fetch(vr, vb, P.v_ls, (kt + NW) * KT, P.S, lane);
@@ -340,6 +345,7 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_small_bwd_kernel(AttnParams P,
                 dp = PCM_MFMA(lds_s4(Vs + off), gf[sl], dp);
             }
             const bool edge = (kt + 1) * KT > P.S || mask != nullptr;
+            const lanemask visb = edge ? tile_visible(mbyte, kt * KT - (lane & 32), P.S, lane) >> (4 * (lane >> 5)) : ~0ull;
             float ds[16];
             if (DROP) {
 #pragma unroll
@@ -353,11 +359,7 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_small_bwd_kernel(AttnParams P,
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float pr = __builtin_amdgcn_exp2f(s[r] * scale2 - lq2);
-                if (edge) {
-                    const int key = kt * KT + crow(r, lane);
-                    const bool vis = key < P.S && !(mask != nullptr && mask[key] != 0);
-                    pr = vis ? pr : 0.f;
-                }
+                if (edge) pr = ((visb >> ((r & 3) + 8 * (r >> 2))) & 1ull) ? pr : 0.f;
                 ds[r] = pr * (dp[r] - Dq) * P.scale;
             }
 #pragma unroll

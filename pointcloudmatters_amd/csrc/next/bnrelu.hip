@@ -37,13 +37,14 @@ struct RowMap {
     }
 };
 
-// MODE 0: (y, y^2)        MODE 1: (g, g*xhat)
+// MODE 0: (y, y^2)        MODE 1: (g, g*xhat), g = dz behind the ReLU gate        MODE 2: the same without a gate (BatchNorm alone)
 template <typename T, int MODE>
 __global__ __launch_bounds__(kBlock) void pcm_bn_colsum_kernel(long n, int C, int chunkW, long rows_per_slot,
                                                                const T *__restrict__ y, const T *__restrict__ dz,
                                                                const float *__restrict__ stat, float *__restrict__ partial)
 {
     __shared__ float lds[8 * kBlock];
+    asm volatile("" ::"s"(n), "s"(C), "s"(chunkW), "s"(rows_per_slot), "s"(y), "s"(dz), "s"(stat), "s"(partial));  // "Kernel heads", pcm_common.hpp
     const RowMap mp(chunkW);
     const int c0 = blockIdx.y * chunkW + mp.col4 * 4;
     const bool act = mp.active && c0 < C;
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(kBlock) void pcm_bn_colsum_kernel(long n, int C, in
     float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
     if (act) {
         float mean[4], invstd[4], a[4], b[4];
-        if (MODE == 1) {
+        if (MODE != 0) {
             load4<float>(stat + c0, mean);
             load4<float>(stat + C + c0, invstd);
             load4<float>(stat + 2 * C + c0, a);
@@ -60,26 +61,44 @@ __global__ __launch_bounds__(kBlock) void pcm_bn_colsum_kernel(long n, int C, in
         }
         float sh[4] = {0.f, 0.f, 0.f, 0.f};
         if (MODE == 0) load4<T>(y + c0, sh);  // shift by row 0: sum (y - sh), sum (y - sh)^2 do not cancel when |mean| >> std
-        for (long r = r_begin + mp.rsub; r < r_end; r += mp.rpp) {
-            float v[4];
-            load4<T>(y + r * C + c0, v);
+        auto accumulate = [&](const float(&v)[4], const float(&d)[4]) {
             if (MODE == 0) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const float d = v[u] - sh[u];
-                    s0[u] += d;
-                    s1[u] += d * d;
+                    const float dd = v[u] - sh[u];
+                    s0[u] += dd;
+                    s1[u] += dd * dd;
                 }
             } else {
-                float d[4];
-                load4<T>(dz + r * C + c0, d);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const float g = (a[u] * v[u] + b[u] > 0.f) ? d[u] : 0.f;
+                    float g;
+                    if constexpr (MODE == 2) g = d[u];
+                    else g = (a[u] * v[u] + b[u] > 0.f) ? d[u] : 0.f;
                     s0[u] += g;
                     s1[u] += g * ((v[u] - mean[u]) * invstd[u]);
                 }
             }
+        };
+        // four rows in flight, accumulated in row order: same sums as the one-row loop, which waited for every row's loads in turn
+        // (tools/isa_load_chains.py: >= 8 exposed round trips in series per thread)
+        long r = r_begin + mp.rsub;
+        for (; r + 3 * mp.rpp < r_end; r += 4 * (long)mp.rpp) {
+            float v[4][4], d[4][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                load4<T>(y + (r + q * (long)mp.rpp) * C + c0, v[q]);
+                if (MODE != 0) load4<T>(dz + (r + q * (long)mp.rpp) * C + c0, d[q]);
+                else d[q][0] = d[q][1] = d[q][2] = d[q][3] = 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) accumulate(v[q], d[q]);
+        }
+        for (; r < r_end; r += mp.rpp) {
+            float v[4], d[4] = {0.f, 0.f, 0.f, 0.f};
+            load4<T>(y + r * C + c0, v);
+            if (MODE != 0) load4<T>(dz + r * C + c0, d);
+            accumulate(v, d);
         }
     }
 #pragma unroll
@@ -106,6 +125,7 @@ __global__ __launch_bounds__(64 * kRedWaves) void pcm_bn_reduce_kernel(int nslot
                                                                          float *__restrict__ out)
 {
     __shared__ double red[kRedWaves][64];
+    asm volatile("" ::"s"(nslots), "s"(VH), "s"(partial), "s"(out));  // "Kernel heads", pcm_common.hpp
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + lane;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;  // four independent chains: four loads in flight per lane
@@ -169,6 +189,7 @@ __global__ __launch_bounds__(64 * kRedWaves) void pcm_bn_reduce_stats_kernel(int
                                                                                float *__restrict__ running_var)
 {
     __shared__ double red[2][kRedWaves][64];
+    asm volatile("" ::"s"(nslots), "s"(C), "s"(partial), "s"(sums), "s"(count), "s"(eps), "s"(momentum), "s"(y), "s"(gamma), "s"(beta), "s"(stat), "s"(running_mean), "s"(running_var));  // "Kernel heads", pcm_common.hpp
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     const int VH = 2 * C;
@@ -210,13 +231,16 @@ __global__ __launch_bounds__(kBlock) void pcm_bn_stats_kernel(int C, double coun
     bn_stats_of<T>(c, C, count, eps, momentum, y, sums[c], sums[C + c], gamma, beta, stat, running_mean, running_var);
 }
 
-template <typename T>
+template <typename T, bool RELU = true>
 __global__ __launch_bounds__(kBlock) void pcm_bn_relu_apply_kernel(long total4, int C, const T *__restrict__ y,
                                                                    const float *__restrict__ stat, T *__restrict__ z)
 {
+    asm volatile("" ::"s"(gridDim.x), "s"(total4), "s"(C), "s"(y), "s"(stat), "s"(z));  // "Kernel heads", pcm_common.hpp
+    const unsigned c4n = (unsigned)C / 4u;
     for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < total4; i += (long)gridDim.x * kBlock) {
         const long e = i * 4;
-        const int c = (int)(e % C);
+        // channel of element e = 4 i: a 32-bit remainder whenever the tensor has fewer than 2^32 four-element pieces (always, here)
+        const int c = total4 <= 0xFFFFFFFFl ? (int)(((unsigned)i % c4n) * 4u) : (int)(e % C);
         float v[4], a[4], b[4], o[4];
         load4<T>(y + e, v);
         load4<float>(stat + 2 * C + c, a);
@@ -224,20 +248,23 @@ __global__ __launch_bounds__(kBlock) void pcm_bn_relu_apply_kernel(long total4, 
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const float t = a[u] * v[u] + b[u];
-            o[u] = t > 0.f ? t : 0.f;
+            if constexpr (RELU) o[u] = t > 0.f ? t : 0.f;
+            else o[u] = t;
         }
         store4<T>(z + e, o);
     }
 }
 
-template <typename T>
+template <typename T, bool RELU = true>
 __global__ __launch_bounds__(kBlock) void pcm_bn_relu_bwd_apply_kernel(long total4, int C, float inv_n, const T *__restrict__ y,
                                                                        const T *__restrict__ dz, const float *__restrict__ stat,
                                                                        const float *__restrict__ sums, T *__restrict__ dy)
 {
+    asm volatile("" ::"s"(gridDim.x), "s"(total4), "s"(C), "s"(inv_n), "s"(y), "s"(dz), "s"(stat), "s"(sums), "s"(dy));  // "Kernel heads", pcm_common.hpp
+    const unsigned c4n = (unsigned)C / 4u;
     for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < total4; i += (long)gridDim.x * kBlock) {
         const long e = i * 4;
-        const int c = (int)(e % C);
+        const int c = total4 <= 0xFFFFFFFFl ? (int)(((unsigned)i % c4n) * 4u) : (int)(e % C);
         float v[4], d[4], mean[4], invstd[4], a[4], b[4], sg[4], sgx[4], o[4];
         load4<T>(y + e, v);
         load4<T>(dz + e, d);
@@ -249,7 +276,9 @@ __global__ __launch_bounds__(kBlock) void pcm_bn_relu_bwd_apply_kernel(long tota
         load4<float>(sums + C + c, sgx);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const float g = (a[u] * v[u] + b[u] > 0.f) ? d[u] : 0.f;
+            float g;
+            if constexpr (RELU) g = (a[u] * v[u] + b[u] > 0.f) ? d[u] : 0.f;
+            else g = d[u];
             const float xhat = (v[u] - mean[u]) * invstd[u];
             o[u] = a[u] * (g - sg[u] * inv_n - xhat * (sgx[u] * inv_n));
         }
@@ -382,9 +411,11 @@ extern "C" int pcm_bn_relu_slots(long n, int C)
     return plan_for(n, C).nslots;
 }
 
-extern "C" int pcm_bn_relu_forward_hip(long n, int C, int is_bf16, const void *y, const float *gamma, const float *beta,
-                                       float eps, float momentum, float *running_mean, float *running_var,
-                                       int use_given_stat, float *partial, float *sums, float *stat, void *z, void *stream)
+// BatchNorm1d over rows with (relu != 0) or without the ReLU behind it: the Diffusion Policy's projector ends with a bare BatchNorm
+// (/root/reference/src/models/components/diffusion_policy/vision/pcd_obs_encoder.py:100-120)
+extern "C" int pcm_bn_act_forward_hip(long n, int C, int is_bf16, int relu, const void *y, const float *gamma, const float *beta,
+                                      float eps, float momentum, float *running_mean, float *running_var, int use_given_stat,
+                                      float *partial, float *sums, float *stat, void *z, void *stream)
 {
     if (n == 0) return PCM_OK;
     if (!pcm_bn_relu_supported(n, C)) return PCM_ERR_UNSUPPORTED;
@@ -422,16 +453,31 @@ extern "C" int pcm_bn_relu_forward_hip(long n, int C, int is_bf16, const void *y
         }
     }
     const long total4 = n * C / 4;
-    if (is_bf16)
+    if (is_bf16 && relu)
         hipLaunchKernelGGL(pcm_bn_relu_apply_kernel<bf>, dim3(ew_grid(total4)), dim3(kBlock), 0, s, total4, C, (const bf *)y, stat, (bf *)z);
-    else
+    else if (is_bf16)
+        hipLaunchKernelGGL((pcm_bn_relu_apply_kernel<bf, false>), dim3(ew_grid(total4)), dim3(kBlock), 0, s, total4, C, (const bf *)y, stat,
+                           (bf *)z);
+    else if (relu)
         hipLaunchKernelGGL(pcm_bn_relu_apply_kernel<float>, dim3(ew_grid(total4)), dim3(kBlock), 0, s, total4, C, (const float *)y, stat,
                            (float *)z);
+    else
+        hipLaunchKernelGGL((pcm_bn_relu_apply_kernel<float, false>), dim3(ew_grid(total4)), dim3(kBlock), 0, s, total4, C, (const float *)y,
+                           stat, (float *)z);
     return PCM_LAUNCH_STATUS();
 }
 
-extern "C" int pcm_bn_relu_backward_hip(long n, int C, int is_bf16, const void *y, const void *dz, const float *stat,
-                                        float *partial, float *sums, void *dy, int phase, double count, void *stream)
+extern "C" int pcm_bn_relu_forward_hip(long n, int C, int is_bf16, const void *y, const float *gamma, const float *beta,
+                                       float eps, float momentum, float *running_mean, float *running_var,
+                                       int use_given_stat, float *partial, float *sums, float *stat, void *z, void *stream)
+{
+    return pcm_bn_act_forward_hip(n, C, is_bf16, 1, y, gamma, beta, eps, momentum, running_mean, running_var, use_given_stat, partial, sums,
+                                  stat, z, stream);
+}
+
+
+extern "C" int pcm_bn_act_backward_hip(long n, int C, int is_bf16, int relu, const void *y, const void *dz, const float *stat,
+                                       float *partial, float *sums, void *dy, int phase, double count, void *stream)
 {
     // phase: 0 = whole backward; 1 = local sums only (sums = {sum g, sum g * xhat}); 2 = apply only with the given sums
     // (all-reduced across ranks by the caller) and `count` = rows of the GLOBAL batch (<= 0: n)
@@ -445,22 +491,42 @@ extern "C" int pcm_bn_relu_backward_hip(long n, int C, int is_bf16, const void *
     const float inv_n = (float)(1.0 / (count > 0.0 ? count : (double)n));
     if (is_bf16) {
         if (phase != 2) {
-            hipLaunchKernelGGL((pcm_bn_colsum_kernel<bf, 1>), grid, dim3(kBlock), 0, s, n, C, p.chunkW, p.rows_per_slot, (const bf *)y,
-                               (const bf *)dz, stat, partial);
+            if (relu)
+                hipLaunchKernelGGL((pcm_bn_colsum_kernel<bf, 1>), grid, dim3(kBlock), 0, s, n, C, p.chunkW, p.rows_per_slot, (const bf *)y,
+                                   (const bf *)dz, stat, partial);
+            else
+                hipLaunchKernelGGL((pcm_bn_colsum_kernel<bf, 2>), grid, dim3(kBlock), 0, s, n, C, p.chunkW, p.rows_per_slot, (const bf *)y,
+                                   (const bf *)dz, stat, partial);
             hipLaunchKernelGGL(pcm_bn_reduce_kernel, dim3((2 * C + 63) / 64), dim3(64 * kRedWaves), 0, s, p.nslots, 2 * C, partial, sums);
         }
-        if (phase != 1)
+        if (phase != 1 && relu)
             hipLaunchKernelGGL(pcm_bn_relu_bwd_apply_kernel<bf>, dim3(ew_grid(total4)), dim3(kBlock), 0, s, total4, C, inv_n, (const bf *)y,
                                (const bf *)dz, stat, sums, (bf *)dy);
+        else if (phase != 1)
+            hipLaunchKernelGGL((pcm_bn_relu_bwd_apply_kernel<bf, false>), dim3(ew_grid(total4)), dim3(kBlock), 0, s, total4, C, inv_n,
+                               (const bf *)y, (const bf *)dz, stat, sums, (bf *)dy);
     } else {
         if (phase != 2) {
-            hipLaunchKernelGGL((pcm_bn_colsum_kernel<float, 1>), grid, dim3(kBlock), 0, s, n, C, p.chunkW, p.rows_per_slot,
-                               (const float *)y, (const float *)dz, stat, partial);
+            if (relu)
+                hipLaunchKernelGGL((pcm_bn_colsum_kernel<float, 1>), grid, dim3(kBlock), 0, s, n, C, p.chunkW, p.rows_per_slot,
+                                   (const float *)y, (const float *)dz, stat, partial);
+            else
+                hipLaunchKernelGGL((pcm_bn_colsum_kernel<float, 2>), grid, dim3(kBlock), 0, s, n, C, p.chunkW, p.rows_per_slot,
+                                   (const float *)y, (const float *)dz, stat, partial);
             hipLaunchKernelGGL(pcm_bn_reduce_kernel, dim3((2 * C + 63) / 64), dim3(64 * kRedWaves), 0, s, p.nslots, 2 * C, partial, sums);
         }
-        if (phase != 1)
+        if (phase != 1 && relu)
             hipLaunchKernelGGL(pcm_bn_relu_bwd_apply_kernel<float>, dim3(ew_grid(total4)), dim3(kBlock), 0, s, total4, C, inv_n,
+                               (const float *)y, (const float *)dz, stat, sums, (float *)dy);
+        else if (phase != 1)
+            hipLaunchKernelGGL((pcm_bn_relu_bwd_apply_kernel<float, false>), dim3(ew_grid(total4)), dim3(kBlock), 0, s, total4, C, inv_n,
                                (const float *)y, (const float *)dz, stat, sums, (float *)dy);
     }
     return PCM_LAUNCH_STATUS();
+}
+
+extern "C" int pcm_bn_relu_backward_hip(long n, int C, int is_bf16, const void *y, const void *dz, const float *stat,
+                                        float *partial, float *sums, void *dy, int phase, double count, void *stream)
+{
+    return pcm_bn_act_backward_hip(n, C, is_bf16, 1, y, dz, stat, partial, sums, dy, phase, count, stream);
 }

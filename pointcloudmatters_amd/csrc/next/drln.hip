@@ -34,6 +34,8 @@ __global__ __launch_bounds__(kBlock) void pcm_drln_fwd_kernel(long R, const floa
                                                               __hip_bfloat16 *__restrict__ sum16, __hip_bfloat16 *__restrict__ x16)
 {
     constexpr int E = NCH * 256;
+    // every kernel argument in registers HERE: one batch of kernarg loads, one wait ("Kernel heads" in pcm_common.hpp)
+    asm volatile("" ::"s"(gridDim.x), "s"(R), "s"(x), "s"(y), "s"(gamma), "s"(beta), "s"(eps), "s"(p_drop), "s"(seed_ptr), "s"(site), "s"(s_out), "s"(out), "s"(mean_out), "s"(rstd_out), "s"(pos), "s"(pos_n), "s"(sum16), "s"(x16));
     const int lane = threadIdx.x & 63;
     const long wave0 = (long)blockIdx.x * kWaves + (threadIdx.x >> 6), nwaves = (long)gridDim.x * kWaves;
     const bool drop = p_drop > 0.f;
@@ -49,15 +51,28 @@ __global__ __launch_bounds__(kBlock) void pcm_drln_fwd_kernel(long R, const floa
     for (long r = wave0; r < R; r += nwaves) {
         float s[NCH][4];
         float sum = 0.f;
+        // the position rows of the emitted operand are requested together with x and y (the first version asked for them behind the
+        // two reductions, one 64-bit modulo and one exposed round trip per chunk)
+        float pv[NCH][4];
+        if (sum16 != nullptr) {
+            const long p0 = (r * E) % pos_n;  // E divides pos_n: a row never wraps
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) load4<float>(pos + p0 + c * 256 + lane * 4, pv[c]);
+        }
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const long e0 = r * E + c * 256 + lane * 4;
             float xv[4], yv[4];
             load4<float>(x + e0, xv);
             load4<T>(y + e0, yv);
+            // the seed is first touched HERE, behind the row's loads in program order: its own load (issued at the kernel's entry) is
+            // then waited for with the row's loads in flight instead of in front of them (the opaque asm keeps the compiler from hoisting
+            // the hash constants -- and with them the wait -- back in front of the loop)
+            uint64_t seed_r = seed;
+            asm volatile("" : "+v"(seed_r));
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const float yy = (keep_elem(seed, site, (uint64_t)(e0 + v), thr)) ? yv[v] * scale : 0.f;
+                const float yy = (keep_elem(seed_r, site, (uint64_t)(e0 + v), thr)) ? yv[v] * scale : 0.f;
                 s[c][v] = xv[v] + yy;
                 sum += s[c][v];
             }
@@ -83,10 +98,9 @@ __global__ __launch_bounds__(kBlock) void pcm_drln_fwd_kernel(long R, const floa
             // the consumer's bf16 operands, emitted here instead of by its own add + cast launch (pcm_add_cast2_hip):
             // sum16 = bf16(out + pos) (pos broadcast over the leading rows), x16 = bf16(out)
             if (sum16 != nullptr) {
-                float p[4], q[4];
-                load4<float>(pos + (r * E) % pos_n + c * 256 + lane * 4, p);  // E divides pos_n: a row never wraps
+                float q[4];
 #pragma unroll
-                for (int v = 0; v < 4; ++v) q[v] = o[v] + p[v];
+                for (int v = 0; v < 4; ++v) q[v] = o[v] + pv[c][v];
                 store4<__hip_bfloat16>(sum16 + e0, q);
             }
             if (x16 != nullptr) store4<__hip_bfloat16>(x16 + e0, o);
@@ -106,6 +120,7 @@ __global__ __launch_bounds__(kBlock) void pcm_drln_bwd_kernel(long R, const floa
 {
     constexpr int E = NCH * 256;
     __shared__ float lds[kWaves][3][E];
+    asm volatile("" ::"s"(gridDim.x), "s"(R), "s"(dout), "s"(dout2), "s"(s), "s"(mean), "s"(rstd), "s"(gamma), "s"(p_drop), "s"(seed_ptr), "s"(site), "s"(dx), "s"(dy), "s"(partial));  // "Kernel heads", pcm_common.hpp
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long wave0 = (long)blockIdx.x * kWaves + wave, nwaves = (long)gridDim.x * kWaves;
     const bool drop = p_drop > 0.f;
@@ -123,18 +138,28 @@ __global__ __launch_bounds__(kBlock) void pcm_drln_bwd_kernel(long R, const floa
         const float mu = mean[r], rs = rstd[r];
         float gd[NCH][4], xh[NCH][4];
         float s1 = 0.f, s2 = 0.f;
+        // every load of the row is requested before the first value is used (written chunk by chunk, the second gradient's
+        // `if` made the compiler wait for each chunk's loads in turn: NCH round trips in series instead of one)
+        float dvs[NCH][4], svs[NCH][4];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const long e0 = r * E + c * 256 + lane * 4;
-            float dv[4], sv[4];
-            load4<float>(dout + e0, dv);
-            if (dout2 != nullptr) {  // the output had two consumers: their gradients are summed here, not by an add launch
-                float d2[4];
-                load4<float>(dout2 + e0, d2);
+            load4<float>(dout + e0, dvs[c]);
+            load4<float>(s + e0, svs[c]);
+        }
+        if (dout2 != nullptr) {  // the output had two consumers: their gradients are summed here, not by an add launch
+            float d2[NCH][4];
 #pragma unroll
-                for (int v = 0; v < 4; ++v) dv[v] += d2[v];
-            }
-            load4<float>(s + e0, sv);
+            for (int c = 0; c < NCH; ++c) load4<float>(dout2 + r * E + c * 256 + lane * 4, d2[c]);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) dvs[c][v] += d2[c][v];
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const float(&dv)[4] = dvs[c];
+            const float(&sv)[4] = svs[c];
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 xh[c][v] = (sv[v] - mu) * rs;
@@ -146,6 +171,8 @@ __global__ __launch_bounds__(kBlock) void pcm_drln_bwd_kernel(long R, const floa
             }
         }
         const float m1 = wave_sum(s1) * (1.f / E), m2 = wave_sum(s2) * (1.f / E);
+        uint64_t seed_r = seed;  // first touched behind the row's loads: "Kernel heads", pcm_common.hpp
+        asm volatile("" : "+v"(seed_r));
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const long e0 = r * E + c * 256 + lane * 4;
@@ -153,7 +180,7 @@ __global__ __launch_bounds__(kBlock) void pcm_drln_bwd_kernel(long R, const floa
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 o[v] = rs * (gd[c][v] - m1 - xh[c][v] * m2);
-                oy[v] = (keep_elem(seed, site, (uint64_t)(e0 + v), thr)) ? o[v] * scale : 0.f;
+                oy[v] = (keep_elem(seed_r, site, (uint64_t)(e0 + v), thr)) ? o[v] * scale : 0.f;
                 dys[c][v] += oy[v];  // column sums of dy = the bias gradient of the projection that produced y
             }
             store4<float>(dx + e0, o);
@@ -186,8 +213,7 @@ __global__ __launch_bounds__(512) void pcm_drln_reduce_kernel(int nslots, int VH
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + lane;
     double acc = 0.0;
-    if (e < VH)
-        for (int s = wave; s < nslots; s += 8) acc += (double)partial[(size_t)s * VH + e];
+    if (e < VH) acc = pcm_slot_sum(partial, (size_t)VH, e, wave, 8, nslots);
     red[wave][lane] = acc;
     __syncthreads();
     if (wave == 0 && e < VH) {

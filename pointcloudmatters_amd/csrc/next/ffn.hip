@@ -108,6 +108,9 @@ __global__ __launch_bounds__(kThreads) void pcm_ffn_ln_fwd_kernel(long R, const 
     static_assert(F == 32 && E % 256 == 0, "specialised for dim_feedforward = 32");
     constexpr int PER = E / 64;
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    // every argument in registers at the entry, i.e. their loads travel UNDER the weight staging ("Kernel heads", pcm_common.hpp; the
+    // compiler had put them -- R, the pointers, the seed through its pointer: five dependent scalar round trips -- behind the barrier)
+    asm volatile("" ::"s"(gridDim.x), "s"(R), "s"(x), "s"(W1), "s"(b1), "s"(W2), "s"(b2), "s"(gamma), "s"(beta), "s"(eps), "s"(pa), "s"(pb), "s"(seed_ptr), "s"(site_a), "s"(site_b), "s"(hd_out), "s"(s_out), "s"(out), "s"(mean_out), "s"(rstd_out), "s"(pos), "s"(pos_n), "s"(sum16), "s"(x16));
     float *w1 = lds, *w2t = lds + F * E;
     stage_weights<E, F>(w1, w2t, W1, W2);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -134,15 +137,25 @@ __global__ __launch_bounds__(kThreads) void pcm_ffn_ln_fwd_kernel(long R, const 
         }
         float part[F];
 #pragma unroll
-        for (int jj = 0; jj < F; ++jj) {
-            float acc = 0.f;
+        for (int j0 = 0; j0 < F; j0 += 8) {
+            float4 wq[8][PER / 4];
 #pragma unroll
-            for (int t = 0; t < PER; t += 4) {
-                const float4 w = *reinterpret_cast<const float4 *>(w1r + jj * E + col_of(lane, t));
-                acc += xv[t] * w.x + xv[t + 1] * w.y + xv[t + 2] * w.z + xv[t + 3] * w.w;
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int t = 0; t < PER; t += 4) wq[u][t / 4] = *reinterpret_cast<const float4 *>(w1r + (j0 + u) * E + col_of(lane, t));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                float acc = 0.f;
+#pragma unroll
+                for (int t = 0; t < PER; t += 4) {
+                    const float4 w = wq[u][t / 4];
+                    acc += xv[t] * w.x + xv[t + 1] * w.y + xv[t + 2] * w.z + xv[t + 3] * w.w;
+                }
+                part[j0 + u] = acc;
             }
-            part[jj] = acc;
-            if (jj % 8 == 7) asm volatile("" ::: "memory");  // at most 16 ds_read_b128 in flight: bounds live VGPRs
+            // schedule of this group: its 16 LDS reads first, then its 128 VALU operations
+            __builtin_amdgcn_sched_group_barrier(0x100, 8 * (PER / 4), 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 8 * 2 * PER, 0);
         }
         float h = butterfly32(part, lane) + bias1;
         h = h > 0.f ? h : 0.f;
@@ -152,14 +165,23 @@ __global__ __launch_bounds__(kThreads) void pcm_ffn_ln_fwd_kernel(long R, const 
 #pragma unroll
         for (int t = 0; t < PER; ++t) s[t] = bias2[t];
 #pragma unroll
-        for (int jj = 0; jj < F; ++jj) {
-            const float hj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hd), 2 * jj));
+        for (int j0 = 0; j0 < F; j0 += 8) {
+            float4 wq[8][PER / 4];
 #pragma unroll
-            for (int t = 0; t < PER; t += 4) {
-                const float4 w = *reinterpret_cast<const float4 *>(w2r + jj * (E + kPad) + col_of(lane, t));
-                s[t] += hj * w.x, s[t + 1] += hj * w.y, s[t + 2] += hj * w.z, s[t + 3] += hj * w.w;
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int t = 0; t < PER; t += 4) wq[u][t / 4] = *reinterpret_cast<const float4 *>(w2r + (j0 + u) * (E + kPad) + col_of(lane, t));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float hj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hd), 2 * (j0 + u)));
+#pragma unroll
+                for (int t = 0; t < PER; t += 4) {
+                    const float4 w = wq[u][t / 4];
+                    s[t] += hj * w.x, s[t + 1] += hj * w.y, s[t + 2] += hj * w.z, s[t + 3] += hj * w.w;
+                }
             }
-            if (jj % 8 == 7) asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_group_barrier(0x100, 8 * (PER / 4), 0);  // this group's 16 LDS reads first ...
+            __builtin_amdgcn_sched_group_barrier(0x002, 8 * (2 * PER + 1), 0);  // ... then its arithmetic
         }
         float sum = 0.f;
 #pragma unroll
@@ -210,6 +232,7 @@ __global__ __launch_bounds__(kThreads) void pcm_ffn_ln_bwd_kernel(long R, const 
     constexpr int PER = E / 64;
     constexpr int PW = 3 * E + F;
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    asm volatile("" ::"s"(gridDim.x), "s"(R), "s"(dout), "s"(dout2), "s"(x), "s"(s), "s"(mean), "s"(rstd), "s"(hd), "s"(W1), "s"(W2), "s"(gamma), "s"(pa), "s"(pb), "s"(seed_ptr), "s"(site_b), "s"(dx), "s"(dy), "s"(dh_out), "s"(partial));  // "Kernel heads", pcm_common.hpp
     float *w1 = lds, *w2t = lds + F * E;
     stage_weights<E, F>(w1, w2t, W1, W2);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -265,15 +288,24 @@ __global__ __launch_bounds__(kThreads) void pcm_ffn_ln_bwd_kernel(long R, const 
         }
         float part[F];
 #pragma unroll
-        for (int jj = 0; jj < F; ++jj) {
-            float acc = 0.f;
+        for (int j0 = 0; j0 < F; j0 += 8) {  // 16 LDS reads requested together, then consumed (see the forward kernel)
+            float4 wq[8][PER / 4];
 #pragma unroll
-            for (int t = 0; t < PER; t += 4) {
-                const float4 w = *reinterpret_cast<const float4 *>(w2r + jj * (E + kPad) + col_of(lane, t));
-                acc += dyv[t] * w.x + dyv[t + 1] * w.y + dyv[t + 2] * w.z + dyv[t + 3] * w.w;
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int t = 0; t < PER; t += 4) wq[u][t / 4] = *reinterpret_cast<const float4 *>(w2r + (j0 + u) * (E + kPad) + col_of(lane, t));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                float acc = 0.f;
+#pragma unroll
+                for (int t = 0; t < PER; t += 4) {
+                    const float4 w = wq[u][t / 4];
+                    acc += dyv[t] * w.x + dyv[t + 1] * w.y + dyv[t + 2] * w.z + dyv[t + 3] * w.w;
+                }
+                part[j0 + u] = acc;
             }
-            part[jj] = acc;
-            if (jj % 8 == 7) asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_group_barrier(0x100, 8 * (PER / 4), 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 8 * 2 * PER, 0);
         }
         const float dhd = butterfly32(part, lane);
         const float hdv = hd[r * F + j];
@@ -283,14 +315,23 @@ __global__ __launch_bounds__(kThreads) void pcm_ffn_ln_bwd_kernel(long R, const 
             db1 += dh;
         }
 #pragma unroll
-        for (int jj = 0; jj < F; ++jj) {
-            const float dj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dh), 2 * jj));
+        for (int j0 = 0; j0 < F; j0 += 8) {
+            float4 wq[8][PER / 4];
 #pragma unroll
-            for (int t = 0; t < PER; t += 4) {
-                const float4 w = *reinterpret_cast<const float4 *>(w1r + jj * E + col_of(lane, t));
-                ds[t] += dj * w.x, ds[t + 1] += dj * w.y, ds[t + 2] += dj * w.z, ds[t + 3] += dj * w.w;
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int t = 0; t < PER; t += 4) wq[u][t / 4] = *reinterpret_cast<const float4 *>(w1r + (j0 + u) * E + col_of(lane, t));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float dj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dh), 2 * (j0 + u)));
+#pragma unroll
+                for (int t = 0; t < PER; t += 4) {
+                    const float4 w = wq[u][t / 4];
+                    ds[t] += dj * w.x, ds[t + 1] += dj * w.y, ds[t + 2] += dj * w.z, ds[t + 3] += dj * w.w;
+                }
             }
-            if (jj % 8 == 7) asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_group_barrier(0x100, 8 * (PER / 4), 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 8 * (2 * PER + 1), 0);
         }
 #pragma unroll
         for (int t = 0; t < PER; t += 4) {
@@ -323,8 +364,7 @@ __global__ __launch_bounds__(512) void pcm_ffn_reduce_kernel(int nslots, int VH,
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + lane;
     double acc = 0.0;
-    if (e < VH)
-        for (int s = wave; s < nslots; s += 8) acc += (double)partial[(size_t)s * VH + e];
+    if (e < VH) acc = pcm_slot_sum(partial, (size_t)VH, e, wave, 8, nslots);
     red[wave][lane] = acc;
     __syncthreads();
     if (wave == 0 && e < VH) {

@@ -84,7 +84,7 @@ __device__ __forceinline__ uint32_t fps_block_argmax(uint32_t bits, uint32_t pri
     return fps_unprio(~(uint32_t)key, L);
 }
 
-typedef float fps_f2 __attribute__((ext_vector_type(2)));  // v_pk_add_f32 / v_pk_mul_f32 operands (no FMA: contract off)
+typedef float fps_f2 __attribute__((ext_vector_type(2)));  // a point pair; the build has no packed-fp32 instructions (Makefile NO_PK): two scalar chains
 
 // Wave-wide unsigned max in 6 DPP-fused instructions + 1 readlane (the builtin form costs a v_mov + s_nop + v_mov_dpp +
 // v_max per step and 4 readlanes): quad swaps, row_half_mirror, row_mirror leave every row's maximum in all of its lanes,
@@ -112,8 +112,9 @@ __device__ __forceinline__ uint32_t fps_wave_max_fast(uint32_t v)
 // ---------------------------------------------------------------------------------------------
 // Register-resident kernel: N_i <= T*PPT for every cloud.  The pick loop is bound by instruction issue of ONE wave per
 // SIMD (~6 clocks per dependent instruction), so it is written to be short:
-//  (a) distance update on point PAIRS with packed fp32 math (same roundings as the scalar chain: sub, mul, add, mul, add,
-//      one at a time), v_min for the running distance, one compare + two selects for the thread's candidate;
+//  (a) distance update on point PAIRS, written on two-element vectors (sub, mul, add, mul, add, one rounding at a time; the build
+//      compiles them to scalar v_sub / v_mul / v_add -- packed fp32 instructions are disabled, Makefile NO_PK -- so the pair form only
+//      keeps two independent chains in flight), v_min for the running distance, one compare + two selects for the thread's candidate;
 //  (b) wave maximum of the candidates' distance bits: 6 fused DPP instructions + 1 readlane;
 //  (c) a ballot finds the owning lane; only an exact tie inside the wave (wave-uniform branch, rare) computes the
 //      reference's tie order (prio) and reduces it;
@@ -139,6 +140,7 @@ __global__ __launch_bounds__(T) void pcm_fps_reg_kernel(const float *__restrict_
     float4 *cand = reinterpret_cast<float4 *>(smem + 2 * WP * 4);        // [2][W]    (local index, x, y, z)
     float4 *lxyz = cand + 2 * W;                                         // [N] when STAGE
 
+    asm volatile("" ::"s"(xyz), "s"(offset), "s"(new_offset), "s"(idx), "s"(L));  // "Kernel heads", pcm_common.hpp
     const int bid = blockIdx.x;
     const int u = threadIdx.x, lane = u & 63, wave = u >> 6;
     const int start_n = bid == 0 ? 0 : offset[bid - 1];
@@ -157,19 +159,26 @@ __global__ __launch_bounds__(T) void pcm_fps_reg_kernel(const float *__restrict_
     fps_f2 px[NP], py[NP], pz[NP];
     float md[2 * NP];
     const float *cloud = xyz + (size_t)start_n * 3;
+    // Two passes: ALL of the thread's points are requested first -- branch-free: a slot past the cloud reads point N - 1 and is zeroed by a
+    // select --, the LDS copy is written from the registers afterwards.  (One pass with the loads inside `if (j < N)` -- load, stage, next
+    // point -- compiled to a full `s_waitcnt vmcnt(0)` per point: PPT round trips in series before the first pick.)
 #pragma unroll
     for (int s = 0; s < 2 * NP; ++s) {
         const int j = s < PPT ? u + slot_to_i<PPT, LOGQ>(s < PPT ? s : 0) * T : N;
-        float x = 0.f, y = 0.f, z = 0.f;
-        md[s] = -1.f;  // min(d, -1) = -1 is never > best
-        if (j < N) {
-            x = cloud[j * 3 + 0], y = cloud[j * 3 + 1], z = cloud[j * 3 + 2];
-            md[s] = 1e10f;  // functions/sampling.py:18 pre-fill
-            if (STAGE) lxyz[j] = make_float4(x, y, z, 0.f);
-        }
-        px[s / 2][s % 2] = x, py[s / 2][s % 2] = y, pz[s / 2][s % 2] = z;
+        const bool in = j < N;
+        const int jc = in ? j : N - 1;
+        const float x = cloud[jc * 3 + 0], y = cloud[jc * 3 + 1], z = cloud[jc * 3 + 2];
+        md[s] = in ? 1e10f : -1.f;  // functions/sampling.py:18 pre-fill; min(d, -1) = -1 is never > best
+        px[s / 2][s % 2] = in ? x : 0.f, py[s / 2][s % 2] = in ? y : 0.f, pz[s / 2][s % 2] = in ? z : 0.f;
     }
     float ox = cloud[0], oy = cloud[1], oz = cloud[2];
+    if (STAGE) {
+#pragma unroll
+        for (int s = 0; s < PPT; ++s) {
+            const int j = u + slot_to_i<PPT, LOGQ>(s) * T;
+            if (j < N) lxyz[j] = make_float4(px[s / 2][s % 2], py[s / 2][s % 2], pz[s / 2][s % 2], 0.f);
+        }
+    }
     __syncthreads();
 
     const uint32_t bs_mask = (1u << L) - 1u;

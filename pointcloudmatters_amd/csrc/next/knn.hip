@@ -52,10 +52,12 @@ __global__ __launch_bounds__(64 * kWaves) void pcm_knn_fast_kernel(int b, int m,
     const int K1 = nsample + 1;
     const uint32_t PAD = __float_as_uint(1e10f);
     constexpr int QB = Q * kWaves;  // queries per workgroup
+    const PcmCloudTable tab(offset, new_offset, b, lane);  // both offset tables in registers: no dependent scalar loads below
     for (int qb = blockIdx.x * QB; qb < m; qb += gridDim.x * QB) {
         const int q0 = qb + wave * Q;  // this wave's first query (may lie beyond m: then it only helps with the staging)
         const int q_last_wg = min(qb + QB, m) - 1;
-        const int c_first = pcm_cloud_of(qb, new_offset, b), c_last = pcm_cloud_of(q_last_wg, new_offset, b);
+        const int c_first = tab.ok ? tab.cloud_of(qb) : pcm_cloud_of(qb, new_offset, b);
+        const int c_last = tab.ok ? tab.cloud_of(q_last_wg) : pcm_cloud_of(q_last_wg, new_offset, b);
         uint32_t ld[Q], tau[Q];
         int li[Q];
         float qx[Q], qy[Q], qz[Q];
@@ -68,8 +70,14 @@ __global__ __launch_bounds__(64 * kWaves) void pcm_knn_fast_kernel(int b, int m,
             qx[i] = new_xyz[(size_t)q * 3 + 0], qy[i] = new_xyz[(size_t)q * 3 + 1], qz[i] = new_xyz[(size_t)q * 3 + 2];
         }
         for (int c = c_first; c <= c_last; ++c) {
-            const int start = c == 0 ? 0 : offset[c - 1], end = offset[c];
-            const int qs = c == 0 ? 0 : new_offset[c - 1], qe = new_offset[c];  // queries of this cloud
+            int start, end, qs, qe;  // points and queries of this cloud
+            if (tab.ok) {
+                start = c == 0 ? 0 : tab.offset_at(c - 1), end = tab.offset_at(c);
+                qs = c == 0 ? 0 : tab.new_offset_at(c - 1), qe = tab.new_offset_at(c);
+            } else {
+                start = c == 0 ? 0 : offset[c - 1], end = offset[c];
+                qs = c == 0 ? 0 : new_offset[c - 1], qe = new_offset[c];
+            }
             bool act[Q];
 #pragma unroll
             for (int i = 0; i < Q; ++i) act[i] = q0 + i >= qs && q0 + i < qe && q0 + i < m;
@@ -265,18 +273,27 @@ __global__ __launch_bounds__(64 * kWaves) void pcm_knn_twopass_kernel(int b, int
     xa.a[3] = (lane ^ 31) << 2, xa.a[4] = (lane ^ 63) << 2, xa.a[5] = (lane ^ 32) << 2;
     uint32_t *bd = cand_d[wave];
     int *bi = cand_i[wave];
+    asm volatile("" ::"s"(b), "s"(m), "s"(nsample), "s"(xyz), "s"(new_xyz), "s"(offset), "s"(new_offset), "s"(idx), "s"(dist2));  // "Kernel heads", pcm_common.hpp
+    const PcmCloudTable tab(offset, new_offset, b, lane);
     for (int qb = blockIdx.x * kWaves; qb < m; qb += gridDim.x * kWaves) {
         const int q = qb + wave;  // may lie beyond m: then the wave only helps with the staging
         const int q_last_wg = min(qb + kWaves, m) - 1;
-        const int c_first = pcm_cloud_of(qb, new_offset, b), c_last = pcm_cloud_of(q_last_wg, new_offset, b);
+        const int c_first = tab.ok ? tab.cloud_of(qb) : pcm_cloud_of(qb, new_offset, b);
+        const int c_last = tab.ok ? tab.cloud_of(q_last_wg) : pcm_cloud_of(q_last_wg, new_offset, b);
         const int qq = q < m ? q : m - 1;
         const float qx = new_xyz[(size_t)qq * 3 + 0], qy = new_xyz[(size_t)qq * 3 + 1], qz = new_xyz[(size_t)qq * 3 + 2];
         int cnt = 0;          // entries in the candidate buffer (wave-uniform)
         uint32_t tau = PAD;   // candidates need d2 < tau (bit patterns: d2 >= +0, unsigned order == float order)
         bool overflow = false;
         for (int c = c_first; c <= c_last; ++c) {
-            const int start = c == 0 ? 0 : offset[c - 1], end = offset[c];
-            const int qs = c == 0 ? 0 : new_offset[c - 1], qe = new_offset[c];
+            int start, end, qs, qe;
+            if (tab.ok) {
+                start = c == 0 ? 0 : tab.offset_at(c - 1), end = tab.offset_at(c);
+                qs = c == 0 ? 0 : tab.new_offset_at(c - 1), qe = tab.new_offset_at(c);
+            } else {
+                start = c == 0 ? 0 : offset[c - 1], end = offset[c];
+                qs = c == 0 ? 0 : new_offset[c - 1], qe = new_offset[c];
+            }
             const bool act = q >= qs && q < qe && q < m;  // wave-uniform
             const int npts = end - start;
             const int nchunks = (npts + kChunk - 1) / kChunk;
@@ -419,15 +436,17 @@ __global__ __launch_bounds__(64 * kWaves) void pcm_knn_exact_kernel(int b, int m
             child = root * 2 + 1;
         }
     };
+    const PcmCloudTable tab(offset, new_offset, b, lane);
     for (int q = blockIdx.x * kWaves + wave; q < m; q += gridDim.x * kWaves) {
         if (!all_queries && !(dist2[(size_t)q * nsample] < 0.f)) continue;  // wave-uniform
-        const int bt = pcm_cloud_of(q, new_offset, b);
-        const int start = bt == 0 ? 0 : offset[bt - 1];
-        const int end = offset[bt];
+        const int bt = tab.ok ? tab.cloud_of(q) : pcm_cloud_of(q, new_offset, b);
+        const int start = bt == 0 ? 0 : (tab.ok ? tab.offset_at(bt - 1) : offset[bt - 1]);
+        const int end = tab.ok ? tab.offset_at(bt) : offset[bt];
         const float qx = new_xyz[(size_t)q * 3 + 0];
         const float qy = new_xyz[(size_t)q * 3 + 1];
         const float qz = new_xyz[(size_t)q * 3 + 2];
         for (int i = lane; i < nsample; i += 64) bd[i] = 1e10f, bi[i] = -1;
+        __builtin_amdgcn_wave_barrier();  // all 64 lanes read the root next: in-wave LDS order, made explicit (no instruction)
         for (int base = start; base < end; base += 64) {
             const int p = base + lane;
             float d2 = INFINITY;

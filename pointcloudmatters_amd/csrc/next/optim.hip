@@ -219,11 +219,9 @@ struct XferBatch {
 __global__ __launch_bounds__(256) void pcm_xfer_batch_kernel(XferBatch b)
 {
     const int c = blockIdx.x;
-    int lo = 0, hi = b.n - 1;  // the job whose chunk range holds c (wave-uniform: scalar loads from the argument segment)
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (b.chunk0[mid] <= c) lo = mid; else hi = mid - 1;
-    }
+    // the job whose chunk range holds c: one lane-indexed load of the table + a ballot (was a bisection: 7 dependent scalar loads)
+    const int lo = pcm_job_of(c, b.n, [&](int j) { return b.chunk0[j]; });
+    asm volatile("" ::"s"((int)b.kind[lo]), "s"(b.chunk0[lo]), "s"(b.numel[lo]), "s"(b.dst[lo]), "s"(b.src[lo]));  // one batch: "Kernel heads", pcm_common.hpp
     const int kind = b.kind[lo];
     const long e0 = (long)(c - b.chunk0[lo]) * kXferChunk;
     const int len = b.numel[lo] - e0 < kXferChunk ? (int)(b.numel[lo] - e0) : kXferChunk;
@@ -231,6 +229,14 @@ __global__ __launch_bounds__(256) void pcm_xfer_batch_kernel(XferBatch b)
         unsigned short *d = static_cast<unsigned short *>(b.dst[lo]) + e0;
         const unsigned short *s_ = static_cast<const unsigned short *>(b.src[lo]) + e0;
         const bool vec = ((((uintptr_t)d) | ((uintptr_t)s_)) & 15) == 0;
+        if (vec && len == kXferChunk) {  // whole aligned chunk: every load in flight before the first store (the loop below: load, wait, store)
+            uint4 q[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) q[t] = *reinterpret_cast<const uint4 *>(s_ + (threadIdx.x + 256 * t) * 8);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) *reinterpret_cast<uint4 *>(d + (threadIdx.x + 256 * t) * 8) = q[t];
+            return;
+        }
         for (int i = threadIdx.x * 8; i < len; i += 256 * 8) {
             if (vec && i + 8 <= len) {
                 *reinterpret_cast<uint4 *>(d + i) = *reinterpret_cast<const uint4 *>(s_ + i);
@@ -254,6 +260,31 @@ __global__ __launch_bounds__(256) void pcm_xfer_batch_kernel(XferBatch b)
     } else if (kind == PCM_XFER_SET_BF16 || kind == PCM_XFER_ADD_BF16) {
         const unsigned short *s_ = static_cast<const unsigned short *>(b.src[lo]) + e0;
         const bool vec = dvec && (((uintptr_t)s_) & 15) == 0;
+        if (vec && len == kXferChunk) {  // whole aligned chunk: every load in flight before the first store; same sums
+            uint4 q[4];
+            float4 u[4][2];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) q[t] = *reinterpret_cast<const uint4 *>(s_ + (threadIdx.x + 256 * t) * 8);
+            if (add) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    u[t][0] = *reinterpret_cast<const float4 *>(d + (threadIdx.x + 256 * t) * 8);
+                    u[t][1] = *reinterpret_cast<const float4 *>(d + (threadIdx.x + 256 * t) * 8 + 4);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float4 a = make_float4(__uint_as_float(q[t].x << 16), __uint_as_float(q[t].x & 0xFFFF0000u), __uint_as_float(q[t].y << 16), __uint_as_float(q[t].y & 0xFFFF0000u));
+                float4 c4 = make_float4(__uint_as_float(q[t].z << 16), __uint_as_float(q[t].z & 0xFFFF0000u), __uint_as_float(q[t].w << 16), __uint_as_float(q[t].w & 0xFFFF0000u));
+                if (add) {
+                    a.x += u[t][0].x, a.y += u[t][0].y, a.z += u[t][0].z, a.w += u[t][0].w;
+                    c4.x += u[t][1].x, c4.y += u[t][1].y, c4.z += u[t][1].z, c4.w += u[t][1].w;
+                }
+                *reinterpret_cast<float4 *>(d + (threadIdx.x + 256 * t) * 8) = a;
+                *reinterpret_cast<float4 *>(d + (threadIdx.x + 256 * t) * 8 + 4) = c4;
+            }
+            return;
+        }
         for (int i = threadIdx.x * 8; i < len; i += 256 * 8) {
             if (vec && i + 8 <= len) {
                 const uint4 q = *reinterpret_cast<const uint4 *>(s_ + i);
@@ -275,6 +306,20 @@ __global__ __launch_bounds__(256) void pcm_xfer_batch_kernel(XferBatch b)
     } else {  // fp32 source
         const float *s_ = static_cast<const float *>(b.src[lo]) + e0;
         const bool vec = dvec && (((uintptr_t)s_) & 15) == 0;
+        if (vec && len == kXferChunk) {  // whole aligned chunk: every load in flight before the first store; same sums
+            float4 a[8], u[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) a[t] = *reinterpret_cast<const float4 *>(s_ + (threadIdx.x + 256 * t) * 4);
+            if (add) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) u[t] = *reinterpret_cast<const float4 *>(d + (threadIdx.x + 256 * t) * 4);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) a[t].x += u[t].x, a[t].y += u[t].y, a[t].z += u[t].z, a[t].w += u[t].w;
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) *reinterpret_cast<float4 *>(d + (threadIdx.x + 256 * t) * 4) = a[t];
+            return;
+        }
         for (int i = threadIdx.x * 4; i < len; i += 256 * 4) {
             if (vec && i + 4 <= len) {
                 float4 a = *reinterpret_cast<const float4 *>(s_ + i);

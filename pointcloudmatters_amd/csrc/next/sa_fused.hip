@@ -365,13 +365,12 @@ __global__ __launch_bounds__(64 * kRedWaves) void pcm_sa_reduce_kernel(int nslot
                                                                          float *__restrict__ out)
 {
     __shared__ double red[kRedWaves][64];
+    asm volatile("" ::"s"(gridDim.y), "s"(nslots), "s"(VH), "s"(partial), "s"(out));  // "Kernel heads", pcm_common.hpp
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + lane;
     const int g = blockIdx.y, ng = gridDim.y;  // slot group: slots g, g + ng, ...
     double acc = 0.0;
-    if (e < VH) {
-        for (int s = g + wave * ng; s < nslots; s += kRedWaves * ng) acc += (double)partial[(size_t)s * VH + e];
-    }
+    if (e < VH) acc = pcm_slot_sum(partial, (size_t)VH, e, g + wave * ng, kRedWaves * ng, nslots);
     red[wave][lane] = acc;
     __syncthreads();
     if (wave == 0 && e < VH) {

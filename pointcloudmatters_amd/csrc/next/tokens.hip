@@ -29,10 +29,12 @@ __global__ __launch_bounds__(kBlock) void pcm_add_cast2_kernel(long n4, long pos
                                                                const float *__restrict__ pos, __hip_bfloat16 *__restrict__ sum16,
                                                                __hip_bfloat16 *__restrict__ x16)
 {
+    asm volatile("" ::"s"(gridDim.x), "s"(n4), "s"(pos4), "s"(x), "s"(pos), "s"(sum16), "s"(x16));  // "Kernel heads", pcm_common.hpp
+    const bool small = n4 <= 0xFFFFFFFFl && pos4 <= 0xFFFFFFFFl;  // 32-bit remainder (always, at this model's sizes)
     for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (long)gridDim.x * kBlock) {
         float a[4], p[4], s[4];
         load4<float>(x + i * 4, a);
-        load4<float>(pos + (i % pos4) * 4, p);
+        load4<float>(pos + (small ? (long)((unsigned)i % (unsigned)pos4) : i % pos4) * 4, p);
 #pragma unroll
         for (int u = 0; u < 4; ++u) s[u] = a[u] + p[u];
         store4<__hip_bfloat16>(sum16 + i * 4, s);
@@ -45,21 +47,25 @@ __global__ __launch_bounds__(kBlock) void pcm_add2_cast_kernel(long n4, const __
                                                                float *__restrict__ a32, const float *__restrict__ c32,
                                                                const __hip_bfloat16 *__restrict__ a2)
 {
+    asm volatile("" ::"s"(gridDim.x), "s"(n4), "s"(a), "s"(b), "s"(out), "s"(a32), "s"(c32), "s"(a2));  // "Kernel heads", pcm_common.hpp
     for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (long)gridDim.x * kBlock) {
-        float x[4], y[4], o[4];
+        // all (up to four) loads of the piece are requested before the first sum (the optional addends' `if`s made each wait for its
+        // own load in turn); the sums themselves are the same, in the same order
+        float x[4], y[4], o[4], z[4] = {0.f, 0.f, 0.f, 0.f};
+        uint2 r2 = make_uint2(0u, 0u);  // raw bits: unpacking inside the `if` would wait for the load there
         load4<__hip_bfloat16>(a + i * 4, x);
-        if (a2 != nullptr) {  // the first addend arrives in two parts (dq W_q + dk W_k of a batched product): a := a + a2
-            float x2[4];
-            load4<__hip_bfloat16>(a2 + i * 4, x2);
+        load4<__hip_bfloat16>(b + i * 4, y);
+        if (a2 != nullptr) r2 = *reinterpret_cast<const uint2 *>(a2 + i * 4);  // the first addend arrives in two parts (dq W_q + dk W_k of a batched product)
+        if (c32 != nullptr) load4<float>(c32 + i * 4, z);                     // a third, fp32 addend: the residual branch's gradient of the same tensor
+        if (a2 != nullptr) {
+            const float x2[4] = {__uint_as_float(r2.x << 16), __uint_as_float(r2.x & 0xFFFF0000u), __uint_as_float(r2.y << 16),
+                                 __uint_as_float(r2.y & 0xFFFF0000u)};
 #pragma unroll
             for (int u = 0; u < 4; ++u) x[u] += x2[u];
         }
-        load4<__hip_bfloat16>(b + i * 4, y);
 #pragma unroll
         for (int u = 0; u < 4; ++u) o[u] = x[u] + y[u];
-        if (c32 != nullptr) {  // a third, fp32 addend: the residual branch's gradient of the same tensor
-            float z[4];
-            load4<float>(c32 + i * 4, z);
+        if (c32 != nullptr) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) o[u] += z[u];
         }
@@ -84,13 +90,25 @@ __device__ __forceinline__ void colsum_body(long rows, int C, long rows_per_slot
     const long r0 = (long)slot * rows_per_slot;
     const long r1 = r0 + rows_per_slot < rows ? r0 + rows_per_slot : rows;
     float s[4] = {0.f, 0.f, 0.f, 0.f};
-    if (act)
-        for (long r = r0 + rsub; r < r1; r += rpp) {
+    if (act) {
+        // four rows in flight, added in row order (the one-row loop waited for every load in turn: >= 8 round trips in series per thread)
+        long r = r0 + rsub;
+        for (; r + 3 * rpp < r1; r += 4 * (long)rpp) {
+            float v[4][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) load4<T>(g + (r + q * (long)rpp) * ld + col4 * 4, v[q]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) s[u] += v[q][u];
+        }
+        for (; r < r1; r += rpp) {
             float v[4];
             load4<T>(g + r * ld + col4 * 4, v);
 #pragma unroll
             for (int u = 0; u < 4; ++u) s[u] += v[u];
         }
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) lds[u * kBlock + threadIdx.x] = s[u];
     __syncthreads();
@@ -130,10 +148,9 @@ struct ColsumBatch {
 __global__ __launch_bounds__(kBlock) void pcm_colsum_batch_kernel(ColsumBatch b)
 {
     __shared__ float lds[4 * kBlock];
-    int i = 0;
-    for (int q = 1; q < b.n; ++q)
-        if ((int)blockIdx.x >= b.j[q].blk0) i = q;
+    const int i = pcm_job_of((int)blockIdx.x, b.n, [&](int q) { return b.j[q].blk0; });
     const ColsumJob &J = b.j[i];
+    asm volatile("" ::"s"(J.a.g[0]), "s"(J.a.g[1]), "s"(J.a.g[2]), "s"(J.a.ld[0]), "s"(J.a.ld[1]), "s"(J.a.ld[2]), "s"(J.rows), "s"(J.rps), "s"(J.partial), "s"(J.C), "s"(J.ntensors), "s"(J.is_bf16), "s"(J.blk0));  // one batch: "Kernel heads", pcm_common.hpp
     const int local = (int)blockIdx.x - J.blk0;
     const int slot = local / J.ntensors, t = local - slot * J.ntensors;
     const void *g = t == 0 ? J.a.g[0] : (t == 1 ? J.a.g[1] : J.a.g[2]);
@@ -149,11 +166,11 @@ __global__ __launch_bounds__(512) void pcm_colsum_reduce_kernel(int nslots, int 
                                                                 TO *__restrict__ out)
 {
     __shared__ double red[8][64];
+    asm volatile("" ::"s"(nslots), "s"(VH), "s"(partial), "s"(out));  // "Kernel heads", pcm_common.hpp
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + lane;
     double acc = 0.0;
-    if (e < VH)
-        for (int s = wave; s < nslots; s += 8) acc += (double)partial[(size_t)s * VH + e];
+    if (e < VH) acc = pcm_slot_sum(partial, (size_t)VH, e, wave, 8, nslots);
     red[wave][lane] = acc;
     __syncthreads();
     if (wave == 0 && e < VH) {
@@ -182,17 +199,15 @@ struct ReduceBatch {
 __global__ __launch_bounds__(512) void pcm_reduce_batch_kernel(ReduceBatch b)
 {
     __shared__ double red[8][64];
-    int i = 0;
-    for (int j = 1; j < b.n; ++j)
-        if ((int)blockIdx.x >= b.d[j].blk0) i = j;
+    const int i = pcm_job_of((int)blockIdx.x, b.n, [&](int j) { return b.d[j].blk0; });
     const ReduceDesc &D = b.d[i];
+    asm volatile("" ::"s"(D.partial), "s"(D.out), "s"(D.out16), "s"(D.nslots), "s"(D.VH), "s"(D.from16), "s"(D.blk0));  // one batch: "Kernel heads", pcm_common.hpp
     const float *__restrict__ partial = D.partial;
     const int VH = D.VH, nslots = D.nslots;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e = ((int)blockIdx.x - D.blk0) * 64 + lane;
     double acc = 0.0;
-    if (e < VH)
-        for (int s = wave; s < nslots; s += 8) acc += (double)partial[(size_t)s * VH + e];
+    if (e < VH) acc = pcm_slot_sum(partial, (size_t)VH, e, wave, 8, nslots);
     red[wave][lane] = acc;
     __syncthreads();
     if (wave == 0 && e < VH) {
@@ -521,10 +536,9 @@ struct CopyBatch {
 };
 __global__ __launch_bounds__(256) void pcm_copy_batch_kernel(CopyBatch b)
 {
-    int i = 0;
-    for (int q = 1; q < b.n; ++q)
-        if ((int)blockIdx.x >= b.j[q].blk0) i = q;
+    const int i = pcm_job_of((int)blockIdx.x, b.n, [&](int q) { return b.j[q].blk0; });
     const CopyJob &J = b.j[i];
+    asm volatile("" ::"s"(J.dst), "s"(J.src), "s"(J.nbytes), "s"(J.blk0));  // one batch: "Kernel heads", pcm_common.hpp
     const long off = (long)((int)blockIdx.x - J.blk0) * 4096;
     const long len = J.nbytes - off < 4096 ? J.nbytes - off : 4096;
     char *d = J.dst + off;

@@ -115,6 +115,13 @@ class _BNReLU(Function):
         return dy, sums[1], sums[0], None, None, None, None, None, None
 
 
+def supported_layer(bn, C):
+    """The part of ``supported`` that depends on the MODULE and the channel count alone (what a caller can check before any layer has run)."""
+    return (type(bn) is torch.nn.BatchNorm1d and bn.affine and bn.track_running_stats and bn.weight.dtype == torch.float32
+            and (not bn.training or bn.momentum is not None) and int(C) == bn.num_features
+            and bool(_lib.load().pcm_bn_relu_supported(1, int(C))))
+
+
 def supported(y, bn):
     if y.is_cuda and y.dim() == 2 and y.shape[0] == 0 and type(bn) is torch.nn.BatchNorm1d and bn.training:
         from .sync_bn import wants_sync
@@ -132,6 +139,8 @@ def bn_relu(y, bn, relu=True):
     if bn.training:
         from .sync_bn import wants_sync
 
+        if y.shape[0] == 1 and not wants_sync(bn):  # what torch.nn.functional.batch_norm (and so the reference) raises for one row
+            raise ValueError("Expected more than 1 value per channel when training, got input size %s" % (tuple(y.shape),))
         z = _BNReLU.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, bn if wants_sync(bn) else None, relu)
         from . import fused_ops
 

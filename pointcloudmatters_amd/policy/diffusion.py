@@ -534,45 +534,68 @@ class PCDObsEncoder(_AttrMixin):
         set_abstraction.load_static(self, pre)
 
     def fused_batchnorms(self):
-        """BatchNorm layers owned by fused kernels: the SA layer's, and (round 5) the projector's -- every BatchNorm of this encoder, so
-        that no torch.nn.SyncBatchNorm module is left under data parallelism (`BCTrainer.all_batchnorms_fused`)."""
+        """BatchNorm layers owned by fused kernels: the SA layer's, and the projector's when its row-layout path applies (PROJECTOR_ROWS on
+        and every layer statically eligible, `_projector_plan`) -- then no torch.nn.SyncBatchNorm module is left under data parallelism
+        (`BCTrainer.all_batchnorms_fused`); otherwise the projector's BatchNorms stay with the framework (SyncBatchNorm conversion)."""
         if self.sa_impl != "fused":
             return []
-        return [self.bn] + [m for m in self.projector if isinstance(m, nn.BatchNorm1d)]
+        plan = self._projector_plan() if PROJECTOR_ROWS else None
+        return [self.bn] + ([m for m in self.projector if isinstance(m, nn.BatchNorm1d)] if plan is not None else [])
+
+    def _projector_plan(self):
+        """The projector as a list of row-layout steps -- ("linear", conv) | ("bn", bn, relu) | ("pool",) -- or None when ANY layer does not
+        qualify.  Decided from the modules alone (kernel sizes, widths), BEFORE anything runs: a BatchNorm executed by the row path has
+        updated its running statistics, so finding a non-qualifying layer half way and re-running the module path would update them twice
+        for one batch (round-5 ADVICE)."""
+        from . import bn_relu as fused
+
+        layers, steps, C, pooled, i = list(self.projector), [], None, False, 0
+        while i < len(layers):
+            layer = layers[i]
+            if isinstance(layer, nn.Conv1d):
+                if layer.kernel_size[0] != 1 or layer.stride[0] != 1 or layer.padding[0] != 0 or layer.groups != 1 or (C is not None and layer.in_channels != C):
+                    return None
+                C = layer.out_channels
+                steps.append(("linear", layer))
+            elif isinstance(layer, nn.BatchNorm1d):
+                relu = i + 1 < len(layers) and isinstance(layers[i + 1], nn.ReLU)
+                if C is None or not fused.supported_layer(layer, C):
+                    return None
+                steps.append(("bn", layer, relu))
+                i += 1 if relu else 0
+            elif isinstance(layer, nn.MaxPool1d):
+                if pooled or not (layer.kernel_size == self.pcd_npoints and layer.stride == layer.kernel_size and layer.padding == 0
+                                  and layer.dilation == 1 and not layer.ceil_mode):
+                    return None
+                pooled = True
+                steps.append(("pool",))
+            else:
+                return None
+            i += 1
+        return steps
 
     def _projector_rows(self, x):
         """The projector (pcd_obs_encoder.py:100-120: [Conv1d(k=1) -> BatchNorm1d -> ReLU] x layers -> MaxPool1d(M) -> Conv1d(k=1) ->
         BatchNorm1d) in ROW layout: tokens stay (b * M, C) -- a 1x1 convolution is a per-row product, BatchNorm1d over (b, C, M) is a
         BatchNorm over the b * M rows, the pool a maximum over each cloud's M rows -- so the BatchNorms run in csrc/bnrelu.hip (the last
-        one without its ReLU: pcm_bn_act_*), exchange their statistics themselves when synchronised, and the transposes disappear.
-        Returns (b, C_out), or None when a layer does not qualify (host tensors, eval-mode autograd, odd widths: the module path)."""
+        one without its ReLU: csrc/bnact.hip, pcm_bn_act_*), exchange their statistics themselves when synchronised, and the transposes
+        disappear.  Returns (b, C_out), or None when the input or a layer does not qualify (host tensors, odd widths: the module path) --
+        decided before any layer runs."""
         from . import bn_relu as fused
 
-        layers = list(self.projector)
-        if self.sa_impl != "fused" or not x.is_cuda or x.dim() != 2 or x.shape[0] % self.pcd_npoints:
+        if self.sa_impl != "fused" or not x.is_cuda or x.dim() != 2 or x.shape[0] % self.pcd_npoints or x.shape[0] == 0 \
+                or x.dtype not in (torch.float32, torch.bfloat16):
             return None
-        i = 0
-        while i < len(layers):
-            layer = layers[i]
-            if isinstance(layer, nn.Conv1d):
-                if layer.kernel_size[0] != 1 or layer.stride[0] != 1 or layer.padding[0] != 0:
-                    return None
-                x = linear_rows(x, layer.weight[:, :, 0], layer.bias)
-            elif isinstance(layer, nn.BatchNorm1d):
-                relu = i + 1 < len(layers) and isinstance(layers[i + 1], nn.ReLU)
-                if type(layer) is not nn.BatchNorm1d or not fused.supported(x, layer):
-                    return None
-                x = fused.bn_relu(x, layer, relu=relu)
-                i += 1 if relu else 0
-            elif isinstance(layer, nn.MaxPool1d):
-                if not (layer.kernel_size == self.pcd_npoints and layer.stride == layer.kernel_size and layer.padding == 0
-                        and layer.dilation == 1 and not layer.ceil_mode):
-                    return None
-                # .max(dim): like the pooling kernel the gradient goes to ONE position, the first maximum
+        steps = self._projector_plan()
+        if steps is None or steps[0][0] != "linear" or steps[0][1].in_channels != x.shape[1]:
+            return None
+        for step in steps:
+            if step[0] == "linear":
+                x = linear_rows(x, step[1].weight[:, :, 0], step[1].bias)
+            elif step[0] == "bn":
+                x = fused.bn_relu(x, step[1], relu=step[2])
+            else:  # .max(dim): like the pooling kernel the gradient goes to ONE position, the first maximum
                 x = x.view(-1, self.pcd_npoints, x.shape[-1]).max(dim=1).values
-            else:
-                return None
-            i += 1
         return x
 
     def pcd_sampling(self, pxo, mask=None, return_index=False):

@@ -9,6 +9,22 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "pointcloudmatters_amd", "csrc")
+# Round 6: ten files of csrc/ are FROZEN at the sources of the last build a GPU executed; round 5's ISA rewrites of them live in csrc/next/
+# (`make next` -> lib_next/, csrc/Makefile).  The static properties below describe the REWRITES: they are checked on next/<file> where one
+# exists, on csrc/<file> otherwise (proj_ln.hip).
+NEXT = os.path.join(CSRC, "next")
+
+
+def _rewritten(src):
+    p = os.path.join(NEXT, src)
+    return p if os.path.exists(p) else os.path.join(CSRC, src)
+
+
+def _compile_to_asm(path, out, include_csrc=False):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    r = subprocess.run([hipcc] + _flags() + ["-I", CSRC, "--cuda-device-only", "-S", path, "-o", str(out)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return out.read_text()
 
 
 def _flags():
@@ -27,14 +43,9 @@ def _flags():
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not installed")
-@pytest.mark.parametrize("src", ["fps.hip", "drln.hip"])
+@pytest.mark.parametrize("src", ["fps.hip", "drln.hip", "next/fps.hip", "next/drln.hip", "bnact.hip"])
 def test_no_packed_fp32_instructions_in_device_code(src, tmp_path):
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    out = tmp_path / (src + ".s")
-    r = subprocess.run([hipcc] + _flags() + ["--cuda-device-only", "-S", os.path.join(CSRC, src), "-o", str(out)], capture_output=True, text=True,
-                       timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    asm = out.read_text()
+    asm = _compile_to_asm(os.path.join(CSRC, src), tmp_path / (os.path.basename(src) + ".s"))
     assert "amdgcn" in asm and "gfx950" in asm
     hits = re.findall(r"v_pk_(?:add|mul|fma)_f32", asm)
     assert not hits, "%d packed-fp32 instructions in %s" % (len(hits), src)
@@ -45,7 +56,7 @@ def test_shipped_library_reads_no_environment():
     library neither imports the symbol nor names a switch in its sources outside that helper (round-4 VERDICT, weak 10)."""
     import glob
 
-    for f in glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.hpp")):
+    for f in glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(NEXT, "*.hip")):
         text = open(f).read()
         if f.endswith("pcm_common.hpp"):
             assert text.count("getenv(") == 1 and "#ifdef PCM_MB_SWITCHES" in text
@@ -94,12 +105,7 @@ def test_latency_bound_loops_keep_their_loads_in_flight(src, kernel, least, tmp_
     trip per iteration.  They were rewritten to request several rows first and consume them in the same order; this keeps a refactoring
     (or a compiler update) from quietly serialising them again.  Also: csrc/proj_ln.hip has no scratch (its 768-wide 64-row variant
     spilled and was dropped)."""
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    out = tmp_path / (src + ".s")
-    r = subprocess.run([hipcc] + _flags() + ["--cuda-device-only", "-S", os.path.join(CSRC, src), "-o", str(out)], capture_output=True, text=True,
-                       timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    asm = out.read_text()
+    asm = _compile_to_asm(_rewritten(src), tmp_path / (src + ".s"))
     found = _main_loop_loads(asm, kernel)
     assert found, "kernel %s not found in %s" % (kernel, src)
     for name, loads in found.items():
@@ -140,12 +146,7 @@ def test_kernel_heads_load_their_arguments_in_one_batch(src, kernel, tmp_path):
     """"Kernel heads" (csrc/pcm_common.hpp): the compiler sinks each kernel-argument load to its first use, which gave the row kernels a chain
     of 4-5 dependent scalar round trips (p_drop -> seed pointer -> seed -> R -> the rest) before their first vector load; naming the arguments
     in an empty asm at the entry makes it one batch.  At most ONE wait for scalar loads before the first vector load (the old code: 4-5)."""
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    out = tmp_path / (src + ".s")
-    r = subprocess.run([hipcc] + _flags() + ["--cuda-device-only", "-S", os.path.join(CSRC, src), "-o", str(out)], capture_output=True, text=True,
-                       timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    found = _scalar_waits_before_first_vector_load(out.read_text(), kernel)
+    found = _scalar_waits_before_first_vector_load(_compile_to_asm(_rewritten(src), tmp_path / (src + ".s")), kernel)
     assert found, "kernel %s not found in %s" % (kernel, src)
     for name, waits in found.items():
         assert waits <= 1, "%s: %d dependent scalar round trips before the first vector load" % (name, waits)
@@ -178,11 +179,116 @@ def test_no_load_and_wait_per_element(src, allowed, tmp_path):
     """The masked attention kernels read `mask[key]` inside the 32 short-circuit conditions of a tile (48 x global_load_ubyte + full wait in
     the forward kernel), FPS loaded each of a thread's points with a full wait (8-32 per kernel): round 5 replaced both by one batch of
     loads.  No kernel of these files may have more than a handful of load-then-full-wait sites again."""
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    out = tmp_path / (src + ".s")
-    r = subprocess.run([hipcc] + _flags() + ["--cuda-device-only", "-S", os.path.join(CSRC, src), "-o", str(out)], capture_output=True, text=True,
-                       timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    worst = _load_then_full_wait_sites(out.read_text())
+    worst = _load_then_full_wait_sites(_compile_to_asm(_rewritten(src), tmp_path / (src + ".s")))
     bad = {k: v for k, v in worst.items() if v > allowed}
     assert not bad, bad
+
+
+FROZEN = ("fps", "knn", "drln", "ffn", "attn_small", "attn_flash", "tokens", "optim", "sa_fused", "bnrelu")
+
+
+def _fatbin_md5(obj, tmp):
+    import hashlib
+
+    oc = "/opt/rocm/lib/llvm/bin/llvm-objcopy"
+    subprocess.run([oc, "-O", "binary", "--only-section=.hip_fatbin", obj, str(tmp)], check=True, timeout=60)
+    return hashlib.md5(open(tmp, "rb").read()).hexdigest()
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc") or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objcopy"), reason="ROCm toolchain not installed")
+def test_shipped_device_code_is_the_hardware_tested_build(tmp_path):
+    """The gfx950 code object of EVERY object of the shipped library that existed in round 4 is byte-identical to the build the last
+    hardware suite ran green (profiles/r04_device_digest.txt = md5 of each object's .hip_fatbin at the round-4 tree; 634 GPU tests,
+    profiles/r04_gpu_tests_run*.log).  Rounds 5 and 6 had no GPU: whatever their sessions wrote for those files is in csrc/next/, not in the
+    shipped library.  New objects (no round-4 digest): bnact.o (BatchNorm without ReLU, the Diffusion Policy projector's last layer) and
+    proj_ln.o (opt-in MFMA projection chain).  Compiles each file the way the Makefile does (cwd = csrc/: the code object embeds the source
+    file name) into a scratch directory, so the test does not depend on stale objects in the tree."""
+    want = dict(reversed(l.split()) for l in open(os.path.join(ROOT, "profiles", "r04_device_digest.txt")).read().splitlines() if l.strip())
+    srcs = re.search(r"^SRCS\s*:=\s*(.+)$", open(os.path.join(CSRC, "Makefile")).read(), re.M).group(1).split()
+    assert set(f + ".hip" for f in FROZEN) <= set(srcs)
+    new = sorted(set(s_[:-4] + ".o" for s_ in srcs) - set(want))
+    assert new == ["bnact.o", "proj_ln.o"], new
+    # a scratch copy of csrc/ + include/ with the tree's relative layout, built by the Makefile's own rules (`-c fps.hip -o fps.o`: the code
+    # object's unit id hashes the command line, so the objects must be produced by the same relative command as the recorded build)
+    import glob
+
+    croot = tmp_path / "pointcloudmatters_amd" / "csrc"
+    os.makedirs(croot)
+    os.makedirs(tmp_path / "include")
+    for f in glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.hpp")) + [os.path.join(CSRC, "Makefile")]:
+        shutil.copy(f, croot)
+    for f in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        shutil.copy(f, tmp_path / "include")
+    objs = [s_[:-4] + ".o" for s_ in srcs if s_[:-4] + ".o" in want]
+    r = subprocess.run(["make", "-j8"] + objs, cwd=croot, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    bad = {}
+    for o in objs:
+        got = _fatbin_md5(str(croot / o), tmp_path / "fb.bin")
+        if got != want[o]:
+            bad[o] = (got, want[o])
+    assert not bad, "device code differs from the hardware-tested build: %s" % bad
+
+
+def test_next_variant_covers_exactly_the_frozen_files():
+    """csrc/next/ holds one rewrite per frozen file and nothing else; the Makefile's NEXT_FILES names the same ten."""
+    have = sorted(f[:-4] for f in os.listdir(NEXT) if f.endswith(".hip"))
+    assert have == sorted(FROZEN), have
+    mk = open(os.path.join(CSRC, "Makefile")).read()
+    assert sorted(re.search(r"^NEXT_FILES\s*:=\s*(.+)$", mk, re.M).group(1).split()) == sorted(FROZEN)
+
+
+# lane-select expressions of every __builtin_amdgcn_readlane in the kernel sources, each with the reason it is the same in all active lanes
+# (v_readlane_b32 takes the lane from an SGPR; a divergent index is legalised by the compiler into a serialising loop -- never wrong, but a
+# kernel written for one instruction then pays 64).  The host model aborts on a divergent index at run time (tests/wavesim/wavesim.cpp
+# OP_READLANE); this list makes a NEW call site state its argument before it ships.
+_UNIFORM_READLANE = {
+    "0": "constant", "16": "constant", "32": "constant", "48": "constant", "63": "constant",
+    "K1 - 1": "template constant",
+    "l": "counter of a loop whose bounds are constants / wave-uniform counts (knn.hip merge loops, ball.hip PCM_RL_F)",
+    "i": "ball.hip: heap position, counter of a loop over a readfirstlane'd count",
+    "child": "ball.hip: heap child index computed from wave-uniform values only (x0, xi are readlane results)",
+    "2 * jj": "ffn.hip: counter of the fully unrolled hidden-unit loop",
+    "2 * (j0 + u)": "next/ffn.hip: the same loop in batches of eight",
+    "c": "pcm_common.hpp PcmCloudTable::offset_at / new_offset_at: c comes from cloud_of() (popcount of a ballot) or a block index",
+}
+
+
+def _readlane_indices(text):
+    text = re.sub(r"//.*", "", text)
+    out = []
+    for m in re.finditer(r"__builtin_amdgcn_readlane\(", text):
+        i, depth, cur, args = m.end(), 1, "", []
+        while True:
+            ch = text[i]
+            if ch == "(":
+                depth += 1
+            elif ch == ")":
+                depth -= 1
+                if depth == 0:
+                    break
+            if ch == "," and depth == 1:
+                args.append(cur)
+                cur = ""
+            else:
+                cur += ch
+            i += 1
+        out.append(" ".join((args + [cur])[-1].split()))
+    return out
+
+
+def test_every_readlane_index_is_wave_uniform():
+    import glob
+
+    seen = set()
+    for f in sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(NEXT, "*.hip"))):
+        for idx in _readlane_indices(open(f).read()):
+            assert idx in _UNIFORM_READLANE, "%s: readlane(..., %s): state why the index is wave-uniform (tests/test_build_flags.py)" % (os.path.relpath(f, CSRC), idx)
+            seen.add(idx)
+    assert seen == set(_UNIFORM_READLANE), "stale entries: %s" % (set(_UNIFORM_READLANE) - seen)
+    # PcmCloudTable's lookups: every caller passes the ballot count of cloud_of() or a value derived from block indices only
+    for f in glob.glob(os.path.join(NEXT, "*.hip")) + glob.glob(os.path.join(CSRC, "*.hip")):
+        text = re.sub(r"//.*", "", open(f).read())
+        for m in re.finditer(r"\.(?:new_)?offset_at\(([^()]*(?:\([^()]*\))?[^()]*)\)", text):
+            arg = " ".join(m.group(1).split())
+            assert re.fullmatch(r"(c|bt)( - 1)?", arg), "%s: offset_at(%s)" % (os.path.basename(f), arg)

@@ -9,13 +9,12 @@ The sources are compiled as they are, except for these mechanical rewrites of co
   3. `asm volatile("" ...)` statements -> removed: scheduling fences (ffn.hip) and the "Kernel heads" statements of pcm_common.hpp (empty asm
      that names kernel arguments as register inputs, or makes the dropout seed / a mask byte opaque at its use): they emit no instruction and
      change no value, only where the device compiler places loads and waits
-  4. attn_small.hip: a wave that stores a tile to ITS OWN LDS region and reads it back relies on the hardware executing one wave's LDS
-     operations in order (no barrier, by design).  The model runs lanes one after another, so the hand-off gets an explicit
-     `__builtin_amdgcn_wave_barrier()` behind `tile_store(vr, Vs, lane);`
-  5. knn.hip `pcm_knn_exact_kernel`: the same reliance inside ONE wave -- the 64 lanes initialise the LDS heap and all of them read its
-     root in the next statement; lane 0 sorts the heap and all lanes store it.  On hardware a wave's (volatile) LDS operations execute
-     in program order for all its lanes at once; in the model the two hand-offs get a `__builtin_amdgcn_wave_barrier()` each (behind the
-     initialisation loop and behind lane 0's sort), otherwise the result depends on WAVESIM_ORDER
+  4. knn.hip `pcm_knn_exact_kernel` of the FROZEN file only (csrc/knn.hip, not csrc/next/knn.hip): the 64 lanes initialise the LDS heap and
+     all of them read its root in the next statement.  On hardware a wave's LDS operations execute in program order for all its lanes
+     at once; the model runs lanes one after another and needs a `__builtin_amdgcn_wave_barrier()` behind the initialisation loop.
+     Everywhere else such hand-offs carry that statement IN THE SOURCE (attn_small.hip `tile_store`, the heap sort of this kernel, both
+     places in next/knn.hip): it emits no instruction.  Here it cannot: with it the compiler schedules the kernel differently, and the
+     frozen file's gfx950 code must stay byte-identical to the hardware-tested build (tests/test_build_flags.py).
 Compiler: the ROCm clang++ in host mode (ext_vector_type, __builtin_convertvector on __bf16), -ffp-contract=off like the device build.
 """
 import hashlib
@@ -31,7 +30,12 @@ CSRC = os.path.join(ROOT, "pointcloudmatters_amd", "csrc")
 # directory; the process needs the clang runtime preloaded: asan_runtime()).  Device-side sanitizers cannot run on this pool (no xnack);
 # on the model an access one element outside a global buffer, an LDS array or the dynamic LDS block aborts the test.
 SANITIZE = os.environ.get("WAVESIM_SANITIZE") == "1"
-OUT = os.path.join(HERE, "_build", "asan") if SANITIZE else os.path.join(HERE, "_build")
+# WAVESIM_VARIANT=next: the ten files of csrc/ that are frozen at the last hardware-tested sources are taken from csrc/next/ instead (round 5's
+# ISA rewrites, `make next`; csrc/Makefile) -- the same curated tests then run against the rewrites.  Default: what ships.
+VARIANT = os.environ.get("WAVESIM_VARIANT", "")
+assert VARIANT in ("", "next"), VARIANT
+NEXT_FILES = ("fps", "knn", "drln", "ffn", "attn_small", "attn_flash", "tokens", "optim", "sa_fused", "bnrelu")
+OUT = os.path.join(HERE, "_build", *([VARIANT] if VARIANT else []), *(["asan"] if SANITIZE else []))
 LIB = os.path.join(OUT, "libpcm_wavesim.so")
 SAN_FLAGS = ["-fsanitize=address,undefined", "-fno-sanitize=vptr,function,alignment", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer",
              "-shared-libsan"] if SANITIZE else []
@@ -47,7 +51,13 @@ CLANG = os.environ.get("WAVESIM_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 # every kernel file of the library except graph_fix.hip (hipGraph surgery: runtime API, no kernel logic)
 SOURCES = ["fps.hip", "knn.hip", "ball.hip", "group.hip", "misc_ops.hip", "segsum.hip", "voxel.hip", "sa_scatter.hip", "sa_fused.hip",
            "bnrelu.hip", "drln.hip", "tokens.hip", "gnmish.hip", "ddpm.hip", "optim.hip", "ffn.hip", "ffn_mfma.hip", "attn_small.hip",
-           "attn_flash.hip", "proj_ln.hip"]
+           "attn_flash.hip", "proj_ln.hip"] + ([] if VARIANT == "next" else ["bnact.hip"])  # next/bnrelu.hip exports the pcm_bn_act_* entry points itself
+
+
+def source_path(name):
+    if VARIANT == "next" and name[:-4] in NEXT_FILES:
+        return os.path.join(CSRC, "next", name)
+    return os.path.join(CSRC, name)
 FLAGS = ["-x", "c++", "-std=c++17", "-O1", "-g0" if not SANITIZE else "-g1", "-ffp-contract=off", "-fPIC", "-fno-strict-aliasing", "-Wno-everything",
          "-I", os.path.join(HERE, "include"), "-I", CSRC] + SAN_FLAGS
 
@@ -61,14 +71,10 @@ def rewrite(name, text):
     if name == "fps.hip":
         text, n = _FPS_ASM.subn(r"\1\n    return pcm_wave_max_u32(v);  // tests/wavesim/build.py, rewrite 2\n}\n", text)
         assert n == 1, "fps_wave_max_fast not found"
-    if name == "attn_small.hip":
-        text, n = re.subn(r"(tile_store\(vr, Vs, lane\);)", r"\1 __builtin_amdgcn_wave_barrier();  /* tests/wavesim/build.py, rewrite 4 */", text)
-        assert n == 2, n
-    if name == "knn.hip":
-        wb = " __builtin_amdgcn_wave_barrier();  /* tests/wavesim/build.py, rewrite 5 */"
+    if name == "knn.hip" and VARIANT != "next":
+        wb = " __builtin_amdgcn_wave_barrier();  /* tests/wavesim/build.py, rewrite 4 */"
         text, n1 = re.subn(r"(for \(int i = lane; i < nsample; i \+= 64\) bd\[i\] = 1e10f, bi\[i\] = -1;)", r"\1" + wb, text)
-        text, n2 = re.subn(r"(reheap\(i\);\n            \}\n        \})", r"\1" + wb, text)
-        assert (n1, n2) == (1, 1), (n1, n2)
+        assert n1 == 1, n1
     text = _FENCE.sub("/* scheduling fence removed (tests/wavesim/build.py, rewrite 3) */;", text)
     assert "asm" not in re.sub(r"//.*", "", text).replace("assume", ""), f"{name}: inline assembly left after the rewrites"
     return text
@@ -88,11 +94,11 @@ def _build(verbose, sources):
     if not os.path.exists(CLANG):
         raise RuntimeError(f"{CLANG} not found (set WAVESIM_CXX)")
     objs, jobs = [], []
-    deps = [os.path.join(HERE, f) for f in ("wavesim.hpp", "include/hip/hip_runtime.h", "include/hip/hip_bf16.h", "build.py")] + \
+    deps = [os.path.join(HERE, f) for f in ("wavesim.hpp", "wavesim.cpp", "include/hip/hip_runtime.h", "include/hip/hip_bf16.h", "build.py")] + \
            [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")] + [os.path.join(ROOT, "include", "pcm_pointops.h")]
     stamp = hashlib.sha1(b"".join(open(d, "rb").read() for d in sorted(deps)) + (b"asan" if SANITIZE else b"")).hexdigest()[:12]
     for name in (sources or SOURCES):
-        src = rewrite(name, open(os.path.join(CSRC, name)).read())
+        src = rewrite(name, open(source_path(name)).read())
         key = hashlib.sha1((stamp + src).encode()).hexdigest()[:16]
         cpp, obj = os.path.join(OUT, name.replace(".hip", ".sim.cpp")), os.path.join(OUT, name.replace(".hip", f".{key}.o"))
         objs.append(obj)

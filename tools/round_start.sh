@@ -1,17 +1,17 @@
 #!/bin/bash
 # Run ON THE GPU BOX as the FIRST gpurun call of a round:   gpurun --timeout 3000 -- 'bash tools/round_start.sh r06'
-# Rounds 4 and 5 ended with the GPU pool closed from outside the build: round 5 rewrote the device code of nine files without a hardware run.
-# This call is therefore a BISECTABLE first contact (round-5 VERDICT item 1): every leg runs on HEAD's library and on
-# pointcloudmatters_amd/lib_base/ (`make -C pointcloudmatters_amd/csrc base`: HEAD with those nine files taken from the round-4 tree).
-#   1  full -m gpu suite at HEAD (no -x: every failure is wanted)     -> gpurun_out/<tag>/gpu_tests.log
-#   2  the pointops / kernel tiers against lib_base                   -> gpurun_out/<tag>/gpu_tests_base.log
-#   3  bench line (library products forced), HEAD and lib_base        -> gpurun_out/<tag>/bench.json, bench_base.json
+# Rounds 4 - 6 had the GPU pool closed from outside the build; round 5 rewrote the device code of ten files without a hardware run.
+# The shipped library (lib/) carries the round-4 device code of those files (byte-identical to the last hardware-tested build,
+# tests/test_build_flags.py); the rewrites build into lib_next/ (`make -C pointcloudmatters_amd/csrc next`).  Every leg runs on both:
+#   1  full -m gpu suite on the shipped library (no -x: every failure is wanted) -> gpurun_out/<tag>/gpu_tests.log
+#   2  the rewritten files' test tiers against lib_next               -> gpurun_out/<tag>/gpu_tests_next.log
+#   3  bench line (library products), shipped and lib_next            -> gpurun_out/<tag>/bench.json, bench_next.json
 #   4  smoke()                                                        -> gpurun_out/<tag>/smoke.log
 #   5  the MFMA projection chain forced on / the bf16 tokenizer       -> bench_mfma_*.json, bench_tokenizer_bf16.json
-#   6  rocprofv3 --kernel-trace --stats of the bench step, both libs  -> gpurun_out/profiles_raw/<tag>/{bench,bench_base}
+#   6  rocprofv3 --kernel-trace --stats of the bench step, both libs  -> gpurun_out/profiles_raw/<tag>/{bench,bench_next}
 TAG=${1:-r06}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
-BASE=$GRAFT_REPO_ROOT/pointcloudmatters_amd/lib_base/libpcm_pointops.so
+BASE=$GRAFT_REPO_ROOT/pointcloudmatters_amd/lib_next/libpcm_pointops.so
 mkdir -p "$OUT"
 cd "$GRAFT_REPO_ROOT" || exit 1
 rocminfo 2>/dev/null | grep -m3 -E "Marketing Name|gfx9" > "$OUT/box.txt"; nproc >> "$OUT/box.txt"
@@ -20,16 +20,16 @@ echo "suite rc=$?" | tee -a "$OUT/gpu_tests.log"
 tail -3 "$OUT/gpu_tests.log"
 if [ -f "$BASE" ]; then
   PCM_POINTOPS_LIB=$BASE timeout 900 python -m pytest tests/test_pointops_gpu.py tests/test_pointops_fuzz_gpu.py tests/test_drln_gpu.py \
-      tests/test_small_attn_gpu.py tests/test_flash_attn_gpu.py tests/test_tokens_gpu.py tests/test_xfer_gpu.py tests/test_sa_fused_gpu.py \
-      -m gpu -q -p no:cacheprovider > "$OUT/gpu_tests_base.log" 2>&1
-  echo "suite (lib_base, rewritten files' tests) rc=$?" | tee -a "$OUT/gpu_tests_base.log"; tail -2 "$OUT/gpu_tests_base.log"
+      tests/test_small_attn_gpu.py tests/test_flash_attn_gpu.py tests/test_tokens_gpu.py tests/test_xfer_gpu.py tests/test_sa_fused_gpu.py tests/test_bn_relu_gpu.py \
+      -m gpu -q -p no:cacheprovider > "$OUT/gpu_tests_next.log" 2>&1
+  echo "suite (lib_next, rewritten files' tests) rc=$?" | tee -a "$OUT/gpu_tests_next.log"; tail -2 "$OUT/gpu_tests_next.log"
 fi
-timeout 900 python bench.py --no-chain-selection --tables-out "$OUT/bench_tables.json" > "$OUT/bench.json" 2> "$OUT/bench.err"
+timeout 900 python bench.py --tables-out "$OUT/bench_tables.json" > "$OUT/bench.json" 2> "$OUT/bench.err"
 echo "bench rc=$?"
 cut -c1-400 "$OUT/bench.json"
 if [ -f "$BASE" ]; then
-  PCM_POINTOPS_LIB=$BASE timeout 600 python bench.py --no-chain-selection --no-cpu-baseline --no-extra --tables-out "$OUT/bench_tables_base.json" > "$OUT/bench_base.json" 2> "$OUT/bench_base.err"
-  echo "bench (lib_base) rc=$?"; cut -c1-300 "$OUT/bench_base.json"
+  PCM_POINTOPS_LIB=$BASE timeout 600 python bench.py --no-cpu-baseline --no-extra --tables-out "$OUT/bench_tables_next.json" > "$OUT/bench_next.json" 2> "$OUT/bench_next.err"
+  echo "bench (lib_next) rc=$?"; cut -c1-300 "$OUT/bench_next.json"
 fi
 timeout 300 python __graft_entry__.py smoke > "$OUT/smoke.log" 2>&1
 echo "smoke rc=$?"; tail -1 "$OUT/smoke.log"
@@ -42,18 +42,18 @@ PCM_PROJ_MFMA=1 PCM_LINEAR_MFMA=1 PCM_PROJ_MFMA_LONG=1 timeout 600 python bench.
 echo "bench (mfma chain, short + long sites) rc=$?"; cut -c1-200 "$OUT/bench_mfma_long.json"
 PCM_PROJ_MFMA=0 PCM_LINEAR_MFMA=0 timeout 600 python bench.py --no-cpu-baseline --no-roofline --no-extra --emit-warmup-losses > "$OUT/bench_lib_losses.json" 2> "$OUT/bench_lib_losses.err"
 echo "bench (library products, with warm-up losses) rc=$?"; cut -c1-200 "$OUT/bench_lib_losses.json"
-timeout 600 python bench.py --no-chain-selection --tokenizer-bf16 --no-cpu-baseline --no-roofline --no-extra > "$OUT/bench_tokenizer_bf16.json" 2> "$OUT/bench_tokenizer_bf16.err"
+timeout 600 python bench.py --tokenizer-bf16 --no-cpu-baseline --no-roofline --no-extra > "$OUT/bench_tokenizer_bf16.json" 2> "$OUT/bench_tokenizer_bf16.err"
 echo "bench (tokenizer bf16, the round-4 recipe) rc=$?"; cut -c1-200 "$OUT/bench_tokenizer_bf16.json"
 cp -f "$GRAFT_REPO_ROOT/gpurun_out/pk_hazard.log" "$OUT/pk_hazard.log" 2>/dev/null  # written by tests/test_pk_hazard_gpu.py: copy to profiles/rNN_pk_hazard.log
 # the rocprofv3 kernel trace of the bench step on both builds: the per-kernel old-vs-new table of profiles/rNN_summary.md
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "gpurun_out/profiles_raw/$TAG/bench" -o bench -- \
-    python bench.py --no-chain-selection --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-extra > "$OUT/rocprof_bench.log" 2>&1
+    python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-extra > "$OUT/rocprof_bench.log" 2>&1
 echo "rocprofv3 bench rc=$?"; ls gpurun_out/profiles_raw/$TAG/bench 2>/dev/null | head -5
 if [ -f "$BASE" ]; then
-  PCM_POINTOPS_LIB=$BASE timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "gpurun_out/profiles_raw/$TAG/bench_base" -o bench -- \
-      python bench.py --no-chain-selection --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-extra > "$OUT/rocprof_bench_base.log" 2>&1
-  echo "rocprofv3 bench (lib_base) rc=$?"
+  PCM_POINTOPS_LIB=$BASE timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "gpurun_out/profiles_raw/$TAG/bench_next" -o bench -- \
+      python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-extra > "$OUT/rocprof_bench_next.log" 2>&1
+  echo "rocprofv3 bench (lib_next) rc=$?"
 fi
 # keep the merged-back size small: only the stats / kernel-trace summaries travel (the 64 MiB limit)
 find gpurun_out/profiles_raw/$TAG -name "*kernel_trace.csv" -size +20M -delete 2>/dev/null
