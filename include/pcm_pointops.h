@@ -367,6 +367,19 @@ int pcm_proj_drln_mfma_forward_hip(long R, int E, int K, const void *a_bf16, lon
                                    const long *seed, unsigned site, float *s, float *out, float *mean, float *rstd, const float *pos,
                                    long pos_n, void *sum_bf16, void *out_bf16, void *stream);
 
+/* The BACKWARD of that chain for the short sites as ONE kernel (csrc/proj_ln.hip, round 6; opt-in, PCM_PROJ_MFMA_BWD): pcm_drln_backward2_hip's
+ * row code -- dx, dy (bf16), the partial rows of dgamma | dbeta | column sums of dy: same arguments, same bits per row -- AND the input
+ * gradient of the projection, da (R, K) bf16 with row stride da_ls = dy W, W (E, K) bf16 row-major (what autograd computes as
+ * `grad_output @ weight` for nn.Linear, transformer.py:244-256, 296-346).  partial: pcm_proj_drln_mfma_backward_blocks(R) rows of 3 E
+ * floats; dgamma_dbeta (3, E) fp32 nullable (NULL: the rows are left for pcm_reduce_batch_hip), dysum_bf16 (E) nullable.
+ * E in {256, 512, 768, 1024}, K in {256, 512, 1024}; 16-byte aligned W and da, da_ls a multiple of 8. */
+int pcm_proj_drln_mfma_backward_supported(int E, int K);
+int pcm_proj_drln_mfma_backward_blocks(long R);
+int pcm_proj_drln_mfma_backward_hip(long R, int E, int K, const float *dout, const float *dout2, const float *s, const float *mean,
+                                    const float *rstd, const float *gamma, float p_drop, const long *seed, unsigned site,
+                                    const void *w_bf16, float *dx, void *dy_bf16, void *da_bf16, long da_ls, float *partial,
+                                    float *dgamma_dbeta, void *dysum_bf16, void *stream);
+
 /* out = A W^T + bias for short activations on the matrix cores, operand preparation fused in (csrc/proj_ln.hip): the in-projections of
  * nn.MultiheadAttention and the cross-attention query projection (transformer.py:244-262, 296-346: `q = k = with_pos_embed(x, pos)`).
  * A: a_is_f32 == 0: bf16 (R, K), row stride a_ls elements, for the output columns [0, pos_cols), and a_alt_bf16 (nullable, same layout)

@@ -75,6 +75,11 @@ SIGNATURES = {
     # R, E, K, a, a_ls, W, bias, bias_is_bf16, x, gamma, beta, eps, p, seed, site, s, out, mean, rstd, pos, pos_n, sum16, out16, stream
     "pcm_proj_drln_mfma_forward_hip": [ctypes.c_long, _i, _i, _P, ctypes.c_long, _P, _P, _i, _P, _P, _P, _f, _f, _P, ctypes.c_uint, _P, _P,
                                        _P, _P, _P, ctypes.c_long, _P, _P, _P],
+    "pcm_proj_drln_mfma_backward_supported": [_i, _i],
+    "pcm_proj_drln_mfma_backward_blocks": [ctypes.c_long],
+    # R, E, K, dout, dout2, s, mean, rstd, gamma, p, seed, site, W, dx, dy, da, da_ls, partial, dgamma_dbeta, dysum_bf16, stream
+    "pcm_proj_drln_mfma_backward_hip": [ctypes.c_long, _i, _i, _P, _P, _P, _P, _P, _P, _f, _P, ctypes.c_uint, _P, _P, _P, _P, ctypes.c_long, _P,
+                                        _P, _P, _P],
     "pcm_linear_mfma_supported": [_i, _i, _i],
     # R, N, K, a, a_is_f32, a_ls, a_alt, pos, pos_n, pos_cols, W, bias, bias_is_bf16, out, out_is_bf16, out_ls, emit_pos16, emit_x16, stream
     "pcm_linear_mfma_forward_hip": [ctypes.c_long, _i, _i, _P, _i, ctypes.c_long, _P, _P, ctypes.c_long, _i, _P, _P, _i, _P, _i, ctypes.c_long,

@@ -616,3 +616,223 @@ extern "C" int pcm_linear_mfma_forward_hip(long R, int N, int K, const void *a, 
     PCM_LIN(false, 1);
 #undef PCM_LIN
 }
+
+// ================================================================================================================================
+// pcm_proj_drln_mfma_backward: the BACKWARD of the chain above for the short sites -- csrc/drln.hip's backward row code and the input
+// gradient of the projection,  da = dy W,  as ONE kernel (round 6; built while the GPU pool was closed: verified on the host wave64
+// model only, opt-in through PCM_PROJ_MFMA_BWD, never timed).  The library served `dy @ W` as an 800 x 512 x 512 product at the launch
+// floor behind pcm_drln_bwd (which had just written dy): one launch and one round trip of dy less per site.
+//
+//  * one workgroup = 16 rows, K / 128 waves (K = 256 / 512 / 1024: 2 / 4 / 8 waves).  Row phase: wave w finishes rows w, w + NW, ... of
+//    the tile exactly like pcm_drln_bwd_kernel (same per-row arithmetic in the same order: dx and dy are bit-identical to it), stores
+//    dx (fp32) and dy (bf16, the weight-gradient product still needs it) and leaves the bf16 dy row in an LDS panel [16][E + 8];
+//    dgamma / dbeta / column sums of dy: per-workgroup partial rows [block][3][E], closed by pcm_reduce_batch_hip like the row kernel's.
+//  * product phase: da (16 x K) = dy (16 x E) W (E x K): the reduction runs over W's ROWS, so the 16x16x32 B operand -- 8 consecutive e of
+//    one output column -- is strided in memory.  No transposed mirror and no LDS staging of W: lane (li, lg) loads the 8 x 8 block
+//    W[32 kt + 8 lg .. + 7][n0 + 8 li .. + 7] as eight 16-byte row pieces (a wave instruction covers 4 rows x 256 contiguous bytes)
+//    and transposes it IN ITS OWN REGISTERS (two operations per operand dword): column j of the block is the B operand of the lane for
+//    output column n0 + 8 li + j.  The eight column tiles of a wave are therefore the INTERLEAVED sets { n0 + 8 li + j : li = 0..15 },
+//    j = 0..7 -- which makes a lane's accumulators for one row eight CONSECUTIVE output columns: da leaves the registers as one 16-byte
+//    store per row, no LDS tile for the output.
+//  * the first two k-steps' weight blocks are requested at the kernel's entry, under the row phase.
+// Algorithmic bytes per row: 8 E read (dout, s) [+ 4 E (dout2)] + 4 E (dx) + 2 E (dy) + 2 K (da); the weight E K 2 once per 16 rows from L2.
+// ================================================================================================================================
+namespace {
+
+constexpr int kBW = 128;  // output columns per wave (16 lanes x 8 columns)
+
+template <int NCH>  // E = 256 NCH
+__global__ __launch_bounds__(512) void pcm_proj_drln_bwd_kernel(long R, int K, const float *__restrict__ dout, const float *__restrict__ dout2,
+                                                                const float *__restrict__ s, const float *__restrict__ mean,
+                                                                const float *__restrict__ rstd, const float *__restrict__ gamma, float p_drop,
+                                                                const long *__restrict__ seed_ptr, unsigned site, const u16 *__restrict__ W,
+                                                                float *__restrict__ dx, __hip_bfloat16 *__restrict__ dy, u16 *__restrict__ da,
+                                                                long da_ls, float *__restrict__ partial)
+{
+    constexpr int E = NCH * 256;
+    constexpr int AS = E + kAPad;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+    u16 *As = reinterpret_cast<u16 *>(smem3);                                  // [16][AS] bf16: the dy panel
+    float *red = reinterpret_cast<float *>(smem3 + (size_t)kTM * AS * 2);      // [NW][3][E]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, NW = blockDim.x >> 6;
+    const long r0 = (long)blockIdx.x * kTM;
+    const int n0 = w * kBW, li = lane & 15, lg = lane >> 4;
+
+    // ---- the weight blocks of the first two k-steps: in flight under the whole row phase
+    const u16 *wp = W + (long)(8 * lg) * K + n0 + 8 * li;
+    constexpr int ksteps = E / 32;
+    uint4 wq[2][8];
+    auto fetch = [&](uint4(&dst)[8], int kt) {
+        const int kk = kt < ksteps ? kt : ksteps - 1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dst[j] = *reinterpret_cast<const uint4 *>(wp + (long)(32 * kk + j) * K);
+    };
+    fetch(wq[0], 0);
+    fetch(wq[1], 1);
+
+    // ---- rows (csrc/drln.hip pcm_drln_bwd_kernel, row for row)
+    const bool drop = p_drop > 0.f;
+    const uint64_t seed = drop ? (uint64_t)seed_ptr[0] : 0ull;
+    const uint32_t thr = drop ? (uint32_t)((double)p_drop * 4294967296.0) : 0u;
+    const float scale = drop ? 1.f / (1.f - p_drop) : 1.f;
+    float g[NCH][4], dg[NCH][4], db[NCH][4], dys[NCH][4];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        load4<float>(gamma + c * 256 + lane * 4, g[c]);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) dg[c][v] = 0.f, db[c][v] = 0.f, dys[c][v] = 0.f;
+    }
+    for (int i = w; i < kTM; i += NW) {
+        const long r = r0 + i;
+        if (r >= R) {  // wave-uniform: a row past the end contributes a zero dy row to the product and nothing else
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) *reinterpret_cast<uint2 *>(As + i * AS + c * 256 + lane * 4) = make_uint2(0u, 0u);
+            continue;
+        }
+        const float mu = mean[r], rs = rstd[r];
+        float gd[NCH][4], xh[NCH][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const long e0 = r * E + c * 256 + lane * 4;
+            float dv[4], sv[4];
+            load4<float>(dout + e0, dv);
+            if (dout2 != nullptr) {
+                float d2[4];
+                load4<float>(dout2 + e0, d2);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) dv[v] += d2[v];
+            }
+            load4<float>(s + e0, sv);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                xh[c][v] = (sv[v] - mu) * rs;
+                gd[c][v] = dv[v] * g[c][v];
+                s1 += gd[c][v];
+                s2 += gd[c][v] * xh[c][v];
+                dg[c][v] += dv[v] * xh[c][v];
+                db[c][v] += dv[v];
+            }
+        }
+        const float m1 = wave_sum(s1) * (1.f / E), m2 = wave_sum(s2) * (1.f / E);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const long e0 = r * E + c * 256 + lane * 4;
+            float o[4], oy[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                o[v] = rs * (gd[c][v] - m1 - xh[c][v] * m2);
+                oy[v] = (keep_elem(seed, site, (uint64_t)(e0 + v), thr)) ? o[v] * scale : 0.f;
+                dys[c][v] += oy[v];
+            }
+            store4<float>(dx + e0, o);
+            store4<__hip_bfloat16>(dy + e0, oy);
+            store4<__hip_bfloat16>(reinterpret_cast<__hip_bfloat16 *>(As + i * AS + c * 256 + lane * 4), oy);  // the product's A panel
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            red[(w * 3 + 0) * E + c * 256 + lane * 4 + v] = dg[c][v];
+            red[(w * 3 + 1) * E + c * 256 + lane * 4 + v] = db[c][v];
+            red[(w * 3 + 2) * E + c * 256 + lane * 4 + v] = dys[c][v];
+        }
+    __syncthreads();  // dy panel and the waves' column sums complete
+    for (int e = tid; e < 3 * E; e += blockDim.x) {
+        float acc = 0.f;
+        for (int ww = 0; ww < NW; ++ww) acc += red[ww * 3 * E + e];
+        partial[(size_t)blockIdx.x * 3 * E + e] = acc;
+    }
+
+    // ---- da tile = dy panel x W: column tile j of this wave = output columns n0 + 8 li + j (interleaved, see above)
+    f4v acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = f4v{0.f, 0.f, 0.f, 0.f};
+    auto multiply = [&](const uint4(&q)[8], int kt) {
+        const bf8 af = lds_bf8(As + li * AS + 32 * kt + 8 * lg);
+        const uint32_t(&u)[8][4] = reinterpret_cast<const uint32_t(&)[8][4]>(q);  // u[row e][dword]: dword d holds columns 2 d, 2 d + 1
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint4 b;
+            uint32_t *bd = reinterpret_cast<uint32_t *>(&b);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {  // operand dword d = (W[e 2 d][col j], W[e 2 d + 1][col j])
+                const uint32_t lo = u[2 * d][j >> 1], hi = u[2 * d + 1][j >> 1];
+                bd[d] = (j & 1) ? ((lo >> 16) | (hi & 0xFFFF0000u)) : ((lo & 0xFFFFu) | (hi << 16));
+            }
+            acc[j] = PCM_MFMA_16x16x32(af, as_bf8(b), acc[j]);
+        }
+    };
+    for (int kt = 0; kt < ksteps; kt += 2) {  // E / 32 is even
+        multiply(wq[0], kt);
+        fetch(wq[0], kt + 2);
+        multiply(wq[1], kt + 1);
+        fetch(wq[1], kt + 3);
+    }
+    // accumulator register r of `lane`: row 4 lg + r, column n0 + 8 li + j for j = 0..7: one 16-byte store per row
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const long row = r0 + 4 * lg + r;
+        if (row < R) {
+            const uint4 o = make_uint4(pcm_cvt_pk_bf16(acc[0][r], acc[1][r]), pcm_cvt_pk_bf16(acc[2][r], acc[3][r]),
+                                       pcm_cvt_pk_bf16(acc[4][r], acc[5][r]), pcm_cvt_pk_bf16(acc[6][r], acc[7][r]));
+            *reinterpret_cast<uint4 *>(da + row * da_ls + n0 + 8 * li) = o;
+        }
+    }
+}
+
+inline size_t proj_bwd_smem_bytes(int E, int K)
+{
+    return (size_t)kTM * (E + kAPad) * 2 + (size_t)(K / kBW) * 3 * E * sizeof(float);
+}
+
+}  // namespace
+
+// E in {256, 512, 768, 1024} (the row code's float4 chunks); K in {256, 512, 1024} (a wave = 128 output columns, 2 / 4 / 8 waves)
+extern "C" int pcm_proj_drln_mfma_backward_supported(int E, int K)
+{
+    return (E == 256 || E == 512 || E == 768 || E == 1024) && (K == 256 || K == 512 || K == 1024);
+}
+
+extern "C" int pcm_proj_drln_mfma_backward_blocks(long R) { return R <= 0 ? 0 : (int)((R + kTM - 1) / kTM); }
+
+extern "C" int pcm_proj_drln_mfma_backward_hip(long R, int E, int K, const float *dout, const float *dout2, const float *s, const float *mean,
+                                               const float *rstd, const float *gamma, float p_drop, const long *seed, unsigned site,
+                                               const void *w_bf16, float *dx, void *dy_bf16, void *da_bf16, long da_ls, float *partial,
+                                               float *dgamma_dbeta, void *dysum_bf16, void *stream)
+{
+    if (R < 0 || E <= 0 || K <= 0 || da_ls < K || !(p_drop >= 0.f && p_drop < 1.f)) return PCM_ERR_BAD_ARG;
+    if (!pcm_proj_drln_mfma_backward_supported(E, K)) return PCM_ERR_UNSUPPORTED;
+    if (R == 0) return PCM_OK;
+    if (!dout || !s || !mean || !rstd || !gamma || !w_bf16 || !dx || !dy_bf16 || !da_bf16 || !partial || (p_drop > 0.f && !seed)) return PCM_ERR_BAD_ARG;
+    if ((da_ls % 8) != 0 || (((uintptr_t)w_bf16 | (uintptr_t)da_bf16) % 16) != 0) return PCM_ERR_BAD_ARG;  // 16-byte loads / stores
+    if (R > 0x7FFFFFFFL * kTM) return PCM_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = pcm_proj_drln_mfma_backward_blocks(R);
+    const size_t smem = proj_bwd_smem_bytes(E, K);
+#define PCM_PB(NCH)                                                                                                                    \
+    do {                                                                                                                               \
+        if (smem > 64 * 1024) {                                                                                                        \
+            const int rc_ = pcm_status(hipFuncSetAttribute(reinterpret_cast<const void *>(pcm_proj_drln_bwd_kernel<NCH>),              \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));                    \
+            if (rc_) return rc_;                                                                                                       \
+        }                                                                                                                              \
+        hipLaunchKernelGGL(pcm_proj_drln_bwd_kernel<NCH>, dim3((unsigned)blocks), dim3(64 * (K / kBW)), smem, st, R, K, dout, dout2, s,   \
+                           mean, rstd, gamma, p_drop, seed, site, (const u16 *)w_bf16, dx, (__hip_bfloat16 *)dy_bf16, (u16 *)da_bf16,  \
+                           da_ls, partial);                                                                                           \
+    } while (0)
+    switch (E / 256) {
+    case 1: PCM_PB(1); break;
+    case 2: PCM_PB(2); break;
+    case 3: PCM_PB(3); break;
+    default: PCM_PB(4); break;
+    }
+#undef PCM_PB
+    int rc = PCM_LAUNCH_STATUS();
+    if (rc || dgamma_dbeta == nullptr) return rc;  // partial rows only: closed later by pcm_reduce_batch_hip (policy/deferred.py)
+    const void *parts[1] = {partial};
+    const int nslots[1] = {blocks}, width[1] = {3 * E}, from[1] = {2 * E};
+    void *o32[1] = {dgamma_dbeta}, *o16[1] = {dysum_bf16};
+    return pcm_reduce_batch_hip(1, parts, nslots, width, o32, o16, from, stream);
+}

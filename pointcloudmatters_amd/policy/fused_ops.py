@@ -204,6 +204,11 @@ PROJ_MFMA_LONG = os.environ.get("PCM_PROJ_MFMA_LONG", "0") != "0"
 PROJ_MFMA_LONG_ROWS = 2048  # csrc/proj_ln.hip kLongRows
 
 
+# the BACKWARD of the chain at the short sites (round 6: csrc/proj_ln.hip pcm_proj_drln_mfma_backward = pcm_drln_bwd's row code + da = dy W in one
+# launch; host-model-verified, never timed: opt-in like the forward)
+PROJ_MFMA_BWD = os.environ.get("PCM_PROJ_MFMA_BWD", "0") != "0"
+
+
 LINEAR_MFMA = os.environ.get("PCM_LINEAR_MFMA", "0") != "0"  # csrc/proj_ln.hip pcm_linear_mfma: same status as PROJ_MFMA (opt-in, untimed)
 
 
@@ -361,6 +366,43 @@ def _drln_backward(dout, s, mean, rstd, gamma, ydtype, p_drop, seed, site, dysum
     return dx, dy, sums
 
 
+def _proj_bwd_mfma_ok(s, wc, ydt, adt):
+    R, E = s.shape
+    return (PROJ_MFMA_BWD and s.is_cuda and 0 < R <= PROJ_MFMA_MAX_ROWS and ydt == torch.bfloat16 and adt == torch.bfloat16
+            and wc.dtype == torch.bfloat16 and wc.is_contiguous() and wc.shape[0] == E and wc.data_ptr() % 16 == 0
+            and bool(_lib.load().pcm_proj_drln_mfma_backward_supported(int(E), int(wc.shape[1]))))
+
+
+def _proj_drln_backward_mfma(dout, s, mean, rstd, gamma, wc, p_drop, seed, site, dysum_bf16=False, defer=False, dout2=None):
+    """`_drln_backward` and the projection's input gradient from ONE launch (csrc/proj_ln.hip):
+    -> dx (R,E) fp32, dy (R,E) bf16, sums (3,E) fp32 [, column sums of dy in bf16], da (R,K) bf16 = dy @ wc."""
+    L = _lib.load()
+    R, E = s.shape
+    K = int(wc.shape[1])
+    dev = s.device
+    d2 = dout.reshape(R, E)
+    if d2.dtype != torch.float32 or not d2.is_contiguous():
+        d2 = d2.float().contiguous()
+    with torch.cuda.device(dev):
+        dx = torch.empty_like(s)
+        dy = deferred.take((R, E), torch.bfloat16, dev, "drln.dy")
+        da = torch.empty((R, K), dtype=torch.bfloat16, device=dev)
+        blocks = L.pcm_proj_drln_mfma_backward_blocks(R)
+        partial = torch.empty(blocks * 3 * E, dtype=torch.float32, device=dev)
+        sums = torch.empty(3, E, dtype=torch.float32, device=dev)
+        db16 = torch.empty(E, dtype=torch.bfloat16, device=dev) if dysum_bf16 else None
+        defer = defer and deferred.push(partial, blocks, 3 * E, out_f32=sums, out_bf16=db16, bf16_from=2 * E)
+        rc = L.pcm_proj_drln_mfma_backward_hip(R, E, K, d2.data_ptr(), dout2.data_ptr() if dout2 is not None else 0, s.data_ptr(),
+                                               mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), p_drop,
+                                               seed.data_ptr() if seed is not None else 0, site, wc.data_ptr(), dx.data_ptr(), dy.data_ptr(),
+                                               da.data_ptr(), int(da.stride(0)), partial.data_ptr(), 0 if defer else sums.data_ptr(),
+                                               db16.data_ptr() if db16 is not None else 0, _raw_stream())
+    _lib.check(rc, "pcm_proj_drln_mfma_backward_hip")
+    if dysum_bf16:
+        return dx, dy, sums, (deferred.handout(db16) if defer else db16), da
+    return dx, dy, sums, da
+
+
 class _ProjDRLN(Function):
     """out = LayerNorm(x + dropout(a @ W^T + b)): the attention output projection, the residual add and the norm as one
     autograd node.  Forward = one GEMM + the drln kernel; backward = the drln kernel (which also yields the column
@@ -411,10 +453,14 @@ class _ProjDRLN(Function):
         if dout is None:
             return (None,) * 12
         defer = deferred.clear(*ctx.defer)
-        res = _drln_backward(dout, s, mean, rstd, gamma, ydt, p_drop, seed, site, dysum_bf16=want16, defer=defer, dout2=dout2)
+        fused_da = _proj_bwd_mfma_ok(s, wc, ydt, a2.dtype)
+        if fused_da:  # the row code and da = dy W in one launch (opt-in, PROJ_MFMA_BWD)
+            res = _proj_drln_backward_mfma(dout, s, mean, rstd, gamma, wc, p_drop, seed, site, dysum_bf16=want16, defer=defer, dout2=dout2)
+        else:
+            res = _drln_backward(dout, s, mean, rstd, gamma, ydt, p_drop, seed, site, dysum_bf16=want16, defer=defer, dout2=dout2)
         dx, dy, sums = res[:3]
         with torch.autocast("cuda", enabled=False):
-            da = (dy @ wc).view(ashape)
+            da = (res[-1] if fused_da else dy @ wc).view(ashape)
             if da.dtype != adt:
                 da = da.to(adt)
             dw = weight_grad(dy, a2, wdt, side=ctx.side_ok, defer=defer, tag="proj_drln")

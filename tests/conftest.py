@@ -61,7 +61,7 @@ _FILE_TIER = {
 # an entry moves out of this table after its first green hardware run.  (module, substring of the test name; "" = whole module)
 _FIRST_CONTACT = (
     ("test_wrappers_ref_gpu", ""),
-    ("test_proj_ln_gpu", ""),
+    ("test_proj_ln_gpu", ""),  # includes round 6's backward chain (pcm_proj_drln_mfma_backward)
     ("test_pk_hazard_gpu", ""),
     ("test_hybrid_two_ranks_gpu", "dp_graph"),
     ("test_bn_relu_gpu", "test_bn_without_relu"),

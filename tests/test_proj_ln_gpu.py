@@ -312,3 +312,146 @@ def test_in_projection_nodes_with_and_without_the_matrix_core_kernel(monkeypatch
         assert (got - want).abs().max().item() <= 2e-2 * scale + 1e-6, (name, (got - want).abs().max().item(), scale)
     for i in range(4):  # the forward values differ only by the summation order inside one bf16 rounding
         assert (runs[True][i] - runs[False][i]).abs().mean().item() <= 2e-3 * runs[False][i].abs().mean().item()
+
+
+# ------------------------------------------------------------------------------------- pcm_proj_drln_mfma_backward (round 6)
+def _bwd_inputs(R, E, K, seed):
+    g = torch.Generator().manual_seed(seed)
+    dout = torch.randn(R, E, generator=g).to(DEV)
+    dout2 = (0.5 * torch.randn(R, E, generator=g)).to(DEV)
+    s = (torch.randn(R, E, generator=g) * 1.3 + 0.2).to(DEV)
+    mean = s.mean(1).contiguous()
+    rstd = (s.var(1, unbiased=False) + 1e-5).rsqrt().contiguous()
+    gamma = (1 + 0.2 * torch.randn(E, generator=g)).to(DEV)
+    W = (torch.randn(E, K, generator=g) / E ** 0.5).bfloat16().to(DEV)
+    return dout, dout2, s, mean, rstd, gamma, W
+
+
+def _row_kernel(dout, dout2, s, mean, rstd, gamma, p, seed, site):
+    """csrc/drln.hip's backward: what the chain kernel's row phase must reproduce bit for bit."""
+    from pointcloudmatters_amd import _lib
+
+    L = _lib.load()
+    R, E = s.shape
+    dx = torch.empty_like(s)
+    dy = torch.empty(R, E, dtype=torch.bfloat16, device=s.device)
+    partial = torch.empty(L.pcm_drln_blocks(R) * 3 * E, dtype=torch.float32, device=s.device)
+    sums = torch.empty(3, E, dtype=torch.float32, device=s.device)
+    db16 = torch.empty(E, dtype=torch.bfloat16, device=s.device)
+    rc = L.pcm_drln_backward2_hip(R, E, 1, dout.data_ptr(), dout2.data_ptr() if dout2 is not None else 0, s.data_ptr(), mean.data_ptr(),
+                                  rstd.data_ptr(), gamma.data_ptr(), p, seed.data_ptr() if seed is not None else 0, site, dx.data_ptr(),
+                                  dy.data_ptr(), partial.data_ptr(), sums.data_ptr(), db16.data_ptr(), _lib.raw_stream())
+    _lib.check(rc, "pcm_drln_backward2_hip")
+    torch.cuda.synchronize()
+    return dx, dy, sums, db16
+
+
+def _chain_bwd(dout, dout2, s, mean, rstd, gamma, W, p, seed, site, da_ls=None, defer=False):
+    from pointcloudmatters_amd import _lib
+
+    L = _lib.load()
+    R, E = s.shape
+    K = W.shape[1]
+    dx = torch.empty_like(s)
+    dy = torch.empty(R, E, dtype=torch.bfloat16, device=s.device)
+    ls = K if da_ls is None else da_ls
+    da = torch.full((R, ls), 7.0, dtype=torch.bfloat16, device=s.device)
+    blocks = L.pcm_proj_drln_mfma_backward_blocks(R)
+    partial = torch.empty(blocks * 3 * E, dtype=torch.float32, device=s.device)
+    sums = torch.empty(3, E, dtype=torch.float32, device=s.device)
+    db16 = torch.empty(E, dtype=torch.bfloat16, device=s.device)
+    rc = L.pcm_proj_drln_mfma_backward_hip(R, E, K, dout.data_ptr(), dout2.data_ptr() if dout2 is not None else 0, s.data_ptr(), mean.data_ptr(),
+                                           rstd.data_ptr(), gamma.data_ptr(), p, seed.data_ptr() if seed is not None else 0, site, W.data_ptr(),
+                                           dx.data_ptr(), dy.data_ptr(), da.data_ptr(), ls, partial.data_ptr(), 0 if defer else sums.data_ptr(),
+                                           0 if defer else db16.data_ptr(), _lib.raw_stream())
+    _lib.check(rc, "pcm_proj_drln_mfma_backward_hip")
+    torch.cuda.synchronize()
+    if defer:
+        sums = partial.view(blocks, 3, E).double().sum(0).float()
+    return dx, dy, sums, db16, da
+
+
+@pytest.mark.parametrize("R,E,K", [(800, 512, 512), (816, 512, 512), (37, 256, 256), (1, 512, 512), (100, 1024, 1024), (50, 768, 256),
+                                   (129, 256, 1024)])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_backward_chain_equals_row_kernel_plus_product(R, E, K, p):
+    """dx and dy are the row kernel's BITS (same arithmetic per row, same dropout hash); the column sums agree up to the fp32 grouping of
+    the per-workgroup partial rows; da = bf16(dy W) with the products accumulated in fp32 on the matrix cores: against the fp64 product
+    of the SAME bf16 dy and W, within one bf16 rounding of the result."""
+    dout, dout2, s, mean, rstd, gamma, W = _bwd_inputs(R, E, K, 7 * R + E)
+    seed = torch.tensor([12345], dtype=torch.int64, device=DEV) if p > 0 else None
+    for d2 in (None, dout2):
+        dx0, dy0, sums0, db0 = _row_kernel(dout, d2, s, mean, rstd, gamma, p, seed, 3)
+        dx, dy, sums, db16, da = _chain_bwd(dout, d2, s, mean, rstd, gamma, W, p, seed, 3)
+        assert torch.equal(dx, dx0) and torch.equal(dy.view(torch.int16), dy0.view(torch.int16))
+        scale = sums0.abs().max().item()
+        assert (sums - sums0).abs().max().item() <= 2e-5 * scale + 1e-6
+        assert (db16.float() - db0.float()).abs().max().item() <= 1e-2 * db0.float().abs().max().item() + 1e-6
+        want = (dy0.double() @ W.double())
+        err = (da.double() - want).abs().max().item()
+        assert err <= 2 ** -8 * want.abs().max().item() + 1e-6, (err, want.abs().max().item())
+    if p > 0:  # the mask really drops: a share p of dy is exactly zero where dx is not
+        dropped = ((dy.float() == 0) & (dx != 0)).float().mean().item()
+        assert abs(dropped - p) < 0.02, dropped
+
+
+def test_backward_chain_row_stride_partial_rows_and_contract():
+    from pointcloudmatters_amd import _lib
+
+    L = _lib.load()
+    R, E, K = 100, 512, 512
+    dout, dout2, s, mean, rstd, gamma, W = _bwd_inputs(R, E, K, 3)
+    ref = _chain_bwd(dout, None, s, mean, rstd, gamma, W, 0.0, None, 0)
+    wide = _chain_bwd(dout, None, s, mean, rstd, gamma, W, 0.0, None, 0, da_ls=K + 64)   # da into a wider buffer: the columns past K untouched
+    assert torch.equal(wide[4][:, :K], ref[4]) and bool((wide[4][:, K:] == 7.0).all())
+    left = _chain_bwd(dout, None, s, mean, rstd, gamma, W, 0.0, None, 0, defer=True)      # NULL result pointer: partial rows only
+    assert (left[2] - ref[2]).abs().max().item() <= 2e-5 * ref[2].abs().max().item() + 1e-6
+    assert L.pcm_proj_drln_mfma_backward_supported(512, 512) == 1 and L.pcm_proj_drln_mfma_backward_supported(512, 384) == 0
+    assert L.pcm_proj_drln_mfma_backward_supported(384, 512) == 0 and L.pcm_proj_drln_mfma_backward_blocks(800) == 50
+    z = [0] * 18
+    assert L.pcm_proj_drln_mfma_backward_hip(-1, 512, 512, *z) == 1          # negative size
+    assert L.pcm_proj_drln_mfma_backward_hip(0, 512, 512, *z[:13], 512, *z[14:]) == 0   # empty call
+    assert L.pcm_proj_drln_mfma_backward_hip(16, 512, 384, *z[:13], 384, *z[14:]) == 2  # unsupported width
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_fused_node_backward_with_and_without_the_chain_kernel(monkeypatch, p):
+    """fused_ops.proj_drln with PROJ_MFMA_BWD on against the same node with pcm_drln_backward2 + the library product: dx / dgamma / dbeta /
+    db / dW as before (dy is the same tensor), da up to the bf16 rounding of the product."""
+    import torch.nn as nn
+
+    from pointcloudmatters_amd.policy import fused_ops
+
+    torch.manual_seed(9)
+    E, Lq, B = 512, 100, 8
+    lin, norm, drop = nn.Linear(E, E).to(DEV), nn.LayerNorm(E).to(DEV), nn.Dropout(p)
+    a0 = torch.randn(Lq, B, E, device=DEV).bfloat16()
+    x0 = torch.randn(Lq, B, E, device=DEV)
+    g = torch.randn(Lq, B, E, device=DEV)
+    runs, called = {}, []
+    orig = fused_ops._lib.check
+
+    def check(rc, what, *args, **kw):
+        called.append(what)
+        return orig(rc, what, *args, **kw)
+
+    monkeypatch.setattr(fused_ops._lib, "check", check)
+    for flag in (False, True):
+        monkeypatch.setattr(fused_ops, "PROJ_MFMA_BWD", flag)
+        a, x = a0.clone().requires_grad_(True), x0.clone().requires_grad_(True)
+        for q in list(lin.parameters()) + list(norm.parameters()):
+            q.grad = None
+        ctx = fused_ops.FusedContext(torch.device(DEV))
+        ctx.set_step(3)
+        with fused_ops.activate(ctx), torch.autocast("cuda", dtype=torch.bfloat16):
+            out = fused_ops.proj_drln(a, lin, x, norm, drop)
+        called.clear()
+        out.backward(g)
+        torch.cuda.synchronize()
+        assert ("pcm_proj_drln_mfma_backward_hip" in called) == flag and ("pcm_drln_backward2_hip" in called) == (not flag), called
+        runs[flag] = [a.grad.float(), x.grad, lin.weight.grad.float(), lin.bias.grad.float(), norm.weight.grad, norm.bias.grad]
+    for got, want, name in zip(runs[True], runs[False], ("da", "dx", "dW", "db", "dgamma", "dbeta")):
+        scale = want.abs().max().item()
+        tol = 2e-2 if name == "da" else (1e-2 if name == "db" else 2e-5)
+        assert (got - want).abs().max().item() <= tol * scale + 1e-6, (name, (got - want).abs().max().item(), scale)
+    assert torch.equal(runs[True][1], runs[False][1])  # dx: the same bits
