@@ -2,6 +2,7 @@
   A  out_proj + residual + norm:  library bf16 product (F.linear) + pcm_drln_forward_hip      vs  pcm_proj_drln_mfma_forward_hip
   B  packed in-projection:        pcm_add_cast2_hip + the doubled-row product [x + pos ; x] W^T  vs  pcm_linear_mfma_forward_hip (fp32 x + pos in)
   C  query projection:            pcm_add_cast2_hip + library product                          vs  pcm_linear_mfma_forward_hip
+  D  backward of A (800 / 816 rows): pcm_drln_backward2_hip + library product dy @ W           vs  pcm_proj_drln_mfma_backward_hip (round 6)
 at the row counts of the ACT step (decoder 800, CVAE encoder 816, encoder 4120 at C2).  Written in round 5 while the GPU pool was closed:
 the FIRST thing to run when it opens --   python tools/mb/mb_proj_ln.py > gpurun_out/mb_proj_ln.log"""
 import os
@@ -68,10 +69,28 @@ for R in (800, 816, 4120):
         assert L.pcm_linear_mfma_forward_hip(R, E, E, x.data_ptr(), 1, E, 0, pos.data_ptr(), pos.numel(), E, W.data_ptr(), b.data_ptr(), 1,
                                              y1.data_ptr(), 1, E, pair[0].data_ptr(), 0, st) == 0
 
-    for fn in (lib_a, new_a, lib_b, new_b, lib_c, new_c):
+    dout, dx, dy16, da16 = torch.randn(R, E, **f32), torch.empty(R, E, **f32), torch.empty(R, E, **bf), torch.empty(R, E, **bf)
+    torch.nn.functional.layer_norm(x, (E,))  # any s / mean / rstd will do for timing
+    mean.copy_(x.mean(1)), rstd.copy_((x.var(1, unbiased=False) + 1e-5).rsqrt())
+    part_old = torch.empty(L.pcm_drln_blocks(R) * 3 * E, **f32)
+    part_new = torch.empty(max(1, L.pcm_proj_drln_mfma_backward_blocks(R)) * 3 * E, **f32)
+    sums, db16 = torch.empty(3, E, **f32), torch.empty(E, **bf)
+
+    def lib_d(st):
+        assert L.pcm_drln_backward2_hip(R, E, 1, dout.data_ptr(), 0, x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), 0.1,
+                                        seed.data_ptr(), 3, dx.data_ptr(), dy16.data_ptr(), part_old.data_ptr(), sums.data_ptr(), db16.data_ptr(), st) == 0
+        dy16 @ W
+
+    def new_d(st):
+        assert L.pcm_proj_drln_mfma_backward_hip(R, E, E, dout.data_ptr(), 0, x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), 0.1,
+                                                 seed.data_ptr(), 3, W.data_ptr(), dx.data_ptr(), dy16.data_ptr(), da16.data_ptr(), E,
+                                                 part_new.data_ptr(), sums.data_ptr(), db16.data_ptr(), st) == 0
+
+    for fn in (lib_a, new_a, lib_b, new_b, lib_c, new_c, lib_d, new_d):
         fn(torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
-    t = {fn.__name__: graphed(fn) for fn in (lib_a, new_a, lib_b, new_b, lib_c, new_c)}
+    t = {fn.__name__: graphed(fn) for fn in (lib_a, new_a, lib_b, new_b, lib_c, new_c, lib_d, new_d)}
     print(f"R={R:5d}  A out_proj+res+norm: library pair {t['lib_a']:6.1f} us  proj_ln {t['new_a']:6.1f} us   "
           f"B in-projection: add_cast + doubled product {t['lib_b']:6.1f} us  linear_mfma {t['new_b']:6.1f} us   "
-          f"C query projection: {t['lib_c']:6.1f} us  linear_mfma {t['new_c']:6.1f} us", flush=True)
+          f"C query projection: {t['lib_c']:6.1f} us  linear_mfma {t['new_c']:6.1f} us   "
+          f"D backward of A: drln_bwd + reduce + dy @ W {t['lib_d']:6.1f} us  chain kernel + reduce {t['new_d']:6.1f} us", flush=True)
