@@ -756,6 +756,9 @@ def act_step_flops(wl, model=None):
     return 3 * 2 * macs * wl["batch"]
 
 
+MODE_FALLBACK = {}  # workload -> the modes that failed before the one that ran (empty: the first choice ran)
+
+
 def run_workload(name, args, device, world, rank, steps, warmup, precision=None, mode="auto", trace_steps=0, losses=None):
     """Build the policy + trainer of workload `name`, run warm-up + `steps` timed steps.  `losses` (a list): receives the loss of every
     WARM-UP step as a float (cloned on the device per step, read back after the warm-up: nothing touches the timed region)."""
@@ -793,39 +796,71 @@ def run_workload(name, args, device, world, rank, steps, warmup, precision=None,
     for opt_key in ("backbone", "obs_encoder"):  # the hierarchical encoders of policy/pointnet2.py (C4N, C5B)
         if opt_key in wl:
             extra[opt_key] = wl[opt_key]
-    policy = build(pcd_npoints=wl["pcd_npoints"], sa_impl=sa_impl, **extra).to(device)
-    if TOKENIZER_BF16:
-        from pointcloudmatters_amd.policy.precision import set_tokenizer_fp32
+    # mode "auto" at N = 1 is a ladder, not a selection: the fastest capture mode the workload allows is ALWAYS tried first (graph for
+    # equal-size clouds, hybrid for ragged ones); only if building the trainer, capturing or warming it up RAISES does the next mode run
+    # (hybrid, then flat: the same step, the same work, more launches from the host).  Rounds 5 and 6 changed the step's Python without a
+    # hardware run; a capture-unsafe operation in there must cost speed, not the bench line.  What ran and why is on the line
+    # (config.step_mode, config.mode_fallback).  An explicit --mode is obeyed as given; N > 1 never falls back (the ranks must agree).
+    ladder = [mode]
+    if mode == "auto" and world == 1:
+        ladder = ["auto", "hybrid", "flat"] if not wl["ragged"] else ["auto", "flat"]
+    fell = []
 
-        set_tokenizer_fp32(policy, False)
-    if mode == "auto":
-        # ragged clouds: the tokenizer runs eagerly, everything behind the fixed-size token matrix replays as hipGraphs.
-        # Data parallel runs take the same mode: every BatchNorm lives in the eager tokenizer, so its statistics are
-        # synchronised across ranks (configs/trainer/ddp.yaml:9) with plain collectives, and the gradient slabs of the
-        # captured stages are exchanged between graph replays, overlapping the rest of backward.
-        # round 4: equal-size clouds at N > 1 no longer fall back to hybrid when every BatchNorm of the policy is owned by a fused
-        # kernel (the ACT policies): mode "graph" then captures the WHOLE step as a chain of graphs cut at the collectives
-        # (_graphs.SegmentedCapture), which stay plain eager RCCL calls between the replays
-        chainable = world > 1 and not wl["ragged"] and BCTrainer.all_batchnorms_fused(policy) and os.environ.get("PCM_DP_MODE", "graph") == "graph"
-        mode = "hybrid" if (wl["ragged"] or (world > 1 and not chainable)) else "graph"
-    trainer = BCTrainer(policy, total_steps=max(steps + warmup + trace_steps, 100), precision=wl["dtype"], device=device,
-                        distributed=world > 1, mode=mode, external_sampling=not getattr(args, "sampling_in_graph", False),
-                        optim=dict(RLBENCH_DP_OPTIM) if is_rlbdp else (dict(DP_OPTIM) if is_dp else (
-                            dict(RLBENCH_ACT_OPTIM) if is_rlb else dict(accumulate_grad_batches=1))))
-    batches = [make_batch(wl["batch"], wl["n_points"], seed=1000 + rank + 97 * i, ragged=wl["ragged"], device=device)
-               for i in range(4)]
+    def attempt(mode):
+        torch.manual_seed(1000 + rank)
+        policy = build(pcd_npoints=wl["pcd_npoints"], sa_impl=sa_impl, **extra).to(device)
+        if TOKENIZER_BF16:
+            from pointcloudmatters_amd.policy.precision import set_tokenizer_fp32
 
-    def step(i):
-        # the next batch is handed over early, as a prefetching data loader would: its FPS + kNN + SA index pass run one step
-        # ahead on the side stream (in graph mode through static index buffers; every batch is sampled exactly once)
-        nxt = None if args.no_prefetch else batches[(i + 1) % len(batches)]
-        return trainer.training_step(clone_batch(batches[i % len(batches)]), prefetch=nxt)
+            set_tokenizer_fp32(policy, False)
+        if mode == "auto":
+            # ragged clouds: the tokenizer runs eagerly, everything behind the fixed-size token matrix replays as hipGraphs.
+            # Data parallel runs take the same mode: every BatchNorm lives in the eager tokenizer, so its statistics are
+            # synchronised across ranks (configs/trainer/ddp.yaml:9) with plain collectives, and the gradient slabs of the
+            # captured stages are exchanged between graph replays, overlapping the rest of backward.
+            # round 4: equal-size clouds at N > 1 no longer fall back to hybrid when every BatchNorm of the policy is owned by a fused
+            # kernel (the ACT policies): mode "graph" then captures the WHOLE step as a chain of graphs cut at the collectives
+            # (_graphs.SegmentedCapture), which stay plain eager RCCL calls between the replays
+            chainable = world > 1 and not wl["ragged"] and BCTrainer.all_batchnorms_fused(policy) and os.environ.get("PCM_DP_MODE", "graph") == "graph"
+            mode = "hybrid" if (wl["ragged"] or (world > 1 and not chainable)) else "graph"
+        trainer = BCTrainer(policy, total_steps=max(steps + warmup + trace_steps, 100), precision=wl["dtype"], device=device,
+                            distributed=world > 1, mode=mode, external_sampling=not getattr(args, "sampling_in_graph", False),
+                            optim=dict(RLBENCH_DP_OPTIM) if is_rlbdp else (dict(DP_OPTIM) if is_dp else (
+                                dict(RLBENCH_ACT_OPTIM) if is_rlb else dict(accumulate_grad_batches=1))))
+        batches = [make_batch(wl["batch"], wl["n_points"], seed=1000 + rank + 97 * i, ragged=wl["ragged"], device=device)
+                   for i in range(4)]
 
-    kept = []
-    for i in range(warmup):
-        out = step(i)
-        if losses is not None and isinstance(out, dict) and "loss" in out:
-            kept.append(out["loss"].detach().float().clone())
+        def step(i):
+            # the next batch is handed over early, as a prefetching data loader would: its FPS + kNN + SA index pass run one step
+            # ahead on the side stream (in graph mode through static index buffers; every batch is sampled exactly once)
+            nxt = None if args.no_prefetch else batches[(i + 1) % len(batches)]
+            return trainer.training_step(clone_batch(batches[i % len(batches)]), prefetch=nxt)
+
+        kept = []
+        for i in range(warmup):
+            out = step(i)
+            if losses is not None and isinstance(out, dict) and "loss" in out:
+                kept.append(out["loss"].detach().float().clone())
+        return trainer, step, kept
+
+    for k, m in enumerate(ladder):
+        try:
+            trainer, step, kept = attempt(m)
+            break
+        except Exception as e:  # noqa: BLE001 -- anything the first contact with the hardware can raise
+            if k + 1 == len(ladder):
+                raise
+            fell.append("%s failed (%s: %s)" % (m, type(e).__name__, str(e).replace("\n", " ")[:160]))
+            print("[bench] step mode %r failed, trying %r: %s: %s" % (m, ladder[k + 1], type(e).__name__, e), file=sys.stderr, flush=True)
+            try:
+                torch.cuda.synchronize()
+            except Exception:  # noqa: BLE001
+                pass
+            import gc
+
+            gc.collect()
+            torch.cuda.empty_cache()
+    MODE_FALLBACK[name] = fell
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -994,7 +1029,7 @@ def main():
                                            "PointNet(6->512->96) + SA(99->96) + projector + U-Net(512/1024/2048, k=5) DDPM-100" if is_dp
                                            else "PointNet(6->512) + SA(515->512) + ACT(4 enc / 7 dec, d=512, 100 queries)"),
                        "global_batch": wl["batch"] * world, "points_per_cloud": wl["n_points"],
-                       "tokens_per_cloud": wl["pcd_npoints"], "parallelism": "dp%d" % world, "sa_impl": sa_impl, "step_mode": trainer.mode,
+                       "tokens_per_cloud": wl["pcd_npoints"], "parallelism": "dp%d" % world, "sa_impl": sa_impl, "step_mode": trainer.mode, "mode_fallback": MODE_FALLBACK.get(args.workload) or None,
                        "batchnorm": "sync" if trainer.sync_batchnorm else "per-rank",
                        "gradient_exchange": getattr(trainer, "exchange_description", "one all-reduce after backward") if world > 1 else "single GPU",
                        "accumulate_grad_batches": trainer.accumulate, "optimizer_step_every_step": trainer.accumulate == 1,

@@ -358,3 +358,55 @@ def test_bench_headline_kernel_set_is_not_chosen_at_run_time(monkeypatch):
         assert "mfma" in info["selected"] and "long" in info["selected"] and "environment" in info["reason"]
     finally:
         fused_ops.PROJ_MFMA, fused_ops.LINEAR_MFMA, fused_ops.PROJ_MFMA_LONG = saved
+
+
+def test_bench_auto_mode_is_a_ladder_that_only_moves_on_an_exception(monkeypatch):
+    import pytest
+
+    """bench.run_workload with --mode auto at N = 1: the capture mode is tried first; a raise while building / warming it up moves to the
+    next mode and is recorded; an explicit --mode is obeyed and its failure propagates."""
+    import argparse
+
+    import torch
+
+    import bench
+    import pointcloudmatters_amd.bc as bc
+
+    tried = []
+
+    class FakeTrainer:
+        def __init__(self, policy, mode=None, **kw):
+            self.mode = mode
+            tried.append(mode)
+            if mode in FAIL:
+                raise RuntimeError("capture failed\nsecond line")
+
+        def training_step(self, batch, prefetch=None):
+            return {"loss": torch.zeros(())}
+
+    monkeypatch.setattr(bc, "BCTrainer", FakeTrainer)
+    monkeypatch.setattr(bc, "build_act_policy", lambda **kw: torch.nn.Linear(1, 1))
+    monkeypatch.setattr(bc, "make_act_batch", lambda b, n, **kw: {})
+    monkeypatch.setattr(bc, "clone_batch", lambda b: b)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    monkeypatch.setattr(torch.cuda, "empty_cache", lambda: None)
+    args = argparse.Namespace(sa_impl="auto", dead_decoder_layers="keep", no_prefetch=True, sampling_in_graph=False)
+    dev = torch.device("cpu")
+    FAIL = {"graph"}
+    _, tr, _, _, _ = bench.run_workload("C2", args, dev, 1, 0, 1, 1, mode="auto")
+    assert tried == ["graph", "hybrid"] and tr.mode == "hybrid"
+    assert len(bench.MODE_FALLBACK["C2"]) == 1 and "capture failed second line" in bench.MODE_FALLBACK["C2"][0]
+    tried.clear()
+    FAIL = set()
+    _, tr, _, _, _ = bench.run_workload("C2", args, dev, 1, 0, 1, 1, mode="auto")
+    assert tried == ["graph"] and bench.MODE_FALLBACK["C2"] == []
+    tried.clear()
+    FAIL = {"graph", "hybrid", "flat"}
+    with pytest.raises(RuntimeError):
+        bench.run_workload("C2", args, dev, 1, 0, 1, 1, mode="auto")
+    assert tried == ["graph", "hybrid", "flat"]
+    tried.clear()
+    FAIL = {"graph"}
+    with pytest.raises(RuntimeError):  # an explicit mode is obeyed as given
+        bench.run_workload("C2", args, dev, 1, 0, 1, 1, mode="graph")
+    assert tried == ["graph"]

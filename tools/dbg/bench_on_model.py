@@ -39,7 +39,7 @@ if "--main" in sys.argv:
 
     WORKLOADS["TINY"] = dict(WORKLOADS["C2"], batch=2, n_points=256, pcd_npoints=64)
     bench.TOKENIZER_BF16 = False
-    sys.argv = ["bench.py", "--workload", "TINY", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extra", "--no-hbm-tables", "--chain-trial", "1,2",
+    sys.argv = ["bench.py", "--workload", "TINY", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extra", "--no-hbm-tables",
                 "--tables-out", "/tmp/bench_on_model_tables.json"] + [a for a in sys.argv[1:] if a not in ("--main",)]
     with simulated_device(claim_cuda=True):
         torch.cuda.is_available = lambda: True
