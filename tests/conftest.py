@@ -12,6 +12,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    """`python -m pytest tests/ -x -q -m "not gpu"` (the CPU suite as the driver runs it) takes ~30 minutes in one process -- most of it the
+    kernel sources executing on the host wave64 model -- and ~6 with pytest-xdist.  When the marker expression is exactly "not gpu", xdist is
+    installed and no -n was given, run it on min(6, cores) workers.  Never for `-m gpu` (one device; the concurrency tests bring their own
+    load) and never inside a worker.  PCM_TEST_SERIAL=1 switches it off."""
+    if (getattr(config.option, "markexpr", "") == "not gpu" and config.pluginmanager.hasplugin("xdist")
+            and not getattr(config.option, "numprocesses", None) and os.environ.get("PCM_TEST_SERIAL") != "1"
+            and "PYTEST_XDIST_WORKER" not in os.environ and not getattr(config.option, "collectonly", False)):
+        config.option.numprocesses = max(1, min(6, os.cpu_count() or 1))
+    return None
+
+
 # PCM_WAVESIM=1 (development aid; tests/test_wavesim_parity.py is the curated form): run `-m gpu` tests on HOST tensors against the
 # product's kernel sources compiled for the CPU wave64 model (tests/wavesim/).  `hip_device` then is the CPU and module-level `DEV`
 # constants are rewritten; tests that need the real runtime (streams, graphs, events, library GEMMs on the device) fail or are slow.
