@@ -146,6 +146,27 @@ __device__ __forceinline__ void store_f32(float *dst, const float (&in)[VEC])
     }
 }
 
+// Streaming (non-temporal) form for outputs that nobody in THIS kernel reads again.  Round 4's counters at the REF shape: pcm_sa_fwd
+// fetched 92.9 MB for 36 MB of algorithmic reads while writing 46 MB -- one cloud's Gf rows are 4 MiB (bf16) / 8 MiB (fp32), an XCD's L2 is
+// 4 MiB, every row is gathered by ~8 queries in farthest-point (= spatially scattered) order, and the 40 MB of sel / asel written through
+// the same L2 in between push those rows out.  The `nt` hint keeps the written lines from displacing them (hypothesis, to be confirmed
+// by the PMC pass of the next hardware run; the results are the same bits either way).
+typedef float f4nt __attribute__((ext_vector_type(4)));
+template <int VEC>
+__device__ __forceinline__ void store_f32_nt(float *dst, const float (&in)[VEC])
+{
+    if constexpr (VEC % 4 == 0) {
+#pragma unroll
+        for (int v = 0; v < VEC; v += 4) {
+            const f4nt q = {in[v], in[v + 1], in[v + 2], in[v + 3]};
+            __builtin_nontemporal_store(q, reinterpret_cast<f4nt *>(dst + v));
+        }
+    } else {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) __builtin_nontemporal_store(in[v], dst + v);
+    }
+}
+
 template <typename T, int VEC>
 __device__ __forceinline__ void store_vec(T *dst, const float (&in)[VEC])
 {
@@ -240,8 +261,12 @@ __global__ __launch_bounds__(kBlock) void pcm_sa_fwd_kernel(int m, int K, int H,
     // neighbours live in the query's own cloud, so an XCD's L2 only ever holds the Gf rows of "its" clouds instead of
     // every XCD streaming the whole (n, H) matrix.  gridDim.x is a multiple of 8 * nchunk (launcher guarantees).
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
-    const int chunk = local % nchunk;
-    const int slot_local = local / nchunk, slots_per_xcd = per_xcd / nchunk;
+    // chunk-MAJOR within an XCD (was chunk = local % nchunk: all channel chunks of a row group in flight together).  Workgroups start in
+    // index order, so an XCD now works through all its queries for chunk 0, then chunk 1, ...: the rows live in its L2 are one cloud x ONE
+    // chunk of channels (REF, fp32 Gf: 4096 rows x 256 channels x 4 B = 4 MiB instead of 8).  A bijection of the same (slot, chunk) pairs:
+    // every block computes what it computed before, `partial` rows included.
+    const int slots_per_xcd = per_xcd / nchunk;
+    const int chunk = local / slots_per_xcd, slot_local = local - chunk * slots_per_xcd;
     const int slot = xcd * slots_per_xcd + slot_local;  // row of `partial` written by this block
     const int q_begin = (int)((long)m * xcd / 8), q_end = (int)((long)m * (xcd + 1) / 8);
     const int qi = lane / lpq, gl = lane - qi * lpq;
@@ -335,15 +360,20 @@ __global__ __launch_bounds__(kBlock) void pcm_sa_fwd_kernel(int m, int K, int H,
             float out[VEC];
 #pragma unroll
             for (int v = 0; v < VEC; ++v) out[v] = best[v / 2][v % 2] * sgn[v / 2][v % 2];
-            store_f32<VEC>(sel + o, out);
+            store_f32_nt<VEC>(sel + o, out);
             if constexpr (VEC % 4 == 0) {
 #pragma unroll
                 for (int v = 0; v < VEC; v += 4)
-                    *reinterpret_cast<uint32_t *>(asel + o + v) =
-                        (uint32_t)arg[v] | ((uint32_t)arg[v + 1] << 8) | ((uint32_t)arg[v + 2] << 16) | ((uint32_t)arg[v + 3] << 24);
+                {
+                    const uint32_t packed = (uint32_t)arg[v] | ((uint32_t)arg[v + 1] << 8) | ((uint32_t)arg[v + 2] << 16) | ((uint32_t)arg[v + 3] << 24);
+                    __builtin_nontemporal_store(packed, reinterpret_cast<uint32_t *>(asel + o + v));
+                }
             } else {
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) asel[o + v] = (uint8_t)arg[v];
+                for (int v = 0; v < VEC; ++v) {
+                    const uint8_t a8 = (uint8_t)arg[v];
+                    __builtin_nontemporal_store(a8, asel + o + v);
+                }
             }
         }
         wave_lds_sync();  // the next pass overwrites the staging area

@@ -292,3 +292,23 @@ def test_every_readlane_index_is_wave_uniform():
         for m in re.finditer(r"\.(?:new_)?offset_at\(([^()]*(?:\([^()]*\))?[^()]*)\)", text):
             arg = " ".join(m.group(1).split())
             assert re.fullmatch(r"(c|bt)( - 1)?", arg), "%s: offset_at(%s)" % (os.path.basename(f), arg)
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not installed")
+def test_no_scratch_outside_the_one_documented_kernel():
+    """Every kernel that has NOT been executed by a GPU yet (the rewrites of csrc/next/, the new bnact.hip and proj_ln.hip) uses no scratch
+    memory and spills no vector register; the only kernel of the library that does is pcm_sa_bwd1_pack_kernel<16> (SA widths 513-1024, no
+    shipped workload; hardware-green at width 1024 in round 4).  The full table: profiles/r06_kernel_resources.md
+    (tools/kernel_resources.py, compiler metadata)."""
+    import glob
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources as kr
+
+    paths = sorted(glob.glob(os.path.join(NEXT, "*.hip"))) + [os.path.join(CSRC, f) for f in ("bnact.hip", "proj_ln.hip", "sa_scatter.hip")]
+    res = kr.collect(paths)
+    spills = {(os.path.basename(p), r["short"]): (r["scratch"], r["vgpr_spill"]) for p, rows in res.items() for r in rows if r["scratch"] or r["vgpr_spill"]}
+    assert set(spills) == {("sa_scatter.hip", "pcm_sa_bwd1_pack_kernel<16>")}, spills
+    assert all(r["vgpr"] + r["agpr"] <= 512 and r["sgpr"] <= 108 for rows in res.values() for r in rows)
+    assert sum(len(rows) for rows in res.values()) >= 120
