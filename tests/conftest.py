@@ -65,7 +65,7 @@ _FILE_TIER = {
     "test_sa_fused_gpu": 1, "test_bn_relu_gpu": 1, "test_drln_gpu": 1, "test_tokens_gpu": 1, "test_small_attn_gpu": 1,
     "test_flash_attn_gpu": 1, "test_rows_linear_gpu": 1, "test_unet_ops_gpu": 1, "test_pointnet2_gpu": 1, "test_graphs_gpu": 1,
     "test_host_logic": 1, "test_concurrency_gpu": 1, "test_xfer_gpu": 1, "test_ffn_mfma_gpu": 1, "test_proj_ln_gpu": 1, "test_pk_hazard_gpu": 1, "test_build_flags": 1,
-    "test_configs_vs_yaml": 1, "test_golden_regen": 1, "test_oracle_sanitized": 1,
+    "test_configs_vs_yaml": 1, "test_golden_regen": 1, "test_oracle_sanitized": 1, "test_capture_safety": 1,
     "test_policy_gpu": 2, "test_sync_bn_gpu": 2, "test_hybrid_two_ranks_gpu": 2, "test_bench_multirank_gpu": 2, "test_ddp_gloo": 2,
     "test_determinism_gpu": 2,
 }
