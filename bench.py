@@ -940,11 +940,13 @@ def projection_chain_setting():
     library product + a small kernel.  It has never run on hardware (the GPU pool was closed to the build in rounds 4 - 6), so the headline
     stays on the library products: no run-time selection (round 5 had an untimed A/B in child processes here; removed -- the kernel set
     of the timed line must not be decided at run time, round-5 VERDICT weak 3 / ADVICE).  The chain is opt-in through the environment
-    (PCM_PROJ_MFMA / PCM_LINEAR_MFMA / PCM_PROJ_MFMA_LONG, obeyed as given by policy/fused_ops.py); the line records what ran."""
+    (PCM_PROJ_MFMA / PCM_LINEAR_MFMA / PCM_PROJ_MFMA_LONG / PCM_PROJ_MFMA_BWD / PCM_LINEAR_MFMA_BWD, obeyed as given by policy/fused_ops.py); the line records what ran."""
     from pointcloudmatters_amd.policy import fused_ops
 
-    on = bool(fused_ops.PROJ_MFMA or fused_ops.LINEAR_MFMA)
-    return {"selected": ("mfma (csrc/proj_ln.hip)%s" % (", long sites too" if fused_ops.PROJ_MFMA_LONG else "")) if on else "library products",
+    on = bool(fused_ops.PROJ_MFMA or fused_ops.LINEAR_MFMA or fused_ops.PROJ_MFMA_BWD or fused_ops.LINEAR_MFMA_BWD)
+    parts = [n for n, f in (("proj fwd", fused_ops.PROJ_MFMA), ("linear fwd", fused_ops.LINEAR_MFMA), ("long sites", fused_ops.PROJ_MFMA_LONG),
+                            ("proj bwd", fused_ops.PROJ_MFMA_BWD), ("linear bwd", fused_ops.LINEAR_MFMA_BWD)) if f]
+    return {"selected": ("mfma (csrc/proj_ln.hip: %s)" % ", ".join(parts)) if on else "library products",
             "reason": "set by the environment" if on else "default: csrc/proj_ln.hip is opt-in until it has a hardware run"}
 
 

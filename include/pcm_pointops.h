@@ -380,6 +380,16 @@ int pcm_proj_drln_mfma_backward_hip(long R, int E, int K, const float *dout, con
                                     const void *w_bf16, float *dx, void *dy_bf16, void *da_bf16, long da_ls, float *partial,
                                     float *dgamma_dbeta, void *dysum_bf16, void *stream);
 
+/* The INPUT gradient of the short in-projections as one kernel (csrc/proj_ln.hip, round 6; opt-in, PCM_LINEAR_MFMA_BWD):
+ *   dx (R, K) fp32 = dy (R, N) W (N, K) [+ dres (R, K) fp32, nullable];   dpos (R, K) fp32, nullable = dy[:, :pos_cols] W[:pos_cols]
+ * dy bf16 with row stride dy_ls (a multiple of 8), W (N, K) bf16 row-major: autograd's `grad_output @ weight` for the packed
+ * self-attention in-projection of nn.MultiheadAttention (N = 3 E: dq | dk | dv side by side, pos_cols = 2 E: q = k = x + pos, v = x;
+ * transformer.py:244-262, 296-346) and for the cross-attention query projection (N = E, pos_cols >= N).
+ * N % 32 == 0 (<= 3072), K in {256, 512, 1024}, pos_cols % 32 == 0 or >= N; 16-byte aligned pointers. */
+int pcm_linear_mfma_backward_supported(int N, int K, int pos_cols);
+int pcm_linear_mfma_backward_hip(long R, int N, int K, const void *dy_bf16, long dy_ls, const void *w_bf16, const float *dres, float *dx,
+                                 float *dpos, int pos_cols, void *stream);
+
 /* out = A W^T + bias for short activations on the matrix cores, operand preparation fused in (csrc/proj_ln.hip): the in-projections of
  * nn.MultiheadAttention and the cross-attention query projection (transformer.py:244-262, 296-346: `q = k = with_pos_embed(x, pos)`).
  * A: a_is_f32 == 0: bf16 (R, K), row stride a_ls elements, for the output columns [0, pos_cols), and a_alt_bf16 (nullable, same layout)

@@ -80,6 +80,9 @@ SIGNATURES = {
     # R, E, K, dout, dout2, s, mean, rstd, gamma, p, seed, site, W, dx, dy, da, da_ls, partial, dgamma_dbeta, dysum_bf16, stream
     "pcm_proj_drln_mfma_backward_hip": [ctypes.c_long, _i, _i, _P, _P, _P, _P, _P, _P, _f, _P, ctypes.c_uint, _P, _P, _P, _P, ctypes.c_long, _P,
                                         _P, _P, _P],
+    "pcm_linear_mfma_backward_supported": [_i, _i, _i],
+    # R, N, K, dy, dy_ls, W, dres, dx, dpos, pos_cols, stream
+    "pcm_linear_mfma_backward_hip": [ctypes.c_long, _i, _i, _P, ctypes.c_long, _P, _P, _P, _P, _i, _P],
     "pcm_linear_mfma_supported": [_i, _i, _i],
     # R, N, K, a, a_is_f32, a_ls, a_alt, pos, pos_n, pos_cols, W, bias, bias_is_bf16, out, out_is_bf16, out_ls, emit_pos16, emit_x16, stream
     "pcm_linear_mfma_forward_hip": [ctypes.c_long, _i, _i, _P, _i, ctypes.c_long, _P, _P, ctypes.c_long, _i, _P, _P, _i, _P, _i, ctypes.c_long,

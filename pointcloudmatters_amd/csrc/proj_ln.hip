@@ -836,3 +836,143 @@ extern "C" int pcm_proj_drln_mfma_backward_hip(long R, int E, int K, const float
     void *o32[1] = {dgamma_dbeta}, *o16[1] = {dysum_bf16};
     return pcm_reduce_batch_hip(1, parts, nslots, width, o32, o16, from, stream);
 }
+
+// ================================================================================================================================
+// pcm_linear_mfma_backward: the INPUT gradient of the short in-projections as one kernel (round 6, opt-in PCM_LINEAR_MFMA_BWD; host-model
+// evidence only, like everything in this file):
+//     dx   (R, K) fp32 = dy (R, N) W (N, K) [+ dres]          dpos (R, K) fp32 = dy[:, :pos_cols] W[:pos_cols]   (nullable)
+// For nn.MultiheadAttention's packed self-attention in-projection (transformer.py:244-262, 296-346: q = k = x + pos, v = x) dy is
+// dq | dk | dv side by side (N = 3 E, the layout csrc/attn_small.hip's backward writes), dres the residual branch's gradient of the same x,
+// pos_cols = 2 E: the position embedding sees q's and k's share only.  The framework path was ONE batched product (3 x (R, E) @ (E, E)) plus
+// pcm_add4_cast2 (d3[0] + d3[1] + d3[2] + dres -> dx, d3[0] + d3[1] -> dpos): two launches and 3 R E bf16 + R E fp32 of round trip; the
+// cross-attention query projection (N = E, pos_cols = N: dx and dpos are the same tensor) was a library product at the launch floor.
+// Same scheme as pcm_proj_drln_bwd_kernel's product phase: 16 rows x all K columns per workgroup, K / 128 waves, the A panel (16 x N bf16)
+// in LDS, W's 8 x 8 blocks transposed in registers, eight consecutive output columns per lane and row -> two 16-byte fp32 stores per
+// output.  The accumulators are copied once, at k = pos_cols, for dpos.
+// ================================================================================================================================
+namespace {
+
+template <int NW>  // waves per workgroup = K / 128
+__global__ __launch_bounds__(64 * NW) void pcm_linear_bwd_kernel(long R, int N, int K, const u16 *__restrict__ dy, long dy_ls,
+                                                                 const u16 *__restrict__ W, const float *__restrict__ dres,
+                                                                 float *__restrict__ dx, float *__restrict__ dpos, int pos_cols)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem4[];
+    u16 *As = reinterpret_cast<u16 *>(smem4);  // [16][N + 8] bf16: the dy panel
+    const int AS = N + kAPad;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const long r0 = (long)blockIdx.x * kTM;
+    const int n0 = w * kBW, li = lane & 15, lg = lane >> 4;
+    const u16 *wp = W + (long)(8 * lg) * K + n0 + 8 * li;
+    const int ksteps = N / 32;
+    uint4 wq[2][8];
+    auto fetch = [&](uint4(&dst)[8], int kt) {
+        const int kk = kt < ksteps ? kt : ksteps - 1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dst[j] = *reinterpret_cast<const uint4 *>(wp + (long)(32 * kk + j) * K);
+    };
+    fetch(wq[0], 0);
+    fetch(wq[1], 1);
+    // the residual gradient of this lane's outputs: requested here, consumed after the products
+    float4 rs[4][2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const long row = r0 + 4 * lg + r;
+        rs[r][0] = rs[r][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (dres != nullptr && row < R) {
+            rs[r][0] = *reinterpret_cast<const float4 *>(dres + row * K + n0 + 8 * li);
+            rs[r][1] = *reinterpret_cast<const float4 *>(dres + row * K + n0 + 8 * li + 4);
+        }
+    }
+    panel_bf16<kTM, 64 * NW, 4>(dy, dy_ls, r0, R, N, As, AS, tid);
+    __syncthreads();
+    f4v acc[8], accp[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = accp[j] = f4v{0.f, 0.f, 0.f, 0.f};
+    auto multiply = [&](const uint4(&q)[8], int kt) {
+        const bf8 af = lds_bf8(As + li * AS + 32 * kt + 8 * lg);
+        const uint32_t(&u)[8][4] = reinterpret_cast<const uint32_t(&)[8][4]>(q);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint4 b;
+            uint32_t *bd = reinterpret_cast<uint32_t *>(&b);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const uint32_t lo = u[2 * d][j >> 1], hi = u[2 * d + 1][j >> 1];
+                bd[d] = (j & 1) ? ((lo >> 16) | (hi & 0xFFFF0000u)) : ((lo & 0xFFFFu) | (hi << 16));
+            }
+            acc[j] = PCM_MFMA_16x16x32(af, as_bf8(b), acc[j]);
+        }
+    };
+    const int ksnap = (dpos != nullptr && pos_cols < N) ? pos_cols / 32 : -1;  // k-step in front of which the accumulators are dpos
+    for (int kt = 0; kt < ksteps; kt += 2) {
+        if (kt == ksnap) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) accp[j] = acc[j];
+        }
+        multiply(wq[0], kt);
+        fetch(wq[0], kt + 2);
+        if (kt + 1 < ksteps) {
+            if (kt + 1 == ksnap) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) accp[j] = acc[j];
+            }
+            multiply(wq[1], kt + 1);
+            fetch(wq[1], kt + 3);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const long row = r0 + 4 * lg + r;
+        if (row >= R) continue;
+        float *o = dx + row * K + n0 + 8 * li;
+        *reinterpret_cast<float4 *>(o) = make_float4(acc[0][r] + rs[r][0].x, acc[1][r] + rs[r][0].y, acc[2][r] + rs[r][0].z, acc[3][r] + rs[r][0].w);
+        *reinterpret_cast<float4 *>(o + 4) = make_float4(acc[4][r] + rs[r][1].x, acc[5][r] + rs[r][1].y, acc[6][r] + rs[r][1].z, acc[7][r] + rs[r][1].w);
+        if (dpos != nullptr) {
+            float *p = dpos + row * K + n0 + 8 * li;
+            if (ksnap >= 0) {
+                *reinterpret_cast<float4 *>(p) = make_float4(accp[0][r], accp[1][r], accp[2][r], accp[3][r]);
+                *reinterpret_cast<float4 *>(p + 4) = make_float4(accp[4][r], accp[5][r], accp[6][r], accp[7][r]);
+            } else {  // pos_cols >= N: the position embedding sees the whole product (without the residual's share)
+                *reinterpret_cast<float4 *>(p) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+                *reinterpret_cast<float4 *>(p + 4) = make_float4(acc[4][r], acc[5][r], acc[6][r], acc[7][r]);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// N: a multiple of 32 up to 3072 (the dy panel: 16 x (N + 8) bf16 of LDS); K in {256, 512, 1024}; pos_cols: a multiple of 32, or >= N
+extern "C" int pcm_linear_mfma_backward_supported(int N, int K, int pos_cols)
+{
+    return N >= 32 && N <= 3072 && N % 32 == 0 && (K == 256 || K == 512 || K == 1024) && pos_cols >= 0 && (pos_cols >= N || pos_cols % 32 == 0);
+}
+
+extern "C" int pcm_linear_mfma_backward_hip(long R, int N, int K, const void *dy_bf16, long dy_ls, const void *w_bf16, const float *dres,
+                                            float *dx, float *dpos, int pos_cols, void *stream)
+{
+    if (R < 0 || N <= 0 || K <= 0 || dy_ls < N) return PCM_ERR_BAD_ARG;
+    if (!pcm_linear_mfma_backward_supported(N, K, pos_cols)) return PCM_ERR_UNSUPPORTED;
+    if (R == 0) return PCM_OK;
+    if (!dy_bf16 || !w_bf16 || !dx) return PCM_ERR_BAD_ARG;
+    if ((dy_ls % 8) != 0 || (((uintptr_t)dy_bf16 | (uintptr_t)w_bf16 | (uintptr_t)dx | (uintptr_t)dpos | (uintptr_t)dres) % 16) != 0) return PCM_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned blocks = (unsigned)((R + kTM - 1) / kTM);
+    const size_t smem = (size_t)kTM * (N + kAPad) * 2;
+#define PCM_LB(NWV)                                                                                                                     \
+    do {                                                                                                                               \
+        if (smem > 64 * 1024) {                                                                                                        \
+            const int rc_ = pcm_status(hipFuncSetAttribute(reinterpret_cast<const void *>(pcm_linear_bwd_kernel<NWV>),                 \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));                    \
+            if (rc_) return rc_;                                                                                                       \
+        }                                                                                                                              \
+        hipLaunchKernelGGL(pcm_linear_bwd_kernel<NWV>, dim3(blocks), dim3(64 * NWV), smem, st, R, N, K, (const u16 *)dy_bf16, dy_ls,     \
+                           (const u16 *)w_bf16, dres, dx, dpos, pos_cols);                                                             \
+    } while (0)
+    if (K == 256) PCM_LB(2);
+    else if (K == 512) PCM_LB(4);
+    else PCM_LB(8);
+#undef PCM_LB
+    return PCM_LAUNCH_STATUS();
+}

@@ -209,6 +209,32 @@ PROJ_MFMA_LONG_ROWS = 2048  # csrc/proj_ln.hip kLongRows
 PROJ_MFMA_BWD = os.environ.get("PCM_PROJ_MFMA_BWD", "0") != "0"
 
 
+# ... and the input gradient of the short in-projections / the query projection (pcm_linear_mfma_backward: dx = dy W + dres and the position
+# embedding's share in one launch instead of a batched product + an add kernel); same status
+LINEAR_MFMA_BWD = os.environ.get("PCM_LINEAR_MFMA_BWD", "0") != "0"
+
+
+def _linear_bwd_mfma_ok(dy2, ld, N, wc, pos_cols):
+    rows = dy2.shape[0]
+    return (LINEAR_MFMA_BWD and dy2.is_cuda and 0 < rows <= PROJ_MFMA_MAX_ROWS and dy2.dtype == torch.bfloat16 and wc.dtype == torch.bfloat16
+            and wc.is_contiguous() and wc.shape[0] == N and ld % 8 == 0 and dy2.data_ptr() % 16 == 0 and wc.data_ptr() % 16 == 0
+            and bool(_lib.load().pcm_linear_mfma_backward_supported(int(N), int(wc.shape[1]), int(pos_cols))))
+
+
+def _linear_mfma_backward(dy_ptr_tensor, rows, ld, N, wc, dres, want_dpos, pos_cols):
+    """dx (rows, K) fp32 = dy (rows, N; row stride ld) @ wc (N, K) [+ dres]; dpos = dy[:, :pos_cols] @ wc[:pos_cols] when wanted."""
+    K = int(wc.shape[1])
+    dev = dy_ptr_tensor.device
+    with torch.cuda.device(dev):
+        dx = torch.empty(rows, K, dtype=torch.float32, device=dev)
+        dpos = torch.empty(rows, K, dtype=torch.float32, device=dev) if want_dpos else None
+        rc = _lib.load().pcm_linear_mfma_backward_hip(rows, int(N), K, dy_ptr_tensor.data_ptr(), int(ld), wc.data_ptr(),
+                                                      dres.data_ptr() if dres is not None else 0, dx.data_ptr(),
+                                                      dpos.data_ptr() if dpos is not None else 0, int(pos_cols), _raw_stream())
+    _lib.check(rc, "pcm_linear_mfma_backward_hip")
+    return dx, dpos
+
+
 LINEAR_MFMA = os.environ.get("PCM_LINEAR_MFMA", "0") != "0"  # csrc/proj_ln.hip pcm_linear_mfma: same status as PROJ_MFMA (opt-in, untimed)
 
 
@@ -690,10 +716,13 @@ class _SelfAttnInProj(Function):
                      and dq.stride()[-2:] == (3 * E, 1) and dk.data_ptr() - dq.data_ptr() == E * es2
                      and dv.data_ptr() - dq.data_ptr() == 2 * E * es2
                      and all(dq.stride(i) == dq.stride(i + 1) * dq.shape[i + 1] for i in range(dq.dim() - 2)))
+            fused_dx = joint and _linear_bwd_mfma_ok(torch.as_strided(dq, (rows, 3 * E), (3 * E, 1)), 3 * E, 3 * E, wc, 2 * E)
             if joint:
                 # dq | dk | dv side by side (small_attn's layout for short self-attention): the three input gradients as ONE
-                # batched product (3 x (rows, E) @ (E, E): 9 us; dqk @ W_qk and dv @ W_v as two: 14.5 us)
-                d3 = torch.bmm(torch.as_strided(dq, (3, rows, E), (E, 3 * E, 1)), wc.view(3, E, E))
+                # batched product (3 x (rows, E) @ (E, E): 9 us; dqk @ W_qk and dv @ W_v as two: 14.5 us) -- or, opt-in, as one
+                # matrix-core launch that also adds the residual's gradient and splits off the position share (LINEAR_MFMA_BWD)
+                if not fused_dx:
+                    d3 = torch.bmm(torch.as_strided(dq, (3, rows, E), (E, 3 * E, 1)), wc.view(3, E, E))
                 dqk = torch.as_strided(dq, (rows, 2 * E), (3 * E, 1))
                 dv2 = torch.as_strided(dv, (rows, E), (3 * E, 1))
                 ld_qk = ld_v = 3 * E
@@ -713,21 +742,29 @@ class _SelfAttnInProj(Function):
                 d_qk_in = dqk @ wc[: 2 * E]
                 d_v_in = dv2 @ wc[2 * E:]
                 ld_qk, ld_v = 2 * E, E
-            dx = torch.empty(rows, E, dtype=torch.float32, device=dev)
-            # the position gradient is d_qk_in alone: widened by the same launch when it has the shape of x (query_pos)
-            dpos32 = torch.empty(rows, E, dtype=torch.float32, device=dev) if (pos_grad and tuple(pos_shape) == tuple(shape)) else None
             if dres is not None:
                 dres = dres.reshape(rows, E)
                 if dres.dtype != torch.float32 or not dres.is_contiguous():
                     dres = dres.float().contiguous()
-            if joint:
+            dpos_wide = None
+            if fused_dx:
+                dx, dpos_wide = _linear_mfma_backward(dq, rows, 3 * E, 3 * E, wc, dres, pos_grad, 2 * E)
+                dpos32 = dpos_wide if (pos_grad and tuple(pos_shape) == tuple(shape)) else None
+            else:
+                dx = torch.empty(rows, E, dtype=torch.float32, device=dev)
+                # the position gradient is d_qk_in alone: widened by the same launch when it has the shape of x (query_pos)
+                dpos32 = torch.empty(rows, E, dtype=torch.float32, device=dev) if (pos_grad and tuple(pos_shape) == tuple(shape)) else None
+            if fused_dx:
+                pass
+            elif joint:
                 rc = L.pcm_add4_cast2_hip(dx.numel(), d3[0].data_ptr(), d3[1].data_ptr(), d3[2].data_ptr(),
                                           dres.data_ptr() if dres is not None else 0, dx.data_ptr(),
                                           dpos32.data_ptr() if dpos32 is not None else 0, st)
             else:
                 rc = L.pcm_add3_cast2_hip(dx.numel(), d_qk_in.data_ptr(), d_v_in.data_ptr(), dres.data_ptr() if dres is not None else 0,
                                           dx.data_ptr(), dpos32.data_ptr() if dpos32 is not None else 0, st)
-            _lib.check(rc, "pcm_add3_cast2_hip")
+            if not fused_dx:
+                _lib.check(rc, "pcm_add3_cast2_hip")
             dw = deferred.take((3 * E, E), wdt, dev, "in_proj.dw")
             defer = deferred.clear(*ctx.defer)
             weight_grad(dqk, qk_in, wdt, out=dw[: 2 * E], side=ctx.side_ok, defer=defer, tag="in_proj.qk")
@@ -746,7 +783,7 @@ class _SelfAttnInProj(Function):
             if dpos32 is not None:
                 dpos = dpos32.view(shape)
             elif pos_grad:
-                dpos = ((d3[0].float() + d3[1].float()) if joint else d_qk_in.float()).view(shape).sum_to_size(pos_shape)
+                dpos = (dpos_wide if fused_dx else ((d3[0].float() + d3[1].float()) if joint else d_qk_in.float())).view(shape).sum_to_size(pos_shape)
             if ctx.sink is not None and dpos is not None:
                 ctx.sink.add(dpos)
                 dpos = None
@@ -815,7 +852,10 @@ class _AddPosLinear(Function):
         dx = dpos = dw = db = None
         with torch.cuda.device(dy.device), torch.autocast("cuda", enabled=False):
             if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.sink is not None:
-                d_in = torch.mm(dy2, wc, out_dtype=torch.float32).view(shape)  # fp32 out of the bf16 GEMM: no cast kernel
+                if _linear_bwd_mfma_ok(dy2, int(dy2.stride(0)), int(wc.shape[0]), wc, int(wc.shape[0])):  # opt-in, LINEAR_MFMA_BWD
+                    d_in = _linear_mfma_backward(dy2, dy2.shape[0], int(dy2.stride(0)), int(wc.shape[0]), wc, None, False, int(wc.shape[0]))[0].view(shape)
+                else:
+                    d_in = torch.mm(dy2, wc, out_dtype=torch.float32).view(shape)  # fp32 out of the bf16 GEMM: no cast kernel
                 dx = d_in if ctx.needs_input_grad[0] else None
                 if ctx.sink is not None:
                     ctx.sink.add(d_in.sum_to_size(pos_shape))

@@ -349,8 +349,9 @@ def test_bench_headline_kernel_set_is_not_chosen_at_run_time(monkeypatch):
     src = open(bench.__file__).read()
     assert "choose_projection_chain" not in src and "--chain-trial" not in src and "--no-chain-selection" not in src
     saved = (fused_ops.PROJ_MFMA, fused_ops.LINEAR_MFMA, fused_ops.PROJ_MFMA_LONG)
+    saved_bwd = (fused_ops.PROJ_MFMA_BWD, fused_ops.LINEAR_MFMA_BWD)
     try:
-        fused_ops.PROJ_MFMA = fused_ops.LINEAR_MFMA = fused_ops.PROJ_MFMA_LONG = False
+        fused_ops.PROJ_MFMA = fused_ops.LINEAR_MFMA = fused_ops.PROJ_MFMA_LONG = fused_ops.PROJ_MFMA_BWD = fused_ops.LINEAR_MFMA_BWD = False
         info = bench.projection_chain_setting()
         assert info["selected"] == "library products" and "opt-in" in info["reason"]
         fused_ops.PROJ_MFMA, fused_ops.PROJ_MFMA_LONG = True, True
@@ -358,6 +359,7 @@ def test_bench_headline_kernel_set_is_not_chosen_at_run_time(monkeypatch):
         assert "mfma" in info["selected"] and "long" in info["selected"] and "environment" in info["reason"]
     finally:
         fused_ops.PROJ_MFMA, fused_ops.LINEAR_MFMA, fused_ops.PROJ_MFMA_LONG = saved
+        fused_ops.PROJ_MFMA_BWD, fused_ops.LINEAR_MFMA_BWD = saved_bwd
 
 
 def test_bench_auto_mode_is_a_ladder_that_only_moves_on_an_exception(monkeypatch):

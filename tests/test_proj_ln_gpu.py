@@ -455,3 +455,114 @@ def test_fused_node_backward_with_and_without_the_chain_kernel(monkeypatch, p):
         tol = 2e-2 if name == "da" else (1e-2 if name == "db" else 2e-5)
         assert (got - want).abs().max().item() <= tol * scale + 1e-6, (name, (got - want).abs().max().item(), scale)
     assert torch.equal(runs[True][1], runs[False][1])  # dx: the same bits
+
+
+# ------------------------------------------------------------------------------------- pcm_linear_mfma_backward (round 6)
+def _lin_bwd(dy, W, dres, pos_cols, want_dpos, N=None):
+    from pointcloudmatters_amd import _lib
+
+    L = _lib.load()
+    R, K = dy.shape[0], W.shape[1]
+    N = W.shape[0] if N is None else N
+    dx = torch.full((R, K), 7.0, dtype=torch.float32, device=dy.device)
+    dpos = torch.full((R, K), 7.0, dtype=torch.float32, device=dy.device) if want_dpos else None
+    rc = L.pcm_linear_mfma_backward_hip(R, N, K, dy.data_ptr(), dy.stride(0), W.data_ptr(), dres.data_ptr() if dres is not None else 0,
+                                        dx.data_ptr(), dpos.data_ptr() if dpos is not None else 0, pos_cols, _lib.raw_stream())
+    _lib.check(rc, "pcm_linear_mfma_backward_hip")
+    torch.cuda.synchronize()
+    return dx, dpos
+
+
+@pytest.mark.parametrize("R,N,K,pos_cols", [(800, 1536, 512, 1024), (816, 1536, 512, 1024), (800, 512, 512, 512), (37, 768, 256, 512), (1, 96, 256, 32),
+                                            (100, 3072, 1024, 2048), (129, 64, 512, 64), (50, 1536, 512, 0)])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_linear_backward_matches_the_fp64_products(R, N, K, pos_cols, with_res):
+    """dx = dy W + dres and dpos = dy[:, :pos_cols] W[:pos_cols] against fp64 products of the same bf16 operands: the matrix cores accumulate
+    in fp32 (no intermediate bf16 rounding, unlike the batched library product + add kernel this replaces), so the bound is fp32 summation
+    noise over N terms."""
+    g = torch.Generator().manual_seed(R + N)
+    wide = torch.randn(R, N + 64, generator=g).bfloat16().to(DEV)      # dy as a strided view of a wider buffer (dq | dk | dv inside more)
+    dy = wide[:, :N]
+    W = (torch.randn(N, K, generator=g) / N ** 0.5).bfloat16().to(DEV)
+    dres = torch.randn(R, K, generator=g).to(DEV) if with_res else None
+    dx, dpos = _lin_bwd(dy, W, dres, pos_cols, True)
+    want = dy.double() @ W.double()
+    wpos = dy[:, :pos_cols].double() @ W[:pos_cols].double() if pos_cols < N else want
+    tol = 3e-6 * N ** 0.5 * max(1.0, want.abs().max().item())
+    assert (dx.double() - (want + (dres.double() if with_res else 0))).abs().max().item() <= tol
+    assert (dpos.double() - wpos).abs().max().item() <= tol
+    dx2, none = _lin_bwd(dy, W, dres, pos_cols, False)
+    assert none is None and torch.equal(dx2, dx)
+
+
+def test_linear_backward_contract():
+    from pointcloudmatters_amd import _lib
+
+    L = _lib.load()
+    assert L.pcm_linear_mfma_backward_supported(1536, 512, 1024) == 1 and L.pcm_linear_mfma_backward_supported(1536, 384, 1024) == 0
+    assert L.pcm_linear_mfma_backward_supported(1530, 512, 1024) == 0 and L.pcm_linear_mfma_backward_supported(512, 512, 500) == 0
+    assert L.pcm_linear_mfma_backward_supported(512, 512, 512) == 1 and L.pcm_linear_mfma_backward_supported(4096, 512, 0) == 0
+    assert L.pcm_linear_mfma_backward_hip(-1, 512, 512, 0, 512, 0, 0, 0, 0, 512, 0) == 1   # negative size
+    assert L.pcm_linear_mfma_backward_hip(0, 512, 512, 0, 512, 0, 0, 0, 0, 512, 0) == 0    # empty call
+    assert L.pcm_linear_mfma_backward_hip(16, 512, 384, 0, 512, 0, 0, 0, 0, 512, 0) == 2   # unsupported width
+    assert L.pcm_linear_mfma_backward_hip(16, 512, 512, 0, 256, 0, 0, 0, 0, 512, 0) == 1   # row stride below N
+
+
+class _JointGrads(torch.autograd.Function):
+    """Hands q, k, v the three column blocks of ONE (rows, 3E) gradient buffer, the layout csrc/attn_small.hip's backward writes."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, g3):
+        ctx.save_for_backward(g3)
+        return (q.float().sum() + k.float().sum() + v.float().sum()) * 0.0
+
+    @staticmethod
+    def backward(ctx, g):
+        (g3,) = ctx.saved_tensors
+        E = g3.shape[-1] // 3
+        return g3[..., :E], g3[..., E:2 * E], g3[..., 2 * E:], None
+
+
+@pytest.mark.parametrize("batch_first_pos", [True, False])  # pos (1, Lq, E): broadcast over the batch, its gradient is summed; (B, Lq, E): x's shape
+def test_in_projection_backward_with_and_without_the_matrix_core_kernel(monkeypatch, batch_first_pos):
+    """The self-attention in-projection node's and the query-projection node's backward with LINEAR_MFMA_BWD on against the batched library
+    product + add kernel / the library product: dx (residual gradient folded in), dpos, and the weight / bias gradients (unchanged path)."""
+    import torch.nn as nn
+
+    from pointcloudmatters_amd.policy import fused_ops
+
+    torch.manual_seed(11)
+    E, Lq, B = 512, 100, 8
+    mha = nn.MultiheadAttention(E, 8).to(DEV)
+    lin = nn.Linear(E, E).to(DEV)
+    x0 = torch.randn(B, Lq, E, device=DEV)
+    pos0 = torch.randn(1 if batch_first_pos else B, Lq, E, device=DEV)
+    g3 = torch.randn(B, Lq, 3 * E, device=DEV).bfloat16()
+    gy, gres = torch.randn(B, Lq, E, device=DEV).bfloat16(), torch.randn(B, Lq, E, device=DEV)
+    called, orig = [], fused_ops._lib.check
+
+    def check(rc, what, *args, **kw):
+        called.append(what)
+        return orig(rc, what, *args, **kw)
+
+    monkeypatch.setattr(fused_ops._lib, "check", check)
+    runs = {}
+    for flag in (False, True):
+        monkeypatch.setattr(fused_ops, "LINEAR_MFMA_BWD", flag)
+        x, pos = x0.clone().requires_grad_(True), pos0.clone().requires_grad_(True)
+        for p_ in list(mha.parameters()) + list(lin.parameters()):
+            p_.grad = None
+        ctx = fused_ops.FusedContext(torch.device(DEV))
+        with fused_ops.activate(ctx), torch.autocast("cuda", dtype=torch.bfloat16):
+            q, k, v, xr = fused_ops.self_attn_in_proj(x, pos, mha)
+            y = fused_ops.add_pos_linear(x.detach().requires_grad_(True), pos, lin.weight, lin.bias)
+        called.clear()
+        (_JointGrads.apply(q, k, v, g3) + (xr * gres).sum() + (y * gy).float().sum()).backward()
+        torch.cuda.synchronize()
+        assert (called.count("pcm_linear_mfma_backward_hip") == 2) == flag, called
+        assert ("pcm_add3_cast2_hip" in called) != flag, called
+        runs[flag] = [x.grad, pos.grad, mha.in_proj_weight.grad.float(), mha.in_proj_bias.grad.float(), lin.weight.grad.float(), lin.bias.grad.float()]
+    for got, want, name in zip(runs[True], runs[False], ("dx", "dpos", "dW_in", "db_in", "dW", "db")):
+        scale = want.abs().max().item()
+        tol = 2e-2 if name in ("dx", "dpos") else 1e-6
+        assert (got - want).abs().max().item() <= tol * scale + 1e-6, (name, (got - want).abs().max().item(), scale)

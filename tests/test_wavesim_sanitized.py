@@ -25,7 +25,7 @@ def test_kernel_sources_pass_their_parity_tests_under_asan_ubsan():
     env.pop("PCM_WAVESIM_FULL", None)
     sel = ("fps_bit_exact or knn_bit_exact or ball_query_bit_exact or random_ball or grouping or interpolation or segsum_gpu__ or "
            "sa_fused_gpu__fused_matches or proj_ln_gpu__projection_residual or proj_ln_gpu__linear_from or proj_ln_gpu__consumer or "
-           "bn_relu_gpu__bn_without or proj_ln_gpu__backward_chain")
+           "bn_relu_gpu__bn_without or proj_ln_gpu__backward_chain or proj_ln_gpu__linear_backward")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", "tests/test_wavesim_parity.py", "-k", sel],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=1800)
     text = r.stdout + r.stderr

@@ -3,6 +3,7 @@
   B  packed in-projection:        pcm_add_cast2_hip + the doubled-row product [x + pos ; x] W^T  vs  pcm_linear_mfma_forward_hip (fp32 x + pos in)
   C  query projection:            pcm_add_cast2_hip + library product                          vs  pcm_linear_mfma_forward_hip
   D  backward of A (800 / 816 rows): pcm_drln_backward2_hip + library product dy @ W           vs  pcm_proj_drln_mfma_backward_hip (round 6)
+  E  backward of B's input (800 / 816): batched product 3 x (R, E) @ (E, E) + pcm_add4_cast2_hip  vs  pcm_linear_mfma_backward_hip (round 6)
 at the row counts of the ACT step (decoder 800, CVAE encoder 816, encoder 4120 at C2).  Written in round 5 while the GPU pool was closed:
 the FIRST thing to run when it opens --   python tools/mb/mb_proj_ln.py > gpurun_out/mb_proj_ln.log"""
 import os
@@ -86,11 +87,23 @@ for R in (800, 816, 4120):
                                                  seed.data_ptr(), 3, W.data_ptr(), dx.data_ptr(), dy16.data_ptr(), da16.data_ptr(), E,
                                                  part_new.data_ptr(), sums.data_ptr(), db16.data_ptr(), st) == 0
 
-    for fn in (lib_a, new_a, lib_b, new_b, lib_c, new_c, lib_d, new_d):
+    d3y = torch.randn(R, 3 * E, **f32).bfloat16()
+    dres, dx32, dpos32 = torch.randn(R, E, **f32), torch.empty(R, E, **f32), torch.empty(R, E, **f32)
+
+    def lib_e(st):
+        d3 = torch.bmm(torch.as_strided(d3y, (3, R, E), (E, 3 * E, 1)), W3.view(3, E, E))
+        assert L.pcm_add4_cast2_hip(dx32.numel(), d3[0].data_ptr(), d3[1].data_ptr(), d3[2].data_ptr(), dres.data_ptr(), dx32.data_ptr(), dpos32.data_ptr(), st) == 0
+
+    def new_e(st):
+        assert L.pcm_linear_mfma_backward_hip(R, 3 * E, E, d3y.data_ptr(), 3 * E, W3.data_ptr(), dres.data_ptr(), dx32.data_ptr(), dpos32.data_ptr(), 2 * E, st) == 0
+
+    ALL = (lib_a, new_a, lib_b, new_b, lib_c, new_c, lib_d, new_d) + ((lib_e, new_e) if R <= 1024 else ())
+    for fn in ALL:
         fn(torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
-    t = {fn.__name__: graphed(fn) for fn in (lib_a, new_a, lib_b, new_b, lib_c, new_c, lib_d, new_d)}
+    t = {fn.__name__: graphed(fn) for fn in ALL}
     print(f"R={R:5d}  A out_proj+res+norm: library pair {t['lib_a']:6.1f} us  proj_ln {t['new_a']:6.1f} us   "
           f"B in-projection: add_cast + doubled product {t['lib_b']:6.1f} us  linear_mfma {t['new_b']:6.1f} us   "
           f"C query projection: {t['lib_c']:6.1f} us  linear_mfma {t['new_c']:6.1f} us   "
-          f"D backward of A: drln_bwd + reduce + dy @ W {t['lib_d']:6.1f} us  chain kernel + reduce {t['new_d']:6.1f} us", flush=True)
+          f"D backward of A: drln_bwd + reduce + dy @ W {t['lib_d']:6.1f} us  chain kernel + reduce {t['new_d']:6.1f} us"
+          + (f"   E in-projection input gradient: bmm + add4 {t['lib_e']:6.1f} us  linear_mfma_backward {t['new_e']:6.1f} us" if 'lib_e' in t else ""), flush=True)

@@ -40,7 +40,7 @@ PCM_PROJ_MFMA=1 PCM_LINEAR_MFMA=1 PCM_PROJ_MFMA_LONG=0 timeout 600 python bench.
 echo "bench (mfma chain, short sites) rc=$?"; cut -c1-200 "$OUT/bench_mfma_short.json"
 PCM_PROJ_MFMA=1 PCM_LINEAR_MFMA=1 PCM_PROJ_MFMA_LONG=1 timeout 600 python bench.py --no-cpu-baseline --no-roofline --no-extra --emit-warmup-losses > "$OUT/bench_mfma_long.json" 2> "$OUT/bench_mfma_long.err"
 echo "bench (mfma chain, short + long sites) rc=$?"; cut -c1-200 "$OUT/bench_mfma_long.json"
-PCM_PROJ_MFMA=1 PCM_LINEAR_MFMA=1 PCM_PROJ_MFMA_BWD=1 timeout 600 python bench.py --no-cpu-baseline --no-roofline --no-extra --emit-warmup-losses > "$OUT/bench_mfma_short_bwd.json" 2> "$OUT/bench_mfma_short_bwd.err"
+PCM_PROJ_MFMA=1 PCM_LINEAR_MFMA=1 PCM_PROJ_MFMA_BWD=1 PCM_LINEAR_MFMA_BWD=1 timeout 600 python bench.py --no-cpu-baseline --no-roofline --no-extra --emit-warmup-losses > "$OUT/bench_mfma_short_bwd.json" 2> "$OUT/bench_mfma_short_bwd.err"
 echo "bench (mfma chain, short sites, forward + backward) rc=$?"; cut -c1-200 "$OUT/bench_mfma_short_bwd.json"
 PCM_PROJ_MFMA=0 PCM_LINEAR_MFMA=0 timeout 600 python bench.py --no-cpu-baseline --no-roofline --no-extra --emit-warmup-losses > "$OUT/bench_lib_losses.json" 2> "$OUT/bench_lib_losses.err"
 echo "bench (library products, with warm-up losses) rc=$?"; cut -c1-200 "$OUT/bench_lib_losses.json"
