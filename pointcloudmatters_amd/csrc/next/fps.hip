@@ -84,7 +84,7 @@ __device__ __forceinline__ uint32_t fps_block_argmax(uint32_t bits, uint32_t pri
     return fps_unprio(~(uint32_t)key, L);
 }
 
-typedef float fps_f2 __attribute__((ext_vector_type(2)));  // a point pair; the build has no packed-fp32 instructions (Makefile NO_PK): two scalar chains
+typedef float fps_f2 __attribute__((ext_vector_type(2)));  // a point pair: packed fp32 in this file (plain forms only, see the pick loop); csrc/fps.hip (frozen, NO_PK): two scalar chains
 
 // Wave-wide unsigned max in 6 DPP-fused instructions + 1 readlane (the builtin form costs a v_mov + s_nop + v_mov_dpp +
 // v_max per step and 4 readlanes): quad swaps, row_half_mirror, row_mirror leave every row's maximum in all of its lanes,
@@ -186,7 +186,15 @@ __global__ __launch_bounds__(T) void pcm_fps_reg_kernel(const float *__restrict_
     for (int it = 1; it < M; ++it) {
         float best = -1.f;
         int bs = 0;
-        const fps_f2 o2x = (fps_f2)(ox), o2y = (fps_f2)(oy), o2z = (fps_f2)(oz);
+        // PACKED fp32 again, in its safe forms only (round 6; this file alone is built without the Makefile's NO_PK).  The hazard of this
+        // stack (tools/dbg/pk_hazard: measured on hardware in round 4) is specific to v_pk_*_f32 with OP_SEL set -- what
+        // the compiler emits for `pair - splat(scalar)`; plain forms, op_sel_hi and neg modifiers were exact in every run beside a GEMM graph.
+        // The pick's centre is therefore made a REAL pair in two registers and hidden from the compiler (the empty asm): it can no longer
+        // fold the splat into an operand-half select, and every packed instruction of this file is plain or neg-modified
+        // (tests/test_build_flags.py checks the assembly).  Same roundings as the scalar chain: a packed add / mul rounds each half on its own.
+        // 8 packed instead of 16 scalar operations per point pair: the per-pick issue budget of DESIGN.md section 10 item 6.
+        fps_f2 o2x = (fps_f2)(ox), o2y = (fps_f2)(oy), o2z = (fps_f2)(oz);
+        asm volatile("" : "+v"(o2x), "+v"(o2y), "+v"(o2z));
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             // pcm_sqdist on two points at once: (a-b)*(a-b) for x, y, z summed left to right, every op rounded on its own
