@@ -23,6 +23,11 @@ if [ -f "$BASE" ]; then
       tests/test_small_attn_gpu.py tests/test_flash_attn_gpu.py tests/test_tokens_gpu.py tests/test_xfer_gpu.py tests/test_sa_fused_gpu.py tests/test_bn_relu_gpu.py \
       -m gpu -q -p no:cacheprovider > "$OUT/gpu_tests_next.log" 2>&1
   echo "suite (lib_next, rewritten files' tests) rc=$?" | tee -a "$OUT/gpu_tests_next.log"; tail -2 "$OUT/gpu_tests_next.log"
+  # next/fps.hip uses packed fp32 (plain forms only): its bit-exact tests BESIDE a busy device (a replayed GEMM graph on another stream), the
+  # load under which round 4's hazard showed
+  PCM_TEST_BUSY=1 PCM_POINTOPS_LIB=$BASE timeout 600 python -m pytest tests/test_pointops_gpu.py tests/test_pointops_fuzz_gpu.py -k "fps" \
+      -m gpu -q -p no:cacheprovider > "$OUT/gpu_tests_next_fps_busy.log" 2>&1
+  echo "FPS tests on lib_next beside a busy device rc=$?"; tail -1 "$OUT/gpu_tests_next_fps_busy.log"
 fi
 timeout 900 python bench.py --tables-out "$OUT/bench_tables.json" > "$OUT/bench.json" 2> "$OUT/bench.err"
 echo "bench rc=$?"
