@@ -20,9 +20,17 @@ def _rewritten(src):
     return p if os.path.exists(p) else os.path.join(CSRC, src)
 
 
+def _next_pk_files():
+    mk = open(os.path.join(CSRC, "Makefile")).read()
+    m = re.search(r"^NEXT_PK_FILES\s*:=\s*(.+)$", mk, re.M)
+    assert m and re.search(r"^\$\(NEXT_PK_FILES:%=next/%\.next\.o\): NO_PK =\s*$", mk, re.M), "the Makefile must name the files of lib_next built with packed fp32"
+    return m.group(1).split()
+
+
 def _packed_allowed(path):
-    """csrc/next/fps.hip is the one file built WITH packed fp32 (Makefile: `next/fps.next.o: NO_PK =`), in its safe forms only."""
-    return os.path.abspath(path) == os.path.join(NEXT, "fps.hip")
+    """The files of csrc/next/ that lib_next builds WITH packed fp32 (Makefile NEXT_PK_FILES), in its safe forms only."""
+    path = os.path.abspath(path)
+    return os.path.dirname(path) == NEXT and os.path.basename(path)[:-4] in _next_pk_files()
 
 
 def _compile_to_asm(path, out, include_csrc=False):
@@ -30,7 +38,6 @@ def _compile_to_asm(path, out, include_csrc=False):
     flags = _flags()
     if _packed_allowed(path):
         mk = open(os.path.join(CSRC, "Makefile")).read()
-        assert re.search(r"^next/fps\.next\.o: NO_PK =\s*$", mk, re.M), "the Makefile must say that next/fps.hip is built with packed fp32"
         no_pk = re.search(r"^NO_PK\s*\?=\s*(.+)$", mk, re.M).group(1).split()
         i = next(k for k in range(len(flags)) if flags[k:k + len(no_pk)] == no_pk)
         flags = flags[:i] + flags[i + len(no_pk):]
@@ -55,7 +62,7 @@ def _flags():
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not installed")
-@pytest.mark.parametrize("src", ["fps.hip", "drln.hip", "next/knn.hip", "next/drln.hip", "bnact.hip", "proj_ln.hip"])
+@pytest.mark.parametrize("src", ["fps.hip", "drln.hip", "ffn.hip", "next/sa_fused.hip", "next/drln.hip", "bnact.hip", "proj_ln.hip"])
 def test_no_packed_fp32_instructions_in_device_code(src, tmp_path):
     asm = _compile_to_asm(os.path.join(CSRC, src), tmp_path / (os.path.basename(src) + ".s"))
     assert "amdgcn" in asm and "gfx950" in asm
@@ -340,3 +347,23 @@ def test_packed_fp32_in_next_fps_has_no_operand_half_select(tmp_path):
     assert not bad, bad[:3]
     mods = set(m for l in pk for m in re.findall(r"(op_sel_hi|neg_lo|neg_hi|op_sel|clamp)", l))
     assert mods <= {"neg_lo", "neg_hi"}, mods  # not even op_sel_hi (exact in round 4's runs, but not needed)
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not installed")
+@pytest.mark.parametrize("name", ["ffn", "attn_small", "attn_flash", "bnrelu", "tokens", "knn"])
+def test_packed_fp32_files_of_lib_next_have_no_op_sel_form(name, tmp_path):
+    """lib_next re-enables packed fp32 per FILE (csrc/Makefile NEXT_PK_FILES) where the compiler's output contains no v_pk_*_f32 with
+    OP_SEL set -- the only form the round-4 hardware reproducer found wrong beside another stream's MFMA work (op_sel_hi and neg modifiers,
+    which these files do use, were exact).  A source change that makes the compiler emit an OP_SEL form fails here; the file then goes back
+    under NO_PK or hides the broadcast operand like next/fps.hip does."""
+    assert name in _next_pk_files()
+    asm = _compile_to_asm(os.path.join(NEXT, name + ".hip"), tmp_path / (name + ".s"))
+    pk = re.findall(r"^\s*(v_pk_(?:add|mul|fma)_f32[^\n]*)$", asm, re.M)
+    assert len(pk) >= 40, len(pk)
+    bad = [l for l in pk if re.search(r"op_sel:", l)]
+    assert not bad, bad[:3]
+
+
+def test_files_that_keep_no_pk_in_lib_next():
+    """drln, sa_fused: the compiler emits OP_SEL forms there; optim: none, but nothing to gain (HBM-bound; the packed Adam kernel is 14 % longer)."""
+    assert sorted(set(FROZEN) - set(_next_pk_files())) == ["drln", "optim", "sa_fused"]

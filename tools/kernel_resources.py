@@ -42,7 +42,9 @@ def kernels_of(path):
     with tempfile.TemporaryDirectory() as td:
         asm = os.path.join(td, "k.s")
         flags = FLAGS
-        if os.path.abspath(path) == os.path.join(CSRC, "next", "fps.hip"):  # the one file built with packed fp32 (csrc/Makefile)
+        mk = open(os.path.join(CSRC, "Makefile")).read()
+        pk_files = re.search(r"^NEXT_PK_FILES\s*:=\s*(.+)$", mk, re.M).group(1).split()
+        if os.path.dirname(os.path.abspath(path)) == os.path.join(CSRC, "next") and os.path.basename(path)[:-4] in pk_files:  # built with packed fp32
             flags = [f for f in FLAGS if f not in ("-Xclang", "-target-feature", "-packed-fp32-ops")]
         r = subprocess.run(["/opt/rocm/bin/hipcc"] + flags + [path, "-o", asm], capture_output=True, text=True, timeout=900)
         if r.returncode != 0:
