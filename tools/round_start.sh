@@ -28,6 +28,10 @@ if [ -f "$BASE" ]; then
   PCM_TEST_BUSY=1 PCM_POINTOPS_LIB=$BASE timeout 600 python -m pytest tests/test_pointops_gpu.py tests/test_pointops_fuzz_gpu.py -k "fps" \
       -m gpu -q -p no:cacheprovider > "$OUT/gpu_tests_next_fps_busy.log" 2>&1
   echo "FPS tests on lib_next beside a busy device rc=$?"; tail -1 "$OUT/gpu_tests_next_fps_busy.log"
+  # ... and the other files lib_next builds with packed fp32 (op_sel_hi / neg forms only): their kernel-level tests beside a busy device
+  PCM_TEST_BUSY=1 PCM_POINTOPS_LIB=$BASE timeout 900 python -m pytest tests/test_small_attn_gpu.py tests/test_flash_attn_gpu.py tests/test_bn_relu_gpu.py \
+      tests/test_tokens_gpu.py tests/test_pointops_gpu.py -k "not fps" -m gpu -q -p no:cacheprovider > "$OUT/gpu_tests_next_pk_busy.log" 2>&1
+  echo "packed-fp32 files of lib_next beside a busy device rc=$?"; tail -1 "$OUT/gpu_tests_next_pk_busy.log"
 fi
 timeout 900 python bench.py --tables-out "$OUT/bench_tables.json" > "$OUT/bench.json" 2> "$OUT/bench.err"
 echo "bench rc=$?"
