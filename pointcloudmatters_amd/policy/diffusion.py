@@ -29,8 +29,11 @@ from .._lib import raw_stream as _raw_stream
 from .rows_linear import RowsLinear
 
 
-# the projector of PCDObsEncoder in row layout through csrc/bnrelu.hip (round 5; PCM_PROJECTOR_ROWS=0: the module path, for A/B)
-PROJECTOR_ROWS = os.environ.get("PCM_PROJECTOR_ROWS", "1") != "0"
+# the projector of PCDObsEncoder in row layout through csrc/bnrelu.hip + csrc/bnact.hip (round 5).  OPT-IN since round 6 (PCM_PROJECTOR_ROWS=1):
+# its last BatchNorm runs the pcm_bnact_* kernels, device code no GPU has executed yet, and the shipped default launches only kernels that
+# have a green hardware run (profiles/r06_summary.md).  Off: the module path of round 4 (framework BatchNorm / SyncBatchNorm for the
+# projector; data-parallel Diffusion-Policy runs then take the hybrid mode instead of the fully captured chain).
+PROJECTOR_ROWS = os.environ.get("PCM_PROJECTOR_ROWS", "0") != "0"
 
 
 # ----------------------------------------------------------------------------- U-Net pieces

@@ -83,6 +83,12 @@ def _build(kind):
 def _train(dev, batches, eps, distributed, kind="act", tsteps=None, mode="hybrid"):
     from pointcloudmatters_amd.bc import BCTrainer, clone_batch
 
+    if kind == "dp_graph" or (kind == "dp" and mode == "flat"):
+        # the projector in row layout (opt-in since round 6, PCM_PROJECTOR_ROWS): with it every BatchNorm of the policy is owned by a fused
+        # kernel -- what the captured N > 1 chain needs, and what the host-model twin of this test needs (no framework SyncBatchNorm on host tensors)
+        from pointcloudmatters_amd.policy import diffusion
+
+        diffusion.PROJECTOR_ROWS = True
     pol, optim = _build(kind)
     tr = BCTrainer(pol.to(dev), total_steps=20, precision="fp32", device=dev, mode=mode, distributed=distributed, optim=optim)
     losses = []
