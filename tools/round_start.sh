@@ -55,6 +55,11 @@ PCM_PROJ_MFMA=0 PCM_LINEAR_MFMA=0 timeout 600 python bench.py --no-cpu-baseline 
 echo "bench (library products, with warm-up losses) rc=$?"; cut -c1-200 "$OUT/bench_lib_losses.json"
 timeout 600 python bench.py --tokenizer-bf16 --no-cpu-baseline --no-roofline --no-extra > "$OUT/bench_tokenizer_bf16.json" 2> "$OUT/bench_tokenizer_bf16.err"
 echo "bench (tokenizer bf16, the round-4 recipe) rc=$?"; cut -c1-200 "$OUT/bench_tokenizer_bf16.json"
+# the Diffusion-Policy workload, projector as modules (default) and in row layout (opt-in: csrc/bnact.hip's first contact)
+timeout 600 python bench.py --workload C3 --no-cpu-baseline --no-roofline --no-extra > "$OUT/bench_c3.json" 2> "$OUT/bench_c3.err"
+echo "bench C3 rc=$?"; cut -c1-160 "$OUT/bench_c3.json"
+PCM_PROJECTOR_ROWS=1 timeout 600 python bench.py --workload C3 --no-cpu-baseline --no-roofline --no-extra > "$OUT/bench_c3_rows.json" 2> "$OUT/bench_c3_rows.err"
+echo "bench C3 (row-layout projector) rc=$?"; cut -c1-160 "$OUT/bench_c3_rows.json"
 cp -f "$GRAFT_REPO_ROOT/gpurun_out/pk_hazard.log" "$OUT/pk_hazard.log" 2>/dev/null  # written by tests/test_pk_hazard_gpu.py: copy to profiles/rNN_pk_hazard.log
 # the rocprofv3 kernel trace of the bench step on both builds: the per-kernel old-vs-new table of profiles/rNN_summary.md
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
