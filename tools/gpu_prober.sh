@@ -6,7 +6,7 @@ TAG=${1:-r06}
 EVERY=${2:-480}
 while true; do
   if [ -f /tmp/pcm_gpu_ready ]; then
-    /usr/local/graft/bin/gpurun --timeout 3300 -- "bash tools/round_start.sh $TAG" > /tmp/pcm_prober_last.log 2>&1
+    /usr/local/graft/bin/gpurun --timeout 4500 -- "bash tools/round_start.sh $TAG" > /tmp/pcm_prober_last.log 2>&1
     if ! grep -q "status=refused" /tmp/pcm_prober_last.log && ! grep -q "rc=3" /tmp/pcm_prober_last.log; then
       cp /tmp/pcm_prober_last.log /tmp/pcm_prober_done.log
       exit 0

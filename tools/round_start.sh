@@ -1,5 +1,5 @@
 #!/bin/bash
-# Run ON THE GPU BOX as the FIRST gpurun call of a round:   gpurun --timeout 3000 -- 'bash tools/round_start.sh r06'
+# Run ON THE GPU BOX as the FIRST gpurun call of a round:   gpurun --timeout 4500 -- 'bash tools/round_start.sh r06'
 # Rounds 4 - 6 had the GPU pool closed from outside the build; round 5 rewrote the device code of ten files without a hardware run.
 # The shipped library (lib/) carries the round-4 device code of those files (byte-identical to the last hardware-tested build,
 # tests/test_build_flags.py); the rewrites build into lib_next/ (`make -C pointcloudmatters_amd/csrc next`).  Every leg runs on both:
