@@ -1,12 +1,14 @@
 """GPU: the packed-fp32 hazard of this MI355X / ROCm stack as a recorded measurement (round-4 VERDICT item 8).
 
 tools/dbg/pk_hazard/pk_hazard.hip evaluates v_pk_add / mul / fma_f32 variants in a loop and compares every result IN REGISTER with the
-scalar computation (no memory race possible); tools/dbg/pk_hazard/run.py found in round 4 that the variants with an operand-half select
-(`op_sel` / `op_sel_hi`: what the compiler emits for `vector - scalar`) return wrong values when their wave shares a SIMD with another
-stream's MFMA kernels, and never on an idle device -- the reason csrc/Makefile builds the library without packed-fp32 instructions (NO_PK).
-This test re-measures it on every hardware run:
-  * the PLAIN packed add must be exact, idle and beside a replayed graph of library GEMMs (a wrong result there would be a new defect);
-  * the op_sel variants are RECORDED (printed, and written to gpurun_out/pk_hazard.log): a runtime / firmware update that fixes or widens
+scalar computation (no memory race possible); tools/dbg/pk_hazard/run.py found in round 4 that the variants with OP_SEL set (the LOW
+lane's source half: one of the forms the compiler emits for `vector - scalar`) return wrong values -- about one evaluation in a thousand --
+when their wave shares a SIMD with another stream's MFMA kernels, and never on an idle device; plain forms, `op_sel_hi` (add / mul / fma) and
+neg modifiers were exact.  The shipped library is built without packed-fp32 instructions altogether (csrc/Makefile
+NO_PK); lib_next (round 6) re-enables them per file where the compiler emits no OP_SEL form.  This test re-measures it on every hardware run:
+  * the forms lib_next relies on -- plain, op_sel_hi:[1,0] (add, add with neg, mul, fma op_sel_hi:[1,0,1]) and neg alone -- must be exact,
+    idle and beside a replayed graph of library GEMMs (a wrong result there would be a new defect, and lib_next must go back under NO_PK);
+  * the OP_SEL variants are RECORDED (printed, and written to gpurun_out/pk_hazard.log): a runtime / firmware update that fixes or widens
     the hazard becomes visible in the GPU test log instead of in a training run's loss curve."""
 import ctypes
 import os
@@ -23,7 +25,7 @@ NAMES = ["v_pk_add_f32 (plain)", "v_pk_add_f32 op_sel_hi:[1,0]", "v_pk_add_f32 o
          "v_pk_mul_f32 op_sel:[0,1]", "v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,0]", "v_pk_add_f32 neg_lo:[0,1] neg_hi:[0,1]"]
 
 
-def test_plain_packed_add_is_exact_and_the_op_sel_variants_are_recorded(hip_device, tmp_path):
+def test_safe_packed_forms_are_exact_and_the_op_sel_variants_are_recorded(hip_device, tmp_path):
     hipcc = "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not installed on this box")
@@ -73,4 +75,6 @@ def test_plain_packed_add_is_exact_and_the_op_sel_variants_are_recorded(hip_devi
     except OSError:
         pass
     assert rows[0][1] == 0 and rows[0][2] == 0, "the PLAIN packed add miscomputes: " + str(rows[0])
+    for v in (1, 2, 4, 5, 10):  # op_sel_hi forms and neg alone: what csrc/next/ (lib_next, NEXT_PK_FILES) lets the compiler emit
+        assert rows[v][1] == 0 and rows[v][2] == 0, "a form lib_next relies on miscomputes: " + str(rows[v])
     assert all(a == 0 for _, a, _ in rows), "a packed variant miscomputes on an IDLE device: " + text
