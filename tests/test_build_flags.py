@@ -62,7 +62,7 @@ def _flags():
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not installed")
-@pytest.mark.parametrize("src", ["fps.hip", "drln.hip", "ffn.hip", "next/sa_fused.hip", "next/drln.hip", "bnact.hip", "proj_ln.hip"])
+@pytest.mark.parametrize("src", ["fps.hip", "drln.hip", "ffn.hip", "next/sa_fused.hip", "next/optim.hip", "bnact.hip", "proj_ln.hip"])
 def test_no_packed_fp32_instructions_in_device_code(src, tmp_path):
     asm = _compile_to_asm(os.path.join(CSRC, src), tmp_path / (os.path.basename(src) + ".s"))
     assert "amdgcn" in asm and "gfx950" in asm
@@ -350,7 +350,7 @@ def test_packed_fp32_in_next_fps_has_no_operand_half_select(tmp_path):
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not installed")
-@pytest.mark.parametrize("name", ["ffn", "attn_small", "attn_flash", "bnrelu", "tokens", "knn"])
+@pytest.mark.parametrize("name", ["ffn", "drln", "attn_small", "attn_flash", "bnrelu", "tokens", "knn"])
 def test_packed_fp32_files_of_lib_next_have_no_op_sel_form(name, tmp_path):
     """lib_next re-enables packed fp32 per FILE (csrc/Makefile NEXT_PK_FILES) where the compiler's output contains no v_pk_*_f32 with
     OP_SEL set -- the only form the round-4 hardware reproducer found wrong beside another stream's MFMA work (op_sel_hi and neg modifiers,
@@ -365,5 +365,5 @@ def test_packed_fp32_files_of_lib_next_have_no_op_sel_form(name, tmp_path):
 
 
 def test_files_that_keep_no_pk_in_lib_next():
-    """drln, sa_fused: the compiler emits OP_SEL forms there; optim: none, but nothing to gain (HBM-bound; the packed Adam kernel is 14 % longer)."""
-    assert sorted(set(FROZEN) - set(_next_pk_files())) == ["drln", "optim", "sa_fused"]
+    """sa_fused: the compiler emits OP_SEL forms at its per-row broadcasts; optim: none, but nothing to gain (HBM-bound; the packed Adam kernel is 14 % longer)."""
+    assert sorted(set(FROZEN) - set(_next_pk_files())) == ["optim", "sa_fused"]
