@@ -641,8 +641,8 @@ namespace {
 
 constexpr int kBW = 128;  // output columns per wave (16 lanes x 8 columns)
 
-template <int NCH>  // E = 256 NCH
-__global__ __launch_bounds__(512) void pcm_proj_drln_bwd_kernel(long R, int K, const float *__restrict__ dout, const float *__restrict__ dout2,
+template <int NCH, int NW>  // E = 256 NCH; NW = K / 128 waves
+__global__ __launch_bounds__(64 * NW) void pcm_proj_drln_bwd_kernel(long R, int K, const float *__restrict__ dout, const float *__restrict__ dout2,
                                                                 const float *__restrict__ s, const float *__restrict__ mean,
                                                                 const float *__restrict__ rstd, const float *__restrict__ gamma, float p_drop,
                                                                 const long *__restrict__ seed_ptr, unsigned site, const u16 *__restrict__ W,
@@ -654,7 +654,7 @@ __global__ __launch_bounds__(512) void pcm_proj_drln_bwd_kernel(long R, int K, c
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
     u16 *As = reinterpret_cast<u16 *>(smem3);                                  // [16][AS] bf16: the dy panel
     float *red = reinterpret_cast<float *>(smem3 + (size_t)kTM * AS * 2);      // [NW][3][E]
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, NW = blockDim.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const long r0 = (long)blockIdx.x * kTM;
     const int n0 = w * kBW, li = lane & 15, lg = lane >> 4;
 
@@ -682,52 +682,69 @@ __global__ __launch_bounds__(512) void pcm_proj_drln_bwd_kernel(long R, int K, c
 #pragma unroll
         for (int v = 0; v < 4; ++v) dg[c][v] = 0.f, db[c][v] = 0.f, dys[c][v] = 0.f;
     }
-    for (int i = w; i < kTM; i += NW) {
-        const long r = r0 + i;
-        if (r >= R) {  // wave-uniform: a row past the end contributes a zero dy row to the product and nothing else
+    // The wave's rows w, w + NW, ... in groups of G: every load of a group (dout [, dout2], s, mean, rstd) is requested before the first row of
+    // the group is worked on -- the row-at-a-time loop of pcm_drln_bwd_kernel exposes one L2 / HBM round trip per row, which that kernel
+    // hides behind the other waves of a full CU and this one (one workgroup of NW waves per CU at 800 rows) cannot.  Rows are still FINISHED
+    // in order w, w + NW, ...: the column sums accumulate in the same order, every bit as before.  A row past R reads row R - 1 and is
+    // discarded (zero dy row in the panel, nothing stored, nothing summed).
+    constexpr int RPW = kTM / NW;          // rows per wave: 8, 4, 2
+    constexpr int G = RPW < 2 ? RPW : 2;   // rows in flight
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) *reinterpret_cast<uint2 *>(As + i * AS + c * 256 + lane * 4) = make_uint2(0u, 0u);
-            continue;
-        }
-        const float mu = mean[r], rs = rstd[r];
-        float gd[NCH][4], xh[NCH][4];
-        float s1 = 0.f, s2 = 0.f;
+    for (int j0 = 0; j0 < RPW; j0 += G) {
+        float dv[G][NCH][4], d2[G][NCH][4], sv[G][NCH][4], mus[G], rss[G];
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const long e0 = r * E + c * 256 + lane * 4;
-            float dv[4], sv[4];
-            load4<float>(dout + e0, dv);
-            if (dout2 != nullptr) {
-                float d2[4];
-                load4<float>(dout2 + e0, d2);
+        for (int jj = 0; jj < G; ++jj) {
+            const long r = r0 + w + NW * (j0 + jj), rc = r < R ? r : R - 1;
+            mus[jj] = mean[rc], rss[jj] = rstd[rc];
 #pragma unroll
-                for (int v = 0; v < 4; ++v) dv[v] += d2[v];
-            }
-            load4<float>(s + e0, sv);
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                xh[c][v] = (sv[v] - mu) * rs;
-                gd[c][v] = dv[v] * g[c][v];
-                s1 += gd[c][v];
-                s2 += gd[c][v] * xh[c][v];
-                dg[c][v] += dv[v] * xh[c][v];
-                db[c][v] += dv[v];
+            for (int c = 0; c < NCH; ++c) {
+                const long e0 = rc * E + c * 256 + lane * 4;
+                load4<float>(dout + e0, dv[jj][c]);
+                if (dout2 != nullptr) load4<float>(dout2 + e0, d2[jj][c]);
+                else d2[jj][c][0] = d2[jj][c][1] = d2[jj][c][2] = d2[jj][c][3] = 0.f;
+                load4<float>(s + e0, sv[jj][c]);
             }
         }
-        const float m1 = wave_sum(s1) * (1.f / E), m2 = wave_sum(s2) * (1.f / E);
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const long e0 = r * E + c * 256 + lane * 4;
-            float o[4], oy[4];
+        for (int jj = 0; jj < G; ++jj) {
+            const int i = w + NW * (j0 + jj);
+            const long r = r0 + i;
+            if (r >= R) {  // wave-uniform: a row past the end contributes a zero dy row to the product and nothing else
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                o[v] = rs * (gd[c][v] - m1 - xh[c][v] * m2);
-                oy[v] = (keep_elem(seed, site, (uint64_t)(e0 + v), thr)) ? o[v] * scale : 0.f;
-                dys[c][v] += oy[v];
+                for (int c = 0; c < NCH; ++c) *reinterpret_cast<uint2 *>(As + i * AS + c * 256 + lane * 4) = make_uint2(0u, 0u);
+                continue;
             }
-            store4<float>(dx + e0, o);
-            store4<__hip_bfloat16>(dy + e0, oy);
-            store4<__hip_bfloat16>(reinterpret_cast<__hip_bfloat16 *>(As + i * AS + c * 256 + lane * 4), oy);  // the product's A panel
+            const float mu = mus[jj], rs = rss[jj];
+            float gd[NCH][4], xh[NCH][4];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float dvv = dout2 != nullptr ? dv[jj][c][v] + d2[jj][c][v] : dv[jj][c][v];
+                    xh[c][v] = (sv[jj][c][v] - mu) * rs;
+                    gd[c][v] = dvv * g[c][v];
+                    s1 += gd[c][v];
+                    s2 += gd[c][v] * xh[c][v];
+                    dg[c][v] += dvv * xh[c][v];
+                    db[c][v] += dvv;
+                }
+            }
+            const float m1 = wave_sum(s1) * (1.f / E), m2 = wave_sum(s2) * (1.f / E);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const long e0 = r * E + c * 256 + lane * 4;
+                float o[4], oy[4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    o[v] = rs * (gd[c][v] - m1 - xh[c][v] * m2);
+                    oy[v] = (keep_elem(seed, site, (uint64_t)(e0 + v), thr)) ? o[v] * scale : 0.f;
+                    dys[c][v] += oy[v];
+                }
+                store4<float>(dx + e0, o);
+                store4<__hip_bfloat16>(dy + e0, oy);
+                store4<__hip_bfloat16>(reinterpret_cast<__hip_bfloat16 *>(As + i * AS + c * 256 + lane * 4), oy);  // the product's A panel
+            }
         }
     }
 #pragma unroll
@@ -739,8 +756,9 @@ __global__ __launch_bounds__(512) void pcm_proj_drln_bwd_kernel(long R, int K, c
             red[(w * 3 + 2) * E + c * 256 + lane * 4 + v] = dys[c][v];
         }
     __syncthreads();  // dy panel and the waves' column sums complete
-    for (int e = tid; e < 3 * E; e += blockDim.x) {
+    for (int e = tid; e < 3 * E; e += 64 * NW) {
         float acc = 0.f;
+#pragma unroll
         for (int ww = 0; ww < NW; ++ww) acc += red[ww * 3 * E + e];
         partial[(size_t)blockIdx.x * 3 * E + e] = acc;
     }
@@ -811,23 +829,30 @@ extern "C" int pcm_proj_drln_mfma_backward_hip(long R, int E, int K, const float
     hipStream_t st = (hipStream_t)stream;
     const int blocks = pcm_proj_drln_mfma_backward_blocks(R);
     const size_t smem = proj_bwd_smem_bytes(E, K);
-#define PCM_PB(NCH)                                                                                                                    \
+#define PCM_PB(NCH, NWV)                                                                                                               \
     do {                                                                                                                               \
         if (smem > 64 * 1024) {                                                                                                        \
-            const int rc_ = pcm_status(hipFuncSetAttribute(reinterpret_cast<const void *>(pcm_proj_drln_bwd_kernel<NCH>),              \
+            const int rc_ = pcm_status(hipFuncSetAttribute(reinterpret_cast<const void *>(pcm_proj_drln_bwd_kernel<NCH, NWV>),         \
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));                    \
             if (rc_) return rc_;                                                                                                       \
         }                                                                                                                              \
-        hipLaunchKernelGGL(pcm_proj_drln_bwd_kernel<NCH>, dim3((unsigned)blocks), dim3(64 * (K / kBW)), smem, st, R, K, dout, dout2, s,   \
+        hipLaunchKernelGGL((pcm_proj_drln_bwd_kernel<NCH, NWV>), dim3((unsigned)blocks), dim3(64 * NWV), smem, st, R, K, dout, dout2, s, \
                            mean, rstd, gamma, p_drop, seed, site, (const u16 *)w_bf16, dx, (__hip_bfloat16 *)dy_bf16, (u16 *)da_bf16,  \
                            da_ls, partial);                                                                                           \
     } while (0)
+#define PCM_PBK(NCH)                                                                                                                   \
+    do {                                                                                                                               \
+        if (K == 256) PCM_PB(NCH, 2);                                                                                                  \
+        else if (K == 512) PCM_PB(NCH, 4);                                                                                             \
+        else PCM_PB(NCH, 8);                                                                                                           \
+    } while (0)
     switch (E / 256) {
-    case 1: PCM_PB(1); break;
-    case 2: PCM_PB(2); break;
-    case 3: PCM_PB(3); break;
-    default: PCM_PB(4); break;
+    case 1: PCM_PBK(1); break;
+    case 2: PCM_PBK(2); break;
+    case 3: PCM_PBK(3); break;
+    default: PCM_PBK(4); break;
     }
+#undef PCM_PBK
 #undef PCM_PB
     int rc = PCM_LAUNCH_STATUS();
     if (rc || dgamma_dbeta == nullptr) return rc;  // partial rows only: closed later by pcm_reduce_batch_hip (policy/deferred.py)
