@@ -747,23 +747,21 @@ class _SelfAttnInProj(Function):
                 if dres.dtype != torch.float32 or not dres.is_contiguous():
                     dres = dres.float().contiguous()
             dpos_wide = None
-            if fused_dx:
+            same_shape = pos_grad and tuple(pos_shape) == tuple(shape)
+            if fused_dx:  # one launch: dx = [dq dk dv] W_in + dres, the position share [dq dk] W_qk split off at k = 2E
                 dx, dpos_wide = _linear_mfma_backward(dq, rows, 3 * E, 3 * E, wc, dres, pos_grad, 2 * E)
-                dpos32 = dpos_wide if (pos_grad and tuple(pos_shape) == tuple(shape)) else None
+                dpos32 = dpos_wide if same_shape else None
             else:
                 dx = torch.empty(rows, E, dtype=torch.float32, device=dev)
                 # the position gradient is d_qk_in alone: widened by the same launch when it has the shape of x (query_pos)
-                dpos32 = torch.empty(rows, E, dtype=torch.float32, device=dev) if (pos_grad and tuple(pos_shape) == tuple(shape)) else None
-            if fused_dx:
-                pass
-            elif joint:
-                rc = L.pcm_add4_cast2_hip(dx.numel(), d3[0].data_ptr(), d3[1].data_ptr(), d3[2].data_ptr(),
-                                          dres.data_ptr() if dres is not None else 0, dx.data_ptr(),
-                                          dpos32.data_ptr() if dpos32 is not None else 0, st)
-            else:
-                rc = L.pcm_add3_cast2_hip(dx.numel(), d_qk_in.data_ptr(), d_v_in.data_ptr(), dres.data_ptr() if dres is not None else 0,
-                                          dx.data_ptr(), dpos32.data_ptr() if dpos32 is not None else 0, st)
-            if not fused_dx:
+                dpos32 = torch.empty(rows, E, dtype=torch.float32, device=dev) if same_shape else None
+                if joint:
+                    rc = L.pcm_add4_cast2_hip(dx.numel(), d3[0].data_ptr(), d3[1].data_ptr(), d3[2].data_ptr(),
+                                              dres.data_ptr() if dres is not None else 0, dx.data_ptr(),
+                                              dpos32.data_ptr() if dpos32 is not None else 0, st)
+                else:
+                    rc = L.pcm_add3_cast2_hip(dx.numel(), d_qk_in.data_ptr(), d_v_in.data_ptr(), dres.data_ptr() if dres is not None else 0,
+                                              dx.data_ptr(), dpos32.data_ptr() if dpos32 is not None else 0, st)
                 _lib.check(rc, "pcm_add3_cast2_hip")
             dw = deferred.take((3 * E, E), wdt, dev, "in_proj.dw")
             defer = deferred.clear(*ctx.defer)
