@@ -261,31 +261,37 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_flash_fwd_kernel(AttnParams P,
         }
         lsum = lsum * f0 + l1 * f1;
         m = mm;
-    } else
-    for (int kt = 0; kt < ntiles; ++kt) {
-        const u16 *Kt = smem + (kt & 1) * TILE, *Vt = smem + (2 + (kt & 1)) * TILE;
-        const unsigned mbyte = tile_mask_byte(mask, kt * TR, P.S, lane);  // before the prefetch: see tile_visible
-        if (kt + 1 < ntiles) {
-            stage_fetch(kr, kb, P.k_ls, (kt + 1) * TR, P.S, tid);
-            stage_fetch(vr, vb, P.v_ls, (kt + 1) * TR, P.S, tid);
-        }
-        f16v s0, s1;
+    } else {
+    // Software pipeline (round 6): the score GEMM of tile t + 1 is ISSUED under the softmax of tile t.  The K ring runs
+    // one tile ahead of the V ring: at the top of iteration t the LDS holds K(t + 1) -- staged an iteration earlier -- and V(t); registers
+    // fetch K(t + 2) and V(t + 1), stored at the END of the iteration into the buffers of K(t) (last read in iteration t - 1) and V(t - 1)
+    // (last read in iteration t - 1): still one barrier per tile.  The matrix instructions of S(t + 1) have no consumer before the next
+    // iteration, so they drain while the VALU works through the softmax, the dropout hash and the bf16 packing of tile t -- per tile and
+    // wave that VALU work is ~4x the MFMA time (static count), and until now the wave could not start it before ITS OWN score GEMM had
+    // returned.  Same arithmetic on the same operands in the same order: the results are the same bits.
+    auto scores = [&](const u16 *Kt, f16v &a0, f16v &a1) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s0[r] = 0.f, s1[r] = 0.f;
+        for (int r = 0; r < 16; ++r) a0[r] = 0.f, a1[r] = 0.f;
 #pragma unroll
         for (int sl = 0; sl < 4; ++sl) {
-            s0 = PCM_MFMA16(lds_bf8(Kt + lo.row[sl]), qf[sl], s0);
-            s1 = PCM_MFMA16(lds_bf8(Kt + lo.row[sl] + 32 * HD), qf[sl], s1);
+            a0 = PCM_MFMA16(lds_bf8(Kt + lo.row[sl]), qf[sl], a0);
+            a1 = PCM_MFMA16(lds_bf8(Kt + lo.row[sl] + 32 * HD), qf[sl], a1);
         }
-        // the transposed V fragments of the whole tile are requested NOW: the LDS reads drain under the softmax below instead
-        // of stalling each P V MFMA on its own operand
-        bf8 va0[4], va1[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const u16 *vs = Vt + j * 16 * HD;
-            va0[j] = cat8(lds_tr(vs + lo.tr[0][0]), lds_tr(vs + lo.tr[1][0]));
-            va1[j] = cat8(lds_tr(vs + lo.tr[0][1]), lds_tr(vs + lo.tr[1][1]));
-        }
+    };
+    if (ntiles > 1) {  // K(1) joins K(0) | V(0) in LDS before the first iteration
+        stage_fetch(kr, kb, P.k_ls, TR, P.S, tid);
+        stage_store(kr, smem + TILE, tid);
+        __syncthreads();
+    }
+    f16v s0, s1;
+    scores(smem, s0, s1);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const u16 *Vt = smem + (2 + (kt & 1)) * TILE;
+        const unsigned mbyte = tile_mask_byte(mask, kt * TR, P.S, lane);  // before the prefetch: see tile_visible
+        if (kt + 2 < ntiles) stage_fetch(kr, kb, P.k_ls, (kt + 2) * TR, P.S, tid);
+        if (kt + 1 < ntiles) stage_fetch(vr, vb, P.v_ls, (kt + 1) * TR, P.S, tid);
+        f16v n0, n1;  // S(t + 1): issued now, first read in the next iteration
+        if (kt + 1 < ntiles) scores(smem + ((kt + 1) & 1) * TILE, n0, n1);
         const bool edge = (kt + 1) * TR > P.S || mask != nullptr;
         // the running maximum is kept on the RAW scores (scale > 0 commutes with max): the scale is folded into the
         // exponent's FMA, exp2(s * scale2 - m * scale2), instead of costing one multiply per score
@@ -321,6 +327,19 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_flash_fwd_kernel(AttnParams P,
         }
         lsum += psum;
         m = m_new;
+        // the transposed V fragments of the whole tile are requested HERE -- behind the exponentials, in front of the dropout hash and the
+        // bf16 packing, under which the LDS reads drain (at the top of the tile they held 32 registers through the whole softmax, which the
+        // pipelined S(t + 1) accumulators now need: 256 VGPRs and 6 spilled otherwise)
+        bf8 va0[2], va1[2];  // two 16-key slabs at a time: the second pair is requested behind the first pair's matrix instructions
+        auto vfrag = [&](int j0) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const u16 *vs = Vt + (j0 + j) * 16 * HD;
+                va0[j] = cat8(lds_tr(vs + lo.tr[0][0]), lds_tr(vs + lo.tr[1][0]));
+                va1[j] = cat8(lds_tr(vs + lo.tr[0][1]), lds_tr(vs + lo.tr[1][1]));
+            }
+        };
+        vfrag(0);
         if (DROP) {
 #pragma unroll
             for (int gh = 0; gh < 8; ++gh) {  // registers 2gh, 2gh+1 hold adjacent keys: one hash for the pair
@@ -336,16 +355,23 @@ __global__ __launch_bounds__(WG, 2) void pcm_attn_flash_fwd_kernel(AttnParams P,
         }
         // O^T += V^T P^T, 16 keys per MFMA: slab j = keys 16j .. 16j+15 of the tile
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bf8 pf = j < 2 ? p_frag(p0, 8 * (j & 1)) : p_frag(p1, 8 * (j & 1));
+        for (int j = 0; j < 2; ++j) {
+            const bf8 pf = p_frag(p0, 8 * j);
             o0 = PCM_MFMA16(va0[j], pf, o0);
             o1 = PCM_MFMA16(va1[j], pf, o1);
         }
-        if (kt + 1 < ntiles) {
-            stage_store(kr, smem + ((kt + 1) & 1) * TILE, tid);
-            stage_store(vr, smem + (2 + ((kt + 1) & 1)) * TILE, tid);
+        vfrag(2);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bf8 pf = p_frag(p1, 8 * j);
+            o0 = PCM_MFMA16(va0[j], pf, o0);
+            o1 = PCM_MFMA16(va1[j], pf, o1);
         }
+        if (kt + 2 < ntiles) stage_store(kr, smem + (kt & 1) * TILE, tid);               // K(t + 2) over K(t)
+        if (kt + 1 < ntiles) stage_store(vr, smem + (2 + ((kt + 1) & 1)) * TILE, tid);   // V(t + 1) over V(t - 1)
         __syncthreads();
+        if (kt + 1 < ntiles) s0 = n0, s1 = n1;
+    }
     }
     const float inv = lsum > 0.f ? dc.inv_keep / lsum : 0.f;
     store_acc_rows(smem + w * RW * OS, o0, o1, inv, out + (long)b * P.L * (P.H * HD) + h * HD, (long)P.H * HD, q0, P.L, lane);

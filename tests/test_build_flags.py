@@ -367,3 +367,25 @@ def test_packed_fp32_files_of_lib_next_have_no_op_sel_form(name, tmp_path):
 def test_files_that_keep_no_pk_in_lib_next():
     """sa_fused: the compiler emits OP_SEL forms at its per-row broadcasts; optim: none, but nothing to gain (HBM-bound; the packed Adam kernel is 14 % longer)."""
     assert sorted(set(FROZEN) - set(_next_pk_files())) == ["optim", "sa_fused"]
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not installed")
+def test_next_flash_forward_issues_the_next_tiles_scores_before_the_softmax(tmp_path):
+    """csrc/next/attn_flash.hip (round 6): the forward kernel's main loop is software-pipelined -- the eight score MFMAs of tile t + 1 come
+    BEFORE the 32 exponentials of tile t in program order, the eight P V MFMAs behind them, one barrier per tile.  Read from the assembly of
+    pcm_attn_flash_fwd_kernel<true>: between two barriers the order is  M x 8 ... exp x 32 ... M x 8.  (The frozen csrc/attn_flash.hip
+    has  M x 8 (scores of THIS tile) ... exp ... M x 8  -- the same picture, but its first group feeds the exponentials that follow.)"""
+    asm = _compile_to_asm(os.path.join(NEXT, "attn_flash.hip"), tmp_path / "af.s")
+    lines = asm.splitlines()
+    starts = [i for i, l in enumerate(lines) if re.match(r"^_Z\w+:", l)]
+    i = next(i for i in starts if "pcm_attn_flash_fwd_kernelILb1E" in lines[i])
+    body = lines[i:next((j for j in starts if j > i), len(lines))]
+    ev = ""
+    for x in body:
+        t = x.split()[0] if x.startswith("\t") and x.strip() else ""
+        ev += "M" if t.startswith("v_mfma") else ("e" if t.startswith("v_exp") else ("|" if t == "s_barrier" else ""))
+    assert re.search(r"M{8}e{32,34}M{8}\|", ev), ev          # the pipelined main loop: S(t + 1), softmax(t), P V (t), barrier
+    assert re.search(r"\|M{8}M{8}e", ev) or re.search(r"M{8}\|?M{8}e", ev), ev  # prologue S(0) directly in front of the first S(1)
+    # and the score operands of a tile really are consumed one iteration later: the source keeps them in n0 / n1 across the barrier
+    src = open(os.path.join(NEXT, "attn_flash.hip")).read()
+    assert "if (kt + 1 < ntiles) s0 = n0, s1 = n1;" in src and "scores(smem + ((kt + 1) & 1) * TILE, n0, n1);" in src
